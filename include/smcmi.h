@@ -1,0 +1,163 @@
+/*
+ * smcmi.h - C ABI of libsmcmi.so, the MI355X-native SMC particle engine.
+ *
+ * Drop-in boundary for the correction / selection / mutation loop of FRBNY-DSGE/SMC.jl
+ * (src/smc_main.jl:377-508 and everything it calls).  The reference is pure Julia and has no FFI
+ * of its own; the entry points below are what a Julia `ccall` shim binds (see INTEGRATION.md and
+ * smc.jl_amd/julia/SMCMI.jl) to keep `smc(loglikelihood, parameters, data; ...)` and the `Cloud`
+ * accessors unchanged.  Each function cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative SMCMI_ERR_* otherwise; text via smcmi_last_error().
+ *  - no exceptions cross the ABI; all pointers are plain host pointers unless named `dev_*`.
+ *  - a cloud is the reference's `cloud.particles`: Float64, Julia column-major N x R, R = n_para + 5,
+ *    element (i, col) at p[col * N + i]; columns 0..d-1 parameters | d loglh | d+1 logprior |
+ *    d+2 old_loglh | d+3 accept | d+4 weight           (src/particle.jl:31-63).  That layout is
+ *    already struct-of-arrays, so upload/download are single contiguous copies.
+ *  - indices returned to the caller are 0-based.
+ *  - a handle owns its device memory and one HIP stream; calls on one handle are not re-entrant.
+ *  - one handle = one shard: `n_local` particles starting at global id `gid0` out of `n_parts`.
+ *    Single-GPU use has n_local == n_parts, gid0 == 0.
+ */
+#ifndef SMCMI_H
+#define SMCMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMCMI_MAX_PARA 64      /* n_para (incl. fixed) supported by the device kernels */
+#define SMCMI_MAX_CAND 32      /* tempering candidates evaluated per ESS pass */
+
+enum { SMCMI_OK = 0, SMCMI_ERR_ARG = -1, SMCMI_ERR_HIP = -2, SMCMI_ERR_NAN_ESS = -3, SMCMI_ERR_POSDEF = -4,
+       SMCMI_ERR_CAPACITY = -5, SMCMI_ERR_BRACKET = -6, SMCMI_ERR_UNSUPPORTED = -7, SMCMI_ERR_STATE = -8 };
+
+/* prior families: Distributions.jl / ModelConstructors priors reachable from `prior(parameters)` (src/mutation.jl:95) */
+enum { SMCMI_PRIOR_NORMAL = 0, SMCMI_PRIOR_UNIFORM = 1, SMCMI_PRIOR_GAMMA = 2, SMCMI_PRIOR_BETA = 3,
+       SMCMI_PRIOR_INVGAMMA = 4, SMCMI_PRIOR_ROOTINVGAMMA = 5 };
+/* device likelihood families standing in for the user callback `loglikelihood(parameters, data)` (src/mutation.jl:96) */
+enum { SMCMI_LIK_NONE = -1, SMCMI_LIK_GAUSS_ISO = 0, SMCMI_LIK_LINREG = 1, SMCMI_LIK_LINMODEL3 = 2,
+       SMCMI_LIK_CAPM_LITERAL = 3, SMCMI_LIK_HOST_CALLBACK = 100 };
+/* src/resample.jl:23 `method`; :polyalgo is served by the multinomial kernel (same distribution) */
+enum { SMCMI_RESAMPLE_SYSTEMATIC = 0, SMCMI_RESAMPLE_MULTINOMIAL = 1 };
+enum { SMCMI_WHICH_NEW = 0, SMCMI_WHICH_OLD = 1 };
+
+typedef struct smcmi_handle smcmi_handle;
+
+typedef struct {
+    int64_t n_parts;        /* global N                                    smc kwarg n_parts (smc_main.jl:123) */
+    int64_t n_local;        /* particles held by this handle (0 => n_parts) */
+    int64_t gid0;           /* global id of the first local particle */
+    int32_t n_para;         /* d = length(parameters) (+ regime columns)   smc_main.jl:207-216 */
+    int32_t device;         /* HIP device ordinal */
+    uint64_t seed;          /* Philox key (replaces Random.seed!) */
+    int32_t max_stages;     /* capacity of per-stage records / history columns (incl. stage 1) */
+    int32_t store_history;  /* keep the N x n_stages w / W matrices (smc_main.jl:363-366,419-420) */
+} smcmi_config;
+
+/* kwargs of smc() that shape the loop (smc_main.jl:119-161) */
+typedef struct {
+    int32_t n_blocks, n_mh_steps;          /* :125-126 */
+    double lambda;                         /* λ :128 */
+    int32_t n_phi;                         /* n_Φ :129 */
+    int32_t resampling_method;             /* :131 */
+    double threshold_ratio;                /* :132 */
+    double c, alpha, target;               /* :135-137 */
+    int32_t use_fixed_schedule;            /* :139 */
+    double tempering_target;               /* :140 */
+    double tempered_update_prior_weight;   /* :156 */
+    double log_prob_old_data;              /* :161 */
+    int32_t n_cand;                        /* ESS candidates per pass (<= SMCMI_MAX_CAND; 0 => default) */
+    int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
+    int32_t use_graph;                     /* replay the stage as a hipGraph */
+} smcmi_run_config;
+
+typedef struct {
+    int32_t n_stages;        /* cloud.stage_index at exit == number of tempering_schedule entries */
+    int32_t resamples;       /* cloud.resamples */
+    double logmdd;           /* Σ_n log((1/N) Σ_i w[i,n] W[i,n-1]) */
+    double c, accept;        /* cloud.c, cloud.accept */
+    double seconds;          /* wall time of the loop = cloud.total_sampling_time (smc_main.jl:489-490) */
+    double kernel_ms_mutate; /* HIP-event time spent in the mutation kernel over the run (0 if not measured) */
+    int32_t n_mutate_launches;
+} smcmi_result;
+
+typedef struct {             /* what one correction step reports (smc_main.jl:401-432) */
+    double ess, sum_unnorm, logz_inc;
+    int32_t resample;        /* ESS < threshold_ratio * N */
+} smcmi_stage_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int smcmi_create(const smcmi_config *cfg, smcmi_handle **out);          /* Cloud(n_params, n_parts), particle.jl:50-53 */
+int smcmi_destroy(smcmi_handle *h);
+const char *smcmi_last_error(void);
+int smcmi_version(void);
+
+/* ---- model: ParameterVector + likelihoods (sendto(workers(), parameters/data), smc_main.jl:169-170) */
+int smcmi_set_parameters(smcmi_handle *h, const int32_t *fixed, const double *lo, const double *hi,
+                         const int32_t *prior_family, const double *prior_a, const double *prior_b);
+int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const double *par, int64_t n_par,
+                         const double *data, int64_t rows, int64_t cols, const double *aux, int64_t aux_rows,
+                         int64_t aux_cols);
+
+/* ---- cloud transfer (cloud.particles; get_vals/get_loglh/... read columns of the download) ---- */
+int smcmi_upload_cloud(smcmi_handle *h, const double *particles);       /* n_local x R, column-major */
+int smcmi_download_cloud(smcmi_handle *h, double *particles);
+int smcmi_init_from_prior(smcmi_handle *h);                              /* initial_draw!, initialization.jl:88-119 */
+int smcmi_cloud_device_ptr(smcmi_handle *h, double **dev_ptr, int64_t *ld); /* current buffer, for zero-copy hosts */
+
+/* ---- stage primitives (same kernels smcmi_run launches) --------------------------------------- */
+/* compute_ESS(loglh, weights, ϕ, ϕ_n1; old_loglh) for k candidate ϕ (helpers.jl:173-181) */
+int smcmi_ess_at(smcmi_handle *h, const double *phis, int32_t k, double phi_prev, double *ess_out);
+/* solve_adaptive_ϕ (helpers.jl:9-56); j is the reference's 1-based index */
+int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_phi, int32_t *j, double *phi_prop,
+                    double phi_prev, double tempering_target, double ess_prev, int32_t *resampled_last,
+                    double *phi_n);
+/* correction: incremental weights, update_weights!, normalize_weights!, ESS (smc_main.jl:401-432) */
+int smcmi_correct(smcmi_handle *h, double phi_n, double phi_prev, double prior_weight, double log_prob_old_data,
+                  double threshold_ratio, smcmi_stage_stats *out);
+/* resample(normalized_weights/n_parts; method) + gather + reset_weights! (smc_main.jl:438-442, resample.jl:23-72).
+   offsets: NULL => Philox (stage); else 1 offset (systematic) or n_parts offsets (multinomial). */
+int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, const double *offsets, int64_t *ancestors_out);
+/* weighted_mean / weighted_cov (particle.jl:481-483, 526-529); cov row-major d x d */
+int smcmi_moments(smcmi_handle *h, double *mean, double *cov);
+/* all particles' mutation() (mutation.jl:56-138, smc_main.jl:472-484); mu_free/Sigma_free are θ̄_fr, R_fr;
+   blocks 0-based: block b = block_idx[block_ptr[b] .. block_ptr[b+1]) over free-parameter positions */
+int smcmi_mutate(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                 const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c, double alpha,
+                 int32_t n_mh_steps, uint32_t stage, double *accept_mean_out);
+/* host-callback split of mutation for arbitrary user likelihoods: propose -> (host evaluates) -> accept */
+int smcmi_propose(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                  const int32_t *blocks_free, int32_t n_blocks, int32_t block, int32_t mh_step, double c, double alpha,
+                  uint32_t stage, double *proposals_out /* n_local x d col-major */, double *logprior_out,
+                  double *q_diff_out);
+int smcmi_accept(smcmi_handle *h, const double *loglik_new, const double *loglik_old_new, double phi_n,
+                 int32_t block, int32_t mh_step, int32_t n_blocks, uint32_t stage, int32_t last);
+
+/* ---- whole loop on device (smc_main.jl:377-508) ------------------------------------------------ */
+int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
+/* per-stage records: cloud.tempering_schedule, cloud.ESS, c, accept, resample flags; arrays of n_stages */
+int smcmi_get_stage_records(smcmi_handle *h, double *phi, double *ess, double *c, double *accept, int32_t *resampled);
+int smcmi_get_history(smcmi_handle *h, double *w, double *W);           /* n_local x n_stages each, column-major */
+
+/* ---- shard-level pieces for multi-GPU hosts (one handle per GPU; host does the collective) ----- */
+/* Every stage step is split as: partial (kernel writes this shard's partial sums into the comm buffer) ->
+   host all-reduces comm buffer over ranks -> apply (kernels consume the global totals). */
+int smcmi_comm_buffer(smcmi_handle *h, double **dev_ptr, int64_t *capacity);
+int smcmi_shard_ess_partial(smcmi_handle *h, const double *phis, int32_t k, double phi_prev);       /* comm[0..2k) = Σv, Σv² */
+int smcmi_shard_correct_partial(smcmi_handle *h, double phi_n, double phi_prev, double prior_weight,
+                                double log_prob_old_data, int32_t stage_col);                         /* comm[0..2) */
+int smcmi_shard_normalize_moments_partial(smcmi_handle *h, double sum_unnorm, int32_t resampled,
+                                          const double *shift, int32_t stage_col);                    /* comm[0..1+d+d(d+1)/2) */
+int smcmi_shard_weights_device_ptr(smcmi_handle *h, double **dev_ptr);
+int smcmi_shard_gather_rows(smcmi_handle *h, const double *dev_full_cloud, int64_t n_full, const int64_t *dev_ancestors);
+int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                               const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c,
+                               double alpha, int32_t n_mh_steps, uint32_t stage);                      /* comm[0] = Σ accept */
+int smcmi_sync(smcmi_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

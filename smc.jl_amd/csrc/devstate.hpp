@@ -1,0 +1,106 @@
+// devstate.hpp - device-resident state of one engine handle.
+//
+// Everything a stage needs lives in HBM so that the stage is a fixed kernel sequence with no host
+// decisions: tempering scalars, the ϕ-solver bracket, resample decision, proposal factors, per-stage
+// records.  Field comments cite the reference variable they replace (src/smc_main.jl unless noted).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/smcmi.h"
+
+namespace smcmi {
+
+constexpr int MAXD = SMCMI_MAX_PARA;
+constexpr int KC = SMCMI_MAX_CAND;          // candidates per ESS pass
+constexpr int NPAIR_MAX = (MAXD + 1) * (MAXD + 2) / 2;
+constexpr int LIK_PAR_MAX = 16;
+
+struct LikDev {
+    int family;
+    int n_par;
+    double par[LIK_PAR_MAX];
+    double c0;                 // family constant precomputed on the host
+    const double *data;        // column-major rows x cols
+    long long rows, cols;
+    const double *aux;
+    long long aux_rows, aux_cols;
+};
+
+struct ModelDev {
+    int d, n_free;
+    int fixed[MAXD];
+    int free_inds[MAXD];
+    double lo[MAXD], hi[MAXD];
+    int prior_family[MAXD];
+    double prior_a[MAXD], prior_b[MAXD];
+    double prior_k[MAXD];      // family constant precomputed on the host (e.g. log σ, -log(b-a))
+    LikDev lik[2];             // [0] loglikelihood/data, [1] old_loglikelihood/old_data
+};
+
+enum SolveMode { MODE_IDLE = 0, MODE_SCAN = 1, MODE_SECTION = 2, MODE_FINAL = 3 };
+
+struct RunParams {             // smc() kwargs, uploaded once per run
+    long long n_parts;         // global N
+    int n_blocks, n_mh_steps;
+    int n_phi;
+    int resampling_method;
+    int use_fixed_schedule;
+    int n_cand;
+    double threshold;          // threshold_ratio * n_parts (:203)
+    double alpha, target;
+    double tempering_target;
+    double pw, logp_old;       // tempered_update_prior_weight, log_prob_old_data
+    int max_stages;
+    int store_history;
+};
+
+struct DevState {
+    RunParams rp;
+    // ---- loop scalars
+    int stage;                 // i == cloud.stage_index
+    int j;                     // 1-based index into the proposed fixed schedule (:129)
+    int resampled_last;        // resampled_last_period
+    int do_resample;           // this stage's selection decision (:435)
+    int done;                  // ϕ_n reached 1 (or error)
+    int err;
+    int cur;                   // ping-pong cloud buffer holding the current particles
+    int resamples;             // cloud.resamples
+    double phi_prev, phi_n, phi_prop;
+    double ess_prev;           // cloud.ESS[i-1]
+    double ess;
+    double sumw, sumw2;        // Σ W̃, Σ W̃² at ϕ_n (unnormalised)
+    double logz;               // running log-MDD
+    double c, accept;          // cloud.c, cloud.accept
+    // ---- ϕ solver (helpers.jl:9-56)
+    int mode;
+    int n_valid;               // valid candidates in cand[]
+    int scan_exhausted;
+    double ess_bar;
+    double lo, hi, glo, ghi;
+    double cand[KC];
+    // ---- moments / proposal (smc_main.jl:457-469, mutation.jl:81)
+    double shift[MAXD];        // centering used by the one-pass moment kernel (previous mean)
+    double mean[MAXD];         // θ_bar
+    double cov[MAXD * MAXD];   // R (row-major d x d)
+    int n_blocks;
+    int block_ptr[MAXD + 1];
+    int blocks_free[MAXD];     // positions in the free-parameter list, block order
+    int blocks_all[MAXD];      // parameter indices, block order
+    int l_off[MAXD];           // offset of block b's factor in L
+    double mu_b[MAXD];         // θ_bar_fr in block order
+    double L[MAXD * MAXD];     // chol(c² Σ_b), row-major per block
+    double sd_draw[MAXD];      // sqrt(c² Σ_ii)   (helpers.jl:94)
+    double sd_dens[MAXD];      // sqrt(Σ_ii)      (helpers.jl:146, quirk Q1)
+    double logdet[MAXD];       // log det(c² Σ_b)
+    double mut_c, mut_alpha, mut_phi;
+    int mut_steps;
+    unsigned mut_stage;
+};
+
+// per-stage records (cloud.tempering_schedule, cloud.ESS, c, accept, resample flag), length max_stages
+struct Records {
+    double *phi, *ess, *c, *accept;
+    int *resampled;
+};
+
+}  // namespace smcmi

@@ -1,0 +1,141 @@
+// model.hpp - device-side prior densities, bounds check and built-in likelihood families.
+//
+// Replaces, per particle and per proposal, the reference's
+//   update!(parameters, para_new)  (bounds => ParamBoundsError)      src/mutation.jl:93
+//   prior(parameters)              (Σ logpdf over free parameters)   src/mutation.jl:95
+//   loglikelihood(parameters, data), old_loglikelihood(.., old_data) src/mutation.jl:96,106
+// A parameter vector is read through an accessor `th(k)` so the caller can keep it in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "devstate.hpp"
+
+namespace smcmi {
+
+constexpr double LOG2PI = 1.8378770664093454835606594728112;
+#define SMCMI_NEG_INF (-__builtin_huge_val())
+
+// host: per-parameter constant so the device never evaluates log() of a constant
+inline double prior_const_host(int fam, double a, double b) {
+    switch (fam) {
+    case SMCMI_PRIOR_NORMAL: return log(b);
+    case SMCMI_PRIOR_UNIFORM: return -log(b - a);
+    case SMCMI_PRIOR_GAMMA: return -lgamma(a) - a * log(b);
+    case SMCMI_PRIOR_BETA: return -(lgamma(a) + lgamma(b) - lgamma(a + b));
+    case SMCMI_PRIOR_INVGAMMA: return a * log(b) - lgamma(a);
+    case SMCMI_PRIOR_ROOTINVGAMMA: return log(2.0) - lgamma(a / 2.0) + (a / 2.0) * log(a * b * b / 2.0);
+    default: return NAN;
+    }
+}
+
+__device__ inline double prior_logpdf(int fam, double a, double b, double k, double x) {
+    switch (fam) {
+    case SMCMI_PRIOR_NORMAL: { const double z = (x - a) / b; return -(z * z + LOG2PI) / 2.0 - k; }
+    case SMCMI_PRIOR_UNIFORM: return (a <= x && x <= b) ? k : SMCMI_NEG_INF;
+    case SMCMI_PRIOR_GAMMA: return x < 0 ? SMCMI_NEG_INF : k + (a - 1.0) * log(x) - x / b;
+    case SMCMI_PRIOR_BETA: return (x < 0 || x > 1) ? SMCMI_NEG_INF : (a - 1.0) * log(x) + (b - 1.0) * log1p(-x) + k;
+    case SMCMI_PRIOR_INVGAMMA: return x <= 0 ? SMCMI_NEG_INF : k - (a + 1.0) * log(x) - b / x;
+    case SMCMI_PRIOR_ROOTINVGAMMA:
+        return x <= 0 ? SMCMI_NEG_INF : k - ((a + 1.0) / 2.0) * log(x * x) - a * b * b / (2.0 * x * x);
+    default: return NAN;
+    }
+}
+
+template <class Th>
+__device__ inline bool in_bounds(const ModelDev &m, Th th) {
+    bool ok = true;
+    for (int k = 0; k < m.d; ++k) {
+        const double x = th(k);
+        ok = ok && (m.lo[k] <= x && x <= m.hi[k]);
+    }
+    return ok;
+}
+
+template <class Th>
+__device__ inline double logprior(const ModelDev &m, Th th) {
+    double s = 0.0;
+    for (int k = 0; k < m.d; ++k)
+        if (!m.fixed[k]) s += prior_logpdf(m.prior_family[k], m.prior_a[k], m.prior_b[k], m.prior_k[k], th(k));
+    return s;
+}
+
+// host: family constant (same expression as the oracle so both sides share the libm value)
+inline double lik_const_host(int family, const double *par, int d) {
+    if (family == SMCMI_LIK_GAUSS_ISO) return -0.5 * (double)d * log(2.0 * M_PI * par[0] * par[0]);
+    return 0.0;
+}
+
+template <class Th>
+__device__ inline double loglik(const LikDev &l, int d, Th th) {
+    switch (l.family) {
+    case SMCMI_LIK_GAUSS_ISO: {
+        const double sig = l.par[0];
+        double acc = 0.0;
+        for (int k = 0; k < d; ++k) { const double e = th(k) - l.data[k]; acc += e * e; }
+        return l.c0 - acc / (2.0 * sig * sig);
+    }
+    case SMCMI_LIK_LINREG: {  // examples/regression_model/estimate_regression.jl:46-53, data = [y X]
+        const long long n = l.rows;
+        const double *y = l.data, *X = l.data + n;
+        const double s2 = l.par[0], Nn = (double)n, a = th(0), b = th(1);
+        const double term1 = -(Nn / 2.0) * log(2.0 * M_PI) - (Nn / 2.0) * log(s2);
+        double dot = 0.0;
+        for (long long t = 0; t < n; ++t) { const double e = y[t] - a - b * X[t]; dot += e * e; }
+        return term1 - (1.0 / (2.0 * s2)) * dot;
+    }
+    case SMCMI_LIK_LINMODEL3: {  // test/modelsetup.jl:119-138 loglik_fn
+        const long long T = l.cols;
+        double a[3], b[3], inv[3], det = 1.0;
+        bool singular = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[i] = th(3 * i); b[i] = th(3 * i + 1);
+            const double s = th(3 * i + 2), v = s * s;
+            singular = singular || (v == 0.0);
+            det *= v; inv[i] = 1.0 / v;
+        }
+        if (singular) return SMCMI_NEG_INF;
+        const double term1 = -3.0 / 2.0 * log(2.0 * M_PI) - 1.0 / 2.0 * log(det);
+        double lp = 0.0;
+        for (long long t = 0; t < T; ++t) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double e = l.data[i + 3 * t] - a[i] - b[i] * l.aux[i + l.aux_rows * t];
+                q += e * (inv[i] * e);
+            }
+            lp += term1 - 1.0 / 2.0 * q;
+        }
+        return lp;
+    }
+    case SMCMI_LIK_CAPM_LITERAL: {  // examples/capm_model/estimate_capm.jl:52-70 as written (quirk Q12)
+        const long long T = l.cols;
+        double a[3], inv[3], det = 1.0;
+        bool singular = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[i] = th(3 * i);
+            const double s = th(3 * i + 2), v = s * s;
+            singular = singular || (v == 0.0);
+            det *= v; inv[i] = 1.0 / v;
+        }
+        if (singular) return SMCMI_NEG_INF;
+        const double term1 = -3.0 / 2.0 * log(2.0 * M_PI) - 1.0 / 2.0 * log(det);
+        double S = 0.0, lp = 0.0;
+        for (long long t = 0; t < T; ++t) {
+            const double mk = l.aux[l.aux_rows * t];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double e = l.data[i + 3 * t] - a[i] - a[i] * mk;
+                S += e * (inv[i] * e);
+            }
+        }
+        for (long long t = 0; t < T; ++t) lp += term1 - 1.0 / 2.0 * S;
+        return lp;
+    }
+    default: return NAN;
+    }
+}
+
+}  // namespace smcmi

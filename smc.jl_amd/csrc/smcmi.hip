@@ -1,0 +1,778 @@
+// smcmi.hip - host side of libsmcmi.so: the C ABI of include/smcmi.h and the stage driver.
+//
+// The driver reproduces the loop order of the reference exactly (src/smc_main.jl:377-508):
+//   ϕ selection -> correction -> ESS / NaN guard -> selection -> c update -> weighted moments -> random blocks
+//   -> mutation -> acceptance rate,
+// but as a fixed sequence of HIP kernels whose branches are resolved on the device (DevState), so the host never
+// waits on the GPU inside a stage.  There is NO CPU fallback: every entry point fails with SMCMI_ERR_HIP when no
+// gfx950 device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smcmi.h"
+#include "devstate.hpp"
+#include "kernels.hpp"
+
+using namespace smcmi;
+
+static thread_local std::string g_err;
+extern "C" const char *smcmi_last_error(void) { return g_err.c_str(); }
+extern "C" int smcmi_version(void) { return 1; }
+
+static int set_err(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return set_err(SMCMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+struct smcmi_handle {
+    smcmi_config cfg{};
+    int d = 0, R = 0, npairs = 0;
+    long long n = 0;                 // local particles
+    hipStream_t stream = nullptr;
+    CloudPtrs cl{};
+    DevState *d_st = nullptr;
+    DevState h_st{};
+    ModelDev *d_model = nullptr;
+    ModelDev h_model{};
+    bool have_params = false, have_lik = false;
+    double *d_data[2] = {nullptr, nullptr}, *d_aux[2] = {nullptr, nullptr};
+    Records rec{};
+    double *d_sched = nullptr;
+    int sched_len = 0;
+    // scratch
+    int nb_e = 0, nb_m = 0, nb_mut = 0, mut_T = 0;
+    size_t mut_lds = 0, mom_lds = 0;
+    double *d_part_ess = nullptr, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
+    long long *d_anc = nullptr;
+    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
+    long long comm_cap = 0;
+    double *d_hist_w = nullptr, *d_hist_W = nullptr;
+    // host-callback split
+    double *d_prop = nullptr, *d_prop_lp = nullptr, *d_prop_q = nullptr, *d_lik_new = nullptr, *d_lik_old = nullptr;
+    int *d_acc_count = nullptr, *d_flag = nullptr;
+    int last_n_stages = 1;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_sig = 0;
+};
+
+static int push_state(smcmi_handle *h) {
+    HIP_TRY(hipMemcpyAsync(h->d_st, &h->h_st, sizeof(DevState), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static int pull_state(smcmi_handle *h) {
+    HIP_TRY(hipMemcpyAsync(&h->h_st, h->d_st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static int push_model(smcmi_handle *h) {
+    HIP_TRY(hipMemcpyAsync(h->d_model, &h->h_model, sizeof(ModelDev), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+template <class T>
+static int dmalloc(T **p, size_t count) {
+    HIP_TRY(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    return 0;
+}
+static int err_from_state(int code) {
+    switch (code) {
+    case 0: return 0;
+    case SMCMI_ERR_NAN_ESS: return set_err(code, "No particles have non-zero weight (ESS is NaN)");
+    case SMCMI_ERR_POSDEF: return set_err(code, "PosDefException: block proposal covariance is not positive definite");
+    case SMCMI_ERR_CAPACITY: return set_err(code, "max_stages exceeded");
+    case SMCMI_ERR_BRACKET: return set_err(code, "adaptive tempering solver did not converge in the allotted passes");
+    default: return set_err(code, "device error");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ lifetime
+extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
+    if (!cfg || !out) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (cfg->n_para < 1 || cfg->n_para > SMCMI_MAX_PARA) return set_err(SMCMI_ERR_ARG, "n_para out of range (1..SMCMI_MAX_PARA)");
+    if (cfg->n_parts < 1) return set_err(SMCMI_ERR_ARG, "n_parts must be positive");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return set_err(SMCMI_ERR_HIP, "no HIP device available: libsmcmi has no CPU fallback (hipGetDeviceCount failed)");
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err(SMCMI_ERR_ARG, "bad device ordinal");
+    HIP_TRY(hipSetDevice(cfg->device));
+    smcmi_handle *h = new smcmi_handle();
+    h->cfg = *cfg;
+    if (h->cfg.n_local <= 0) h->cfg.n_local = cfg->n_parts;
+    if (h->cfg.max_stages < 2) h->cfg.max_stages = 2;
+    h->n = h->cfg.n_local;
+    h->d = cfg->n_para;
+    h->R = h->d + 5;
+    h->npairs = (h->d + 1) * (h->d + 2) / 2;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const long long n = h->n;
+    for (int b = 0; b < 2; ++b) {
+        if (dmalloc(&h->cl.buf[b], (size_t)n * h->R)) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemsetAsync(h->cl.buf[b], 0, (size_t)n * h->R * sizeof(double), h->stream));
+    }
+    h->cl.n = n;
+    h->cl.R = h->R;
+    if (dmalloc(&h->d_st, 1) || dmalloc(&h->d_model, 1)) return SMCMI_ERR_HIP;
+    const int ms = h->cfg.max_stages;
+    if (dmalloc(&h->rec.phi, ms) || dmalloc(&h->rec.ess, ms) || dmalloc(&h->rec.c, ms) || dmalloc(&h->rec.accept, ms) ||
+        dmalloc(&h->rec.resampled, ms))
+        return SMCMI_ERR_HIP;
+    h->nb_e = (int)std::min<long long>(1024, std::max<long long>(1, (n + 511) / 512));
+    h->nb_m = (int)std::min<long long>(1024, std::max<long long>(1, (n + MT - 1) / MT));
+    // mutation block size: largest of 256/128/64 threads whose per-thread LDS vectors fit 64 KiB
+    for (int T : {256, 128, 64}) {
+        h->mut_T = T;
+        h->mut_lds = (size_t)(4 * h->d * T + T / 64) * sizeof(double);
+        if (h->mut_lds <= 64 * 1024) break;
+    }
+    h->nb_mut = (int)((n + h->mut_T - 1) / h->mut_T);
+    h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;
+    h->comm_cap = std::max<long long>(2 * KC, h->npairs) + 8;
+    if (dmalloc(&h->d_part_ess, (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) ||
+        dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
+        dmalloc(&h->d_part_mom, (size_t)h->nb_m * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
+        dmalloc(&h->d_acc_part, h->nb_mut) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_flag, 4))
+        return SMCMI_ERR_HIP;
+    if (h->cfg.store_history) {
+        if (dmalloc(&h->d_hist_w, (size_t)n * ms) || dmalloc(&h->d_hist_W, (size_t)n * ms)) return SMCMI_ERR_HIP;
+    }
+    memset(&h->h_st, 0, sizeof(DevState));
+    h->h_st.rp.n_parts = cfg->n_parts;
+    h->h_st.rp.n_cand = KC;
+    h->h_st.rp.max_stages = ms;
+    h->h_st.stage = 1;
+    h->h_st.c = 0.5;
+    h->h_st.accept = 0.25;
+    h->h_st.ess_prev = (double)cfg->n_parts;
+    memset(&h->h_model, 0, sizeof(ModelDev));
+    h->h_model.d = h->d;
+    h->h_model.lik[0].family = SMCMI_LIK_NONE;
+    h->h_model.lik[1].family = SMCMI_LIK_NONE;
+    if (push_state(h) || push_model(h)) return SMCMI_ERR_HIP;
+    HIP_TRY(hipFuncSetAttribute((const void *)k_moments, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mom_lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
+    *out = h;
+    return 0;
+}
+
+extern "C" int smcmi_destroy(smcmi_handle *h) {
+    if (!h) return 0;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
+                    h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess,
+                    h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part,
+                    h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
+                    h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ model
+extern "C" int smcmi_set_parameters(smcmi_handle *h, const int32_t *fixed, const double *lo, const double *hi,
+                                    const int32_t *prior_family, const double *prior_a, const double *prior_b) {
+    if (!h || !lo || !hi || !prior_family || !prior_a || !prior_b) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    ModelDev &m = h->h_model;
+    m.n_free = 0;
+    for (int k = 0; k < h->d; ++k) {
+        m.fixed[k] = fixed ? fixed[k] : 0;
+        m.lo[k] = lo[k]; m.hi[k] = hi[k];
+        m.prior_family[k] = prior_family[k];
+        m.prior_a[k] = prior_a[k]; m.prior_b[k] = prior_b[k];
+        m.prior_k[k] = m.fixed[k] ? 0.0 : prior_const_host(prior_family[k], prior_a[k], prior_b[k]);
+        if (!m.fixed[k]) {
+            if (prior_family[k] < SMCMI_PRIOR_NORMAL || prior_family[k] > SMCMI_PRIOR_ROOTINVGAMMA)
+                return set_err(SMCMI_ERR_ARG, "unknown prior family");
+            m.free_inds[m.n_free++] = k;
+        }
+    }
+    if (m.n_free == 0) return set_err(SMCMI_ERR_ARG, "All model parameters are fixed!");   // smc_main.jl:237
+    h->have_params = true;
+    return push_model(h);
+}
+
+extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const double *par, int64_t n_par,
+                                    const double *data, int64_t rows, int64_t cols, const double *aux, int64_t aux_rows,
+                                    int64_t aux_cols) {
+    if (!h || which < 0 || which > 1) return set_err(SMCMI_ERR_ARG, "bad argument");
+    if (n_par > LIK_PAR_MAX) return set_err(SMCMI_ERR_ARG, "too many likelihood parameters");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    LikDev &l = h->h_model.lik[which];
+    if (h->d_data[which]) { hipFree(h->d_data[which]); h->d_data[which] = nullptr; }
+    if (h->d_aux[which]) { hipFree(h->d_aux[which]); h->d_aux[which] = nullptr; }
+    memset(&l, 0, sizeof(LikDev));
+    l.family = family;
+    if (family == SMCMI_LIK_NONE || family == SMCMI_LIK_HOST_CALLBACK) { if (which == 0) h->have_lik = true; return push_model(h); }
+    if (family < SMCMI_LIK_GAUSS_ISO || family > SMCMI_LIK_CAPM_LITERAL) return set_err(SMCMI_ERR_ARG, "unknown likelihood family");
+    l.n_par = (int)n_par;
+    for (int k = 0; k < n_par; ++k) l.par[k] = par[k];
+    const int d = h->d;
+    if (family == SMCMI_LIK_GAUSS_ISO && (n_par < 1 || rows * cols < d)) return set_err(SMCMI_ERR_ARG, "gauss_iso needs sigma and d means");
+    if (family == SMCMI_LIK_LINREG && (n_par < 1 || cols != 2 || d != 2)) return set_err(SMCMI_ERR_ARG, "linreg needs sigma2, data n x 2, d = 2");
+    if ((family == SMCMI_LIK_LINMODEL3 || family == SMCMI_LIK_CAPM_LITERAL) &&
+        (rows != 3 || d != 9 || !aux || aux_cols < cols || (family == SMCMI_LIK_LINMODEL3 && aux_rows != 3)))
+        return set_err(SMCMI_ERR_ARG, "3-equation families need data 3 x T, regressors with >= T columns, d = 9");
+    l.c0 = lik_const_host(family, l.par, d);
+    if (data && rows * cols > 0) {
+        if (dmalloc(&h->d_data[which], (size_t)(rows * cols))) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemcpy(h->d_data[which], data, sizeof(double) * rows * cols, hipMemcpyHostToDevice));
+    }
+    if (aux && aux_rows * aux_cols > 0) {
+        if (dmalloc(&h->d_aux[which], (size_t)(aux_rows * aux_cols))) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemcpy(h->d_aux[which], aux, sizeof(double) * aux_rows * aux_cols, hipMemcpyHostToDevice));
+    }
+    l.data = h->d_data[which]; l.rows = rows; l.cols = cols;
+    l.aux = h->d_aux[which]; l.aux_rows = aux_rows; l.aux_cols = aux_cols;
+    if (which == 0) h->have_lik = true;
+    return push_model(h);
+}
+
+// ------------------------------------------------------------------------------------------------ cloud transfer
+extern "C" int smcmi_upload_cloud(smcmi_handle *h, const double *particles) {
+    if (!h || !particles) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    HIP_TRY(hipMemcpy(h->cl.buf[h->h_st.cur], particles, sizeof(double) * h->n * h->R, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int smcmi_download_cloud(smcmi_handle *h, double *particles) {
+    if (!h || !particles) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    HIP_TRY(hipMemcpy(particles, h->cl.buf[h->h_st.cur], sizeof(double) * h->n * h->R, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int smcmi_cloud_device_ptr(smcmi_handle *h, double **dev_ptr, int64_t *ld) {
+    if (!h || !dev_ptr) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    *dev_ptr = h->cl.buf[h->h_st.cur];
+    if (ld) *ld = h->n;
+    return 0;
+}
+extern "C" int smcmi_sync(smcmi_handle *h) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int need_model(smcmi_handle *h, bool lik) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    if (!h->have_params) return set_err(SMCMI_ERR_STATE, "smcmi_set_parameters has not been called");
+    if (lik && (!h->have_lik || h->h_model.lik[0].family < 0 || h->h_model.lik[0].family == SMCMI_LIK_HOST_CALLBACK))
+        return set_err(SMCMI_ERR_STATE, "no device likelihood set (smcmi_set_likelihood)");
+    hipError_t e = hipSetDevice(h->cfg.device);
+    if (e != hipSuccess) return set_err(SMCMI_ERR_HIP, "hipSetDevice failed");
+    return 0;
+}
+
+extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
+    if (int rc = need_model(h, true)) return rc;
+    for (int k = 0; k < h->d; ++k)
+        if (!h->h_model.fixed[k] && h->h_model.prior_family[k] != SMCMI_PRIOR_NORMAL && h->h_model.prior_family[k] != SMCMI_PRIOR_UNIFORM)
+            return set_err(SMCMI_ERR_UNSUPPORTED, "device prior sampling supports Normal/Uniform priors; draw on the host and upload");
+    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+    k_init_prior<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_model, h->cfg.seed, h->cfg.gid0, h->d_flag);
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (flag) return set_err(SMCMI_ERR_STATE, "initial draw: no finite-likelihood draw found");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ stage primitives
+static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
+    if (h->sched_len < n_phi) {
+        if (h->d_sched) hipFree(h->d_sched);
+        h->d_sched = nullptr;
+        if (dmalloc(&h->d_sched, n_phi)) return SMCMI_ERR_HIP;
+        h->sched_len = n_phi;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_sched, sched, sizeof(double) * n_phi, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+extern "C" int smcmi_ess_at(smcmi_handle *h, const double *phis, int32_t k, double phi_prev, double *ess_out) {
+    if (!h || !phis || !ess_out || k < 1) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState saved = h->h_st;
+    std::vector<double> tot(2 * KC);
+    for (int base = 0; base < k; base += KC) {
+        const int nv = std::min(KC, k - base);
+        h->h_st.done = 0; h->h_st.mode = MODE_SECTION; h->h_st.phi_prev = phi_prev; h->h_st.n_valid = nv;
+        for (int q = 0; q < nv; ++q) h->h_st.cand[q] = phis[base + q];
+        if (push_state(h)) return SMCMI_ERR_HIP;
+        k_ess_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_ess, nullptr, 0);
+        k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess, h->nb_e, 2 * KC, h->d_comm);
+        HIP_TRY(hipMemcpyAsync(tot.data(), h->d_comm, sizeof(double) * 2 * KC, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int q = 0; q < nv; ++q) ess_out[base + q] = tot[q] * tot[q] / tot[KC + q];
+    }
+    h->h_st = saved;
+    return push_state(h);
+}
+
+static const int DEFAULT_SOLVER_PASSES = 16;
+
+static void enqueue_solver(smcmi_handle *h, int passes) {
+    for (int p = 0; p < passes; ++p) {
+        k_ess_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_ess, nullptr, 0);
+        k_phi_decide<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_part_ess, h->nb_e);
+    }
+}
+
+extern "C" int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_phi, int32_t *j, double *phi_prop,
+                               double phi_prev, double tempering_target, double ess_prev, int32_t *resampled_last,
+                               double *phi_n) {
+    if (!h || !sched || !j || !phi_prop || !resampled_last || !phi_n || n_phi < 2) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState saved = h->h_st;
+    DevState &s = h->h_st;
+    s.done = 0; s.err = 0; s.do_resample = 0; s.stage = 1; s.rp.use_fixed_schedule = 0; s.rp.n_phi = n_phi;
+    s.rp.tempering_target = tempering_target; s.rp.n_cand = KC; s.phi_n = phi_prev; s.phi_prop = *phi_prop; s.j = *j;
+    s.resampled_last = *resampled_last; s.ess_prev = ess_prev; s.mode = MODE_IDLE;
+    if (upload_sched(h, sched, n_phi) || push_state(h)) return SMCMI_ERR_HIP;
+    k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, 0, h->rec);
+    const int passes = (n_phi + KC - 2) / (KC - 1) + 14;
+    enqueue_solver(h, passes);
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    const int mode = s.mode, err = s.err;
+    const double out_phi = s.phi_n, out_prop = s.phi_prop;
+    const int out_j = s.j, out_rl = s.resampled_last;
+    h->h_st = saved;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    if (err) return err_from_state(err);
+    if (mode != MODE_FINAL) return err_from_state(SMCMI_ERR_BRACKET);
+    *phi_n = out_phi; *phi_prop = out_prop; *j = out_j; *resampled_last = out_rl;
+    return 0;
+}
+
+extern "C" int smcmi_correct(smcmi_handle *h, double phi_n, double phi_prev, double prior_weight, double log_prob_old_data,
+                             double threshold_ratio, smcmi_stage_stats *out) {
+    if (!h || !out) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    const double c_save = s.c, logz_save = s.logz;
+    const int resamples_save = s.resamples, rl_save = s.resampled_last, stage_save = s.stage;
+    s.done = 0; s.err = 0; s.mode = MODE_FINAL; s.phi_n = phi_n; s.phi_prev = phi_prev; s.rp.pw = prior_weight;
+    s.rp.logp_old = log_prob_old_data; s.rp.threshold = threshold_ratio * (double)s.rp.n_parts; s.logz = 0.0;
+    s.stage = h->cfg.max_stages;   // records of a stand-alone call land in the last (scratch) slot
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_ess_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin, nullptr, 0);
+    k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec);
+    k_normalize_weights<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st);
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    out->ess = s.ess; out->sum_unnorm = s.sumw; out->logz_inc = s.logz; out->resample = s.do_resample;
+    const int err = s.err;
+    s.c = c_save; s.logz = logz_save; s.resamples = resamples_save; s.resampled_last = rl_save; s.stage = stage_save;
+    s.do_resample = 0; s.done = 0; s.err = 0; s.mode = MODE_IDLE;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    return err_from_state(err);
+}
+
+extern "C" int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, const double *offsets, int64_t *ancestors_out) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    if (method != SMCMI_RESAMPLE_SYSTEMATIC && method != SMCMI_RESAMPLE_MULTINOMIAL)
+        return set_err(SMCMI_ERR_ARG, "Invalid resampler in SMC. Options are systematic or multinomial");   // resample.jl:77
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const long long n = h->n;
+    const double *d_off = nullptr;
+    if (offsets) {
+        const long long cnt = method == SMCMI_RESAMPLE_MULTINOMIAL ? n : 1;
+        HIP_TRY(hipMemcpyAsync(h->d_offsets, offsets, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+        d_off = h->d_offsets;
+    }
+    k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
+    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
+    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1);
+    k_search_ancestors<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->d_st, h->d_cum, n, h->cfg.gid0, n, h->cfg.n_parts,
+                                                                          method, h->cfg.seed, stage, d_off, h->d_anc, 1);
+    k_gather<<<dim3((unsigned)((n + TB - 1) / TB), h->R), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_anc, 1);
+    k_flip<<<1, 1, 0, h->stream>>>(h->d_st);
+    if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, h->d_anc, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int smcmi_moments(smcmi_handle *h, double *mean, double *cov) {
+    if (!h || !mean || !cov) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int d = h->d;
+    k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, nullptr, 0, 1);
+    k_moments_reduce<<<(h->npairs + 63) / 64, TB, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 1);
+    k_finalize_moments<<<1, 64, 0, h->stream>>>(h->d_st, h->d_totals, d);
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    for (int a = 0; a < d; ++a) mean[a] = h->h_st.mean[a];
+    for (int e = 0; e < d * d; ++e) cov[e] = h->h_st.cov[e];
+    return 0;
+}
+
+static int stage_blocks(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                        const int32_t *blocks_free, int32_t n_blocks, double c) {
+    DevState &s = h->h_st;
+    const ModelDev &m = h->h_model;
+    const int nf = m.n_free, d = h->d;
+    if (n_blocks < 1 || n_blocks > nf || block_ptr[0] != 0 || block_ptr[n_blocks] != nf) return set_err(SMCMI_ERR_ARG, "bad block structure");
+    for (int a = 0; a < d; ++a) s.mean[a] = 0.0;
+    for (int e = 0; e < d * d; ++e) s.cov[e] = 0.0;
+    for (int a = 0; a < nf; ++a) {
+        s.mean[m.free_inds[a]] = mu_free[a];
+        for (int b = 0; b < nf; ++b) s.cov[m.free_inds[a] * d + m.free_inds[b]] = Sigma_free[a * nf + b];
+    }
+    s.n_blocks = n_blocks;
+    for (int b = 0; b <= n_blocks; ++b) s.block_ptr[b] = block_ptr[b];
+    for (int i = 0; i < nf; ++i) {
+        if (blocks_free[i] < 0 || blocks_free[i] >= nf) return set_err(SMCMI_ERR_ARG, "block index out of range");
+        s.blocks_free[i] = blocks_free[i];
+    }
+    s.c = c;
+    return 0;
+}
+
+extern "C" int smcmi_mutate(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                            const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c, double alpha,
+                            int32_t n_mh_steps, uint32_t stage, double *accept_mean_out) {
+    (void)phi_prev;
+    if (int rc = need_model(h, true)) return rc;
+    if (!mu_free || !Sigma_free || !block_ptr || !blocks_free) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    const double c_save = s.c;
+    if (int rc = stage_blocks(h, mu_free, Sigma_free, block_ptr, blocks_free, n_blocks, c)) return rc;
+    s.done = 0; s.err = 0; s.do_resample = 0;
+    s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = phi_n; s.mut_steps = n_mh_steps; s.mut_stage = stage;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
+    k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 1);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_comm);
+    double asum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&asum, h->d_comm, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    const int err = s.err;
+    s.c = c_save; s.err = 0; s.done = 0;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    if (err) return err_from_state(err);
+    if (accept_mean_out) *accept_mean_out = asum / (double)h->n;
+    return 0;
+}
+
+static int ensure_split_buffers(smcmi_handle *h) {
+    if (h->d_prop) return 0;
+    const long long n = h->n;
+    if (dmalloc(&h->d_prop, (size_t)n * h->d) || dmalloc(&h->d_prop_lp, n) || dmalloc(&h->d_prop_q, n) ||
+        dmalloc(&h->d_lik_new, n) || dmalloc(&h->d_lik_old, n) || dmalloc(&h->d_acc_count, n))
+        return SMCMI_ERR_HIP;
+    return 0;
+}
+
+extern "C" int smcmi_propose(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                             const int32_t *blocks_free, int32_t n_blocks, int32_t block, int32_t mh_step, double c, double alpha,
+                             uint32_t stage, double *proposals_out, double *logprior_out, double *q_diff_out) {
+    if (int rc = need_model(h, false)) return rc;
+    if (!mu_free || !Sigma_free || !block_ptr || !blocks_free || !proposals_out) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (block < 0 || block >= n_blocks || mh_step < 0) return set_err(SMCMI_ERR_ARG, "bad block / step");
+    if (ensure_split_buffers(h) || pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    if (int rc = stage_blocks(h, mu_free, Sigma_free, block_ptr, blocks_free, n_blocks, c)) return rc;
+    s.done = 0; s.err = 0; s.do_resample = 0;
+    s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = 0.0; s.mut_steps = mh_step + 1; s.mut_stage = stage;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.proposals = h->d_prop; ma.prop_logprior = h->d_prop_lp;
+    ma.prop_qdiff = h->d_prop_q; ma.acc_count = h->d_acc_count; ma.block = block; ma.step = mh_step;
+    k_mutate<1><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 1);
+    HIP_TRY(hipMemcpyAsync(proposals_out, h->d_prop, sizeof(double) * h->n * h->d, hipMemcpyDeviceToHost, h->stream));
+    if (logprior_out) HIP_TRY(hipMemcpyAsync(logprior_out, h->d_prop_lp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (q_diff_out) HIP_TRY(hipMemcpyAsync(q_diff_out, h->d_prop_q, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    return err_from_state(s.err);
+}
+
+extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const double *loglik_old_new, double phi_n, int32_t block,
+                            int32_t mh_step, int32_t n_blocks, uint32_t stage, int32_t last) {
+    if (int rc = need_model(h, false)) return rc;
+    if (!loglik_new || !h->d_prop) return set_err(SMCMI_ERR_STATE, "smcmi_accept needs a preceding smcmi_propose");
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    if (n_blocks != s.n_blocks) return set_err(SMCMI_ERR_ARG, "n_blocks differs from the preceding smcmi_propose");
+    s.mut_phi = phi_n; s.mut_stage = stage; s.done = 0;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(h->d_lik_new, loglik_new, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    if (loglik_old_new) HIP_TRY(hipMemcpyAsync(h->d_lik_old, loglik_old_new, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.proposals = h->d_prop; ma.prop_logprior = h->d_prop_lp;
+    ma.prop_qdiff = h->d_prop_q; ma.lik_new = h->d_lik_new; ma.lik_old_new = loglik_old_new ? h->d_lik_old : nullptr;
+    ma.acc_count = h->d_acc_count; ma.block = block; ma.step = mh_step; ma.last = last;
+    k_mutate<2><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 1);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ whole loop
+static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int acc_nb, hipEvent_t ev0, hipEvent_t ev1) {
+    const long long n = h->n;
+    hipStream_t s = h->stream;
+    k_stage_begin<<<1, TB, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
+    if (adaptive) enqueue_solver(h, solver_passes);
+    k_ess_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_part_fin, h->d_hist_w, n);
+    k_post_correct<<<1, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec);
+    k_scan_weights<<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 0);
+    k_search_ancestors<<<(unsigned)((n + TB - 1) / TB), TB, 0, s>>>(h->d_st, h->d_cum, n, 0, n, h->cfg.n_parts, method, h->cfg.seed, 0u,
+                                                                  nullptr, h->d_anc, 0);
+    k_gather<<<dim3((unsigned)((n + TB - 1) / TB), h->R), TB, 0, s>>>(h->cl, h->d_st, h->d_anc, 0);
+    k_moments<<<h->nb_m, TB, h->mom_lds, s>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, n, 0);
+    k_moments_reduce<<<(h->npairs + 63) / 64, TB, 0, s>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 0);
+    k_prepare_mutation<<<1, 64, 0, s>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 1, 1, 0);
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
+    if (ev0) hipEventRecord(ev0, s);
+    k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, s>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
+    if (ev1) hipEventRecord(ev1, s);
+}
+
+extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
+    if (int e = need_model(h, true)) return e;
+    if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
+    const int nf = h->h_model.n_free;
+    if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
+        return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
+    if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
+    if (rc->resampling_method != SMCMI_RESAMPLE_SYSTEMATIC && rc->resampling_method != SMCMI_RESAMPLE_MULTINOMIAL)
+        return set_err(SMCMI_ERR_ARG, "Invalid resampler in SMC. Options are systematic or multinomial");
+    const bool adaptive = !rc->use_fixed_schedule;
+    if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    // proposed fixed schedule ((k-1)/(n_Φ-1))^λ, smc_main.jl:348-352
+    std::vector<double> sched(rc->n_phi);
+    for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
+    if (upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    const int cur = s.cur;
+    RunParams rp{};
+    rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
+    rp.resampling_method = rc->resampling_method; rp.use_fixed_schedule = rc->use_fixed_schedule;
+    rp.n_cand = (rc->n_cand > 1 && rc->n_cand <= KC) ? rc->n_cand : KC;
+    rp.threshold = rc->threshold_ratio * (double)h->cfg.n_parts;
+    rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
+    rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
+    rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+    memset(&s, 0, sizeof(DevState));
+    s.rp = rp; s.cur = cur;
+    s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
+    s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
+    s.ess_prev = (double)h->cfg.n_parts;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    // stage-1 records and history columns (w[:,1] = 0, W[:,1] = weights; smc_main.jl:363-366)
+    {
+        const double v0[4] = {0.0, (double)h->cfg.n_parts, rc->c, rc->target};
+        HIP_TRY(hipMemcpyAsync(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->rec.accept, &v0[3], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages, h->stream));
+        if (h->cfg.store_history) {
+            HIP_TRY(hipMemsetAsync(h->d_hist_w, 0, sizeof(double) * h->n, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_hist_W, h->cl.buf[cur] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n,
+                                   hipMemcpyDeviceToDevice, h->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    const int solver_passes = DEFAULT_SOLVER_PASSES;
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 8;
+    const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
+    std::vector<hipEvent_t> evs;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    if (rc->use_graph == 1) {
+        HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, h->nb_mut, nullptr, nullptr);
+        HIP_TRY(hipStreamEndCapture(h->stream, &graph));
+        HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int launched = 0, done = 0;
+    const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
+    while (launched < max_iter && !done) {
+        const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
+        for (int b = 0; b < batch; ++b) {
+            if (gexec) HIP_TRY(hipGraphLaunch(gexec, h->stream));
+            else {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
+                enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, h->nb_mut, e0, e1);
+            }
+            ++launched;
+        }
+        HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    // fold the last mutation's acceptance rate and close the run
+    k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, h->nb_mut, h->rec);
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    const auto t1 = std::chrono::steady_clock::now();
+    if (gexec) { hipGraphExecDestroy(gexec); hipGraphDestroy(graph); }
+    res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;
+    for (size_t k = 0; k + 1 < evs.size(); k += 2) {
+        float ms = 0.f;
+        if ((int)(k / 2) < s.stage - 1 && hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) { res->kernel_ms_mutate += ms; res->n_mutate_launches += 1; }
+    }
+    for (hipEvent_t e : evs) hipEventDestroy(e);
+    res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
+    res->seconds = std::chrono::duration<double>(t1 - t0).count();
+    h->last_n_stages = s.stage;
+    if (s.err) return err_from_state(s.err);
+    if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
+    return 0;
+}
+
+extern "C" int smcmi_get_stage_records(smcmi_handle *h, double *phi, double *ess, double *c, double *accept, int32_t *resampled) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int ns = h->last_n_stages;
+    if (phi) HIP_TRY(hipMemcpy(phi, h->rec.phi, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    if (ess) HIP_TRY(hipMemcpy(ess, h->rec.ess, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    if (c) HIP_TRY(hipMemcpy(c, h->rec.c, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    if (accept) HIP_TRY(hipMemcpy(accept, h->rec.accept, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    if (resampled) HIP_TRY(hipMemcpy(resampled, h->rec.resampled, sizeof(int) * ns, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int smcmi_get_history(smcmi_handle *h, double *w, double *W) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    if (!h->cfg.store_history) return set_err(SMCMI_ERR_STATE, "history was not stored (store_history = 0)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t bytes = sizeof(double) * (size_t)h->n * h->last_n_stages;
+    if (w) HIP_TRY(hipMemcpy(w, h->d_hist_w, bytes, hipMemcpyDeviceToHost));
+    if (W) HIP_TRY(hipMemcpy(W, h->d_hist_W, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ shard-level pieces
+extern "C" int smcmi_comm_buffer(smcmi_handle *h, double **dev_ptr, int64_t *capacity) {
+    if (!h || !dev_ptr) return set_err(SMCMI_ERR_ARG, "null argument");
+    *dev_ptr = h->d_comm;
+    if (capacity) *capacity = h->comm_cap;
+    return 0;
+}
+
+extern "C" int smcmi_shard_ess_partial(smcmi_handle *h, const double *phis, int32_t k, double phi_prev) {
+    if (!h || !phis || k < 1 || k > KC) return set_err(SMCMI_ERR_ARG, "bad argument (1 <= k <= SMCMI_MAX_CAND)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    s.done = 0; s.mode = MODE_SECTION; s.phi_prev = phi_prev; s.n_valid = k;
+    for (int q = 0; q < k; ++q) s.cand[q] = phis[q];
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_ess_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_ess, nullptr, 0);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess, h->nb_e, 2 * KC, h->d_comm);   // comm[q] = Σv, comm[KC+q] = Σv²
+    s.mode = MODE_IDLE;
+    return push_state(h);
+}
+
+extern "C" int smcmi_shard_correct_partial(smcmi_handle *h, double phi_n, double phi_prev, double prior_weight,
+                                           double log_prob_old_data, int32_t stage_col) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    if (stage_col + 1 > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded");
+    s.done = 0; s.mode = MODE_FINAL; s.phi_n = phi_n; s.phi_prev = phi_prev; s.rp.pw = prior_weight; s.rp.logp_old = log_prob_old_data;
+    s.stage = stage_col + 1; s.rp.store_history = h->cfg.store_history;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_ess_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin, h->d_hist_w, h->n);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_comm);
+    h->last_n_stages = std::max(h->last_n_stages, stage_col + 1);
+    s.mode = MODE_IDLE;
+    return push_state(h);
+}
+
+extern "C" int smcmi_shard_normalize_moments_partial(smcmi_handle *h, double sum_unnorm, int32_t resampled, const double *shift,
+                                                     int32_t stage_col) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    s.done = 0; s.sumw = sum_unnorm; s.do_resample = 0; s.stage = stage_col + 1; s.rp.store_history = h->cfg.store_history;
+    for (int a = 0; a < h->d; ++a) s.shift[a] = shift ? shift[a] : 0.0;
+    if (resampled) {
+        // after a gather the weights are already 1: normalise with Σ = N so (w*N)/Σ == w
+        s.sumw = (double)h->cfg.n_parts;
+    }
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, h->n, 0);
+    k_moments_reduce<<<(h->npairs + 63) / 64, TB, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_comm, 0);
+    return 0;
+}
+
+extern "C" int smcmi_shard_weights_device_ptr(smcmi_handle *h, double **dev_ptr) {
+    if (!h || !dev_ptr) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    *dev_ptr = h->cl.buf[h->h_st.cur] + (long long)(h->R - 1) * h->n;
+    return 0;
+}
+
+// rows of this shard <- rows `ancestors` (global ids) of an all-gathered full cloud (n_full x R, column-major, device)
+__global__ void k_gather_full(CloudPtrs cl, const DevState *st, const double *full, long long n_full, const long long *anc) {
+    const long long k = (long long)blockIdx.x * TB + threadIdx.x;
+    if (k >= cl.n) return;
+    const int c = blockIdx.y;
+    double *out = col(cl, st->cur, c);
+    out[k] = (c == cl.R - 1) ? 1.0 : full[(long long)c * n_full + anc[k]];
+}
+extern "C" int smcmi_shard_gather_rows(smcmi_handle *h, const double *dev_full_cloud, int64_t n_full, const int64_t *dev_ancestors) {
+    if (!h || !dev_full_cloud || !dev_ancestors) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    k_gather_full<<<dim3((unsigned)((h->n + TB - 1) / TB), h->R), TB, 0, h->stream>>>(h->cl, h->d_st, dev_full_cloud, n_full,
+                                                                                    (const long long *)dev_ancestors);
+    return 0;
+}
+
+extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
+                                          const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c,
+                                          double alpha, int32_t n_mh_steps, uint32_t stage) {
+    (void)phi_prev;
+    if (int rc = need_model(h, true)) return rc;
+    if (!mu_free || !Sigma_free || !block_ptr || !blocks_free) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    if (int rc = stage_blocks(h, mu_free, Sigma_free, block_ptr, blocks_free, n_blocks, c)) return rc;
+    s.done = 0; s.err = 0; s.do_resample = 0;
+    s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = phi_n; s.mut_steps = n_mh_steps; s.mut_stage = stage;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
+    k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 1);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_comm);
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    return err_from_state(s.err);
+}

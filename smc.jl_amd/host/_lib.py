@@ -1,0 +1,111 @@
+"""ctypes binding of libsmcmi.so (include/smcmi.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises - there is no
+Python / CPU fallback for any of the engine's entry points.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsmcmi.so")
+
+MAX_PARA = 64
+MAX_CAND = 32
+
+PRIOR = {"normal": 0, "uniform": 1, "gamma": 2, "beta": 3, "invgamma": 4, "rootinvgamma": 5}
+LIK = {"none": -1, "gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "host_callback": 100}
+RESAMPLE = {"systematic": 0, "multinomial": 1, "polyalgo": 1}
+
+ERRORS = {-1: "ARG", -2: "HIP", -3: "NAN_ESS", -4: "POSDEF", -5: "CAPACITY", -6: "BRACKET", -7: "UNSUPPORTED", -8: "STATE"}
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+lp = C.POINTER(C.c_int64)
+
+
+class Config(C.Structure):
+    _fields_ = [("n_parts", C.c_int64), ("n_local", C.c_int64), ("gid0", C.c_int64), ("n_para", C.c_int32),
+                ("device", C.c_int32), ("seed", C.c_uint64), ("max_stages", C.c_int32), ("store_history", C.c_int32)]
+
+
+class RunConfig(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("n_mh_steps", C.c_int32), ("lam", C.c_double), ("n_phi", C.c_int32),
+                ("resampling_method", C.c_int32), ("threshold_ratio", C.c_double), ("c", C.c_double),
+                ("alpha", C.c_double), ("target", C.c_double), ("use_fixed_schedule", C.c_int32),
+                ("tempering_target", C.c_double), ("tempered_update_prior_weight", C.c_double),
+                ("log_prob_old_data", C.c_double), ("n_cand", C.c_int32), ("sync_every", C.c_int32),
+                ("use_graph", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_stages", C.c_int32), ("resamples", C.c_int32), ("logmdd", C.c_double), ("c", C.c_double),
+                ("accept", C.c_double), ("seconds", C.c_double), ("kernel_ms_mutate", C.c_double),
+                ("n_mutate_launches", C.c_int32)]
+
+
+class StageStats(C.Structure):
+    _fields_ = [("ess", C.c_double), ("sum_unnorm", C.c_double), ("logz_inc", C.c_double), ("resample", C.c_int32)]
+
+
+# every symbol include/smcmi.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = [
+    ("smcmi_create", C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    ("smcmi_destroy", C.c_int, [_H]),
+    ("smcmi_last_error", C.c_char_p, []),
+    ("smcmi_version", C.c_int, []),
+    ("smcmi_set_parameters", C.c_int, [_H, ip, dp, dp, ip, dp, dp]),
+    ("smcmi_set_likelihood", C.c_int, [_H, C.c_int32, C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int64, dp, C.c_int64, C.c_int64]),
+    ("smcmi_upload_cloud", C.c_int, [_H, dp]),
+    ("smcmi_download_cloud", C.c_int, [_H, dp]),
+    ("smcmi_init_from_prior", C.c_int, [_H]),
+    ("smcmi_cloud_device_ptr", C.c_int, [_H, C.POINTER(C.c_void_p), lp]),
+    ("smcmi_ess_at", C.c_int, [_H, dp, C.c_int32, C.c_double, dp]),
+    ("smcmi_solve_phi", C.c_int, [_H, dp, C.c_int32, ip, dp, C.c_double, C.c_double, C.c_double, ip, dp]),
+    ("smcmi_correct", C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(StageStats)]),
+    ("smcmi_resample", C.c_int, [_H, C.c_int32, C.c_uint32, dp, lp]),
+    ("smcmi_moments", C.c_int, [_H, dp, dp]),
+    ("smcmi_mutate", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32, dp]),
+    ("smcmi_propose", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint32, dp, dp, dp]),
+    ("smcmi_accept", C.c_int, [_H, dp, dp, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32]),
+    ("smcmi_run", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),
+    ("smcmi_get_stage_records", C.c_int, [_H, dp, dp, dp, dp, ip]),
+    ("smcmi_get_history", C.c_int, [_H, dp, dp]),
+    ("smcmi_comm_buffer", C.c_int, [_H, C.POINTER(C.c_void_p), lp]),
+    ("smcmi_shard_ess_partial", C.c_int, [_H, dp, C.c_int32, C.c_double]),
+    ("smcmi_shard_correct_partial", C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32]),
+    ("smcmi_shard_normalize_moments_partial", C.c_int, [_H, C.c_double, C.c_int32, dp, C.c_int32]),
+    ("smcmi_shard_weights_device_ptr", C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    ("smcmi_shard_gather_rows", C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("smcmi_shard_mutate_partial", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32]),
+    ("smcmi_sync", C.c_int, [_H]),
+]
+
+_LIB = None
+
+
+class SMCMIError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("smcmi error %s (%d): %s" % (ERRORS.get(code, "?"), code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libsmcmi.so (built in-tree by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libsmcmi.so not found at %s - build it with `python __graft_entry__.py` "
+                              "(hipcc --offload-arch=gfx950); the engine has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise SMCMIError(rc, lib().smcmi_last_error().decode())

@@ -1,0 +1,173 @@
+"""Engine: thin object wrapper over one libsmcmi handle (= one particle shard on one MI355X).
+
+Method names follow the reference functions they stand in for (src/helpers.jl, src/resample.jl,
+src/particle.jl, src/mutation.jl); arrays are numpy float64, clouds are (N, R) Fortran-ordered like
+the reference's `cloud.particles`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dp, ip, lp
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(ip)
+
+
+class Engine:
+    def __init__(self, n_parts, n_para, seed=0, device=0, max_stages=300, store_history=True, n_local=None, gid0=0):
+        self._L = _lib.lib()
+        self.n_parts, self.d, self.R = int(n_parts), int(n_para), int(n_para) + 5
+        self.n = int(n_parts if n_local is None else n_local)
+        self.gid0, self.seed, self.max_stages, self.store_history = int(gid0), int(seed), int(max_stages), bool(store_history)
+        cfg = _lib.Config(self.n_parts, self.n, self.gid0, self.d, device, self.seed, self.max_stages, int(store_history))
+        self._h = C.c_void_p()
+        check(self._L.smcmi_create(C.byref(cfg), C.byref(self._h)))
+        self.free_inds = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.smcmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model -------------------------------------------------------------------------------------
+    def set_parameters(self, priors, bounds, fixed=None):
+        d = self.d
+        assert len(priors) == d and len(bounds) == d
+        fam = np.array([_lib.PRIOR[p[0]] if isinstance(p[0], str) else int(p[0]) for p in priors], dtype=np.int32)
+        a, b = _f64([p[1] for p in priors]), _f64([p[2] for p in priors])
+        lo, hi = _f64([x[0] for x in bounds]), _f64([x[1] for x in bounds])
+        fx = np.zeros(d, dtype=np.int32) if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
+        check(self._L.smcmi_set_parameters(self._h, _i(fx), _d(lo), _d(hi), _i(fam), _d(a), _d(b)))
+        self.free_inds = np.flatnonzero(fx == 0).astype(np.int32)
+
+    def set_likelihood(self, family, par=(), data=None, aux=None, which=0):
+        fam = _lib.LIK[family] if isinstance(family, str) else int(family)
+        par = _f64(par).ravel()
+        data = None if data is None else np.asfortranarray(np.atleast_2d(np.asarray(data, dtype=np.float64)))
+        aux = None if aux is None else np.asfortranarray(np.atleast_2d(np.asarray(aux, dtype=np.float64)))
+        check(self._L.smcmi_set_likelihood(
+            self._h, which, fam, _d(par) if par.size else None, par.size,
+            None if data is None else _d(data), 0 if data is None else data.shape[0], 0 if data is None else data.shape[1],
+            None if aux is None else _d(aux), 0 if aux is None else aux.shape[0], 0 if aux is None else aux.shape[1]))
+
+    def set_model(self, spec):
+        """spec: dict(priors, bounds, fixed, lik=(family, par, data, aux), old_lik=None|(...))."""
+        self.set_parameters(spec["priors"], spec["bounds"], spec.get("fixed"))
+        lk = spec["lik"]
+        self.set_likelihood(lk[0], lk[1], lk[2], lk[3], which=0)
+        ol = spec.get("old_lik")
+        if ol is None:
+            self.set_likelihood("none", which=1)
+        else:
+            self.set_likelihood(ol[0], ol[1], ol[2], ol[3], which=1)
+
+    # ---- cloud -------------------------------------------------------------------------------------
+    def upload_cloud(self, particles):
+        p = np.asfortranarray(np.asarray(particles, dtype=np.float64))
+        assert p.shape == (self.n, self.R), (p.shape, (self.n, self.R))
+        check(self._L.smcmi_upload_cloud(self._h, _d(p)))
+
+    def download_cloud(self):
+        p = np.empty((self.n, self.R), order="F")
+        check(self._L.smcmi_download_cloud(self._h, _d(p)))
+        return p
+
+    def init_from_prior(self):
+        check(self._L.smcmi_init_from_prior(self._h))
+
+    # ---- stage primitives --------------------------------------------------------------------------
+    def ess_at(self, phis, phi_prev):
+        phis = _f64(np.atleast_1d(phis))
+        out = np.empty_like(phis)
+        check(self._L.smcmi_ess_at(self._h, _d(phis), phis.size, phi_prev, _d(out)))
+        return out
+
+    def solve_phi(self, sched, j, phi_prop, phi_prev, tempering_target, ess_prev, resampled_last):
+        sched = _f64(sched)
+        jj, pp, rl, out = C.c_int32(j), C.c_double(phi_prop), C.c_int32(int(resampled_last)), C.c_double()
+        check(self._L.smcmi_solve_phi(self._h, _d(sched), sched.size, C.byref(jj), C.byref(pp), phi_prev, tempering_target,
+                                      ess_prev, C.byref(rl), C.byref(out)))
+        return out.value, bool(rl.value), jj.value, pp.value
+
+    def correct(self, phi_n, phi_prev, prior_weight=0.0, log_prob_old_data=0.0, threshold_ratio=0.5):
+        st = _lib.StageStats()
+        check(self._L.smcmi_correct(self._h, phi_n, phi_prev, prior_weight, log_prob_old_data, threshold_ratio, C.byref(st)))
+        return dict(ess=st.ess, sum_unnorm=st.sum_unnorm, logz_inc=st.logz_inc, resample=bool(st.resample))
+
+    def resample(self, method="systematic", stage=0, offsets=None):
+        anc = np.empty(self.n, dtype=np.int64)
+        off = None if offsets is None else _f64(np.atleast_1d(offsets))
+        check(self._L.smcmi_resample(self._h, _lib.RESAMPLE[method], stage, None if off is None else _d(off),
+                                     anc.ctypes.data_as(lp)))
+        return anc
+
+    def moments(self):
+        mean, cov = np.empty(self.d), np.empty((self.d, self.d))
+        check(self._L.smcmi_moments(self._h, _d(mean), _d(cov)))
+        return mean, cov
+
+    def mutate(self, mu_free, Sigma_free, block_ptr, blocks_free, phi_n, phi_prev, c, alpha, n_mh_steps, stage):
+        mu, S = _f64(mu_free), _f64(Sigma_free)
+        bp, bf = np.ascontiguousarray(block_ptr, dtype=np.int32), np.ascontiguousarray(blocks_free, dtype=np.int32)
+        acc = C.c_double()
+        check(self._L.smcmi_mutate(self._h, _d(mu), _d(S), _i(bp), _i(bf), bp.size - 1, phi_n, phi_prev, c, alpha, n_mh_steps,
+                                   stage, C.byref(acc)))
+        return acc.value
+
+    def propose(self, mu_free, Sigma_free, block_ptr, blocks_free, block, mh_step, c, alpha, stage):
+        mu, S = _f64(mu_free), _f64(Sigma_free)
+        bp, bf = np.ascontiguousarray(block_ptr, dtype=np.int32), np.ascontiguousarray(blocks_free, dtype=np.int32)
+        prop = np.empty((self.n, self.d), order="F")
+        lpr, qd = np.empty(self.n), np.empty(self.n)
+        check(self._L.smcmi_propose(self._h, _d(mu), _d(S), _i(bp), _i(bf), bp.size - 1, block, mh_step, c, alpha, stage,
+                                    _d(prop), _d(lpr), _d(qd)))
+        return prop, lpr, qd
+
+    def accept(self, loglik_new, loglik_old_new, phi_n, block, mh_step, n_blocks, stage, last):
+        ln = _f64(loglik_new)
+        lo = None if loglik_old_new is None else _f64(loglik_old_new)
+        check(self._L.smcmi_accept(self._h, _d(ln), None if lo is None else _d(lo), phi_n, block, mh_step, n_blocks, stage,
+                                   int(last)))
+
+    # ---- whole loop --------------------------------------------------------------------------------
+    def run(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
+            c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
+            log_prob_old_data=0.0, n_cand=0, sync_every=0, use_graph=0):
+        rc = _lib.RunConfig(n_blocks, n_mh_steps, lam, n_phi, _lib.RESAMPLE[resampling_method], threshold_ratio, c, alpha,
+                            target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, n_cand,
+                            sync_every, use_graph)
+        res = _lib.Result()
+        check(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
+        return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
+                    seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches)
+
+    def stage_records(self, n_stages):
+        phi, ess, c, acc = (np.empty(n_stages) for _ in range(4))
+        rs = np.empty(n_stages, dtype=np.int32)
+        check(self._L.smcmi_get_stage_records(self._h, _d(phi), _d(ess), _d(c), _d(acc), _i(rs)))
+        return dict(schedule=phi, ess=ess, c_hist=c, accept_hist=acc, resampled=rs)
+
+    def history(self, n_stages):
+        w, W = np.empty((self.n, n_stages), order="F"), np.empty((self.n, n_stages), order="F")
+        check(self._L.smcmi_get_history(self._h, _d(w), _d(W)))
+        return w, W
+
+    def sync(self):
+        check(self._L.smcmi_sync(self._h))
