@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py - particle-stages/sec of the SMC correction/selection/mutation loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete pass of the hot path over one batch: a full smc() run (all tempering stages) of
+BASELINE config 2 - 10-dim isotropic-Gaussian log-likelihood, n_parts = 100k per GPU, adaptive ϕ
+(tempering_target 0.97, n_Φ = 300, λ = 2.1), systematic resampling, 1 block, 1 MH step - on synthetic
+prior draws already resident in HBM.  value = n_parts * (n_stages - 1) * K / wall, the reference's metric
+(stage bracket src/smc_main.jl:378,489-490; initialisation and file I/O excluded).  For N > 1 the driver
+launches one rank per GPU (torch.distributed, RCCL); particles are sharded (weak scaling: 100k per GPU) with
+small all-reduces per stage and an exchange on resample stages.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+D = 10
+N_PER_GPU = 100_000
+RUN_KW = dict(use_fixed_schedule=False, tempering_target=0.97, n_phi=300, lam=2.1, resampling_method="systematic",
+              n_blocks=1, n_mh_steps=1, alpha=1.0, c=0.5, target=0.25, threshold_ratio=0.5)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def mutate_bytes_per_particle(d):
+    # mutate reads θ(d), ℓ, π, ℓ_old and writes θ(d), ℓ, π, ℓ_old, accept = 16 d + 56 bytes (FP64)
+    return 16 * d + 56
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nparts", type=int, default=N_PER_GPU, help="particles per GPU")
+    ap.add_argument("--mode", default="direct", choices=["direct", "graph"], help="stage launch mode")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--no-history", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from tests import models
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    spec = models.gauss_spec(D)
+    seed = 1
+    n_local = args.nparts
+    n_total = n_local * world
+    max_stages = 1500
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        from smc_jl_amd import Engine
+
+        eng = Engine(n_total, D, seed=seed, device=local_rank, max_stages=max_stages, store_history=not args.no_history)
+        eng.set_model(spec)
+        eng.init_from_prior()
+        P0 = eng.download_cloud()            # pristine initial cloud (prior draws + log-likelihoods)
+        dev0 = torch.from_numpy(np.ascontiguousarray(P0.T)).cuda()   # resident copy; rows = columns of the cloud
+
+        def reset():
+            # device-to-device restore of the initial cloud (12 MB) - inputs stay resident in HBM
+            eng.upload_cloud_from_device(dev0.data_ptr())
+
+        def one_step(profile=False):
+            reset()
+            return eng.run(use_graph=(2 if profile else (1 if args.mode == "graph" else 0)), **RUN_KW)
+    else:
+        from smc_jl_amd.host.distributed import ShardedSMC
+
+        sm = ShardedSMC(spec, n_total, seed=seed, device=local_rank, max_stages=max_stages,
+                        store_history=not args.no_history)
+        sm.init_from_prior()
+        sm.snapshot()
+
+        def one_step(profile=False):
+            sm.restore()
+            return sm.run(**RUN_KW)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    stages = 0
+    last = None
+    for _ in range(args.steps):
+        last = one_step()
+        stages += last["n_stages"] - 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = n_total * stages / dt
+
+    out = {
+        "metric": "particle-stages/sec", "value": value, "unit": "particle-stages/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "gauss%d_isotropic_adaptive_phi_n%dk_per_gpu" % (D, n_local // 1000),
+                   "n_parts_total": n_total, "n_para": D, "tempering_target": 0.97, "n_phi": 300, "lambda": 2.1,
+                   "resampling": "systematic", "n_blocks": 1, "n_mh_steps": 1, "launch_mode": args.mode,
+                   "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
+        "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
+        "logmdd_exact": models.gauss_logmdd(D),
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel (mutation): HIP events around every k_mutate launch of one more
+        # identical run on the engine's stream (smcmi_run use_graph = 2), algorithmic bytes / mean duration
+        prof = one_step(profile=True)
+        nl = max(prof["n_mutate_launches"], 1)
+        mean_ms = prof["kernel_ms_mutate"] / nl
+        bytes_per_launch = mutate_bytes_per_particle(D) * n_total
+        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "k_mutate<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl}
+        # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages
+        stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
+        out["stage_gbs"] = stage_bytes * args.steps / dt / 1e9
+        if not args.no_cpu:
+            from oracle import oracle as orc
+
+            orc.build()
+            m = models.oracle_model(spec)
+            cores = os.cpu_count() or 1
+            r = orc.smc_run(m, P0, seed=seed, n_threads=cores, history=False, max_stages=max_stages, **RUN_KW)
+            cpu_value = n_total * (r["n_stages"] - 1) / r["seconds"]
+            out["cpu_baseline"] = {"value": cpu_value, "unit": "particle-stages/s", "cores": cores, "kind": "port",
+                                   "sample": "the full workload once (n_parts=%d, %d stages, same Philox seed); OpenMP over "
+                                             "particles in the mutation step only, like the reference's @distributed "
+                                             "mutation (src/smc_main.jl:472-476)" % (n_total, r["n_stages"] - 1),
+                                   "seconds": r["seconds"], "logmdd": r["logmdd"]}
+            out["logmdd_cpu"] = r["logmdd"]
+            out["logmdd_abs_err"] = abs(last["logmdd"] - r["logmdd"])
+            out["gpu_over_cpu"] = value / cpu_value
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,7 @@ int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const d
 /* ---- cloud transfer (cloud.particles; get_vals/get_loglh/... read columns of the download) ---- */
 int smcmi_upload_cloud(smcmi_handle *h, const double *particles);       /* n_local x R, column-major */
 int smcmi_download_cloud(smcmi_handle *h, double *particles);
+int smcmi_upload_cloud_device(smcmi_handle *h, const double *dev_particles);   /* device-to-device, same layout */
 int smcmi_init_from_prior(smcmi_handle *h);                              /* initial_draw!, initialization.jl:88-119 */
 int smcmi_cloud_device_ptr(smcmi_handle *h, double **dev_ptr, int64_t *ld); /* current buffer, for zero-copy hosts */
 

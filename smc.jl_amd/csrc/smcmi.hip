@@ -255,6 +255,14 @@ extern "C" int smcmi_upload_cloud(smcmi_handle *h, const double *particles) {
     HIP_TRY(hipMemcpy(h->cl.buf[h->h_st.cur], particles, sizeof(double) * h->n * h->R, hipMemcpyHostToDevice));
     return 0;
 }
+extern "C" int smcmi_upload_cloud_device(smcmi_handle *h, const double *dev_particles) {
+    if (!h || !dev_particles) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(h->cl.buf[h->h_st.cur], dev_particles, sizeof(double) * h->n * h->R, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
 extern "C" int smcmi_download_cloud(smcmi_handle *h, double *particles) {
     if (!h || !particles) return set_err(SMCMI_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("smcmi_set_likelihood", C.c_int, [_H, C.c_int32, C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int64, dp, C.c_int64, C.c_int64]),
     ("smcmi_upload_cloud", C.c_int, [_H, dp]),
     ("smcmi_download_cloud", C.c_int, [_H, dp]),
+    ("smcmi_upload_cloud_device", C.c_int, [_H, C.c_void_p]),
     ("smcmi_init_from_prior", C.c_int, [_H]),
     ("smcmi_cloud_device_ptr", C.c_int, [_H, C.POINTER(C.c_void_p), lp]),
     ("smcmi_ess_at", C.c_int, [_H, dp, C.c_int32, C.c_double, dp]),

@@ -84,6 +84,10 @@ class Engine:
         assert p.shape == (self.n, self.R), (p.shape, (self.n, self.R))
         check(self._L.smcmi_upload_cloud(self._h, _d(p)))
 
+    def upload_cloud_from_device(self, dev_ptr):
+        """Device-to-device restore from a resident n x R column-major buffer (e.g. a torch tensor's data_ptr())."""
+        check(self._L.smcmi_upload_cloud_device(self._h, C.c_void_p(int(dev_ptr))))
+
     def download_cloud(self):
         p = np.empty((self.n, self.R), order="F")
         check(self._L.smcmi_download_cloud(self._h, _d(p)))
