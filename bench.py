@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--mode", default="direct", choices=["direct", "graph"], help="stage launch mode")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-history", action="store_true")
+    ap.add_argument("--solver-passes", type=int, default=0)
+    ap.add_argument("--sync-every", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -57,7 +59,8 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("SMCMI_FORCE_SHARDED") == "1"
+    if world > 1 or (force_sharded and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -74,7 +77,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         from smc_jl_amd import Engine
 
         eng = Engine(n_total, D, seed=seed, device=local_rank, max_stages=max_stages, store_history=not args.no_history)
@@ -89,7 +92,8 @@ def main():
 
         def one_step(profile=False):
             reset()
-            return eng.run(use_graph=(2 if profile else (1 if args.mode == "graph" else 0)), **RUN_KW)
+            return eng.run(use_graph=(2 if profile else (1 if args.mode == "graph" else 0)), solver_passes=args.solver_passes,
+                           sync_every=args.sync_every, **RUN_KW)
     else:
         from smc_jl_amd.host.distributed import ShardedSMC
 
@@ -128,10 +132,10 @@ def main():
                    "resampling": "systematic", "n_blocks": 1, "n_mh_steps": 1, "launch_mode": args.mode,
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
-        "logmdd_exact": models.gauss_logmdd(D),
+        "logmdd_exact": models.gauss_logmdd(D), "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not force_sharded:
         # ---- roofline of the dominant kernel (mutation): HIP events around every k_mutate launch of one more
         # identical run on the engine's stream (smcmi_run use_graph = 2), algorithmic bytes / mean duration
         prof = one_step(profile=True)

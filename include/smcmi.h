@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SMCMI_MAX_PARA 64      /* n_para (incl. fixed) supported by the device kernels */
-#define SMCMI_MAX_CAND 32      /* tempering candidates evaluated per ESS pass */
+#define SMCMI_MAX_CAND 16      /* tempering candidates evaluated per ESS pass */
 
 enum { SMCMI_OK = 0, SMCMI_ERR_ARG = -1, SMCMI_ERR_HIP = -2, SMCMI_ERR_NAN_ESS = -3, SMCMI_ERR_POSDEF = -4,
        SMCMI_ERR_CAPACITY = -5, SMCMI_ERR_BRACKET = -6, SMCMI_ERR_UNSUPPORTED = -7, SMCMI_ERR_STATE = -8 };
@@ -68,9 +68,10 @@ typedef struct {
     double tempering_target;               /* :140 */
     double tempered_update_prior_weight;   /* :156 */
     double log_prob_old_data;              /* :161 */
-    int32_t n_cand;                        /* ESS candidates per pass (<= SMCMI_MAX_CAND; 0 => default) */
+    int32_t solver_passes;                 /* kernel passes allotted to the adaptive-ϕ solver per stage (0 => default 8) */
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
-    int32_t use_graph;                     /* replay the stage as a hipGraph */
+    int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
+    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-12; <0 => adjacent floats) */
 } smcmi_run_config;
 
 typedef struct {
@@ -81,6 +82,7 @@ typedef struct {
     double seconds;          /* wall time of the loop = cloud.total_sampling_time (smc_main.jl:489-490) */
     double kernel_ms_mutate; /* HIP-event time spent in the mutation kernel over the run (0 if not measured) */
     int32_t n_mutate_launches;
+    int64_t solver_passes;   /* particle passes spent in the adaptive-ϕ solver over the run */
 } smcmi_result;
 
 typedef struct {             /* what one correction step reports (smc_main.jl:401-432) */
@@ -146,13 +148,15 @@ int smcmi_get_history(smcmi_handle *h, double *w, double *W);           /* n_loc
 /* Every stage step is split as: partial (kernel writes this shard's partial sums into the comm buffer) ->
    host all-reduces comm buffer over ranks -> apply (kernels consume the global totals). */
 int smcmi_comm_buffer(smcmi_handle *h, double **dev_ptr, int64_t *capacity);
+int smcmi_comm_read(smcmi_handle *h, double *out, int64_t count);             /* synchronous device-to-host copy of comm[0..count) */
 int smcmi_shard_ess_partial(smcmi_handle *h, const double *phis, int32_t k, double phi_prev);       /* comm[0..2k) = Σv, Σv² */
 int smcmi_shard_correct_partial(smcmi_handle *h, double phi_n, double phi_prev, double prior_weight,
                                 double log_prob_old_data, int32_t stage_col);                         /* comm[0..2) */
 int smcmi_shard_normalize_moments_partial(smcmi_handle *h, double sum_unnorm, int32_t resampled,
                                           const double *shift, int32_t stage_col);                    /* comm[0..1+d+d(d+1)/2) */
 int smcmi_shard_weights_device_ptr(smcmi_handle *h, double **dev_ptr);
-int smcmi_shard_gather_rows(smcmi_handle *h, const double *dev_full_cloud, int64_t n_full, const int64_t *dev_ancestors);
+int smcmi_shard_resample(smcmi_handle *h, const double *dev_full_weights, const double *dev_full_cloud, int32_t method,
+                         uint32_t stage, int64_t *ancestors_out);
 int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
                                const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c,
                                double alpha, int32_t n_mh_steps, uint32_t stage);                      /* comm[0] = Σ accept */

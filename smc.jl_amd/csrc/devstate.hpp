@@ -45,20 +45,34 @@ struct RunParams {             // smc() kwargs, uploaded once per run
     int n_phi;
     int resampling_method;
     int use_fixed_schedule;
-    int n_cand;
+    int max_stages;
+    int store_history;
+    int pad0;
     double threshold;          // threshold_ratio * n_parts (:203)
     double alpha, target;
     double tempering_target;
     double pw, logp_old;       // tempered_update_prior_weight, log_prob_old_data
-    int max_stages;
-    int store_history;
+    double phi_rtol;           // bracket width (relative) at which the adaptive-ϕ root is accepted
+};
+
+// Adaptive-ϕ solver state (src/helpers.jl:9-56).  Two copies are kept (ping-pong by pass parity): every block of
+// pass p reads copy (p-1)&1, all blocks recompute the same decision, block 0 alone writes copy p&1.
+struct Solver {
+    int mode;
+    int n_valid;               // valid entries of cand[]
+    int j;                     // 1-based index into the proposed fixed schedule (:129)
+    int unconverged;           // passes ran out before the bracket reached phi_rtol (diagnostic)
+    double phi_prop, ess_bar;
+    double lo, hi, glo, ghi;   // bracket with g(lo) >= 0 > g(hi), g = ESS(ϕ) - ESS_bar
+    double phi_n;
+    double cand[KC];
 };
 
 struct DevState {
     RunParams rp;
     // ---- loop scalars
     int stage;                 // i == cloud.stage_index
-    int j;                     // 1-based index into the proposed fixed schedule (:129)
+    int j;                     // 1-based index into the proposed fixed schedule
     int resampled_last;        // resampled_last_period
     int do_resample;           // this stage's selection decision (:435)
     int done;                  // ϕ_n reached 1 (or error)
@@ -71,18 +85,14 @@ struct DevState {
     double sumw, sumw2;        // Σ W̃, Σ W̃² at ϕ_n (unnormalised)
     double logz;               // running log-MDD
     double c, accept;          // cloud.c, cloud.accept
-    // ---- ϕ solver (helpers.jl:9-56)
-    int mode;
-    int n_valid;               // valid candidates in cand[]
-    int scan_exhausted;
-    double ess_bar;
-    double lo, hi, glo, ghi;
-    double cand[KC];
+    long long solver_passes;   // diagnostic: number of particle passes spent in the adaptive-ϕ solver
+    Solver sol[2];
     // ---- moments / proposal (smc_main.jl:457-469, mutation.jl:81)
     double shift[MAXD];        // centering used by the one-pass moment kernel (previous mean)
     double mean[MAXD];         // θ_bar
     double cov[MAXD * MAXD];   // R (row-major d x d)
     int n_blocks;
+    int max_db;                // largest block length
     int block_ptr[MAXD + 1];
     int blocks_free[MAXD];     // positions in the free-parameter list, block order
     int blocks_all[MAXD];      // parameter indices, block order

@@ -2,8 +2,12 @@
 //
 // Cloud layout in HBM: column-major n x R doubles per buffer (two ping-pong buffers), i.e. one contiguous
 // array per parameter / metadata column -> every kernel reads and writes fully coalesced 8-byte lanes.
-// All stage decisions are taken on the device from DevState, so a stage is a fixed launch sequence.
-// Reductions are deterministic: wavefront butterfly -> LDS -> per-block partials -> fixed-order final sum.
+// All stage decisions are taken on the device from DevState, so a stage is a fixed launch sequence:
+//   k_stage_begin -> P x k_pass<KC,false> -> k_pass<1,true> -> k_post_correct -> k_scan_weights ->
+//   k_resample_gather -> k_moments -> k_prepare_mutation -> k_mutate*
+// Reductions are deterministic: wavefront butterfly -> LDS -> per-block partials -> fixed-order final sum,
+// and the final sum + decision of pass p is recomputed by every block in the prologue of pass p+1 (no
+// single-block "decide" launches, no atomics, no grid barriers).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -67,21 +71,30 @@ __device__ inline double block_reduce_many(double (&a)[M], double *red) {
     return tot;
 }
 
-// Fixed-order sum of per-block partials: partials[b * m + idx], b < nb.  Called by all threads of a 1-block
-// kernel; returns the total for idx = threadIdx.x (< m) in every thread with threadIdx.x < m.
-// Requires blockDim.x >= m;  uses 4 interleaved slices when blockDim.x >= 4 m.
+// Fixed-order sum of per-block partials partials[b * m + idx], b < nb, by one whole block: thread (s, idx) adds the
+// blocks b = s (mod S), S = blockDim.x / m slices, four independent loads in flight; slices are then combined in
+// slice order.  Result for idx = threadIdx.x (< m).  scratch: blockDim.x doubles.  Requires m <= blockDim.x.
 __device__ inline double final_sum(const double *partials, int nb, int m, double *scratch) {
-    const int t = threadIdx.x;
-    const int slices = (blockDim.x >= 4 * m) ? 4 : 1;
+    const int t = threadIdx.x, S = blockDim.x / m;
     const int idx = t % m, s = t / m;
-    double acc = 0.0;
-    if (s < slices)
-        for (int b = s; b < nb; b += slices) acc += partials[(long long)b * m + idx];
-    if (slices == 1) return acc;
-    if (s < slices) scratch[s * m + idx] = acc;
+    if (s < S) {
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = 0.0;
+        int b = s;
+        for (; b + 7 * S < nb; b += 8 * S) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += partials[(long long)(b + q * S) * m + idx];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (b + q * S < nb) a[q] += partials[(long long)(b + q * S) * m + idx];
+        scratch[s * m + idx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     __syncthreads();
     double tot = 0.0;
-    if (t < m) tot = ((scratch[t] + scratch[m + t]) + scratch[2 * m + t]) + scratch[3 * m + t];
+    if (t < m)
+        for (int q = 0; q < S; ++q) tot += scratch[q * m + t];
     __syncthreads();
     return tot;
 }
@@ -89,9 +102,11 @@ __device__ inline double final_sum(const double *partials, int nb, int m, double
 // Fixed-order total of nb scalars using the whole block (nb can be ~1e5 mutation blocks).
 __device__ inline double final_sum1(const double *partials, int nb, double *scratch /* blockDim.x doubles */) {
     const int t = threadIdx.x, T = blockDim.x;
-    double acc = 0.0;
-    for (int b = t; b < nb; b += T) acc += partials[b];
-    scratch[t] = acc;
+    double a0 = 0.0, a1 = 0.0;
+    int b = t;
+    for (; b + T < nb; b += 2 * T) { a0 += partials[b]; a1 += partials[b + T]; }
+    if (b < nb) a0 += partials[b];
+    scratch[t] = a0 + a1;
     __syncthreads();
     for (int off = T >> 1; off >= 1; off >>= 1) {
         if (t < off) scratch[t] += scratch[t + off];
@@ -119,23 +134,156 @@ struct CloudPtrs {
 
 __device__ inline double *col(const CloudPtrs &c, int which, int column) { return c.buf[which] + (long long)column * c.n; }
 
+// ------------------------------------------------------------------------------------------------ ϕ solver
+// solve_adaptive_ϕ (src/helpers.jl:9-56) as a bracketing search driven by K-candidate ESS passes:
+//   SCAN    : candidates = ϕ_prop, schedule[j], schedule[j+1], ...  - the reference's `while g(ϕ_prop) >= 0` loop
+//             (helpers.jl:29-32), K entries per pass; the first candidate with g < 0 becomes ϕ_prop.
+//   SECTION : Roots.fzero(g, [ϕ_n1, ϕ_prop]) (helpers.jl:49) restated as a bracketing search whose K candidates per
+//             pass are 3 uniform points (guaranteed shrink) plus the secant estimate and geometric rings around it
+//             (2^-3 ... 2^-23 of the bracket): superlinear in practice, 4-5 passes to 1e-12 relative.
+//   FINAL   : ϕ_n known.
+constexpr double RING[6] = {0x1p-3, 0x1p-7, 0x1p-11, 0x1p-15, 0x1p-19, 0x1p-23};
+
+__device__ inline void section_candidates(Solver &S, double rtol) {
+    const double lo = S.lo, hi = S.hi, h = hi - lo;
+    int c = 0;
+    if (h > rtol * hi) {
+        double t = 0.5;
+        if (S.glo > S.ghi && S.glo < 1e300 && S.ghi > -1e300) t = S.glo / (S.glo - S.ghi);
+        const double xs = lo + h * t;
+        // ascending list: xs - h r0 < ... < xs - h r5 < xs < xs + h r5 < ... < xs + h r0, merged with lo + h k/4
+        double prev = lo;
+        int u = 1;   // next uniform point
+        for (int q = 0; q < 13; ++q) {
+            double x;
+            if (q < 6) x = xs - h * RING[q];
+            else if (q == 6) x = xs;
+            else x = xs + h * RING[12 - q];
+            while (u <= 3) {
+                const double xu = lo + h * (0.25 * u);
+                if (xu < x) { if (xu > prev && xu < hi && c < KC) { S.cand[c++] = xu; prev = xu; } ++u; }
+                else break;
+            }
+            if (x > prev && x < hi && c < KC) { S.cand[c++] = x; prev = x; }
+        }
+        for (; u <= 3; ++u) {
+            const double xu = lo + h * (0.25 * u);
+            if (xu > prev && xu < hi && c < KC) { S.cand[c++] = xu; prev = xu; }
+        }
+    }
+    if (c == 0) {   // bracket at the requested resolution (or no representable interior point)
+        S.phi_n = (fabs(S.glo) <= fabs(S.ghi)) ? lo : hi;
+        S.mode = MODE_FINAL;
+    } else {
+        S.n_valid = c;
+        S.mode = MODE_SECTION;
+    }
+}
+
+// one decision step from the candidate totals tot[0..KC) = Σv, tot[KC..2KC) = Σv² (single thread, S in LDS)
+__device__ inline void solver_decide(Solver &S, const double *tot, const double *sched, int n_phi, double rtol, int *err) {
+    double g[KC];
+    const int nv = S.n_valid;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) g[k] = tot[k] * tot[k] / tot[KC + k] - S.ess_bar;   // ESS(ϕ) = (Σv)²/Σv²
+    int m = -1;
+#pragma unroll
+    for (int k = KC - 1; k >= 0; --k)
+        if (k < nv && !(g[k] >= 0.0)) m = k;
+    if (S.mode == MODE_SCAN) {
+        // candidate 0 is the current ϕ_prop, candidate q > 0 is schedule[j + q - 1] (1-based j)
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (k < nv && (m < 0 || k < m) && S.cand[k] > S.lo) { S.lo = S.cand[k]; S.glo = g[k]; }
+        if (m >= 0) {
+            double gm = 0.0, cm = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k == m) { gm = g[k]; cm = S.cand[k]; }
+            if (gm != gm) { *err = SMCMI_ERR_NAN_ESS; return; }
+            S.phi_prop = cm; S.j += m; S.hi = cm; S.ghi = gm;
+        } else {
+            const int j_new = S.j + (nv - 1);
+            double clast = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k == nv - 1) clast = S.cand[k];
+            S.phi_prop = clast;
+            S.j = j_new;
+            if (j_new > n_phi) { S.phi_n = clast; S.mode = MODE_FINAL; return; }   // ϕ_prop == 1 and g(1) >= 0 (helpers.jl:51-53)
+            int c = 0;
+            for (int jj = j_new; jj <= n_phi && c < KC; ++jj) S.cand[c++] = sched[jj - 1];
+            S.n_valid = c;
+            S.j = j_new + 1;            // cand[0] is schedule[j_new]: keeps "cand[q] == schedule[j + q - 1]"
+            S.phi_prop = S.cand[0];
+            return;                     // stay in SCAN
+        }
+    } else {
+        if (m >= 0) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                if (k == m) { S.hi = S.cand[k]; S.ghi = g[k]; }
+                if (k == m - 1) { S.lo = S.cand[k]; S.glo = g[k]; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k == nv - 1) { S.lo = S.cand[k]; S.glo = g[k]; }
+        }
+    }
+    section_candidates(S, rtol);
+}
+
+// Prologue shared by every pass kernel: bring the solver state of pass p into LDS.  p == 0 reads copy 0 as written by
+// k_stage_begin; p > 0 reduces the partials of pass p-1 and takes the decision; block 0 publishes copy p&1.
+// Returns through *S; all threads must call.  scratch: TB doubles, tot: 2 KC doubles (LDS).
+__device__ inline void solver_prologue(DevState *st, const double *sched, const double *partials_prev, int nb, int p,
+                                       Solver *S, double *scratch, double *tot, int force_final) {
+    const int t = threadIdx.x;
+    constexpr int NW = sizeof(Solver) / sizeof(double);
+    static_assert(sizeof(Solver) % sizeof(double) == 0, "Solver must be a whole number of doubles");
+    const Solver *src = &st->sol[p == 0 ? 0 : ((p - 1) & 1)];
+    if (t < NW) reinterpret_cast<double *>(S)[t] = reinterpret_cast<const double *>(src)[t];
+    __syncthreads();
+    if (p == 0) return;
+    const int mode = S->mode;
+    if (mode == MODE_SCAN || mode == MODE_SECTION) {
+        const double v = final_sum(partials_prev, nb, 2 * KC, scratch);
+        if (t < 2 * KC) tot[t] = v;
+        __syncthreads();
+        if (t == 0) {
+            int err = 0;
+            solver_decide(*S, tot, sched, st->rp.n_phi, st->rp.phi_rtol, &err);
+            if (force_final && S->mode != MODE_FINAL && !err) {   // out of passes: accept the current bracket
+                if (S->mode == MODE_SECTION) { S->phi_n = (fabs(S->glo) <= fabs(S->ghi)) ? S->lo : S->hi; S->unconverged += 1; S->mode = MODE_FINAL; }
+                else err = SMCMI_ERR_BRACKET;                       // still scanning the schedule
+            }
+            if (err && blockIdx.x == 0) { st->err = err; st->done = 1; }
+            if (err) S->mode = MODE_IDLE;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && t < NW) reinterpret_cast<double *>(&st->sol[p & 1])[t] = reinterpret_cast<const double *>(S)[t];
+}
+
 // ------------------------------------------------------------------------------------------------ ESS passes
 // One pass over (loglh, old_loglh, weight): for K candidate ϕ accumulate Σ v and Σ v², v = W exp((ϕ_n1-ϕ)old + (ϕ-ϕ_n1)ℓ)
-// (src/helpers.jl:173-181, always the prior_weight == 0 formula: quirk Q4).  K = KC for the solver passes.
+// (src/helpers.jl:173-181, always the prior_weight == 0 formula: quirk Q4).
 // FINAL = true is the correction step at the chosen ϕ_n (src/smc_main.jl:401-420): the incremental weight uses the
 // prior-weight variant, the unnormalised weight W̃ = W w̃ is written back and w̃ goes to the history column.
 template <int K, bool FINAL>
-__global__ void __launch_bounds__(TB) k_ess_pass(CloudPtrs cl, DevState *st, double *partials, double *hist_w,
-                                                 long long hist_ld) {
+__global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const double *sched, const double *partials_prev,
+                                             double *partials_out, int nb_prev, int p, double *hist_w, long long hist_ld) {
     __shared__ double red[(TB / 64) * 2 * K];
-    __shared__ double s_c[K];
+    __shared__ double scratch[TB];
+    __shared__ double tot[2 * KC];
+    __shared__ Solver S;
     if (st->done) return;
-    const int mode = st->mode;
+    solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, FINAL ? 1 : 0);
+    const int mode = S.mode;
     if (FINAL ? (mode != MODE_FINAL) : (mode != MODE_SCAN && mode != MODE_SECTION)) return;
-    const int src = st->cur;
+    const int src = st->cur, nv = S.n_valid;
     const double phi_prev = st->phi_prev;
-    if (threadIdx.x < K) s_c[threadIdx.x] = FINAL ? st->phi_n : st->cand[threadIdx.x < st->n_valid ? threadIdx.x : st->n_valid - 1];
-    __syncthreads();
     const int R = cl.R;
     const double *loglh = col(cl, src, R - 5), *old = col(cl, src, R - 3);
     double *w = col(cl, src, R - 1);
@@ -151,7 +299,8 @@ __global__ void __launch_bounds__(TB) k_ess_pass(CloudPtrs cl, DevState *st, dou
         const double l = loglh[i], o = old[i], wi = w[i];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const double phi = s_c[k];
+            if (!FINAL && k >= nv) continue;
+            const double phi = FINAL ? S.phi_n : S.cand[k];
             double inc;
             if (!FINAL || pw == 0.0) inc = exp((phi_prev - phi) * o + (phi - phi_prev) * l);
             else if (pw == 1.0) inc = exp((phi - phi_prev) * l);
@@ -165,14 +314,23 @@ __global__ void __launch_bounds__(TB) k_ess_pass(CloudPtrs cl, DevState *st, dou
             }
         }
     }
-    const double tot = block_reduce_many<2 * K>(acc, red);
-    if (threadIdx.x < 2 * K) partials[(long long)blockIdx.x * (2 * K) + threadIdx.x] = tot;
+    const double total = block_reduce_many<2 * K>(acc, red);
+    if (threadIdx.x < 2 * K) partials_out[(long long)blockIdx.x * (2 * K) + threadIdx.x] = total;
+    if (!FINAL && blockIdx.x == 0 && threadIdx.x == 0) st->solver_passes += 1;
 }
 
-// ------------------------------------------------------------------------------------------------ ϕ solver
+// decision of the last solver pass without a correction (stand-alone smcmi_solve_phi)
+__global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double *sched, const double *partials_prev, int nb_prev, int p) {
+    __shared__ double scratch[TB];
+    __shared__ double tot[2 * KC];
+    __shared__ Solver S;
+    if (st->done) return;
+    solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, 1);
+}
+
 // Stage begin (src/smc_main.jl:378-396 + src/helpers.jl:14-20): bump the stage index, fold the previous
 // mutation's acceptance sums into cloud.accept, flip the cloud buffer after a resample, pick ϕ_n from the fixed
-// schedule or arm the adaptive solver with its first candidates.
+// schedule or arm the adaptive solver with its first candidates (solver copy 0).
 __global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
                                                     int acc_nb, Records rec) {
     __shared__ double scratch[TB];
@@ -181,143 +339,97 @@ __global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *
     double asum = 0.0;
     if (acc_nb > 0) asum = final_sum1(acc_partials, acc_nb, scratch);
     if (threadIdx.x != 0) return;
-    if (acc_nb > 0 && st->stage > 1) {
-        st->accept = asum / (double)st->rp.n_parts;
-        rec.accept[st->stage - 1] = st->accept;
+    const int stage0 = st->stage, rs = st->do_resample, n_phi = st->rp.n_phi, fixed = st->rp.use_fixed_schedule;
+    const int max_stages = st->rp.max_stages, rl = st->resampled_last, j = st->j;
+    const double phi_n = st->phi_n, phi_prop = st->phi_prop, ess_prev = st->ess_prev, target = st->rp.tempering_target;
+    const double N = (double)st->rp.n_parts;
+    if (acc_nb > 0 && stage0 > 1) {
+        const double a = asum / N;
+        st->accept = a;
+        rec.accept[stage0 - 1] = a;
     }
-    if (st->do_resample) { st->cur ^= 1; st->do_resample = 0; }
-    if (st->phi_n >= 1.0) { st->done = 1; return; }
-    const int i = st->stage + 1;
-    if (i > st->rp.max_stages) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; return; }
+    if (rs) { st->cur ^= 1; st->do_resample = 0; }
+    if (phi_n >= 1.0) { st->done = 1; return; }
+    const int i = stage0 + 1;
+    if (i > max_stages) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; return; }
     st->stage = i;
-    st->phi_prev = st->phi_n;
-    if (st->rp.use_fixed_schedule) {
-        st->phi_n = sched[i - 1];
-        st->mode = MODE_FINAL;
+    st->phi_prev = phi_n;
+    Solver &S = st->sol[0];
+    S.unconverged = 0;
+    if (fixed) {
+        const double ph = sched[i - 1];
+        st->phi_n = ph;
+        S.phi_n = ph; S.mode = MODE_FINAL; S.j = j; S.phi_prop = phi_prop; S.n_valid = 0;
         return;
     }
     double ess_now;   // ESS of the current weights = ESS(ϕ_n1)
-    if (st->resampled_last) { st->ess_bar = st->rp.tempering_target * (double)st->rp.n_parts; st->resampled_last = 0; ess_now = (double)st->rp.n_parts; }
-    else { st->ess_bar = st->rp.tempering_target * st->ess_prev; ess_now = st->ess_prev; }
-    st->lo = st->phi_prev;
-    st->glo = ess_now - st->ess_bar;
+    if (rl) { S.ess_bar = target * N; st->resampled_last = 0; ess_now = N; }
+    else { S.ess_bar = target * ess_prev; ess_now = ess_prev; }
+    S.lo = phi_n;
+    S.glo = ess_now - S.ess_bar;
+    S.hi = phi_prop; S.ghi = 0.0;
+    S.j = j; S.phi_prop = phi_prop;
     // scan candidates: current ϕ_prop, then schedule[j], schedule[j+1], ... (1-based j; helpers.jl:29-32)
-    const int K = st->rp.n_cand, n_phi = st->rp.n_phi;
     int nv = 0;
-    st->cand[nv++] = st->phi_prop;
-    for (int jj = st->j; jj <= n_phi && nv < K; ++jj) st->cand[nv++] = sched[jj - 1];
-    st->n_valid = nv;
-    st->mode = MODE_SCAN;
-}
-
-// After a solver pass: reduce the block partials and move the bracket (helpers.jl:29-32 scan, :49 root solve
-// restated as K-section to floating-point resolution).
-__global__ void __launch_bounds__(TB) k_phi_decide(DevState *st, const double *sched, const double *partials, int nb) {
-    __shared__ double scratch[4 * 2 * KC];
-    __shared__ double g[KC];
-    if (st->done) return;
-    const int mode = st->mode;
-    if (mode != MODE_SCAN && mode != MODE_SECTION) return;
-    const double tot = final_sum(partials, nb, 2 * KC, scratch);
-    if (threadIdx.x < 2 * KC) scratch[threadIdx.x] = tot;
-    __syncthreads();
-    if (threadIdx.x < KC) {
-        const double s1 = scratch[threadIdx.x], s2 = scratch[KC + threadIdx.x];
-        g[threadIdx.x] = s1 * s1 / s2 - st->ess_bar;   // ESS(ϕ) = (Σv)²/Σv²
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const int nv = st->n_valid, K = st->rp.n_cand, n_phi = st->rp.n_phi;
-    if (mode == MODE_SCAN) {
-        // first candidate with g < 0 ends the reference's while loop; candidate m>0 is schedule[j+m-1]
-        int m = -1;
-        for (int k = 0; k < nv; ++k) {
-            if (!(g[k] >= 0.0)) { m = k; break; }
-            if (g[k] >= 0.0 && st->cand[k] > st->lo) { st->lo = st->cand[k]; st->glo = g[k]; }
-        }
-        if (m >= 0) {
-            st->phi_prop = st->cand[m];
-            st->j += m;
-            if (isnan(g[m])) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; return; }
-            st->hi = st->cand[m]; st->ghi = g[m];
-            st->mode = MODE_SECTION;
-        } else {
-            // all tested candidates keep ESS above target
-            const int j_new = st->j + (nv - 1);
-            st->phi_prop = st->cand[nv - 1];
-            st->j = j_new;
-            if (j_new > n_phi) {              // schedule exhausted: ϕ_prop == 1 and g(1) >= 0 -> ϕ_n = 1 (helpers.jl:51-53)
-                st->phi_n = st->phi_prop;
-                st->mode = MODE_FINAL;
-                return;
-            }
-            int c = 0;                         // continue the scan with the next chunk (current ϕ_prop already known >= 0)
-            for (int jj = j_new; jj <= n_phi && c < K; ++jj) st->cand[c++] = sched[jj - 1];
-            st->n_valid = c;
-            st->j = j_new + 1;                 // cand[0] is schedule[j_new]: keep "cand[m] == schedule[j + m - 1]"
-            st->phi_prop = st->cand[0];
-            return;
-        }
-    } else {
-        // K-section: candidates are increasing interior points of (lo, hi)
-        int m = -1;
-        for (int k = 0; k < nv; ++k) {
-            if (!(g[k] >= 0.0)) { m = k; break; }
-        }
-        if (m >= 0) { st->hi = st->cand[m]; st->ghi = g[m]; if (m > 0) { st->lo = st->cand[m - 1]; st->glo = g[m - 1]; } }
-        else if (nv > 0) { st->lo = st->cand[nv - 1]; st->glo = g[nv - 1]; }
-    }
-    // next candidates or convergence
-    const double lo = st->lo, hi = st->hi;
-    int c = 0;
-    double prev = lo;
-    for (int k = 1; k <= K; ++k) {
-        const double x = lo + (hi - lo) * ((double)k / (double)(K + 1));
-        if (x > prev && x < hi) { st->cand[c++] = x; prev = x; }
-    }
-    if (c == 0) {   // no representable point strictly inside: root at floating-point resolution
-        st->phi_n = (fabs(st->glo) <= fabs(st->ghi)) ? lo : hi;
-        st->mode = MODE_FINAL;
-    } else {
-        st->n_valid = c;
-        st->mode = MODE_SECTION;
-    }
+    S.cand[nv++] = phi_prop;
+    for (int jj = j; jj <= n_phi && nv < KC; ++jj) S.cand[nv++] = sched[jj - 1];
+    S.n_valid = nv;
+    S.mode = MODE_SCAN;
 }
 
 // After the correction pass: ESS, log-MDD increment, resample decision, step-size adaptation
-// (src/smc_main.jl:427-455, src/particle.jl:362-366).  Also the exclusive prefix of the per-block weight sums
-// for the resampling scan.
+// (src/smc_main.jl:427-455, src/particle.jl:362-366); copies the solver's (ϕ_n, j, ϕ_prop) back to the loop scalars and,
+// on resample stages, forms the exclusive prefix of the per-block weight sums for the resampling scan.
 __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double *partials, int nb, double *chunk_off,
-                                                     Records rec) {
-    __shared__ double scratch[4 * 2];
+                                                     Records rec, int sol_slot) {
+    __shared__ double scratch[TB];
+    __shared__ double s_tot[2];
+    __shared__ int s_rs;
     if (st->done) return;
-    if (st->mode != MODE_FINAL) {     // the fixed number of solver passes did not reach floating-point resolution
+    const Solver &S = st->sol[sol_slot];
+    if (S.mode != MODE_FINAL) {       // cannot happen unless a pass kernel flagged an error
         if (threadIdx.x == 0) { st->err = SMCMI_ERR_BRACKET; st->done = 1; }
         return;
     }
-    const double tot = final_sum(partials, nb, 2, scratch);
-    if (threadIdx.x < 2) scratch[threadIdx.x] = tot;
+    const double v = final_sum(partials, nb, 2, scratch);
+    if (threadIdx.x < 2) s_tot[threadIdx.x] = v;
+    if (threadIdx.x == 0) s_rs = 0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const double s1 = scratch[0], s2 = scratch[1], N = (double)st->rp.n_parts;
-    const double ess = s1 * s1 / s2;
-    const int i = st->stage;
-    st->sumw = s1; st->sumw2 = s2; st->ess = ess; st->ess_prev = ess;
-    st->mode = MODE_IDLE;
-    rec.phi[i - 1] = st->phi_n;
-    rec.ess[i - 1] = ess;
-    if (isnan(ess)) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; return; }     // check_nan_ess, helpers.jl:270-305
-    st->logz += log(s1 / N);
-    const int rs = ess < st->rp.threshold;
-    st->do_resample = rs;
-    rec.resampled[i - 1] = rs;
-    if (rs) { st->resamples += 1; st->resampled_last = 1; }
-    const double a = st->accept, t = st->rp.target;
-    st->c = st->c * (0.95 + 0.10 * exp(16.0 * (a - t)) / (1.0 + exp(16.0 * (a - t))));
-    rec.c[i - 1] = st->c;
-    if (rs && chunk_off) {
-        double run = 0.0;
-        for (int b = 0; b < nb; ++b) { chunk_off[b] = run; run += partials[2 * (long long)b]; }
+    if (threadIdx.x == 0) {
+        const double s1 = s_tot[0], s2 = s_tot[1], N = (double)st->rp.n_parts;
+        const double ess = s1 * s1 / s2, a = st->accept, tg = st->rp.target, c0 = st->c, thr = st->rp.threshold;
+        const double phi_n = S.phi_n, phi_prop = S.phi_prop, logz = st->logz;
+        const int i = st->stage, jj = S.j;
+        st->phi_n = phi_n; st->phi_prop = phi_prop; st->j = jj;
+        st->sumw = s1; st->sumw2 = s2; st->ess = ess; st->ess_prev = ess;
+        rec.phi[i - 1] = phi_n;
+        rec.ess[i - 1] = ess;
+        if (isnan(ess)) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; }     // check_nan_ess, helpers.jl:270-305
+        else {
+            st->logz = logz + log(s1 / N);
+            const int rs = ess < thr;
+            st->do_resample = rs;
+            rec.resampled[i - 1] = rs;
+            if (rs) { st->resamples += 1; st->resampled_last = 1; }
+            const double c1 = c0 * (0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))));
+            st->c = c1;
+            rec.c[i - 1] = c1;
+            s_rs = rs;
+        }
+    }
+    __syncthreads();
+    if (s_rs && chunk_off) {
+        // exclusive prefix of partials[2 b] in block order: 256 threads x 4 blocks each, then a sequential carry
+        const int t = threadIdx.x;
+        double loc[4], run = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; loc[q] = run; run += (b < nb) ? partials[2 * (long long)b] : 0.0; }
+        scratch[t] = run;
+        __syncthreads();
+        if (t == 0) { double carry = 0.0; for (int q = 0; q < TB; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; if (b < nb) chunk_off[b] = scratch[t] + loc[q]; }
     }
 }
 
@@ -342,9 +454,8 @@ __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevStat
         for (int k = 0; k < IPT; ++k) { v[k] = (i0 + k < end) ? w[i0 + k] : 0.0; run += v[k]; v[k] = run; }
         s_tot[threadIdx.x] = run;
         __syncthreads();
-        // Hillis-Steele inclusive scan of the 256 thread totals
-        for (int off = 1; off < TB; off <<= 1) {
-            double add = (threadIdx.x >= off) ? s_tot[threadIdx.x - off] : 0.0;
+        for (int off = 1; off < TB; off <<= 1) {   // Hillis-Steele inclusive scan of the 256 thread totals
+            const double add = (threadIdx.x >= off) ? s_tot[threadIdx.x - off] : 0.0;
             __syncthreads();
             s_tot[threadIdx.x] += add;
             __syncthreads();
@@ -358,47 +469,40 @@ __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevStat
     }
 }
 
-// Ancestor of output slot k: first j with cum[j] > thr  (src/resample.jl:51-70 systematic walk, :33-41 multinomial
-// findfirst).  Fall-through (reference returns 0 / nothing; reachable only by round-off) clamps to the last index.
-__global__ void __launch_bounds__(TB) k_search_ancestors(const DevState *st, const double *cum, long long n_cum,
-                                                         long long slot0, long long n_slots, long long n_parts_total,
-                                                         int method, unsigned long long seed, unsigned stage,
-                                                         const double *offsets, long long *anc, int force) {
+// Selection for output slot k: ancestor = first j with cum[j] > thr (src/resample.jl:51-70 systematic walk, :33-41
+// multinomial findfirst; fall-through, which the reference turns into index 0 / nothing and is reachable only by
+// round-off, clamps to the last index), then cloud.particles = particles[new_inds, :] and reset_weights!
+// (src/smc_main.jl:440-442): the thread copies its ancestor's R-1 columns into the other cloud buffer and sets W = 1.
+// full != nullptr: rows come from an all-gathered n_cum x R cloud (multi-GPU) and go to the current buffer.
+__global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevState *st, const double *cum, long long n_cum,
+                                                        long long slot0, long long n_parts_total, int method,
+                                                        unsigned long long seed, unsigned stage, const double *offsets,
+                                                        long long *anc, const double *full, int force) {
     if (!force && (st->done || !st->do_resample)) return;
     const long long k = (long long)blockIdx.x * TB + threadIdx.x;
-    if (k >= n_slots) return;
+    if (k >= cl.n) return;
     const long long slot = slot0 + k;
     if (!force) stage = (unsigned)st->stage;
-    double thr;
+    double ua, ub;
     if (method == SMCMI_RESAMPLE_MULTINOMIAL) {
-        double ua, ub;
         if (offsets) ua = offsets[slot];
         else uniform_pair(seed, (unsigned long long)slot, stage, rng_tag(P_RES, 0, 0), ua, ub);
-        thr = ua;
     } else {
-        double ua, ub;
         if (offsets) ua = offsets[0];
         else uniform_pair(seed, 0ull, stage, rng_tag(P_RES, 0, 0), ua, ub);
-        thr = ((double)slot + ua) / (double)n_parts_total;
+        ua = ((double)slot + ua) / (double)n_parts_total;       // (i - 1 + offset) / n_parts
     }
     long long lo = 0, hi = n_cum;   // upper_bound: first index with cum > thr
     while (lo < hi) {
         const long long mid = (lo + hi) >> 1;
-        if (cum[mid] > thr) hi = mid; else lo = mid + 1;
+        if (cum[mid] > ua) hi = mid; else lo = mid + 1;
     }
-    anc[k] = lo < n_cum ? lo : n_cum - 1;
-}
-
-// cloud.particles = particles[new_inds, :]; reset_weights! (src/smc_main.jl:440-442).  Column-wise gather:
-// coalesced writes, sorted (systematic) or random (multinomial) indexed reads.  grid.y = column.
-__global__ void __launch_bounds__(TB) k_gather(CloudPtrs cl, const DevState *st, const long long *anc, int force) {
-    if (!force && (st->done || !st->do_resample)) return;
-    const long long k = (long long)blockIdx.x * TB + threadIdx.x;
-    if (k >= cl.n) return;
-    const int c = blockIdx.y, src = st->cur, dst = src ^ 1;
-    double *out = col(cl, dst, c);
-    if (c == cl.R - 1) { out[k] = 1.0; return; }
-    out[k] = col(cl, src, c)[anc[k]];
+    const long long a = lo < n_cum ? lo : n_cum - 1;
+    if (anc) anc[k] = a;
+    const int src = st->cur, dst = full ? src : (src ^ 1), R = cl.R;
+    for (int c = 0; c < R - 1; ++c)
+        col(cl, dst, c)[k] = full ? full[(long long)c * n_cum + a] : col(cl, src, c)[a];
+    col(cl, dst, R - 1)[k] = 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------ moments
@@ -491,20 +595,28 @@ __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, doub
     }
 }
 
-// Fixed-order reduction of the moment partials: totals[p] for the (d+1)(d+2)/2 pairs.  grid = ceil(npairs / 64).
-__global__ void __launch_bounds__(TB) k_moments_reduce(const DevState *st, const double *partials, int nb, int npairs,
-                                                       double *totals, int standalone) {
-    __shared__ double scratch[4 * 64];
+// Fixed-order reduction of the moment partials: totals[p] for the (d+1)(d+2)/2 pairs, 1024 threads per block:
+// thread (s, idx) sums blocks b = s (mod 16) of pair p0 + idx; grid = ceil(npairs / 64).
+__global__ void __launch_bounds__(1024) k_moments_reduce(const DevState *st, const double *partials, int nb, int npairs,
+                                                         double *totals, int standalone) {
+    __shared__ double scratch[1024];
     if (!standalone && st->done) return;
     const int p0 = blockIdx.x * 64, m = (npairs - p0) < 64 ? (npairs - p0) : 64;
-    // view: partials[b * npairs + p0 + idx]
     const int t = threadIdx.x, idx = t % 64, s = t / 64;
-    double acc = 0.0;
-    if (idx < m)
-        for (int b = s; b < nb; b += 4) acc += partials[(long long)b * npairs + p0 + idx];
-    scratch[s * 64 + idx] = acc;
+    double a0 = 0.0, a1 = 0.0;
+    if (idx < m) {
+        int b = s;
+        for (; b + 16 < nb; b += 32) { a0 += partials[(long long)b * npairs + p0 + idx]; a1 += partials[(long long)(b + 16) * npairs + p0 + idx]; }
+        if (b < nb) a0 += partials[(long long)b * npairs + p0 + idx];
+    }
+    scratch[s * 64 + idx] = a0 + a1;
     __syncthreads();
-    if (t < m) totals[p0 + t] = ((scratch[t] + scratch[64 + t]) + scratch[128 + t]) + scratch[192 + t];
+    if (t < m) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += scratch[q * 64 + t];
+        totals[p0 + t] = tot;
+    }
 }
 
 // totals of the augmented pair sums -> θ_bar (st->mean), R (st->cov); the shift moves to the new mean
@@ -569,13 +681,15 @@ __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 // θ_bar, R from the totals; free subset + symmetrisation (src/smc_main.jl:457-465); random blocks
 // (generate_free_blocks/all_blocks, src/helpers.jl:215-260, Fisher-Yates on Philox); then per block the scaled
 // covariance c²Σ_b and its Cholesky factor - done ONCE per stage instead of per particle (src/mutation.jl:81,
-// src/helpers.jl:90-94,135-155).  One block of 64 threads.
+// src/helpers.jl:90-94,135-155).  One block of 64 threads; all matrix work happens in LDS.
 __global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const ModelDev *md, const double *totals,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
                                                          int standalone) {
     __shared__ double A[MAXD * MAXD];
+    __shared__ double Ls[MAXD * MAXD];
     __shared__ double sig_f[MAXD * MAXD];
     __shared__ double mu_f[MAXD];
+    __shared__ int bfree[MAXD], bptr[MAXD + 1];
     __shared__ int s_fail;
     if (!standalone && st->done) return;
     const int d = md->d, nf = md->n_free, t = threadIdx.x;
@@ -588,73 +702,78 @@ __global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const Mod
         sig_f[e] = (st->cov[a * d + b] + st->cov[b * d + a]) / 2.0;
     }
     for (int a = t; a < nf; a += 64) mu_f[a] = st->mean[md->free_inds[a]];
-    __syncthreads();
-    if (gen_blocks && t == 0) {
-        const int nb = st->rp.n_blocks;
-        int *bf = st->blocks_free;
-        for (int i = 0; i < nf; ++i) bf[i] = i;
-        for (int i = nf - 1; i >= 1; --i) {
-            double ua, ub;
-            uniform_pair(seed, 0ull, (unsigned)st->stage, rng_tag(P_BLK, (unsigned)i, 0), ua, ub);
-            int jx = (int)(ua * (double)(i + 1));
-            if (jx > i) jx = i;
-            const int tmp = bf[i]; bf[i] = bf[jx]; bf[jx] = tmp;
+    const int nb = gen_blocks ? st->rp.n_blocks : st->n_blocks;
+    if (gen_blocks) {
+        if (t == 0) {
+            const unsigned stage = (unsigned)st->stage;
+            for (int i = 0; i < nf; ++i) bfree[i] = i;
+            for (int i = nf - 1; i >= 1; --i) {
+                double ua, ub;
+                uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i, 0), ua, ub);
+                int jx = (int)(ua * (double)(i + 1));
+                if (jx > i) jx = i;
+                const int tmp = bfree[i]; bfree[i] = bfree[jx]; bfree[jx] = tmp;
+            }
+            const int sub = (nf + nb - 1) / nb;
+            for (int b = 0; b < nb; ++b) bptr[b] = b * sub;
+            bptr[nb] = nf;
         }
-        const int sub = (nf + nb - 1) / nb;
-        for (int b = 0; b < nb; ++b) st->block_ptr[b] = b * sub;
-        st->block_ptr[nb] = nf;
-        st->n_blocks = nb;
+    } else {
+        for (int i = t; i < nf; i += 64) bfree[i] = st->blocks_free[i];
+        for (int b = t; b <= nb; b += 64) bptr[b] = st->block_ptr[b];
     }
     __syncthreads();
-    const int nb = st->n_blocks;
     const double c = st->c;
-    if (t == 0) {
-        int off = 0;
-        for (int b = 0; b < nb; ++b) { st->l_off[b] = off; const int db = st->block_ptr[b + 1] - st->block_ptr[b]; off += db * db; }
-    }
     for (int i = t; i < nf; i += 64) {
-        const int f = st->blocks_free[i];
+        const int f = bfree[i];
+        st->blocks_free[i] = f;
         st->blocks_all[i] = md->free_inds[f];
         st->mu_b[i] = mu_f[f];
         st->sd_draw[i] = sqrt(c * c * sig_f[f * nf + f]);
         st->sd_dens[i] = sqrt(sig_f[f * nf + f]);
     }
-    __syncthreads();
+    int off = 0, max_db = 0;
     for (int b = 0; b < nb; ++b) {
-        const int p0 = st->block_ptr[b], db = st->block_ptr[b + 1] - p0;
-        double *L = st->L + st->l_off[b];
+        const int p0 = bptr[b], db = bptr[b + 1] - p0;
+        if (db > max_db) max_db = db;
         for (int e = t; e < db * db; e += 64) {
-            const int fa = st->blocks_free[p0 + e / db], fb = st->blocks_free[p0 + e % db];
-            A[e] = c * c * sig_f[fa * nf + fb];
-            L[e] = 0.0;
+            A[e] = c * c * sig_f[bfree[p0 + e / db] * nf + bfree[p0 + e % db]];
+            Ls[e] = 0.0;
         }
         __syncthreads();
-        // right-looking Cholesky, lane i owns row i; same operation order as the textbook column loop
+        // column Cholesky, lane i owns row i; same operation order as the textbook loop of the oracle
         for (int jx = 0; jx < db; ++jx) {
             if (t == jx) {
                 double s = A[jx * db + jx];
-                for (int k = 0; k < jx; ++k) s -= L[jx * db + k] * L[jx * db + k];
+                for (int k = 0; k < jx; ++k) s -= Ls[jx * db + k] * Ls[jx * db + k];
                 if (!(s > 0.0)) s_fail = 1;
-                L[jx * db + jx] = sqrt(s);
+                Ls[jx * db + jx] = sqrt(s);
             }
             __syncthreads();
             if (s_fail) break;
             if (t > jx && t < db) {
                 double s = A[t * db + jx];
-                for (int k = 0; k < jx; ++k) s -= L[t * db + k] * L[jx * db + k];
-                L[t * db + jx] = s / L[jx * db + jx];
+                for (int k = 0; k < jx; ++k) s -= Ls[t * db + k] * Ls[jx * db + k];
+                Ls[t * db + jx] = s / Ls[jx * db + jx];
             }
             __syncthreads();
         }
+        if (s_fail) break;
+        for (int e = t; e < db * db; e += 64) st->L[off + e] = Ls[e];
         if (t == 0) {
             double ld = 0.0;
-            for (int i = 0; i < db; ++i) ld += log(L[i * db + i]);
+            for (int i = 0; i < db; ++i) ld += log(Ls[i * db + i]);
             st->logdet[b] = 2.0 * ld;
+            st->l_off[b] = off;
         }
+        off += db * db;
         __syncthreads();
-        if (s_fail) break;
     }
+    if (t <= nb) st->block_ptr[t] = bptr[t];
+    for (int b = 64 + t; b <= nb; b += 64) st->block_ptr[b] = bptr[b];
     if (t == 0) {
+        st->n_blocks = nb;
+        st->max_db = max_db;
         if (s_fail) { st->err = SMCMI_ERR_POSDEF; st->done = 1; }   // PosDefException aborts the run (mutation.jl:81)
         if (!standalone) {
             st->mut_c = c; st->mut_alpha = st->rp.alpha; st->mut_phi = st->phi_n; st->mut_steps = st->rp.n_mh_steps;
@@ -840,6 +959,186 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     // Σ accept over the block (update_acceptance_rate!, src/particle.jl:466-468), fixed order
     double a1[1] = {acc_val};
     Butterfly<0, 32>::run(a1, tid & 63);
+    if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < T / 64; ++w) s += red[w];
+        acc_partials[blockIdx.x] = s;
+    }
+}
+
+// Register-resident mutation for blocks of at most DB parameters (MODE 0 of k_mutate, same arithmetic in the same
+// order): the block's z / draw / solve vectors live in VGPRs with compile-time indices, the block factor L and the
+// other per-block constants are staged once into LDS (uniform-address reads), only the parameter vector itself sits in
+// per-thread LDS columns because block membership is a run-time index and the likelihood reads it by position.
+template <int DB>
+__global__ void __launch_bounds__(256) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
+                                                   double *acc_partials, int standalone) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (!standalone && st->done) return;
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int d = md->d, nf = md->n_free;
+    double *th = sm;                                // θ [d][T]
+    double *Ls = th + (long long)d * T;             // [DB*DB] row-major with stride DB, identity-padded
+    double *mu_s = Ls + DB * DB;                    // [DB]
+    double *sdd_s = mu_s + DB, *sdn_s = sdd_s + DB; // [DB] each
+    double *red = sdn_s + DB;                       // [T/64]
+    int *ball_s = (int *)(red + 4);                 // [DB]
+    const long long i = (long long)blockIdx.x * T + tid;
+    const bool live = i < cl.n;
+    const int src = standalone ? st->cur : (st->cur ^ st->do_resample);
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    const unsigned stage = st->mut_stage;
+    const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
+    const int nb = st->n_blocks, n_steps = st->mut_steps;
+    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    if (live) {
+        for (int k = 0; k < d; ++k) th[k * T + tid] = col(cl, src, k)[i];
+        like = col(cl, src, d)[i]; lprior = col(cl, src, d + 1)[i]; like_prev = col(cl, src, d + 2)[i];
+    }
+    auto TH = [&](int k) { return th[k * T + tid]; };
+    for (int step = 0; step < n_steps; ++step) {
+        for (int b = 0; b < nb; ++b) {
+            const int p0 = st->block_ptr[b], db = st->block_ptr[b + 1] - p0;
+            if (nb > 1 || step == 0) {              // (re)stage this block's constants
+                __syncthreads();
+                const double *L = st->L + st->l_off[b];
+                for (int e = tid; e < DB * DB; e += T) {
+                    const int r = e / DB, cidx = e % DB;
+                    Ls[e] = (r < db && cidx < db) ? L[r * db + cidx] : (r == cidx ? 1.0 : 0.0);
+                }
+                for (int e = tid; e < DB; e += T) {
+                    const bool in = e < db;
+                    mu_s[e] = in ? st->mu_b[p0 + e] : 0.0;
+                    sdd_s[e] = in ? st->sd_draw[p0 + e] : 0.0;
+                    sdn_s[e] = in ? st->sd_dens[p0 + e] : 1.0;
+                    ball_s[e] = in ? st->blocks_all[p0 + e] : 0;
+                }
+                __syncthreads();
+            }
+            if (!live) continue;
+            const unsigned t = (unsigned)(step * nb + b);
+            double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
+            if (t == 0) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
+            else uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
+            // ---- mvnormal_mixture_draw (src/helpers.jl:87-100)
+            double uc, unext;
+            uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
+            double z[DB], sub[DB], dr[DB], v[DB];
+#pragma unroll
+            for (int e = 0; e < DB; e += 2) {
+                double z0 = 0.0, z1 = 0.0;
+                if (e < db) normal_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 1 + e / 2), z0, z1);
+                z[e] = z0;
+                if (e + 1 < DB) z[e + 1] = (e + 1 < db) ? z1 : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < DB; ++e) sub[e] = (e < db) ? th[ball_s[e] * T + tid] : 0.0;
+            const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
+            if (comp == 1) {
+#pragma unroll
+                for (int e = 0; e < DB; ++e) dr[e] = sub[e] + sdd_s[e] * z[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < DB; ++e) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k <= e; ++k) s += Ls[e * DB + k] * z[k];
+                    dr[e] = ((comp == 0) ? sub[e] : mu_s[e]) + s;
+                }
+            }
+            // ---- compute_proposal_densities (src/helpers.jl:128-164)
+            const double cst = (double)db * LOG2PI + st->logdet[b];
+            double q0, q1;
+            double zz2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < DB; ++e) zz2 += z[e] * z[e];
+            if (c_alpha == 1.0 && -(cst + zz2) / 2.0 > -600.0) {
+                // α = 1: q0 = q1 = log N(θ_b; ϑ_b, c²Σ) bit for bit (the quadratic form is sign-symmetric), the other two
+                // mixture terms carry weight 0, so q0 - q1 == 0 unless exp() underflows (log-density < -745, the
+                // reference then rejects through NaN); |L⁻¹(θ_b-ϑ_b)|² = Σz² up to rounding, far from that edge here.
+                q0 = q1 = 0.0;
+            } else {
+            double quad = 0.0;
+#pragma unroll
+            for (int e = 0; e < DB; ++e) {            // L⁻¹(θ_b - ϑ_b): forward == reverse density
+                double s = sub[e] - dr[e];
+#pragma unroll
+                for (int k = 0; k < e; ++k) s -= Ls[e * DB + k] * v[k];
+                v[e] = s / Ls[e * DB + e];
+                quad += v[e] * v[e];
+            }
+            q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;
+            double ind_pdf = 1.0;
+#pragma unroll
+            for (int e = 0; e < DB; ++e) {
+                if (e < db) {
+                    const double sii = sdn_s[e];
+                    const double zz = (sub[e] - dr[e]) / sii;
+                    ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * zz * zz);
+                }
+            }
+            q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+            q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+            double quad_s = 0.0, quad_d = 0.0;
+#pragma unroll
+            for (int e = 0; e < DB; ++e) {            // log N(θ_b; θ̄_b, c²Σ)
+                double s = sub[e] - mu_s[e];
+#pragma unroll
+                for (int k = 0; k < e; ++k) s -= Ls[e * DB + k] * v[k];
+                v[e] = s / Ls[e * DB + e];
+                quad_s += v[e] * v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < DB; ++e) {            // log N(ϑ_b; θ̄_b, c²Σ)
+                double s = dr[e] - mu_s[e];
+#pragma unroll
+                for (int k = 0; k < e; ++k) s -= Ls[e * DB + k] * v[k];
+                v[e] = s / Ls[e * DB + e];
+                quad_d += v[e] * v[e];
+            }
+            q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
+            q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
+            q0 = log(q0);
+            q1 = log(q1);
+            if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
+            }
+            // ---- para_new: the proposal temporarily replaces the block inside th
+#pragma unroll
+            for (int e = 0; e < DB; ++e)
+                if (e < db) th[ball_s[e] * T + tid] = dr[e];
+            double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
+            if (in_bounds(*md, TH)) {
+                prior_new = logprior(*md, TH);
+                like_new = loglik(md->lik[0], d, TH);
+                if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
+                like_old_data = (md->lik[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik(md->lik[1], d, TH);
+            }
+            const double eta = exp(phi_n * (like_new - like) + (1.0 - phi_n) * (like_old_data - like_prev) +
+                                   (prior_new - lprior) + (q0 - q1));
+            if (step_prob < eta) {
+                like = like_new; lprior = prior_new; like_prev = like_old_data;
+                accept += (double)db;
+            } else {
+#pragma unroll
+                for (int e = 0; e < DB; ++e)
+                    if (e < db) th[ball_s[e] * T + tid] = sub[e];
+            }
+        }
+    }
+    double acc_val = 0.0;
+    if (live) {
+        for (int k = 0; k < d; ++k) col(cl, src, k)[i] = th[k * T + tid];
+        col(cl, src, d)[i] = like;
+        col(cl, src, d + 1)[i] = lprior;
+        col(cl, src, d + 2)[i] = like_prev;
+        acc_val = accept / (double)nf;                      // quirk Q2: normalised by n_free only
+        col(cl, src, d + 3)[i] = acc_val;
+    }
+    double a1[1] = {acc_val};
+    Butterfly<0, 32>::run(a1, tid & 63);
+    __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = a1[0];
     __syncthreads();
     if (tid == 0) {

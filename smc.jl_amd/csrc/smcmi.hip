@@ -51,9 +51,9 @@ struct smcmi_handle {
     double *d_sched = nullptr;
     int sched_len = 0;
     // scratch
-    int nb_e = 0, nb_m = 0, nb_mut = 0, mut_T = 0;
-    size_t mut_lds = 0, mom_lds = 0;
-    double *d_part_ess = nullptr, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
+    int nb_e = 0, nb_m = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
+    size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0;
+    double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
@@ -61,6 +61,8 @@ struct smcmi_handle {
     // host-callback split
     double *d_prop = nullptr, *d_prop_lp = nullptr, *d_prop_q = nullptr, *d_lik_new = nullptr, *d_lik_old = nullptr;
     int *d_acc_count = nullptr, *d_flag = nullptr;
+    double *d_cum_full = nullptr, *d_part_full = nullptr, *d_off_full = nullptr;
+    int nb_full = 0;
     int last_n_stages = 1;
     hipGraphExec_t graph_exec = nullptr;
     int graph_sig = 0;
@@ -97,6 +99,8 @@ static int err_from_state(int code) {
     }
 }
 
+static int set_mutate_attrs(smcmi_handle *h);
+
 // ------------------------------------------------------------------------------------------------ lifetime
 extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (!cfg || !out) return set_err(SMCMI_ERR_ARG, "null argument");
@@ -130,7 +134,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         dmalloc(&h->rec.resampled, ms))
         return SMCMI_ERR_HIP;
     h->nb_e = (int)std::min<long long>(1024, std::max<long long>(1, (n + 511) / 512));
-    h->nb_m = (int)std::min<long long>(1024, std::max<long long>(1, (n + MT - 1) / MT));
+    h->nb_m = (int)std::min<long long>(256, std::max<long long>(1, (n + MT - 1) / MT));
     // mutation block size: largest of 256/128/64 threads whose per-thread LDS vectors fit 64 KiB
     for (int T : {256, 128, 64}) {
         h->mut_T = T;
@@ -138,12 +142,19 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         if (h->mut_lds <= 64 * 1024) break;
     }
     h->nb_mut = (int)((n + h->mut_T - 1) / h->mut_T);
+    // register-resident variant: only θ lives in per-thread LDS columns
+    for (int T : {256, 128, 64}) {
+        h->reg_T = T;
+        h->reg_lds_base = (size_t)(h->d * T + 8) * sizeof(double);
+        if (h->reg_lds_base <= 48 * 1024) break;
+    }
+    h->nb_reg = (int)((n + h->reg_T - 1) / h->reg_T);
     h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;
     h->comm_cap = std::max<long long>(2 * KC, h->npairs) + 8;
-    if (dmalloc(&h->d_part_ess, (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) ||
+    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)h->nb_m * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, h->nb_mut) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -151,7 +162,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     }
     memset(&h->h_st, 0, sizeof(DevState));
     h->h_st.rp.n_parts = cfg->n_parts;
-    h->h_st.rp.n_cand = KC;
+    h->h_st.rp.phi_rtol = 1e-12;
     h->h_st.rp.max_stages = ms;
     h->h_st.stage = 1;
     h->h_st.c = 0.5;
@@ -166,6 +177,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
+    if (set_mutate_attrs(h)) return SMCMI_ERR_HIP;
     *out = h;
     return 0;
 }
@@ -176,10 +188,10 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
-                    h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess,
+                    h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
                     h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
-                    h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag};
+                    h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -321,6 +333,15 @@ static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
     return 0;
 }
 
+static const int DEFAULT_SOLVER_PASSES = 8;   // 1 schedule scan + bracketing passes (4-5 typical, see kernels.hpp)
+
+// P solver passes; pass p consumes the partials of pass p-1 in its prologue.  The correction pass that follows is pass P.
+static void enqueue_solver(smcmi_handle *h, int passes) {
+    for (int p = 0; p < passes; ++p)
+        k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(p + 1) & 1], h->d_part_ess[p & 1],
+                                                           h->nb_e, p, nullptr, 0);
+}
+
 extern "C" int smcmi_ess_at(smcmi_handle *h, const double *phis, int32_t k, double phi_prev, double *ess_out) {
     if (!h || !phis || !ess_out || k < 1) return set_err(SMCMI_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -329,26 +350,19 @@ extern "C" int smcmi_ess_at(smcmi_handle *h, const double *phis, int32_t k, doub
     std::vector<double> tot(2 * KC);
     for (int base = 0; base < k; base += KC) {
         const int nv = std::min(KC, k - base);
-        h->h_st.done = 0; h->h_st.mode = MODE_SECTION; h->h_st.phi_prev = phi_prev; h->h_st.n_valid = nv;
-        for (int q = 0; q < nv; ++q) h->h_st.cand[q] = phis[base + q];
+        Solver &S = h->h_st.sol[0];
+        h->h_st.done = 0; h->h_st.phi_prev = phi_prev;
+        S.mode = MODE_SECTION; S.n_valid = nv;
+        for (int q = 0; q < nv; ++q) S.cand[q] = phis[base + q];
         if (push_state(h)) return SMCMI_ERR_HIP;
-        k_ess_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_ess, nullptr, 0);
-        k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess, h->nb_e, 2 * KC, h->d_comm);
+        k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0);
+        k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess[0], h->nb_e, 2 * KC, h->d_comm);
         HIP_TRY(hipMemcpyAsync(tot.data(), h->d_comm, sizeof(double) * 2 * KC, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         for (int q = 0; q < nv; ++q) ess_out[base + q] = tot[q] * tot[q] / tot[KC + q];
     }
     h->h_st = saved;
     return push_state(h);
-}
-
-static const int DEFAULT_SOLVER_PASSES = 16;
-
-static void enqueue_solver(smcmi_handle *h, int passes) {
-    for (int p = 0; p < passes; ++p) {
-        k_ess_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_ess, nullptr, 0);
-        k_phi_decide<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_part_ess, h->nb_e);
-    }
 }
 
 extern "C" int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_phi, int32_t *j, double *phi_prop,
@@ -360,21 +374,23 @@ extern "C" int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_p
     DevState saved = h->h_st;
     DevState &s = h->h_st;
     s.done = 0; s.err = 0; s.do_resample = 0; s.stage = 1; s.rp.use_fixed_schedule = 0; s.rp.n_phi = n_phi;
-    s.rp.tempering_target = tempering_target; s.rp.n_cand = KC; s.phi_n = phi_prev; s.phi_prop = *phi_prop; s.j = *j;
-    s.resampled_last = *resampled_last; s.ess_prev = ess_prev; s.mode = MODE_IDLE;
+    s.rp.tempering_target = tempering_target; s.phi_n = phi_prev; s.phi_prop = *phi_prop; s.j = *j;
+    s.resampled_last = *resampled_last; s.ess_prev = ess_prev;
+    if (s.rp.phi_rtol <= 0.0) s.rp.phi_rtol = 1e-12;
     if (upload_sched(h, sched, n_phi) || push_state(h)) return SMCMI_ERR_HIP;
     k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, 0, h->rec);
-    const int passes = (n_phi + KC - 2) / (KC - 1) + 14;
+    // enough passes to walk the whole schedule in the worst case plus the bracketing passes
+    const int passes = (n_phi + KC - 2) / (KC - 1) + 28;
     enqueue_solver(h, passes);
+    k_solver_finish<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_part_ess[(passes + 1) & 1], h->nb_e, passes);
     if (pull_state(h)) return SMCMI_ERR_HIP;
-    const int mode = s.mode, err = s.err;
-    const double out_phi = s.phi_n, out_prop = s.phi_prop;
-    const int out_j = s.j, out_rl = s.resampled_last;
+    const Solver S = s.sol[passes & 1];
+    const int err = s.err, rl = s.resampled_last;
     h->h_st = saved;
     if (push_state(h)) return SMCMI_ERR_HIP;
     if (err) return err_from_state(err);
-    if (mode != MODE_FINAL) return err_from_state(SMCMI_ERR_BRACKET);
-    *phi_n = out_phi; *phi_prop = out_prop; *j = out_j; *resampled_last = out_rl;
+    if (S.mode != MODE_FINAL) return err_from_state(SMCMI_ERR_BRACKET);
+    *phi_n = S.phi_n; *phi_prop = S.phi_prop; *j = S.j; *resampled_last = rl;
     return 0;
 }
 
@@ -384,20 +400,20 @@ extern "C" int smcmi_correct(smcmi_handle *h, double phi_n, double phi_prev, dou
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (pull_state(h)) return SMCMI_ERR_HIP;
     DevState &s = h->h_st;
-    const double c_save = s.c, logz_save = s.logz;
-    const int resamples_save = s.resamples, rl_save = s.resampled_last, stage_save = s.stage;
-    s.done = 0; s.err = 0; s.mode = MODE_FINAL; s.phi_n = phi_n; s.phi_prev = phi_prev; s.rp.pw = prior_weight;
+    const DevState saved = s;
+    s.done = 0; s.err = 0; s.phi_n = phi_n; s.phi_prev = phi_prev; s.rp.pw = prior_weight;
     s.rp.logp_old = log_prob_old_data; s.rp.threshold = threshold_ratio * (double)s.rp.n_parts; s.logz = 0.0;
     s.stage = h->cfg.max_stages;   // records of a stand-alone call land in the last (scratch) slot
+    s.rp.store_history = 0;
+    s.sol[0].mode = MODE_FINAL; s.sol[0].phi_n = phi_n; s.sol[0].j = s.j; s.sol[0].phi_prop = s.phi_prop;
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_ess_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin, nullptr, 0);
-    k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec);
+    k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, nullptr, 0);
+    k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, 0);
     k_normalize_weights<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     out->ess = s.ess; out->sum_unnorm = s.sumw; out->logz_inc = s.logz; out->resample = s.do_resample;
     const int err = s.err;
-    s.c = c_save; s.logz = logz_save; s.resamples = resamples_save; s.resampled_last = rl_save; s.stage = stage_save;
-    s.do_resample = 0; s.done = 0; s.err = 0; s.mode = MODE_IDLE;
+    s = saved;
     if (push_state(h)) return SMCMI_ERR_HIP;
     return err_from_state(err);
 }
@@ -417,9 +433,8 @@ extern "C" int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, c
     k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
     k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
     k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1);
-    k_search_ancestors<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->d_st, h->d_cum, n, h->cfg.gid0, n, h->cfg.n_parts,
-                                                                          method, h->cfg.seed, stage, d_off, h->d_anc, 1);
-    k_gather<<<dim3((unsigned)((n + TB - 1) / TB), h->R), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_anc, 1);
+    k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, h->cfg.gid0, h->cfg.n_parts, method,
+                                                                         h->cfg.seed, stage, d_off, h->d_anc, nullptr, 1);
     k_flip<<<1, 1, 0, h->stream>>>(h->d_st);
     if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, h->d_anc, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -431,7 +446,7 @@ extern "C" int smcmi_moments(smcmi_handle *h, double *mean, double *cov) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int d = h->d;
     k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, nullptr, 0, 1);
-    k_moments_reduce<<<(h->npairs + 63) / 64, TB, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 1);
+    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 1);
     k_finalize_moments<<<1, 64, 0, h->stream>>>(h->d_st, h->d_totals, d);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     for (int a = 0; a < d; ++a) mean[a] = h->h_st.mean[a];
@@ -452,13 +467,51 @@ static int stage_blocks(smcmi_handle *h, const double *mu_free, const double *Si
         for (int b = 0; b < nf; ++b) s.cov[m.free_inds[a] * d + m.free_inds[b]] = Sigma_free[a * nf + b];
     }
     s.n_blocks = n_blocks;
+    int max_db = 0;
     for (int b = 0; b <= n_blocks; ++b) s.block_ptr[b] = block_ptr[b];
+    for (int b = 0; b < n_blocks; ++b) max_db = std::max(max_db, block_ptr[b + 1] - block_ptr[b]);
+    s.max_db = max_db;
     for (int i = 0; i < nf; ++i) {
         if (blocks_free[i] < 0 || blocks_free[i] >= nf) return set_err(SMCMI_ERR_ARG, "block index out of range");
         s.blocks_free[i] = blocks_free[i];
     }
     s.c = c;
     return 0;
+}
+
+// ---- mutation launch: register-resident kernel for blocks up to 10 parameters, generic LDS kernel beyond
+template <int DB>
+static void launch_reg(smcmi_handle *h, const MutArgs &ma, int standalone) {
+    const size_t lds = h->reg_lds_base + (size_t)(DB * DB + 3 * DB + 4) * sizeof(double) + (size_t)DB * sizeof(int) + 16;
+    k_mutate_reg<DB><<<h->nb_reg, h->reg_T, lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone);
+}
+template <int DB>
+static int set_reg_attr(smcmi_handle *h) {
+    const size_t lds = h->reg_lds_base + (size_t)(DB * DB + 3 * DB + 4) * sizeof(double) + (size_t)DB * sizeof(int) + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)k_mutate_reg<DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return 0;
+}
+static int set_mutate_attrs(smcmi_handle *h) {
+    return set_reg_attr<1>(h) || set_reg_attr<2>(h) || set_reg_attr<3>(h) || set_reg_attr<4>(h) || set_reg_attr<5>(h) ||
+           set_reg_attr<6>(h) || set_reg_attr<8>(h) || set_reg_attr<10>(h);
+}
+// max_db: upper bound on the block length for this launch; returns the number of blocks launched (acc partials)
+static int launch_mutate(smcmi_handle *h, int max_db, int standalone) {
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
+    if (max_db <= 1) launch_reg<1>(h, ma, standalone);
+    else if (max_db <= 2) launch_reg<2>(h, ma, standalone);
+    else if (max_db <= 3) launch_reg<3>(h, ma, standalone);
+    else if (max_db <= 4) launch_reg<4>(h, ma, standalone);
+    else if (max_db <= 5) launch_reg<5>(h, ma, standalone);
+    else if (max_db <= 6) launch_reg<6>(h, ma, standalone);
+    else if (max_db <= 8) launch_reg<8>(h, ma, standalone);
+    else if (max_db <= 10) launch_reg<10>(h, ma, standalone);
+    else {
+        k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone);
+        return h->nb_mut;
+    }
+    return h->nb_reg;
 }
 
 extern "C" int smcmi_mutate(smcmi_handle *h, const double *mu_free, const double *Sigma_free, const int32_t *block_ptr,
@@ -475,10 +528,8 @@ extern "C" int smcmi_mutate(smcmi_handle *h, const double *mu_free, const double
     s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = phi_n; s.mut_steps = n_mh_steps; s.mut_stage = stage;
     if (push_state(h)) return SMCMI_ERR_HIP;
     k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
-    MutArgs ma{};
-    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
-    k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 1);
-    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_comm);
+    const int nbl = launch_mutate(h, s.max_db, 1);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_comm);
     double asum = 0.0;
     HIP_TRY(hipMemcpyAsync(&asum, h->d_comm, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (pull_state(h)) return SMCMI_ERR_HIP;
@@ -544,24 +595,24 @@ extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const dou
 }
 
 // ------------------------------------------------------------------------------------------------ whole loop
-static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int acc_nb, hipEvent_t ev0, hipEvent_t ev1) {
+// One stage = a fixed kernel sequence (no host decision inside): see the header of kernels.hpp.
+static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int max_db, int acc_nb, hipEvent_t ev0,
+                          hipEvent_t ev1) {
     const long long n = h->n;
     hipStream_t s = h->stream;
+    const int P = adaptive ? solver_passes : 0;
     k_stage_begin<<<1, TB, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
-    if (adaptive) enqueue_solver(h, solver_passes);
-    k_ess_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_part_fin, h->d_hist_w, n);
-    k_post_correct<<<1, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec);
+    if (adaptive) enqueue_solver(h, P);
+    k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
+    k_post_correct<<<1, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, P == 0 ? 0 : (P & 1));
     k_scan_weights<<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 0);
-    k_search_ancestors<<<(unsigned)((n + TB - 1) / TB), TB, 0, s>>>(h->d_st, h->d_cum, n, 0, n, h->cfg.n_parts, method, h->cfg.seed, 0u,
-                                                                  nullptr, h->d_anc, 0);
-    k_gather<<<dim3((unsigned)((n + TB - 1) / TB), h->R), TB, 0, s>>>(h->cl, h->d_st, h->d_anc, 0);
+    k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
+                                                                 nullptr, h->d_anc, nullptr, 0);
     k_moments<<<h->nb_m, TB, h->mom_lds, s>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, n, 0);
-    k_moments_reduce<<<(h->npairs + 63) / 64, TB, 0, s>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 0);
+    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, s>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 0);
     k_prepare_mutation<<<1, 64, 0, s>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 1, 1, 0);
-    MutArgs ma{};
-    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
     if (ev0) hipEventRecord(ev0, s);
-    k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, s>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
+    launch_mutate(h, max_db, 0);
     if (ev1) hipEventRecord(ev1, s);
 }
 
@@ -587,11 +638,11 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     RunParams rp{};
     rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
     rp.resampling_method = rc->resampling_method; rp.use_fixed_schedule = rc->use_fixed_schedule;
-    rp.n_cand = (rc->n_cand > 1 && rc->n_cand <= KC) ? rc->n_cand : KC;
     rp.threshold = rc->threshold_ratio * (double)h->cfg.n_parts;
     rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
     rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
     rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+    rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-12);
     memset(&s, 0, sizeof(DevState));
     s.rp = rp; s.cur = cur;
     s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
@@ -613,15 +664,17 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    const int solver_passes = DEFAULT_SOLVER_PASSES;
+    const int solver_passes = rc->solver_passes > 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 8;
+    const int max_db = (nf + rc->n_blocks - 1) / rc->n_blocks;
+    const int acc_nb = max_db <= 10 ? h->nb_reg : h->nb_mut;
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
     std::vector<hipEvent_t> evs;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     if (rc->use_graph == 1) {
         HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, h->nb_mut, nullptr, nullptr);
+        enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, max_db, acc_nb, nullptr, nullptr);
         HIP_TRY(hipStreamEndCapture(h->stream, &graph));
         HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     }
@@ -635,7 +688,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
-                enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, h->nb_mut, e0, e1);
+                enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, max_db, acc_nb, e0, e1);
             }
             ++launched;
         }
@@ -643,7 +696,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     // fold the last mutation's acceptance rate and close the run
-    k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, h->nb_mut, h->rec);
+    k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     const auto t1 = std::chrono::steady_clock::now();
     if (gexec) { hipGraphExecDestroy(gexec); hipGraphDestroy(graph); }
@@ -655,6 +708,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     for (hipEvent_t e : evs) hipEventDestroy(e);
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
+    res->solver_passes = s.solver_passes;
     h->last_n_stages = s.stage;
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
@@ -691,18 +745,26 @@ extern "C" int smcmi_comm_buffer(smcmi_handle *h, double **dev_ptr, int64_t *cap
     return 0;
 }
 
+extern "C" int smcmi_comm_read(smcmi_handle *h, double *out, int64_t count) {
+    if (!h || !out || count < 0 || count > h->comm_cap) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpyAsync(out, h->d_comm, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int smcmi_shard_ess_partial(smcmi_handle *h, const double *phis, int32_t k, double phi_prev) {
     if (!h || !phis || k < 1 || k > KC) return set_err(SMCMI_ERR_ARG, "bad argument (1 <= k <= SMCMI_MAX_CAND)");
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (pull_state(h)) return SMCMI_ERR_HIP;
     DevState &s = h->h_st;
-    s.done = 0; s.mode = MODE_SECTION; s.phi_prev = phi_prev; s.n_valid = k;
-    for (int q = 0; q < k; ++q) s.cand[q] = phis[q];
+    s.done = 0; s.phi_prev = phi_prev;
+    s.sol[0].mode = MODE_SECTION; s.sol[0].n_valid = k;
+    for (int q = 0; q < k; ++q) s.sol[0].cand[q] = phis[q];
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_ess_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_ess, nullptr, 0);
-    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess, h->nb_e, 2 * KC, h->d_comm);   // comm[q] = Σv, comm[KC+q] = Σv²
-    s.mode = MODE_IDLE;
-    return push_state(h);
+    k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess[0], h->nb_e, 2 * KC, h->d_comm);   // comm[q] = Σv, comm[KC+q] = Σv²
+    return 0;
 }
 
 extern "C" int smcmi_shard_correct_partial(smcmi_handle *h, double phi_n, double phi_prev, double prior_weight,
@@ -712,14 +774,14 @@ extern "C" int smcmi_shard_correct_partial(smcmi_handle *h, double phi_n, double
     if (pull_state(h)) return SMCMI_ERR_HIP;
     DevState &s = h->h_st;
     if (stage_col + 1 > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded");
-    s.done = 0; s.mode = MODE_FINAL; s.phi_n = phi_n; s.phi_prev = phi_prev; s.rp.pw = prior_weight; s.rp.logp_old = log_prob_old_data;
+    s.done = 0; s.phi_n = phi_n; s.phi_prev = phi_prev; s.rp.pw = prior_weight; s.rp.logp_old = log_prob_old_data;
     s.stage = stage_col + 1; s.rp.store_history = h->cfg.store_history;
+    s.sol[0].mode = MODE_FINAL; s.sol[0].phi_n = phi_n;
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_ess_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin, h->d_hist_w, h->n);
+    k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, h->d_hist_w, h->n);
     k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_comm);
     h->last_n_stages = std::max(h->last_n_stages, stage_col + 1);
-    s.mode = MODE_IDLE;
-    return push_state(h);
+    return 0;
 }
 
 extern "C" int smcmi_shard_normalize_moments_partial(smcmi_handle *h, double sum_unnorm, int32_t resampled, const double *shift,
@@ -730,13 +792,10 @@ extern "C" int smcmi_shard_normalize_moments_partial(smcmi_handle *h, double sum
     DevState &s = h->h_st;
     s.done = 0; s.sumw = sum_unnorm; s.do_resample = 0; s.stage = stage_col + 1; s.rp.store_history = h->cfg.store_history;
     for (int a = 0; a < h->d; ++a) s.shift[a] = shift ? shift[a] : 0.0;
-    if (resampled) {
-        // after a gather the weights are already 1: normalise with Σ = N so (w*N)/Σ == w
-        s.sumw = (double)h->cfg.n_parts;
-    }
+    if (resampled) s.sumw = (double)h->cfg.n_parts;   // after a gather the weights are already 1: (w*N)/N == w
     if (push_state(h)) return SMCMI_ERR_HIP;
     k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, h->n, 0);
-    k_moments_reduce<<<(h->npairs + 63) / 64, TB, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_comm, 0);
+    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_comm, 0);
     return 0;
 }
 
@@ -748,19 +807,29 @@ extern "C" int smcmi_shard_weights_device_ptr(smcmi_handle *h, double **dev_ptr)
     return 0;
 }
 
-// rows of this shard <- rows `ancestors` (global ids) of an all-gathered full cloud (n_full x R, column-major, device)
-__global__ void k_gather_full(CloudPtrs cl, const DevState *st, const double *full, long long n_full, const long long *anc) {
-    const long long k = (long long)blockIdx.x * TB + threadIdx.x;
-    if (k >= cl.n) return;
-    const int c = blockIdx.y;
-    double *out = col(cl, st->cur, c);
-    out[k] = (c == cl.R - 1) ? 1.0 : full[(long long)c * n_full + anc[k]];
-}
-extern "C" int smcmi_shard_gather_rows(smcmi_handle *h, const double *dev_full_cloud, int64_t n_full, const int64_t *dev_ancestors) {
-    if (!h || !dev_full_cloud || !dev_ancestors) return set_err(SMCMI_ERR_ARG, "null argument");
+// Selection on one shard of a sharded population: `dev_full_weights` (n_parts unnormalised weights, all-gathered) gives the
+// global cumulative sum; this shard's output slots pick their ancestors (global ids) and copy the rows from the
+// all-gathered cloud `dev_full_cloud` (n_parts x R column-major).
+extern "C" int smcmi_shard_resample(smcmi_handle *h, const double *dev_full_weights, const double *dev_full_cloud, int32_t method,
+                                    uint32_t stage, int64_t *ancestors_out) {
+    if (!h || !dev_full_weights || !dev_full_cloud) return set_err(SMCMI_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    k_gather_full<<<dim3((unsigned)((h->n + TB - 1) / TB), h->R), TB, 0, h->stream>>>(h->cl, h->d_st, dev_full_cloud, n_full,
-                                                                                    (const long long *)dev_ancestors);
+    const long long N = h->cfg.n_parts;
+    if (!h->d_cum_full) {
+        if (dmalloc(&h->d_cum_full, N)) return SMCMI_ERR_HIP;
+        h->nb_full = (int)std::min<long long>(1024, std::max<long long>(1, (N + 511) / 512));
+        if (dmalloc(&h->d_part_full, (size_t)h->nb_full * 2) || dmalloc(&h->d_off_full, h->nb_full)) return SMCMI_ERR_HIP;
+    }
+    CloudPtrs wcl{};                      // view the full weight vector as a 1-column "cloud"
+    wcl.buf[0] = wcl.buf[1] = const_cast<double *>(dev_full_weights);
+    wcl.n = N; wcl.R = 1;
+    k_weight_chunk_sums<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_part_full);
+    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_full, h->nb_full, h->d_off_full, 0.0, 1);
+    k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 1);
+    k_resample_gather<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum_full, N, h->cfg.gid0, N, method,
+                                                                            h->cfg.seed, stage, nullptr, h->d_anc, dev_full_cloud, 1);
+    if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, h->d_anc, sizeof(long long) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -777,10 +846,8 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
     s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = phi_n; s.mut_steps = n_mh_steps; s.mut_stage = stage;
     if (push_state(h)) return SMCMI_ERR_HIP;
     k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
-    MutArgs ma{};
-    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
-    k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 1);
-    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_comm);
+    const int nbl = launch_mutate(h, s.max_db, 1);
+    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_comm);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     return err_from_state(s.err);
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsmcmi.so")
 
 MAX_PARA = 64
-MAX_CAND = 32
+MAX_CAND = 16
 
 PRIOR = {"normal": 0, "uniform": 1, "gamma": 2, "beta": 3, "invgamma": 4, "rootinvgamma": 5}
 LIK = {"none": -1, "gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "host_callback": 100}
@@ -33,14 +33,14 @@ class RunConfig(C.Structure):
                 ("resampling_method", C.c_int32), ("threshold_ratio", C.c_double), ("c", C.c_double),
                 ("alpha", C.c_double), ("target", C.c_double), ("use_fixed_schedule", C.c_int32),
                 ("tempering_target", C.c_double), ("tempered_update_prior_weight", C.c_double),
-                ("log_prob_old_data", C.c_double), ("n_cand", C.c_int32), ("sync_every", C.c_int32),
-                ("use_graph", C.c_int32)]
+                ("log_prob_old_data", C.c_double), ("solver_passes", C.c_int32), ("sync_every", C.c_int32),
+                ("use_graph", C.c_int32), ("phi_rtol", C.c_double)]
 
 
 class Result(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("resamples", C.c_int32), ("logmdd", C.c_double), ("c", C.c_double),
                 ("accept", C.c_double), ("seconds", C.c_double), ("kernel_ms_mutate", C.c_double),
-                ("n_mutate_launches", C.c_int32)]
+                ("n_mutate_launches", C.c_int32), ("solver_passes", C.c_int64)]
 
 
 class StageStats(C.Structure):
@@ -73,11 +73,12 @@ SYMBOLS = [
     ("smcmi_get_stage_records", C.c_int, [_H, dp, dp, dp, dp, ip]),
     ("smcmi_get_history", C.c_int, [_H, dp, dp]),
     ("smcmi_comm_buffer", C.c_int, [_H, C.POINTER(C.c_void_p), lp]),
+    ("smcmi_comm_read", C.c_int, [_H, dp, C.c_int64]),
     ("smcmi_shard_ess_partial", C.c_int, [_H, dp, C.c_int32, C.c_double]),
     ("smcmi_shard_correct_partial", C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32]),
     ("smcmi_shard_normalize_moments_partial", C.c_int, [_H, C.c_double, C.c_int32, dp, C.c_int32]),
     ("smcmi_shard_weights_device_ptr", C.c_int, [_H, C.POINTER(C.c_void_p)]),
-    ("smcmi_shard_gather_rows", C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("smcmi_shard_resample", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, lp]),
     ("smcmi_shard_mutate_partial", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32]),
     ("smcmi_sync", C.c_int, [_H]),
 ]
@@ -91,6 +92,27 @@ class SMCMIError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not share devices, so
+    when torch is installed (it is the plumbing for torch.distributed / device tensors in the multi-GPU path) load ITS
+    runtime first; libsmcmi.so's NEEDED libamdhip64.so.7 then resolves to the same, already-loaded copy whatever the
+    import order.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libsmcmi.so (built in-tree by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
     global _LIB
@@ -98,6 +120,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libsmcmi.so not found at %s - build it with `python __graft_entry__.py` "
                               "(hipcc --offload-arch=gfx950); the engine has no CPU fallback" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)

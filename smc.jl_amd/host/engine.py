@@ -153,14 +153,15 @@ class Engine:
     # ---- whole loop --------------------------------------------------------------------------------
     def run(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
             c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
-            log_prob_old_data=0.0, n_cand=0, sync_every=0, use_graph=0):
+            log_prob_old_data=0.0, solver_passes=0, sync_every=0, use_graph=0, phi_rtol=0.0):
         rc = _lib.RunConfig(n_blocks, n_mh_steps, lam, n_phi, _lib.RESAMPLE[resampling_method], threshold_ratio, c, alpha,
-                            target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, n_cand,
-                            sync_every, use_graph)
+                            target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, solver_passes,
+                            sync_every, use_graph, phi_rtol)
         res = _lib.Result()
         check(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
         return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
-                    seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches)
+                    seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
+                    solver_passes=res.solver_passes)
 
     def stage_records(self, n_stages):
         phi, ess, c, acc = (np.empty(n_stages) for _ in range(4))
@@ -175,3 +176,56 @@ class Engine:
 
     def sync(self):
         check(self._L.smcmi_sync(self._h))
+
+    # ---- shard-level calls (multi-GPU hosts; see host/distributed.py) ------------------------------------
+    tensor_device = "cuda"
+
+    def _comm(self, count):
+        out = np.empty(count)
+        check(self._L.smcmi_comm_read(self._h, _d(out), count))
+        return out
+
+    def shard_ess_sums(self, phis, phi_prev):
+        phis = _f64(np.atleast_1d(phis))
+        check(self._L.smcmi_shard_ess_partial(self._h, _d(phis), phis.size, phi_prev))
+        c = self._comm(2 * _lib.MAX_CAND)
+        return c[:phis.size].copy(), c[_lib.MAX_CAND:_lib.MAX_CAND + phis.size].copy()
+
+    def shard_correct(self, phi_n, phi_prev, prior_weight, log_prob_old_data, stage_col):
+        check(self._L.smcmi_shard_correct_partial(self._h, phi_n, phi_prev, prior_weight, log_prob_old_data, stage_col))
+        return self._comm(2)
+
+    def shard_normalize_moments(self, sum_unnorm, resampled, shift, stage_col):
+        sh = _f64(shift)
+        check(self._L.smcmi_shard_normalize_moments_partial(self._h, sum_unnorm, int(resampled), _d(sh), stage_col))
+        return self._comm((self.d + 1) * (self.d + 2) // 2)
+
+    def shard_mutate(self, mu_free, Sigma_free, block_ptr, blocks_free, phi_n, phi_prev, c, alpha, n_mh_steps, stage):
+        mu, S = _f64(mu_free), _f64(Sigma_free)
+        bp, bf = np.ascontiguousarray(block_ptr, dtype=np.int32), np.ascontiguousarray(blocks_free, dtype=np.int32)
+        check(self._L.smcmi_shard_mutate_partial(self._h, _d(mu), _d(S), _i(bp), _i(bf), bp.size - 1, phi_n, phi_prev, c, alpha,
+                                                 n_mh_steps, stage))
+        return float(self._comm(1)[0])
+
+    def _dev_tensor(self, ptr, shape):
+        import torch
+
+        class _A:
+            pass
+
+        a = _A()
+        a.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(a, device="cuda")
+
+    def cloud_tensor(self):
+        """Zero-copy torch view [R, n] of the current cloud buffer (rows = columns of cloud.particles)."""
+        ptr, ld = C.c_void_p(), C.c_int64()
+        check(self._L.smcmi_cloud_device_ptr(self._h, C.byref(ptr), C.byref(ld)))
+        return self._dev_tensor(ptr.value, (self.R, self.n))
+
+    def shard_resample(self, full_weights, full_cloud, method, stage):
+        """full_weights: torch cuda tensor [N]; full_cloud: torch cuda tensor [R, N] (all-gathered)."""
+        anc = np.empty(self.n, dtype=np.int64)
+        check(self._L.smcmi_shard_resample(self._h, C.c_void_p(full_weights.data_ptr()), C.c_void_p(full_cloud.data_ptr()),
+                                           _lib.RESAMPLE[method], stage, anc.ctypes.data_as(lp)))
+        return anc
