@@ -143,8 +143,19 @@ def main():
         mean_ms = prof["kernel_ms_mutate"] / nl
         bytes_per_launch = mutate_bytes_per_particle(D) * n_total
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "k_mutate<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read correction):
+        # profiles/pmc_extract.py -> profiles/r01_pmc_traffic.json, bytes per particle of this kernel x particles
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            k = [v for name, v in pm["kernels"].items() if "k_mutate_reg<%d>" % D in name]
+            if k:
+                traffic = k[0]["bytes_per_particle"] * n_total
+        except OSError:
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": "k_mutate_reg<%d>" % D, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl}
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages
         stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
