@@ -1,0 +1,396 @@
+"""Python mirror of the reference's user-facing interface for the hot path:
+
+    smc(loglikelihood, parameters, data; kwargs...)          src/smc_main.jl:118-161
+    Cloud + get_vals / get_loglh / ... / weighted_mean / weighted_cov / weighted_std   src/particle.jl
+    parameter(...) / Normal / Uniform / ...                   ModelConstructors.jl + Distributions.jl (absent deps)
+
+Same names, argument meaning and error behaviour; the work happens in libsmcmi.so (HIP).  A Julia user gets the same
+surface through smc.jl_amd/julia/SMCMI.jl (ccall); this module exists because Julia is not installed in the build image,
+so the parity tests drive the C ABI from Python.
+
+`loglikelihood` is either a device family (GaussIso, LinReg, LinModel3, CapmLiteral: evaluated inside the mutation
+kernel) or any Python callable f(theta: ndarray, data: ndarray) -> float, which runs through the propose / accept split
+(device proposal + prior + MH decision, host likelihood) exactly as a Julia closure would.
+"""
+import math
+import time
+
+import numpy as np
+
+from . import hostmath as hm
+from ._lib import SMCMIError
+from .engine import Engine
+
+VERBOSITY = {"none": 0, "low": 1, "high": 2}
+
+
+# ----------------------------------------------------------------------------------------------- priors / parameters
+class _Prior:
+    family = None
+
+    def __init__(self, a, b):
+        self.a, self.b = float(a), float(b)
+
+    def triple(self):
+        return (self.family, self.a, self.b)
+
+
+class Normal(_Prior):          # Distributions.Normal(μ, σ)
+    family = "normal"
+
+
+class Uniform(_Prior):         # Distributions.Uniform(a, b)
+    family = "uniform"
+
+
+class Gamma(_Prior):           # Distributions.Gamma(shape, scale)
+    family = "gamma"
+
+
+class Beta(_Prior):            # Distributions.Beta(α, β)
+    family = "beta"
+
+
+class InverseGamma(_Prior):    # Distributions.InverseGamma(shape, scale)
+    family = "invgamma"
+
+
+class RootInverseGamma(_Prior):  # ModelConstructors.RootInverseGamma(ν, τ)
+    family = "rootinvgamma"
+
+
+class Parameter:
+    def __init__(self, key, value, valuebounds, prior, fixed=False):
+        self.key, self.value, self.valuebounds, self.prior, self.fixed = key, float(value), tuple(valuebounds), prior, bool(fixed)
+
+
+def parameter(key, value, valuebounds=(-1e5, 1e5), transform_parameterization=None, transform=None, prior=None, fixed=False):
+    """ModelConstructors.parameter(key, value, valuebounds, transform_parameterization, transform, prior; fixed).
+    The transform arguments are accepted for call compatibility; SMC itself never uses them."""
+    if prior is None and not fixed:
+        raise ValueError("a free parameter needs a prior")
+    return Parameter(key, value, valuebounds, prior, fixed)
+
+
+def _spec_from(parameters, lik, old_lik):
+    pri, bnd, fx = [], [], []
+    for p in parameters:
+        if p.fixed:
+            pri.append(("normal", p.value, 1.0))        # fixed: the value rides in prior_a (see k_init_prior)
+        else:
+            pri.append(p.prior.triple())
+        bnd.append(p.valuebounds)
+        fx.append(1 if p.fixed else 0)
+    return dict(priors=pri, bounds=bnd, fixed=fx, lik=lik, old_lik=old_lik)
+
+
+# ----------------------------------------------------------------------------------------------- device likelihoods
+class DeviceLikelihood:
+    family = None
+
+    def spec(self, data):
+        raise NotImplementedError
+
+
+class GaussIso(DeviceLikelihood):
+    """ℓ(θ) = -(d/2) log(2πσ²) - Σ(θ_j - m_j)²/(2σ²); data = m (d x 1)."""
+
+    def __init__(self, sigma):
+        self.sigma = float(sigma)
+
+    def spec(self, data):
+        return ("gauss_iso", [self.sigma], np.asarray(data, dtype=np.float64).reshape(-1, 1), None)
+
+
+class LinReg(DeviceLikelihood):
+    """examples/regression_model/estimate_regression.jl:46-53; data = [y X] (n x 2)."""
+
+    def __init__(self, sigma2=1.0):
+        self.sigma2 = float(sigma2)
+
+    def spec(self, data):
+        return ("linreg", [self.sigma2], np.asarray(data, dtype=np.float64), None)
+
+
+class LinModel3(DeviceLikelihood):
+    """test/modelsetup.jl:119-138 loglik_fn; data 3 x T, regressors X 3 x (>= T)."""
+
+    def __init__(self, X):
+        self.X = np.asarray(X, dtype=np.float64)
+
+    def spec(self, data):
+        return ("linmodel3", [], np.asarray(data, dtype=np.float64), self.X)
+
+
+class CapmLiteral(DeviceLikelihood):
+    """examples/capm_model/estimate_capm.jl:52-70 as written; data 3 x T, market 1 x T."""
+
+    def __init__(self, market_data):
+        self.market = np.asarray(market_data, dtype=np.float64).reshape(1, -1)
+
+    def spec(self, data):
+        return ("capm_literal", [], np.asarray(data, dtype=np.float64), self.market)
+
+
+# ----------------------------------------------------------------------------------------------- Cloud
+class Cloud:
+    """src/particle.jl:31-53.  particles: (n_parts, n_params + 5) float64, Fortran order."""
+
+    def __init__(self, n_params=0, n_parts=0):
+        self.particles = np.empty((n_parts, n_params + 5), order="F")
+        self.tempering_schedule = np.zeros(1)
+        self.ESS = np.zeros(1)
+        self.stage_index = 1
+        self.n_Phi = 0
+        self.resamples = 0
+        self.c = 0.0
+        self.accept = 0.25
+        self.total_sampling_time = 0.0
+
+    def __len__(self):
+        return self.particles.shape[0]
+
+
+def _P(c):
+    return c.particles if isinstance(c, Cloud) else c
+
+
+def get_vals(c, transpose=True):
+    v = _P(c)[:, :-5]
+    return np.array(v.T if transpose else v)
+
+
+def get_loglh(c):
+    return np.array(_P(c)[:, -5])
+
+
+def get_logprior(c):
+    return np.array(_P(c)[:, -4])
+
+
+def get_old_loglh(c):
+    return np.array(_P(c)[:, -3])
+
+
+def get_logpost(c):
+    return get_loglh(c) + get_logprior(c)
+
+
+def get_accept(c):
+    return np.array(_P(c)[:, -2])
+
+
+def get_weights(c):
+    return np.array(_P(c)[:, -1])
+
+
+def weighted_mean(c):
+    w = get_weights(c)
+    return get_vals(c) @ w / w.sum()
+
+
+def weighted_cov(c):
+    w = get_weights(c)
+    w = w / w.sum()
+    X = get_vals(c, transpose=False)
+    m = (w @ X) / w.sum()
+    Xc = X - m
+    return (Xc.T * w) @ Xc / w.sum()
+
+
+def weighted_std(c):
+    return np.sqrt(np.diag(weighted_cov(c)))
+
+
+def cloud_isempty(c):
+    return len(c) == 0
+
+
+# ----------------------------------------------------------------------------------------------- smc()
+def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300,
+        resampling_method="systematic", threshold_ratio=0.5, c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True,
+        tempering_target=0.97, old_data=None, old_loglikelihood=None, tempered_update_prior_weight=0.0,
+        log_prob_old_data=0.0, savepath=None, seed=0, device=0, max_stages=None, initial_cloud=None, use_graph=0):
+    """Sequential Monte Carlo on one MI355X.  Keyword names follow src/smc_main.jl:119-161 (λ -> lam, n_Φ -> n_phi,
+    α -> alpha).  Returns (cloud, w, W) - the three objects the reference writes to `savepath` - and, when `savepath`
+    is given, stores them as a numpy .npz (the reference's JLD2/HDF5 writers are outside the hot path)."""
+    if verbose not in VERBOSITY:
+        raise ValueError("verbose must be one of :none, :low, :high")
+    if resampling_method not in ("systematic", "multinomial", "polyalgo"):
+        raise ValueError("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
+    if not 0.0 <= tempered_update_prior_weight <= 1.0:
+        raise ValueError("The keyword tempered_update_prior_weight must be within the interval [0, 1]")
+    parameters = list(parameters)
+    d = len(parameters)
+    if all(p.fixed for p in parameters):
+        raise AssertionError("All model parameters are fixed!")
+    if old_data is not None and np.size(old_data) and initial_cloud is None:
+        raise NotImplementedError("tempered updates need initial_cloud = the bridged old cloud (SURVEY §8f-2: next row)")
+    data = np.asarray(data, dtype=np.float64)
+    device_lik = isinstance(loglikelihood, DeviceLikelihood)
+    lik = loglikelihood.spec(data) if device_lik else ("host_callback", [], None, None)
+    old_lik = None
+    tempered = old_data is not None and np.size(old_data) > 0
+    if tempered:
+        ol = old_loglikelihood if old_loglikelihood is not None else loglikelihood
+        old_lik = ol.spec(np.asarray(old_data, dtype=np.float64)) if isinstance(ol, DeviceLikelihood) else ("host_callback", [], None, None)
+    if max_stages is None:
+        max_stages = n_phi if use_fixed_schedule else 20 * n_phi
+    spec = _spec_from(parameters, lik, old_lik)
+    eng = Engine(n_parts, d, seed=seed, device=device, max_stages=max_stages, store_history=True)
+    eng.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
+    if device_lik:
+        eng.set_likelihood(*lik, which=0)
+        if old_lik is not None and old_lik[0] != "host_callback":
+            eng.set_likelihood(*old_lik, which=1)
+        else:
+            eng.set_likelihood("none", which=1)
+    else:
+        eng.set_likelihood("host_callback", which=0)
+        eng.set_likelihood("none", which=1)
+    kw = dict(n_blocks=n_blocks, n_mh_steps=n_mh_steps, lam=lam, n_phi=n_phi, resampling_method=resampling_method,
+              threshold_ratio=threshold_ratio, c=c, alpha=alpha, target=target, use_fixed_schedule=use_fixed_schedule,
+              tempering_target=tempering_target, prior_weight=tempered_update_prior_weight,
+              log_prob_old_data=log_prob_old_data)
+    if verbose != "none":
+        print("\n\n SMC starts ....\n")
+    if device_lik:
+        if initial_cloud is not None:
+            eng.upload_cloud(initial_cloud.particles if isinstance(initial_cloud, Cloud) else initial_cloud)
+        else:
+            eng.init_from_prior()
+        r = eng.run(use_graph=use_graph, **kw)
+        rec = eng.stage_records(r["n_stages"])
+        w, W = eng.history(r["n_stages"])
+        P = eng.download_cloud()
+    else:
+        r, rec, w, W, P = _run_host_callback(eng, loglikelihood, parameters, data, spec, initial_cloud, seed, max_stages, kw)
+    cloud = Cloud(d, n_parts)
+    cloud.particles = P
+    cloud.tempering_schedule = rec["schedule"]
+    cloud.ESS = rec["ess"]
+    cloud.stage_index = r["n_stages"]
+    cloud.n_Phi = n_phi
+    cloud.resamples = r["resamples"]
+    cloud.c = r["c"]
+    cloud.accept = r["accept"]
+    cloud.total_sampling_time = r["seconds"]
+    cloud.logmdd = r["logmdd"]
+    if verbose != "none":
+        print(" SMC finished: %d stages, %d resamples, c = %.4f, accept = %.4f, log-MDD = %.6f, %.3f s" %
+              (r["n_stages"], r["resamples"], r["c"], r["accept"], r["logmdd"], r["seconds"]))
+        if verbose == "high":
+            mu, sd = weighted_mean(cloud), weighted_std(cloud)
+            for p, m_, s_ in zip(parameters, mu, sd):
+                print("   %-12s mean %12.6f  std %12.6f" % (p.key, m_, s_))
+    if savepath:
+        np.savez(savepath, particles=cloud.particles, tempering_schedule=cloud.tempering_schedule, ESS=cloud.ESS,
+                 stage_index=cloud.stage_index, n_Phi=n_phi, resamples=cloud.resamples, c=cloud.c, accept=cloud.accept,
+                 total_sampling_time=cloud.total_sampling_time, w=w, W=W)
+    eng.close()
+    return cloud, w, W
+
+
+def _host_initial_draw(eng, loglikelihood, parameters, data, spec, seed):
+    """initial_draw! (src/initialization.jl:88-119) with a host likelihood: prior draws on the host RNG contract."""
+    n, d = eng.n, eng.d
+    P = np.zeros((n, d + 5), order="F")
+    for i in range(n):
+        for attempt in range(100000):
+            th = np.empty(d)
+            for k, p in enumerate(parameters):
+                if p.fixed:
+                    th[k] = p.value
+                    continue
+                fam, a, b = p.prior.triple()
+                if fam not in ("normal", "uniform"):
+                    raise NotImplementedError("host prior sampling supports Normal/Uniform")
+                for r in range(100000):
+                    ua, ub = hm.uniform_pair(seed, i, attempt, hm.rng_tag(hm.P_INIT, r, k))
+                    x = a + b * (math.sqrt(-2.0 * math.log(ua)) * math.cos(2.0 * math.pi * ub)) if fam == "normal" else a + (b - a) * ua
+                    if p.valuebounds[0] < x < p.valuebounds[1]:
+                        th[k] = x
+                        break
+            ll = _safe_call(loglikelihood, th, data)
+            if not math.isinf(ll):
+                break
+        P[i, :d] = th
+        P[i, d] = ll
+        P[i, d + 4] = 1.0
+    eng.upload_cloud(P)
+    # log-priors through the device prior table (zero-width proposal: returns prior(θ))
+    nf = int(sum(1 for p in parameters if not p.fixed))
+    _, lpr, _ = eng.propose(np.zeros(nf), np.eye(nf), [0, nf], np.arange(nf), 0, 0, 1e-150, 1.0, 0)
+    P[:, d + 1] = lpr
+    eng.upload_cloud(P)
+    return P
+
+
+def _safe_call(f, th, data):
+    """The reference maps ParamBoundsError / LAPACK / PosDef / Singular / DomainError inside the likelihood to -Inf
+    (src/mutation.jl:112-121); the Python equivalents are ArithmeticError, ValueError and numpy LinAlgError."""
+    try:
+        v = float(f(th, data))
+    except (ArithmeticError, ValueError, np.linalg.LinAlgError):
+        return -math.inf
+    return -math.inf if math.isnan(v) else v
+
+
+def _run_host_callback(eng, loglikelihood, parameters, data, spec, initial_cloud, seed, max_stages, kw):
+    """The loop of src/smc_main.jl:377-508 with the mutation split around a host likelihood:
+    device ϕ-solve / correction / selection / moments / proposals / MH decision, host loglikelihood(θ', data)."""
+    n, d = eng.n, eng.d
+    N = float(n)
+    if initial_cloud is not None:
+        eng.upload_cloud(initial_cloud.particles if isinstance(initial_cloud, Cloud) else initial_cloud)
+    else:
+        _host_initial_draw(eng, loglikelihood, parameters, data, spec, seed)
+    free = np.array([k for k, p in enumerate(parameters) if not p.fixed], dtype=np.int32)
+    nf = len(free)
+    sched = hm.schedule(kw["n_phi"], kw["lam"])
+    i, j, phi_n, phi_prop, resampled_last = 1, 2, 0.0, 0.0, False
+    c, accept, logz, resamples = kw["c"], kw["target"], 0.0, 0
+    phi_h, ess_h, c_h, acc_h, rs_h = [0.0], [N], [c], [accept], [0]
+    w_cols, W_cols = [np.zeros(n)], [eng.download_cloud()[:, d + 4].copy()]
+    t0 = time.perf_counter()
+    while phi_n < 1.0:
+        i += 1
+        if i > max_stages:
+            raise SMCMIError(-5, "max_stages exceeded")
+        phi_prev = phi_n
+        if kw["use_fixed_schedule"]:
+            phi_n = float(sched[i - 1])
+        else:
+            phi_n, resampled_last, j, phi_prop = eng.solve_phi(sched, j, phi_prop, phi_prev, kw["tempering_target"], ess_h[-1],
+                                                               resampled_last)
+        before = eng.download_cloud()[:, d + 4]
+        st = eng.correct(phi_n, phi_prev, kw["prior_weight"], kw["log_prob_old_data"], kw["threshold_ratio"])
+        after = eng.download_cloud()[:, d + 4]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            w_cols.append(np.where(before > 0, after * st["sum_unnorm"] / N / before, 0.0))
+        logz += st["logz_inc"]
+        rs = st["resample"]
+        if rs:
+            eng.resample("multinomial" if kw["resampling_method"] == "polyalgo" else kw["resampling_method"], stage=i)
+            resamples += 1
+            resampled_last = True
+            W_cols.append(np.ones(n))
+        else:
+            W_cols.append(after.copy())
+        c = hm.update_c(c, accept, kw["target"])
+        mean, cov = eng.moments()
+        mu_f, S_f = mean[free], (cov[np.ix_(free, free)] + cov[np.ix_(free, free)].T) / 2.0
+        bf, ba, bp = hm.generate_blocks(nf, kw["n_blocks"], free, seed, i)
+        for step in range(kw["n_mh_steps"]):
+            for b in range(kw["n_blocks"]):
+                prop, lpr, qd = eng.propose(mu_f, S_f, bp, bf, b, step, c, kw["alpha"], i)
+                ll = np.array([_safe_call(loglikelihood, prop[k], data) if np.isfinite(lpr[k]) else -math.inf for k in range(n)])
+                eng.accept(ll, None, phi_n, b, step, kw["n_blocks"], i,
+                           last=(step == kw["n_mh_steps"] - 1 and b == kw["n_blocks"] - 1))
+        accept = float(eng.download_cloud()[:, d + 3].mean())
+        phi_h.append(phi_n); ess_h.append(st["ess"]); c_h.append(c); acc_h.append(accept); rs_h.append(int(rs))
+    secs = time.perf_counter() - t0
+    r = dict(n_stages=i, resamples=resamples, logmdd=logz, c=c, accept=accept, seconds=secs)
+    rec = dict(schedule=np.array(phi_h), ess=np.array(ess_h), c_hist=np.array(c_h), accept_hist=np.array(acc_h),
+               resampled=np.array(rs_h, dtype=np.int32))
+    return r, rec, np.asfortranarray(np.stack(w_cols, 1)), np.asfortranarray(np.stack(W_cols, 1)), eng.download_cloud()
