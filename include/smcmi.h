@@ -161,6 +161,10 @@ int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free, const dou
                                const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c,
                                double alpha, int32_t n_mh_steps, uint32_t stage);                      /* comm[0] = Σ accept */
 int smcmi_sync(smcmi_handle *h);
+/* development aid: mean duration (µs, HIP events on the handle's stream) of `reps` back-to-back launches of one stage kernel on
+   the current cloud.  which: 0 pass16(p=0) 1 pass16(p=1, with decision prologue) 2 correction 3 post_correct 4 scan 5 resample_gather
+   6 moments 7 moments_reduce 8 prepare_mutation 9 mutate 10 stage_begin 11 empty kernel */
+int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t reps, double *usec_per_launch);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,8 @@ struct LikDev {
 
 struct ModelDev {
     int d, n_free;
+    int has_other_priors;      // some free parameter has a prior family other than Normal / Uniform
+    int pad_;
     int fixed[MAXD];
     int free_inds[MAXD];
     double lo[MAXD], hi[MAXD];

@@ -74,7 +74,8 @@ __device__ inline double block_reduce_many(double (&a)[M], double *red) {
 // Fixed-order sum of per-block partials partials[b * m + idx], b < nb, by one whole block: thread (s, idx) adds the
 // blocks b = s (mod S), S = blockDim.x / m slices, four independent loads in flight; slices are then combined in
 // slice order.  Result for idx = threadIdx.x (< m).  scratch: blockDim.x doubles.  Requires m <= blockDim.x.
-__device__ inline double final_sum(const double *partials, int nb, int m, double *scratch) {
+__device__ inline double final_sum(const double *partials, int nb, int m, double *scratch, int stride = 0) {
+    if (stride == 0) stride = m;
     const int t = threadIdx.x, S = blockDim.x / m;
     const int idx = t % m, s = t / m;
     if (s < S) {
@@ -84,17 +85,22 @@ __device__ inline double final_sum(const double *partials, int nb, int m, double
         int b = s;
         for (; b + 7 * S < nb; b += 8 * S) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] += partials[(long long)(b + q * S) * m + idx];
+            for (int q = 0; q < 8; ++q) a[q] += partials[(long long)(b + q * S) * stride + idx];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (b + q * S < nb) a[q] += partials[(long long)(b + q * S) * m + idx];
+            if (b + q * S < nb) a[q] += partials[(long long)(b + q * S) * stride + idx];
         scratch[s * m + idx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     __syncthreads();
-    double tot = 0.0;
-    if (t < m)
-        for (int q = 0; q < S; ++q) tot += scratch[q * m + t];
+    // combine the S slices pairwise in a fixed tree (slice s absorbs slice s + half)
+    int half = 1;
+    while (half * 2 < S) half *= 2;
+    for (; half >= 1; half >>= 1) {
+        if (s < half && s + half < S) scratch[s * m + idx] += scratch[(s + half) * m + idx];
+        __syncthreads();
+    }
+    const double tot = (t < m) ? scratch[t] : 0.0;
     __syncthreads();
     return tot;
 }
@@ -126,6 +132,19 @@ __device__ inline void block_chunk(long long n, int nb, int b, long long &beg, l
     if (beg > n) beg = n;
 }
 
+// Loads column k = 0..nc-1 of particle i into dst[k * stride] with 8 global loads in flight: a plain run-time loop of
+// load -> LDS store serialises one ~1 µs memory round trip per column.
+__device__ inline void load_columns(const double *base, long long ld, long long i, int nc, double *dst, int stride) {
+    for (int k0 = 0; k0 < nc; k0 += 8) {
+        double tmp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tmp[q] = (k0 + q < nc) ? base[(long long)(k0 + q) * ld + i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (k0 + q < nc) dst[(k0 + q) * stride] = tmp[q];
+    }
+}
+
 struct CloudPtrs {
     double *buf[2];     // two n x R column-major buffers
     long long n;        // local particles (leading dimension)
@@ -144,116 +163,118 @@ __device__ inline double *col(const CloudPtrs &c, int which, int column) { retur
 //   FINAL   : ϕ_n known.
 constexpr double RING[6] = {0x1p-3, 0x1p-7, 0x1p-11, 0x1p-15, 0x1p-19, 0x1p-23};
 
-__device__ inline void section_candidates(Solver &S, double rtol) {
-    const double lo = S.lo, hi = S.hi, h = hi - lo;
+// One decision step from the candidate totals tot[0..KC) = Σv, tot[KC..2KC) = Σv², executed by the 64 lanes of wave 0
+// (lane k owns candidate k; S and tot live in LDS; `srt` is KC doubles of LDS scratch).  Same decisions as the serial
+// formulation in host/hostmath.py: first candidate with g < 0 ends the scan / splits the bracket; new candidates are the
+// ascending merge of 3 uniform points, the secant estimate and 6 geometric rings on each side, deduplicated.
+__device__ inline void solver_decide_wave(Solver &S, const double *tot, const double *sched, int n_phi, double rtol, int *err,
+                                          double *srt) {
+    const int lane = threadIdx.x & 63;
+    const int nv = S.n_valid, mode = S.mode;
+    const bool mine = lane < nv && lane < KC;
+    const double ck = mine ? S.cand[lane] : 0.0;
+    const double gk = mine ? tot[lane] * tot[lane] / tot[KC + lane] - S.ess_bar : 0.0;     // ESS(ϕ) = (Σv)²/Σv²
+    const unsigned long long negmask = __ballot(mine && !(gk >= 0.0));
+    const int m = negmask ? (__ffsll((long long)negmask) - 1) : -1;
+    double lo = S.lo, hi = S.hi, glo = S.glo, ghi = S.ghi;
+    if (mode == MODE_SCAN) {
+        // candidate 0 is the current ϕ_prop, candidate q > 0 is schedule[j + q - 1] (1-based j); candidates increase with q
+        const int kk = (m < 0 ? nv : m) - 1;           // last candidate known to keep ESS above the target
+        if (kk >= 0) {
+            const double ckk = __shfl(ck, kk, 64), gkk = __shfl(gk, kk, 64);
+            if (ckk > lo) { lo = ckk; glo = gkk; }
+        }
+        if (m >= 0) {
+            const double cm = __shfl(ck, m, 64), gm = __shfl(gk, m, 64);
+            if (gm != gm) { if (lane == 0) *err = SMCMI_ERR_NAN_ESS; return; }
+            hi = cm; ghi = gm;
+            if (lane == 0) { S.phi_prop = cm; S.j += m; }
+        } else {
+            const int j_new = S.j + (nv - 1);
+            const double clast = __shfl(ck, nv - 1, 64);
+            if (j_new > n_phi) {                         // ϕ_prop == 1 and g(1) >= 0 -> ϕ_n = 1 (helpers.jl:51-53)
+                if (lane == 0) { S.lo = lo; S.glo = glo; S.phi_prop = clast; S.j = j_new; S.phi_n = clast; S.mode = MODE_FINAL; }
+                return;
+            }
+            int c = n_phi - j_new + 1;                   // continue the scan with the next chunk of the schedule
+            if (c > KC) c = KC;
+            if (lane < c) S.cand[lane] = sched[j_new - 1 + lane];
+            if (lane == 0) { S.lo = lo; S.glo = glo; S.n_valid = c; S.j = j_new + 1; S.phi_prop = sched[j_new - 1]; }
+            return;                                      // stay in SCAN
+        }
+    } else {
+        if (m >= 0) {
+            hi = __shfl(ck, m, 64); ghi = __shfl(gk, m, 64);
+            if (m > 0) { lo = __shfl(ck, m - 1, 64); glo = __shfl(gk, m - 1, 64); }
+        } else if (nv > 0) {
+            lo = __shfl(ck, nv - 1, 64); glo = __shfl(gk, nv - 1, 64);
+        }
+    }
+    // ---- section candidates for the bracket (lo, hi)
+    const double h = hi - lo;
     int c = 0;
     if (h > rtol * hi) {
         double t = 0.5;
-        if (S.glo > S.ghi && S.glo < 1e300 && S.ghi > -1e300) t = S.glo / (S.glo - S.ghi);
+        if (glo > ghi && glo < 1e300 && ghi > -1e300) t = glo / (glo - ghi);
         const double xs = lo + h * t;
-        // ascending list: xs - h r0 < ... < xs - h r5 < xs < xs + h r5 < ... < xs + h r0, merged with lo + h k/4
-        double prev = lo;
-        int u = 1;   // next uniform point
-        for (int q = 0; q < 13; ++q) {
-            double x;
-            if (q < 6) x = xs - h * RING[q];
-            else if (q == 6) x = xs;
-            else x = xs + h * RING[12 - q];
-            while (u <= 3) {
-                const double xu = lo + h * (0.25 * u);
-                if (xu < x) { if (xu > prev && xu < hi && c < KC) { S.cand[c++] = xu; prev = xu; } ++u; }
-                else break;
-            }
-            if (x > prev && x < hi && c < KC) { S.cand[c++] = x; prev = x; }
+        double x = 0.0;
+        if (lane < 6) x = xs - h * RING[lane];
+        else if (lane == 6) x = xs;
+        else if (lane < 13) x = xs + h * RING[12 - lane];
+        else if (lane < 16) x = lo + h * (0.25 * (lane - 12));
+        // rank among the 16 raw values (stable), scatter to sorted order
+        int rank = 0;
+#pragma unroll
+        for (int r = 0; r < KC; ++r) {
+            const double xr = __shfl(x, r, 64);
+            rank += (xr < x || (xr == x && r < lane)) ? 1 : 0;
         }
-        for (; u <= 3; ++u) {
-            const double xu = lo + h * (0.25 * u);
-            if (xu > prev && xu < hi && c < KC) { S.cand[c++] = xu; prev = xu; }
-        }
+        if (lane < KC) srt[rank] = x;
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the wave's LDS writes have landed (single wave, no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+        const double xq = lane < KC ? srt[lane] : 0.0;
+        const double xp = (lane > 0 && lane < KC) ? srt[lane - 1] : lo;
+        const bool ok = lane < KC && xq > lo && xq < hi && (lane == 0 || xq > xp);
+        const unsigned long long okm = __ballot(ok);
+        c = __popcll(okm);
+        if (ok) S.cand[__popcll(okm & ((1ull << lane) - 1ull))] = xq;
     }
-    if (c == 0) {   // bracket at the requested resolution (or no representable interior point)
-        S.phi_n = (fabs(S.glo) <= fabs(S.ghi)) ? lo : hi;
-        S.mode = MODE_FINAL;
-    } else {
-        S.n_valid = c;
-        S.mode = MODE_SECTION;
-    }
-}
-
-// one decision step from the candidate totals tot[0..KC) = Σv, tot[KC..2KC) = Σv² (single thread, S in LDS)
-__device__ inline void solver_decide(Solver &S, const double *tot, const double *sched, int n_phi, double rtol, int *err) {
-    double g[KC];
-    const int nv = S.n_valid;
-#pragma unroll
-    for (int k = 0; k < KC; ++k) g[k] = tot[k] * tot[k] / tot[KC + k] - S.ess_bar;   // ESS(ϕ) = (Σv)²/Σv²
-    int m = -1;
-#pragma unroll
-    for (int k = KC - 1; k >= 0; --k)
-        if (k < nv && !(g[k] >= 0.0)) m = k;
-    if (S.mode == MODE_SCAN) {
-        // candidate 0 is the current ϕ_prop, candidate q > 0 is schedule[j + q - 1] (1-based j)
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-            if (k < nv && (m < 0 || k < m) && S.cand[k] > S.lo) { S.lo = S.cand[k]; S.glo = g[k]; }
-        if (m >= 0) {
-            double gm = 0.0, cm = 0.0;
-#pragma unroll
-            for (int k = 0; k < KC; ++k)
-                if (k == m) { gm = g[k]; cm = S.cand[k]; }
-            if (gm != gm) { *err = SMCMI_ERR_NAN_ESS; return; }
-            S.phi_prop = cm; S.j += m; S.hi = cm; S.ghi = gm;
+    if (lane == 0) {
+        S.lo = lo; S.hi = hi; S.glo = glo; S.ghi = ghi;
+        if (c == 0) {   // bracket at the requested resolution (or no representable interior point)
+            S.phi_n = (fabs(glo) <= fabs(ghi)) ? lo : hi;
+            S.mode = MODE_FINAL;
         } else {
-            const int j_new = S.j + (nv - 1);
-            double clast = 0.0;
-#pragma unroll
-            for (int k = 0; k < KC; ++k)
-                if (k == nv - 1) clast = S.cand[k];
-            S.phi_prop = clast;
-            S.j = j_new;
-            if (j_new > n_phi) { S.phi_n = clast; S.mode = MODE_FINAL; return; }   // ϕ_prop == 1 and g(1) >= 0 (helpers.jl:51-53)
-            int c = 0;
-            for (int jj = j_new; jj <= n_phi && c < KC; ++jj) S.cand[c++] = sched[jj - 1];
             S.n_valid = c;
-            S.j = j_new + 1;            // cand[0] is schedule[j_new]: keeps "cand[q] == schedule[j + q - 1]"
-            S.phi_prop = S.cand[0];
-            return;                     // stay in SCAN
-        }
-    } else {
-        if (m >= 0) {
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                if (k == m) { S.hi = S.cand[k]; S.ghi = g[k]; }
-                if (k == m - 1) { S.lo = S.cand[k]; S.glo = g[k]; }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < KC; ++k)
-                if (k == nv - 1) { S.lo = S.cand[k]; S.glo = g[k]; }
+            S.mode = MODE_SECTION;
         }
     }
-    section_candidates(S, rtol);
 }
 
 // Prologue shared by every pass kernel: bring the solver state of pass p into LDS.  p == 0 reads copy 0 as written by
 // k_stage_begin; p > 0 reduces the partials of pass p-1 and takes the decision; block 0 publishes copy p&1.
 // Returns through *S; all threads must call.  scratch: TB doubles, tot: 2 KC doubles (LDS).
 __device__ inline void solver_prologue(DevState *st, const double *sched, const double *partials_prev, int nb, int p,
-                                       Solver *S, double *scratch, double *tot, int force_final) {
+                                       Solver *S, double *scratch, double *tot, int force_final, int done = 0) {
     const int t = threadIdx.x;
     constexpr int NW = sizeof(Solver) / sizeof(double);
     static_assert(sizeof(Solver) % sizeof(double) == 0, "Solver must be a whole number of doubles");
     const Solver *src = &st->sol[p == 0 ? 0 : ((p - 1) & 1)];
     if (t < NW) reinterpret_cast<double *>(S)[t] = reinterpret_cast<const double *>(src)[t];
     __syncthreads();
-    if (p == 0) return;
+    if (p == 0 || done) return;
     const int mode = S->mode;
     if (mode == MODE_SCAN || mode == MODE_SECTION) {
         const double v = final_sum(partials_prev, nb, 2 * KC, scratch);
         if (t < 2 * KC) tot[t] = v;
         __syncthreads();
+        __shared__ int s_err;
+        if (t == 0) s_err = 0;
+        __syncthreads();
+        if (t < 64) solver_decide_wave(*S, tot, sched, st->rp.n_phi, st->rp.phi_rtol, &s_err, scratch);
+        __syncthreads();
         if (t == 0) {
-            int err = 0;
-            solver_decide(*S, tot, sched, st->rp.n_phi, st->rp.phi_rtol, &err);
+            int err = s_err;
             if (force_final && S->mode != MODE_FINAL && !err) {   // out of passes: accept the current bracket
                 if (S->mode == MODE_SECTION) { S->phi_n = (fabs(S->glo) <= fabs(S->ghi)) ? S->lo : S->hi; S->unconverged += 1; S->mode = MODE_FINAL; }
                 else err = SMCMI_ERR_BRACKET;                       // still scanning the schedule
@@ -278,18 +299,20 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
     __shared__ double scratch[TB];
     __shared__ double tot[2 * KC];
     __shared__ Solver S;
-    if (st->done) return;
-    solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, FINAL ? 1 : 0);
-    const int mode = S.mode;
-    if (FINAL ? (mode != MODE_FINAL) : (mode != MODE_SCAN && mode != MODE_SECTION)) return;
-    const int src = st->cur, nv = S.n_valid;
+    // independent scalar loads first (one memory round trip): done flag, buffer index, ϕ_{n-1}, solver copy
+    const int done = st->done, src = st->cur;
     const double phi_prev = st->phi_prev;
-    const int R = cl.R;
-    const double *loglh = col(cl, src, R - 5), *old = col(cl, src, R - 3);
-    double *w = col(cl, src, R - 1);
     const double pw = st->rp.pw, logp_old = st->rp.logp_old;
     const int stage_col = st->stage - 1;
     const bool hist = FINAL && st->rp.store_history && hist_w != nullptr;
+    solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, FINAL ? 1 : 0, done);
+    if (done) return;
+    const int mode = S.mode;
+    if (FINAL ? (mode != MODE_FINAL) : (mode != MODE_SCAN && mode != MODE_SECTION)) return;
+    const int nv = S.n_valid;
+    const int R = cl.R;
+    const double *loglh = col(cl, src, R - 5), *old = col(cl, src, R - 3);
+    double *w = col(cl, src, R - 1);
     double acc[2 * K];
 #pragma unroll
     for (int k = 0; k < 2 * K; ++k) acc[k] = 0.0;
@@ -385,33 +408,37 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
     __shared__ double scratch[TB];
     __shared__ double s_tot[2];
     __shared__ int s_rs;
-    if (st->done) return;
     const Solver &S = st->sol[sol_slot];
-    if (S.mode != MODE_FINAL) {       // cannot happen unless a pass kernel flagged an error
+    // every scalar the decision needs, loaded up front together with the partial sums (one memory round trip)
+    const int done = st->done, smode = S.mode;
+    const double N = (double)st->rp.n_parts, a = st->accept, tg = st->rp.target, c0 = st->c, thr = st->rp.threshold;
+    const double phi_n = S.phi_n, phi_prop = S.phi_prop, logz = st->logz;
+    const int i = st->stage, jj = S.j, resamples = st->resamples;
+    const double v = final_sum(partials, nb, 2, scratch);
+    if (done) return;
+    if (smode != MODE_FINAL) {       // cannot happen unless a pass kernel flagged an error
         if (threadIdx.x == 0) { st->err = SMCMI_ERR_BRACKET; st->done = 1; }
         return;
     }
-    const double v = final_sum(partials, nb, 2, scratch);
     if (threadIdx.x < 2) s_tot[threadIdx.x] = v;
     if (threadIdx.x == 0) s_rs = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double s1 = s_tot[0], s2 = s_tot[1], N = (double)st->rp.n_parts;
-        const double ess = s1 * s1 / s2, a = st->accept, tg = st->rp.target, c0 = st->c, thr = st->rp.threshold;
-        const double phi_n = S.phi_n, phi_prop = S.phi_prop, logz = st->logz;
-        const int i = st->stage, jj = S.j;
+        const double s1 = s_tot[0], s2 = s_tot[1];
+        const double ess = s1 * s1 / s2;
+        const bool bad = isnan(ess);
+        const int rs = (!bad && ess < thr) ? 1 : 0;
+        const double c1 = c0 * (0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))));
         st->phi_n = phi_n; st->phi_prop = phi_prop; st->j = jj;
         st->sumw = s1; st->sumw2 = s2; st->ess = ess; st->ess_prev = ess;
         rec.phi[i - 1] = phi_n;
         rec.ess[i - 1] = ess;
-        if (isnan(ess)) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; }     // check_nan_ess, helpers.jl:270-305
+        if (bad) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; }     // check_nan_ess, helpers.jl:270-305
         else {
             st->logz = logz + log(s1 / N);
-            const int rs = ess < thr;
             st->do_resample = rs;
             rec.resampled[i - 1] = rs;
-            if (rs) { st->resamples += 1; st->resampled_last = 1; }
-            const double c1 = c0 * (0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))));
+            if (rs) { st->resamples = resamples + 1; st->resampled_last = 1; }
             st->c = c1;
             rec.c[i - 1] = c1;
             s_rs = rs;
@@ -500,8 +527,16 @@ __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevS
     const long long a = lo < n_cum ? lo : n_cum - 1;
     if (anc) anc[k] = a;
     const int src = st->cur, dst = full ? src : (src ^ 1), R = cl.R;
-    for (int c = 0; c < R - 1; ++c)
-        col(cl, dst, c)[k] = full ? full[(long long)c * n_cum + a] : col(cl, src, c)[a];
+    const double *from = full ? full : cl.buf[src];
+    const long long ldf = full ? n_cum : cl.n;
+    for (int c0 = 0; c0 < R - 1; c0 += 8) {          // 8 indexed loads in flight, then the coalesced stores
+        double tmp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tmp[q] = (c0 + q < R - 1) ? from[(long long)(c0 + q) * ldf + a] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (c0 + q < R - 1) col(cl, dst, c0 + q)[k] = tmp[q];
+    }
     col(cl, dst, R - 1)[k] = 1.0;
 }
 
@@ -595,6 +630,62 @@ __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, doub
     }
 }
 
+// Register-resident variant for d <= 12: one thread streams particles (coalesced 8-byte column reads) and keeps all
+// (d+1)(d+2)/2 augmented pair sums in VGPRs with compile-time indices - no LDS traffic in the main loop, 1 FMA per pair
+// per particle, so the pass is HBM-bound.  Same outputs (normalised weights, W history, per-block pair partials in the
+// same (a <= b) order) as k_moments.
+template <int D>
+__global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, double *partials, double *hist_W,
+                                                    long long hist_ld, int standalone) {
+    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2;
+    constexpr int NCH = (NP + 63) / 64;                  // chunks of 64 accumulators for the block reduction
+    __shared__ double red[(TB / 64) * 64];
+    if (!standalone && st->done) return;
+    const int resampled = standalone ? 0 : st->do_resample;
+    const int src = st->cur ^ resampled;
+    double *w = col(cl, src, cl.R - 1);
+    const double N = (double)st->rp.n_parts, sumw = st->sumw;
+    const int stage_col = st->stage - 1;
+    const bool hist = !standalone && st->rp.store_history && hist_W != nullptr;
+    double sh[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) sh[a] = st->shift[a];
+    double acc[NCH * 64];
+#pragma unroll
+    for (int p = 0; p < NCH * 64; ++p) acc[p] = 0.0;
+    long long beg, end;
+    block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
+    for (long long i = beg + threadIdx.x; i < end; i += TB) {
+        double wi;
+        if (standalone) wi = w[i];
+        else {
+            wi = resampled ? 1.0 : (w[i] * N) / sumw;
+            w[i] = wi;
+            if (hist) hist_W[(long long)stage_col * hist_ld + i] = wi;
+        }
+        double x[DA];
+        x[0] = 1.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) x[a + 1] = col(cl, src, a)[i] - sh[a];
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < DA; ++a) {
+            const double wx = wi * x[a];
+#pragma unroll
+            for (int b = a; b < DA; ++b) { acc[p] += wx * x[b]; ++p; }
+        }
+    }
+    double *out = partials + (long long)blockIdx.x * NP;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double a64[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
+        const double tot = block_reduce_many<64>(a64, red);
+        if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NP) out[ch * 64 + threadIdx.x] = tot;
+    }
+}
+
 // Fixed-order reduction of the moment partials: totals[p] for the (d+1)(d+2)/2 pairs, 1024 threads per block:
 // thread (s, idx) sums blocks b = s (mod 16) of pair p0 + idx; grid = ceil(npairs / 64).
 __global__ void __launch_bounds__(1024) k_moments_reduce(const DevState *st, const double *partials, int nb, int npairs,
@@ -678,33 +769,84 @@ __global__ void k_chunk_offsets(DevState *st, const double *partials, int nb, do
 }
 __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 
-// θ_bar, R from the totals; free subset + symmetrisation (src/smc_main.jl:457-465); random blocks
+// θ_bar, R from the moment partials; free subset + symmetrisation (src/smc_main.jl:457-465); random blocks
 // (generate_free_blocks/all_blocks, src/helpers.jl:215-260, Fisher-Yates on Philox); then per block the scaled
 // covariance c²Σ_b and its Cholesky factor - done ONCE per stage instead of per particle (src/mutation.jl:81,
-// src/helpers.jl:90-94,135-155).  One block of 64 threads; all matrix work happens in LDS.
-__global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const ModelDev *md, const double *totals,
+// src/helpers.jl:90-94,135-155).  One block of 256 threads; all matrix work happens in LDS, DevState is written once.
+// from_totals: 0 = use st->mean / st->cov as given (stand-alone mutation), 1 = reduce `partials` (nb blocks x npairs,
+// fixed order) first, 2 = `partials` already holds the npairs totals.
+constexpr int PT = 1024;  // threads of the single prepare block
+__global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
                                                          int standalone) {
-    __shared__ double A[MAXD * MAXD];
-    __shared__ double Ls[MAXD * MAXD];
-    __shared__ double sig_f[MAXD * MAXD];
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    __shared__ double scratch[PT];
     __shared__ double mu_f[MAXD];
-    __shared__ int bfree[MAXD], bptr[MAXD + 1];
+    __shared__ int bfree[MAXD], bptr[MAXD + 1], fi[MAXD];
     __shared__ int s_fail;
     if (!standalone && st->done) return;
-    const int d = md->d, nf = md->n_free, t = threadIdx.x;
+    const int d = md->d, nf = md->n_free, t = threadIdx.x, da = d + 1, npairs = da * (da + 1) / 2;
+    double *tot = psm;                       // [npairs] (rounded up to 64)
+    double *covl = tot + ((npairs + 63) / 64) * 64;   // [d*d]
+    double *sig_f = covl + d * d;            // [nf*nf]
+    double *A = sig_f + nf * nf;             // [nf*nf] scaled block covariance
+    double *Ls = A + nf * nf;                // [nf*nf] factor of the current block
     if (t == 0) s_fail = 0;
-    if (from_totals) moments_from_totals(st, totals, d, t, 64);
-    __syncthreads();
-    // R_fr = (R[f,f] + R[f,f]')/2, θ_bar_fr
-    for (int e = t; e < nf * nf; e += 64) {
-        const int a = md->free_inds[e / nf], b = md->free_inds[e % nf];
-        sig_f[e] = (st->cov[a * d + b] + st->cov[b * d + a]) / 2.0;
+    if (t < nf) fi[t] = md->free_inds[t];
+    const double c = st->c;
+    if (from_totals) {
+        if (from_totals == 1) {
+            for (int p0 = 0; p0 < npairs; p0 += 64) {
+                const int m = (npairs - p0) < 64 ? (npairs - p0) : 64;
+                // pad to 64-wide rows so every 64-thread slice adds whole blocks; out-of-range idx contribute nothing
+                const int idx = t % 64, sl = t / 64;          // 16 slices of blocks
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                if (idx < m) {
+                    const double *pp = partials + p0 + idx;
+                    int b = sl;
+                    for (; b + 48 < nb_part; b += 64) {
+                        a0 += pp[(long long)b * npairs]; a1 += pp[(long long)(b + 16) * npairs];
+                        a2 += pp[(long long)(b + 32) * npairs]; a3 += pp[(long long)(b + 48) * npairs];
+                    }
+                    for (; b < nb_part; b += 16) a0 += pp[(long long)b * npairs];
+                }
+                scratch[t] = (a0 + a1) + (a2 + a3);
+                __syncthreads();
+                if (t < m) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc += scratch[q * 64 + t];
+                    tot[p0 + t] = acc;
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int p = t; p < npairs; p += PT) tot[p] = partials[p];
+            __syncthreads();
+        }
+        const double sw = tot[0];
+        for (int e = t; e < d * d; e += PT) {
+            int a = e / d, b = e % d;
+            if (a > b) { const int tmp = a; a = b; b = tmp; }
+            const int ra = a + 1, rb = b + 1;
+            const int p = ra * da - ra * (ra - 1) / 2 + (rb - ra);
+            const double v = tot[p] / sw - (tot[a + 1] / sw) * (tot[b + 1] / sw);
+            covl[e] = v;
+            st->cov[e] = v;
+        }
+        for (int a = t; a < d; a += PT) {
+            const double mn = st->shift[a] + tot[a + 1] / sw;
+            scratch[a] = mn;                       // d <= MAXD <= TB
+            st->mean[a] = mn;
+            st->shift[a] = mn;
+        }
+    } else {
+        for (int e = t; e < d * d; e += PT) covl[e] = st->cov[e];
+        for (int a = t; a < d; a += PT) scratch[a] = st->mean[a];
     }
-    for (int a = t; a < nf; a += 64) mu_f[a] = st->mean[md->free_inds[a]];
     const int nb = gen_blocks ? st->rp.n_blocks : st->n_blocks;
     if (gen_blocks) {
-        if (t == 0) {
+        if (t == 64) {                       // a lane of another wave shuffles while wave 0 finishes the covariance
             const unsigned stage = (unsigned)st->stage;
             for (int i = 0; i < nf; ++i) bfree[i] = i;
             for (int i = nf - 1; i >= 1; --i) {
@@ -719,15 +861,21 @@ __global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const Mod
             bptr[nb] = nf;
         }
     } else {
-        for (int i = t; i < nf; i += 64) bfree[i] = st->blocks_free[i];
-        for (int b = t; b <= nb; b += 64) bptr[b] = st->block_ptr[b];
+        for (int i = t; i < nf; i += PT) bfree[i] = st->blocks_free[i];
+        for (int b = t; b <= nb; b += PT) bptr[b] = st->block_ptr[b];
     }
     __syncthreads();
-    const double c = st->c;
-    for (int i = t; i < nf; i += 64) {
+    // R_fr = (R[f,f] + R[f,f]')/2, θ_bar_fr
+    for (int e = t; e < nf * nf; e += PT) {
+        const int a = fi[e / nf], b = fi[e % nf];
+        sig_f[e] = (covl[a * d + b] + covl[b * d + a]) / 2.0;
+    }
+    for (int a = t; a < nf; a += PT) mu_f[a] = scratch[fi[a]];
+    __syncthreads();
+    for (int i = t; i < nf; i += PT) {
         const int f = bfree[i];
         st->blocks_free[i] = f;
-        st->blocks_all[i] = md->free_inds[f];
+        st->blocks_all[i] = fi[f];
         st->mu_b[i] = mu_f[f];
         st->sd_draw[i] = sqrt(c * c * sig_f[f * nf + f]);
         st->sd_dens[i] = sqrt(sig_f[f * nf + f]);
@@ -736,7 +884,7 @@ __global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const Mod
     for (int b = 0; b < nb; ++b) {
         const int p0 = bptr[b], db = bptr[b + 1] - p0;
         if (db > max_db) max_db = db;
-        for (int e = t; e < db * db; e += 64) {
+        for (int e = t; e < db * db; e += PT) {
             A[e] = c * c * sig_f[bfree[p0 + e / db] * nf + bfree[p0 + e % db]];
             Ls[e] = 0.0;
         }
@@ -759,7 +907,7 @@ __global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const Mod
             __syncthreads();
         }
         if (s_fail) break;
-        for (int e = t; e < db * db; e += 64) st->L[off + e] = Ls[e];
+        for (int e = t; e < db * db; e += PT) st->L[off + e] = Ls[e];
         if (t == 0) {
             double ld = 0.0;
             for (int i = 0; i < db; ++i) ld += log(Ls[i * db + i]);
@@ -769,8 +917,7 @@ __global__ void __launch_bounds__(64) k_prepare_mutation(DevState *st, const Mod
         off += db * db;
         __syncthreads();
     }
-    if (t <= nb) st->block_ptr[t] = bptr[t];
-    for (int b = 64 + t; b <= nb; b += 64) st->block_ptr[b] = bptr[b];
+    for (int b = t; b <= nb; b += PT) st->block_ptr[b] = bptr[b];
     if (t == 0) {
         st->n_blocks = nb;
         st->max_db = max_db;
@@ -795,6 +942,8 @@ struct MutArgs {
     const double *lik_new, *lik_old_new;   // MODE 2
     int *acc_count;            // MODE 1/2: accepted block lengths so far
     int block, step, last;     // MODE 1/2
+    long long *prof;           // development only: per-phase shader-clock stamps of block 0 / middle block, wave 0
+    int debug;                 // development only (tools/kbench.py): bit0 skip normals, bit1 skip prior/likelihood, bit2 skip matvec
 };
 
 template <int MODE>
@@ -818,8 +967,9 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     const int nb = st->n_blocks, n_steps = st->mut_steps;
     double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
     if (live) {
-        for (int k = 0; k < d; ++k) { const double x = col(cl, src, k)[i]; th[k * T + tid] = x; tn[k * T + tid] = x; }
         like = col(cl, src, d)[i]; lprior = col(cl, src, d + 1)[i]; like_prev = col(cl, src, d + 2)[i];
+        load_columns(cl.buf[src], cl.n, i, d, th + tid, T);
+        for (int k = 0; k < d; ++k) tn[k * T + tid] = th[k * T + tid];
     }
     auto TN = [&](int k) { return tn[k * T + tid]; };
     if (live) {
@@ -968,55 +1118,127 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     }
 }
 
-// Register-resident mutation for blocks of at most DB parameters (MODE 0 of k_mutate, same arithmetic in the same
-// order): the block's z / draw / solve vectors live in VGPRs with compile-time indices, the block factor L and the
-// other per-block constants are staged once into LDS (uniform-address reads), only the parameter vector itself sits in
-// per-thread LDS columns because block membership is a run-time index and the likelihood reads it by position.
-template <int DB>
-__global__ void __launch_bounds__(256) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
-                                                   double *acc_partials, int standalone) {
+// Register-resident mutation for models with D = n_para <= 10 (MODE 0 of k_mutate, same arithmetic in the same order).
+// Everything per-particle lives in VGPRs with compile-time indices: the parameter vector x[D], and the block's z / draw /
+// solve vectors (padded to D entries; identity-padded factor).  Block membership is a run-time (but wave-uniform) index,
+// so gathering θ_b and scattering the proposal back are D x D chains of uniform selects instead of memory indexing -
+// at ~1.5 wavefronts per SIMD (N = 1e5) every LDS / global round trip is exposed latency, a select is not.
+// The block factor L, the block constants and the model constants are staged once into LDS (uniform-address reads).
+template <int D, bool ALPHA1>
+__global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
+                                                   double *acc_partials, int standalone, int nb, int nf) {
+#pragma clang fp contract(fast)
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (!standalone && st->done) return;
     const int T = blockDim.x, tid = threadIdx.x;
-    const int d = md->d, nf = md->n_free;
-    double *th = sm;                                // θ [d][T]
-    double *Ls = th + (long long)d * T;             // [DB*DB] row-major with stride DB, identity-padded
-    double *mu_s = Ls + DB * DB;                    // [DB]
-    double *sdd_s = mu_s + DB, *sdn_s = sdd_s + DB; // [DB] each
-    double *red = sdn_s + DB;                       // [T/64]
-    int *ball_s = (int *)(red + 4);                 // [DB]
-    const long long i = (long long)blockIdx.x * T + tid;
-    const bool live = i < cl.n;
-    const int src = standalone ? st->cur : (st->cur ^ st->do_resample);
-    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    const bool profme = ma.prof != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);
+    long long *profp = ma.prof + (blockIdx.x == 0 ? 0 : 16);
+#define SMCMI_PROF(slot)                                                                                    \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (profme) { unsigned long long tt_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory"); profp[slot] = (long long)tt_; } \
+    } while (0)
+    SMCMI_PROF(0);
+    double *Ls = sm;                                // [D*D] row-major with stride D, identity-padded
+    double *mu_s = Ls + D * D;                      // [D]
+    double *sdd_s = mu_s + D, *sdn_s = sdd_s + D;   // [D] each
+    double *red = sdn_s + D;                        // [4]
+    double *m_lo = red + 4;
+    double *m_hi = m_lo + D, *m_a = m_hi + D, *m_b = m_a + D, *m_k = m_b + D;
+    double *l_par = m_k + D;                        // [2 * LIK_PAR_MAX]
+    double *l_dat = l_par + 2 * LIK_PAR_MAX;        // [LIK_LDS_CAP]
+    double *Lraw = l_dat + LIK_LDS_CAP;             // [D*D] packed block factors as k_prepare_mutation wrote them
+    double *logdet_s = Lraw + D * D;                // [D]
+    double *mub_raw = logdet_s + D, *sdd_raw = mub_raw + D, *sdn_raw = sdd_raw + D;   // [D] each, block order
+    int *ball_s = (int *)(sdn_raw + D);             // [D]
+    int *m_fix = ball_s + D + (D & 1), *m_fam = m_fix + D;
+    int *bptr_s = m_fam + D, *loff_s = bptr_s + D + 1, *ball_raw = loff_s + D;
+    // ---- round 1: every uniform input of the launch, issued back to back (a dependent global round trip costs ~1 µs
+    // at this occupancy, so the kernel is organised as: one round of parameter loads, one round of particle loads,
+    // compute, one round of stores).  nb / nf are launch arguments so the copy extents do not depend on loaded data.
+    const int done = st->done, cur = st->cur, rsf = st->do_resample, n_steps = st->mut_steps;
     const unsigned stage = st->mut_stage;
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
-    const int nb = st->n_blocks, n_steps = st->mut_steps;
-    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
-    if (live) {
-        for (int k = 0; k < d; ++k) th[k * T + tid] = col(cl, src, k)[i];
-        like = col(cl, src, d)[i]; lprior = col(cl, src, d + 1)[i]; like_prev = col(cl, src, d + 2)[i];
+    for (int e = tid; e < nf * nf; e += T) Lraw[e] = st->L[e];
+    for (int e = tid; e < nf; e += T) {
+        mub_raw[e] = st->mu_b[e]; sdd_raw[e] = st->sd_draw[e]; sdn_raw[e] = st->sd_dens[e]; ball_raw[e] = st->blocks_all[e];
     }
-    auto TH = [&](int k) { return th[k * T + tid]; };
+    for (int b = tid; b < nb; b += T) { loff_s[b] = st->l_off[b]; logdet_s[b] = st->logdet[b]; }
+    for (int b = tid; b <= nb; b += T) bptr_s[b] = st->block_ptr[b];
+    for (int k = tid; k < D; k += T) {
+        m_lo[k] = md->lo[k]; m_hi[k] = md->hi[k]; m_a[k] = md->prior_a[k]; m_b[k] = md->prior_b[k]; m_k[k] = md->prior_k[k];
+        m_fix[k] = md->fixed[k]; m_fam[k] = md->prior_family[k];
+    }
+    for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
+    const LikDev ld0 = md->lik[0], ld1 = md->lik[1];
+    const int has_other = md->has_other_priors;
+    if (!standalone && done) return;
+    SMCMI_PROF(1);
+    // ---- round 2: the particle and the likelihood data
+    const long long i = (long long)blockIdx.x * T + tid;
+    const bool live = i < cl.n;
+    const int src = standalone ? cur : (cur ^ rsf);
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = 0.0;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[i];
+        like = col(cl, src, D)[i]; lprior = col(cl, src, D + 1)[i]; like_prev = col(cl, src, D + 2)[i];
+    }
+    ModelView mv{D, m_fix, m_fam, m_lo, m_hi, m_a, m_b, m_k};
+    LikView lv[2];
+    {
+        int used = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const LikDev &ld = q == 0 ? ld0 : ld1;
+            const long long nd = ld.rows * ld.cols, na = ld.aux_rows * ld.aux_cols;
+            const bool fits = ld.family >= 0 && used + nd + na <= LIK_LDS_CAP;
+            if (fits) {
+                for (long long k = tid; k < nd; k += T) l_dat[used + k] = ld.data[k];
+                for (long long k = tid; k < na; k += T) l_dat[used + nd + k] = ld.aux[k];
+            }
+            lv[q] = LikView{ld.family, l_par + q * LIK_PAR_MAX, ld.c0, fits ? l_dat + used : ld.data, ld.rows, ld.cols,
+                            fits ? l_dat + used + nd : ld.aux, ld.aux_rows, ld.aux_cols};
+            if (fits) used += (int)(nd + na);
+        }
+    }
+    SMCMI_PROF(2);
+    auto XN = [&](int k) { return x[k]; };
     for (int step = 0; step < n_steps; ++step) {
         for (int b = 0; b < nb; ++b) {
-            const int p0 = st->block_ptr[b], db = st->block_ptr[b + 1] - p0;
-            if (nb > 1 || step == 0) {              // (re)stage this block's constants
-                __syncthreads();
-                const double *L = st->L + st->l_off[b];
-                for (int e = tid; e < DB * DB; e += T) {
-                    const int r = e / DB, cidx = e % DB;
+            if (nb > 1 || step == 0) __syncthreads();   // raw copies (first pass) / previous block's readers (later passes)
+            const int p0 = bptr_s[b], db = bptr_s[b + 1] - p0;
+            if (nb > 1 || step == 0) {              // expand this block's constants to the padded D x D form
+                const double *L = Lraw + loff_s[b];
+                if constexpr (ALPHA1) {
+                    // α = 1 only ever draws θ_b + L z.  Store the factor with its rows scattered to NATURAL parameter
+                    // order, M[k][:] = L[e][:] for k = blocks_all[e] (zero rows elsewhere): the proposal becomes
+                    // x_k + Σ_e M[k][e] z_e with compile-time indices - no gather / scatter of the parameter vector at all
+                    // (the added zero terms do not change any sum).
+                    for (int e = tid; e < D * D; e += T) Ls[e] = 0.0;
+                    __syncthreads();
+                    for (int e = tid; e < db * db; e += T) {
+                        const int r = e / db, cidx = e % db;
+                        if (cidx <= r) Ls[cidx * D + ball_raw[p0 + r]] = L[r * db + cidx];   // transposed: Ls[e][k] = M[k][e]
+                    }
+                } else
+                for (int e = tid; e < D * D; e += T) {
+                    const int r = e / D, cidx = e % D;
                     Ls[e] = (r < db && cidx < db) ? L[r * db + cidx] : (r == cidx ? 1.0 : 0.0);
                 }
-                for (int e = tid; e < DB; e += T) {
+                for (int e = tid; e < D; e += T) {
                     const bool in = e < db;
-                    mu_s[e] = in ? st->mu_b[p0 + e] : 0.0;
-                    sdd_s[e] = in ? st->sd_draw[p0 + e] : 0.0;
-                    sdn_s[e] = in ? st->sd_dens[p0 + e] : 1.0;
-                    ball_s[e] = in ? st->blocks_all[p0 + e] : 0;
+                    mu_s[e] = in ? mub_raw[p0 + e] : 0.0;
+                    sdd_s[e] = in ? sdd_raw[p0 + e] : 0.0;
+                    sdn_s[e] = in ? sdn_raw[p0 + e] : 1.0;
+                    ball_s[e] = in ? ball_raw[p0 + e] : -1;
                 }
                 __syncthreads();
             }
+            SMCMI_PROF(3);
             if (!live) continue;
             const unsigned t = (unsigned)(step * nb + b);
             double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
@@ -1025,96 +1247,175 @@ __global__ void __launch_bounds__(256) k_mutate_reg(CloudPtrs cl, const DevState
             // ---- mvnormal_mixture_draw (src/helpers.jl:87-100)
             double uc, unext;
             uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
-            double z[DB], sub[DB], dr[DB], v[DB];
+            double z[D], sub[D], dr[D];
+            {
+                // Box-Muller for the block, written stage by stage over all pairs so the independent log / sqrt / sincospi
+                // chains can be interleaved by the scheduler (at <= 2 wavefronts per SIMD dependent FP64 latency is exposed)
+                constexpr int NP2 = (D + 1) / 2;
+                constexpr int GRP = 2;                     // pairs interleaved at a time (more raises register pressure past 2 waves/SIMD)
+                double ua[NP2], ub[NP2], rr[NP2], sn[NP2], cs[NP2];
 #pragma unroll
-            for (int e = 0; e < DB; e += 2) {
-                double z0 = 0.0, z1 = 0.0;
-                if (e < db) normal_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 1 + e / 2), z0, z1);
-                z[e] = z0;
-                if (e + 1 < DB) z[e + 1] = (e + 1 < db) ? z1 : 0.0;
+                for (int q = 0; q < NP2; ++q) {
+                    ua[q] = 0.5; ub[q] = 0.0;
+                    if (2 * q < db) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua[q], ub[q]);
+                }
+#pragma unroll
+                for (int g0 = 0; g0 < NP2; g0 += GRP) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) rr[q] = log(ua[q]);
+#pragma unroll
+                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) rr[q] = sqrt(-2.0 * rr[q]);
+#pragma unroll
+                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) sincospi(2.0 * ub[q], &sn[q], &cs[q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NP2; ++q) {
+                    if (ma.debug & 1) { rr[q] = 1.0; cs[q] = uc - 0.5; sn[q] = unext - 0.5; }
+                    z[2 * q] = (2 * q < db) ? rr[q] * cs[q] : 0.0;
+                    if (2 * q + 1 < D) z[2 * q + 1] = (2 * q + 1 < db) ? rr[q] * sn[q] : 0.0;
+                }
+#pragma unroll
+                for (int e = 0; e < D; ++e) asm volatile("" : "+v"(z[e]));   // materialise the normals here (see the matvec note)
             }
+            SMCMI_PROF(4);
+            double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
+            double q0 = 0.0, q1 = 0.0;
+            double xo[D];
+            if constexpr (ALPHA1) {
+                double zz2 = 0.0;
 #pragma unroll
-            for (int e = 0; e < DB; ++e) sub[e] = (e < db) ? th[ball_s[e] * T + tid] : 0.0;
+                for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
+                // q0 = q1 = log N(θ_b; ϑ_b, c²Σ) bit for bit (sign-symmetric quadratic form), other mixture terms have weight 0:
+                // q0 - q1 == 0 unless exp() underflows to 0 (log-density < -745.13: the reference gets NaN and rejects).
+                q1 = (-((double)db * LOG2PI + logdet_s[b] + zz2) / 2.0 < -745.1332191019412) ? __builtin_nan("") : 0.0;
+                SMCMI_PROF(5);
+                // column sweep: D independent accumulators (one per parameter), one factor column live at a time; every
+                // accumulator still adds its terms in ascending e, i.e. the same order as the row-wise triangular product
+                double sacc[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { xo[k] = x[k]; sacc[k] = 0.0; }
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc[k] += Ls[e * D + k] * z[e];
+                    // pin the accumulators here: otherwise the optimiser sinks all FMAs to the use site and keeps the whole
+                    // factor (100 LDS values = 200 VGPRs) live, which costs the second wavefront per SIMD
+#pragma unroll
+                    for (int k = 0; k < D; ++k) asm volatile("" : "+v"(sacc[k]));
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] = xo[k] + sacc[k];
+                SMCMI_PROF(6);
+                if (ma.debug & 2) { prior_new = lprior - 0.1 * zz2; like_new = like - 0.2; like_old_data = 0.0; }
+                else if (in_bounds_s<D>(mv, XN)) {
+                    prior_new = logprior_s<D>(mv, XN, has_other);
+                    like_new = loglik_s<D>(lv[0], XN);
+                    if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
+                    like_old_data = (lv[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik_s<D>(lv[1], XN);
+                }
+            } else {
+            // gather θ_b = x[blocks_all[..]]: uniform selects over the register-resident parameter vector
+            int bal[D];
+#pragma unroll
+            for (int e = 0; e < D; ++e) bal[e] = ball_s[e];
+#pragma unroll
+            for (int e = 0; e < D; ++e) {
+                double sv = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) sv = (bal[e] == k) ? x[k] : sv;
+                sub[e] = sv;
+            }
             const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
-            if (comp == 1) {
+            if (comp == 1 || (ma.debug & 4)) {
 #pragma unroll
-                for (int e = 0; e < DB; ++e) dr[e] = sub[e] + sdd_s[e] * z[e];
+                for (int e = 0; e < D; ++e) dr[e] = sub[e] + sdd_s[e] * z[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < DB; ++e) {
+                for (int e = 0; e < D; ++e) {
                     double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k <= e; ++k) s += Ls[e * DB + k] * z[k];
+                    for (int k = 0; k <= e; ++k) s += Ls[e * D + k] * z[k];
                     dr[e] = ((comp == 0) ? sub[e] : mu_s[e]) + s;
                 }
             }
+            SMCMI_PROF(5);
             // ---- compute_proposal_densities (src/helpers.jl:128-164)
-            const double cst = (double)db * LOG2PI + st->logdet[b];
-            double q0, q1;
+            const double cst = (double)db * LOG2PI + logdet_s[b];
             double zz2 = 0.0;
 #pragma unroll
-            for (int e = 0; e < DB; ++e) zz2 += z[e] * z[e];
-            if (c_alpha == 1.0 && -(cst + zz2) / 2.0 > -600.0) {
-                // α = 1: q0 = q1 = log N(θ_b; ϑ_b, c²Σ) bit for bit (the quadratic form is sign-symmetric), the other two
-                // mixture terms carry weight 0, so q0 - q1 == 0 unless exp() underflows (log-density < -745, the
-                // reference then rejects through NaN); |L⁻¹(θ_b-ϑ_b)|² = Σz² up to rounding, far from that edge here.
-                q0 = q1 = 0.0;
+            for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
+            if constexpr (ALPHA1) {
+                // α = 1 (launch-time dispatch): q0 = q1 = log N(θ_b; ϑ_b, c²Σ) bit for bit (the quadratic form is
+                // sign-symmetric) and the other mixture terms carry weight 0, so q0 - q1 == 0 - unless exp() underflows to 0
+                // (log-density < -745.13), where the reference gets log(0) - log(0) = NaN and rejects.  |L⁻¹(θ_b-ϑ_b)|² = Σz².
+                q0 = 0.0;
+                q1 = (-(cst + zz2) / 2.0 < -745.1332191019412) ? __builtin_nan("") : 0.0;
             } else {
-            double quad = 0.0;
+                double v[D];
+                double quad = 0.0;
 #pragma unroll
-            for (int e = 0; e < DB; ++e) {            // L⁻¹(θ_b - ϑ_b): forward == reverse density
-                double s = sub[e] - dr[e];
+                for (int e = 0; e < D; ++e) {            // L⁻¹(θ_b - ϑ_b): forward == reverse density
+                    double s = sub[e] - dr[e];
 #pragma unroll
-                for (int k = 0; k < e; ++k) s -= Ls[e * DB + k] * v[k];
-                v[e] = s / Ls[e * DB + e];
-                quad += v[e] * v[e];
-            }
-            q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;
-            double ind_pdf = 1.0;
-#pragma unroll
-            for (int e = 0; e < DB; ++e) {
-                if (e < db) {
-                    const double sii = sdn_s[e];
-                    const double zz = (sub[e] - dr[e]) / sii;
-                    ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * zz * zz);
+                    for (int k = 0; k < e; ++k) s -= Ls[e * D + k] * v[k];
+                    v[e] = s / Ls[e * D + e];
+                    quad += v[e] * v[e];
                 }
+                q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;
+                double ind_pdf = 1.0;
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+                    if (e < db) {
+                        const double sii = sdn_s[e];
+                        const double zz = (sub[e] - dr[e]) / sii;
+                        ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * zz * zz);
+                    }
+                }
+                q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+                q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+                double quad_s = 0.0, quad_d = 0.0;
+#pragma unroll
+                for (int e = 0; e < D; ++e) {            // log N(θ_b; θ̄_b, c²Σ)
+                    double s = sub[e] - mu_s[e];
+#pragma unroll
+                    for (int k = 0; k < e; ++k) s -= Ls[e * D + k] * v[k];
+                    v[e] = s / Ls[e * D + e];
+                    quad_s += v[e] * v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < D; ++e) {            // log N(ϑ_b; θ̄_b, c²Σ)
+                    double s = dr[e] - mu_s[e];
+#pragma unroll
+                    for (int k = 0; k < e; ++k) s -= Ls[e * D + k] * v[k];
+                    v[e] = s / Ls[e * D + e];
+                    quad_d += v[e] * v[e];
+                }
+                q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
+                q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
+                q0 = log(q0);
+                q1 = log(q1);
+                if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
+                        }
+            SMCMI_PROF(6);
+            // ---- para_new: scatter the proposal into the parameter vector (the old vector stays in xo[])
+#pragma unroll
+            for (int k = 0; k < D; ++k) xo[k] = x[k];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+#pragma unroll
+                for (int e = 0; e < D; ++e) x[k] = (bal[e] == k) ? dr[e] : x[k];
             }
-            q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-            q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-            double quad_s = 0.0, quad_d = 0.0;
-#pragma unroll
-            for (int e = 0; e < DB; ++e) {            // log N(θ_b; θ̄_b, c²Σ)
-                double s = sub[e] - mu_s[e];
-#pragma unroll
-                for (int k = 0; k < e; ++k) s -= Ls[e * DB + k] * v[k];
-                v[e] = s / Ls[e * DB + e];
-                quad_s += v[e] * v[e];
-            }
-#pragma unroll
-            for (int e = 0; e < DB; ++e) {            // log N(ϑ_b; θ̄_b, c²Σ)
-                double s = dr[e] - mu_s[e];
-#pragma unroll
-                for (int k = 0; k < e; ++k) s -= Ls[e * DB + k] * v[k];
-                v[e] = s / Ls[e * DB + e];
-                quad_d += v[e] * v[e];
-            }
-            q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
-            q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
-            q0 = log(q0);
-            q1 = log(q1);
-            if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
-            }
-            // ---- para_new: the proposal temporarily replaces the block inside th
-#pragma unroll
-            for (int e = 0; e < DB; ++e)
-                if (e < db) th[ball_s[e] * T + tid] = dr[e];
-            double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
-            if (in_bounds(*md, TH)) {
-                prior_new = logprior(*md, TH);
-                like_new = loglik(md->lik[0], d, TH);
+            if (ma.debug & 2) { prior_new = lprior - 0.1 * zz2; like_new = like - 0.2; like_old_data = 0.0; }
+            else if (in_bounds_s<D>(mv, XN)) {
+                prior_new = logprior_s<D>(mv, XN, has_other);
+                like_new = loglik_s<D>(lv[0], XN);
                 if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
-                like_old_data = (md->lik[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik(md->lik[1], d, TH);
+                like_old_data = (lv[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik_s<D>(lv[1], XN);
             }
+            }
+            SMCMI_PROF(7);
             const double eta = exp(phi_n * (like_new - like) + (1.0 - phi_n) * (like_old_data - like_prev) +
                                    (prior_new - lprior) + (q0 - q1));
             if (step_prob < eta) {
@@ -1122,19 +1423,20 @@ __global__ void __launch_bounds__(256) k_mutate_reg(CloudPtrs cl, const DevState
                 accept += (double)db;
             } else {
 #pragma unroll
-                for (int e = 0; e < DB; ++e)
-                    if (e < db) th[ball_s[e] * T + tid] = sub[e];
+                for (int k = 0; k < D; ++k) x[k] = xo[k];
             }
         }
     }
+    SMCMI_PROF(8);
     double acc_val = 0.0;
     if (live) {
-        for (int k = 0; k < d; ++k) col(cl, src, k)[i] = th[k * T + tid];
-        col(cl, src, d)[i] = like;
-        col(cl, src, d + 1)[i] = lprior;
-        col(cl, src, d + 2)[i] = like_prev;
+#pragma unroll
+        for (int k = 0; k < D; ++k) col(cl, src, k)[i] = x[k];
+        col(cl, src, D)[i] = like;
+        col(cl, src, D + 1)[i] = lprior;
+        col(cl, src, D + 2)[i] = like_prev;
         acc_val = accept / (double)nf;                      // quirk Q2: normalised by n_free only
-        col(cl, src, d + 3)[i] = acc_val;
+        col(cl, src, D + 3)[i] = acc_val;
     }
     double a1[1] = {acc_val};
     Butterfly<0, 32>::run(a1, tid & 63);
@@ -1146,6 +1448,8 @@ __global__ void __launch_bounds__(256) k_mutate_reg(CloudPtrs cl, const DevState
         for (int w = 0; w < T / 64; ++w) s += red[w];
         acc_partials[blockIdx.x] = s;
     }
+    SMCMI_PROF(9);
+#undef SMCMI_PROF
 }
 
 // ------------------------------------------------------------------------------------------------ initial draw

@@ -42,9 +42,28 @@ __device__ inline double prior_logpdf(int fam, double a, double b, double k, dou
     }
 }
 
-template <class Th>
-__device__ inline bool in_bounds(const ModelDev &m, Th th) {
+// LDS-resident views of the model constants: uniform reads of ModelDev in the per-parameter loops would be global loads
+// with ~1 µs dependent latency each (the compiler cannot prove them invariant), the views make them ds_reads.
+struct ModelView {
+    int d;
+    const int *fixed, *prior_family;
+    const double *lo, *hi, *prior_a, *prior_b, *prior_k;
+};
+struct LikView {
+    int family;
+    const double *par;
+    double c0;
+    const double *data;
+    long long rows, cols;
+    const double *aux;
+    long long aux_rows, aux_cols;
+};
+constexpr int LIK_LDS_CAP = 768;          // doubles of likelihood data + regressors staged in LDS
+
+template <class M, class Th>
+__device__ inline bool in_bounds(const M &m, Th th) {
     bool ok = true;
+#pragma unroll 4
     for (int k = 0; k < m.d; ++k) {
         const double x = th(k);
         ok = ok && (m.lo[k] <= x && x <= m.hi[k]);
@@ -52,11 +71,54 @@ __device__ inline bool in_bounds(const ModelDev &m, Th th) {
     return ok;
 }
 
-template <class Th>
-__device__ inline double logprior(const ModelDev &m, Th th) {
+template <class M, class Th>
+__device__ inline double logprior(const M &m, Th th) {
     double s = 0.0;
+#pragma unroll 4
     for (int k = 0; k < m.d; ++k)
         if (!m.fixed[k]) s += prior_logpdf(m.prior_family[k], m.prior_a[k], m.prior_b[k], m.prior_k[k], th(k));
+    return s;
+}
+
+// Compile-time-d variants: fully unrolled so that th(k) can index a register array.
+template <int D, class M, class Th>
+__device__ inline bool in_bounds_s(const M &m, Th th) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double x = th(k);
+        ok = ok && (m.lo[k] <= x && x <= m.hi[k]);
+    }
+    return ok;
+}
+// Normal and Uniform priors (what the reference's examples and tests use) are evaluated branch-free inside the unrolled
+// loop; the other families go through ONE rolled copy of prior_logpdf (selected by `has_other`), otherwise ten inlined
+// copies of six log()-heavy cases bloat the kernel by ~60 KB of code and the wavefronts stall on instruction fetch.
+template <int D, class M, class Th>
+__device__ inline double logprior_s(const M &m, Th th, int has_other) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const int fam = m.prior_family[k];
+        const double a = m.prior_a[k], b = m.prior_b[k], kk = m.prior_k[k], x = th(k);
+        const double z = (x - a) / b;
+        const double ln = -(z * z + LOG2PI) / 2.0 - kk;
+        const double lu = (a <= x && x <= b) ? kk : SMCMI_NEG_INF;
+        const double v = (fam == SMCMI_PRIOR_NORMAL) ? ln : lu;
+        s += (m.fixed[k] || fam > SMCMI_PRIOR_UNIFORM) ? 0.0 : v;
+    }
+    if (has_other) {
+#pragma nounroll
+        for (int k = 0; k < D; ++k) {
+            const int fam = m.prior_family[k];
+            if (fam > SMCMI_PRIOR_UNIFORM && !m.fixed[k]) {
+                double x = 0.0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) x = (q == k) ? th(q) : x;
+                s += prior_logpdf(fam, m.prior_a[k], m.prior_b[k], m.prior_k[k], x);
+            }
+        }
+    }
     return s;
 }
 
@@ -66,12 +128,13 @@ inline double lik_const_host(int family, const double *par, int d) {
     return 0.0;
 }
 
-template <class Th>
-__device__ inline double loglik(const LikDev &l, int d, Th th) {
+template <class L, class Th>
+__device__ inline double loglik(const L &l, int d, Th th) {
     switch (l.family) {
     case SMCMI_LIK_GAUSS_ISO: {
         const double sig = l.par[0];
         double acc = 0.0;
+#pragma unroll 4
         for (int k = 0; k < d; ++k) { const double e = th(k) - l.data[k]; acc += e * e; }
         return l.c0 - acc / (2.0 * sig * sig);
     }
@@ -81,6 +144,7 @@ __device__ inline double loglik(const LikDev &l, int d, Th th) {
         const double s2 = l.par[0], Nn = (double)n, a = th(0), b = th(1);
         const double term1 = -(Nn / 2.0) * log(2.0 * M_PI) - (Nn / 2.0) * log(s2);
         double dot = 0.0;
+#pragma unroll 4
         for (long long t = 0; t < n; ++t) { const double e = y[t] - a - b * X[t]; dot += e * e; }
         return term1 - (1.0 / (2.0 * s2)) * dot;
     }
@@ -137,5 +201,84 @@ __device__ inline double loglik(const LikDev &l, int d, Th th) {
     default: return NAN;
     }
 }
+
+
+
+template <int D, class L, class Th>
+__device__ inline double loglik_s(const L &l, Th th) {
+    constexpr int d = D;
+    switch (l.family) {
+    case SMCMI_LIK_GAUSS_ISO: {
+        const double sig = l.par[0];
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { const double e = th(k) - l.data[k]; acc += e * e; }
+        return l.c0 - acc / (2.0 * sig * sig);
+    }
+    case SMCMI_LIK_LINREG: if constexpr (D == 2) {  // examples/regression_model/estimate_regression.jl:46-53, data = [y X]
+        const long long n = l.rows;
+        const double *y = l.data, *X = l.data + n;
+        const double s2 = l.par[0], Nn = (double)n, a = th(0), b = th(1);
+        const double term1 = -(Nn / 2.0) * log(2.0 * M_PI) - (Nn / 2.0) * log(s2);
+        double dot = 0.0;
+#pragma unroll 4
+        for (long long t = 0; t < n; ++t) { const double e = y[t] - a - b * X[t]; dot += e * e; }
+        return term1 - (1.0 / (2.0 * s2)) * dot;
+    } else return NAN;
+    case SMCMI_LIK_LINMODEL3: if constexpr (D == 9) {  // test/modelsetup.jl:119-138 loglik_fn
+        const long long T = l.cols;
+        double a[3], b[3], inv[3], det = 1.0;
+        bool singular = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[i] = th(3 * i); b[i] = th(3 * i + 1);
+            const double s = th(3 * i + 2), v = s * s;
+            singular = singular || (v == 0.0);
+            det *= v; inv[i] = 1.0 / v;
+        }
+        if (singular) return SMCMI_NEG_INF;
+        const double term1 = -3.0 / 2.0 * log(2.0 * M_PI) - 1.0 / 2.0 * log(det);
+        double lp = 0.0;
+        for (long long t = 0; t < T; ++t) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double e = l.data[i + 3 * t] - a[i] - b[i] * l.aux[i + l.aux_rows * t];
+                q += e * (inv[i] * e);
+            }
+            lp += term1 - 1.0 / 2.0 * q;
+        }
+        return lp;
+    } else return NAN;
+    case SMCMI_LIK_CAPM_LITERAL: if constexpr (D == 9) {  // examples/capm_model/estimate_capm.jl:52-70 as written (quirk Q12)
+        const long long T = l.cols;
+        double a[3], inv[3], det = 1.0;
+        bool singular = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[i] = th(3 * i);
+            const double s = th(3 * i + 2), v = s * s;
+            singular = singular || (v == 0.0);
+            det *= v; inv[i] = 1.0 / v;
+        }
+        if (singular) return SMCMI_NEG_INF;
+        const double term1 = -3.0 / 2.0 * log(2.0 * M_PI) - 1.0 / 2.0 * log(det);
+        double S = 0.0, lp = 0.0;
+        for (long long t = 0; t < T; ++t) {
+            const double mk = l.aux[l.aux_rows * t];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double e = l.data[i + 3 * t] - a[i] - a[i] * mk;
+                S += e * (inv[i] * e);
+            }
+        }
+        for (long long t = 0; t < T; ++t) lp += term1 - 1.0 / 2.0 * S;
+        return lp;
+    } else return NAN;
+    default: return NAN;
+    }
+}
+
+
 
 }  // namespace smcmi

@@ -51,8 +51,8 @@ struct smcmi_handle {
     double *d_sched = nullptr;
     int sched_len = 0;
     // scratch
-    int nb_e = 0, nb_m = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
-    size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0;
+    int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
+    size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
@@ -64,6 +64,9 @@ struct smcmi_handle {
     double *d_cum_full = nullptr, *d_part_full = nullptr, *d_off_full = nullptr;
     int nb_full = 0;
     int last_n_stages = 1;
+    int launch_nb = 1;
+    bool launch_alpha1 = false;
+    long long *d_prof = nullptr;   // development only (smcmi_debug_time_kernel with which = 9 and SMCMI_PROF_MUT=1)
     hipGraphExec_t graph_exec = nullptr;
     int graph_sig = 0;
 };
@@ -135,6 +138,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         return SMCMI_ERR_HIP;
     h->nb_e = (int)std::min<long long>(1024, std::max<long long>(1, (n + 511) / 512));
     h->nb_m = (int)std::min<long long>(256, std::max<long long>(1, (n + MT - 1) / MT));
+    h->nb_mr = (int)std::min<long long>(512, std::max<long long>(std::min<long long>(64, (n + TB - 1) / TB), n / 1536));
     // mutation block size: largest of 256/128/64 threads whose per-thread LDS vectors fit 64 KiB
     for (int T : {256, 128, 64}) {
         h->mut_T = T;
@@ -143,17 +147,14 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     }
     h->nb_mut = (int)((n + h->mut_T - 1) / h->mut_T);
     // register-resident variant: only θ lives in per-thread LDS columns
-    for (int T : {256, 128, 64}) {
-        h->reg_T = T;
-        h->reg_lds_base = (size_t)(h->d * T + 8) * sizeof(double);
-        if (h->reg_lds_base <= 48 * 1024) break;
-    }
+    h->reg_T = 256;
     h->nb_reg = (int)((n + h->reg_T - 1) / h->reg_T);
     h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;
     h->comm_cap = std::max<long long>(2 * KC, h->npairs) + 8;
+    h->prep_lds = (size_t)(((h->npairs + 63) / 64) * 64 + 4 * h->d * h->d + 8) * sizeof(double);
     if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
-        dmalloc(&h->d_part_mom, (size_t)h->nb_m * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
+        dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
         dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
@@ -174,6 +175,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     h->h_model.lik[1].family = SMCMI_LIK_NONE;
     if (push_state(h) || push_model(h)) return SMCMI_ERR_HIP;
     HIP_TRY(hipFuncSetAttribute((const void *)k_moments, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mom_lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_prepare_mutation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->prep_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
@@ -206,6 +208,7 @@ extern "C" int smcmi_set_parameters(smcmi_handle *h, const int32_t *fixed, const
     HIP_TRY(hipSetDevice(h->cfg.device));
     ModelDev &m = h->h_model;
     m.n_free = 0;
+    m.has_other_priors = 0;
     for (int k = 0; k < h->d; ++k) {
         m.fixed[k] = fixed ? fixed[k] : 0;
         m.lo[k] = lo[k]; m.hi[k] = hi[k];
@@ -216,6 +219,7 @@ extern "C" int smcmi_set_parameters(smcmi_handle *h, const int32_t *fixed, const
             if (prior_family[k] < SMCMI_PRIOR_NORMAL || prior_family[k] > SMCMI_PRIOR_ROOTINVGAMMA)
                 return set_err(SMCMI_ERR_ARG, "unknown prior family");
             m.free_inds[m.n_free++] = k;
+            if (prior_family[k] > SMCMI_PRIOR_UNIFORM) m.has_other_priors = 1;
         }
     }
     if (m.n_free == 0) return set_err(SMCMI_ERR_ARG, "All model parameters are fixed!");   // smc_main.jl:237
@@ -333,7 +337,7 @@ static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
     return 0;
 }
 
-static const int DEFAULT_SOLVER_PASSES = 8;   // 1 schedule scan + bracketing passes (4-5 typical, see kernels.hpp)
+static const int DEFAULT_SOLVER_PASSES = 6;   // 1 schedule scan + bracketing passes (4-5 typical, see kernels.hpp)
 
 // P solver passes; pass p consumes the partials of pass p-1 in its prologue.  The correction pass that follows is pass P.
 static void enqueue_solver(smcmi_handle *h, int passes) {
@@ -441,12 +445,39 @@ extern "C" int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, c
     return 0;
 }
 
+// ---- moments launch: register-resident kernel for d <= 12, LDS-tiled kernel beyond
+template <int D>
+static void launch_moments_reg(smcmi_handle *h, double *hist_W, int standalone) {
+    k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone);
+}
+// returns the number of blocks that wrote partials
+static int launch_moments(smcmi_handle *h, double *hist_W, int standalone) {
+    switch (h->d) {
+    case 1: launch_moments_reg<1>(h, hist_W, standalone); break;
+    case 2: launch_moments_reg<2>(h, hist_W, standalone); break;
+    case 3: launch_moments_reg<3>(h, hist_W, standalone); break;
+    case 4: launch_moments_reg<4>(h, hist_W, standalone); break;
+    case 5: launch_moments_reg<5>(h, hist_W, standalone); break;
+    case 6: launch_moments_reg<6>(h, hist_W, standalone); break;
+    case 7: launch_moments_reg<7>(h, hist_W, standalone); break;
+    case 8: launch_moments_reg<8>(h, hist_W, standalone); break;
+    case 9: launch_moments_reg<9>(h, hist_W, standalone); break;
+    case 10: launch_moments_reg<10>(h, hist_W, standalone); break;
+    case 11: launch_moments_reg<11>(h, hist_W, standalone); break;
+    case 12: launch_moments_reg<12>(h, hist_W, standalone); break;
+    default:
+        k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone);
+        return h->nb_m;
+    }
+    return h->nb_mr;
+}
+
 extern "C" int smcmi_moments(smcmi_handle *h, double *mean, double *cov) {
     if (!h || !mean || !cov) return set_err(SMCMI_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int d = h->d;
-    k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, nullptr, 0, 1);
-    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 1);
+    const int nbm = launch_moments(h, nullptr, 1);
+    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm, h->npairs, h->d_totals, 1);
     k_finalize_moments<<<1, 64, 0, h->stream>>>(h->d_st, h->d_totals, d);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     for (int a = 0; a < d; ++a) mean[a] = h->h_st.mean[a];
@@ -479,35 +510,42 @@ static int stage_blocks(smcmi_handle *h, const double *mu_free, const double *Si
     return 0;
 }
 
-// ---- mutation launch: register-resident kernel for blocks up to 10 parameters, generic LDS kernel beyond
-template <int DB>
+// ---- mutation launch: register-resident kernel for models with n_para <= 10, generic LDS kernel beyond
+static size_t reg_lds_bytes(int D) {
+    return (size_t)(2 * D * D + 12 * D + 4 + 2 * LIK_PAR_MAX + LIK_LDS_CAP) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32;
+}
+template <int D>
 static void launch_reg(smcmi_handle *h, const MutArgs &ma, int standalone) {
-    const size_t lds = h->reg_lds_base + (size_t)(DB * DB + 3 * DB + 4) * sizeof(double) + (size_t)DB * sizeof(int) + 16;
-    k_mutate_reg<DB><<<h->nb_reg, h->reg_T, lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone);
+    if (h->launch_alpha1)
+        k_mutate_reg<D, true><<<h->nb_reg, h->reg_T, reg_lds_bytes(D), h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone,
+                                                                                    h->launch_nb, h->h_model.n_free);
+    else
+    k_mutate_reg<D, false><<<h->nb_reg, h->reg_T, reg_lds_bytes(D), h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone,
+                                                                           h->launch_nb, h->h_model.n_free);
 }
-template <int DB>
-static int set_reg_attr(smcmi_handle *h) {
-    const size_t lds = h->reg_lds_base + (size_t)(DB * DB + 3 * DB + 4) * sizeof(double) + (size_t)DB * sizeof(int) + 16;
-    HIP_TRY(hipFuncSetAttribute((const void *)k_mutate_reg<DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    return 0;
-}
-static int set_mutate_attrs(smcmi_handle *h) {
-    return set_reg_attr<1>(h) || set_reg_attr<2>(h) || set_reg_attr<3>(h) || set_reg_attr<4>(h) || set_reg_attr<5>(h) ||
-           set_reg_attr<6>(h) || set_reg_attr<8>(h) || set_reg_attr<10>(h);
-}
-// max_db: upper bound on the block length for this launch; returns the number of blocks launched (acc partials)
-static int launch_mutate(smcmi_handle *h, int max_db, int standalone) {
+static int set_mutate_attrs(smcmi_handle *) { return 0; }   // the register kernel needs < 64 KiB of dynamic LDS
+static bool use_reg_mutate(const smcmi_handle *h) { return h->d <= 10; }
+// returns the number of blocks launched (= acceptance partials written)
+static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double alpha) {
+    h->launch_nb = n_blocks;
+    h->launch_alpha1 = (alpha == 1.0);
     MutArgs ma{};
     ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
-    if (max_db <= 1) launch_reg<1>(h, ma, standalone);
-    else if (max_db <= 2) launch_reg<2>(h, ma, standalone);
-    else if (max_db <= 3) launch_reg<3>(h, ma, standalone);
-    else if (max_db <= 4) launch_reg<4>(h, ma, standalone);
-    else if (max_db <= 5) launch_reg<5>(h, ma, standalone);
-    else if (max_db <= 6) launch_reg<6>(h, ma, standalone);
-    else if (max_db <= 8) launch_reg<8>(h, ma, standalone);
-    else if (max_db <= 10) launch_reg<10>(h, ma, standalone);
-    else {
+    static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
+    ma.debug = dbg;
+    ma.prof = h->d_prof;
+    switch (h->d) {
+    case 1: launch_reg<1>(h, ma, standalone); break;
+    case 2: launch_reg<2>(h, ma, standalone); break;
+    case 3: launch_reg<3>(h, ma, standalone); break;
+    case 4: launch_reg<4>(h, ma, standalone); break;
+    case 5: launch_reg<5>(h, ma, standalone); break;
+    case 6: launch_reg<6>(h, ma, standalone); break;
+    case 7: launch_reg<7>(h, ma, standalone); break;
+    case 8: launch_reg<8>(h, ma, standalone); break;
+    case 9: launch_reg<9>(h, ma, standalone); break;
+    case 10: launch_reg<10>(h, ma, standalone); break;
+    default:
         k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone);
         return h->nb_mut;
     }
@@ -527,8 +565,8 @@ extern "C" int smcmi_mutate(smcmi_handle *h, const double *mu_free, const double
     s.done = 0; s.err = 0; s.do_resample = 0;
     s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = phi_n; s.mut_steps = n_mh_steps; s.mut_stage = stage;
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
-    const int nbl = launch_mutate(h, s.max_db, 1);
+    k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_totals, 0, h->cfg.seed, 0, 0, 1);
+    const int nbl = launch_mutate(h, s.n_blocks, 1, alpha);
     k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_comm);
     double asum = 0.0;
     HIP_TRY(hipMemcpyAsync(&asum, h->d_comm, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -562,7 +600,7 @@ extern "C" int smcmi_propose(smcmi_handle *h, const double *mu_free, const doubl
     s.done = 0; s.err = 0; s.do_resample = 0;
     s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = 0.0; s.mut_steps = mh_step + 1; s.mut_stage = stage;
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
+    k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_totals, 0, h->cfg.seed, 0, 0, 1);
     MutArgs ma{};
     ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.proposals = h->d_prop; ma.prop_logprior = h->d_prop_lp;
     ma.prop_qdiff = h->d_prop_q; ma.acc_count = h->d_acc_count; ma.block = block; ma.step = mh_step;
@@ -596,8 +634,8 @@ extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const dou
 
 // ------------------------------------------------------------------------------------------------ whole loop
 // One stage = a fixed kernel sequence (no host decision inside): see the header of kernels.hpp.
-static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int max_db, int acc_nb, hipEvent_t ev0,
-                          hipEvent_t ev1) {
+static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int n_blocks, double alpha, int acc_nb,
+                          hipEvent_t ev0, hipEvent_t ev1) {
     const long long n = h->n;
     hipStream_t s = h->stream;
     const int P = adaptive ? solver_passes : 0;
@@ -608,11 +646,10 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     k_scan_weights<<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 0);
     k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
                                                                  nullptr, h->d_anc, nullptr, 0);
-    k_moments<<<h->nb_m, TB, h->mom_lds, s>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, n, 0);
-    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, s>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_totals, 0);
-    k_prepare_mutation<<<1, 64, 0, s>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 1, 1, 0);
+    const int nbm = launch_moments(h, h->d_hist_W, 0);
+    k_prepare_mutation<<<1, PT, h->prep_lds, s>>>(h->d_st, h->d_model, h->d_part_mom, nbm, h->cfg.seed, 1, 1, 0);
     if (ev0) hipEventRecord(ev0, s);
-    launch_mutate(h, max_db, 0);
+    launch_mutate(h, n_blocks, 0, alpha);
     if (ev1) hipEventRecord(ev1, s);
 }
 
@@ -667,14 +704,14 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int solver_passes = rc->solver_passes > 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 8;
     const int max_db = (nf + rc->n_blocks - 1) / rc->n_blocks;
-    const int acc_nb = max_db <= 10 ? h->nb_reg : h->nb_mut;
+    const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
     std::vector<hipEvent_t> evs;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     if (rc->use_graph == 1) {
         HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, max_db, acc_nb, nullptr, nullptr);
+        enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr);
         HIP_TRY(hipStreamEndCapture(h->stream, &graph));
         HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     }
@@ -688,7 +725,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
-                enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, max_db, acc_nb, e0, e1);
+                enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, e0, e1);
             }
             ++launched;
         }
@@ -794,8 +831,8 @@ extern "C" int smcmi_shard_normalize_moments_partial(smcmi_handle *h, double sum
     for (int a = 0; a < h->d; ++a) s.shift[a] = shift ? shift[a] : 0.0;
     if (resampled) s.sumw = (double)h->cfg.n_parts;   // after a gather the weights are already 1: (w*N)/N == w
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, h->n, 0);
-    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_m, h->npairs, h->d_comm, 0);
+    const int nbm = launch_moments(h, h->d_hist_W, 0);
+    k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm, h->npairs, h->d_comm, 0);
     return 0;
 }
 
@@ -845,9 +882,82 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
     s.done = 0; s.err = 0; s.do_resample = 0;
     s.mut_c = c; s.mut_alpha = alpha; s.mut_phi = phi_n; s.mut_steps = n_mh_steps; s.mut_stage = stage;
     if (push_state(h)) return SMCMI_ERR_HIP;
-    k_prepare_mutation<<<1, 64, 0, h->stream>>>(h->d_st, h->d_model, h->d_totals, h->cfg.seed, 0, 0, 1);
-    const int nbl = launch_mutate(h, s.max_db, 1);
+    k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_totals, 0, h->cfg.seed, 0, 0, 1);
+    const int nbl = launch_mutate(h, s.n_blocks, 1, alpha);
     k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_comm);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     return err_from_state(s.err);
+}
+
+// ------------------------------------------------------------------------------------------------ development aid
+__global__ void k_empty(const DevState *st) { if (st->done == 12345) printf("x"); }
+
+extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t reps, double *usec_per_launch) {
+    if (int rc = need_model(h, true)) return rc;
+    if (!usec_per_launch || reps < 1) return set_err(SMCMI_ERR_ARG, "bad argument");
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    const DevState saved = s;
+    const long long n = h->n;
+    s.done = 0; s.err = 0; s.stage = 2; s.rp.store_history = h->cfg.store_history; s.rp.phi_rtol = 1e-12;
+    if (s.rp.n_phi < 2) { s.rp.n_phi = 300; }
+    s.phi_prev = 0.0; s.phi_n = 1e-4; s.sumw = (double)h->cfg.n_parts; s.c = 0.5; s.rp.n_blocks = 1; s.rp.n_mh_steps = 1; s.rp.alpha = 1.0;
+    s.rp.threshold = 0.5 * (double)h->cfg.n_parts; s.rp.target = 0.25; s.accept = 0.25; s.rp.tempering_target = 0.97; s.ess_prev = (double)h->cfg.n_parts;
+    Solver &S = s.sol[0];
+    S.mode = MODE_SECTION; S.n_valid = KC; S.ess_bar = 0.97 * (double)h->cfg.n_parts; S.lo = 0.0; S.hi = 1e-3; S.glo = 1.0; S.ghi = -1.0; S.j = 5; S.phi_prop = 1e-3;
+    for (int q = 0; q < KC; ++q) S.cand[q] = 1e-5 * (q + 1);
+    if (which == 2 || which == 3) { S.mode = MODE_FINAL; S.phi_n = 1e-5; }
+    if (which == 4 || which == 5) s.do_resample = 1;
+    std::vector<double> sched(s.rp.n_phi);
+    for (int k = 0; k < s.rp.n_phi; ++k) sched[k] = pow((double)k / (double)(s.rp.n_phi - 1), 2.1);
+    if (upload_sched(h, sched.data(), s.rp.n_phi) || push_state(h)) return SMCMI_ERR_HIP;
+    // make every input buffer valid once
+    k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0);
+    k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
+    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
+    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1);
+    { const int nbm0 = launch_moments(h, nullptr, 1);
+      k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm0, h->npairs, h->d_totals, 1); }
+    k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_totals, 0, h->cfg.seed, 2, 1, 0);
+    const int max_db = h->h_model.n_free;
+    (void)max_db;
+    if (getenv("SMCMI_PROF_MUT") && !h->d_prof) { if (dmalloc(&h->d_prof, 32)) return SMCMI_ERR_HIP; }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        switch (which) {
+        case 0: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0); break;
+        case 1: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[0], h->d_part_ess[1], h->nb_e, 1, nullptr, 0); break;
+        case 2: k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, h->d_hist_w, n); break;
+        case 3: k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, 0); break;
+        case 4: k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1); break;
+        case 5: k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, 0, h->cfg.seed, 3u, nullptr, h->d_anc, nullptr, 1); break;
+        case 6: launch_moments(h, nullptr, 1); break;
+        case 7: k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->npairs, h->d_totals, 1); break;
+        case 8: k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->cfg.seed, 1, 1, 0); break;
+        case 9: launch_mutate(h, 1, 0, 1.0); break;
+        case 10: k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, use_reg_mutate(h) ? h->nb_reg : h->nb_mut, h->rec); break;
+        default: k_empty<<<1, 64, 0, h->stream>>>(h->d_st); break;
+        }
+        if (which == 10 || which == 3) { /* keep the stage counter / weights bounded */ }
+    }
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *usec_per_launch = 1e3 * (double)ms / reps;
+    if (h->d_prof && which == 9) {
+        long long pr[32];
+        hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
+        for (int blk = 0; blk < 2; ++blk) {
+            fprintf(stderr, "mutate phase cycles (block %s):", blk ? "mid" : "0");
+            for (int q = 1; q < 10; ++q) fprintf(stderr, " %lld", pr[blk * 16 + q] - pr[blk * 16 + q - 1]);
+            fprintf(stderr, "  total %lld\n", pr[blk * 16 + 9] - pr[blk * 16]);
+        }
+    }
+    h->h_st = saved;
+    return push_state(h);
 }

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("smcmi_shard_resample", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, lp]),
     ("smcmi_shard_mutate_partial", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32]),
     ("smcmi_sync", C.c_int, [_H]),
+    ("smcmi_debug_time_kernel", C.c_int, [_H, C.c_int32, C.c_int32, dp]),
 ]
 
 _LIB = None

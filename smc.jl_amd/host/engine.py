@@ -174,6 +174,11 @@ class Engine:
         check(self._L.smcmi_get_history(self._h, _d(w), _d(W)))
         return w, W
 
+    def time_kernel(self, which, reps=200):
+        us = C.c_double()
+        check(self._L.smcmi_debug_time_kernel(self._h, which, reps, C.byref(us)))
+        return us.value
+
     def sync(self):
         check(self._L.smcmi_sync(self._h))
 
