@@ -19,6 +19,16 @@ namespace smcmi {
 
 constexpr int TB = 256;  // threads per block for streaming kernels (4 wavefronts)
 
+// development aid: shader-clock stamp of (block 0, thread 0) into prof[slot] when prof != nullptr
+#define SMCMI_STAMP(prof, slot)                                                                              \
+    do {                                                                                                    \
+        if ((prof) != nullptr && threadIdx.x == 0 && blockIdx.x == 0) {                                      \
+            unsigned long long tt_;                                                                          \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory"); \
+            (prof)[slot] = (long long)tt_;                                                                   \
+        }                                                                                                   \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------ reductions
 // Butterfly "reduce-scatter" across the 64 lanes of a wavefront: M accumulators per lane go in, and lane l
 // comes out holding (in a[0]) the wavefront total of accumulator  l >> (6 - log2 M).  M-1 shuffles instead
@@ -775,14 +785,46 @@ __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 // src/helpers.jl:90-94,135-155).  One block of 256 threads; all matrix work happens in LDS, DevState is written once.
 // from_totals: 0 = use st->mean / st->cov as given (stand-alone mutation), 1 = reduce `partials` (nb blocks x npairs,
 // fixed order) first, 2 = `partials` already holds the npairs totals.
+// Cholesky of a db x db matrix (db <= DBM) held one row per lane in registers: column j's pivot and multipliers are
+// broadcast with v_readlane (no LDS round trips); same k-ascending subtraction order per entry as the oracle's loop.
+// Returns false when a pivot is not positive.  On return lane i holds row i of L in r[0..i].
+// broadcast lane `src`'s double to the whole wavefront through SGPRs (v_readlane_b32 x2): a few cycles, no LDS latency
+__device__ inline double bcast_lane(double x, int src) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(x), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)__double2hiint(x), src);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+template <int DBM>
+__device__ inline bool chol_rows_in_regs(double (&r)[DBM], int db, int lane) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < DBM; ++j) {
+        if (j < db) {
+            const double ajj = bcast_lane(r[j], j);
+            if (!(ajj > 0.0)) ok = false;
+            const double ljj = sqrt(ajj);
+            const double lij = (lane == j) ? ljj : r[j] / ljj;      // column j of L (valid for lanes >= j)
+#pragma unroll
+            for (int k = j + 1; k < DBM; ++k) {
+                const double lkj = bcast_lane(lij, k);
+                r[k] -= lij * lkj;                                   // meaningful for lanes i >= k, k < db
+            }
+            r[j] = lij;
+        }
+    }
+    return ok;
+}
+
 constexpr int PT = 1024;  // threads of the single prepare block
 __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
-                                                         int standalone) {
+                                                         int standalone, long long *prof = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
+    SMCMI_STAMP(prof, 0);
     __shared__ double scratch[PT];
     __shared__ double mu_f[MAXD];
-    __shared__ int bfree[MAXD], bptr[MAXD + 1], fi[MAXD];
+    __shared__ int bfree[MAXD], bptr[MAXD + 1], fi[MAXD], fi_j[MAXD];
     __shared__ int s_fail;
     if (!standalone && st->done) return;
     const int d = md->d, nf = md->n_free, t = threadIdx.x, da = d + 1, npairs = da * (da + 1) / 2;
@@ -794,6 +836,7 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
     if (t == 0) s_fail = 0;
     if (t < nf) fi[t] = md->free_inds[t];
     const double c = st->c;
+    SMCMI_STAMP(prof, 1);
     if (from_totals) {
         if (from_totals == 1) {
             for (int p0 = 0; p0 < npairs; p0 += 64) {
@@ -844,16 +887,28 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
         for (int e = t; e < d * d; e += PT) covl[e] = st->cov[e];
         for (int a = t; a < d; a += PT) scratch[a] = st->mean[a];
     }
+    SMCMI_STAMP(prof, 2);
     const int nb = gen_blocks ? st->rp.n_blocks : st->n_blocks;
     if (gen_blocks) {
-        if (t == 64) {                       // a lane of another wave shuffles while wave 0 finishes the covariance
+        if (t >= 64 && t < 128) {            // wave 1 shuffles while wave 0 finishes the covariance
             const unsigned stage = (unsigned)st->stage;
-            for (int i = 0; i < nf; ++i) bfree[i] = i;
+            const int i0 = t - 64;               // lane i draws the Fisher-Yates partner of position i (independent Philox calls)
+            if (i0 < nf) {
+                bfree[i0] = i0;
+                int jx = 0;
+                if (i0 >= 1) {
+                    double ua, ub;
+                    uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i0, 0), ua, ub);
+                    jx = (int)(ua * (double)(i0 + 1));
+                    if (jx > i0) jx = i0;
+                }
+                fi_j[i0] = jx;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (t == 64) {
             for (int i = nf - 1; i >= 1; --i) {
-                double ua, ub;
-                uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i, 0), ua, ub);
-                int jx = (int)(ua * (double)(i + 1));
-                if (jx > i) jx = i;
+                const int jx = fi_j[i];
                 const int tmp = bfree[i]; bfree[i] = bfree[jx]; bfree[jx] = tmp;
             }
             const int sub = (nf + nb - 1) / nb;
@@ -865,6 +920,7 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
         for (int b = t; b <= nb; b += PT) bptr[b] = st->block_ptr[b];
     }
     __syncthreads();
+    SMCMI_STAMP(prof, 3);
     // R_fr = (R[f,f] + R[f,f]')/2, θ_bar_fr
     for (int e = t; e < nf * nf; e += PT) {
         const int a = fi[e / nf], b = fi[e % nf];
@@ -880,6 +936,7 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
         st->sd_draw[i] = sqrt(c * c * sig_f[f * nf + f]);
         st->sd_dens[i] = sqrt(sig_f[f * nf + f]);
     }
+    SMCMI_STAMP(prof, 4);
     int off = 0, max_db = 0;
     for (int b = 0; b < nb; ++b) {
         const int p0 = bptr[b], db = bptr[b + 1] - p0;
@@ -889,34 +946,52 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
             Ls[e] = 0.0;
         }
         __syncthreads();
-        // column Cholesky, lane i owns row i; same operation order as the textbook loop of the oracle
-        for (int jx = 0; jx < db; ++jx) {
-            if (t == jx) {
-                double s = A[jx * db + jx];
-                for (int k = 0; k < jx; ++k) s -= Ls[jx * db + k] * Ls[jx * db + k];
-                if (!(s > 0.0)) s_fail = 1;
-                Ls[jx * db + jx] = sqrt(s);
+        // Right-looking Cholesky inside ONE wavefront (lane i owns row i, no block barriers): after column j is final the
+        // trailing rows are updated A[i][k] -= L[i][j] L[k][j]; every entry therefore receives its subtractions in the same
+        // k-ascending order as the textbook left-looking loop of the oracle (bitwise the same factor).
+        if (t < 64 && db <= 12) {
+            double r[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) r[k] = (t < db && k < db) ? A[t * db + k] : 0.0;
+            const bool ok = chol_rows_in_regs<12>(r, db, t);
+            if (!ok && t == 0) s_fail = 1;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (t < db && k <= t) Ls[t * db + k] = r[k];
+        } else if (t < 64) {
+            for (int jx = 0; jx < db; ++jx) {
+                const double ajj = A[jx * db + jx];
+                if (!(ajj > 0.0)) { if (t == 0) s_fail = 1; break; }
+                const double ljj = sqrt(ajj);
+                double lij = 0.0;
+                if (t == jx) Ls[jx * db + jx] = ljj;
+                if (t > jx && t < db) { lij = A[t * db + jx] / ljj; Ls[t * db + jx] = lij; }
+                (void)lij;
+                __builtin_amdgcn_wave_barrier();
+                // trailing update of the lower triangle, one (i, k) pair per lane
+                const int m = db - 1 - jx, npr = m * (m + 1) / 2;
+                for (int pq = t; pq < npr; pq += 64) {
+                    int r = 0, rem = pq;
+                    while (rem > r) { rem -= r + 1; ++r; }
+                    const int i2 = jx + 1 + r, k2 = jx + 1 + rem;
+                    A[i2 * db + k2] -= Ls[i2 * db + jx] * Ls[k2 * db + jx];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
-            if (s_fail) break;
-            if (t > jx && t < db) {
-                double s = A[t * db + jx];
-                for (int k = 0; k < jx; ++k) s -= Ls[t * db + k] * Ls[jx * db + k];
-                Ls[t * db + jx] = s / Ls[jx * db + jx];
-            }
-            __syncthreads();
         }
+        __syncthreads();
         if (s_fail) break;
         for (int e = t; e < db * db; e += PT) st->L[off + e] = Ls[e];
-        if (t == 0) {
+        if (t < 64) {                                  // log of the diagonal in parallel, summed in index order
+            const double lg = (t < db) ? log(Ls[t * db + t]) : 0.0;
             double ld = 0.0;
-            for (int i = 0; i < db; ++i) ld += log(Ls[i * db + i]);
-            st->logdet[b] = 2.0 * ld;
-            st->l_off[b] = off;
+            for (int i = 0; i < db; ++i) ld += __shfl(lg, i, 64);
+            if (t == 0) { st->logdet[b] = 2.0 * ld; st->l_off[b] = off; }
         }
         off += db * db;
         __syncthreads();
     }
+    SMCMI_STAMP(prof, 5);
     for (int b = t; b <= nb; b += PT) st->block_ptr[b] = bptr[b];
     if (t == 0) {
         st->n_blocks = nb;
@@ -927,6 +1002,7 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
             st->mut_stage = (unsigned)st->stage;
         }
     }
+    SMCMI_STAMP(prof, 6);
 }
 
 // ------------------------------------------------------------------------------------------------ mutation
@@ -1252,7 +1328,7 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
                 // Box-Muller for the block, written stage by stage over all pairs so the independent log / sqrt / sincospi
                 // chains can be interleaved by the scheduler (at <= 2 wavefronts per SIMD dependent FP64 latency is exposed)
                 constexpr int NP2 = (D + 1) / 2;
-                constexpr int GRP = 2;                     // pairs interleaved at a time (more raises register pressure past 2 waves/SIMD)
+                constexpr int GRP = 3;                     // pairs interleaved at a time (more raises register pressure past 2 waves/SIMD)
                 double ua[NP2], ub[NP2], rr[NP2], sn[NP2], cs[NP2];
 #pragma unroll
                 for (int q = 0; q < NP2; ++q) {

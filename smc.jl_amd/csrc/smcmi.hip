@@ -936,7 +936,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
         case 5: k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, 0, h->cfg.seed, 3u, nullptr, h->d_anc, nullptr, 1); break;
         case 6: launch_moments(h, nullptr, 1); break;
         case 7: k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->npairs, h->d_totals, 1); break;
-        case 8: k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->cfg.seed, 1, 1, 0); break;
+        case 8: k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->cfg.seed, 1, 1, 0, h->d_prof); break;
         case 9: launch_mutate(h, 1, 0, 1.0); break;
         case 10: k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, use_reg_mutate(h) ? h->nb_reg : h->nb_mut, h->rec); break;
         default: k_empty<<<1, 64, 0, h->stream>>>(h->d_st); break;
@@ -949,6 +949,13 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     *usec_per_launch = 1e3 * (double)ms / reps;
+    if (h->d_prof && which == 8) {
+        long long pr[32];
+        hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
+        fprintf(stderr, "prepare phase cycles:");
+        for (int q = 1; q < 7; ++q) fprintf(stderr, " %lld", pr[q] - pr[q - 1]);
+        fprintf(stderr, "  total %lld\n", pr[6] - pr[0]);
+    }
     if (h->d_prof && which == 9) {
         long long pr[32];
         hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
