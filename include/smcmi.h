@@ -71,7 +71,7 @@ typedef struct {
     int32_t solver_passes;                 /* kernel passes allotted to the adaptive-ϕ solver per stage (0 => default 8) */
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
     int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
-    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-12; <0 => adjacent floats) */
+    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-10; <0 => adjacent floats) */
 } smcmi_run_config;
 
 typedef struct {

@@ -304,19 +304,23 @@ __device__ inline void solver_prologue(DevState *st, const double *sched, const 
 // prior-weight variant, the unnormalised weight W̃ = W w̃ is written back and w̃ goes to the history column.
 template <int K, bool FINAL>
 __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const double *sched, const double *partials_prev,
-                                             double *partials_out, int nb_prev, int p, double *hist_w, long long hist_ld) {
+                                             double *partials_out, int nb_prev, int p, double *hist_w, long long hist_ld,
+                                             long long *prof = nullptr) {
+    SMCMI_STAMP(prof, 0);
     __shared__ double red[(TB / 64) * 2 * K];
     __shared__ double scratch[TB];
     __shared__ double tot[2 * KC];
     __shared__ Solver S;
     // independent scalar loads first (one memory round trip): done flag, buffer index, ϕ_{n-1}, solver copy
-    const int done = st->done, src = st->cur;
+    const int done = st->done;
+    constexpr int src = 0;             // the current cloud always lives in buffer 0 (k_moments copies a resampled cloud back)
     const double phi_prev = st->phi_prev;
     const double pw = st->rp.pw, logp_old = st->rp.logp_old;
     const int stage_col = st->stage - 1;
     const bool hist = FINAL && st->rp.store_history && hist_w != nullptr;
     solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, FINAL ? 1 : 0, done);
     if (done) return;
+    SMCMI_STAMP(prof, 1);
     const int mode = S.mode;
     if (FINAL ? (mode != MODE_FINAL) : (mode != MODE_SCAN && mode != MODE_SECTION)) return;
     const int nv = S.n_valid;
@@ -347,9 +351,12 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
             }
         }
     }
+    SMCMI_STAMP(prof, 2);
     const double total = block_reduce_many<2 * K>(acc, red);
+    SMCMI_STAMP(prof, 3);
     if (threadIdx.x < 2 * K) partials_out[(long long)blockIdx.x * (2 * K) + threadIdx.x] = total;
     if (!FINAL && blockIdx.x == 0 && threadIdx.x == 0) st->solver_passes += 1;
+    SMCMI_STAMP(prof, 4);
 }
 
 // decision of the last solver pass without a correction (stand-alone smcmi_solve_phi)
@@ -381,7 +388,7 @@ __global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *
         st->accept = a;
         rec.accept[stage0 - 1] = a;
     }
-    if (rs) { st->cur ^= 1; st->do_resample = 0; }
+    if (rs) st->do_resample = 0;
     if (phi_n >= 1.0) { st->done = 1; return; }
     const int i = stage0 + 1;
     if (i > max_stages) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; return; }
@@ -571,8 +578,8 @@ __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, doub
         pa[p] = (unsigned char)a; pb[p] = (unsigned char)(a + rem);
     }
     const int resampled = standalone ? 0 : st->do_resample;
-    const int src = st->cur ^ resampled;
-    double *w = col(cl, src, cl.R - 1);
+    const int src = resampled ? 1 : 0;       // a resampled cloud was gathered into buffer 1; it is copied back to buffer 0 here
+    double *w = col(cl, 0, cl.R - 1);
     const double N = (double)st->rp.n_parts, sumw = st->sumw;
     const int stage_col = st->stage - 1;
     const bool hist = !standalone && st->rp.store_history && hist_W != nullptr;
@@ -597,8 +604,13 @@ __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, doub
         }
         wv[threadIdx.x] = wi;
         xs[threadIdx.x] = 1.0;
-        for (int a = 0; a < d; ++a)
-            xs[(a + 1) * ldx + threadIdx.x] = (i < end) ? col(cl, src, a)[i] - st->shift[a] : 0.0;
+        for (int a = 0; a < d; ++a) {
+            const double th = (i < end) ? col(cl, src, a)[i] : 0.0;
+            if (resampled && i < end) col(cl, 0, a)[i] = th;
+            xs[(a + 1) * ldx + threadIdx.x] = (i < end) ? th - st->shift[a] : 0.0;
+        }
+        if (resampled && i < end)
+            for (int c = d; c < d + 4; ++c) col(cl, 0, c)[i] = col(cl, 1, c)[i];
         __syncthreads();
         if (slices > 1) {
             const int p = threadIdx.x % npairs, s = threadIdx.x / npairs;
@@ -652,8 +664,8 @@ __global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, 
     __shared__ double red[(TB / 64) * 64];
     if (!standalone && st->done) return;
     const int resampled = standalone ? 0 : st->do_resample;
-    const int src = st->cur ^ resampled;
-    double *w = col(cl, src, cl.R - 1);
+    const int src = resampled ? 1 : 0;       // a resampled cloud was gathered into buffer 1; it is copied back to buffer 0 here
+    double *w = col(cl, 0, cl.R - 1);
     const double N = (double)st->rp.n_parts, sumw = st->sumw;
     const int stage_col = st->stage - 1;
     const bool hist = !standalone && st->rp.store_history && hist_W != nullptr;
@@ -676,7 +688,18 @@ __global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, 
         double x[DA];
         x[0] = 1.0;
 #pragma unroll
-        for (int a = 0; a < D; ++a) x[a + 1] = col(cl, src, a)[i] - sh[a];
+        for (int a = 0; a < D; ++a) x[a + 1] = col(cl, src, a)[i];
+        if (resampled) {
+            double meta[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) meta[c] = col(cl, 1, D + c)[i];
+#pragma unroll
+            for (int a = 0; a < D; ++a) col(cl, 0, a)[i] = x[a + 1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col(cl, 0, D + c)[i] = meta[c];
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) x[a + 1] -= sh[a];
         int p = 0;
 #pragma unroll
         for (int a = 0; a < DA; ++a) {
@@ -1036,7 +1059,7 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     double *red = v + (long long)d * T;    // [T/64]
     const long long i = (long long)blockIdx.x * T + tid;
     const bool live = i < cl.n;
-    const int src = standalone ? st->cur : (st->cur ^ st->do_resample);
+    constexpr int src = 0;
     const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
     const unsigned stage = st->mut_stage;
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
@@ -1231,7 +1254,7 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     // ---- round 1: every uniform input of the launch, issued back to back (a dependent global round trip costs ~1 µs
     // at this occupancy, so the kernel is organised as: one round of parameter loads, one round of particle loads,
     // compute, one round of stores).  nb / nf are launch arguments so the copy extents do not depend on loaded data.
-    const int done = st->done, cur = st->cur, rsf = st->do_resample, n_steps = st->mut_steps;
+    const int done = st->done, n_steps = st->mut_steps;
     const unsigned stage = st->mut_stage;
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
     for (int e = tid; e < nf * nf; e += T) Lraw[e] = st->L[e];
@@ -1252,7 +1275,7 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     // ---- round 2: the particle and the likelihood data
     const long long i = (long long)blockIdx.x * T + tid;
     const bool live = i < cl.n;
-    const int src = standalone ? cur : (cur ^ rsf);
+    constexpr int src = 0;
     const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
     double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
     double x[D];

@@ -163,7 +163,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     }
     memset(&h->h_st, 0, sizeof(DevState));
     h->h_st.rp.n_parts = cfg->n_parts;
-    h->h_st.rp.phi_rtol = 1e-12;
+    h->h_st.rp.phi_rtol = 1e-10;
     h->h_st.rp.max_stages = ms;
     h->h_st.stage = 1;
     h->h_st.c = 0.5;
@@ -337,7 +337,7 @@ static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
     return 0;
 }
 
-static const int DEFAULT_SOLVER_PASSES = 6;   // 1 schedule scan + bracketing passes (4-5 typical, see kernels.hpp)
+static const int DEFAULT_SOLVER_PASSES = 5;   // 1 schedule scan + bracketing passes (4-5 typical, see kernels.hpp)
 
 // P solver passes; pass p consumes the partials of pass p-1 in its prologue.  The correction pass that follows is pass P.
 static void enqueue_solver(smcmi_handle *h, int passes) {
@@ -380,7 +380,7 @@ extern "C" int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_p
     s.done = 0; s.err = 0; s.do_resample = 0; s.stage = 1; s.rp.use_fixed_schedule = 0; s.rp.n_phi = n_phi;
     s.rp.tempering_target = tempering_target; s.phi_n = phi_prev; s.phi_prop = *phi_prop; s.j = *j;
     s.resampled_last = *resampled_last; s.ess_prev = ess_prev;
-    if (s.rp.phi_rtol <= 0.0) s.rp.phi_rtol = 1e-12;
+    if (s.rp.phi_rtol <= 0.0) s.rp.phi_rtol = 1e-10;
     if (upload_sched(h, sched, n_phi) || push_state(h)) return SMCMI_ERR_HIP;
     k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, 0, h->rec);
     // enough passes to walk the whole schedule in the worst case plus the bracketing passes
@@ -439,7 +439,8 @@ extern "C" int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, c
     k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1);
     k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, h->cfg.gid0, h->cfg.n_parts, method,
                                                                          h->cfg.seed, stage, d_off, h->d_anc, nullptr, 1);
-    k_flip<<<1, 1, 0, h->stream>>>(h->d_st);
+    // the gathered cloud sits in buffer 1; the current cloud is always buffer 0
+    HIP_TRY(hipMemcpyAsync(h->cl.buf[0], h->cl.buf[1], sizeof(double) * n * h->R, hipMemcpyDeviceToDevice, h->stream));
     if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, h->d_anc, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -679,7 +680,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
     rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
     rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
-    rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-12);
+    rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
     memset(&s, 0, sizeof(DevState));
     s.rp = rp; s.cur = cur;
     s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
@@ -702,7 +703,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     const int solver_passes = rc->solver_passes > 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
-    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 8;
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
     const int max_db = (nf + rc->n_blocks - 1) / rc->n_blocks;
     const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
@@ -899,7 +900,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     DevState &s = h->h_st;
     const DevState saved = s;
     const long long n = h->n;
-    s.done = 0; s.err = 0; s.stage = 2; s.rp.store_history = h->cfg.store_history; s.rp.phi_rtol = 1e-12;
+    s.done = 0; s.err = 0; s.stage = 2; s.rp.store_history = h->cfg.store_history; s.rp.phi_rtol = 1e-10;
     if (s.rp.n_phi < 2) { s.rp.n_phi = 300; }
     s.phi_prev = 0.0; s.phi_n = 1e-4; s.sumw = (double)h->cfg.n_parts; s.c = 0.5; s.rp.n_blocks = 1; s.rp.n_mh_steps = 1; s.rp.alpha = 1.0;
     s.rp.threshold = 0.5 * (double)h->cfg.n_parts; s.rp.target = 0.25; s.accept = 0.25; s.rp.tempering_target = 0.97; s.ess_prev = (double)h->cfg.n_parts;
@@ -928,8 +929,8 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     HIP_TRY(hipEventRecord(e0, h->stream));
     for (int r = 0; r < reps; ++r) {
         switch (which) {
-        case 0: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0); break;
-        case 1: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[0], h->d_part_ess[1], h->nb_e, 1, nullptr, 0); break;
+        case 0: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0, h->d_prof); break;
+        case 1: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[0], h->d_part_ess[1], h->nb_e, 1, nullptr, 0, h->d_prof); break;
         case 2: k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, h->d_hist_w, n); break;
         case 3: k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, 0); break;
         case 4: k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1); break;
@@ -949,6 +950,13 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     *usec_per_launch = 1e3 * (double)ms / reps;
+    if (h->d_prof && which <= 1) {
+        long long pr[32];
+        hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
+        fprintf(stderr, "pass phase cycles:");
+        for (int q = 1; q < 5; ++q) fprintf(stderr, " %lld", pr[q] - pr[q - 1]);
+        fprintf(stderr, "  total %lld\n", pr[4] - pr[0]);
+    }
     if (h->d_prof && which == 8) {
         long long pr[32];
         hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);

@@ -74,7 +74,7 @@ def test_host_solver_matches_oracle_bisection():
 
     phi, j, phi_prop, passes = hm.PhiSolver(sched).solve(sums, 100, sched[98], 0.1, 0.97 * ess_now, ess_now)
     want = orc.solve_adaptive_phi(P, ess_now, sched, 100, sched[98], 0.1, 0.97, False)
-    assert phi == pytest.approx(want[0], rel=1e-10) and j == want[2] and phi_prop == want[3]
+    assert phi == pytest.approx(want[0], rel=1e-9) and j == want[2] and phi_prop == want[3]
     assert passes <= 7
 
 

@@ -77,7 +77,7 @@ def test_solve_phi_golden(golden):
     e.upload_cloud(P)
     phi_n, rl, j, phi_prop = e.solve_phi(z["schedule"], int(z["j"]), float(z["phi_prop"]), float(z["phi_n1"]),
                                          float(z["target"]), float(z["cloud_ess"][int(z["i"]) - 2]), bool(z["resampled_last"]))
-    assert phi_n == pytest.approx(1.212927219006027e-05, rel=1e-10)
+    assert phi_n == pytest.approx(1.212927219006027e-05, rel=1e-9)
     assert j == 3 and phi_prop == float(z["out_phi_prop"]) and rl is False
 
 
@@ -109,7 +109,7 @@ def test_solve_phi_vs_oracle(orc, case):
     e.upload_cloud(P)
     got = e.solve_phi(sched, args["j"], args["phi_prop"], args["phi_prev"], 0.97, args["ess_prev"], args["rl"])
     want = orc.solve_adaptive_phi(P, args["ess_prev"], sched, args["j"], args["phi_prop"], args["phi_prev"], 0.97, args["rl"])
-    assert got[0] == pytest.approx(want[0], rel=1e-10)
+    assert got[0] == pytest.approx(want[0], rel=1e-9)
     assert got[1] == want[1] and got[2] == want[2] and got[3] == want[3]
     if case == "reach_one":
         assert got[0] == 1.0
