@@ -481,14 +481,16 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
 // Inclusive scan of W̃/ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) in the block chunks of the
 // correction pass; chunk offsets come from k_post_correct.
 __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevState *st, const double *chunk_off,
-                                                     double *cum, int force) {
+                                                     double *cum, int force, int n_chunks) {
     __shared__ double s_tot[TB];
     if (!force && (st->done || !st->do_resample)) return;
     const double *w = col(cl, st->cur, cl.R - 1);
     const double total = st->sumw;
+    // the launch may use fewer blocks than chunks (most stages do not resample: a small grid makes the no-op cheap)
+    for (int vb = blockIdx.x; vb < n_chunks; vb += gridDim.x) {
     long long beg, end;
-    block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
-    double carry = chunk_off[blockIdx.x];
+    block_chunk(cl.n, n_chunks, vb, beg, end);
+    double carry = chunk_off[vb];
     constexpr int IPT = 4;
     for (long long base = beg; base < end; base += (long long)TB * IPT) {
         // thread t owns IPT consecutive items so that the running sum follows particle order
@@ -511,6 +513,7 @@ __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevStat
         carry += s_tot[TB - 1];
         __syncthreads();
     }
+    }
 }
 
 // Selection for output slot k: ancestor = first j with cum[j] > thr (src/resample.jl:51-70 systematic walk, :33-41
@@ -523,10 +526,9 @@ __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevS
                                                         unsigned long long seed, unsigned stage, const double *offsets,
                                                         long long *anc, const double *full, int force) {
     if (!force && (st->done || !st->do_resample)) return;
-    const long long k = (long long)blockIdx.x * TB + threadIdx.x;
-    if (k >= cl.n) return;
-    const long long slot = slot0 + k;
     if (!force) stage = (unsigned)st->stage;
+    for (long long k = (long long)blockIdx.x * TB + threadIdx.x; k < cl.n; k += (long long)gridDim.x * TB) {
+    const long long slot = slot0 + k;
     double ua, ub;
     if (method == SMCMI_RESAMPLE_MULTINOMIAL) {
         if (offsets) ua = offsets[slot];
@@ -555,6 +557,7 @@ __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevS
             if (c0 + q < R - 1) col(cl, dst, c0 + q)[k] = tmp[q];
     }
     col(cl, dst, R - 1)[k] = 1.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ moments
@@ -677,35 +680,47 @@ __global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, 
     for (int p = 0; p < NCH * 64; ++p) acc[p] = 0.0;
     long long beg, end;
     block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
-    for (long long i = beg + threadIdx.x; i < end; i += TB) {
-        double wi;
-        if (standalone) wi = w[i];
-        else {
-            wi = resampled ? 1.0 : (w[i] * N) / sumw;
-            w[i] = wi;
-            if (hist) hist_W[(long long)stage_col * hist_ld + i] = wi;
-        }
-        double x[DA];
-        x[0] = 1.0;
+    for (long long i0 = beg + threadIdx.x; i0 < end; i0 += 2 * TB) {
+        // two particles per trip: both particles' column loads are issued before any arithmetic (each trip is otherwise one
+        // exposed ~1 µs memory round trip at this occupancy)
+        double xx[2][DA], ww[2];
 #pragma unroll
-        for (int a = 0; a < D; ++a) x[a + 1] = col(cl, src, a)[i];
-        if (resampled) {
-            double meta[4];
+        for (int u = 0; u < 2; ++u) {
+            const long long i = i0 + (long long)u * TB;
+            const bool in = i < end;
+            ww[u] = in ? w[i] : 0.0;
+            xx[u][0] = 1.0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) meta[c] = col(cl, 1, D + c)[i];
-#pragma unroll
-            for (int a = 0; a < D; ++a) col(cl, 0, a)[i] = x[a + 1];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) col(cl, 0, D + c)[i] = meta[c];
+            for (int a = 0; a < D; ++a) xx[u][a + 1] = in ? col(cl, src, a)[i] : 0.0;
         }
 #pragma unroll
-        for (int a = 0; a < D; ++a) x[a + 1] -= sh[a];
-        int p = 0;
+        for (int u = 0; u < 2; ++u) {
+            const long long i = i0 + (long long)u * TB;
+            if (i >= end) continue;
+            double wi = ww[u];
+            if (!standalone) {
+                wi = resampled ? 1.0 : (wi * N) / sumw;
+                w[i] = wi;
+                if (hist) hist_W[(long long)stage_col * hist_ld + i] = wi;
+            }
+            if (resampled) {
+                double meta[4];
 #pragma unroll
-        for (int a = 0; a < DA; ++a) {
-            const double wx = wi * x[a];
+                for (int c = 0; c < 4; ++c) meta[c] = col(cl, 1, D + c)[i];
 #pragma unroll
-            for (int b = a; b < DA; ++b) { acc[p] += wx * x[b]; ++p; }
+                for (int a = 0; a < D; ++a) col(cl, 0, a)[i] = xx[u][a + 1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) col(cl, 0, D + c)[i] = meta[c];
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) xx[u][a + 1] -= sh[a];
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < DA; ++a) {
+                const double wx = wi * xx[u][a];
+#pragma unroll
+                for (int b = a; b < DA; ++b) { acc[p] += wx * xx[u][b]; ++p; }
+            }
         }
     }
     double *out = partials + (long long)blockIdx.x * NP;

@@ -65,6 +65,7 @@ struct smcmi_handle {
     int nb_full = 0;
     int last_n_stages = 1;
     int launch_nb = 1;
+    int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
     bool launch_alpha1 = false;
     long long *d_prof = nullptr;   // development only (smcmi_debug_time_kernel with which = 9 and SMCMI_PROF_MUT=1)
     hipGraphExec_t graph_exec = nullptr;
@@ -138,7 +139,9 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         return SMCMI_ERR_HIP;
     h->nb_e = (int)std::min<long long>(1024, std::max<long long>(1, (n + 511) / 512));
     h->nb_m = (int)std::min<long long>(256, std::max<long long>(1, (n + MT - 1) / MT));
-    h->nb_mr = (int)std::min<long long>(512, std::max<long long>(std::min<long long>(64, (n + TB - 1) / TB), n / 1536));
+    h->nb_mr = (int)std::min<long long>(512, std::max<long long>(std::min<long long>(64, (n + TB - 1) / TB), n / 1024));
+    if (getenv("SMCMI_NOOP_GRID")) h->noop_grid = std::max(1, atoi(getenv("SMCMI_NOOP_GRID")));   // development only
+    if (getenv("SMCMI_NB_MR")) h->nb_mr = std::max(1, atoi(getenv("SMCMI_NB_MR")));   // development only
     // mutation block size: largest of 256/128/64 threads whose per-thread LDS vectors fit 64 KiB
     for (int T : {256, 128, 64}) {
         h->mut_T = T;
@@ -436,7 +439,7 @@ extern "C" int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, c
     }
     k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
     k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
-    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1);
+    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1, h->nb_e);
     k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, h->cfg.gid0, h->cfg.n_parts, method,
                                                                          h->cfg.seed, stage, d_off, h->d_anc, nullptr, 1);
     // the gathered cloud sits in buffer 1; the current cloud is always buffer 0
@@ -644,8 +647,8 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     if (adaptive) enqueue_solver(h, P);
     k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
     k_post_correct<<<1, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, P == 0 ? 0 : (P & 1));
-    k_scan_weights<<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 0);
-    k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
+    k_scan_weights<<<std::min(h->nb_e, h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 0, h->nb_e);
+    k_resample_gather<<<(unsigned)std::min<long long>((n + TB - 1) / TB, 4 * h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
                                                                  nullptr, h->d_anc, nullptr, 0);
     const int nbm = launch_moments(h, h->d_hist_W, 0);
     k_prepare_mutation<<<1, PT, h->prep_lds, s>>>(h->d_st, h->d_model, h->d_part_mom, nbm, h->cfg.seed, 1, 1, 0);
@@ -863,7 +866,7 @@ extern "C" int smcmi_shard_resample(smcmi_handle *h, const double *dev_full_weig
     wcl.n = N; wcl.R = 1;
     k_weight_chunk_sums<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_part_full);
     k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_full, h->nb_full, h->d_off_full, 0.0, 1);
-    k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 1);
+    k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 1, h->nb_full);
     k_resample_gather<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum_full, N, h->cfg.gid0, N, method,
                                                                             h->cfg.seed, stage, nullptr, h->d_anc, dev_full_cloud, 1);
     if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, h->d_anc, sizeof(long long) * h->n, hipMemcpyDeviceToHost, h->stream));
@@ -916,7 +919,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0);
     k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
     k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
-    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1);
+    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1, h->nb_e);
     { const int nbm0 = launch_moments(h, nullptr, 1);
       k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm0, h->npairs, h->d_totals, 1); }
     k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_totals, 0, h->cfg.seed, 2, 1, 0);
@@ -933,7 +936,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
         case 1: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[0], h->d_part_ess[1], h->nb_e, 1, nullptr, 0, h->d_prof); break;
         case 2: k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, h->d_hist_w, n); break;
         case 3: k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, 0); break;
-        case 4: k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1); break;
+        case 4: k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1, h->nb_e); break;
         case 5: k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, 0, h->cfg.seed, 3u, nullptr, h->d_anc, nullptr, 1); break;
         case 6: launch_moments(h, nullptr, 1); break;
         case 7: k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->npairs, h->d_totals, 1); break;
