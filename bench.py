@@ -95,16 +95,22 @@ def main():
             return eng.run(use_graph=(2 if profile else (1 if args.mode == "graph" else 0)), solver_passes=args.solver_passes,
                            sync_every=args.sync_every, **RUN_KW)
     else:
-        from smc_jl_amd.host.distributed import ShardedSMC
+        # one process per GPU: equal contiguous shards, RCCL communicator bootstrapped through torch.distributed
+        from smc_jl_amd import Engine, comm_unique_id
 
-        sm = ShardedSMC(spec, n_total, seed=seed, device=local_rank, max_stages=max_stages,
-                        store_history=not args.no_history)
-        sm.init_from_prior()
-        sm.snapshot()
+        eng = Engine(n_total, D, seed=seed, device=local_rank, max_stages=max_stages, store_history=not args.no_history,
+                     n_local=n_local, gid0=rank * n_local)
+        eng.set_model(spec)
+        eng.init_from_prior()
+        uid = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(rank, world, uid[0])
+        snap = eng.cloud_tensor().clone()
 
         def one_step(profile=False):
-            sm.restore()
-            return sm.run(**RUN_KW)
+            eng.cloud_tensor().copy_(snap)
+            torch.cuda.synchronize()
+            return eng.run_sharded(solver_passes=args.solver_passes, **RUN_KW)
 
     for _ in range(args.warmup):
         one_step()

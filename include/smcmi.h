@@ -161,6 +161,16 @@ int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free, const dou
                                const int32_t *blocks_free, int32_t n_blocks, double phi_n, double phi_prev, double c,
                                double alpha, int32_t n_mh_steps, uint32_t stage);                      /* comm[0] = Σ accept */
 int smcmi_sync(smcmi_handle *h);
+
+/* ---- sharded whole-loop drivers (csrc/sharded.hpp) -------------------------------------------------
+   One handle per GPU/process, equal contiguous shards.  smcmi_comm_unique_id on rank 0 -> broadcast the 128 bytes by any means
+   -> smcmi_comm_init on every rank (RCCL communicator over xGMI) -> smcmi_run_sharded: the loop of smcmi_run with in-stream
+   all-reduces of the stage sums and an all-gather on resample stages.  smcmi_run_group drives several handles of ONE process
+   in lock step (single-process multi-shard / multi-GPU; host-mediated sums). */
+int smcmi_comm_unique_id(uint8_t *id_out /* 128 bytes */);
+int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *id);
+int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
+int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res);
 /* development aid: mean duration (µs, HIP events on the handle's stream) of `reps` back-to-back launches of one stage kernel on
    the current cloud.  which: 0 pass16(p=0) 1 pass16(p=1, with decision prologue) 2 correction 3 post_correct 4 scan 5 resample_gather
    6 moments 7 moments_reduce 8 prepare_mutation 9 mutate 10 stage_begin 11 empty kernel */

@@ -524,7 +524,8 @@ __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevStat
 __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevState *st, const double *cum, long long n_cum,
                                                         long long slot0, long long n_parts_total, int method,
                                                         unsigned long long seed, unsigned stage, const double *offsets,
-                                                        long long *anc, const double *full, int force) {
+                                                        long long *anc, const double *full, int force, long long full_shard_n = 0,
+                                                        int dst_buf = -1) {
     if (!force && (st->done || !st->do_resample)) return;
     if (!force) stage = (unsigned)st->stage;
     for (long long k = (long long)blockIdx.x * TB + threadIdx.x; k < cl.n; k += (long long)gridDim.x * TB) {
@@ -545,13 +546,20 @@ __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevS
     }
     const long long a = lo < n_cum ? lo : n_cum - 1;
     if (anc) anc[k] = a;
-    const int src = st->cur, dst = full ? src : (src ^ 1), R = cl.R;
+    const int src = st->cur, dst = dst_buf >= 0 ? dst_buf : (full ? src : (src ^ 1)), R = cl.R;
+    // source row: the local buffer, an n_cum x R column-major cloud, or (full_shard_n > 0) the concatenation of per-rank
+    // [R][full_shard_n] shard buffers as an all-gather delivers them
     const double *from = full ? full : cl.buf[src];
-    const long long ldf = full ? n_cum : cl.n;
+    long long ldf = full ? n_cum : cl.n, a_row = a;
+    if (full && full_shard_n > 0) {
+        from = full + (a / full_shard_n) * (long long)R * full_shard_n;
+        ldf = full_shard_n;
+        a_row = a % full_shard_n;
+    }
     for (int c0 = 0; c0 < R - 1; c0 += 8) {          // 8 indexed loads in flight, then the coalesced stores
         double tmp[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) tmp[q] = (c0 + q < R - 1) ? from[(long long)(c0 + q) * ldf + a] : 0.0;
+        for (int q = 0; q < 8; ++q) tmp[q] = (c0 + q < R - 1) ? from[(long long)(c0 + q) * ldf + a_row] : 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (c0 + q < R - 1) col(cl, dst, c0 + q)[k] = tmp[q];

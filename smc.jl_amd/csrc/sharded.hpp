@@ -1,0 +1,301 @@
+// sharded.hpp - the stage loop over particle shards (one shard per GPU), included by smcmi.hip.
+//
+// Replaces the reference's only parallel mode - `@distributed` over particles with the whole cloud serialised to every worker
+// each stage (src/smc_main.jl:169-170, 472-476) - by resident shards and a handful of tiny in-stream collectives:
+//   per solver pass : all-reduce of 2 KC doubles (Σv, Σv² per candidate)      correction : all-reduce of (ΣW̃, ΣW̃²)
+//   moments         : all-reduce of 1 + d + d(d+1)/2 doubles                  mutation   : all-reduce of Σ accept
+//   selection       : (ESS < threshold only) all-gather of the weight column and of the shard clouds; every rank forms the
+//                     same global cumulative sum and gathers the ancestors of ITS output slots.
+// The kernels are the single-GPU ones: a pass prologue / k_post_correct / k_prepare_mutation / k_stage_begin that is handed
+// the all-reduced totals as "partials of 1 block" takes exactly the same decision on every rank.
+// Two communicators implement the collectives: RCCL (one process per GPU, xGMI; the library is dlopen'ed so that libsmcmi.so
+// has no hard dependency on it) and an in-process group of handles (single-process multi-shard runs; used by the GPU tests
+// to exercise this driver with 2-4 shards on one device).
+#pragma once
+#include <dlfcn.h>
+
+// ---- minimal RCCL surface (rccl.h:40-43 and the five entry points used), resolved at run time
+struct smcmi_nccl_uid { char internal[128]; };
+typedef void *smcmi_nccl_comm;
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(smcmi_nccl_uid *) = nullptr;
+    int (*CommInitRank)(smcmi_nccl_comm *, int, smcmi_nccl_uid, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, smcmi_nccl_comm, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, smcmi_nccl_comm, hipStream_t) = nullptr;
+    int (*CommDestroy)(smcmi_nccl_comm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+enum { SMCMI_NCCL_DOUBLE = 8, SMCMI_NCCL_SUM = 0 };   // ncclFloat64, ncclSum
+
+static int load_rccl() {
+    if (g_rccl.lib) return 0;
+    const char *cands[] = {getenv("SMCMI_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *c : cands) {
+        if (!c || !*c) continue;
+        g_rccl.lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return set_err(SMCMI_ERR_UNSUPPORTED, std::string("cannot load RCCL: ") + dlerror());
+#define SMCMI_SYM(field, name) *(void **)(&g_rccl.field) = dlsym(g_rccl.lib, name)
+    SMCMI_SYM(GetUniqueId, "ncclGetUniqueId"); SMCMI_SYM(CommInitRank, "ncclCommInitRank"); SMCMI_SYM(AllReduce, "ncclAllReduce");
+    SMCMI_SYM(AllGather, "ncclAllGather"); SMCMI_SYM(CommDestroy, "ncclCommDestroy"); SMCMI_SYM(GetErrorString, "ncclGetErrorString");
+#undef SMCMI_SYM
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather)
+        return set_err(SMCMI_ERR_UNSUPPORTED, "RCCL library lacks the required entry points");
+    return 0;
+}
+#define NCCL_TRY(expr)                                                                                                    \
+    do {                                                                                                                  \
+        int r_ = (expr);                                                                                                  \
+        if (r_ != 0) return set_err(SMCMI_ERR_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "nccl error")); \
+    } while (0)
+
+static void smcmi_comm_release(smcmi_handle *h) {
+    if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
+    h->nccl = nullptr;
+}
+
+extern "C" int smcmi_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (int rc = load_rccl()) return rc;
+    smcmi_nccl_uid id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, id.internal, 128);
+    return 0;
+}
+
+extern "C" int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *id) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return set_err(SMCMI_ERR_ARG, "bad argument");
+    if (h->cfg.n_local * world != h->cfg.n_parts || h->cfg.gid0 != rank * h->cfg.n_local)
+        return set_err(SMCMI_ERR_ARG, "handle shard (n_local, gid0) does not match (rank, world): equal contiguous shards are required");
+    if (int rc = load_rccl()) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    smcmi_nccl_uid uid;
+    memcpy(uid.internal, id, 128);
+    smcmi_nccl_comm c = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&c, world, uid, rank));
+    h->nccl = c; h->rank = rank; h->world = world;
+    return 0;
+}
+
+// ---- collectives over a group of lock-stepped local handles, optionally extended over ranks by RCCL
+struct ShardGroup {
+    std::vector<smcmi_handle *> hs;   // local shards (same process); RCCL mode: exactly one
+    int world = 1;                    // total number of shards
+    bool rccl = false;
+
+    int sync_all() {
+        for (auto *h : hs) { HIP_TRY(hipSetDevice(h->cfg.device)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+        return 0;
+    }
+    // in-place sum of `count` doubles at buf(h) over all shards, same result everywhere (fixed shard order)
+    template <class F>
+    int allreduce(F buf, int count) {
+        if (rccl) {
+            smcmi_handle *h = hs[0];
+            NCCL_TRY(g_rccl.AllReduce(buf(h), buf(h), (size_t)count, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
+            return 0;
+        }
+        if (hs.size() == 1) return 0;
+        if (int rc = sync_all()) return rc;
+        std::vector<double> tot(count, 0.0), tmp(count);
+        for (auto *h : hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            HIP_TRY(hipMemcpy(tmp.data(), buf(h), sizeof(double) * count, hipMemcpyDeviceToHost));
+            for (int k = 0; k < count; ++k) tot[k] += tmp[k];
+        }
+        for (auto *h : hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            HIP_TRY(hipMemcpy(buf(h), tot.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+    // recv(h)[r * count .. (r+1) * count) = send(shard r)
+    template <class FS, class FR>
+    int allgather(FS send, FR recv, size_t count) {
+        if (rccl) {
+            smcmi_handle *h = hs[0];
+            NCCL_TRY(g_rccl.AllGather(send(h), recv(h), count, SMCMI_NCCL_DOUBLE, h->nccl, h->stream));
+            return 0;
+        }
+        if (int rc = sync_all()) return rc;
+        for (auto *dst : hs) {
+            HIP_TRY(hipSetDevice(dst->cfg.device));
+            for (size_t r = 0; r < hs.size(); ++r)
+                HIP_TRY(hipMemcpy(recv(dst) + r * count, send(hs[r]), sizeof(double) * count, hipMemcpyDeviceToDevice));
+        }
+        return 0;
+    }
+};
+
+static int ensure_shard_buffers(smcmi_handle *h) {
+    const long long N = h->cfg.n_parts;
+    if (!h->d_tot_ess) {
+        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs) || dmalloc(&h->d_tot_acc, 1))
+            return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double)));
+    }
+    if (!h->d_cum_full) {
+        if (dmalloc(&h->d_cum_full, N)) return SMCMI_ERR_HIP;
+        h->nb_full = (int)std::min<long long>(1024, std::max<long long>(1, (N + 511) / 512));
+        if (dmalloc(&h->d_part_full, (size_t)h->nb_full * 2) || dmalloc(&h->d_off_full, h->nb_full)) return SMCMI_ERR_HIP;
+    }
+    if (!h->d_full_w) {
+        if (dmalloc(&h->d_full_w, N) || dmalloc(&h->d_full_cloud, (size_t)N * h->R)) return SMCMI_ERR_HIP;
+    }
+    return 0;
+}
+
+// one stage, phase by phase over all local shards (the phases between collectives are independent per shard)
+static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res) {
+    smcmi_handle *h0 = g.hs[0];
+    const int nf = h0->h_model.n_free;
+    if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
+        return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
+    if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
+    const bool adaptive = !rc->use_fixed_schedule;
+    const int P = adaptive ? (rc->solver_passes > 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES) : 0;
+    std::vector<double> sched(rc->n_phi);
+    for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
+    for (auto *h : g.hs) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
+        if (ensure_shard_buffers(h) || pull_state(h) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
+        DevState &s = h->h_st;
+        RunParams rp{};
+        rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
+        rp.resampling_method = rc->resampling_method; rp.use_fixed_schedule = rc->use_fixed_schedule;
+        rp.threshold = rc->threshold_ratio * (double)h->cfg.n_parts;
+        rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
+        rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
+        rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+        rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
+        memset(&s, 0, sizeof(DevState));
+        s.rp = rp;
+        s.stage = 1; s.j = 2; s.c = rc->c; s.accept = rc->target; s.ess_prev = (double)h->cfg.n_parts;
+        if (push_state(h)) return SMCMI_ERR_HIP;
+        const double v0[4] = {0.0, (double)h->cfg.n_parts, rc->c, rc->target};
+        HIP_TRY(hipMemcpy(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->rec.accept, &v0[3], sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages));
+        if (h->cfg.store_history) {
+            HIP_TRY(hipMemset(h->d_hist_w, 0, sizeof(double) * h->n));
+            HIP_TRY(hipMemcpy(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice));
+        }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int max_iter = adaptive ? h0->cfg.max_stages : rc->n_phi - 1;
+    int done = 0, iters = 0;
+    while (iters < max_iter && !done) {
+        // ---- stage begin + adaptive-ϕ solver
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc, 1, h->rec);
+        }
+        for (int p = 0; p < P; ++p) {
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_ess[p & 1], 1, p, nullptr, 0);
+                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess[p & 1], h->nb_e, 2 * KC, h->d_tot_ess);
+            }
+            if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_ess; }, 2 * KC)) return rc2;
+        }
+        // ---- correction
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_fin, 1, P, h->d_hist_w, h->n);
+            k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
+        }
+        if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
+        int flags[2] = {0, 0};
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_tot_fin, 1, nullptr, h->rec, P == 0 ? 0 : (P & 1));
+        }
+        // the selection needs a collective only on resample stages: the one host decision per stage (identical on all ranks)
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        HIP_TRY(hipMemcpyAsync(&flags[0], &h0->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+        HIP_TRY(hipMemcpyAsync(&flags[1], &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+        HIP_TRY(hipStreamSynchronize(h0->stream));
+        if (flags[1]) { done = 1; break; }
+        if (flags[0]) {
+            const size_t nloc = (size_t)h0->n;
+            if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)(h->cl.buf[0] + (long long)(h->R - 1) * h->n); },
+                                      [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return rc2;
+            if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)h->cl.buf[0]; },
+                                      [](smcmi_handle *h) { return h->d_full_cloud; }, nloc * h0->R)) return rc2;
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                const long long N = h->cfg.n_parts;
+                CloudPtrs wcl{};
+                wcl.buf[0] = wcl.buf[1] = h->d_full_w; wcl.n = N; wcl.R = 1;
+                k_weight_chunk_sums<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_part_full);
+                k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_full, h->nb_full, h->d_off_full, 0.0, 0);
+                k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 1, h->nb_full);
+                k_resample_gather<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum_full, N, h->cfg.gid0, N,
+                                                                                        rc->resampling_method, h->cfg.seed, 0u, nullptr, h->d_anc,
+                                                                                        h->d_full_cloud, 0, h->n, 1);
+            }
+        }
+        // ---- moments -> proposal -> mutation
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            const int nbm = launch_moments(h, h->d_hist_W, 0);
+            k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm, h->npairs, h->d_tot_mom, 0);
+        }
+        if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_mom; }, h0->npairs)) return rc2;
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_tot_mom, 1, h->cfg.seed, 2, 1, 0);
+            const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
+            k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc);
+        }
+        if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, 1)) return rc2;
+        ++iters;
+    }
+    // fold the last acceptance rate, close the run
+    for (auto *h : g.hs) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc, 1, h->rec);
+        if (pull_state(h)) return SMCMI_ERR_HIP;
+        h->last_n_stages = h->h_st.stage;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const DevState &s = h0->h_st;
+    memset(res, 0, sizeof(*res));
+    res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
+    res->seconds = std::chrono::duration<double>(t1 - t0).count();
+    res->solver_passes = s.solver_passes;
+    if (s.err) return err_from_state(s.err);
+    if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
+    return 0;
+}
+
+extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
+    if (int e = need_model(h, true)) return e;
+    if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (!h->nccl) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init has not been called on this handle");
+    ShardGroup g;
+    g.hs = {h}; g.world = h->world; g.rccl = true;
+    return run_sharded_impl(g, rc, res);
+}
+
+extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res) {
+    if (!hs || n < 1 || !rc || !res) return set_err(SMCMI_ERR_ARG, "bad argument");
+    ShardGroup g;
+    long long expect = 0;
+    for (int k = 0; k < n; ++k) {
+        if (int e = need_model(hs[k], true)) return e;
+        if (hs[k]->cfg.gid0 != expect || hs[k]->cfg.n_local != hs[0]->cfg.n_local || hs[k]->cfg.n_parts != hs[0]->cfg.n_parts)
+            return set_err(SMCMI_ERR_ARG, "group handles must be equal contiguous shards in rank order");
+        expect += hs[k]->cfg.n_local;
+        g.hs.push_back(hs[k]);
+    }
+    if (expect != hs[0]->cfg.n_parts) return set_err(SMCMI_ERR_ARG, "group handles do not cover n_parts");
+    g.world = n; g.rccl = false;
+    return run_sharded_impl(g, rc, res);
+}

@@ -63,6 +63,10 @@ struct smcmi_handle {
     int *d_acc_count = nullptr, *d_flag = nullptr;
     double *d_cum_full = nullptr, *d_part_full = nullptr, *d_off_full = nullptr;
     int nb_full = 0;
+    // sharded driver (sharded.hpp)
+    void *nccl = nullptr;
+    int rank = 0, world = 1;
+    double *d_tot_ess = nullptr, *d_tot_fin = nullptr, *d_tot_mom = nullptr, *d_tot_acc = nullptr, *d_full_w = nullptr, *d_full_cloud = nullptr;
     int last_n_stages = 1;
     int launch_nb = 1;
     int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
@@ -104,6 +108,7 @@ static int err_from_state(int code) {
 }
 
 static int set_mutate_attrs(smcmi_handle *h);
+static void smcmi_comm_release(smcmi_handle *h);
 
 // ------------------------------------------------------------------------------------------------ lifetime
 extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
@@ -192,11 +197,13 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
                     h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
-                    h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full};
+                    h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
+                    h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -892,6 +899,8 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
     if (pull_state(h)) return SMCMI_ERR_HIP;
     return err_from_state(s.err);
 }
+
+#include "sharded.hpp"
 
 // ------------------------------------------------------------------------------------------------ development aid
 __global__ void k_empty(const DevState *st) { if (st->done == 12345) printf("x"); }

@@ -82,6 +82,10 @@ SYMBOLS = [
     ("smcmi_shard_mutate_partial", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32]),
     ("smcmi_sync", C.c_int, [_H]),
     ("smcmi_debug_time_kernel", C.c_int, [_H, C.c_int32, C.c_int32, dp]),
+    ("smcmi_comm_unique_id", C.c_int, [C.c_char_p]),
+    ("smcmi_comm_init", C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p]),
+    ("smcmi_run_sharded", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),
+    ("smcmi_run_group", C.c_int, [C.POINTER(_H), C.c_int32, C.POINTER(RunConfig), C.POINTER(Result)]),
 ]
 
 _LIB = None
@@ -106,7 +110,11 @@ def _share_hip_runtime_with_torch():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("SMCMI_RCCL_PATH", rccl)      # the sharded driver dlopens the same RCCL copy torch uses
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)

@@ -163,6 +163,33 @@ class Engine:
                     seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
                     solver_passes=res.solver_passes)
 
+    def _run_config(self, n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
+                    use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, sync_every, use_graph,
+                    phi_rtol):
+        return _lib.RunConfig(n_blocks, n_mh_steps, lam, n_phi, _lib.RESAMPLE[resampling_method], threshold_ratio, c, alpha,
+                              target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, solver_passes,
+                              sync_every, use_graph, phi_rtol)
+
+    @staticmethod
+    def _result(res):
+        return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
+                    seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
+                    solver_passes=res.solver_passes)
+
+    # ---- sharded whole-loop drivers (csrc/sharded.hpp) ---------------------------------------------------
+    def comm_init(self, rank, world, unique_id):
+        """Join the RCCL communicator (unique_id: the 128 bytes of comm_unique_id() from rank 0)."""
+        check(self._L.smcmi_comm_init(self._h, rank, world, bytes(unique_id)))
+
+    def run_sharded(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
+                    c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
+                    log_prob_old_data=0.0, solver_passes=0, phi_rtol=0.0):
+        rc = self._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
+                              use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, 0, 0, phi_rtol)
+        res = _lib.Result()
+        check(self._L.smcmi_run_sharded(self._h, C.byref(rc), C.byref(res)))
+        return self._result(res)
+
     def stage_records(self, n_stages):
         phi, ess, c, acc = (np.empty(n_stages) for _ in range(4))
         rs = np.empty(n_stages, dtype=np.int32)
@@ -234,3 +261,23 @@ class Engine:
         check(self._L.smcmi_shard_resample(self._h, C.c_void_p(full_weights.data_ptr()), C.c_void_p(full_cloud.data_ptr()),
                                            _lib.RESAMPLE[method], stage, anc.ctypes.data_as(lp)))
         return anc
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (call on rank 0, broadcast the 128 bytes to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    check(_lib.lib().smcmi_comm_unique_id(buf))
+    return buf.raw
+
+
+def run_group(engines, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5, c=0.5,
+              alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0, log_prob_old_data=0.0,
+              solver_passes=0, phi_rtol=0.0):
+    """Drive several shard engines of this process in lock step (smcmi_run_group)."""
+    e0 = engines[0]
+    rc = e0._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target, use_fixed_schedule,
+                        tempering_target, prior_weight, log_prob_old_data, solver_passes, 0, 0, phi_rtol)
+    res = _lib.Result()
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    check(_lib.lib().smcmi_run_group(arr, len(engines), C.byref(rc), C.byref(res)))
+    return Engine._result(res)
