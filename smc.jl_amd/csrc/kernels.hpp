@@ -417,11 +417,44 @@ __global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *
     S.mode = MODE_SCAN;
 }
 
+// Inclusive scan of W̃/ΣW̃ over chunk `vb` (cumsum(weights ./ sum(weights)), src/resample.jl:29,47): thread t owns IPT
+// consecutive items so the running sum follows particle order; `carry` = sum of the preceding chunks.
+__device__ inline void scan_chunk(const double *w, long long n, int n_chunks, int vb, double carry, double total, double *cum,
+                                  double *s_tot /* TB doubles of LDS */) {
+    long long beg, end;
+    block_chunk(n, n_chunks, vb, beg, end);
+    constexpr int IPT = 4;
+    for (long long base = beg; base < end; base += (long long)TB * IPT) {
+        const long long i0 = base + (long long)threadIdx.x * IPT;
+        double v[IPT], run = 0.0;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { v[k] = (i0 + k < end) ? w[i0 + k] : 0.0; run += v[k]; v[k] = run; }
+        s_tot[threadIdx.x] = run;
+        __syncthreads();
+        for (int off = 1; off < TB; off <<= 1) {   // Hillis-Steele inclusive scan of the 256 thread totals
+            const double add = (threadIdx.x >= off) ? s_tot[threadIdx.x - off] : 0.0;
+            __syncthreads();
+            s_tot[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const double excl = (threadIdx.x > 0 ? s_tot[threadIdx.x - 1] : 0.0) + carry;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k)
+            if (i0 + k < end) cum[i0 + k] = (excl + v[k]) / total;
+        carry += s_tot[TB - 1];
+        __syncthreads();
+    }
+}
+
 // After the correction pass: ESS, log-MDD increment, resample decision, step-size adaptation
 // (src/smc_main.jl:427-455, src/particle.jl:362-366); copies the solver's (ϕ_n, j, ϕ_prop) back to the loop scalars and,
 // on resample stages, forms the exclusive prefix of the per-block weight sums for the resampling scan.
+// Launched with one block (stand-alone / sharded callers, chunk offsets only) or with one block per weight chunk and `cum`
+// set (smcmi_run): then every block recomputes the decision from the same partial sums (no mutable state is read for it),
+// block 0 alone does the bookkeeping, and on resample stages each block scans its own chunk right here - the separate scan
+// launch (a ~4 µs no-op on 95 % of the stages) disappears.
 __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double *partials, int nb, double *chunk_off,
-                                                     Records rec, int sol_slot) {
+                                                     Records rec, int sol_slot, CloudPtrs cl = CloudPtrs{}, double *cum = nullptr) {
     __shared__ double scratch[TB];
     __shared__ double s_tot[2];
     __shared__ int s_rs;
@@ -440,7 +473,11 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
     if (threadIdx.x < 2) s_tot[threadIdx.x] = v;
     if (threadIdx.x == 0) s_rs = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.x != 0) {          // other blocks: the decision only
+        const double ess = s_tot[0] * s_tot[0] / s_tot[1];
+        s_rs = (!isnan(ess) && ess < thr) ? 1 : 0;
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double s1 = s_tot[0], s2 = s_tot[1];
         const double ess = s1 * s1 / s2;
         const bool bad = isnan(ess);
@@ -462,7 +499,7 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
         }
     }
     __syncthreads();
-    if (s_rs && chunk_off) {
+    if (s_rs && (chunk_off || cum)) {
         // exclusive prefix of partials[2 b] in block order: 256 threads x 4 blocks each, then a sequential carry
         const int t = threadIdx.x;
         double loc[4], run = 0.0;
@@ -472,8 +509,19 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
         __syncthreads();
         if (t == 0) { double carry = 0.0; for (int q = 0; q < TB; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
         __syncthreads();
+        if (cum) {
+            // fused selection scan: this block's chunk(s); offsets come from the prefix every block just rebuilt identically
+            __shared__ double s_off[4 * TB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; if (b < nb) chunk_off[b] = scratch[t] + loc[q]; }
+            for (int q = 0; q < 4; ++q) s_off[t * 4 + q] = scratch[t] + loc[q];
+            __syncthreads();
+            const double *w = col(cl, 0, cl.R - 1);
+            const double total = s_tot[0];
+            for (int vb = blockIdx.x; vb < nb; vb += gridDim.x) scan_chunk(w, cl.n, nb, vb, s_off[vb], total, cum, scratch);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; if (b < nb) chunk_off[b] = scratch[t] + loc[q]; }
+        }
     }
 }
 
@@ -486,34 +534,7 @@ __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevStat
     if (!force && (st->done || !st->do_resample)) return;
     const double *w = col(cl, st->cur, cl.R - 1);
     const double total = st->sumw;
-    // the launch may use fewer blocks than chunks (most stages do not resample: a small grid makes the no-op cheap)
-    for (int vb = blockIdx.x; vb < n_chunks; vb += gridDim.x) {
-    long long beg, end;
-    block_chunk(cl.n, n_chunks, vb, beg, end);
-    double carry = chunk_off[vb];
-    constexpr int IPT = 4;
-    for (long long base = beg; base < end; base += (long long)TB * IPT) {
-        // thread t owns IPT consecutive items so that the running sum follows particle order
-        const long long i0 = base + (long long)threadIdx.x * IPT;
-        double v[IPT], run = 0.0;
-#pragma unroll
-        for (int k = 0; k < IPT; ++k) { v[k] = (i0 + k < end) ? w[i0 + k] : 0.0; run += v[k]; v[k] = run; }
-        s_tot[threadIdx.x] = run;
-        __syncthreads();
-        for (int off = 1; off < TB; off <<= 1) {   // Hillis-Steele inclusive scan of the 256 thread totals
-            const double add = (threadIdx.x >= off) ? s_tot[threadIdx.x - off] : 0.0;
-            __syncthreads();
-            s_tot[threadIdx.x] += add;
-            __syncthreads();
-        }
-        const double excl = (threadIdx.x > 0 ? s_tot[threadIdx.x - 1] : 0.0) + carry;
-#pragma unroll
-        for (int k = 0; k < IPT; ++k)
-            if (i0 + k < end) cum[i0 + k] = (excl + v[k]) / total;
-        carry += s_tot[TB - 1];
-        __syncthreads();
-    }
-    }
+    for (int vb = blockIdx.x; vb < n_chunks; vb += gridDim.x) scan_chunk(w, cl.n, n_chunks, vb, chunk_off[vb], total, cum, s_tot);
 }
 
 // Selection for output slot k: ancestor = first j with cum[j] > thr (src/resample.jl:51-70 systematic walk, :33-41

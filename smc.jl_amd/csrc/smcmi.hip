@@ -653,8 +653,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     k_stage_begin<<<1, TB, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
     if (adaptive) enqueue_solver(h, P);
     k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
-    k_post_correct<<<1, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, P == 0 ? 0 : (P & 1));
-    k_scan_weights<<<std::min(h->nb_e, h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 0, h->nb_e);
+    k_post_correct<<<h->nb_e, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, P == 0 ? 0 : (P & 1), h->cl, h->d_cum);
     k_resample_gather<<<(unsigned)std::min<long long>((n + TB - 1) / TB, 4 * h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
                                                                  nullptr, h->d_anc, nullptr, 0);
     const int nbm = launch_moments(h, h->d_hist_W, 0);
