@@ -155,12 +155,12 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pm = json.load(f)
-            k = [v for name, v in pm["kernels"].items() if "k_mutate_reg<%d>" % D in name]
+            k = [v for name, v in pm["kernels"].items() if "k_mutate_reg<%d," % D in name]
             if k:
                 traffic = k[0]["bytes_per_particle"] * n_total
         except OSError:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "k_mutate_reg<%d>" % D, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "k_mutate_reg<%d,true>" % D, "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl}
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages

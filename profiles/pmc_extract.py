@@ -19,9 +19,14 @@ def per_kernel(db, counter):
 
 
 def active_mean(vals):
-    m = max(vals)
-    act = [v for v in vals if v > 0.5 * m]      # drop early-exit (no-op) launches
-    return sum(act) / len(act), len(act), len(vals)
+    """Typical (median) value over the launches that did work: early-exit no-ops are dropped; the rare heavier launches
+    (resample stages copy the cloud back inside k_moments) do not move a median."""
+    pos = sorted(v for v in vals if v > 0)
+    if not pos:
+        return 0.0, 0, len(vals)
+    med = pos[len(pos) // 2]
+    act = sorted(v for v in vals if v > 0.5 * med)
+    return act[len(act) // 2], len(act), len(vals)
 
 
 fetch, write, n = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3])
