@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--mode", default="direct", choices=["direct", "graph"], help="stage launch mode")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-history", action="store_true")
+    ap.add_argument("--workload", default="gauss10", choices=["gauss10", "capm"],
+                    help="gauss10 = BASELINE config 2 (the bench line); capm = config 4 (examples/capm_model, 3 MH steps, fixed schedule)")
     ap.add_argument("--solver-passes", type=int, default=0)
     ap.add_argument("--sync-every", type=int, default=0)
     args = ap.parse_args()
@@ -66,7 +68,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    spec = models.gauss_spec(D)
+    global D, RUN_KW
+    if args.workload == "capm":
+        spec, D = models.capm_spec(), 9
+        RUN_KW = dict(use_fixed_schedule=True, n_phi=300, lam=2.1, resampling_method="systematic", n_blocks=1, n_mh_steps=3,
+                      alpha=1.0, c=0.5, target=0.25, threshold_ratio=0.5)
+        if args.nparts == N_PER_GPU:
+            args.nparts = 200_000
+    else:
+        spec = models.gauss_spec(D)
     seed = 1
     n_local = args.nparts
     n_total = n_local * world
@@ -133,12 +143,13 @@ def main():
         "metric": "particle-stages/sec", "value": value, "unit": "particle-stages/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "gauss%d_isotropic_adaptive_phi_n%dk_per_gpu" % (D, n_local // 1000),
+        "config": {"workload": ("gauss%d_isotropic_adaptive_phi_n%dk_per_gpu" % (D, n_local // 1000)) if args.workload == "gauss10"
+                   else "capm_literal_fixed_schedule_3mh_n%dk_per_gpu" % (n_local // 1000),
                    "n_parts_total": n_total, "n_para": D, "tempering_target": 0.97, "n_phi": 300, "lambda": 2.1,
-                   "resampling": "systematic", "n_blocks": 1, "n_mh_steps": 1, "launch_mode": args.mode,
+                   "resampling": "systematic", "n_blocks": 1, "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
-        "logmdd_exact": models.gauss_logmdd(D), "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
+        "logmdd_exact": models.gauss_logmdd(D) if args.workload == "gauss10" else None, "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
     }
 
     if rank == 0 and world == 1 and not force_sharded:
@@ -147,7 +158,7 @@ def main():
         prof = one_step(profile=True)
         nl = max(prof["n_mutate_launches"], 1)
         mean_ms = prof["kernel_ms_mutate"] / nl
-        bytes_per_launch = mutate_bytes_per_particle(D) * n_total
+        bytes_per_launch = mutate_bytes_per_particle(D) * n_total      # all MH steps of a stage are fused in the one launch
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read correction):
         # profiles/pmc_extract.py -> profiles/r01_pmc_traffic.json, bytes per particle of this kernel x particles

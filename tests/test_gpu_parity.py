@@ -237,9 +237,11 @@ def _mutation_case(orc, spec, n, n_blocks, n_mh, alpha, c, phi, seed, stage, P=N
 
 @pytest.mark.parametrize("name,n_blocks,n_mh,alpha", [("gauss", 1, 1, 1.0), ("gauss", 3, 2, 0.9), ("linmodel", 1, 1, 1.0),
                                                     ("linmodel", 2, 3, 0.9), ("capm", 1, 3, 1.0), ("regression", 2, 1, 0.8),
-                                                    ("linmodel_tempered", 3, 1, 0.9)])
+                                                    ("linmodel_tempered", 3, 1, 0.9), ("gauss", 3, 2, 1.0), ("linmodel", 2, 2, 1.0),
+                                                    ("linmodel_tempered", 2, 1, 1.0), ("gauss12", 2, 1, 0.9), ("gauss12", 1, 2, 1.0),
+                                                    ("gauss20", 3, 1, 0.9)])
 def test_mutation_vs_oracle(orc, name, n_blocks, n_mh, alpha):
-    spec = {"gauss": models.gauss_spec, "linmodel": models.linmodel_spec, "capm": models.capm_spec,
+    spec = {"gauss": models.gauss_spec, "gauss12": lambda: models.gauss_spec(d=12), "gauss20": lambda: models.gauss_spec(d=20), "linmodel": models.linmodel_spec, "capm": models.capm_spec,
             "regression": models.regression_spec, "linmodel_tempered": lambda: models.linmodel_spec(T=100, old_T=50)}[name]()
     n = 20000
     phi = 0.002 if name.startswith("linmodel") or name == "capm" else 0.05
@@ -400,6 +402,39 @@ def test_run_linmodel_posterior_mean(orc):
     assert g["n_stages"] == 120
 
 
+def test_run_capm_config4_vs_oracle(orc):
+    """BASELINE config 4 at test size: examples/capm_model (literal likelihood, Uniform priors on σ with bounds, 3 MH steps per
+    mutation, fixed schedule n_Φ = 300, defaults otherwise)."""
+    spec = models.capm_spec()
+    e, g, r = _compare_runs(orc, spec, 10000, 1793, 1e-3, n_mh_steps=3)
+    assert g["n_stages"] == 300
+    P = e.download_cloud()
+    assert np.all(P[:, [2, 5, 8]] >= 1e-5)                       # σ_i stay inside their bounds
+    assert 0.0 < g["accept"] < 3.0                               # quirk Q2: accept is normalised by n_free only
+
+
+def test_run_capm_config4_full_size_properties():
+    """Config 4 at its full size (N = 200 000): size-independent properties of the loop."""
+    spec = models.capm_spec()
+    n = 200000
+    e = make_engine(spec, n, seed=1793, max_stages=300, store_history=True)
+    e.init_from_prior()
+    g = e.run(n_mh_steps=3)
+    assert g["n_stages"] == 300 and np.isfinite(g["logmdd"])
+    rec = e.stage_records(300)
+    np.testing.assert_allclose(rec["schedule"], (np.arange(300) / 299.0) ** 2.1, rtol=1e-14)
+    assert np.all(rec["ess"] > 0) and np.all(rec["ess"] <= n * (1 + 1e-12))
+    assert np.all(rec["ess"][1:][rec["resampled"][1:] == 0] >= 0.5 * n)          # strict threshold (quirk Q9)
+    w, W = e.history(300)
+    np.testing.assert_allclose(W.sum(axis=0), float(n), rtol=1e-9)
+    assert np.all(W[:, rec["resampled"] == 1] == 1.0)
+    h = np.sum(np.log(np.sum(w[:, 1:] * W[:, :-1], axis=0) / n))
+    assert h == pytest.approx(g["logmdd"], abs=1e-7)
+    P = e.download_cloud()
+    assert np.all(np.isfinite(P)) and np.all(P[:, 13] == W[:, -1])
+    assert g["accept"] == pytest.approx(P[:, 12].mean(), rel=1e-12)
+
+
 def test_run_graph_equals_direct(orc):
     spec = models.gauss_spec(d=4)
     out = []
@@ -410,6 +445,16 @@ def test_run_graph_equals_direct(orc):
         out.append((g["n_stages"], g["logmdd"], e.download_cloud()))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     np.testing.assert_array_equal(out[0][2], out[1][2])         # bitwise: same kernels, same order
+
+
+@pytest.mark.parametrize("d,kw", [(12, dict(use_fixed_schedule=False, tempering_target=0.95)),
+                                  (20, dict(n_phi=80, n_blocks=3, alpha=0.9)),
+                                  (10, dict(n_phi=60, n_blocks=3, n_mh_steps=2))])
+def test_run_other_dimensions_and_blockings(orc, d, kw):
+    """d = 12 (register moments + generic LDS mutation), d = 20 (LDS-tiled moments + generic mutation), and the α = 1
+    natural-order factor with several blocks and MH steps."""
+    spec = models.gauss_spec(d=d)
+    _compare_runs(orc, spec, 8000, 23, 1e-3, **kw)
 
 
 def test_run_deterministic(orc):
