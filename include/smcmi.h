@@ -71,6 +71,7 @@ typedef struct {
     int32_t solver_passes;                 /* kernel passes allotted to the adaptive-ϕ solver per stage (0 => default 8) */
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
     int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
+    double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */
     double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-10; <0 => adjacent floats) */
 } smcmi_run_config;
 
@@ -108,6 +109,16 @@ int smcmi_upload_cloud(smcmi_handle *h, const double *particles);       /* n_loc
 int smcmi_download_cloud(smcmi_handle *h, double *particles);
 int smcmi_upload_cloud_device(smcmi_handle *h, const double *dev_particles);   /* device-to-device, same layout */
 int smcmi_init_from_prior(smcmi_handle *h);                              /* initial_draw!, initialization.jl:88-119 */
+int smcmi_initialize_likelihoods(smcmi_handle *h);                       /* initialize_likelihoods!, initialization.jl:153-186 */
+/* ---- tempered update from an old cloud (smc_main.jl:244-333); both handles whole clouds on one device ----
+   bridge_resample: resample(get_weights(old); n_parts = n_out, method) and copy those rows (weights included, as
+   update_cloud! does) to rows [0, n_out) of dst (:266-279).  offsets as in smcmi_resample.
+   copy_rows: vcat(bridge_cloud.particles, prior_cloud.particles) (:296).
+   normalize_weights: zero_bad_loglh_weights! (optional) then normalize_weights! (:313-314, particle.jl:362-366,392-396). */
+int smcmi_bridge_resample(smcmi_handle *dst, smcmi_handle *src, int32_t method, uint32_t stage, int64_t n_out,
+                          const double *offsets, int64_t *ancestors_out);
+int smcmi_copy_rows(smcmi_handle *dst, int64_t dst_row0, smcmi_handle *src, int64_t src_row0, int64_t n_rows);
+int smcmi_normalize_weights(smcmi_handle *h, int32_t zero_bad_loglh);
 int smcmi_cloud_device_ptr(smcmi_handle *h, double **dev_ptr, int64_t *ld); /* current buffer, for zero-copy hosts */
 
 /* ---- stage primitives (same kernels smcmi_run launches) --------------------------------------- */

@@ -6,6 +6,7 @@ cpu_baseline leg.  The product (smc.jl_amd -> libsmcmi.so) never imports this mo
 Clouds are numpy float64 arrays of shape (N, R) in FORTRAN order (= the reference's
 `cloud.particles`, Julia column-major; src/particle.jl:31-63).
 """
+import copy
 import ctypes as C
 import os
 import subprocess
@@ -39,7 +40,7 @@ class _RunConfig(C.Structure):
                 ("n_phi", C.c_int32), ("resampling_method", C.c_int32), ("threshold_ratio", C.c_double),
                 ("c", C.c_double), ("alpha", C.c_double), ("target", C.c_double), ("use_fixed_schedule", C.c_int32),
                 ("tempering_target", C.c_double), ("prior_weight", C.c_double), ("log_prob_old_data", C.c_double),
-                ("seed", C.c_uint64), ("max_stages", C.c_int32), ("n_threads", C.c_int32)]
+                ("seed", C.c_uint64), ("max_stages", C.c_int32), ("n_threads", C.c_int32), ("initial_ess", C.c_double)]
 
 
 class _RunResult(C.Structure):
@@ -265,9 +266,51 @@ def initial_draw(model, n, seed, pid0=0):
     return p
 
 
+def initialize_likelihoods(model, particles):
+    """initialize_likelihoods! (src/initialization.jl:153-186)."""
+    p = fcloud(particles)
+    m = model.struct()
+    lib().orc_initialize_likelihoods(C.byref(m), _d(p), C.c_int64(p.shape[0]))
+    return p
+
+
+def tempered_update_cloud(model, old_particles, old_ess_last, n_parts, prior_weight=0.0, resampling_method="systematic",
+                          seed=0):
+    """Initial cloud of a tempered update (src/smc_main.jl:244-333).  `model.lik` = new likelihood/data,
+    `model.old_lik` = old likelihood/old data.  Returns (particles, ESS[1]).  RNG: bridge resample = stage 0,
+    clean-up resample = stage 1, prior draws = initial_draw streams of particle ids 0..n_from_prior-1."""
+    old = fcloud(old_particles)
+    old_n, R = old.shape
+    d = R - 5
+    if prior_weight == 0.0 and old_n == n_parts:                      # :249-260
+        return initialize_likelihoods(model, old), float(old_ess_last)
+    n_to = int(round((1.0 - prior_weight) * n_parts))                  # :262-264
+    n_pr = n_parts - n_to
+    parts = []
+    if n_to > 0:
+        idx = resample(old[:, R - 1].copy(), n_parts=n_to, method=resampling_method, seed=seed, stage=0)
+        parts.append(old[idx, :])                                      # update_cloud!: whole rows, old weights kept
+    if n_pr > 0:
+        pm = copy.copy(model)
+        pm.lik, pm.old_lik = model.old_lik, Lik("none")
+        parts.append(initial_draw(pm, n_pr, seed))                     # :288-291 old_loglikelihood on old_data
+    p = np.asfortranarray(np.vstack(parts))
+    p = initialize_likelihoods(model, p)                               # :308
+    w = p[:, R - 1]
+    w[p[:, d] == -np.inf] = 0.0                                        # zero_bad_loglh_weights! :313
+    sw = 0.0
+    for v in w:                                                        # sequential sum as Julia's sum over a column view
+        sw += v
+    p[:, R - 1] = (w * n_parts) / sw                                   # normalize_weights! :314
+    idx = resample(p[:, R - 1] / n_parts, n_parts=n_parts, method=resampling_method, seed=seed, stage=1)   # :317
+    p = np.asfortranarray(p[idx, :])
+    p[:, R - 1] = 1.0                                                  # reset_weights! :322
+    return p, float(n_parts)                                           # push!(cloud.ESS, n_parts) :325
+
+
 def smc_run(model, particles, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic",
             threshold_ratio=0.5, c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97,
-            prior_weight=0.0, log_prob_old_data=0.0, seed=0, max_stages=None, n_threads=1, history=True):
+            prior_weight=0.0, log_prob_old_data=0.0, seed=0, max_stages=None, n_threads=1, history=True, initial_ess=0.0):
     """The reference's while-loop (src/smc_main.jl:377-508) on an initial cloud.  Returns a dict."""
     p = fcloud(particles)
     n = p.shape[0]
@@ -275,7 +318,7 @@ def smc_run(model, particles, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resa
         max_stages = n_phi if use_fixed_schedule else 20 * n_phi
     cfg = _RunConfig(n, n_blocks, n_mh_steps, lam, n_phi, RESAMPLE[resampling_method], threshold_ratio, c, alpha,
                      target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, seed,
-                     max_stages, n_threads)
+                     max_stages, n_threads, initial_ess)
     sched, ess, cs, acc = (np.zeros(max_stages) for _ in range(4))
     res_flags = np.zeros(max_stages, dtype=np.int32)
     wh = Wh = None

@@ -549,6 +549,22 @@ int orc_mutate_cloud(const orc_model *m, double *particles, int64_t n, int64_t p
 }
 
 /* ------------------------------------------------------------------ initialization.jl */
+/* ref: src/initialization.jl:153-186 initialize_likelihoods!: loglh -> old_loglh, then loglh / logpost(prior)
+   re-evaluated on the current (new) data for every particle (draw_likelihood, :125-137).  The reference lets a
+   ParamBoundsError escape here; out-of-bounds values are recorded as -Inf instead. */
+void orc_initialize_likelihoods(const orc_model *m, double *particles, int64_t n) {
+    int d = m->n_para;
+    for (int64_t i = 0; i < n; ++i) {
+        double th[ORC_MAXD];
+        for (int k = 0; k < d; ++k) th[k] = particles[(int64_t)k * n + i];
+        particles[(int64_t)(d + 2) * n + i] = particles[(int64_t)d * n + i];
+        double ll = -INFINITY, lp = -INFINITY;
+        if (orc_in_bounds(m, th)) { ll = orc_loglik(&m->lik, th, d); lp = orc_logprior(m, th); }
+        particles[(int64_t)d * n + i] = ll;
+        particles[(int64_t)(d + 1) * n + i] = lp;
+    }
+}
+
 /* ref: src/initialization.jl:23-63 one_draw + :88-119 initial_draw!.  Philox: counter stage field = outer
    attempt, tag(P_INIT, redraw, k) per parameter.  Only Normal / Uniform priors can be sampled here. */
 int orc_initial_draw(const orc_model *m, double *particles, int64_t n, int64_t pid0, uint64_t seed) {
@@ -620,7 +636,8 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
     int i = 1, j = 2, rc = 0, resampled_last = 0, resamples = 0;
     double phi_n = 0.0, phi_prop = 0.0, c = cfg->c, accept = cfg->target, logmdd = 0.0, secs = 0.0;
     const double threshold = cfg->threshold_ratio * (double)n;
-    sched_out[0] = 0.0; ess_out[0] = (double)n; c_out[0] = c; accept_out[0] = accept; resampled_out[0] = 0;
+    sched_out[0] = 0.0; ess_out[0] = cfg->initial_ess > 0.0 ? cfg->initial_ess : (double)n;   /* initialization.jl:199-200 */
+    c_out[0] = c; accept_out[0] = accept; resampled_out[0] = 0;
     if (w_hist) for (int64_t k = 0; k < n; ++k) { w_hist[k] = 0.0; W_hist[k] = wcol[k]; }       /* :363-366 */
 
     while (phi_n < 1.0) {                                                                        /* :377 */

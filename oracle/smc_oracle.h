@@ -70,6 +70,7 @@ typedef struct {
     uint64_t seed;
     int32_t max_stages;          /* capacity of per-stage outputs (incl. stage 1) */
     int32_t n_threads;           /* OpenMP threads for the mutation loop (results do not depend on it) */
+    double initial_ess;          /* cloud.ESS[1] when continuing from an old cloud (tempered update); 0 => n_parts */
 } orc_run_config;
 
 typedef struct {
@@ -129,6 +130,7 @@ int orc_mutate_cloud(const orc_model *m, double *particles, int64_t n, int64_t p
 int orc_initial_draw(const orc_model *m, double *particles, int64_t n, int64_t pid0, uint64_t seed);
 
 /* --- smc_main.jl:377-508 whole loop --- */
+void orc_initialize_likelihoods(const orc_model *m, double *particles, int64_t n);
 int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles, double *sched_out,
                 double *ess_out, double *c_out, double *accept_out, int32_t *resampled_out,
                 double *w_hist, double *W_hist, orc_run_result *res);

@@ -589,6 +589,52 @@ __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevS
     }
 }
 
+// Bridge resampling of a tempered update (src/smc_main.jl:266-279): n_out rows of the old cloud `src` are drawn by its
+// weights (cum = cumsum(weights ./ sum(weights)) over the n_src old particles) and written to rows [0, n_out) of `dst`
+// WITH their old weights (update_cloud! copies whole rows; the weights are only reset after the second resample, :322).
+// Systematic search range is start_ind:n_parts of the *output* length (resample.jl:54, quirk Q5) -> lim = min(n_out, n_src).
+__global__ void __launch_bounds__(TB) k_bridge_gather(CloudPtrs src, int src_buf, const double *cum, long long n_src,
+                                                      CloudPtrs dst, int dst_buf, long long n_out, int method,
+                                                      unsigned long long seed, unsigned stage, const double *offsets,
+                                                      long long *anc) {
+    const long long k = (long long)blockIdx.x * TB + threadIdx.x;
+    if (k >= n_out) return;
+    double ua, ub;
+    long long lim = n_src;
+    if (method == SMCMI_RESAMPLE_MULTINOMIAL) {
+        if (offsets) ua = offsets[k];
+        else uniform_pair(seed, (unsigned long long)k, stage, rng_tag(P_RES, 0, 0), ua, ub);
+    } else {
+        if (offsets) ua = offsets[0];
+        else uniform_pair(seed, 0ull, stage, rng_tag(P_RES, 0, 0), ua, ub);
+        ua = ((double)k + ua) / (double)n_out;
+        lim = n_out < n_src ? n_out : n_src;
+    }
+    long long lo = 0, hi = lim;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (cum[mid] > ua) hi = mid; else lo = mid + 1;
+    }
+    const long long a = lo < lim ? lo : lim - 1;
+    if (anc) anc[k] = a;
+    for (int c = 0; c < src.R; ++c) col(dst, dst_buf, c)[k] = col(src, src_buf, c)[a];
+}
+
+// zero_bad_loglh_weights! (src/particle.jl:392-396): weight 0 where loglh == -Inf
+__global__ void __launch_bounds__(TB) k_zero_bad_weights(CloudPtrs cl, const DevState *st) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= cl.n) return;
+    const int d = cl.R - 5;
+    if (col(cl, st->cur, d)[i] == SMCMI_NEG_INF) col(cl, st->cur, cl.R - 1)[i] = 0.0;
+}
+// normalize_weights! (src/particle.jl:362-366): W *= n_parts, W /= sum(W); st->sumw holds the fixed-order sum
+__global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st, double n_parts) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= cl.n) return;
+    double *w = col(cl, st->cur, cl.R - 1);
+    w[i] = (w[i] * n_parts) / st->sumw;
+}
+
 // ------------------------------------------------------------------------------------------------ moments
 // One pass over (θ, W̃): normalise the weights (normalize_weights!, src/particle.jl:362-366: W*N then /ΣW; or 1 after a
 // resample), write them to the weight column and the W history, and accumulate the augmented second-moment matrix
@@ -1633,6 +1679,22 @@ __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState 
     col(cl, dst, d + 2)[i] = 0.0;
     col(cl, dst, d + 3)[i] = 0.0;
     col(cl, dst, d + 4)[i] = 1.0;
+}
+
+// initialize_likelihoods! (src/initialization.jl:153-186): retire loglh to old_loglh, then evaluate the (new-data) likelihood
+// and the prior at every particle.  Out-of-bounds parameters give -Inf (the reference would throw ParamBoundsError here).
+__global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, const ModelDev *md) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= cl.n) return;
+    const int d = md->d;
+    double thl[MAXD];
+    for (int k = 0; k < d; ++k) thl[k] = col(cl, 0, k)[i];
+    auto TH = [&](int k) { return thl[k]; };
+    col(cl, 0, d + 2)[i] = col(cl, 0, d)[i];
+    double ll = SMCMI_NEG_INF, lp = SMCMI_NEG_INF;
+    if (in_bounds(*md, TH)) { ll = loglik(md->lik[0], d, TH); lp = logprior(*md, TH); }
+    col(cl, 0, d)[i] = ll;
+    col(cl, 0, d + 1)[i] = lp;
 }
 
 __global__ void k_fill(double *p, long long n, double v) {

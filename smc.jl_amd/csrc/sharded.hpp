@@ -174,9 +174,10 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
         memset(&s, 0, sizeof(DevState));
         s.rp = rp;
-        s.stage = 1; s.j = 2; s.c = rc->c; s.accept = rc->target; s.ess_prev = (double)h->cfg.n_parts;
+        s.stage = 1; s.j = 2; s.c = rc->c; s.accept = rc->target;
+        s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;
         if (push_state(h)) return SMCMI_ERR_HIP;
-        const double v0[4] = {0.0, (double)h->cfg.n_parts, rc->c, rc->target};
+        const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};
         HIP_TRY(hipMemcpy(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice));

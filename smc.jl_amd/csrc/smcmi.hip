@@ -335,6 +335,13 @@ extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
     return 0;
 }
 
+extern "C" int smcmi_initialize_likelihoods(smcmi_handle *h) {
+    if (int rc = need_model(h, true)) return rc;
+    k_initialize_likelihoods<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ stage primitives
 static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
     if (h->sched_len < n_phi) {
@@ -452,6 +459,67 @@ extern "C" int smcmi_resample(smcmi_handle *h, int32_t method, uint32_t stage, c
     // the gathered cloud sits in buffer 1; the current cloud is always buffer 0
     HIP_TRY(hipMemcpyAsync(h->cl.buf[0], h->cl.buf[1], sizeof(double) * n * h->R, hipMemcpyDeviceToDevice, h->stream));
     if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, h->d_anc, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- tempered-update initialisation pieces (smc_main.jl:244-333): bridge resample, row copy, weight clean-up
+extern "C" int smcmi_bridge_resample(smcmi_handle *dst, smcmi_handle *src, int32_t method, uint32_t stage, int64_t n_out,
+                                     const double *offsets, int64_t *ancestors_out) {
+    if (!dst || !src) return set_err(SMCMI_ERR_ARG, "null handle");
+    if (method != SMCMI_RESAMPLE_SYSTEMATIC && method != SMCMI_RESAMPLE_MULTINOMIAL)
+        return set_err(SMCMI_ERR_ARG, "Invalid resampler in SMC. Options are systematic or multinomial");
+    if (dst->R != src->R || dst->cfg.device != src->cfg.device) return set_err(SMCMI_ERR_ARG, "bridge: clouds differ in n_para or device");
+    if (n_out < 0 || n_out > dst->n) return set_err(SMCMI_ERR_ARG, "bridge: n_to_resample exceeds the new cloud");
+    if (src->cfg.n_local != src->cfg.n_parts || dst->cfg.n_local != dst->cfg.n_parts)
+        return set_err(SMCMI_ERR_ARG, "bridge: whole (unsharded) clouds only");
+    if (n_out == 0) return 0;
+    HIP_TRY(hipSetDevice(src->cfg.device));
+    if (pull_state(src) || pull_state(dst)) return SMCMI_ERR_HIP;
+    double *d_off = nullptr;
+    if (offsets) {
+        const long long cnt = method == SMCMI_RESAMPLE_MULTINOMIAL ? n_out : 1;
+        HIP_TRY(hipMalloc(&d_off, sizeof(double) * cnt));
+        HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(double) * cnt, hipMemcpyHostToDevice, src->stream));
+    }
+    long long *d_anc = nullptr;
+    if (ancestors_out) HIP_TRY(hipMalloc(&d_anc, sizeof(long long) * n_out));
+    k_weight_chunk_sums<<<src->nb_e, TB, 0, src->stream>>>(src->cl, src->d_st, src->d_part_fin);
+    k_chunk_offsets<<<1, 1, 0, src->stream>>>(src->d_st, src->d_part_fin, src->nb_e, src->d_chunk_off, 0.0, 1);
+    k_scan_weights<<<src->nb_e, TB, 0, src->stream>>>(src->cl, src->d_st, src->d_chunk_off, src->d_cum, 1, src->nb_e);
+    k_bridge_gather<<<(unsigned)((n_out + TB - 1) / TB), TB, 0, src->stream>>>(src->cl, src->h_st.cur, src->d_cum, src->n, dst->cl,
+                                                                            dst->h_st.cur, n_out, method, src->cfg.seed, stage,
+                                                                            d_off, d_anc);
+    if (ancestors_out) HIP_TRY(hipMemcpyAsync(ancestors_out, d_anc, sizeof(long long) * n_out, hipMemcpyDeviceToHost, src->stream));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    if (d_off) hipFree(d_off);
+    if (d_anc) hipFree(d_anc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int smcmi_copy_rows(smcmi_handle *dst, int64_t dst_row0, smcmi_handle *src, int64_t src_row0, int64_t n_rows) {
+    if (!dst || !src) return set_err(SMCMI_ERR_ARG, "null handle");
+    if (dst->R != src->R || dst->cfg.device != src->cfg.device) return set_err(SMCMI_ERR_ARG, "copy_rows: clouds differ in n_para or device");
+    if (n_rows < 0 || dst_row0 < 0 || src_row0 < 0 || dst_row0 + n_rows > dst->n || src_row0 + n_rows > src->n)
+        return set_err(SMCMI_ERR_ARG, "copy_rows: row range outside the cloud");
+    if (n_rows == 0) return 0;
+    HIP_TRY(hipSetDevice(src->cfg.device));
+    if (pull_state(src) || pull_state(dst)) return SMCMI_ERR_HIP;
+    HIP_TRY(hipMemcpy2DAsync(dst->cl.buf[dst->h_st.cur] + dst_row0, sizeof(double) * dst->n, src->cl.buf[src->h_st.cur] + src_row0,
+                             sizeof(double) * src->n, sizeof(double) * n_rows, (size_t)src->R, hipMemcpyDeviceToDevice, src->stream));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    return 0;
+}
+
+extern "C" int smcmi_normalize_weights(smcmi_handle *h, int32_t zero_bad_loglh) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const unsigned g = (unsigned)((h->n + TB - 1) / TB);
+    if (zero_bad_loglh) k_zero_bad_weights<<<g, TB, 0, h->stream>>>(h->cl, h->d_st);
+    k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
+    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
+    k_normalize_weights<<<g, TB, 0, h->stream>>>(h->cl, h->d_st, (double)h->cfg.n_parts);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -694,11 +762,11 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     s.rp = rp; s.cur = cur;
     s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
     s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
-    s.ess_prev = (double)h->cfg.n_parts;
+    s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;   // tempered update: ESS of the old cloud (initialization.jl:199-200)
     if (push_state(h)) return SMCMI_ERR_HIP;
     // stage-1 records and history columns (w[:,1] = 0, W[:,1] = weights; smc_main.jl:363-366)
     {
-        const double v0[4] = {0.0, (double)h->cfg.n_parts, rc->c, rc->target};
+        const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};
         HIP_TRY(hipMemcpyAsync(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice, h->stream));

@@ -34,7 +34,7 @@ class RunConfig(C.Structure):
                 ("alpha", C.c_double), ("target", C.c_double), ("use_fixed_schedule", C.c_int32),
                 ("tempering_target", C.c_double), ("tempered_update_prior_weight", C.c_double),
                 ("log_prob_old_data", C.c_double), ("solver_passes", C.c_int32), ("sync_every", C.c_int32),
-                ("use_graph", C.c_int32), ("phi_rtol", C.c_double)]
+                ("use_graph", C.c_int32), ("initial_ess", C.c_double), ("phi_rtol", C.c_double)]
 
 
 class Result(C.Structure):
@@ -60,6 +60,10 @@ SYMBOLS = [
     ("smcmi_download_cloud", C.c_int, [_H, dp]),
     ("smcmi_upload_cloud_device", C.c_int, [_H, C.c_void_p]),
     ("smcmi_init_from_prior", C.c_int, [_H]),
+    ("smcmi_initialize_likelihoods", C.c_int, [_H]),
+    ("smcmi_bridge_resample", C.c_int, [_H, _H, C.c_int32, C.c_uint32, C.c_int64, dp, lp]),
+    ("smcmi_copy_rows", C.c_int, [_H, C.c_int64, _H, C.c_int64, C.c_int64]),
+    ("smcmi_normalize_weights", C.c_int, [_H, C.c_int32]),
     ("smcmi_cloud_device_ptr", C.c_int, [_H, C.POINTER(C.c_void_p), lp]),
     ("smcmi_ess_at", C.c_int, [_H, dp, C.c_int32, C.c_double, dp]),
     ("smcmi_solve_phi", C.c_int, [_H, dp, C.c_int32, ip, dp, C.c_double, C.c_double, C.c_double, ip, dp]),

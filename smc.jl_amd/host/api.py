@@ -210,10 +210,16 @@ def cloud_isempty(c):
 def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300,
         resampling_method="systematic", threshold_ratio=0.5, c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True,
         tempering_target=0.97, old_data=None, old_loglikelihood=None, tempered_update_prior_weight=0.0,
-        log_prob_old_data=0.0, savepath=None, seed=0, device=0, max_stages=None, initial_cloud=None, use_graph=0):
+        log_prob_old_data=0.0, old_cloud=None, savepath=None, seed=0, device=0, max_stages=None, initial_cloud=None,
+        use_graph=0):
     """Sequential Monte Carlo on one MI355X.  Keyword names follow src/smc_main.jl:119-161 (λ -> lam, n_Φ -> n_phi,
     α -> alpha).  Returns (cloud, w, W) - the three objects the reference writes to `savepath` - and, when `savepath`
-    is given, stores them as a numpy .npz (the reference's JLD2/HDF5 writers are outside the hot path)."""
+    is given, stores them as a numpy .npz (the reference's JLD2/HDF5 writers are outside the hot path).
+
+    Tempered update (src/smc_main.jl:244-333): pass `old_data` (and `old_loglikelihood` if it differs) together with
+    `old_cloud`, the Cloud of the previous estimation; the initial cloud is then built on the device from the old cloud
+    (same-size continuation, or bridge resample + prior draws when tempered_update_prior_weight > 0 / sizes differ).
+    `initial_cloud` instead starts the recursion from a ready-made cloud."""
     if verbose not in VERBOSITY:
         raise ValueError("verbose must be one of :none, :low, :high")
     if resampling_method not in ("systematic", "multinomial", "polyalgo"):
@@ -224,8 +230,8 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     d = len(parameters)
     if all(p.fixed for p in parameters):
         raise AssertionError("All model parameters are fixed!")
-    if old_data is not None and np.size(old_data) and initial_cloud is None:
-        raise NotImplementedError("tempered updates need initial_cloud = the bridged old cloud (SURVEY §8f-2: next row)")
+    if old_data is not None and np.size(old_data) and initial_cloud is None and old_cloud is None:
+        raise ValueError("a tempered update (non-empty old_data) needs old_cloud = the Cloud of the old estimation")
     data = np.asarray(data, dtype=np.float64)
     device_lik = isinstance(loglikelihood, DeviceLikelihood)
     lik = loglikelihood.spec(data) if device_lik else ("host_callback", [], None, None)
@@ -255,13 +261,23 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     if verbose != "none":
         print("\n\n SMC starts ....\n")
     if device_lik:
+        w0 = None
         if initial_cloud is not None:
             eng.upload_cloud(initial_cloud.particles if isinstance(initial_cloud, Cloud) else initial_cloud)
+        elif tempered and old_cloud is not None:
+            if not (old_lik is not None and old_lik[0] != "host_callback"):
+                raise NotImplementedError("tempered updates need a device old_loglikelihood")
+            kw["initial_ess"] = _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, tempered_update_prior_weight,
+                                                       resampling_method, seed, device)
+            w0 = eng.download_cloud()[:, d + 4].copy()
         else:
             eng.init_from_prior()
         r = eng.run(use_graph=use_graph, **kw)
         rec = eng.stage_records(r["n_stages"])
         w, W = eng.history(r["n_stages"])
+        if w0 is not None:                       # W_matrix[:, 1] of a tempered update (smc_main.jl:364-365)
+            W = np.array(W)
+            W[:, 0] = w0 * n_parts if w0.sum() <= 1.0 else w0
         P = eng.download_cloud()
     else:
         r, rec, w, W, P = _run_host_callback(eng, loglikelihood, parameters, data, spec, initial_cloud, seed, max_stages, kw)
@@ -289,6 +305,40 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
                  total_sampling_time=cloud.total_sampling_time, w=w, W=W)
     eng.close()
     return cloud, w, W
+
+
+def _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, prior_weight, resampling_method, seed, device):
+    """Initial cloud of a tempered update, built on the device (src/smc_main.jl:244-333).  Returns cloud.ESS[1].
+    RNG contract: bridge resample = stage 0, clean-up resample = stage 1, prior draws = init streams of ids 0.."""
+    oldP = np.asfortranarray(old_cloud.particles, dtype=np.float64)
+    old_n, d = oldP.shape[0], oldP.shape[1] - 5
+    if prior_weight == 0.0 and old_n == n_parts:                           # :249-260
+        eng.upload_cloud(oldP)
+        eng.initialize_likelihoods()
+        return float(np.asarray(old_cloud.ESS)[-1])
+    n_to = int(round((1.0 - prior_weight) * n_parts))                       # :262-264
+    n_pr = n_parts - n_to
+    if n_to > 0:
+        old = Engine(old_n, d, seed=seed, device=device, max_stages=2, store_history=False)
+        try:
+            old.upload_cloud(oldP)
+            eng.bridge_resample_from(old, n_to, method=resampling_method, stage=0)     # :266-279
+        finally:
+            old.close()
+    if n_pr > 0:
+        pri = Engine(n_pr, d, seed=seed, device=device, max_stages=2, store_history=False)
+        try:
+            pri.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
+            pri.set_likelihood(*old_lik, which=0)                           # old_loglikelihood on old_data, :288-291
+            pri.set_likelihood("none", which=1)
+            pri.init_from_prior()
+            eng.copy_rows_from(pri, n_pr, dst_row0=n_to)                    # vcat, :296
+        finally:
+            pri.close()
+    eng.initialize_likelihoods()                                            # :308
+    eng.normalize_weights(zero_bad_loglh=True)                              # :313-314
+    eng.resample(resampling_method, stage=1)                                # :317-322 (incl. reset_weights!)
+    return float(n_parts)                                                   # push!(cloud.ESS, n_parts), :325
 
 
 def _host_initial_draw(eng, loglikelihood, parameters, data, spec, seed):

@@ -96,6 +96,10 @@ class Engine:
     def init_from_prior(self):
         check(self._L.smcmi_init_from_prior(self._h))
 
+    def initialize_likelihoods(self):
+        """initialize_likelihoods!: old_loglh <- loglh, then loglh / logprior on the (new) data."""
+        check(self._L.smcmi_initialize_likelihoods(self._h))
+
     # ---- stage primitives --------------------------------------------------------------------------
     def ess_at(self, phis, phi_prev):
         phis = _f64(np.atleast_1d(phis))
@@ -121,6 +125,22 @@ class Engine:
         check(self._L.smcmi_resample(self._h, _lib.RESAMPLE[method], stage, None if off is None else _d(off),
                                      anc.ctypes.data_as(lp)))
         return anc
+
+    def bridge_resample_from(self, old, n_out, method="systematic", stage=0, offsets=None):
+        """Rows [0, n_out) of this cloud <- resample(get_weights(old); n_parts = n_out) rows of `old`, weights included
+        (src/smc_main.jl:266-279)."""
+        anc = np.empty(max(int(n_out), 1), dtype=np.int64)
+        off = None if offsets is None else _f64(np.atleast_1d(offsets))
+        check(self._L.smcmi_bridge_resample(self._h, old._h, _lib.RESAMPLE[method], stage, int(n_out),
+                                            None if off is None else _d(off), anc.ctypes.data_as(lp)))
+        return anc[:int(n_out)]
+
+    def copy_rows_from(self, src, n_rows, dst_row0=0, src_row0=0):
+        check(self._L.smcmi_copy_rows(self._h, int(dst_row0), src._h, int(src_row0), int(n_rows)))
+
+    def normalize_weights(self, zero_bad_loglh=False):
+        """zero_bad_loglh_weights! (optional) + normalize_weights! (src/particle.jl:362-366, 392-396)."""
+        check(self._L.smcmi_normalize_weights(self._h, int(zero_bad_loglh)))
 
     def moments(self):
         mean, cov = np.empty(self.d), np.empty((self.d, self.d))
@@ -153,10 +173,10 @@ class Engine:
     # ---- whole loop --------------------------------------------------------------------------------
     def run(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
             c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
-            log_prob_old_data=0.0, solver_passes=0, sync_every=0, use_graph=0, phi_rtol=0.0):
-        rc = _lib.RunConfig(n_blocks, n_mh_steps, lam, n_phi, _lib.RESAMPLE[resampling_method], threshold_ratio, c, alpha,
-                            target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, solver_passes,
-                            sync_every, use_graph, phi_rtol)
+            log_prob_old_data=0.0, solver_passes=0, sync_every=0, use_graph=0, phi_rtol=0.0, initial_ess=0.0):
+        rc = self._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
+                              use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, sync_every,
+                              use_graph, phi_rtol, initial_ess)
         res = _lib.Result()
         check(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
         return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
@@ -165,10 +185,10 @@ class Engine:
 
     def _run_config(self, n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
                     use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, sync_every, use_graph,
-                    phi_rtol):
+                    phi_rtol, initial_ess=0.0):
         return _lib.RunConfig(n_blocks, n_mh_steps, lam, n_phi, _lib.RESAMPLE[resampling_method], threshold_ratio, c, alpha,
                               target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, solver_passes,
-                              sync_every, use_graph, phi_rtol)
+                              sync_every, use_graph, initial_ess, phi_rtol)
 
     @staticmethod
     def _result(res):

@@ -1,0 +1,131 @@
+"""Tempered update from an old cloud (src/smc_main.jl:244-333): the initial cloud is built on the device
+from the old estimation - same-size continuation, bridge resample + prior draws, or a change of n_parts - and the
+recursion then runs on old/new likelihoods.  Checked against the oracle's restatement of the same steps."""
+import numpy as np
+import pytest
+
+from tests import models
+
+pytestmark = pytest.mark.gpu
+
+OLD_T = 60
+
+
+def _pars(S):
+    return [S.parameter("α1", 0.0, (-1e5, 1e5), (-1e5, 1e5), None, S.Normal(0, 10), fixed=False),
+            S.parameter("β1", 0.0, (-1e5, 1e5), (-1e5, 1e5), None, S.Normal(0, 10), fixed=False)]
+
+
+def _spec(data, old):
+    return dict(priors=[("normal", 0.0, 10.0)] * 2, bounds=[(-1e5, 1e5)] * 2, fixed=[0, 0],
+                lik=("linreg", [1.0], data, None), old_lik=("linreg", [1.0], old, None))
+
+
+@pytest.fixture(scope="module")
+def old_run():
+    import smc_jl_amd as S
+    data = models.regression_spec()["lik"][2]
+    old = np.ascontiguousarray(data[:OLD_T])
+    cloud, _, _ = S.smc(S.LinReg(1.0), _pars(S), old, n_parts=4000, n_phi=60, use_fixed_schedule=True, seed=5, verbose="none")
+    return data, old, cloud
+
+
+def _rows_match(P, Q, tol=1e-9):
+    same = np.all(np.abs(P - Q) <= tol * (1.0 + np.abs(Q)), axis=1)
+    return same.mean()
+
+
+@pytest.mark.parametrize("n_parts,pw,method", [(4000, 0.0, "systematic"), (4000, 0.3, "systematic"), (3000, 0.0, "systematic"),
+                                               (5000, 0.25, "multinomial"), (4000, 1.0, "systematic")])
+def test_tempered_initial_cloud_vs_oracle(old_run, n_parts, pw, method):
+    import smc_jl_amd as S
+    from smc_jl_amd import Engine
+    from oracle import oracle as orc
+    import importlib
+    api = importlib.import_module(S.smc.__module__)
+
+    data, old, cloud = old_run
+    sp = _spec(data, old)
+    eng = Engine(n_parts, 2, seed=11, max_stages=4)
+    eng.set_parameters(sp["priors"], sp["bounds"], sp["fixed"])
+    eng.set_likelihood(*sp["lik"], which=0)
+    eng.set_likelihood(*sp["old_lik"], which=1)
+    ess0 = api._tempered_update_cloud(eng, cloud, sp, sp["old_lik"], n_parts, pw, method, 11, 0)
+    P = eng.download_cloud()
+    eng.close()
+    m = models.oracle_model(sp)
+    Q, ess0_o = orc.tempered_update_cloud(m, cloud.particles, cloud.ESS[-1], n_parts, prior_weight=pw, resampling_method=method,
+                                          seed=11)
+    assert ess0 == ess0_o
+    assert P.shape == Q.shape == (n_parts, 7)
+    # rows agree except where a cumulative-weight rounding moved an ancestor by one (scan order differs)
+    assert _rows_match(P, Q) > 0.995
+    # old_loglh column = old likelihood of the particle, loglh = new likelihood, weights reset/kept as the reference does
+    if pw == 0.0 and n_parts == 4000:
+        np.testing.assert_array_equal(P[:, 6], cloud.particles[:, 6])
+        np.testing.assert_array_equal(P[:, 4], cloud.particles[:, 2])
+    else:
+        np.testing.assert_array_equal(P[:, 6], 1.0)
+    th = P[:, :2]
+    e_new = data[:, 0][None, :] - th[:, :1] - th[:, 1:2] * data[:, 1][None, :]
+    ll_new = -(len(data) / 2) * np.log(2 * np.pi) - 0.5 * np.sum(e_new ** 2, axis=1)
+    np.testing.assert_allclose(P[:, 2], ll_new, rtol=1e-10)
+    e_old = old[:, 0][None, :] - th[:, :1] - th[:, 1:2] * old[:, 1][None, :]
+    ll_old = -(len(old) / 2) * np.log(2 * np.pi) - 0.5 * np.sum(e_old ** 2, axis=1)
+    np.testing.assert_allclose(P[:, 4], ll_old, rtol=1e-10)
+
+
+@pytest.mark.parametrize("n_parts,pw,fixed", [(4000, 0.0, True), (4000, 0.3, True), (3000, 0.0, False), (4000, 0.5, False)])
+def test_tempered_update_run_vs_oracle(old_run, n_parts, pw, fixed):
+    import smc_jl_amd as S
+    from oracle import oracle as orc
+
+    data, old, cloud = old_run
+    kw = dict(n_parts=n_parts, n_phi=40, use_fixed_schedule=fixed, tempering_target=0.9, seed=11, verbose="none",
+              tempered_update_prior_weight=pw, log_prob_old_data=-3.0 if pw > 0 else 0.0)
+    c, w, W = S.smc(S.LinReg(1.0), _pars(S), data, old_data=old, old_cloud=cloud, **kw)
+    sp = _spec(data, old)
+    m = models.oracle_model(sp)
+    Q, ess0 = orc.tempered_update_cloud(m, cloud.particles, cloud.ESS[-1], n_parts, prior_weight=pw, seed=11)
+    r = orc.smc_run(m, Q, n_phi=40, use_fixed_schedule=fixed, tempering_target=0.9, prior_weight=pw,
+                    log_prob_old_data=kw["log_prob_old_data"], seed=11, initial_ess=ess0, n_threads=2)
+    assert c.stage_index == r["n_stages"]
+    assert c.ESS[0] == ess0
+    np.testing.assert_allclose(c.tempering_schedule, r["schedule"], rtol=1e-6)
+    np.testing.assert_allclose(c.ESS, r["ess"], rtol=2e-3)
+    assert c.logmdd == pytest.approx(r["logmdd"], abs=5e-3)
+    assert c.tempering_schedule[-1] == 1.0
+    # posterior of the full sample
+    np.testing.assert_allclose(S.weighted_mean(c), [1.0, 1.0], atol=0.25)
+    # first W column rule of a tempered update (smc_main.jl:364-365)
+    if pw == 0.0 and n_parts == 4000:
+        w0 = cloud.particles[:, 6]
+        np.testing.assert_allclose(W[:, 0], w0 * n_parts if w0.sum() <= 1.0 else w0, rtol=1e-14)
+    else:
+        np.testing.assert_array_equal(W[:, 0], 1.0)
+
+
+def test_reference_bridge_scenario_linear_model():
+    """test/smc.jl:95-140: linear model estimated on the first half of the sample with 1000 particles, then a tempered
+    update on the full sample with the default 5000 particles (n_parts differs -> bridge branch), polyalgo resampler,
+    α = 0.9, n_Φ = 100; the reference asserts posterior means within 0.5 of the true parameters."""
+    import smc_jl_amd as S
+
+    sp = models.linmodel_spec(T=100)
+    data, X = sp["lik"][2], sp["lik"][3]
+    half = np.ascontiguousarray(data[:, :data.shape[1] // 2])
+    pars = []
+    for k in range(3):
+        pars += [S.parameter("a%d" % k, 0.0, (-1e5, 1e5), prior=S.Normal(0, 1e3)),
+                 S.parameter("b%d" % k, 0.0, (-1e5, 1e5), prior=S.Normal(0, 1e3)),
+                 S.parameter("s%d" % k, 1.0, (1e-5, 1e5), prior=S.Uniform(0, 1e3))]
+    kw = dict(verbose="none", use_fixed_schedule=True, n_phi=100, n_mh_steps=1, resampling_method="polyalgo", target=0.25,
+              alpha=0.9, threshold_ratio=0.5, seed=42)
+    old_cloud, _, _ = S.smc(S.LinModel3(X), pars, half, n_parts=1000, **kw)
+    new_cloud, w, W = S.smc(S.LinModel3(X), pars, data, old_data=half, old_cloud=old_cloud, **kw)
+    assert len(new_cloud) == 5000 and new_cloud.stage_index == 100
+    assert new_cloud.ESS[0] == 5000.0
+    truth = np.array([1., 1., 1., 2., 2., 1., 3., 3., 1.])
+    assert np.max(np.abs(S.get_vals(new_cloud).mean(axis=1) - truth)) < 0.5
+    assert np.max(np.abs(S.weighted_mean(new_cloud) - truth)) < 0.5
+    assert np.all(new_cloud.particles[:, 9 + 2] != 0.0)          # old_loglh column filled by initialize_likelihoods!

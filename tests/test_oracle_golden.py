@@ -216,3 +216,32 @@ def test_gauss10_adaptive_end_to_end():
     for k in range(2, len(ess) - 1):
         base = 4000.0 if res[k - 1] else ess[k - 1]
         assert ess[k] == pytest.approx(0.97 * base, rel=1e-6)
+
+
+def test_oracle_tempered_update_cloud_branches():
+    """Oracle restatement of src/smc_main.jl:244-333 (no golden vectors exist for it: structural checks)."""
+    data = models.regression_spec()["lik"][2]
+    old = np.ascontiguousarray(data[:60])
+    sp = dict(priors=[("normal", 0.0, 10.0)] * 2, bounds=[(-1e5, 1e5)] * 2, fixed=[0, 0],
+              lik=("linreg", [1.0], data, None), old_lik=("linreg", [1.0], old, None))
+    m = models.oracle_model(sp)
+    m_old = models.oracle_model(dict(sp, lik=sp["old_lik"], old_lik=None))
+    r = orc.smc_run(m_old, orc.initial_draw(m_old, 500, seed=2), n_phi=30, seed=2)
+    P_old, ess_old = r["particles"], r["ess"][-1]
+    # same size, no prior weight: likelihood columns re-evaluated, θ / weights untouched, ESS carried over
+    P, e0 = orc.tempered_update_cloud(m, P_old, ess_old, 500)
+    assert e0 == ess_old
+    np.testing.assert_array_equal(P[:, [0, 1, 5, 6]], P_old[:, [0, 1, 5, 6]])
+    np.testing.assert_array_equal(P[:, 4], P_old[:, 2])
+    assert np.all(P[:, 2] < P[:, 4])                       # 100 observations fit worse than 60
+    # bridge: 70 % resampled old particles, 30 % prior draws, everything resampled once more -> weights 1, ESS = N
+    P, e0 = orc.tempered_update_cloud(m, P_old, ess_old, 400, prior_weight=0.3)
+    assert e0 == 400.0 and P.shape == (400, 7)
+    np.testing.assert_array_equal(P[:, 6], 1.0)
+    assert np.all(np.isfinite(P[:, 2])) and np.all(np.isfinite(P[:, 4]))
+    # different size only: every new particle is one of the old ones
+    P, _ = orc.tempered_update_cloud(m, P_old, ess_old, 800)
+    assert set(map(tuple, P[:, :2])) <= set(map(tuple, P_old[:, :2]))
+    # run continues from it
+    r2 = orc.smc_run(m, P, n_phi=30, seed=2, initial_ess=800.0)
+    assert r2["ess"][0] == 800.0 and np.isfinite(r2["logmdd"])
