@@ -14,6 +14,9 @@ constexpr int MAXD = SMCMI_MAX_PARA;
 constexpr int KC = SMCMI_MAX_CAND;          // candidates per ESS pass
 constexpr int NPAIR_MAX = (MAXD + 1) * (MAXD + 2) / 2;
 constexpr int LIK_PAR_MAX = 16;
+constexpr int EK = 8;                       // energy power sums a_0..a_{EK-1}, b_0..b_{EK-1} (ϕ predictor)
+constexpr int ES = 2 * EK;
+constexpr int ESP = ES + 1;                  // per-block partial row: ES energy sums + the block's acceptance sum
 
 struct LikDev {
     int family;
@@ -49,7 +52,7 @@ struct RunParams {             // smc() kwargs, uploaded once per run
     int use_fixed_schedule;
     int max_stages;
     int store_history;
-    int pad0;
+    int stall_on_exhaust;      // out of solver passes: 1 = stall the run (done = 2) for the host to resume, 0 = accept the bracket
     double threshold;          // threshold_ratio * n_parts (:203)
     double alpha, target;
     double tempering_target;
@@ -67,7 +70,9 @@ struct Solver {
     double phi_prop, ess_bar;
     double lo, hi, glo, ghi;   // bracket with g(lo) >= 0 > g(hi), g = ESS(ϕ) - ESS_bar
     double phi_n;
+    double phi0;               // ϕ_{n-1}, the start of the tempering step being solved
     double cand[KC];
+    int cj[KC];                // SCAN: walk step of cand[k] (0 = ϕ_prop, q = schedule[j+q-1]); -1 = predictor ring point
 };
 
 struct DevState {
@@ -88,6 +93,8 @@ struct DevState {
     double logz;               // running log-MDD
     double c, accept;          // cloud.c, cloud.accept
     long long solver_passes;   // diagnostic: number of particle passes spent in the adaptive-ϕ solver
+    double e_center;           // centre of the energy power sums the mutation epilogue accumulates (predictor, kernels.hpp)
+    double pred_delta;         // diagnostic: predicted ϕ_n - ϕ_{n-1} of the current stage (NaN: no prediction)
     Solver sol[2];
     // ---- moments / proposal (smc_main.jl:457-469, mutation.jl:81)
     double shift[MAXD];        // centering used by the one-pass moment kernel (previous mean)

@@ -163,6 +163,84 @@ struct CloudPtrs {
 
 __device__ inline double *col(const CloudPtrs &c, int which, int column) { return c.buf[which] + (long long)column * c.n; }
 
+// ------------------------------------------------------------------------------------------------ ϕ predictor
+// ESS(ϕ_{n-1} + δ) = A(δ)² / B(δ) with A = Σ W e^{δ e_i}, B = Σ W² e^{2 δ e_i}, e_i = loglh_i - old_loglh_i (helpers.jl:173-181).
+// The mutation epilogue accumulates the power sums a_k = Σ W (e - c)^k, b_k = Σ W² (e - c)^k, k < EK (the common factor
+// e^{δ c} cancels in A²/B), so the next stage can solve the truncated-Taylor model A_K(δ)²/B_K(δ) = ESS_bar for a starting
+// point that is typically within 1e-7..1e-4 of the true root - the solver then only has to certify it with a bracket.
+// uniform = every weight is 1 (the stage resampled): then b_k = a_k and the ES slots hold a_0 .. a_{ES-1} instead, a model of
+// twice the order exactly where the tempering step is largest.
+__device__ inline void energy_terms(double (&es)[ES], double W, double like, double like_prev, double c, bool live, bool uniform) {
+    const double p = (like - like_prev) - c;
+    const bool ok = live && p == p && fabs(p) < 1e300;       // -Inf likelihoods carry no weight for any δ > 0
+    const double w1 = ok ? (uniform ? 1.0 : W) : 0.0, w2 = w1 * w1, pp = ok ? p : 0.0;
+    double pk = 1.0;
+    if (uniform) {
+#pragma unroll
+        for (int k = 0; k < ES; ++k) { es[k] = w1 * pk; pk *= pp; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EK; ++k) { es[k] = w1 * pk; es[EK + k] = w2 * pk; pk *= pp; }
+    }
+}
+
+// Block-wide fixed-order reduction of ES accumulators for any block of `nw` wavefronts; thread t < ES gets total t.
+// red: nw * ES doubles of LDS.
+__device__ inline double block_reduce_es(double (&a)[ES], double *red, int nw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Butterfly<ES / 2, 32>::run(a, lane);
+    constexpr int SH = 6 - ilog2(ES);
+    __syncthreads();
+    if ((lane & ((1 << SH) - 1)) == 0) red[wave * ES + (lane >> SH)] = a[0];
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < ES)
+        for (int w = 0; w < nw; ++w) tot += red[w * ES + threadIdx.x];
+    __syncthreads();
+    return tot;
+}
+
+// Root δ > 0 of the Taylor model G(δ) = A_K(δ)² - ESS_bar B_K(δ) (one thread; polynomial Newton, no transcendentals).
+// a[k] = Σ W p^k, b[k] = Σ W² p^k, k < KK.  NaN when the model is unusable.
+template <int KK>
+__device__ inline double predict_delta(const double *a, const double *b, double T) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (!(a[0] > 0.0) || !(b[0] > 0.0) || !(T > 0.0)) return nan;
+    double ca[KK], cb[KK];               // a_k / k!,  b_k 2^k / k!
+    double inv = 1.0, p2 = 1.0;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+        if (k > 0) { inv *= 1.0 / (double)k; p2 *= 2.0; }      // compile-time constants after unrolling
+        ca[k] = a[k] * inv; cb[k] = b[k] * (p2 * inv);
+    }
+    const double G0 = ca[0] * ca[0] - T * cb[0];
+    if (!(G0 > 0.0)) return nan;
+    const double G1 = 2.0 * ca[0] * ca[1] - T * cb[1];
+    const double G2h = ca[1] * ca[1] + 2.0 * ca[0] * ca[2] - T * cb[2];
+    const double disc = G1 * G1 - 4.0 * G2h * G0;
+    double x;
+    if (disc >= 0.0 && -G1 + sqrt(disc) > 0.0) x = 2.0 * G0 / (-G1 + sqrt(disc));
+    else if (G1 < 0.0) x = -G0 / G1;
+    else return nan;
+    for (int it = 0; it < 4; ++it) {
+        double A = ca[KK - 1], B = cb[KK - 1], dA = (double)(KK - 1) * ca[KK - 1], dB = (double)(KK - 1) * cb[KK - 1];
+#pragma unroll
+        for (int k = KK - 2; k >= 0; --k) {
+            A = A * x + ca[k];
+            B = B * x + cb[k];
+            if (k >= 1) { dA = dA * x + (double)k * ca[k]; dB = dB * x + (double)k * cb[k]; }
+        }
+        const double G = A * A - T * B, dG = 2.0 * A * dA - T * dB;
+        if (!(dG < 0.0) || !(A > 0.0) || !(B > 0.0)) return nan;
+        const double xn = x - G / dG;
+        if (!(xn > 0.0) || !(xn < 1e300)) return nan;
+        x = xn;
+    }
+    return x;
+}
+constexpr int NPR = 6;
+constexpr double PRING[NPR] = {0x1p-5, 0x1p-10, 0x1p-15, 0x1p-20, 0x1p-25, 0x1p-30};
+
 // ------------------------------------------------------------------------------------------------ ϕ solver
 // solve_adaptive_ϕ (src/helpers.jl:9-56) as a bracketing search driven by K-candidate ESS passes:
 //   SCAN    : candidates = ϕ_prop, schedule[j], schedule[j+1], ...  - the reference's `while g(ϕ_prop) >= 0` loop
@@ -185,30 +263,58 @@ __device__ inline void solver_decide_wave(Solver &S, const double *tot, const do
     const double ck = mine ? S.cand[lane] : 0.0;
     const double gk = mine ? tot[lane] * tot[lane] / tot[KC + lane] - S.ess_bar : 0.0;     // ESS(ϕ) = (Σv)²/Σv²
     const unsigned long long negmask = __ballot(mine && !(gk >= 0.0));
-    const int m = negmask ? (__ffsll((long long)negmask) - 1) : -1;
     double lo = S.lo, hi = S.hi, glo = S.glo, ghi = S.ghi;
+    int m = negmask ? (__ffsll((long long)negmask) - 1) : -1;
     if (mode == MODE_SCAN) {
-        // candidate 0 is the current ϕ_prop, candidate q > 0 is schedule[j + q - 1] (1-based j); candidates increase with q
-        const int kk = (m < 0 ? nv : m) - 1;           // last candidate known to keep ESS above the target
-        if (kk >= 0) {
-            const double ckk = __shfl(ck, kk, 64), gkk = __shfl(gk, kk, 64);
-            if (ckk > lo) { lo = ckk; glo = gkk; }
-        }
-        if (m >= 0) {
-            const double cm = __shfl(ck, m, 64), gm = __shfl(gk, m, 64);
+        // Candidates ascend.  Those flagged in sched_mask are the reference's walk: the current ϕ_prop, then schedule[j],
+        // schedule[j+1], ... (1-based j; helpers.jl:29-32): the first of them with g < 0 becomes ϕ_prop and closes the
+        // bracket.  The others are predictor rings; they only refine the bracket between the two schedule points around the root.
+        const int cjk = mine ? S.cj[lane] : -1;                 // walk steps from the current ϕ_prop, -1 = ring point
+        const unsigned long long smask = __ballot(cjk >= 0);
+        const unsigned long long sneg = negmask & smask;
+        const int ms = sneg ? (__ffsll((long long)sneg) - 1) : -1;
+        if (ms >= 0) {
+            const double cm = __shfl(ck, ms, 64), gm = __shfl(gk, ms, 64);
             if (gm != gm) { if (lane == 0) *err = SMCMI_ERR_NAN_ESS; return; }
             hi = cm; ghi = gm;
-            if (lane == 0) { S.phi_prop = cm; S.j += m; }
+            const unsigned long long below = smask & ((1ull << ms) - 1ull);
+            const int ps = below ? 63 - __clzll((long long)below) : -1;       // previous schedule candidate (g >= 0), if any
+            if (ps >= 0) {
+                const double cp = __shfl(ck, ps, 64), gp = __shfl(gk, ps, 64);
+                if (cp > lo) { lo = cp; glo = gp; }
+            }
+            const int qs = __shfl(cjk, ms, 64);
+            if (lane == 0) { S.phi_prop = cm; S.j += qs; }
+            // ring candidates strictly between them (list positions ps+1 .. ms-1)
+            const unsigned long long upto = (1ull << ms) - 1ull;
+            const unsigned long long inner = ps < 0 ? upto : (upto & ~((2ull << ps) - 1ull));
+            const unsigned long long rneg = negmask & inner;
+            int top = ms;                                   // list position of the upper bracket end
+            if (rneg) {
+                top = __ffsll((long long)rneg) - 1;
+                hi = __shfl(ck, top, 64); ghi = __shfl(gk, top, 64);
+            }
+            if (top - 1 > ps) {                             // a ring point with g >= 0 just below it
+                const double cq = __shfl(ck, top - 1, 64), gq = __shfl(gk, top - 1, 64);
+                if (cq > lo) { lo = cq; glo = gq; }
+            }
+            m = top;
         } else {
-            const int j_new = S.j + (nv - 1);
-            const double clast = __shfl(ck, nv - 1, 64);
+            // every schedule candidate keeps ESS above the target: lo = the last of them, continue the walk
+            const int last_s = 63 - __clzll((long long)smask);
+            {
+                const double cl_ = __shfl(ck, last_s, 64), gl_ = __shfl(gk, last_s, 64);
+                if (cl_ > lo) { lo = cl_; glo = gl_; }
+            }
+            const int j_new = S.j + __shfl(cjk, last_s, 64);
+            const double clast = __shfl(ck, last_s, 64);
             if (j_new > n_phi) {                         // ϕ_prop == 1 and g(1) >= 0 -> ϕ_n = 1 (helpers.jl:51-53)
                 if (lane == 0) { S.lo = lo; S.glo = glo; S.phi_prop = clast; S.j = j_new; S.phi_n = clast; S.mode = MODE_FINAL; }
                 return;
             }
             int c = n_phi - j_new + 1;                   // continue the scan with the next chunk of the schedule
             if (c > KC) c = KC;
-            if (lane < c) S.cand[lane] = sched[j_new - 1 + lane];
+            if (lane < c) { S.cand[lane] = sched[j_new - 1 + lane]; S.cj[lane] = lane; }
             if (lane == 0) { S.lo = lo; S.glo = glo; S.n_valid = c; S.j = j_new + 1; S.phi_prop = sched[j_new - 1]; }
             return;                                      // stay in SCAN
         }
@@ -221,9 +327,13 @@ __device__ inline void solver_decide_wave(Solver &S, const double *tot, const do
         }
     }
     // ---- section candidates for the bracket (lo, hi)
+    // Termination: the bracket is at the requested resolution, or it is so short against the length of the tempering step
+    // (the scale on which ESS(ϕ) bends: it is analytic in ϕ - ϕ_{n-1}) that linear interpolation between its evaluated ends is
+    // already exact to that resolution - interpolation error ~ h² g''/(8 g') ~ h² / (8 (hi - ϕ_{n-1})), taken with a 64x margin.
     const double h = hi - lo;
     int c = 0;
-    if (h > rtol * hi) {
+    const bool interp_ok = glo > 0.0 && ghi < 0.0 && glo < 1e300 && ghi > -1e300 && 64.0 * h * h <= rtol * hi * (hi - S.phi0);
+    if (h > rtol * hi && !interp_ok) {
         double t = 0.5;
         if (glo > ghi && glo < 1e300 && ghi > -1e300) t = glo / (glo - ghi);
         const double xs = lo + h * t;
@@ -252,7 +362,12 @@ __device__ inline void solver_decide_wave(Solver &S, const double *tot, const do
     if (lane == 0) {
         S.lo = lo; S.hi = hi; S.glo = glo; S.ghi = ghi;
         if (c == 0) {   // bracket at the requested resolution (or no representable interior point)
-            S.phi_n = (fabs(glo) <= fabs(ghi)) ? lo : hi;
+            double pn = (fabs(glo) <= fabs(ghi)) ? lo : hi;
+            if (glo > 0.0 && ghi < 0.0 && glo < 1e300 && ghi > -1e300) {   // interpolate inside the certified bracket
+                const double xs = lo + h * (glo / (glo - ghi));
+                if (xs >= lo && xs <= hi) pn = xs;
+            }
+            S.phi_n = pn;
             S.mode = MODE_FINAL;
         } else {
             S.n_valid = c;
@@ -285,7 +400,11 @@ __device__ inline void solver_prologue(DevState *st, const double *sched, const 
         __syncthreads();
         if (t == 0) {
             int err = s_err;
-            if (force_final && S->mode != MODE_FINAL && !err) {   // out of passes: accept the current bracket
+            if (force_final && S->mode != MODE_FINAL && !err && st->rp.stall_on_exhaust) {
+                // out of passes: stall.  This and every later kernel does nothing until the host resumes the stage with more
+                // passes (smcmi_run); the search state (copy (p-1)&1 and the partials of pass p-1) is left intact.
+                if (blockIdx.x == 0) st->done = 2;
+            } else if (force_final && S->mode != MODE_FINAL && !err) {   // out of passes: accept the current bracket
                 if (S->mode == MODE_SECTION) { S->phi_n = (fabs(S->glo) <= fabs(S->ghi)) ? S->lo : S->hi; S->unconverged += 1; S->mode = MODE_FINAL; }
                 else err = SMCMI_ERR_BRACKET;                       // still scanning the schedule
             }
@@ -372,17 +491,35 @@ __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double
 // mutation's acceptance sums into cloud.accept, flip the cloud buffer after a resample, pick ϕ_n from the fixed
 // schedule or arm the adaptive solver with its first candidates (solver copy 0).
 __global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
-                                                    int acc_nb, Records rec) {
+                                                    int acc_nb, Records rec, const double *esum_partials = nullptr) {
     __shared__ double scratch[TB];
-    if (st->done) return;
-    // Σ accept over blocks of the previous mutation (update_acceptance_rate!, src/particle.jl:466-468)
-    double asum = 0.0;
-    if (acc_nb > 0) asum = final_sum1(acc_partials, acc_nb, scratch);
-    if (threadIdx.x != 0) return;
-    const int stage0 = st->stage, rs = st->do_resample, n_phi = st->rp.n_phi, fixed = st->rp.use_fixed_schedule;
+    __shared__ double s_es[ESP];
+    __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
+    __shared__ double s_ring[2 * NPR + 1];
+    __shared__ int s_qs[KC];
+    // one round of scalar loads
+    const int done = st->done, stage0 = st->stage, rs = st->do_resample, n_phi = st->rp.n_phi, fixed = st->rp.use_fixed_schedule;
     const int max_stages = st->rp.max_stages, rl = st->resampled_last, j = st->j;
     const double phi_n = st->phi_n, phi_prop = st->phi_prop, ess_prev = st->ess_prev, target = st->rp.tempering_target;
-    const double N = (double)st->rp.n_parts;
+    const double N = (double)st->rp.n_parts, e_center = st->e_center;
+    if (done) return;
+    const int i = stage0 + 1;
+    if (threadIdx.x < 64) {
+        const int jj = j - 1 + (int)threadIdx.x;       // 0-based index of walk step threadIdx.x + 1
+        s_sw[threadIdx.x] = (!fixed && jj < n_phi) ? sched[jj] : 2.0;
+    }
+    const double ph_fixed = (fixed && i <= n_phi) ? sched[i - 1] : 0.0;
+    // Σ accept over blocks of the previous mutation (update_acceptance_rate!, src/particle.jl:466-468)
+    const bool have_es = esum_partials != nullptr && acc_nb > 0 && stage0 > 1 && !fixed;
+    if (have_es) {                       // energy sums and (last column) the acceptance sum in one fixed-order reduction
+        const double v = final_sum(esum_partials, acc_nb, ESP, scratch);
+        if (threadIdx.x < ESP) s_es[threadIdx.x] = v;
+    }
+    double asum = 0.0;
+    if (!have_es && acc_nb > 0) asum = final_sum1(acc_partials, acc_nb, scratch);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (have_es) asum = s_es[ES];
     if (acc_nb > 0 && stage0 > 1) {
         const double a = asum / N;
         st->accept = a;
@@ -390,29 +527,74 @@ __global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *
     }
     if (rs) st->do_resample = 0;
     if (phi_n >= 1.0) { st->done = 1; return; }
-    const int i = stage0 + 1;
     if (i > max_stages) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; return; }
     st->stage = i;
     st->phi_prev = phi_n;
     Solver &S = st->sol[0];
     S.unconverged = 0;
     if (fixed) {
-        const double ph = sched[i - 1];
-        st->phi_n = ph;
-        S.phi_n = ph; S.mode = MODE_FINAL; S.j = j; S.phi_prop = phi_prop; S.n_valid = 0;
+        st->phi_n = ph_fixed;
+        S.phi_n = ph_fixed; S.mode = MODE_FINAL; S.j = j; S.phi_prop = phi_prop; S.n_valid = 0;
         return;
     }
-    double ess_now;   // ESS of the current weights = ESS(ϕ_n1)
-    if (rl) { S.ess_bar = target * N; st->resampled_last = 0; ess_now = N; }
-    else { S.ess_bar = target * ess_prev; ess_now = ess_prev; }
-    S.lo = phi_n;
-    S.glo = ess_now - S.ess_bar;
+    double ess_now, ess_bar;   // ESS of the current weights = ESS(ϕ_n1)
+    if (rl) { ess_bar = target * N; st->resampled_last = 0; ess_now = N; }
+    else { ess_bar = target * ess_prev; ess_now = ess_prev; }
+    S.ess_bar = ess_bar;
+    S.lo = phi_n; S.phi0 = phi_n;
+    S.glo = ess_now - ess_bar;
     S.hi = phi_prop; S.ghi = 0.0;
     S.j = j; S.phi_prop = phi_prop;
-    // scan candidates: current ϕ_prop, then schedule[j], schedule[j+1], ... (1-based j; helpers.jl:29-32)
-    int nv = 0;
-    S.cand[nv++] = phi_prop;
-    for (int jj = j; jj <= n_phi && nv < KC; ++jj) S.cand[nv++] = sched[jj - 1];
+    // predictor rings around the Taylor-model root, when the mutation left its energy sums
+    int nr = 0;
+    double pd = __longlong_as_double(0x7ff8000000000000ll);
+    if (have_es) {
+        pd = rs ? predict_delta<ES>(s_es, s_es, ess_bar) : predict_delta<EK>(s_es, s_es + EK, ess_bar);
+        const double ec = e_center + s_es[1] / s_es[0];        // weighted mean energy: centre for the next epilogue
+        if (fabs(ec) < 1e300) st->e_center = ec;
+        const double ph = phi_n + pd;
+        if (pd > 0.0 && ph < 1.0) {
+            double prev = phi_n;
+#pragma unroll
+            for (int q = 0; q < 2 * NPR + 1; ++q) {
+                const double r = q < NPR ? -PRING[q] : (q == NPR ? 0.0 : PRING[2 * NPR - q]);
+                const double x = ph + pd * r;
+                if (x > prev && x < 1.0) { s_ring[nr++] = x; prev = x; }
+            }
+        }
+    }
+    st->pred_delta = pd;
+    // Scan candidates, ascending: the reference's walk (step 0 = the current ϕ_prop, step q = schedule[j + q - 1], 1-based;
+    // helpers.jl:29-32) merged with the ring points.  With a prediction only the steps around it are evaluated (ϕ_prop, the last
+    // step below the prediction, the first two above it): ESS(ϕ) falls with ϕ, so the skipped steps in between keep it above
+    // the target just like their neighbours.
+    int nq = 0;
+    const int q_end = n_phi - j + 1;                         // last existing walk step
+    if (nr > 0) {
+        const double ph = phi_n + pd;
+        int q = 0;
+        double v = phi_prop;
+        while (v <= ph && q < q_end && q < 62) { ++q; v = s_sw[q - 1]; }      // first step above the prediction
+        if (v <= ph && q < q_end) nr = 0;                    // prediction beyond the staged window: plain walk
+        else {
+            s_qs[nq++] = 0;
+            if (q - 1 > 0) s_qs[nq++] = q - 1;
+            if (q > 0) s_qs[nq++] = q;
+            if (nq < KC - nr && q + 1 <= q_end) s_qs[nq++] = q + 1;
+        }
+    }
+    if (nr == 0) {
+        nq = 0;
+        for (int q = 0; q <= q_end && nq < KC; ++q) s_qs[nq++] = q;
+    }
+    int nv = 0, ir = 0, is = 0;
+    while (nv < KC && is < nq) {
+        const int q = s_qs[is];
+        const double vs = q == 0 ? phi_prop : s_sw[q - 1];
+        if (ir < nr && s_ring[ir] < vs) { S.cand[nv] = s_ring[ir++]; S.cj[nv] = -1; ++nv; continue; }
+        if (ir < nr && s_ring[ir] == vs) ++ir;
+        S.cand[nv] = vs; S.cj[nv] = q; ++nv; ++is;
+    }
     S.n_valid = nv;
     S.mode = MODE_SCAN;
 }
@@ -1133,6 +1315,7 @@ struct MutArgs {
     int block, step, last;     // MODE 1/2
     long long *prof;           // development only: per-phase shader-clock stamps of block 0 / middle block, wave 0
     int debug;                 // development only (tools/kbench.py): bit0 skip normals, bit1 skip prior/likelihood, bit2 skip matvec
+    double *esum;              // in-run MODE 0: per-block energy power sums for the next stage's ϕ predictor ([blocks][ES]) or null
 };
 
 template <int MODE>
@@ -1299,11 +1482,18 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     double a1[1] = {acc_val};
     Butterfly<0, 32>::run(a1, tid & 63);
     if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+    if (MODE == 0 && ma.esum) {                      // energy power sums of the mutated cloud (ϕ predictor of the next stage)
+        double es[ES];
+        energy_terms(es, live ? col(cl, src, d + 4)[i] : 0.0, like, like_prev, st->e_center, live, st->do_resample != 0);
+        const double tot = block_reduce_es(es, th, T / 64);          // θ staging area is dead by now ((T/64) ES <= d T)
+        if (tid < ES) ma.esum[(long long)blockIdx.x * ESP + tid] = tot;
+    }
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
         for (int w = 0; w < T / 64; ++w) s += red[w];
         acc_partials[blockIdx.x] = s;
+        if (ma.esum) ma.esum[(long long)blockIdx.x * ESP + ES] = s;
     }
 }
 
@@ -1347,6 +1537,8 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     const int done = st->done, n_steps = st->mut_steps;
     const unsigned stage = st->mut_stage;
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
+    const double e_center = st->e_center;
+    const bool es_uniform = st->do_resample != 0;       // this stage resampled: all weights are 1
     for (int e = tid; e < nf * nf; e += T) Lraw[e] = st->L[e];
     for (int e = tid; e < nf; e += T) {
         mub_raw[e] = st->mu_b[e]; sdd_raw[e] = st->sd_draw[e]; sdn_raw[e] = st->sd_dens[e]; ball_raw[e] = st->blocks_all[e];
@@ -1376,6 +1568,7 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
         for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[i];
         like = col(cl, src, D)[i]; lprior = col(cl, src, D + 1)[i]; like_prev = col(cl, src, D + 2)[i];
     }
+    const double w_part = (live && ma.esum) ? col(cl, src, D + 4)[i] : 0.0;
     ModelView mv{D, m_fix, m_fam, m_lo, m_hi, m_a, m_b, m_k};
     LikView lv[2];
     {
@@ -1631,11 +1824,18 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     Butterfly<0, 32>::run(a1, tid & 63);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+    if (ma.esum) {                                   // energy power sums of the mutated cloud (ϕ predictor of the next stage)
+        double es[ES];
+        energy_terms(es, w_part, like, like_prev, e_center, live, es_uniform);
+        const double tot = block_reduce_es(es, l_dat, T / 64);       // likelihood data in LDS is dead by now
+        if (tid < ES) ma.esum[(long long)blockIdx.x * ESP + tid] = tot;
+    }
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
         for (int w = 0; w < T / 64; ++w) s += red[w];
         acc_partials[blockIdx.x] = s;
+        if (ma.esum) ma.esum[(long long)blockIdx.x * ESP + ES] = s;
     }
     SMCMI_PROF(9);
 #undef SMCMI_PROF

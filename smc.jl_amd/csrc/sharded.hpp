@@ -156,7 +156,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
     if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
     const bool adaptive = !rc->use_fixed_schedule;
-    const int P = adaptive ? (rc->solver_passes > 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES) : 0;
+    const int P = adaptive ? (rc->solver_passes > 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
     std::vector<double> sched(rc->n_phi);
     for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
     for (auto *h : g.hs) {

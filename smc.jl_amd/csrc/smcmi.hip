@@ -55,7 +55,7 @@ struct smcmi_handle {
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
-    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
+    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
     // host-callback split
@@ -69,6 +69,7 @@ struct smcmi_handle {
     double *d_tot_ess = nullptr, *d_tot_fin = nullptr, *d_tot_mom = nullptr, *d_tot_acc = nullptr, *d_full_w = nullptr, *d_full_cloud = nullptr;
     int last_n_stages = 1;
     int launch_nb = 1;
+    bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
     int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
     bool launch_alpha1 = false;
     long long *d_prof = nullptr;   // development only (smcmi_debug_time_kernel with which = 9 and SMCMI_PROF_MUT=1)
@@ -163,7 +164,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ESP) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -200,7 +201,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part,
+                    h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
@@ -354,11 +355,13 @@ static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
     return 0;
 }
 
-static const int DEFAULT_SOLVER_PASSES = 5;   // 1 schedule scan + bracketing passes (4-5 typical, see kernels.hpp)
+static const int DEFAULT_SOLVER_PASSES = 2;   // with the energy-sum predictor 1-2 passes certify the root; a stage that needs more stalls and is resumed (smcmi_run)
+static const int FIRST_SOLVER_PASSES = 6;     // first adaptive stage: no prediction yet (1 schedule scan + bracketing passes)
+static const int SHARDED_SOLVER_PASSES = 5;   // sharded driver: no predictor yet
 
 // P solver passes; pass p consumes the partials of pass p-1 in its prologue.  The correction pass that follows is pass P.
-static void enqueue_solver(smcmi_handle *h, int passes) {
-    for (int p = 0; p < passes; ++p)
+static void enqueue_solver(smcmi_handle *h, int passes, int p0 = 0) {
+    for (int p = p0; p < passes; ++p)
         k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(p + 1) & 1], h->d_part_ess[p & 1],
                                                            h->nb_e, p, nullptr, 0);
 }
@@ -613,6 +616,8 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
     ma.debug = dbg;
     ma.prof = h->d_prof;
+    static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
+    ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
     switch (h->d) {
     case 1: launch_reg<1>(h, ma, standalone); break;
     case 2: launch_reg<2>(h, ma, standalone); break;
@@ -713,13 +718,18 @@ extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const dou
 
 // ------------------------------------------------------------------------------------------------ whole loop
 // One stage = a fixed kernel sequence (no host decision inside): see the header of kernels.hpp.
+// p0 > 0 resumes a stage whose solver ran out of passes after p0 of them (st->done == 2 stall, see solver_prologue): the
+// search continues with passes p0 .. p0 + solver_passes - 1 exactly as if the original list had been that much longer.
 static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int n_blocks, double alpha, int acc_nb,
-                          hipEvent_t ev0, hipEvent_t ev1) {
+                          hipEvent_t ev0, hipEvent_t ev1, int p0 = 0) {
     const long long n = h->n;
     hipStream_t s = h->stream;
-    const int P = adaptive ? solver_passes : 0;
-    k_stage_begin<<<1, TB, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
-    if (adaptive) enqueue_solver(h, P);
+    const int P = adaptive ? p0 + solver_passes : 0;
+    static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
+    h->run_adaptive = adaptive;
+    if (p0 == 0)
+        k_stage_begin<<<1, TB, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec, (adaptive && !no_pred) ? h->d_esum_part : nullptr);
+    if (adaptive) enqueue_solver(h, P, p0);
     k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
     k_post_correct<<<h->nb_e, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, P == 0 ? 0 : (P & 1), h->cl, h->d_cum);
     k_resample_gather<<<(unsigned)std::min<long long>((n + TB - 1) / TB, 4 * h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
@@ -757,6 +767,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
     rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
     rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+    rp.stall_on_exhaust = 1;
     rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
     memset(&s, 0, sizeof(DevState));
     s.rp = rp; s.cur = cur;
@@ -779,7 +790,8 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    const int solver_passes = rc->solver_passes > 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
+    const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
+    const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
     const int max_db = (nf + rc->n_blocks - 1) / rc->n_blocks;
     const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
@@ -795,20 +807,51 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     }
     const auto t0 = std::chrono::steady_clock::now();
     int launched = 0, done = 0;
+    res->solver_stalls = 0; res->reserved_ = 0;
     const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
+    int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
     while (launched < max_iter && !done) {
         const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
-            if (gexec) HIP_TRY(hipGraphLaunch(gexec, h->stream));
+            if (gexec && launched > 0) HIP_TRY(hipGraphLaunch(gexec, h->stream));
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
-                enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, e0, e1);
+                enqueue_stage(h, adaptive, launched == 0 ? first_passes : solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha,
+                              acc_nb, e0, e1);
             }
             ++launched;
         }
         HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        while (done == 2) {
+            // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give that
+            // stage more passes (continuing the same search), and go on from the stage after it.
+            if (pull_state(h)) return SMCMI_ERR_HIP;
+            const int st_i = s.stage;
+            const int had = (st_i == stall_stage) ? stall_p : (st_i == 2 ? first_passes : solver_passes);
+            const int more = 8;
+            const int zero = 0;
+            HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had);
+            stall_stage = st_i; stall_p = had + more;
+            launched = st_i - 1;
+            res->solver_stalls += 1;
+            HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        static const int trace = getenv("SMCMI_TRACE") ? atoi(getenv("SMCMI_TRACE")) : 0;   // development only
+        if (trace) {
+            static long long last_passes = 0;
+            if (pull_state(h)) return SMCMI_ERR_HIP;
+            fprintf(stderr, "[smcmi] stage %d phi %.12e dphi %.6e pred %.6e relerr %.2e passes %lld ess %.1f rs %d\n", s.stage, s.phi_n,
+                    s.phi_n - s.phi_prev, s.pred_delta, (s.pred_delta - (s.phi_n - s.phi_prev)) / (s.phi_n - s.phi_prev),
+                    s.solver_passes - last_passes, s.ess, s.do_resample);
+            last_passes = s.solver_passes;
+            for (int q = 0; q < 2; ++q)
+                fprintf(stderr, "[smcmi]    sol[%d] mode %d nv %d lo-phi %.3e hi-phi %.3e glo %.3e ghi %.3e\n", q, s.sol[q].mode, s.sol[q].n_valid,
+                        s.sol[q].lo - s.phi_n, s.sol[q].hi - s.phi_n, s.sol[q].glo, s.sol[q].ghi);
+        }
     }
     // fold the last mutation's acceptance rate and close the run
     k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);

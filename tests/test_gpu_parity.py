@@ -475,3 +475,22 @@ def test_run_config2_logmdd_vs_oracle(orc):
     spec = models.gauss_spec()
     e, g, r = _compare_runs(orc, spec, 100000, 1, 1e-3, use_fixed_schedule=False, tempering_target=0.97)
     assert g["logmdd"] == pytest.approx(models.gauss_logmdd(), abs=0.1)
+
+
+def test_solver_stall_resume_is_exact():
+    """A stage whose adaptive-ϕ search needs more kernel passes than were enqueued stalls the run (DevState.done = 2) and the
+    host resumes it with more passes: the search, and therefore every result, is identical to a run with a generous list."""
+    spec = models.gauss_spec(d=6)
+    out = []
+    for P in (1, 2, 12):
+        eng = make_engine(spec, 8192, seed=21, max_stages=2000)
+        eng.init_from_prior()
+        r = eng.run(use_fixed_schedule=False, tempering_target=0.9, n_phi=100, solver_passes=P, sync_every=4)
+        out.append((r, eng.stage_records(r["n_stages"]), eng.download_cloud()))
+        eng.close()
+    assert out[0][0]["solver_stalls"] > 0 and out[2][0]["solver_stalls"] == 0
+    for r, rec, P_ in out[:2]:
+        assert r["n_stages"] == out[2][0]["n_stages"] and r["logmdd"] == out[2][0]["logmdd"]
+        np.testing.assert_array_equal(rec["schedule"], out[2][1]["schedule"])
+        np.testing.assert_array_equal(rec["ess"], out[2][1]["ess"])
+        np.testing.assert_array_equal(P_, out[2][2])
