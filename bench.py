@@ -174,6 +174,22 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_mutate_reg<%d,true>" % D, "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl}
+        # The kernel is FP64-VALU bound, not HBM bound: express it against the VALU issue rate as well.
+        # One VALU instruction of a wave64 occupies a SIMD for 4 cycles; instr_per_wave is the static count of the
+        # straight-line kernel body from its gfx950 ISA (profiles/isa_count.py -> r01_isa_counts.json; an upper bound on
+        # the dynamic count, the MH loop is unrolled for one step x one block).
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_isa_counts.json")) as f:
+                isa = json.load(f).get("k_mutate_reg<%d,true>" % D)
+            if isa and RUN_KW.get("n_mh_steps", 1) == 1 and mean_ms > 0:
+                waves = -(-n_total // 64)
+                peak = 256 * 4 * 2.4e9 / 4            # wave-instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+                ach = waves * isa["valu_total"] / (mean_ms * 1e-3)
+                out["roofline"]["valu_issue"] = {"valu_instr_per_wave": isa["valu_total"], "waves": waves, "achieved": ach,
+                                                 "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
+                                                 "waves_per_simd": waves / 1024.0}
+        except OSError:
+            pass
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages
         stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
         out["stage_gbs"] = stage_bytes * args.steps / dt / 1e9

@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(TB) k_zero_bad_weights(CloudPtrs cl, const Dev
     if (col(cl, st->cur, d)[i] == SMCMI_NEG_INF) col(cl, st->cur, cl.R - 1)[i] = 0.0;
 }
 // normalize_weights! (src/particle.jl:362-366): W *= n_parts, W /= sum(W); st->sumw holds the fixed-order sum
-__global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st, double n_parts) {
+__global__ void __launch_bounds__(TB) k_normalize_weights_n(CloudPtrs cl, const DevState *st, double n_parts) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     double *w = col(cl, st->cur, cl.R - 1);

@@ -133,9 +133,9 @@ struct ShardGroup {
 static int ensure_shard_buffers(smcmi_handle *h) {
     const long long N = h->cfg.n_parts;
     if (!h->d_tot_ess) {
-        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs) || dmalloc(&h->d_tot_acc, 1))
+        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs) || dmalloc(&h->d_tot_acc, ESP))
             return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double)));
+        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * ESP));
     }
     if (!h->d_cum_full) {
         if (dmalloc(&h->d_cum_full, N)) return SMCMI_ERR_HIP;
@@ -156,7 +156,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
     if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
     const bool adaptive = !rc->use_fixed_schedule;
-    const int P = adaptive ? (rc->solver_passes > 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
+    const int P_default = adaptive ? (rc->solver_passes >= 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
+    static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
+    const bool predict = adaptive && !no_pred;
     std::vector<double> sched(rc->n_phi);
     for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
     for (auto *h : g.hs) {
@@ -171,6 +173,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
         rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
         rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+        rp.stall_on_exhaust = 1;
         rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
         memset(&s, 0, sizeof(DevState));
         s.rp = rp;
@@ -190,38 +193,52 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     }
     const auto t0 = std::chrono::steady_clock::now();
     const int max_iter = adaptive ? h0->cfg.max_stages : rc->n_phi - 1;
-    int done = 0, iters = 0;
+    int done = 0, iters = 0, stalls = 0;
     while (iters < max_iter && !done) {
-        // ---- stage begin + adaptive-ϕ solver
+        // ---- stage begin + adaptive-ϕ solver + correction.  d_tot_acc holds the all-reduced [energy sums | acceptance sum]
+        // of the previous mutation (ESP doubles; only the last one on a fixed schedule).
+        int P = adaptive ? (iters == 0 ? std::max(P_default, FIRST_SOLVER_PASSES) : P_default) : 0;
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
-            k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc, 1, h->rec);
+            h->run_adaptive = predict;
+            k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec, predict ? h->d_tot_acc : nullptr);
         }
-        for (int p = 0; p < P; ++p) {
+        int flags[2] = {0, 0};
+        for (int p0 = 0;;) {
+            for (int p = p0; p < P; ++p) {
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_ess[p & 1], 1, p, nullptr, 0);
+                    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess[p & 1], h->nb_e, 2 * KC, h->d_tot_ess);
+                }
+                if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_ess; }, 2 * KC)) return rc2;
+            }
+            // ---- correction
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
-                k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_ess[p & 1], 1, p, nullptr, 0);
-                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_ess[p & 1], h->nb_e, 2 * KC, h->d_tot_ess);
+                k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_fin, 1, P, h->d_hist_w, h->n);
+                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
             }
-            if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_ess; }, 2 * KC)) return rc2;
+            if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_tot_fin, 1, nullptr, h->rec, P == 0 ? 0 : (P & 1));
+            }
+            // the selection needs a collective only on resample stages: the one host decision per stage (identical on all ranks)
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(&flags[0], &h0->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipMemcpyAsync(&flags[1], &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipStreamSynchronize(h0->stream));
+            if (flags[1] != 2) break;
+            // the solver ran out of passes (stall, see solver_prologue): clear it on every shard and continue the same search
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                const int zero = 0;
+                HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            }
+            p0 = P; P += 4;
+            ++stalls;
         }
-        // ---- correction
-        for (auto *h : g.hs) {
-            HIP_TRY(hipSetDevice(h->cfg.device));
-            k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_fin, 1, P, h->d_hist_w, h->n);
-            k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
-        }
-        if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
-        int flags[2] = {0, 0};
-        for (auto *h : g.hs) {
-            HIP_TRY(hipSetDevice(h->cfg.device));
-            k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_tot_fin, 1, nullptr, h->rec, P == 0 ? 0 : (P & 1));
-        }
-        // the selection needs a collective only on resample stages: the one host decision per stage (identical on all ranks)
-        HIP_TRY(hipSetDevice(h0->cfg.device));
-        HIP_TRY(hipMemcpyAsync(&flags[0], &h0->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
-        HIP_TRY(hipMemcpyAsync(&flags[1], &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
-        HIP_TRY(hipStreamSynchronize(h0->stream));
         if (flags[1]) { done = 1; break; }
         if (flags[0]) {
             const size_t nloc = (size_t)h0->n;
@@ -253,15 +270,17 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             HIP_TRY(hipSetDevice(h->cfg.device));
             k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_tot_mom, 1, h->cfg.seed, 2, 1, 0);
             const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
-            k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc);
+            if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ESP, h->d_tot_acc);
+            else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + ES);
         }
-        if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, 1)) return rc2;
+        if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ESP)) return rc2; }
+        else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, 1)) return rc2;
         ++iters;
     }
     // fold the last acceptance rate, close the run
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc, 1, h->rec);
+        k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec);
         if (pull_state(h)) return SMCMI_ERR_HIP;
         h->last_n_stages = h->h_st.stage;
     }
@@ -271,6 +290,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
+    res->solver_stalls = stalls;
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;

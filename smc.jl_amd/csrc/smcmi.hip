@@ -357,7 +357,7 @@ static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
 
 static const int DEFAULT_SOLVER_PASSES = 2;   // with the energy-sum predictor 1-2 passes certify the root; a stage that needs more stalls and is resumed (smcmi_run)
 static const int FIRST_SOLVER_PASSES = 6;     // first adaptive stage: no prediction yet (1 schedule scan + bracketing passes)
-static const int SHARDED_SOLVER_PASSES = 5;   // sharded driver: no predictor yet
+static const int SHARDED_SOLVER_PASSES = 1;   // sharded driver: every pass costs a collective and the host syncs per stage anyway, so a stall is cheap
 
 // P solver passes; pass p consumes the partials of pass p-1 in its prologue.  The correction pass that follows is pass P.
 static void enqueue_solver(smcmi_handle *h, int passes, int p0 = 0) {
@@ -522,7 +522,7 @@ extern "C" int smcmi_normalize_weights(smcmi_handle *h, int32_t zero_bad_loglh) 
     if (zero_bad_loglh) k_zero_bad_weights<<<g, TB, 0, h->stream>>>(h->cl, h->d_st);
     k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
     k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
-    k_normalize_weights<<<g, TB, 0, h->stream>>>(h->cl, h->d_st, (double)h->cfg.n_parts);
+    k_normalize_weights_n<<<g, TB, 0, h->stream>>>(h->cl, h->d_st, (double)h->cfg.n_parts);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
