@@ -115,6 +115,47 @@ __device__ inline double final_sum(const double *partials, int nb, int m, double
     return tot;
 }
 
+// Fixed-order total of column `colx` of partials[nb][stride] by ONE wavefront: lane l adds rows l, l + 64, ... (eight loads in
+// flight), then a 6-step xor butterfly.  Every lane returns the total.  No LDS, no block barrier.
+__device__ inline double wave_column_sum(const double *partials, int nb, int stride, int colx) {
+    const int lane = threadIdx.x & 63;
+    double a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.0;
+    int b = lane;
+    for (; b + 7 * 64 < nb; b += 8 * 64) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += partials[(long long)(b + q * 64) * stride + colx];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (b + q * 64 < nb) a[q] += partials[(long long)(b + q * 64) * stride + colx];
+    double v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// two columns in one round of loads
+__device__ inline void wave_column_sum2(const double *partials, int nb, int stride, int c0, int c1, double &v0, double &v1) {
+    const int lane = threadIdx.x & 63;
+    double a[8], g[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = g[q] = 0.0;
+    int b = lane;
+    for (; b + 7 * 64 < nb; b += 8 * 64) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a[q] += partials[(long long)(b + q * 64) * stride + c0]; g[q] += partials[(long long)(b + q * 64) * stride + c1]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (b + q * 64 < nb) { a[q] += partials[(long long)(b + q * 64) * stride + c0]; g[q] += partials[(long long)(b + q * 64) * stride + c1]; }
+    v0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    v1 = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); }
+}
+
 // Fixed-order total of nb scalars using the whole block (nb can be ~1e5 mutation blocks).
 __device__ inline double final_sum1(const double *partials, int nb, double *scratch /* blockDim.x doubles */) {
     const int t = threadIdx.x, T = blockDim.x;
@@ -222,7 +263,7 @@ __device__ inline double predict_delta(const double *a, const double *b, double 
     if (disc >= 0.0 && -G1 + sqrt(disc) > 0.0) x = 2.0 * G0 / (-G1 + sqrt(disc));
     else if (G1 < 0.0) x = -G0 / G1;
     else return nan;
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 3; ++it) {
         double A = ca[KK - 1], B = cb[KK - 1], dA = (double)(KK - 1) * ca[KK - 1], dB = (double)(KK - 1) * cb[KK - 1];
 #pragma unroll
         for (int k = KK - 2; k >= 0; --k) {
@@ -238,8 +279,10 @@ __device__ inline double predict_delta(const double *a, const double *b, double 
     }
     return x;
 }
-constexpr int NPR = 6;
-constexpr double PRING[NPR] = {0x1p-5, 0x1p-10, 0x1p-15, 0x1p-20, 0x1p-25, 0x1p-30};
+constexpr int NPR = 3;                       // rings on each side of the predicted root, as fractions of the predicted step
+constexpr double PRING[NPR] = {0x1p-10, 0x1p-20, 0x1p-30};
+constexpr int NRL = 2 * NPR + 1;             // lanes that own ring points in k_stage_begin
+constexpr int NLANE = (NRL + 4 > KC) ? NRL + 4 : KC;   // lanes that can hold a candidate there (rings + 4 walk steps, or KC walk steps)
 
 // ------------------------------------------------------------------------------------------------ ϕ solver
 // solve_adaptive_ϕ (src/helpers.jl:9-56) as a bracketing search driven by K-candidate ESS passes:
@@ -490,113 +533,148 @@ __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double
 // Stage begin (src/smc_main.jl:378-396 + src/helpers.jl:14-20): bump the stage index, fold the previous
 // mutation's acceptance sums into cloud.accept, flip the cloud buffer after a resample, pick ϕ_n from the fixed
 // schedule or arm the adaptive solver with its first candidates (solver copy 0).
-__global__ void __launch_bounds__(TB) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
-                                                    int acc_nb, Records rec, const double *esum_partials = nullptr) {
-    __shared__ double scratch[TB];
+constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
+__global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
+                                                    int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr) {
+    __shared__ double scratch[BT];
+    SMCMI_STAMP(prof, 0);
     __shared__ double s_es[ESP];
     __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
-    __shared__ double s_ring[2 * NPR + 1];
-    __shared__ int s_qs[KC];
     // one round of scalar loads
     const int done = st->done, stage0 = st->stage, rs = st->do_resample, n_phi = st->rp.n_phi, fixed = st->rp.use_fixed_schedule;
     const int max_stages = st->rp.max_stages, rl = st->resampled_last, j = st->j;
     const double phi_n = st->phi_n, phi_prop = st->phi_prop, ess_prev = st->ess_prev, target = st->rp.tempering_target;
     const double N = (double)st->rp.n_parts, e_center = st->e_center;
+    // Energy sums and (last column) the acceptance sum of the previous mutation: wave w totals column w (wave 0 also the last
+    // one).  Issued before anything else - the partials come cold from another die (~2.5 µs), the scalars overlap with them.
+    const bool try_es = esum_partials != nullptr && acc_nb > 0;
+    double es_col = 0.0, es_last = 0.0;
+    if (try_es) {
+        const int w = threadIdx.x >> 6;
+        if (w == 0) wave_column_sum2(esum_partials, acc_nb, ESP, 0, ES, es_col, es_last);
+        else if (w < ES) es_col = wave_column_sum(esum_partials, acc_nb, ESP, w);
+    }
     if (done) return;
+    SMCMI_STAMP(prof, 1);
     const int i = stage0 + 1;
+    double swv = 2.0;                                  // stays in flight across the reduction's loads; stored to LDS after them
     if (threadIdx.x < 64) {
         const int jj = j - 1 + (int)threadIdx.x;       // 0-based index of walk step threadIdx.x + 1
-        s_sw[threadIdx.x] = (!fixed && jj < n_phi) ? sched[jj] : 2.0;
+        if (!fixed && jj < n_phi) swv = sched[jj];
     }
     const double ph_fixed = (fixed && i <= n_phi) ? sched[i - 1] : 0.0;
     // Σ accept over blocks of the previous mutation (update_acceptance_rate!, src/particle.jl:466-468)
-    const bool have_es = esum_partials != nullptr && acc_nb > 0 && stage0 > 1 && !fixed;
-    if (have_es) {                       // energy sums and (last column) the acceptance sum in one fixed-order reduction
-        const double v = final_sum(esum_partials, acc_nb, ESP, scratch);
-        if (threadIdx.x < ESP) s_es[threadIdx.x] = v;
+    const bool have_es = try_es && stage0 > 1 && !fixed;
+    if (have_es && (threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        if (w < ES) s_es[w] = es_col;
+        if (w == 0) s_es[ES] = es_last;
     }
     double asum = 0.0;
     if (!have_es && acc_nb > 0) asum = final_sum1(acc_partials, acc_nb, scratch);
+    if (threadIdx.x < 64) s_sw[threadIdx.x] = swv;
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    SMCMI_STAMP(prof, 2);
+    // Wavefront 0 finishes: the scalar bookkeeping is lane 0's, the candidate set is built by all lanes (no serial loops).
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     if (have_es) asum = s_es[ES];
-    if (acc_nb > 0 && stage0 > 1) {
-        const double a = asum / N;
-        st->accept = a;
-        rec.accept[stage0 - 1] = a;
+    if (lane == 0) {
+        if (acc_nb > 0 && stage0 > 1) {
+            const double a = asum / N;
+            st->accept = a;
+            rec.accept[stage0 - 1] = a;
+        }
+        if (rs) st->do_resample = 0;
     }
-    if (rs) st->do_resample = 0;
-    if (phi_n >= 1.0) { st->done = 1; return; }
-    if (i > max_stages) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; return; }
-    st->stage = i;
-    st->phi_prev = phi_n;
+    if (phi_n >= 1.0) { if (lane == 0) st->done = 1; return; }
+    if (i > max_stages) { if (lane == 0) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; } return; }
     Solver &S = st->sol[0];
-    S.unconverged = 0;
+    if (lane == 0) { st->stage = i; st->phi_prev = phi_n; S.unconverged = 0; }
     if (fixed) {
-        st->phi_n = ph_fixed;
-        S.phi_n = ph_fixed; S.mode = MODE_FINAL; S.j = j; S.phi_prop = phi_prop; S.n_valid = 0;
+        if (lane == 0) {
+            st->phi_n = ph_fixed;
+            S.phi_n = ph_fixed; S.mode = MODE_FINAL; S.j = j; S.phi_prop = phi_prop; S.n_valid = 0;
+        }
         return;
     }
     double ess_now, ess_bar;   // ESS of the current weights = ESS(ϕ_n1)
-    if (rl) { ess_bar = target * N; st->resampled_last = 0; ess_now = N; }
+    if (rl) { ess_bar = target * N; ess_now = N; }
     else { ess_bar = target * ess_prev; ess_now = ess_prev; }
-    S.ess_bar = ess_bar;
-    S.lo = phi_n; S.phi0 = phi_n;
-    S.glo = ess_now - ess_bar;
-    S.hi = phi_prop; S.ghi = 0.0;
-    S.j = j; S.phi_prop = phi_prop;
-    // predictor rings around the Taylor-model root, when the mutation left its energy sums
-    int nr = 0;
+    if (lane == 0) {
+        if (rl) st->resampled_last = 0;
+        S.ess_bar = ess_bar;
+        S.lo = phi_n; S.phi0 = phi_n;
+        S.glo = ess_now - ess_bar;
+        S.hi = phi_prop; S.ghi = 0.0;
+        S.j = j; S.phi_prop = phi_prop;
+    }
+    // predictor: root of the Taylor model (every lane computes the same scalar), then rings around it
     double pd = __longlong_as_double(0x7ff8000000000000ll);
     if (have_es) {
         pd = rs ? predict_delta<ES>(s_es, s_es, ess_bar) : predict_delta<EK>(s_es, s_es + EK, ess_bar);
         const double ec = e_center + s_es[1] / s_es[0];        // weighted mean energy: centre for the next epilogue
-        if (fabs(ec) < 1e300) st->e_center = ec;
-        const double ph = phi_n + pd;
-        if (pd > 0.0 && ph < 1.0) {
-            double prev = phi_n;
-#pragma unroll
-            for (int q = 0; q < 2 * NPR + 1; ++q) {
-                const double r = q < NPR ? -PRING[q] : (q == NPR ? 0.0 : PRING[2 * NPR - q]);
-                const double x = ph + pd * r;
-                if (x > prev && x < 1.0) { s_ring[nr++] = x; prev = x; }
-            }
-        }
+        if (lane == 0 && fabs(ec) < 1e300) st->e_center = ec;
     }
-    st->pred_delta = pd;
+    if (lane == 0) st->pred_delta = pd;
+    SMCMI_STAMP(prof, 3);
     // Scan candidates, ascending: the reference's walk (step 0 = the current ϕ_prop, step q = schedule[j + q - 1], 1-based;
     // helpers.jl:29-32) merged with the ring points.  With a prediction only the steps around it are evaluated (ϕ_prop, the last
     // step below the prediction, the first two above it): ESS(ϕ) falls with ϕ, so the skipped steps in between keep it above
-    // the target just like their neighbours.
-    int nq = 0;
+    // the target just like their neighbours.  Lanes 0..NRL-1 own the ring points, the next four the walk steps; each kept value
+    // finds its slot by counting the kept values below it.
     const int q_end = n_phi - j + 1;                         // last existing walk step
-    if (nr > 0) {
-        const double ph = phi_n + pd;
-        int q = 0;
-        double v = phi_prop;
-        while (v <= ph && q < q_end && q < 62) { ++q; v = s_sw[q - 1]; }      // first step above the prediction
-        if (v <= ph && q < q_end) nr = 0;                    // prediction beyond the staged window: plain walk
-        else {
-            s_qs[nq++] = 0;
-            if (q - 1 > 0) s_qs[nq++] = q - 1;
-            if (q > 0) s_qs[nq++] = q;
-            if (nq < KC - nr && q + 1 <= q_end) s_qs[nq++] = q + 1;
+    const double ph = phi_n + pd;
+    bool use_pred = pd > 0.0 && ph < 1.0;
+    // first walk step above the prediction among steps 0..62 (lane l looks at step l)
+    const double wl = lane == 0 ? phi_prop : s_sw[lane - 1];
+    const unsigned long long above = __ballot(lane <= 62 && lane <= q_end && wl > ph);
+    int qstar = above ? (__ffsll((long long)above) - 1) : (q_end <= 62 ? q_end : -1);
+    if (qstar < 0) use_pred = false;                         // prediction beyond the staged window: plain walk
+    double x = 0.0;
+    int cq = -1;
+    bool keep = false;
+    if (use_pred) {
+        if (lane < 2 * NPR + 1) {
+            const double r = lane < NPR ? -PRING[lane < NPR ? lane : 0] : (lane == NPR ? 0.0 : PRING[2 * NPR - lane]);
+            x = ph + pd * r;
+            keep = x > phi_n && x < 1.0;
         }
+        const unsigned long long ringm = __ballot(keep);
+        if (!ringm) use_pred = false;
+        const int nr = __popcll(ringm);
+        if (lane == NRL) { cq = 0; keep = true; }
+        if (lane == NRL + 1) { cq = qstar - 1; keep = cq > 0; }
+        if (lane == NRL + 2) { cq = qstar; keep = cq > 0; }
+        const int nq3 = 1 + (qstar - 1 > 0 ? 1 : 0) + (qstar > 0 ? 1 : 0);
+        if (lane == NRL + 3) { cq = qstar + 1; keep = cq <= q_end && nq3 < KC - nr; }
+        if (lane >= NRL && lane <= NRL + 3 && keep) x = cq == 0 ? phi_prop : s_sw[cq - 1];
     }
-    if (nr == 0) {
-        nq = 0;
-        for (int q = 0; q <= q_end && nq < KC; ++q) s_qs[nq++] = q;
+    if (!use_pred) {                                         // plain walk: steps 0 .. min(q_end, KC - 1)
+        cq = lane; keep = lane < KC && lane <= q_end;
+        x = keep ? wl : 0.0;
+    } else {
+        // drop ring points that coincide with a lower-lane ring point or with any walk step
+        bool dup = false;
+#pragma unroll
+        for (int o = 0; o < NLANE; ++o) {
+            const double xo = __shfl(x, o, 64);
+            const bool ko = (bool)__shfl((int)keep, o, 64);
+            if (ko && lane < NRL && xo == x && (o < lane || o >= NRL)) dup = true;
+        }
+        if (dup) keep = false;
     }
-    int nv = 0, ir = 0, is = 0;
-    while (nv < KC && is < nq) {
-        const int q = s_qs[is];
-        const double vs = q == 0 ? phi_prop : s_sw[q - 1];
-        if (ir < nr && s_ring[ir] < vs) { S.cand[nv] = s_ring[ir++]; S.cj[nv] = -1; ++nv; continue; }
-        if (ir < nr && s_ring[ir] == vs) ++ir;
-        S.cand[nv] = vs; S.cj[nv] = q; ++nv; ++is;
+    int rank = 0;
+#pragma unroll
+    for (int o = 0; o < NLANE; ++o) {
+        const double xo = __shfl(x, o, 64);
+        const bool ko = (bool)__shfl((int)keep, o, 64);
+        if (ko && xo < x) ++rank;
     }
-    S.n_valid = nv;
-    S.mode = MODE_SCAN;
+    const int nv = __popcll(__ballot(keep));
+    if (keep) { S.cand[rank] = x; S.cj[rank] = use_pred ? (lane >= NRL ? cq : -1) : cq; }
+    if (lane == 0) { S.n_valid = nv; S.mode = MODE_SCAN; }
+    SMCMI_STAMP(prof, 5);
 }
 
 // Inclusive scan of W̃/ΣW̃ over chunk `vb` (cumsum(weights ./ sum(weights)), src/resample.jl:29,47): thread t owns IPT
@@ -1134,29 +1212,19 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
     SMCMI_STAMP(prof, 1);
     if (from_totals) {
         if (from_totals == 1) {
-            for (int p0 = 0; p0 < npairs; p0 += 64) {
-                const int m = (npairs - p0) < 64 ? (npairs - p0) : 64;
-                // pad to 64-wide rows so every 64-thread slice adds whole blocks; out-of-range idx contribute nothing
-                const int idx = t % 64, sl = t / 64;          // 16 slices of blocks
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                if (idx < m) {
-                    const double *pp = partials + p0 + idx;
-                    int b = sl;
-                    for (; b + 48 < nb_part; b += 64) {
-                        a0 += pp[(long long)b * npairs]; a1 += pp[(long long)(b + 16) * npairs];
-                        a2 += pp[(long long)(b + 32) * npairs]; a3 += pp[(long long)(b + 48) * npairs];
-                    }
-                    for (; b < nb_part; b += 16) a0 += pp[(long long)b * npairs];
-                }
-                scratch[t] = (a0 + a1) + (a2 + a3);
+            // all (d+1)(d+2)/2 pair sums in one round of loads: thread (slice, pair) adds the blocks of its slice, eight
+            // loads in flight, slices combined in a fixed tree (final_sum); npairs <= PT for d <= 43, else 64-wide chunks
+            if (npairs <= PT) {
+                const double v = final_sum(partials, nb_part, npairs, scratch);
+                if (t < npairs) tot[t] = v;
                 __syncthreads();
-                if (t < m) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc += scratch[q * 64 + t];
-                    tot[p0 + t] = acc;
+            } else {
+                for (int p0 = 0; p0 < npairs; p0 += 64) {
+                    const int m = (npairs - p0) < 64 ? (npairs - p0) : 64;
+                    const double v = final_sum(partials + p0, nb_part, m, scratch, npairs);
+                    if (t < m) tot[p0 + t] = v;
+                    __syncthreads();
                 }
-                __syncthreads();
             }
         } else {
             for (int p = t; p < npairs; p += PT) tot[p] = partials[p];

@@ -201,7 +201,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             h->run_adaptive = predict;
-            k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec, predict ? h->d_tot_acc : nullptr);
+            k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec, predict ? h->d_tot_acc : nullptr);
         }
         int flags[2] = {0, 0};
         for (int p0 = 0;;) {
@@ -280,7 +280,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     // fold the last acceptance rate, close the run
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec);
+        k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec);
         if (pull_state(h)) return SMCMI_ERR_HIP;
         h->last_n_stages = h->h_st.stage;
     }

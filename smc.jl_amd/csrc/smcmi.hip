@@ -144,6 +144,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         dmalloc(&h->rec.resampled, ms))
         return SMCMI_ERR_HIP;
     h->nb_e = (int)std::min<long long>(1024, std::max<long long>(1, (n + 511) / 512));
+    if (getenv("SMCMI_NB_E")) h->nb_e = std::max(1, std::min(1024, atoi(getenv("SMCMI_NB_E"))));   // development only
     h->nb_m = (int)std::min<long long>(256, std::max<long long>(1, (n + MT - 1) / MT));
     h->nb_mr = (int)std::min<long long>(512, std::max<long long>(std::min<long long>(64, (n + TB - 1) / TB), n / 1024));
     if (getenv("SMCMI_NOOP_GRID")) h->noop_grid = std::max(1, atoi(getenv("SMCMI_NOOP_GRID")));   // development only
@@ -402,7 +403,7 @@ extern "C" int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_p
     s.resampled_last = *resampled_last; s.ess_prev = ess_prev;
     if (s.rp.phi_rtol <= 0.0) s.rp.phi_rtol = 1e-10;
     if (upload_sched(h, sched, n_phi) || push_state(h)) return SMCMI_ERR_HIP;
-    k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, 0, h->rec);
+    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, 0, h->rec);
     // enough passes to walk the whole schedule in the worst case plus the bracketing passes
     const int passes = (n_phi + KC - 2) / (KC - 1) + 28;
     enqueue_solver(h, passes);
@@ -728,7 +729,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     h->run_adaptive = adaptive;
     if (p0 == 0)
-        k_stage_begin<<<1, TB, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec, (adaptive && !no_pred) ? h->d_esum_part : nullptr);
+        k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec, (adaptive && !no_pred) ? h->d_esum_part : nullptr, h->d_prof ? h->d_prof + 9 : nullptr);
     if (adaptive) enqueue_solver(h, P, p0);
     k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
     k_post_correct<<<h->nb_e, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, P == 0 ? 0 : (P & 1), h->cl, h->d_cum);
@@ -790,6 +791,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    if (getenv("SMCMI_PROF_MUT") && !h->d_prof) { if (dmalloc(&h->d_prof, 32)) return SMCMI_ERR_HIP; }
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
@@ -848,13 +850,18 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                     s.phi_n - s.phi_prev, s.pred_delta, (s.pred_delta - (s.phi_n - s.phi_prev)) / (s.phi_n - s.phi_prev),
                     s.solver_passes - last_passes, s.ess, s.do_resample);
             last_passes = s.solver_passes;
+            if (h->d_prof) {
+                long long pr[16];
+                hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[smcmi]    begin phase ticks: %lld %lld %lld %lld %lld\n", pr[10] - pr[9], pr[11] - pr[10], pr[12] - pr[11], pr[14] - pr[12], 0ll);
+            }
             for (int q = 0; q < 2; ++q)
                 fprintf(stderr, "[smcmi]    sol[%d] mode %d nv %d lo-phi %.3e hi-phi %.3e glo %.3e ghi %.3e\n", q, s.sol[q].mode, s.sol[q].n_valid,
                         s.sol[q].lo - s.phi_n, s.sol[q].hi - s.phi_n, s.sol[q].glo, s.sol[q].ghi);
         }
     }
     // fold the last mutation's acceptance rate and close the run
-    k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
+    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     const auto t1 = std::chrono::steady_clock::now();
     if (gexec) { hipGraphExecDestroy(gexec); hipGraphDestroy(graph); }
@@ -1061,7 +1068,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
         case 7: k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->npairs, h->d_totals, 1); break;
         case 8: k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->cfg.seed, 1, 1, 0, h->d_prof); break;
         case 9: launch_mutate(h, 1, 0, 1.0); break;
-        case 10: k_stage_begin<<<1, TB, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, use_reg_mutate(h) ? h->nb_reg : h->nb_mut, h->rec); break;
+        case 10: k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, use_reg_mutate(h) ? h->nb_reg : h->nb_mut, h->rec); break;
         default: k_empty<<<1, 64, 0, h->stream>>>(h->d_st); break;
         }
         if (which == 10 || which == 3) { /* keep the stage counter / weights bounded */ }
