@@ -43,8 +43,8 @@ def main():
     ap.add_argument("--mode", default="direct", choices=["direct", "graph"], help="stage launch mode")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-history", action="store_true")
-    ap.add_argument("--workload", default="gauss10", choices=["gauss10", "capm"],
-                    help="gauss10 = BASELINE config 2 (the bench line); capm = config 4 (examples/capm_model, 3 MH steps, fixed schedule)")
+    ap.add_argument("--workload", default="gauss10", choices=["gauss10", "capm", "kalman"],
+                    help="gauss10 = BASELINE config 2 (the bench line); capm = config 4 (examples/capm_model, 3 MH steps, fixed schedule); kalman = config 5 (13-parameter state-space model, Kalman-filter likelihood, old + new data)")
     ap.add_argument("--solver-passes", type=int, default=0)
     ap.add_argument("--sync-every", type=int, default=0)
     args = ap.parse_args()
@@ -75,6 +75,12 @@ def main():
                       alpha=1.0, c=0.5, target=0.25, threshold_ratio=0.5)
         if args.nparts == N_PER_GPU:
             args.nparts = 200_000
+    elif args.workload == "kalman":
+        spec, D = models.kalman_spec(T=80, old_T=40), 13
+        RUN_KW = dict(use_fixed_schedule=False, tempering_target=0.95, n_phi=100, lam=2.1, resampling_method="systematic", n_blocks=1,
+                      n_mh_steps=1, alpha=0.9, c=0.5, target=0.25, threshold_ratio=0.5)
+        if args.nparts == N_PER_GPU:
+            args.nparts = 50_000
     else:
         spec = models.gauss_spec(D)
     seed = 1
@@ -144,8 +150,10 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("gauss%d_isotropic_adaptive_phi_n%dk_per_gpu" % (D, n_local // 1000)) if args.workload == "gauss10"
-                   else "capm_literal_fixed_schedule_3mh_n%dk_per_gpu" % (n_local // 1000),
-                   "n_parts_total": n_total, "n_para": D, "tempering_target": 0.97, "n_phi": 300, "lambda": 2.1,
+                   else ("capm_literal_fixed_schedule_3mh_n%dk_per_gpu" % (n_local // 1000) if args.workload == "capm"
+                         else "lgss_kalman13_old40_new80_adaptive_phi_n%dk_per_gpu" % (n_local // 1000)),
+                   "n_parts_total": n_total, "n_para": D, "tempering_target": RUN_KW.get("tempering_target", 0.97),
+                   "n_phi": RUN_KW.get("n_phi", 300), "lambda": 2.1,
                    "resampling": "systematic", "n_blocks": 1, "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
@@ -171,7 +179,7 @@ def main():
                 traffic = k[0]["bytes_per_particle"] * n_total
         except OSError:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "k_mutate_reg<%d,true>" % D, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_mutate_reg<%d,true>" % D) if D <= 10 else "k_mutate<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl}
         # The kernel is FP64-VALU bound, not HBM bound: express it against the VALU issue rate as well.

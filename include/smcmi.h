@@ -38,7 +38,7 @@ enum { SMCMI_PRIOR_NORMAL = 0, SMCMI_PRIOR_UNIFORM = 1, SMCMI_PRIOR_GAMMA = 2, S
        SMCMI_PRIOR_INVGAMMA = 4, SMCMI_PRIOR_ROOTINVGAMMA = 5 };
 /* device likelihood families standing in for the user callback `loglikelihood(parameters, data)` (src/mutation.jl:96) */
 enum { SMCMI_LIK_NONE = -1, SMCMI_LIK_GAUSS_ISO = 0, SMCMI_LIK_LINREG = 1, SMCMI_LIK_LINMODEL3 = 2,
-       SMCMI_LIK_CAPM_LITERAL = 3, SMCMI_LIK_HOST_CALLBACK = 100 };
+       SMCMI_LIK_CAPM_LITERAL = 3, SMCMI_LIK_LGSS_KALMAN = 4, SMCMI_LIK_HOST_CALLBACK = 100 };
 /* src/resample.jl:23 `method`; :polyalgo is served by the multinomial kernel (same distribution) */
 enum { SMCMI_RESAMPLE_SYSTEMATIC = 0, SMCMI_RESAMPLE_MULTINOMIAL = 1 };
 enum { SMCMI_WHICH_NEW = 0, SMCMI_WHICH_OLD = 1 };

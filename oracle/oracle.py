@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 PRIOR = {"normal": 0, "uniform": 1, "gamma": 2, "beta": 3, "invgamma": 4, "rootinvgamma": 5}
-LIK = {"gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "none": -1}
+LIK = {"gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "lgss_kalman": 4, "none": -1}
 RESAMPLE = {"systematic": 0, "multinomial": 1, "polyalgo": 1}
 
 _dp = C.POINTER(C.c_double)

@@ -382,6 +382,97 @@ double orc_logprior(const orc_model *m, const double *theta) {
     return s;
 }
 
+/* Linear-Gaussian state-space likelihood by the Kalman filter - the same statement order as the device code (csrc/model.hpp). */
+static double orc_kalman_lgss(const orc_lik *l, const double *th) {
+#define TH(k) th[k]
+#define AUX l->aux
+#define PAR0 l->par[0]
+#define YDAT l->data
+#define NT l->cols
+#define NEGINF (-INFINITY)
+    /* LGSS_KALMAN (build-defined, no reference source).  n_s = 8 states, n_y = 3 observables, n_r = 3 shocks,
+       d = 13 parameters: th[0..7] = ρ (diagonal of the transition), th[8..10] = shock std σ, th[11] = measurement std σ_e,
+       th[12] = measurement mean μ.  x_t = Tm x_{t-1} + Rm ε_t, ε ~ N(0, diag σ²); y_t = μ + Z x_t + u_t, u ~ N(0, σ_e² I);
+       Tm = diag(ρ) + κ C.  aux = [C (8x8) | Rm (8x3) | Z (3x8)] row-major, par[0] = κ, data = y (3 x T, column-major).
+       x_0 = 0, P_0 = I.  Innovations form with a 3x3 Cholesky of F_t; returns -Inf when F_t is not positive definite. */
+    const double *Cm = AUX, *Rm = AUX + 64, *Zm = AUX + 88;
+    const double kappa = PAR0, mu = TH(12), se2 = TH(11) * TH(11);
+    double Tm[64], RQR[64], P[64], TP[64], x[8], xp[8], PZ[24], G[24];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+            Tm[i * 8 + j] = (i == j ? TH(i) : 0.0) + kappa * Cm[i * 8 + j];
+            double s = 0.0;
+            for (int m = 0; m < 3; ++m) s += Rm[i * 3 + m] * (TH(8 + m) * TH(8 + m)) * Rm[j * 3 + m];
+            RQR[i * 8 + j] = s;
+            P[i * 8 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int i = 0; i < 8; ++i) x[i] = 0.0;
+    double ll = 0.0;
+    for (long long t = 0; t < NT; ++t) {
+        for (int i = 0; i < 8; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < 8; ++j) s += Tm[i * 8 + j] * x[j];
+            xp[i] = s;
+        }
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 8; ++k) s += Tm[i * 8 + k] * P[k * 8 + j];
+                TP[i * 8 + j] = s;
+            }
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j) {
+                double s = RQR[i * 8 + j];
+                for (int k = 0; k < 8; ++k) s += TP[i * 8 + k] * Tm[j * 8 + k];
+                P[i * 8 + j] = s;                                   /* P_{t|t-1} */
+            }
+        double v[3], F[9];
+        for (int a = 0; a < 3; ++a) {
+            double s = 0.0;
+            for (int j = 0; j < 8; ++j) s += Zm[a * 8 + j] * xp[j];
+            v[a] = YDAT[a + 3 * t] - mu - s;
+        }
+        for (int i = 0; i < 8; ++i)
+            for (int a = 0; a < 3; ++a) {
+                double s = 0.0;
+                for (int j = 0; j < 8; ++j) s += P[i * 8 + j] * Zm[a * 8 + j];
+                PZ[i * 3 + a] = s;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double s = (a == b) ? se2 : 0.0;
+                for (int i = 0; i < 8; ++i) s += Zm[a * 8 + i] * PZ[i * 3 + b];
+                F[a * 3 + b] = s;
+            }
+        if (!(F[0] > 0.0)) return NEGINF;
+        const double l00 = sqrt(F[0]), l10 = F[3] / l00, l20 = F[6] / l00;
+        const double p11 = F[4] - l10 * l10;
+        if (!(p11 > 0.0)) return NEGINF;
+        const double l11 = sqrt(p11), l21 = (F[7] - l20 * l10) / l11;
+        const double p22 = F[8] - l20 * l20 - l21 * l21;
+        if (!(p22 > 0.0)) return NEGINF;
+        const double l22 = sqrt(p22);
+        const double w0 = v[0] / l00, w1 = (v[1] - l10 * w0) / l11, w2 = (v[2] - l20 * w0 - l21 * w1) / l22;
+        ll += -1.5 * log(2.0 * M_PI) - (log(l00) + log(l11) + log(l22)) - 0.5 * (w0 * w0 + w1 * w1 + w2 * w2);
+        const double u2 = w2 / l22, u1 = (w1 - l21 * u2) / l11, u0 = (w0 - l10 * u1 - l20 * u2) / l00;
+        for (int i = 0; i < 8; ++i) {
+            x[i] = xp[i] + (PZ[i * 3 + 0] * u0 + PZ[i * 3 + 1] * u1 + PZ[i * 3 + 2] * u2);
+            const double g0 = PZ[i * 3 + 0] / l00, g1 = (PZ[i * 3 + 1] - l10 * g0) / l11;
+            G[i * 3 + 0] = g0; G[i * 3 + 1] = g1; G[i * 3 + 2] = (PZ[i * 3 + 2] - l20 * g0 - l21 * g1) / l22;
+        }
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j)
+                P[i * 8 + j] -= G[i * 3 + 0] * G[j * 3 + 0] + G[i * 3 + 1] * G[j * 3 + 1] + G[i * 3 + 2] * G[j * 3 + 2];
+    }
+    return ll;
+#undef TH
+#undef AUX
+#undef PAR0
+#undef YDAT
+#undef NT
+#undef NEGINF
+}
+
 double orc_loglik(const orc_lik *l, const double *th, int32_t d) {
     switch (l->family) {
     case ORC_LIK_GAUSS_ISO: { /* ℓ = -(d/2) log(2π σ²) - Σ(θ_j - m_j)²/(2σ²) */
@@ -417,6 +508,7 @@ double orc_loglik(const orc_lik *l, const double *th, int32_t d) {
         }
         return lp;
     }
+    case ORC_LIK_LGSS_KALMAN: return (d == 13 && l->rows == 3 && l->aux_rows * l->aux_cols >= 112) ? orc_kalman_lgss(l, th) : NAN;
     case ORC_LIK_CAPM_LITERAL: { /* ref: examples/capm_model/estimate_capm.jl:52-70 AS WRITTEN (quirk Q12):
                                     β_i := p[3i-2] (= α_i) and the full 3xT quadratic form inside the t loop */
         int64_t T = l->cols;

@@ -31,7 +31,7 @@ extern "C" {
 enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_UNIFORM = 1, ORC_PRIOR_GAMMA = 2, ORC_PRIOR_BETA = 3,
        ORC_PRIOR_INVGAMMA = 4, ORC_PRIOR_ROOTINVGAMMA = 5 };
 /* built-in likelihood families */
-enum { ORC_LIK_GAUSS_ISO = 0, ORC_LIK_LINREG = 1, ORC_LIK_LINMODEL3 = 2, ORC_LIK_CAPM_LITERAL = 3,
+enum { ORC_LIK_GAUSS_ISO = 0, ORC_LIK_LINREG = 1, ORC_LIK_LINMODEL3 = 2, ORC_LIK_CAPM_LITERAL = 3, ORC_LIK_LGSS_KALMAN = 4,
        ORC_LIK_NONE = -1 };
 enum { ORC_RESAMPLE_SYSTEMATIC = 0, ORC_RESAMPLE_MULTINOMIAL = 1 };
 

@@ -251,7 +251,9 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
     memset(&l, 0, sizeof(LikDev));
     l.family = family;
     if (family == SMCMI_LIK_NONE || family == SMCMI_LIK_HOST_CALLBACK) { if (which == 0) h->have_lik = true; return push_model(h); }
-    if (family < SMCMI_LIK_GAUSS_ISO || family > SMCMI_LIK_CAPM_LITERAL) return set_err(SMCMI_ERR_ARG, "unknown likelihood family");
+    if (family < SMCMI_LIK_GAUSS_ISO || family > SMCMI_LIK_LGSS_KALMAN) return set_err(SMCMI_ERR_ARG, "unknown likelihood family");
+    if (family == SMCMI_LIK_LGSS_KALMAN && (n_par < 1 || rows != 3 || h->d != 13 || !aux || aux_rows * aux_cols < 112))
+        return set_err(SMCMI_ERR_ARG, "lgss_kalman needs kappa, data 3 x T, aux = [C 8x8 | R 8x3 | Z 3x8] (112 doubles), d = 13");
     l.n_par = (int)n_par;
     for (int k = 0; k < n_par; ++k) l.par[k] = par[k];
     const int d = h->d;

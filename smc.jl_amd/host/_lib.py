@@ -13,7 +13,7 @@ MAX_PARA = 64
 MAX_CAND = 16
 
 PRIOR = {"normal": 0, "uniform": 1, "gamma": 2, "beta": 3, "invgamma": 4, "rootinvgamma": 5}
-LIK = {"none": -1, "gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "host_callback": 100}
+LIK = {"none": -1, "gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "lgss_kalman": 4, "host_callback": 100}
 RESAMPLE = {"systematic": 0, "multinomial": 1, "polyalgo": 1}
 
 ERRORS = {-1: "ARG", -2: "HIP", -3: "NAN_ESS", -4: "POSDEF", -5: "CAPACITY", -6: "BRACKET", -7: "UNSUPPORTED", -8: "STATE"}

@@ -122,6 +122,20 @@ class LinModel3(DeviceLikelihood):
         return ("linmodel3", [], np.asarray(data, dtype=np.float64), self.X)
 
 
+class LGSSKalman(DeviceLikelihood):
+    """Linear-Gaussian state-space model, Kalman-filter likelihood per particle (csrc/model.hpp
+    kalman_lgss).  8 states, 3 observables, 3 shocks, 13 parameters (ρ[8], σ[3], σ_e, μ); transition diag(ρ) + κ C, shock
+    loadings R (8x3), measurement matrix Z (3x8); data 3 x T."""
+
+    def __init__(self, C, R, Z, kappa):
+        self.aux = np.concatenate([np.asarray(C, dtype=np.float64).reshape(64), np.asarray(R, dtype=np.float64).reshape(24),
+                                   np.asarray(Z, dtype=np.float64).reshape(24)]).reshape(1, -1)
+        self.kappa = float(kappa)
+
+    def spec(self, data):
+        return ("lgss_kalman", [self.kappa], np.asarray(data, dtype=np.float64), self.aux)
+
+
 class CapmLiteral(DeviceLikelihood):
     """examples/capm_model/estimate_capm.jl:52-70 as written; data 3 x T, market 1 x T."""
 

@@ -58,6 +58,69 @@ def capm_spec():
                 old_lik=None)
 
 
+def kalman_structure():
+    """Fixed structure of the config-5 state-space model (build-defined): coupling pattern C (8x8),
+    shock loadings R (8x3), measurement Z (3x8), packed row-major as the `aux` block of the lgss_kalman family."""
+    i, j = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    C = 0.5 * np.cos(1.0 + i + 2.0 * j) * (i != j)
+    R = np.zeros((8, 3))
+    for k in range(8):
+        R[k, k % 3] = 1.0 / (1.0 + k // 3)
+    a, k = np.meshgrid(np.arange(3), np.arange(8), indexing="ij")
+    Z = 1.0 / (1.0 + np.abs(k - 3 * a))
+    return C, R, Z
+
+
+KALMAN_TRUTH = np.array([0.9, 0.7, 0.5, 0.3, -0.2, 0.6, 0.8, 0.4, 0.5, 0.3, 0.2, 0.25, 1.0])
+KALMAN_KAPPA = 0.2
+
+
+def kalman_data(T=80, seed=123):
+    """Synthetic observations from the model at KALMAN_TRUTH (numpy legacy RandomState: stable across versions)."""
+    C, R, Z = kalman_structure()
+    th = KALMAN_TRUTH
+    Tm = np.diag(th[:8]) + KALMAN_KAPPA * C
+    rs = np.random.RandomState(seed)
+    x = np.zeros(8)
+    y = np.zeros((3, T))
+    for t in range(T):
+        x = Tm @ x + R @ (th[8:11] * rs.standard_normal(3))
+        y[:, t] = th[12] + Z @ x + th[11] * rs.standard_normal(3)
+    return y
+
+
+def kalman_loglik_numpy(th, y, kappa=KALMAN_KAPPA):
+    """Textbook Kalman-filter log-likelihood with numpy.linalg (independent of the oracle's statement order)."""
+    C, R, Z = kalman_structure()
+    Tm = np.diag(th[:8]) + kappa * C
+    Q = R @ np.diag(th[8:11] ** 2) @ R.T
+    E = th[11] ** 2 * np.eye(3)
+    x, P, ll = np.zeros(8), np.eye(8), 0.0
+    for t in range(y.shape[1]):
+        x = Tm @ x
+        P = Tm @ P @ Tm.T + Q
+        v = y[:, t] - th[12] - Z @ x
+        F = Z @ P @ Z.T + E
+        Fi = np.linalg.inv(F)
+        ll += -1.5 * np.log(2 * np.pi) - 0.5 * np.log(np.linalg.det(F)) - 0.5 * v @ Fi @ v
+        K = P @ Z.T @ Fi
+        x = x + K @ v
+        P = P - K @ Z @ P
+    return ll
+
+
+def kalman_spec(T=80, old_T=None):
+    """Config 5: 13 parameters = 8 AR coefficients, 3 shock std, measurement std, measurement mean."""
+    y = kalman_data(80)
+    C, R, Z = kalman_structure()
+    aux = np.concatenate([C.ravel(), R.ravel(), Z.ravel()]).reshape(1, -1)
+    pri = [("uniform", -0.95, 0.95)] * 8 + [("uniform", 0.0, 2.0)] * 4 + [("normal", 0.0, 5.0)]
+    bnd = [(-0.95, 0.95)] * 8 + [(1e-3, 2.0)] * 4 + [(-1e5, 1e5)]
+    old = None if old_T is None else ("lgss_kalman", [KALMAN_KAPPA], np.ascontiguousarray(y[:, :old_T]), aux)
+    return dict(priors=pri, bounds=bnd, fixed=[0] * 13, lik=("lgss_kalman", [KALMAN_KAPPA], np.ascontiguousarray(y[:, :T]), aux),
+                old_lik=old)
+
+
 def oracle_model(spec):
     from oracle import oracle as orc
 

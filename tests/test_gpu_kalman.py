@@ -1,0 +1,108 @@
+"""Config 5: linear-Gaussian state-space model with a per-particle Kalman-filter likelihood on the device,
+13 parameters, generalized tempering from old (40 periods) to new (80 periods) data.  No reference source exists for this
+likelihood (parity unpinned): the device filter is checked against the oracle's, the oracle's against numpy.linalg
+(tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+
+from tests import models
+from tests.test_gpu_parity import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _pars(S):
+    pars = [S.parameter("rho%d" % k, 0.0, (-0.95, 0.95), prior=S.Uniform(-0.95, 0.95)) for k in range(8)]
+    pars += [S.parameter("sig%d" % k, 0.5, (1e-3, 2.0), prior=S.Uniform(0.0, 2.0)) for k in range(4)]
+    pars += [S.parameter("mu", 0.0, (-1e5, 1e5), prior=S.Normal(0.0, 5.0))]
+    return pars
+
+
+def test_kalman_device_loglik_vs_oracle():
+    from oracle import oracle as orc
+
+    sp = models.kalman_spec()
+    eng = make_engine(sp, 2048, seed=4)
+    eng.init_from_prior()
+    P = eng.download_cloud()
+    m = models.oracle_model(sp)
+    ll = np.array([orc.loglik(m.lik, P[i, :13]) for i in range(256)])
+    np.testing.assert_allclose(P[:256, 13], ll, rtol=1e-11, atol=1e-9)
+    Q = orc.initial_draw(m, 2048, seed=4)
+    np.testing.assert_allclose(P[:, :13], Q[:, :13], rtol=1e-12, atol=1e-14)      # same Philox prior draws
+    np.testing.assert_allclose(P[:, 13], Q[:, 13], rtol=1e-10, atol=1e-8)
+    eng.close()
+
+
+def test_kalman_fixed_schedule_run_vs_oracle():
+    from oracle import oracle as orc
+
+    sp = models.kalman_spec()
+    m = models.oracle_model(sp)
+    n = 2000
+    eng = make_engine(sp, n, seed=9, max_stages=64)
+    eng.init_from_prior()
+    r = eng.run(n_phi=50, use_fixed_schedule=True, n_blocks=2, n_mh_steps=1, alpha=0.9)
+    rec = eng.stage_records(r["n_stages"])
+    ro = orc.smc_run(m, orc.initial_draw(m, n, seed=9), n_phi=50, n_blocks=2, n_mh_steps=1, alpha=0.9, seed=9, n_threads=8)
+    assert r["n_stages"] == ro["n_stages"] == 50
+    np.testing.assert_allclose(rec["ess"][:10], ro["ess"][:10], rtol=1e-6)
+    np.testing.assert_allclose(rec["ess"], ro["ess"], rtol=0.05)
+    assert r["logmdd"] == pytest.approx(ro["logmdd"], abs=0.05)
+    assert r["resamples"] == ro["resamples"]
+    eng.close()
+
+
+def test_config5_generalized_tempering_old_to_new_data():
+    """First estimation on 40 periods, then a tempered update to 80 periods starting from the old cloud (pw = 0, same
+    n_parts: smc_main.jl:249-260), adaptive schedule; posterior means move towards the data-generating parameters."""
+    import smc_jl_amd as S
+    from oracle import oracle as orc
+
+    y = models.kalman_data(80)
+    C, R, Z = models.kalman_structure()
+    lik = S.LGSSKalman(C, R, Z, models.KALMAN_KAPPA)
+    old = np.ascontiguousarray(y[:, :40])
+    kw = dict(n_parts=4000, n_phi=60, n_blocks=3, n_mh_steps=1, alpha=0.9, verbose="none", seed=17)
+    c_old, _, _ = S.smc(lik, _pars(S), old, use_fixed_schedule=True, **kw)
+    c_new, w, W = S.smc(lik, _pars(S), y, old_data=old, old_cloud=c_old, use_fixed_schedule=False, tempering_target=0.9, **kw)
+    assert c_new.tempering_schedule[-1] == 1.0 and c_new.ESS[0] == c_old.ESS[-1]
+    assert np.all(np.isfinite(c_new.particles))
+    # oracle on the same old cloud
+    sp = models.kalman_spec(T=80, old_T=40)
+    m = models.oracle_model(sp)
+    P0, ess0 = orc.tempered_update_cloud(m, c_old.particles, c_old.ESS[-1], 4000, seed=17)
+    ro = orc.smc_run(m, P0, n_phi=60, n_blocks=3, n_mh_steps=1, alpha=0.9, use_fixed_schedule=False, tempering_target=0.9, seed=17,
+                     initial_ess=ess0, n_threads=8)
+    assert c_new.stage_index == ro["n_stages"]
+    np.testing.assert_allclose(c_new.tempering_schedule, ro["schedule"], rtol=1e-4)
+    assert c_new.logmdd == pytest.approx(ro["logmdd"], abs=0.1)
+    mu = S.weighted_mean(c_new)
+    assert abs(mu[12] - 1.0) < 0.5 and abs(mu[0] - 0.9) < 0.3          # measurement mean and the most persistent root
+
+
+def test_config5_sharded_group_matches_single():
+    from smc_jl_amd import Engine, run_group
+
+    sp = models.kalman_spec(T=80, old_T=40)
+    n = 16384
+    e1 = make_engine(sp, n, seed=5, max_stages=400)
+    e1.init_from_prior()
+    P0 = e1.download_cloud()
+    r1 = e1.run(n_phi=40, use_fixed_schedule=False, tempering_target=0.9, n_blocks=2)
+    P1 = e1.download_cloud()
+    e1.close()
+    shards = []
+    for k in range(2):
+        e = Engine(n, 13, seed=5, n_local=n // 2, gid0=k * (n // 2), max_stages=400)
+        e.set_model(sp)
+        e.upload_cloud(P0[k * (n // 2):(k + 1) * (n // 2)])
+        shards.append(e)
+    r2 = run_group(shards, n_phi=40, use_fixed_schedule=False, tempering_target=0.9, n_blocks=2)
+    P2 = np.vstack([e.download_cloud() for e in shards])
+    for e in shards:
+        e.close()
+    assert r1["n_stages"] == r2["n_stages"] and r1["resamples"] == r2["resamples"]
+    assert r2["logmdd"] == pytest.approx(r1["logmdd"], abs=1e-8)
+    same = np.all(np.abs(P1 - P2) <= 1e-8 * (1 + np.abs(P1)), axis=1)
+    assert same.mean() > 0.99

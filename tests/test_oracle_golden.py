@@ -245,3 +245,18 @@ def test_oracle_tempered_update_cloud_branches():
     # run continues from it
     r2 = orc.smc_run(m, P, n_phi=30, seed=2, initial_ess=800.0)
     assert r2["ess"][0] == 800.0 and np.isfinite(r2["logmdd"])
+
+
+def test_oracle_kalman_loglik_vs_numpy():
+    """Config 5's likelihood has no reference source (parity unpinned): the oracle's filter is checked against an
+    independent numpy.linalg statement of the Kalman recursions at random parameter values."""
+    sp = models.kalman_spec()
+    m = models.oracle_model(sp)
+    y = sp["lik"][2]
+    rs = np.random.RandomState(0)
+    for _ in range(20):
+        th = np.concatenate([rs.uniform(-0.9, 0.9, 8), rs.uniform(0.05, 1.5, 4), rs.normal(0, 2, 1)])
+        ll = orc.loglik(m.lik, th)
+        assert ll == pytest.approx(models.kalman_loglik_numpy(th, y), rel=1e-9, abs=1e-8)
+    # the truth explains the data better than a perturbed parameter vector
+    assert orc.loglik(m.lik, models.KALMAN_TRUTH) > orc.loglik(m.lik, models.KALMAN_TRUTH * 0.5)
