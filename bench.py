@@ -191,13 +191,25 @@ def main():
                 isa = json.load(f).get("k_mutate_reg<%d,true>" % D)
             if isa and RUN_KW.get("n_mh_steps", 1) == 1 and mean_ms > 0:
                 waves = -(-n_total // 64)
-                peak = 256 * 4 * 2.4e9 / 4            # wave-instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
-                ach = waves * isa["valu_total"] / (mean_ms * 1e-3)
-                out["roofline"]["valu_issue"] = {"valu_instr_per_wave": isa["valu_total"], "waves": waves, "achieved": ach,
-                                                 "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
+                # SIMD-32: a wave64 VALU instruction issues over 2 cycles, FP64 over 4 (half rate), 32x32-bit multiplies over 8
+                cyc = 4 * isa["valu_f64"] + 2 * isa["valu_other"] + 8 * isa.get("valu_int_mul", 0)
+                peak = 256 * 4 * 2.4e9                # SIMD issue cycles / s
+                ach = waves * cyc / (mean_ms * 1e-3)
+                out["roofline"]["valu_issue"] = {"valu_instr_per_wave": isa["valu_total"], "issue_cycles_per_wave": cyc, "waves": waves,
+                                                 "achieved": ach, "peak": peak, "unit": "SIMD issue cycles/s", "frac": ach / peak,
                                                  "waves_per_simd": waves / 1024.0}
         except OSError:
             pass
+        if args.workload == "kalman" and mean_ms > 0:
+            # config 5 is compute bound: ~3300 FP64 flops per filter step (FMA = 2; csrc/model.hpp kalman_lgss), steps = new + old
+            # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s
+            # (vector = matrix rate for FP64 on gfx950)
+            steps = spec["lik"][2].shape[1] + (spec["old_lik"][2].shape[1] if spec["old_lik"] else 0)
+            flops = 3300.0 * steps * RUN_KW["n_mh_steps"] * n_total
+            tf = flops / (mean_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_mutate<0> / kalman_lgss (FP64 vector FMA)", "achieved": tf, "peak": 78.6,
+                               "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None, "flops_per_launch": flops,
+                               "mean_launch_us": 1e3 * mean_ms, "launches": nl}
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages
         stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
         out["stage_gbs"] = stage_bytes * args.steps / dt / 1e9

@@ -128,96 +128,119 @@ inline double lik_const_host(int family, const double *par, int d) {
     return 0.0;
 }
 
-// Linear-Gaussian state-space likelihood by the Kalman filter (config 5).  Out of line: ~380 doubles of per-thread state live in
-// scratch; the statement order is the oracle's (oracle/smc_oracle.c orc_kalman_lgss).
-__device__ __attribute__((noinline)) static double kalman_lgss(const double *thv, const double *ydat, long long nt, const double *aux, double par0) {
-#define TH(k) thv[k]
-#define AUX aux
-#define PAR0 par0
-#define YDAT ydat
-#define NT nt
-#define NEGINF SMCMI_NEG_INF
-    /* LGSS_KALMAN (build-defined, no reference source).  n_s = 8 states, n_y = 3 observables, n_r = 3 shocks,
-       d = 13 parameters: th[0..7] = ρ (diagonal of the transition), th[8..10] = shock std σ, th[11] = measurement std σ_e,
-       th[12] = measurement mean μ.  x_t = Tm x_{t-1} + Rm ε_t, ε ~ N(0, diag σ²); y_t = μ + Z x_t + u_t, u ~ N(0, σ_e² I);
-       Tm = diag(ρ) + κ C.  aux = [C (8x8) | Rm (8x3) | Z (3x8)] row-major, par[0] = κ, data = y (3 x T, column-major).
-       x_0 = 0, P_0 = I.  Innovations form with a 3x3 Cholesky of F_t; returns -Inf when F_t is not positive definite. */
-    const double *Cm = AUX, *Rm = AUX + 64, *Zm = AUX + 88;
-    const double kappa = PAR0, mu = TH(12), se2 = TH(11) * TH(11);
-    double Tm[64], RQR[64], P[64], TP[64], x[8], xp[8], PZ[24], G[24];
-    for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 8; ++j) {
-            Tm[i * 8 + j] = (i == j ? TH(i) : 0.0) + kappa * Cm[i * 8 + j];
-            double s = 0.0;
-            for (int m = 0; m < 3; ++m) s += Rm[i * 3 + m] * (TH(8 + m) * TH(8 + m)) * Rm[j * 3 + m];
-            RQR[i * 8 + j] = s;
-            P[i * 8 + j] = (i == j) ? 1.0 : 0.0;
-        }
-    for (int i = 0; i < 8; ++i) x[i] = 0.0;
+// Linear-Gaussian state-space likelihood by the Kalman filter (build-defined model, no reference source).
+// n_s = 8 states, n_y = 3 observables, n_r = 3 shocks, d = 13 parameters: th[0..7] = ρ, th[8..10] = shock std σ, th[11] =
+// measurement std σ_e, th[12] = measurement mean μ.  x_t = Tm x_{t-1} + Rm ε_t, ε ~ N(0, diag σ²); y_t = μ + Z x_t + u_t,
+// u ~ N(0, σ_e² I); Tm = diag(ρ) + κ C.  aux = [C (8x8) | Rm (8x3) | Z (3x8)] row-major, par0 = κ, y = 3 x T column-major.
+// x_0 = 0, P_0 = I.  Innovations form with a 3x3 Cholesky of F_t; -Inf when F_t is not positive definite.
+//
+// One thread = one particle; one time step is fully unrolled so that every index is a compile-time constant and the whole
+// filter state lives in registers: the covariance as a packed symmetric upper triangle (36 doubles, two copies), one row of
+// Tm P at a time, P Z' (24) and its triangular solve (24).  C, Rm, Z are uniform across the wavefront (scalar loads); Tm and
+// R Q R' are never stored: Tm[i][k] = κ C[i][k] (+ ρ_i on the diagonal) and the 36 entries of R Q R' are rebuilt from the three
+// σ² each step (cheaper than 72 more registers).  Out of line so the callers' other likelihood families stay small.
+__device__ constexpr int ksym(int i, int j) { return i <= j ? i * 8 - i * (i - 1) / 2 + (j - i) : j * 8 - j * (j - 1) / 2 + (i - j); }
+
+__device__ __attribute__((noinline)) static double kalman_lgss(const double *thv, const double *ydat, long long nt, const double *aux, double kappa) {
+#pragma clang fp contract(fast)
+    const double *Cm = aux, *Rm = aux + 64, *Zm = aux + 88;
+    double rho[8], s2[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rho[i] = thv[i];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) s2[m] = thv[8 + m] * thv[8 + m];
+    const double se2 = thv[11] * thv[11], mu = thv[12];
+    double P[36], Pn[36], x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = 0.0;
+#pragma unroll
+        for (int j = i; j < 8; ++j) P[ksym(i, j)] = (i == j) ? 1.0 : 0.0;
+    }
     double ll = 0.0;
-    for (long long t = 0; t < NT; ++t) {
+#pragma nounroll
+    for (long long t = 0; t < nt; ++t) {
+        double xp[8];
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
-            double s = 0.0;
-            for (int j = 0; j < 8; ++j) s += Tm[i * 8 + j] * x[j];
+            double s = rho[i] * x[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (kappa * Cm[i * 8 + j]) * x[j];
             xp[i] = s;
         }
-        _Pragma("nounroll") for (int i = 0; i < 8; ++i)
-            _Pragma("nounroll") for (int j = 0; j < 8; ++j) {
-                double s = 0.0;
-                for (int k = 0; k < 8; ++k) s += Tm[i * 8 + k] * P[k * 8 + j];
-                TP[i * 8 + j] = s;
+        // P_{t|t-1} = Tm P Tm' + R Q R', upper triangle, one row of Tm P at a time
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double tp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                double s = rho[i] * P[ksym(i, j)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += (kappa * Cm[i * 8 + k]) * P[ksym(k, j)];
+                tp[j] = s;
             }
-        _Pragma("nounroll") for (int i = 0; i < 8; ++i)
-            _Pragma("nounroll") for (int j = 0; j < 8; ++j) {
-                double s = RQR[i * 8 + j];
-                for (int k = 0; k < 8; ++k) s += TP[i * 8 + k] * Tm[j * 8 + k];
-                P[i * 8 + j] = s;                                   /* P_{t|t-1} */
+#pragma unroll
+            for (int j = i; j < 8; ++j) {
+                double s = (Rm[i * 3 + 0] * Rm[j * 3 + 0]) * s2[0] + (Rm[i * 3 + 1] * Rm[j * 3 + 1]) * s2[1] + (Rm[i * 3 + 2] * Rm[j * 3 + 2]) * s2[2];
+                s += tp[j] * rho[j];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += tp[k] * (kappa * Cm[j * 8 + k]);
+                Pn[ksym(i, j)] = s;
             }
-        double v[3], F[9];
+        }
+        double v[3], PZ[24], F[6];
+#pragma unroll
         for (int a = 0; a < 3; ++a) {
             double s = 0.0;
+#pragma unroll
             for (int j = 0; j < 8; ++j) s += Zm[a * 8 + j] * xp[j];
-            v[a] = YDAT[a + 3 * t] - mu - s;
+            v[a] = ydat[a + 3 * t] - mu - s;
         }
+#pragma unroll
         for (int i = 0; i < 8; ++i)
+#pragma unroll
             for (int a = 0; a < 3; ++a) {
                 double s = 0.0;
-                for (int j = 0; j < 8; ++j) s += P[i * 8 + j] * Zm[a * 8 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += Pn[ksym(i, j)] * Zm[a * 8 + j];
                 PZ[i * 3 + a] = s;
             }
+        // F = Z P Z' + σ_e² I (lower triangle: F00 F10 F11 F20 F21 F22)
+#pragma unroll
         for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
                 double s = (a == b) ? se2 : 0.0;
+#pragma unroll
                 for (int i = 0; i < 8; ++i) s += Zm[a * 8 + i] * PZ[i * 3 + b];
-                F[a * 3 + b] = s;
+                F[a * (a + 1) / 2 + b] = s;
             }
-        if (!(F[0] > 0.0)) return NEGINF;
-        const double l00 = sqrt(F[0]), l10 = F[3] / l00, l20 = F[6] / l00;
-        const double p11 = F[4] - l10 * l10;
-        if (!(p11 > 0.0)) return NEGINF;
-        const double l11 = sqrt(p11), l21 = (F[7] - l20 * l10) / l11;
-        const double p22 = F[8] - l20 * l20 - l21 * l21;
-        if (!(p22 > 0.0)) return NEGINF;
+        if (!(F[0] > 0.0)) return SMCMI_NEG_INF;
+        const double l00 = sqrt(F[0]), l10 = F[1] / l00, l20 = F[3] / l00;
+        const double p11 = F[2] - l10 * l10;
+        if (!(p11 > 0.0)) return SMCMI_NEG_INF;
+        const double l11 = sqrt(p11), l21 = (F[4] - l20 * l10) / l11;
+        const double p22 = F[5] - l20 * l20 - l21 * l21;
+        if (!(p22 > 0.0)) return SMCMI_NEG_INF;
         const double l22 = sqrt(p22);
         const double w0 = v[0] / l00, w1 = (v[1] - l10 * w0) / l11, w2 = (v[2] - l20 * w0 - l21 * w1) / l22;
-        ll += -1.5 * log(2.0 * M_PI) - (log(l00) + log(l11) + log(l22)) - 0.5 * (w0 * w0 + w1 * w1 + w2 * w2);
+        ll += -1.5 * log(2.0 * M_PI) - log(l00 * l11 * l22) - 0.5 * (w0 * w0 + w1 * w1 + w2 * w2);
         const double u2 = w2 / l22, u1 = (w1 - l21 * u2) / l11, u0 = (w0 - l10 * u1 - l20 * u2) / l00;
+        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+        double G[24];
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             x[i] = xp[i] + (PZ[i * 3 + 0] * u0 + PZ[i * 3 + 1] * u1 + PZ[i * 3 + 2] * u2);
-            const double g0 = PZ[i * 3 + 0] / l00, g1 = (PZ[i * 3 + 1] - l10 * g0) / l11;
-            G[i * 3 + 0] = g0; G[i * 3 + 1] = g1; G[i * 3 + 2] = (PZ[i * 3 + 2] - l20 * g0 - l21 * g1) / l22;
+            const double g0 = PZ[i * 3 + 0] * i00, g1 = (PZ[i * 3 + 1] - l10 * g0) * i11;
+            G[i * 3 + 0] = g0; G[i * 3 + 1] = g1; G[i * 3 + 2] = (PZ[i * 3 + 2] - l20 * g0 - l21 * g1) * i22;
         }
+#pragma unroll
         for (int i = 0; i < 8; ++i)
-            for (int j = 0; j < 8; ++j)
-                P[i * 8 + j] -= G[i * 3 + 0] * G[j * 3 + 0] + G[i * 3 + 1] * G[j * 3 + 1] + G[i * 3 + 2] * G[j * 3 + 2];
+#pragma unroll
+            for (int j = i; j < 8; ++j)
+                P[ksym(i, j)] = Pn[ksym(i, j)] - (G[i * 3 + 0] * G[j * 3 + 0] + G[i * 3 + 1] * G[j * 3 + 1] + G[i * 3 + 2] * G[j * 3 + 2]);
     }
     return ll;
-#undef TH
-#undef AUX
-#undef PAR0
-#undef YDAT
-#undef NT
-#undef NEGINF
 }
 
 template <class L, class Th>

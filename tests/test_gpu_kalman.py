@@ -27,7 +27,7 @@ def test_kalman_device_loglik_vs_oracle():
     P = eng.download_cloud()
     m = models.oracle_model(sp)
     ll = np.array([orc.loglik(m.lik, P[i, :13]) for i in range(256)])
-    np.testing.assert_allclose(P[:256, 13], ll, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(P[:256, 13], ll, rtol=1e-10, atol=1e-8)
     Q = orc.initial_draw(m, 2048, seed=4)
     np.testing.assert_allclose(P[:, :13], Q[:, :13], rtol=1e-12, atol=1e-14)      # same Philox prior draws
     np.testing.assert_allclose(P[:, 13], Q[:, 13], rtol=1e-10, atol=1e-8)
