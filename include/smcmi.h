@@ -68,7 +68,7 @@ typedef struct {
     double tempering_target;               /* :140 */
     double tempered_update_prior_weight;   /* :156 */
     double log_prob_old_data;              /* :161 */
-    int32_t solver_passes;                 /* kernel passes enqueued for the adaptive-ϕ solver per stage (0 => default 2); a stage that needs more is resumed */
+    int32_t solver_passes;                 /* kernel passes enqueued for the adaptive-ϕ solver per stage (0 => default 1); a stage that needs more is resumed */
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
     int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
     double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */

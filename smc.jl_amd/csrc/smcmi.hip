@@ -358,8 +358,8 @@ static int upload_sched(smcmi_handle *h, const double *sched, int n_phi) {
     return 0;
 }
 
-static const int DEFAULT_SOLVER_PASSES = 2;   // with the energy-sum predictor 1-2 passes certify the root; a stage that needs more stalls and is resumed (smcmi_run)
-static const int FIRST_SOLVER_PASSES = 6;     // first adaptive stage: no prediction yet (1 schedule scan + bracketing passes)
+static const int DEFAULT_SOLVER_PASSES = 1;   // with the energy-sum predictor 1-2 passes certify the root; a stage that needs more stalls and is resumed (smcmi_run)
+static const int FIRST_SOLVER_PASSES = 6;     // first two adaptive stages: no / poor prediction yet (1 schedule scan + bracketing passes)
 static const int SHARDED_SOLVER_PASSES = 1;   // sharded driver: every pass costs a collective and the host syncs per stage anyway, so a stall is cheap
 
 // P solver passes; pass p consumes the partials of pass p-1 in its prologue.  The correction pass that follows is pass P.
@@ -817,11 +817,11 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     while (launched < max_iter && !done) {
         const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
-            if (gexec && launched > 0) HIP_TRY(hipGraphLaunch(gexec, h->stream));
+            if (gexec && launched > 1) HIP_TRY(hipGraphLaunch(gexec, h->stream));
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
-                enqueue_stage(h, adaptive, launched == 0 ? first_passes : solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha,
+                enqueue_stage(h, adaptive, launched < 2 ? first_passes : solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha,
                               acc_nb, e0, e1);
             }
             ++launched;
@@ -833,7 +833,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             // stage more passes (continuing the same search), and go on from the stage after it.
             if (pull_state(h)) return SMCMI_ERR_HIP;
             const int st_i = s.stage;
-            const int had = (st_i == stall_stage) ? stall_p : (st_i == 2 ? first_passes : solver_passes);
+            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : solver_passes);
             const int more = 8;
             const int zero = 0;
             HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
