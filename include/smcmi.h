@@ -85,7 +85,7 @@ typedef struct {
     int32_t n_mutate_launches;
     int64_t solver_passes;   /* particle passes spent in the adaptive-ϕ solver over the run */
     int32_t solver_stalls;   /* stages that ran out of enqueued solver passes and were resumed by the host */
-    int32_t reserved_;
+    int32_t select_stalls;   /* stages enqueued without selection kernels that had to resample after all (host resumed them) */
 } smcmi_result;
 
 typedef struct {             /* what one correction step reports (smc_main.jl:401-432) */

@@ -713,17 +713,48 @@ __device__ inline void scan_chunk(const double *w, long long n, int n_chunks, in
 // set (smcmi_run): then every block recomputes the decision from the same partial sums (no mutable state is read for it),
 // block 0 alone does the bookkeeping, and on resample stages each block scans its own chunk right here - the separate scan
 // launch (a ~4 µs no-op on 95 % of the stages) disappears.
+// Scalars of the post-correction bookkeeping, loaded by every thread up front (one memory round trip with the partial sums).
+struct PostIn {
+    int done, smode, i, jj, resamples;
+    double N, a, tg, c0, thr, phi_n, phi_prop, logz;
+};
+__device__ inline PostIn post_load(const DevState *st, int sol_slot) {
+    const Solver &S = st->sol[sol_slot];
+    PostIn p;
+    p.done = st->done; p.smode = S.mode; p.i = st->stage; p.jj = S.j; p.resamples = st->resamples;
+    p.N = (double)st->rp.n_parts; p.a = st->accept; p.tg = st->rp.target; p.c0 = st->c; p.thr = st->rp.threshold;
+    p.phi_n = S.phi_n; p.phi_prop = S.phi_prop; p.logz = st->logz;
+    return p;
+}
+// ESS, log-MDD increment, resample decision, step-size adaptation, records (src/smc_main.jl:427-455); one thread.
+// Returns the resample decision (-1: ESS is NaN, run aborted).
+__device__ inline int post_write(DevState *st, const Records &rec, const PostIn &p, double s1, double s2) {
+    const double ess = s1 * s1 / s2;
+    const bool bad = isnan(ess);
+    const int rs = (!bad && ess < p.thr) ? 1 : 0;
+    const double c1 = p.c0 * (0.95 + 0.10 * exp(16.0 * (p.a - p.tg)) / (1.0 + exp(16.0 * (p.a - p.tg))));
+    st->phi_n = p.phi_n; st->phi_prop = p.phi_prop; st->j = p.jj;
+    st->sumw = s1; st->sumw2 = s2; st->ess = ess; st->ess_prev = ess;
+    rec.phi[p.i - 1] = p.phi_n;
+    rec.ess[p.i - 1] = ess;
+    if (bad) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; return -1; }     // check_nan_ess, helpers.jl:270-305
+    st->logz = p.logz + log(s1 / p.N);
+    st->do_resample = rs;
+    rec.resampled[p.i - 1] = rs;
+    if (rs) { st->resamples = p.resamples + 1; st->resampled_last = 1; }
+    st->c = c1;
+    rec.c[p.i - 1] = c1;
+    return rs;
+}
+
 __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double *partials, int nb, double *chunk_off,
                                                      Records rec, int sol_slot, CloudPtrs cl = CloudPtrs{}, double *cum = nullptr) {
     __shared__ double scratch[TB];
     __shared__ double s_tot[2];
     __shared__ int s_rs;
-    const Solver &S = st->sol[sol_slot];
-    // every scalar the decision needs, loaded up front together with the partial sums (one memory round trip)
-    const int done = st->done, smode = S.mode;
-    const double N = (double)st->rp.n_parts, a = st->accept, tg = st->rp.target, c0 = st->c, thr = st->rp.threshold;
-    const double phi_n = S.phi_n, phi_prop = S.phi_prop, logz = st->logz;
-    const int i = st->stage, jj = S.j, resamples = st->resamples;
+    const PostIn pin = post_load(st, sol_slot);
+    const int done = pin.done, smode = pin.smode;
+    const double thr = pin.thr;
     const double v = final_sum(partials, nb, 2, scratch);
     if (done) return;
     if (smode != MODE_FINAL) {       // cannot happen unless a pass kernel flagged an error
@@ -738,25 +769,8 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
         s_rs = (!isnan(ess) && ess < thr) ? 1 : 0;
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double s1 = s_tot[0], s2 = s_tot[1];
-        const double ess = s1 * s1 / s2;
-        const bool bad = isnan(ess);
-        const int rs = (!bad && ess < thr) ? 1 : 0;
-        const double c1 = c0 * (0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))));
-        st->phi_n = phi_n; st->phi_prop = phi_prop; st->j = jj;
-        st->sumw = s1; st->sumw2 = s2; st->ess = ess; st->ess_prev = ess;
-        rec.phi[i - 1] = phi_n;
-        rec.ess[i - 1] = ess;
-        if (bad) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; }     // check_nan_ess, helpers.jl:270-305
-        else {
-            st->logz = logz + log(s1 / N);
-            st->do_resample = rs;
-            rec.resampled[i - 1] = rs;
-            if (rs) { st->resamples = resamples + 1; st->resampled_last = 1; }
-            st->c = c1;
-            rec.c[i - 1] = c1;
-            s_rs = rs;
-        }
+        const int rs = post_write(st, rec, pin, s_tot[0], s_tot[1]);
+        if (rs > 0) s_rs = 1;
     }
     __syncthreads();
     if (s_rs && (chunk_off || cum)) {
@@ -996,15 +1010,43 @@ __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, doub
 // same (a <= b) order) as k_moments.
 template <int D>
 __global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, double *partials, double *hist_W,
-                                                    long long hist_ld, int standalone) {
+                                                    long long hist_ld, int standalone, const double *fin_partials = nullptr,
+                                                    int nb_fin = 0, int sol_slot = 0, Records rec = Records{}) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2;
     constexpr int NCH = (NP + 63) / 64;                  // chunks of 64 accumulators for the block reduction
     __shared__ double red[(TB / 64) * 64];
-    if (!standalone && st->done) return;
-    const int resampled = standalone ? 0 : st->do_resample;
+    // fin_partials != nullptr: the stage was enqueued WITHOUT k_post_correct / k_resample_gather because the host expects no
+    // resampling (smcmi_run).  Every block re-derives the post-correction decision from the correction partials (same fixed-order
+    // sums as k_post_correct), block 0 does the bookkeeping; if the decision is to resample after all, nothing is written and the
+    // run stalls (done = 3) until the host enqueues the selection path for this stage.
+    double sumw_f = 0.0;
+    if (fin_partials) {
+        __shared__ double s_fin[2];
+        const PostIn pin = post_load(st, sol_slot);
+        const double v = final_sum(fin_partials, nb_fin, 2, red);
+        if (pin.done) return;
+        if (pin.smode != MODE_FINAL) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) { st->err = SMCMI_ERR_BRACKET; st->done = 1; }
+            return;
+        }
+        if (threadIdx.x < 2) s_fin[threadIdx.x] = v;
+        __syncthreads();
+        const double s1 = s_fin[0], s2 = s_fin[1];
+        const double ess = s1 * s1 / s2;
+        if (!isnan(ess) && ess < pin.thr) {              // selection needed: stall, the host resumes with the full path
+            if (threadIdx.x == 0 && blockIdx.x == 0) st->done = 3;
+            return;
+        }
+        if (threadIdx.x == 0 && blockIdx.x == 0) post_write(st, rec, pin, s1, s2);
+        if (isnan(ess)) return;
+        sumw_f = s1;
+        __syncthreads();
+    }
+    if (!standalone && !fin_partials && st->done) return;
+    const int resampled = (standalone || fin_partials) ? 0 : st->do_resample;
     const int src = resampled ? 1 : 0;       // a resampled cloud was gathered into buffer 1; it is copied back to buffer 0 here
     double *w = col(cl, 0, cl.R - 1);
-    const double N = (double)st->rp.n_parts, sumw = st->sumw;
+    const double N = (double)st->rp.n_parts, sumw = fin_partials ? sumw_f : st->sumw;
     const int stage_col = st->stage - 1;
     const bool hist = !standalone && st->rp.store_history && hist_W != nullptr;
     double sh[D];

@@ -531,25 +531,31 @@ extern "C" int smcmi_normalize_weights(smcmi_handle *h, int32_t zero_bad_loglh) 
 }
 
 // ---- moments launch: register-resident kernel for d <= 12, LDS-tiled kernel beyond
+// fused_slot >= 0: the kernel also takes the post-correction decision itself (no k_post_correct / k_resample_gather in front)
 template <int D>
-static void launch_moments_reg(smcmi_handle *h, double *hist_W, int standalone) {
-    k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone);
+static void launch_moments_reg(smcmi_handle *h, double *hist_W, int standalone, int fused_slot) {
+    if (fused_slot >= 0)
+        k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone, h->d_part_fin, h->nb_e,
+                                                        fused_slot, h->rec);
+    else
+        k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone);
 }
+static bool can_fuse_post(const smcmi_handle *h) { return h->d <= 12; }
 // returns the number of blocks that wrote partials
-static int launch_moments(smcmi_handle *h, double *hist_W, int standalone) {
+static int launch_moments(smcmi_handle *h, double *hist_W, int standalone, int fused_slot = -1) {
     switch (h->d) {
-    case 1: launch_moments_reg<1>(h, hist_W, standalone); break;
-    case 2: launch_moments_reg<2>(h, hist_W, standalone); break;
-    case 3: launch_moments_reg<3>(h, hist_W, standalone); break;
-    case 4: launch_moments_reg<4>(h, hist_W, standalone); break;
-    case 5: launch_moments_reg<5>(h, hist_W, standalone); break;
-    case 6: launch_moments_reg<6>(h, hist_W, standalone); break;
-    case 7: launch_moments_reg<7>(h, hist_W, standalone); break;
-    case 8: launch_moments_reg<8>(h, hist_W, standalone); break;
-    case 9: launch_moments_reg<9>(h, hist_W, standalone); break;
-    case 10: launch_moments_reg<10>(h, hist_W, standalone); break;
-    case 11: launch_moments_reg<11>(h, hist_W, standalone); break;
-    case 12: launch_moments_reg<12>(h, hist_W, standalone); break;
+    case 1: launch_moments_reg<1>(h, hist_W, standalone, fused_slot); break;
+    case 2: launch_moments_reg<2>(h, hist_W, standalone, fused_slot); break;
+    case 3: launch_moments_reg<3>(h, hist_W, standalone, fused_slot); break;
+    case 4: launch_moments_reg<4>(h, hist_W, standalone, fused_slot); break;
+    case 5: launch_moments_reg<5>(h, hist_W, standalone, fused_slot); break;
+    case 6: launch_moments_reg<6>(h, hist_W, standalone, fused_slot); break;
+    case 7: launch_moments_reg<7>(h, hist_W, standalone, fused_slot); break;
+    case 8: launch_moments_reg<8>(h, hist_W, standalone, fused_slot); break;
+    case 9: launch_moments_reg<9>(h, hist_W, standalone, fused_slot); break;
+    case 10: launch_moments_reg<10>(h, hist_W, standalone, fused_slot); break;
+    case 11: launch_moments_reg<11>(h, hist_W, standalone, fused_slot); break;
+    case 12: launch_moments_reg<12>(h, hist_W, standalone, fused_slot); break;
     default:
         k_moments<<<h->nb_m, TB, h->mom_lds, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone);
         return h->nb_m;
@@ -723,21 +729,31 @@ extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const dou
 // One stage = a fixed kernel sequence (no host decision inside): see the header of kernels.hpp.
 // p0 > 0 resumes a stage whose solver ran out of passes after p0 of them (st->done == 2 stall, see solver_prologue): the
 // search continues with passes p0 .. p0 + solver_passes - 1 exactly as if the original list had been that much longer.
+// no_select: the host expects no resampling in this stage: k_post_correct and k_resample_gather are not launched, the moments
+// kernel takes the decision itself and stalls the run (done = 3) if selection is needed after all.
+// tail_only: resume such a stage from k_post_correct on (the correction is already done).
 static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int n_blocks, double alpha, int acc_nb,
-                          hipEvent_t ev0, hipEvent_t ev1, int p0 = 0) {
+                          hipEvent_t ev0, hipEvent_t ev1, int p0 = 0, bool no_select = false, bool tail_only = false) {
     const long long n = h->n;
     hipStream_t s = h->stream;
     const int P = adaptive ? p0 + solver_passes : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     h->run_adaptive = adaptive;
+    const int fin_slot = P == 0 ? 0 : (P & 1);
+    if (!tail_only) {
     if (p0 == 0)
         k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec, (adaptive && !no_pred) ? h->d_esum_part : nullptr, h->d_prof ? h->d_prof + 9 : nullptr);
     if (adaptive) enqueue_solver(h, P, p0);
     k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
-    k_post_correct<<<h->nb_e, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, P == 0 ? 0 : (P & 1), h->cl, h->d_cum);
-    k_resample_gather<<<(unsigned)std::min<long long>((n + TB - 1) / TB, 4 * h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method, h->cfg.seed, 0u,
-                                                                 nullptr, h->d_anc, nullptr, 0);
-    const int nbm = launch_moments(h, h->d_hist_W, 0);
+    }
+    int nbm;
+    if (no_select && !tail_only && can_fuse_post(h)) nbm = launch_moments(h, h->d_hist_W, 0, fin_slot);
+    else {
+        k_post_correct<<<h->nb_e, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, fin_slot, h->cl, h->d_cum);
+        k_resample_gather<<<(unsigned)std::min<long long>((n + TB - 1) / TB, 4 * h->noop_grid), TB, 0, s>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, method,
+                                                                     h->cfg.seed, 0u, nullptr, h->d_anc, nullptr, 0);
+        nbm = launch_moments(h, h->d_hist_W, 0);
+    }
     k_prepare_mutation<<<1, PT, h->prep_lds, s>>>(h->d_st, h->d_model, h->d_part_mom, nbm, h->cfg.seed, 1, 1, 0);
     if (ev0) hipEventRecord(ev0, s);
     launch_mutate(h, n_blocks, 0, alpha);
@@ -801,48 +817,79 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
     std::vector<hipEvent_t> evs;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
+    // Resampling is predictable on an adaptive schedule (every stage ends at ESS = target x the previous ESS, or x N after a
+    // resample), so the host enqueues the selection kernels only where it expects a resample; the device checks the expectation
+    // (k_moments_reg) and stalls the run if it was wrong.  SMCMI_NO_SELECT_PREDICT=1 (development) keeps the full list everywhere,
+    // =2 deliberately predicts "never" to exercise the stall path.
+    static const int sel_mode = getenv("SMCMI_NO_SELECT_PREDICT") ? atoi(getenv("SMCMI_NO_SELECT_PREDICT")) : 0;
+    const bool predict_select = adaptive && can_fuse_post(h) && sel_mode != 1;
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};       // [0] full stage, [1] stage without selection kernels
     if (rc->use_graph == 1) {
-        HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr);
-        HIP_TRY(hipStreamEndCapture(h->stream, &graph));
-        HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+        for (int v = 0; v < (predict_select ? 2 : 1); ++v) {
+            HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, v == 1);
+            HIP_TRY(hipStreamEndCapture(h->stream, &graph[v]));
+            HIP_TRY(hipGraphInstantiate(&gexec[v], graph[v], nullptr, nullptr, 0));
+        }
     }
+    double pred_ess = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;   // ESS after the last completed stage
+    int pred_rl = 0;                                                                       // resampled_last_period
     const auto t0 = std::chrono::steady_clock::now();
     int launched = 0, done = 0;
-    res->solver_stalls = 0; res->reserved_ = 0;
+    res->solver_stalls = 0; res->select_stalls = 0;
     const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
     int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
     while (launched < max_iter && !done) {
         const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
-            if (gexec && launched > 1) HIP_TRY(hipGraphLaunch(gexec, h->stream));
+            bool no_select = false;
+            if (predict_select) {
+                // ESS this stage will end at (helpers.jl:14-20), with a margin: a wrong "resample" guess only costs two idle launches
+                const double ess_bar = rc->tempering_target * (pred_rl ? (double)h->cfg.n_parts : pred_ess);
+                const bool rs = ess_bar < rp.threshold * (1.0 + 1e-6);
+                no_select = !rs || sel_mode == 2;
+                pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
+            }
+            if (gexec[0] && launched > 1) HIP_TRY(hipGraphLaunch(gexec[no_select ? 1 : 0], h->stream));
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
                 enqueue_stage(h, adaptive, launched < 2 ? first_passes : solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha,
-                              acc_nb, e0, e1);
+                              acc_nb, e0, e1, 0, no_select);
             }
             ++launched;
         }
         HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        while (done == 2) {
-            // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give that
-            // stage more passes (continuing the same search), and go on from the stage after it.
+        while (done == 2 || done == 3) {
             if (pull_state(h)) return SMCMI_ERR_HIP;
             const int st_i = s.stage;
             const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : solver_passes);
-            const int more = 8;
             const int zero = 0;
             HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
-            enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had);
-            stall_stage = st_i; stall_p = had + more;
+            if (done == 2) {
+                // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give
+                // that stage more passes (continuing the same search), and go on from the stage after it.
+                const int more = 8;
+                enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had);
+                stall_stage = st_i; stall_p = had + more;
+                res->solver_stalls += 1;
+            } else {
+                // A stage enqueued without selection kernels needs to resample after all: nothing past its correction has run.
+                // Run the rest of that stage with the full path, then go on from the stage after it.
+                enqueue_stage(h, adaptive, 0, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had, false, true);
+                res->select_stalls += 1;                   // selection stalls (diagnostic)
+            }
             launched = st_i - 1;
-            res->solver_stalls += 1;
             HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        if (predict_select) {
+            // re-anchor the expectation on the device's ESS / flag after every sync (cheap: the stream is idle here)
+            HIP_TRY(hipMemcpy(&s.resampled_last, &h->d_st->resampled_last, sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&s.ess_prev, &h->d_st->ess_prev, sizeof(double), hipMemcpyDeviceToHost));
+            pred_ess = s.ess_prev; pred_rl = s.resampled_last;
         }
         static const int trace = getenv("SMCMI_TRACE") ? atoi(getenv("SMCMI_TRACE")) : 0;   // development only
         if (trace) {
@@ -866,7 +913,8 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     const auto t1 = std::chrono::steady_clock::now();
-    if (gexec) { hipGraphExecDestroy(gexec); hipGraphDestroy(graph); }
+    for (int v = 0; v < 2; ++v)
+        if (gexec[v]) { hipGraphExecDestroy(gexec[v]); hipGraphDestroy(graph[v]); }
     res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;
     for (size_t k = 0; k + 1 < evs.size(); k += 2) {
         float ms = 0.f;

@@ -22,7 +22,7 @@ struct RunConfig
 end
 mutable struct Result
     n_stages::Int32; resamples::Int32; logmdd::Float64; c::Float64; accept::Float64; seconds::Float64
-    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; reserved_::Int32
+    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32
     Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0)
 end
 

@@ -494,3 +494,34 @@ def test_solver_stall_resume_is_exact():
         np.testing.assert_array_equal(rec["schedule"], out[2][1]["schedule"])
         np.testing.assert_array_equal(rec["ess"], out[2][1]["ess"])
         np.testing.assert_array_equal(P_, out[2][2])
+
+
+def test_selection_kernels_skipped_when_no_resample_expected(monkeypatch):
+    """On an adaptive schedule the host leaves k_post_correct / k_resample_gather out of stages it expects not to resample
+    (the moments kernel takes the decision); a wrong expectation stalls the run and the host resumes the stage with the full
+    path.  All three ways of running give identical results."""
+    import subprocess, sys, json, os
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+from tests import models
+from tests.test_gpu_parity import make_engine
+spec = models.gauss_spec(d=6)
+eng = make_engine(spec, 8192, seed=33, max_stages=2000)
+eng.init_from_prior()
+r = eng.run(use_fixed_schedule=False, tempering_target=0.9, n_phi=100, sync_every=8)
+rec = eng.stage_records(r["n_stages"])
+P = eng.download_cloud()
+print(json.dumps(dict(n=r["n_stages"], logmdd=r["logmdd"], resamples=r["resamples"], sel=r["select_stalls"], ess=rec["ess"].tolist(),
+                      chk=float(np.sum(P * np.arange(1, P.shape[1] + 1)[None, :])))))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("0", "1", "2"):          # predicted / always the full list / deliberately wrong prediction
+        env = dict(os.environ, SMCMI_NO_SELECT_PREDICT=mode)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[mode] = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["0"]["sel"] == 0 and out["1"]["sel"] == 0 and out["2"]["sel"] == out["2"]["resamples"] > 0
+    for mode in ("1", "2"):
+        assert out[mode]["n"] == out["0"]["n"] and out[mode]["logmdd"] == out["0"]["logmdd"]
+        assert out[mode]["ess"] == out["0"]["ess"] and out[mode]["chk"] == out["0"]["chk"]
