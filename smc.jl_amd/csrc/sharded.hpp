@@ -159,6 +159,8 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     const int P_default = adaptive ? (rc->solver_passes >= 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     const bool predict = adaptive && !no_pred;
+    static const int sel_mode = getenv("SMCMI_NO_SELECT_PREDICT") ? atoi(getenv("SMCMI_NO_SELECT_PREDICT")) : 0;   // development only
+    const bool predict_select = adaptive && can_fuse_post(h0) && sel_mode != 1;
     std::vector<double> sched(rc->n_phi);
     for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
     for (auto *h : g.hs) {
@@ -191,20 +193,22 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             HIP_TRY(hipMemcpy(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice));
         }
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    const int max_iter = adaptive ? h0->cfg.max_stages : rc->n_phi - 1;
-    int done = 0, iters = 0, stalls = 0;
-    while (iters < max_iter && !done) {
-        // ---- stage begin + adaptive-ϕ solver + correction.  d_tot_acc holds the all-reduced [energy sums | acceptance sum]
-        // of the previous mutation (ESP doubles; only the last one on a fixed schedule).
-        int P = adaptive ? (iters == 0 ? std::max(P_default, FIRST_SOLVER_PASSES) : P_default) : 0;
-        for (auto *h : g.hs) {
-            HIP_TRY(hipSetDevice(h->cfg.device));
-            h->run_adaptive = predict;
-            k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec, predict ? h->d_tot_acc : nullptr);
-        }
-        int flags[2] = {0, 0};
-        for (int p0 = 0;;) {
+    // One stage = the single-GPU launch sequence with the collectives in-stream.  Nothing in it needs the host: on an adaptive
+    // schedule resampling is predictable (smcmi_run), so the selection path - all-gather of weights and shard clouds, global
+    // scan, gather - is enqueued exactly where a resample is expected (its kernels gate themselves on the device's decision)
+    // and elsewhere k_moments_reg takes the post-correction decision itself; a wrong expectation or a solver that runs out
+    // of passes stalls the run (done = 3 / 2) identically on every rank and is resumed at the next host sync.  Fixed schedules
+    // cannot be predicted: they keep one flag read per stage.
+    // mode 0: full stage with selection path; 1: no selection expected; 2: tail only (from k_post_correct on; selection path)
+    auto enqueue = [&](int p0, int P, int mode) -> int {
+        const int fin_slot = P == 0 ? 0 : (P & 1);
+        if (mode != 2) {
+            if (p0 == 0)
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    h->run_adaptive = predict;
+                    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec, predict ? h->d_tot_acc : nullptr);
+                }
             for (int p = p0; p < P; ++p) {
                 for (auto *h : g.hs) {
                     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -213,57 +217,66 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 }
                 if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_ess; }, 2 * KC)) return rc2;
             }
-            // ---- correction
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_fin, 1, P, h->d_hist_w, h->n);
                 k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
             }
             if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
-            for (auto *h : g.hs) {
-                HIP_TRY(hipSetDevice(h->cfg.device));
-                k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_tot_fin, 1, nullptr, h->rec, P == 0 ? 0 : (P & 1));
-            }
-            // the selection needs a collective only on resample stages: the one host decision per stage (identical on all ranks)
-            HIP_TRY(hipSetDevice(h0->cfg.device));
-            HIP_TRY(hipMemcpyAsync(&flags[0], &h0->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
-            HIP_TRY(hipMemcpyAsync(&flags[1], &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
-            HIP_TRY(hipStreamSynchronize(h0->stream));
-            if (flags[1] != 2) break;
-            // the solver ran out of passes (stall, see solver_prologue): clear it on every shard and continue the same search
-            for (auto *h : g.hs) {
-                HIP_TRY(hipSetDevice(h->cfg.device));
-                const int zero = 0;
-                HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
-            }
-            p0 = P; P += 4;
-            ++stalls;
         }
-        if (flags[1]) { done = 1; break; }
-        if (flags[0]) {
-            const size_t nloc = (size_t)h0->n;
-            if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)(h->cl.buf[0] + (long long)(h->R - 1) * h->n); },
-                                      [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return rc2;
-            if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)h->cl.buf[0]; },
-                                      [](smcmi_handle *h) { return h->d_full_cloud; }, nloc * h0->R)) return rc2;
+        if (mode == 1) {
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
-                const long long N = h->cfg.n_parts;
-                CloudPtrs wcl{};
-                wcl.buf[0] = wcl.buf[1] = h->d_full_w; wcl.n = N; wcl.R = 1;
-                k_weight_chunk_sums<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_part_full);
-                k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_full, h->nb_full, h->d_off_full, 0.0, 0);
-                k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 1, h->nb_full);
-                k_resample_gather<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum_full, N, h->cfg.gid0, N,
-                                                                                        rc->resampling_method, h->cfg.seed, 0u, nullptr, h->d_anc,
-                                                                                        h->d_full_cloud, 0, h->n, 1);
+                // the moments kernel decides from the all-reduced (ΣW̃, ΣW̃²) handed over as the partials of one block
+                float dummy = 0.f; (void)dummy;
+                switch (h->d) {
+#define SMCMI_FUSED_CASE(D) case D: k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, h->n, 0, h->d_tot_fin, 1, fin_slot, h->rec); break;
+                SMCMI_FUSED_CASE(1) SMCMI_FUSED_CASE(2) SMCMI_FUSED_CASE(3) SMCMI_FUSED_CASE(4) SMCMI_FUSED_CASE(5) SMCMI_FUSED_CASE(6)
+                SMCMI_FUSED_CASE(7) SMCMI_FUSED_CASE(8) SMCMI_FUSED_CASE(9) SMCMI_FUSED_CASE(10) SMCMI_FUSED_CASE(11) SMCMI_FUSED_CASE(12)
+#undef SMCMI_FUSED_CASE
+                default: return set_err(SMCMI_ERR_STATE, "fused post-correction needs d <= 12");
+                }
+                k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->nb_mr, h->npairs, h->d_tot_mom, 0);
             }
-        }
-        // ---- moments -> proposal -> mutation
-        for (auto *h : g.hs) {
-            HIP_TRY(hipSetDevice(h->cfg.device));
-            const int nbm = launch_moments(h, h->d_hist_W, 0);
-            k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm, h->npairs, h->d_tot_mom, 0);
+        } else {
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_tot_fin, 1, nullptr, h->rec, fin_slot);
+            }
+            int rs = 1;
+            if (!adaptive || !predict_select) {
+                // the one host decision per stage of the unpredicted path (identical on all ranks)
+                int fl[2] = {0, 0};
+                HIP_TRY(hipSetDevice(h0->cfg.device));
+                HIP_TRY(hipMemcpyAsync(&fl[0], &h0->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+                HIP_TRY(hipMemcpyAsync(&fl[1], &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+                HIP_TRY(hipStreamSynchronize(h0->stream));
+                rs = fl[0] && !fl[1];
+            }
+            if (rs) {
+                const size_t nloc = (size_t)h0->n;
+                if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)(h->cl.buf[0] + (long long)(h->R - 1) * h->n); },
+                                          [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return rc2;
+                if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)h->cl.buf[0]; },
+                                          [](smcmi_handle *h) { return h->d_full_cloud; }, nloc * h0->R)) return rc2;
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    const long long N = h->cfg.n_parts;
+                    CloudPtrs wcl{};
+                    wcl.buf[0] = wcl.buf[1] = h->d_full_w; wcl.n = N; wcl.R = 1;
+                    k_weight_chunk_sums<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_part_full);
+                    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_full, h->nb_full, h->d_off_full, 0.0, 0);
+                    k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 0, h->nb_full);
+                    k_resample_gather<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum_full, N, h->cfg.gid0, N,
+                                                                                            rc->resampling_method, h->cfg.seed, 0u, nullptr, h->d_anc,
+                                                                                            h->d_full_cloud, 0, h->n, 1);
+                }
+            }
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                const int nbm = launch_moments(h, h->d_hist_W, 0);
+                k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm, h->npairs, h->d_tot_mom, 0);
+            }
         }
         if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_mom; }, h0->npairs)) return rc2;
         for (auto *h : g.hs) {
@@ -275,7 +288,59 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         }
         if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ESP)) return rc2; }
         else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, 1)) return rc2;
-        ++iters;
+        return 0;
+    };
+
+    const auto t0 = std::chrono::steady_clock::now();
+    const int max_iter = adaptive ? h0->cfg.max_stages : rc->n_phi - 1;
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
+    const int first_passes = std::max(P_default, FIRST_SOLVER_PASSES);
+    const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
+    double pred_ess = rc->initial_ess > 0.0 ? rc->initial_ess : N_tot;
+    int pred_rl = 0, stall_stage = -1, stall_p = 0;
+    int done = 0, iters = 0, stalls = 0, sel_stalls = 0;
+    while (iters < max_iter && !done) {
+        const int batch = adaptive ? std::min(sync_every, max_iter - iters) : max_iter - iters;
+        for (int b = 0; b < batch; ++b) {
+            int mode = 0;
+            if (predict_select) {
+                const double ess_bar = rc->tempering_target * (pred_rl ? N_tot : pred_ess);
+                const bool rs = ess_bar < thr * (1.0 + 1e-6);
+                mode = (!rs || sel_mode == 2) ? 1 : 0;
+                pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
+            }
+            if (int rc2 = enqueue(0, adaptive ? (iters < 2 ? first_passes : P_default) : 0, mode)) return rc2;
+            ++iters;
+        }
+        for (;;) {
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(&done, &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipStreamSynchronize(h0->stream));
+            if (done != 2 && done != 3) break;
+            // stall (identical on every rank: all decisions come from all-reduced totals): clear it and resume that stage
+            if (pull_state(h0)) return SMCMI_ERR_HIP;
+            const int st_i = h0->h_st.stage;
+            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : P_default);
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                const int zero = 0;
+                HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            }
+            if (done == 2) {
+                if (int rc2 = enqueue(had, had + 4, 0)) return rc2;
+                stall_stage = st_i; stall_p = had + 4;
+                ++stalls;
+            } else {
+                if (int rc2 = enqueue(had, had, 2)) return rc2;
+                ++sel_stalls;
+            }
+            iters = st_i - 1;
+        }
+        if (predict_select) {
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpy(&pred_rl, &h0->d_st->resampled_last, sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&pred_ess, &h0->d_st->ess_prev, sizeof(double), hipMemcpyDeviceToHost));
+        }
     }
     // fold the last acceptance rate, close the run
     for (auto *h : g.hs) {
@@ -290,7 +355,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
-    res->solver_stalls = stalls;
+    res->solver_stalls = stalls; res->select_stalls = sel_stalls;
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;
