@@ -1232,10 +1232,63 @@ __device__ inline bool chol_rows_in_regs(double (&r)[DBM], int db, int lane) {
 }
 
 constexpr int PT = 1024;  // threads of the single prepare block
+
+// Random numbers of one stage's mutation, generated AHEAD of it: the draws depend only on (seed, particle id, stage, step), so
+// while block 0 of k_prepare_mutation does its serial set-up on one CU the rest of the chip is idle - blocks 1.. of the same
+// launch fill it with the Philox + Box-Muller work (~40 % of the mutation kernel's instructions), which the mutation kernel
+// then just loads.  Layout: zbuf[(t ZS + slot) n + i], t = mh_step n_blocks + block, ZS = D + 2 slots: MH uniform, mixture
+// uniform, D normals (zero beyond the block length).  Same tags and the same expressions as the in-kernel path -> same bits.
+constexpr int RA_T = 256;
+struct RngAhead {
+    double *zbuf;            // null: disabled
+    long long n, gid0;
+    int D;
+};
+__device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, unsigned long long seed, const RngAhead &ra) {
+    // RA_T particles per block although the launch has PT threads per block (block 0 needs them): 4 wavefronts per CU spread the
+    // draws over the whole chip instead of 16 per CU on a quarter of it
+    if (threadIdx.x >= RA_T) return;
+    const long long i = (long long)(blockIdx.x - 1) * RA_T + threadIdx.x;
+    if (i >= ra.n) return;
+    const int nf = md->n_free, nb = st->rp.n_blocks, n_steps = st->rp.n_mh_steps, D = ra.D, ZS = D + 2;
+    const unsigned stage = (unsigned)st->stage;
+    const unsigned long long pid = (unsigned long long)(ra.gid0 + i);
+    const int sub = (nf + nb - 1) / nb;
+    for (int step = 0; step < n_steps; ++step)
+        for (int b = 0; b < nb; ++b) {
+            const unsigned t = (unsigned)(step * nb + b);
+            const int db = (b < nb - 1) ? sub : nf - sub * (nb - 1);
+            double step_prob, u_dummy, uc, unext;
+            if (t == 0) uniform_pair(seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
+            else uniform_pair(seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
+            uniform_pair(seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
+            double *zt = ra.zbuf + (long long)t * ZS * ra.n + i;
+            zt[0] = step_prob;
+            zt[ra.n] = uc;
+            for (int q = 0; 2 * q < D; ++q) {
+                double z0 = 0.0, z1 = 0.0;
+                if (2 * q < db) {
+                    double ua, ub, sn, cs;
+                    uniform_pair(seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua, ub);
+                    const double rr = sqrt(-2.0 * log(ua));
+                    sincospi(2.0 * ub, &sn, &cs);
+                    z0 = rr * cs;
+                    z1 = (2 * q + 1 < db) ? rr * sn : 0.0;
+                }
+                zt[(long long)(2 + 2 * q) * ra.n] = z0;
+                if (2 * q + 1 < D) zt[(long long)(3 + 2 * q) * ra.n] = z1;
+            }
+        }
+}
+
 __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
-                                                         int standalone, long long *prof = nullptr) {
+                                                         int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
+    if (blockIdx.x > 0) {                    // the idle CUs draw the mutation's random numbers (see RngAhead)
+        if (ra.zbuf && !st->done) rng_ahead_block(st, md, seed, ra);
+        return;
+    }
     SMCMI_STAMP(prof, 0);
     __shared__ double scratch[PT];
     __shared__ double mu_f[MAXD];
@@ -1426,6 +1479,7 @@ struct MutArgs {
     long long *prof;           // development only: per-phase shader-clock stamps of block 0 / middle block, wave 0
     int debug;                 // development only (tools/kbench.py): bit0 skip normals, bit1 skip prior/likelihood, bit2 skip matvec
     double *esum;              // in-run MODE 0: per-block energy power sums for the next stage's ϕ predictor ([blocks][ES]) or null
+    const double *zbuf;        // in-run register kernel: random numbers drawn ahead by k_prepare_mutation (RngAhead layout) or null
 };
 
 template <int MODE>
@@ -1734,12 +1788,20 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
             if (!live) continue;
             const unsigned t = (unsigned)(step * nb + b);
             double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
+            double uc, unext;
+            double z[D], sub[D], dr[D];
+            if (ma.zbuf) {
+                // drawn ahead by the idle CUs during k_prepare_mutation (RngAhead): D + 2 coalesced loads
+                const double *zt = ma.zbuf + (long long)t * (D + 2) * cl.n + i;
+                step_prob = zt[0];
+                uc = zt[cl.n];
+#pragma unroll
+                for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * cl.n];
+            } else {
             if (t == 0) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
             else uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
             // ---- mvnormal_mixture_draw (src/helpers.jl:87-100)
-            double uc, unext;
             uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
-            double z[D], sub[D], dr[D];
             {
                 // Box-Muller for the block, written stage by stage over all pairs so the independent log / sqrt / sincospi
                 // chains can be interleaved by the scheduler (at <= 2 wavefronts per SIMD dependent FP64 latency is exposed)
@@ -1770,6 +1832,7 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
                 }
 #pragma unroll
                 for (int e = 0; e < D; ++e) asm volatile("" : "+v"(z[e]));   // materialise the normals here (see the matvec note)
+            }
             }
             SMCMI_PROF(4);
             double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;

@@ -167,6 +167,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         HIP_TRY(hipSetDevice(h->cfg.device));
         if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
         if (ensure_shard_buffers(h) || pull_state(h) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
+        if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
         DevState &s = h->h_st;
         RunParams rp{};
         rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
@@ -281,7 +282,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_mom; }, h0->npairs)) return rc2;
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
-            k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_tot_mom, 1, h->cfg.seed, 2, 1, 0);
+            launch_prepare_in_run(h, h->d_tot_mom, 1, 2);
             const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
             if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ESP, h->d_tot_acc);
             else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + ES);

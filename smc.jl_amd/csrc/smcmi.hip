@@ -55,7 +55,7 @@ struct smcmi_handle {
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
-    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
+    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
     // host-callback split
@@ -69,6 +69,8 @@ struct smcmi_handle {
     double *d_tot_ess = nullptr, *d_tot_fin = nullptr, *d_tot_mom = nullptr, *d_tot_acc = nullptr, *d_full_w = nullptr, *d_full_cloud = nullptr;
     int last_n_stages = 1;
     int launch_nb = 1;
+    size_t zbuf_cap = 0;         // doubles allocated in d_zbuf (random numbers drawn ahead of the mutation, kernels.hpp RngAhead)
+    bool rng_ahead = false;      // the enqueued stage's k_prepare_mutation fills d_zbuf and the mutation kernel reads it
     bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
     int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
     bool launch_alpha1 = false;
@@ -202,7 +204,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part,
+                    h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
@@ -627,6 +629,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     ma.prof = h->d_prof;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
+    ma.zbuf = (!standalone && h->rng_ahead && use_reg_mutate(h)) ? h->d_zbuf : nullptr;
     switch (h->d) {
     case 1: launch_reg<1>(h, ma, standalone); break;
     case 2: launch_reg<2>(h, ma, standalone); break;
@@ -725,6 +728,32 @@ extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const dou
     return 0;
 }
 
+// In-run proposal set-up: block 0 prepares the proposal, the other blocks draw the stage's random numbers ahead (RngAhead) when
+// the register mutation kernel will run and the buffer fits.  from_totals as in k_prepare_mutation.
+static int ensure_zbuf(smcmi_handle *h, int n_mh_steps, int n_blocks) {
+    static const int off = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
+    h->rng_ahead = false;
+    if (off || !use_reg_mutate(h)) return 0;
+    const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)n_mh_steps * (size_t)n_blocks;
+    if (need * sizeof(double) > ((size_t)8 << 30)) return 0;                  // > 8 GiB: draw inside the mutation kernel instead
+    if (need > h->zbuf_cap) {
+        if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
+        if (dmalloc(&h->d_zbuf, need)) return SMCMI_ERR_HIP;
+        h->zbuf_cap = need;
+    }
+    h->rng_ahead = true;
+    return 0;
+}
+static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int nb_part, int from_totals) {
+    RngAhead ra{};
+    unsigned grid = 1;
+    if (h->rng_ahead) {
+        ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d;
+        grid = 1 + (unsigned)((h->n + RA_T - 1) / RA_T);
+    }
+    k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, nullptr, ra);
+}
+
 // ------------------------------------------------------------------------------------------------ whole loop
 // One stage = a fixed kernel sequence (no host decision inside): see the header of kernels.hpp.
 // p0 > 0 resumes a stage whose solver ran out of passes after p0 of them (st->done == 2 stall, see solver_prologue): the
@@ -754,7 +783,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
                                                                      h->cfg.seed, 0u, nullptr, h->d_anc, nullptr, 0);
         nbm = launch_moments(h, h->d_hist_W, 0);
     }
-    k_prepare_mutation<<<1, PT, h->prep_lds, s>>>(h->d_st, h->d_model, h->d_part_mom, nbm, h->cfg.seed, 1, 1, 0);
+    launch_prepare_in_run(h, h->d_part_mom, nbm, 1);
     if (ev0) hipEventRecord(ev0, s);
     launch_mutate(h, n_blocks, 0, alpha);
     if (ev1) hipEventRecord(ev1, s);
@@ -810,6 +839,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     if (getenv("SMCMI_PROF_MUT") && !h->d_prof) { if (dmalloc(&h->d_prof, 32)) return SMCMI_ERR_HIP; }
+    if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
