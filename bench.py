@@ -188,7 +188,9 @@ def main():
         # the dynamic count, the MH loop is unrolled for one step x one block).
         try:
             with open(os.path.join(ROOT, "profiles", "r01_isa_counts.json")) as f:
-                isa = json.load(f).get("k_mutate_reg<%d,true>" % D)
+                # below 5e5 draws per stage the random numbers are drawn ahead by k_prepare_mutation's idle CUs (csrc ensure_zbuf)
+                ahead = n_local * RUN_KW.get("n_mh_steps", 1) * RUN_KW.get("n_blocks", 1) <= 500000 and not os.environ.get("SMCMI_NO_RNG_AHEAD")
+                isa = json.load(f).get(("k_mutate_reg<%d,true>" % D) + (" rng_ahead" if ahead else ""))
             if isa and RUN_KW.get("n_mh_steps", 1) == 1 and mean_ms > 0:
                 waves = -(-n_total // 64)
                 # SIMD-32: a wave64 VALU instruction issues over 2 cycles, FP64 over 4 (half rate), 32x32-bit multiplies over 8
@@ -197,7 +199,7 @@ def main():
                 ach = waves * cyc / (mean_ms * 1e-3)
                 out["roofline"]["valu_issue"] = {"valu_instr_per_wave": isa["valu_total"], "issue_cycles_per_wave": cyc, "waves": waves,
                                                  "achieved": ach, "peak": peak, "unit": "SIMD issue cycles/s", "frac": ach / peak,
-                                                 "waves_per_simd": waves / 1024.0}
+                                                 "waves_per_simd": waves / 1024.0, "rng_drawn_ahead": bool(ahead)}
         except OSError:
             pass
         if args.workload == "kalman" and mean_ms > 0:

@@ -1790,7 +1790,12 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
             double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
             double uc, unext;
             double z[D], sub[D], dr[D];
-            if (ma.zbuf) {
+#ifdef SMCMI_COUNT_RNG_AHEAD   // profiles/isa_count.py: instruction mix of the path that loads the draws (dead-codes the in-kernel RNG)
+            constexpr bool z_only = true;
+#else
+            constexpr bool z_only = false;
+#endif
+            if (z_only || ma.zbuf) {
                 // drawn ahead by the idle CUs during k_prepare_mutation (RngAhead): D + 2 coalesced loads
                 const double *zt = ma.zbuf + (long long)t * (D + 2) * cl.n + i;
                 step_prob = zt[0];
