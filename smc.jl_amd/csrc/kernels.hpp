@@ -521,6 +521,77 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
     SMCMI_STAMP(prof, 4);
 }
 
+// Correction pass that also gathers the moments (stages where no resampling is expected, smcmi_run): weighted mean and
+// covariance are ratios of sums, so they can be accumulated with the UNNORMALISED weights W̃ in the same pass that creates them
+// (Σ W̃ x̃ x̃ᵀ, x̃ = (1, θ - shift), as k_moments_reg) - the cloud is not read a second time and the separate moments launch
+// disappears; the weights are normalised later by the mutation kernel, which reads them anyway.  Per-block partial row:
+// [ΣW̃, ΣW̃², pair sums (a <= b)]; the classic 2-column partials are written too so that a stalled stage can be resumed by the
+// full path.  Same solver prologue / stall semantics as k_pass<1, true>.
+template <int D>
+__global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *st, const double *sched, const double *partials_prev,
+                                                        double *partials_fin, double *partials_cm, int nb_prev, int p, double *hist_w,
+                                                        long long hist_ld) {
+    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
+    constexpr int NCH = (NPF + 63) / 64;
+    __shared__ double red[(TB / 64) * 64];
+    __shared__ double scratch[TB];
+    __shared__ double tot[2 * KC];
+    __shared__ Solver S;
+    const int done = st->done;
+    const double phi_prev = st->phi_prev;
+    const double pw = st->rp.pw, logp_old = st->rp.logp_old;
+    const int stage_col = st->stage - 1;
+    const bool hist = st->rp.store_history && hist_w != nullptr;
+    double sh[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) sh[a] = st->shift[a];
+    solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, 1, done);
+    if (done) return;
+    if (S.mode != MODE_FINAL) return;
+    const double phi = S.phi_n;
+    const int R = cl.R;
+    const double *loglh = col(cl, 0, R - 5), *old = col(cl, 0, R - 3);
+    double *w = col(cl, 0, R - 1);
+    double acc[NCH * 64];
+#pragma unroll
+    for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+    long long beg, end;
+    block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
+    for (long long i = beg + threadIdx.x; i < end; i += TB) {
+        const double l = loglh[i], o = old[i], wi = w[i];
+        double xx[DA];
+        xx[0] = 1.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) xx[a + 1] = col(cl, 0, a)[i] - sh[a];
+        double inc;
+        if (pw == 0.0) inc = exp((phi_prev - phi) * o + (phi - phi_prev) * l);
+        else if (pw == 1.0) inc = exp((phi - phi_prev) * l);
+        else inc = exp((phi_prev - phi) * log(exp(o - logp_old + log(1.0 - pw)) + pw) + (phi - phi_prev) * l);
+        const double v = wi * inc;
+        acc[0] += v;
+        acc[1] += v * v;
+        w[i] = v;
+        if (hist) hist_w[(long long)stage_col * hist_ld + i] = inc;
+        int q = 2;
+#pragma unroll
+        for (int a = 0; a < DA; ++a) {
+            const double wx = v * xx[a];
+#pragma unroll
+            for (int b = a; b < DA; ++b) { acc[q] += wx * xx[b]; ++q; }
+        }
+    }
+    double *out = partials_cm + (long long)blockIdx.x * NPF;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double a64[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
+        const double t64 = block_reduce_many<64>(a64, red);
+        if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = t64;
+        if (ch == 0 && threadIdx.x < 2) partials_fin[2 * (long long)blockIdx.x + threadIdx.x] = t64;
+    }
+}
+
 // decision of the last solver pass without a correction (stand-alone smcmi_solve_phi)
 __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double *sched, const double *partials_prev, int nb_prev, int p) {
     __shared__ double scratch[TB];
@@ -1283,7 +1354,8 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
 
 __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
-                                                         int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}) {
+                                                         int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}, int sol_slot = 0,
+                                                         Records rec = Records{}) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
     if (blockIdx.x > 0) {                    // the idle CUs draw the mutation's random numbers (see RngAhead)
         if (ra.zbuf && !st->done) rng_ahead_block(st, md, seed, ra);
@@ -1303,10 +1375,37 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
     double *Ls = A + nf * nf;                // [nf*nf] factor of the current block
     if (t == 0) s_fail = 0;
     if (t < nf) fi[t] = md->free_inds[t];
-    const double c = st->c;
+    double c = st->c;
     SMCMI_STAMP(prof, 1);
+    if (from_totals == 3) {
+        // `partials` are the rows of k_correct_moments: [ΣW̃, ΣW̃², pair sums].  This block first takes the post-correction
+        // decision k_post_correct would take (the stage was enqueued without it); if selection is needed after all the run
+        // stalls (done = 3) and the host resumes the stage with the full path.
+        __shared__ double s_cm[2];
+        __shared__ double s_c;
+        __shared__ int s_go;
+        const PostIn pin = post_load(st, sol_slot);
+        const int npf = npairs + 2;
+        const double v = final_sum(partials, nb_part, npf, scratch);
+        if (t < 2) s_cm[t] = v;
+        else if (t < npf) tot[t - 2] = v;
+        if (t == 0) s_go = 0;
+        __syncthreads();
+        if (t == 0) {
+            if (pin.smode != MODE_FINAL) { st->err = SMCMI_ERR_BRACKET; st->done = 1; }
+            else {
+                const double ess = s_cm[0] * s_cm[0] / s_cm[1];
+                if (!isnan(ess) && ess < pin.thr) st->done = 3;
+                else if (post_write(st, rec, pin, s_cm[0], s_cm[1]) == 0) { s_go = 1; s_c = st->c; }
+            }
+        }
+        __syncthreads();
+        if (!s_go) return;
+        c = s_c;
+    }
     if (from_totals) {
-        if (from_totals == 1) {
+        if (from_totals == 3) {
+        } else if (from_totals == 1) {
             // all (d+1)(d+2)/2 pair sums in one round of loads: thread (slice, pair) adds the blocks of its slice, eight
             // loads in flight, slices combined in a fixed tree (final_sum); npairs <= PT for d <= 43, else 64-wide chunks
             if (npairs <= PT) {
@@ -1480,6 +1579,10 @@ struct MutArgs {
     int debug;                 // development only (tools/kbench.py): bit0 skip normals, bit1 skip prior/likelihood, bit2 skip matvec
     double *esum;              // in-run MODE 0: per-block energy power sums for the next stage's ϕ predictor ([blocks][ES]) or null
     const double *zbuf;        // in-run register kernel: random numbers drawn ahead by k_prepare_mutation (RngAhead layout) or null
+    int normalize;             // in-run register kernel after k_correct_moments: the weight column still holds W̃ - apply
+                               // normalize_weights! (src/particle.jl:362-366) here and write the W history column
+    double *hist_W;
+    long long hist_ld;
 };
 
 template <int MODE>
@@ -1703,6 +1806,8 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
     const double e_center = st->e_center;
     const bool es_uniform = st->do_resample != 0;       // this stage resampled: all weights are 1
+    const double nrm_N = (double)st->rp.n_parts, nrm_sumw = st->sumw;       // only used with ma.normalize
+    const int nrm_col = st->stage - 1, nrm_hist = st->rp.store_history;
     for (int e = tid; e < nf * nf; e += T) Lraw[e] = st->L[e];
     for (int e = tid; e < nf; e += T) {
         mub_raw[e] = st->mu_b[e]; sdd_raw[e] = st->sd_draw[e]; sdn_raw[e] = st->sd_dens[e]; ball_raw[e] = st->blocks_all[e];
@@ -1732,7 +1837,14 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
         for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[i];
         like = col(cl, src, D)[i]; lprior = col(cl, src, D + 1)[i]; like_prev = col(cl, src, D + 2)[i];
     }
-    const double w_part = (live && ma.esum) ? col(cl, src, D + 4)[i] : 0.0;
+    double w_part = (live && (ma.esum || ma.normalize)) ? col(cl, src, D + 4)[i] : 0.0;
+    if (ma.normalize) {
+        w_part = (w_part * nrm_N) / nrm_sumw;                             // W·N then /ΣW̃, two roundings like the reference
+        if (live) {
+            col(cl, src, D + 4)[i] = w_part;
+            if (ma.hist_W && nrm_hist) ma.hist_W[(long long)nrm_col * ma.hist_ld + i] = w_part;
+        }
+    }
     ModelView mv{D, m_fix, m_fam, m_lo, m_hi, m_a, m_b, m_k};
     LikView lv[2];
     {

@@ -53,7 +53,7 @@ struct smcmi_handle {
     // scratch
     int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
-    double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
+    double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
@@ -70,6 +70,7 @@ struct smcmi_handle {
     int last_n_stages = 1;
     int launch_nb = 1;
     size_t zbuf_cap = 0;         // doubles allocated in d_zbuf (random numbers drawn ahead of the mutation, kernels.hpp RngAhead)
+    bool fused_cm = false;       // the enqueued stage ran k_correct_moments: the mutation kernel normalises the weights
     bool rng_ahead = false;      // the enqueued stage's k_prepare_mutation fills d_zbuf and the mutation kernel reads it
     bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
     int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
@@ -164,7 +165,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;
     h->comm_cap = std::max<long long>(2 * KC, h->npairs) + 8;
     h->prep_lds = (size_t)(((h->npairs + 63) / 64) * 64 + 4 * h->d * h->d + 8) * sizeof(double);
-    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) ||
+    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
         dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ESP) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
@@ -204,7 +205,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_zbuf,
+                    h->d_part_fin, h->d_part_cm, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
@@ -543,6 +544,27 @@ static void launch_moments_reg(smcmi_handle *h, double *hist_W, int standalone, 
         k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, hist_W, h->n, standalone);
 }
 static bool can_fuse_post(const smcmi_handle *h) { return h->d <= 12; }
+// the correction pass that also gathers the moments is used with the register mutation kernel (which normalises the weights)
+static bool can_fuse_cm(const smcmi_handle *h) { return h->d <= 10; }
+template <int D>
+static void launch_cm(smcmi_handle *h, int P) {
+    k_correct_moments<D><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->d_part_cm, h->nb_e, P,
+                                                     h->d_hist_w, h->n);
+}
+static void launch_correct_moments(smcmi_handle *h, int P) {
+    switch (h->d) {
+    case 1: launch_cm<1>(h, P); break;
+    case 2: launch_cm<2>(h, P); break;
+    case 3: launch_cm<3>(h, P); break;
+    case 4: launch_cm<4>(h, P); break;
+    case 5: launch_cm<5>(h, P); break;
+    case 6: launch_cm<6>(h, P); break;
+    case 7: launch_cm<7>(h, P); break;
+    case 8: launch_cm<8>(h, P); break;
+    case 9: launch_cm<9>(h, P); break;
+    default: launch_cm<10>(h, P); break;
+    }
+}
 // returns the number of blocks that wrote partials
 static int launch_moments(smcmi_handle *h, double *hist_W, int standalone, int fused_slot = -1) {
     switch (h->d) {
@@ -630,6 +652,8 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
     ma.zbuf = (!standalone && h->rng_ahead && use_reg_mutate(h)) ? h->d_zbuf : nullptr;
+    ma.normalize = (!standalone && h->fused_cm) ? 1 : 0;
+    ma.hist_W = h->d_hist_W; ma.hist_ld = h->n;
     switch (h->d) {
     case 1: launch_reg<1>(h, ma, standalone); break;
     case 2: launch_reg<2>(h, ma, standalone); break;
@@ -746,14 +770,15 @@ static int ensure_zbuf(smcmi_handle *h, int n_mh_steps, int n_blocks) {
     h->rng_ahead = true;
     return 0;
 }
-static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int nb_part, int from_totals) {
+static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int nb_part, int from_totals, int sol_slot = 0) {
     RngAhead ra{};
     unsigned grid = 1;
     if (h->rng_ahead) {
         ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d;
         grid = 1 + (unsigned)((h->n + RA_T - 1) / RA_T);
     }
-    k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, nullptr, ra);
+    k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, nullptr, ra,
+                                                             sol_slot, h->rec);
 }
 
 // ------------------------------------------------------------------------------------------------ whole loop
@@ -771,13 +796,26 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     h->run_adaptive = adaptive;
     const int fin_slot = P == 0 ? 0 : (P & 1);
+    static const int no_cm = getenv("SMCMI_NO_CORRECT_MOMENTS") ? atoi(getenv("SMCMI_NO_CORRECT_MOMENTS")) : 0;   // development only
+    // no selection expected and the register kernels apply: the correction pass gathers the moments too, k_prepare_mutation
+    // takes the post-correction decision, the mutation kernel normalises the weights (5 launches per stage)
+    const bool cm = no_select && !tail_only && can_fuse_cm(h) && !no_cm;
+    h->fused_cm = cm;
     if (!tail_only) {
     if (p0 == 0)
         k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec, (adaptive && !no_pred) ? h->d_esum_part : nullptr, h->d_prof ? h->d_prof + 9 : nullptr);
     if (adaptive) enqueue_solver(h, P, p0);
-    k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
+    if (cm) launch_correct_moments(h, P);
+    else k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
     }
-    int nbm;
+    int nbm = 0;
+    if (cm) {
+        launch_prepare_in_run(h, h->d_part_cm, h->nb_e, 3, fin_slot);
+        if (ev0) hipEventRecord(ev0, s);
+        launch_mutate(h, n_blocks, 0, alpha);
+        if (ev1) hipEventRecord(ev1, s);
+        return;
+    }
     if (no_select && !tail_only && can_fuse_post(h)) nbm = launch_moments(h, h->d_hist_W, 0, fin_slot);
     else {
         k_post_correct<<<h->nb_e, TB, 0, s>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, fin_slot, h->cl, h->d_cum);
