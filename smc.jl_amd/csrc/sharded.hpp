@@ -133,7 +133,7 @@ struct ShardGroup {
 static int ensure_shard_buffers(smcmi_handle *h) {
     const long long N = h->cfg.n_parts;
     if (!h->d_tot_ess) {
-        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs) || dmalloc(&h->d_tot_acc, ESP))
+        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs + 2) || dmalloc(&h->d_tot_acc, ESP))
             return SMCMI_ERR_HIP;
         HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * ESP));
     }
@@ -203,6 +203,20 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     // mode 0: full stage with selection path; 1: no selection expected; 2: tail only (from k_post_correct on; selection path)
     auto enqueue = [&](int p0, int P, int mode) -> int {
         const int fin_slot = P == 0 ? 0 : (P & 1);
+        static const int no_cm = getenv("SMCMI_NO_CORRECT_MOMENTS") ? atoi(getenv("SMCMI_NO_CORRECT_MOMENTS")) : 0;   // development only
+        // no selection expected + register kernels: the correction pass gathers the moments too, so (ΣW̃, ΣW̃², pair sums) travel
+        // in ONE all-reduce (3 collectives per stage instead of 4); k_prepare_mutation decides, the mutation kernel normalises
+        const bool cm = mode == 1 && can_fuse_cm(h0) && !no_cm;
+        const int npf = h0->npairs + 2;
+        for (auto *h : g.hs) h->fused_cm = cm;
+        if (mode == 2) {
+            // resume of a stalled stage: its correction left the per-block (ΣW̃, ΣW̃²) partials - total them first
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
+            }
+            if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
+        }
         if (mode != 2) {
             if (p0 == 0)
                 for (auto *h : g.hs) {
@@ -218,12 +232,33 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 }
                 if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_ess; }, 2 * KC)) return rc2;
             }
+            if (cm) {
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    launch_correct_moments(h, P, h->d_tot_ess, 1);
+                    k_moments_reduce<<<(npf + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_cm, h->nb_e, npf, h->d_tot_mom, 0);
+                }
+                if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_mom; }, npf)) return rc2;
+            } else {
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_fin, 1, P, h->d_hist_w, h->n);
+                    k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
+                }
+                if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
+            }
+        }
+        if (cm) {
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
-                k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_tot_ess, h->d_part_fin, 1, P, h->d_hist_w, h->n);
-                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_part_fin, h->nb_e, 2, h->d_tot_fin);
+                launch_prepare_in_run(h, h->d_tot_mom, 1, 3, fin_slot);
+                const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
+                if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ESP, h->d_tot_acc);
+                else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + ES);
             }
-            if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
+            if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ESP)) return rc2; }
+            else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, 1)) return rc2;
+            return 0;
         }
         if (mode == 1) {
             for (auto *h : g.hs) {

@@ -546,23 +546,24 @@ static void launch_moments_reg(smcmi_handle *h, double *hist_W, int standalone, 
 static bool can_fuse_post(const smcmi_handle *h) { return h->d <= 12; }
 // the correction pass that also gathers the moments is used with the register mutation kernel (which normalises the weights)
 static bool can_fuse_cm(const smcmi_handle *h) { return h->d <= 10; }
+// prev / nb_prev: partials of the last solver pass (or, sharded, their all-reduced totals as one row)
 template <int D>
-static void launch_cm(smcmi_handle *h, int P) {
-    k_correct_moments<D><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->d_part_cm, h->nb_e, P,
-                                                     h->d_hist_w, h->n);
+static void launch_cm(smcmi_handle *h, int P, const double *prev, int nb_prev) {
+    k_correct_moments<D><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, prev, h->d_part_fin, h->d_part_cm, nb_prev, P, h->d_hist_w, h->n);
 }
-static void launch_correct_moments(smcmi_handle *h, int P) {
+static void launch_correct_moments(smcmi_handle *h, int P, const double *prev = nullptr, int nb_prev = 0) {
+    if (!prev) { prev = h->d_part_ess[(P + 1) & 1]; nb_prev = h->nb_e; }
     switch (h->d) {
-    case 1: launch_cm<1>(h, P); break;
-    case 2: launch_cm<2>(h, P); break;
-    case 3: launch_cm<3>(h, P); break;
-    case 4: launch_cm<4>(h, P); break;
-    case 5: launch_cm<5>(h, P); break;
-    case 6: launch_cm<6>(h, P); break;
-    case 7: launch_cm<7>(h, P); break;
-    case 8: launch_cm<8>(h, P); break;
-    case 9: launch_cm<9>(h, P); break;
-    default: launch_cm<10>(h, P); break;
+    case 1: launch_cm<1>(h, P, prev, nb_prev); break;
+    case 2: launch_cm<2>(h, P, prev, nb_prev); break;
+    case 3: launch_cm<3>(h, P, prev, nb_prev); break;
+    case 4: launch_cm<4>(h, P, prev, nb_prev); break;
+    case 5: launch_cm<5>(h, P, prev, nb_prev); break;
+    case 6: launch_cm<6>(h, P, prev, nb_prev); break;
+    case 7: launch_cm<7>(h, P, prev, nb_prev); break;
+    case 8: launch_cm<8>(h, P, prev, nb_prev); break;
+    case 9: launch_cm<9>(h, P, prev, nb_prev); break;
+    default: launch_cm<10>(h, P, prev, nb_prev); break;
     }
 }
 // returns the number of blocks that wrote partials
