@@ -1238,6 +1238,16 @@ __global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, 
     if (threadIdx.x < m) out[threadIdx.x] = tot;
 }
 
+// First level of a two-level row reduction for very many partial rows (N >= ~3e5: one row per 256 particles): block g totals the
+// rows of its contiguous chunk in fixed order -> out[g][m]; the consumer then totals gridDim.x rows instead of nb.
+__global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int nb, int m, double *out) {
+    __shared__ double scratch[TB];
+    const int per = (nb + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, rows = (r0 + per <= nb) ? per : (nb > r0 ? nb - r0 : 0);
+    const double tot = final_sum(partials + (long long)r0 * m, rows, m, scratch);
+    if (threadIdx.x < m) out[(long long)blockIdx.x * m + threadIdx.x] = tot;
+}
+
 // normalize_weights! as its own pass (src/particle.jl:362-366) for the stand-alone correction call
 __global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;

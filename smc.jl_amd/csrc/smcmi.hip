@@ -35,6 +35,7 @@ static int set_err(int code, const std::string &msg) { g_err = msg; return code;
             return set_err(SMCMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
     } while (0)
 
+static const int ESUM_RED_ROWS = 128;         // rows left by the first level of the energy-sum reduction when there are very many blocks
 struct smcmi_handle {
     smcmi_config cfg{};
     int d = 0, R = 0, npairs = 0;
@@ -55,7 +56,7 @@ struct smcmi_handle {
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
-    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
+    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
     // host-callback split
@@ -168,7 +169,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ESP) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ESP) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * ESP) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -205,7 +206,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_part_cm, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_zbuf,
+                    h->d_part_fin, h->d_part_cm, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
@@ -803,8 +804,15 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     const bool cm = no_select && !tail_only && can_fuse_cm(h) && !no_cm;
     h->fused_cm = cm;
     if (!tail_only) {
-    if (p0 == 0)
-        k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec, (adaptive && !no_pred) ? h->d_esum_part : nullptr, h->d_prof ? h->d_prof + 9 : nullptr);
+    if (p0 == 0) {
+        const double *es = (adaptive && !no_pred) ? h->d_esum_part : nullptr;
+        int es_nb = acc_nb;
+        if (es && acc_nb > 2048) {       // one wave per column in k_stage_begin does not scale to tens of thousands of rows
+            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ESP, h->d_esum_red);
+            es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
+        }
+        k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr);
+    }
     if (adaptive) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);
     else k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
