@@ -779,7 +779,7 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
         ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d;
         grid = 1 + (unsigned)((h->n + RA_T - 1) / RA_T);
     }
-    k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, nullptr, ra,
+    k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, h->d_prof ? h->d_prof + 25 : nullptr, ra,
                                                              sol_slot, h->rec);
 }
 
@@ -981,6 +981,9 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             if (h->d_prof) {
                 long long pr[16];
                 hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
+                long long pq[32];
+                hipMemcpy(pq, h->d_prof, sizeof(pq), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[smcmi]    prepare phase ticks: %lld %lld %lld %lld %lld %lld\n", pq[26] - pq[25], pq[27] - pq[26], pq[28] - pq[27], pq[29] - pq[28], pq[30] - pq[29], pq[31] - pq[30]);
                 fprintf(stderr, "[smcmi]    begin phase ticks: %lld %lld %lld %lld %lld\n", pr[10] - pr[9], pr[11] - pr[10], pr[12] - pr[11], pr[14] - pr[12], 0ll);
             }
             for (int q = 0; q < 2; ++q)
