@@ -2197,6 +2197,9 @@ __global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, con
     col(cl, 0, d + 1)[i] = lp;
 }
 
+// empty kernel (event-overhead calibration, smcmi_run profile mode)
+__global__ void k_noop(const DevState *st) { (void)st; }
+
 __global__ void k_fill(double *p, long long n, double v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
