@@ -896,6 +896,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
     std::vector<hipEvent_t> evs;
+    std::vector<int> ev_iter;      // profile mode: iteration each event pair belongs to, -1 once known to have bracketed a no-op
     // Resampling is predictable on an adaptive schedule (every stage ends at ESS = target x the previous ESS, or x N after a
     // resample), so the host enqueues the selection kernels only where it expects a resample; the device checks the expectation
     // (k_moments_reg) and stalls the run if it was wrong.  SMCMI_NO_SELECT_PREDICT=1 (development) keeps the full list everywhere,
@@ -919,7 +920,9 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     res->solver_stalls = 0; res->select_stalls = 0;
     const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
     int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
+    int dyn_P = solver_passes;                // passes enqueued per stage: raised when stalls are frequent (poorly predictable models)
     while (launched < max_iter && !done) {
+        const int stalls_before = res->solver_stalls;
         const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
             bool no_select = false;
@@ -930,11 +933,11 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 no_select = !rs || sel_mode == 2;
                 pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
             }
-            if (gexec[0] && launched > 1) HIP_TRY(hipGraphLaunch(gexec[no_select ? 1 : 0], h->stream));
+            if (gexec[0] && launched > 1 && dyn_P == solver_passes) HIP_TRY(hipGraphLaunch(gexec[no_select ? 1 : 0], h->stream));
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); }
-                enqueue_stage(h, adaptive, launched < 2 ? first_passes : solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha,
+                if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_iter.push_back(launched); }
+                enqueue_stage(h, adaptive, launched < 2 ? first_passes : dyn_P, rc->resampling_method, rc->n_blocks, rc->alpha,
                               acc_nb, e0, e1, 0, no_select);
             }
             ++launched;
@@ -944,26 +947,32 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         while (done == 2 || done == 3) {
             if (pull_state(h)) return SMCMI_ERR_HIP;
             const int st_i = s.stage;
-            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : solver_passes);
+            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : dyn_P);
             const int zero = 0;
             HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            for (int &it : ev_iter)
+                if (it >= st_i - 2) it = -1;           // the stalled stage and everything behind it were no-ops
+            hipEvent_t r0 = nullptr, r1 = nullptr;
+            if (profile) { hipEventCreate(&r0); hipEventCreate(&r1); evs.push_back(r0); evs.push_back(r1); ev_iter.push_back(st_i - 2); }
             if (done == 2) {
                 // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give
                 // that stage more passes (continuing the same search), and go on from the stage after it.
                 const int more = 8;
-                enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had);
+                enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, had);
                 stall_stage = st_i; stall_p = had + more;
                 res->solver_stalls += 1;
             } else {
                 // A stage enqueued without selection kernels needs to resample after all: nothing past its correction has run.
                 // Run the rest of that stage with the full path, then go on from the stage after it.
-                enqueue_stage(h, adaptive, 0, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had, false, true);
+                enqueue_stage(h, adaptive, 0, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, had, false, true);
                 res->select_stalls += 1;                   // selection stalls (diagnostic)
             }
             launched = st_i - 1;
             HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
+        // two or more stalls in one batch: a stall flushes the rest of the batch, an idle pass launch costs 3 µs - enqueue one more
+        if (res->solver_stalls - stalls_before >= 2 && dyn_P < 4) ++dyn_P;
         if (predict_select) {
             // re-anchor the expectation on the device's ESS / flag after every sync (cheap: the stream is idle here)
             HIP_TRY(hipMemcpy(&s.resampled_last, &h->d_st->resampled_last, sizeof(int), hipMemcpyDeviceToHost));
@@ -1023,7 +1032,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     }
     for (size_t k = 0; k + 1 < evs.size(); k += 2) {
         float ms = 0.f;
-        if ((int)(k / 2) < s.stage - 1 && hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) { res->kernel_ms_mutate += std::max(0.0, (double)ms - ev_overhead_ms); res->n_mutate_launches += 1; }
+        if (ev_iter[k / 2] >= 0 && ev_iter[k / 2] < s.stage - 1 && hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) { res->kernel_ms_mutate += std::max(0.0, (double)ms - ev_overhead_ms); res->n_mutate_launches += 1; }
     }
     for (hipEvent_t e : evs) hipEventDestroy(e);
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
