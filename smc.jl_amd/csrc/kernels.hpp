@@ -581,14 +581,26 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
         }
     }
     double *out = partials_cm + (long long)blockIdx.x * NPF;
+    constexpr int REM = NPF - 64 * (NCH - 1);                                   // accumulators in the last chunk
+    constexpr int REMP = REM <= 1 ? 1 : REM <= 2 ? 2 : REM <= 4 ? 4 : REM <= 8 ? 8 : REM <= 16 ? 16 : REM <= 32 ? 32 : 64;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        double a64[64];
+        if (ch < NCH - 1 || REMP == 64) {
+            double a64[64];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
-        const double t64 = block_reduce_many<64>(a64, red);
-        if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = t64;
-        if (ch == 0 && threadIdx.x < 2) partials_fin[2 * (long long)blockIdx.x + threadIdx.x] = t64;
+            for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
+            const double t64 = block_reduce_many<64>(a64, red);
+            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = t64;
+            if (ch == 0 && threadIdx.x < 2) partials_fin[2 * (long long)blockIdx.x + threadIdx.x] = t64;
+        } else {
+            // short tail (4 sums at d = 10): a REMP-wide butterfly instead of a 64-wide one
+            double ar[REMP];
+#pragma unroll
+            for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
+            const double tr = block_reduce_many<REMP>(ar, red);
+            if (threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = tr;
+            if (ch == 0 && threadIdx.x < 2) partials_fin[2 * (long long)blockIdx.x + threadIdx.x] = tr;
+        }
     }
 }
 
