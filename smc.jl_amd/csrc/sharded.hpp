@@ -77,6 +77,17 @@ extern "C" int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, con
     smcmi_nccl_comm c = nullptr;
     NCCL_TRY(g_rccl.CommInitRank(&c, world, uid, rank));
     h->nccl = c; h->rank = rank; h->world = world;
+    // self-test: every rank contributes (1, rank) -> (world, world (world - 1) / 2); a broken transport fails here, loudly,
+    // instead of producing a wrong posterior later
+    if (!h->d_comm || h->comm_cap < 2) return set_err(SMCMI_ERR_STATE, "communication scratch buffer missing");
+    const double mine[2] = {1.0, (double)rank};
+    double got[2] = {0.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(h->d_comm, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(g_rccl.AllReduce(h->d_comm, h->d_comm, 2, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
+    HIP_TRY(hipMemcpyAsync(got, h->d_comm, sizeof(got), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (got[0] != (double)world || got[1] != 0.5 * (double)world * (double)(world - 1))
+        return set_err(SMCMI_ERR_HIP, "RCCL all-reduce self-test failed (got " + std::to_string(got[0]) + ", " + std::to_string(got[1]) + ")");
     return 0;
 }
 
