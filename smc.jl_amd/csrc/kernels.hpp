@@ -992,6 +992,28 @@ __global__ void __launch_bounds__(TB) k_normalize_weights_n(CloudPtrs cl, const 
     w[i] = (w[i] * n_parts) / st->sumw;
 }
 
+// Systematic resampling, sharded: ancestor (global row) of the first and of the last output slot of every shard r - the rows a
+// shard must receive form the contiguous range [out[2r], out[2r+1]] (thresholds ascend with the slot).  Same threshold and
+// upper_bound as k_resample_gather.  out[0] = -1 when this stage does not resample.  One wavefront, lane r = shard r.
+__global__ void k_anc_ranges(const DevState *st, const double *cum, long long N, long long n_local, int world, unsigned long long seed,
+                             long long *out) {
+    const int r = threadIdx.x;
+    if (st->done || !st->do_resample) { if (r == 0) out[0] = -1; return; }
+    if (r >= world) return;
+    double ua, ub;
+    uniform_pair(seed, 0ull, (unsigned)st->stage, rng_tag(P_RES, 0, 0), ua, ub);
+    for (int e = 0; e < 2; ++e) {
+        const long long slot = e == 0 ? (long long)r * n_local : (long long)(r + 1) * n_local - 1;
+        const double thr = ((double)slot + ua) / (double)N;
+        long long lo = 0, hi = N;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (cum[mid] > thr) hi = mid; else lo = mid + 1;
+        }
+        out[2 * r + e] = lo < N ? lo : N - 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ moments
 // One pass over (θ, W̃): normalise the weights (normalize_weights!, src/particle.jl:362-366: W*N then /ΣW; or 1 after a
 // resample), write them to the weight column and the W history, and accumulate the augmented second-moment matrix

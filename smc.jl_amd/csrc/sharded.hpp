@@ -23,6 +23,10 @@ struct RcclApi {
     int (*CommInitRank)(smcmi_nccl_comm *, int, smcmi_nccl_uid, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, smcmi_nccl_comm, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, smcmi_nccl_comm, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, smcmi_nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, smcmi_nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(smcmi_nccl_comm) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -40,7 +44,8 @@ static int load_rccl() {
     if (!g_rccl.lib) return set_err(SMCMI_ERR_UNSUPPORTED, std::string("cannot load RCCL: ") + dlerror());
 #define SMCMI_SYM(field, name) *(void **)(&g_rccl.field) = dlsym(g_rccl.lib, name)
     SMCMI_SYM(GetUniqueId, "ncclGetUniqueId"); SMCMI_SYM(CommInitRank, "ncclCommInitRank"); SMCMI_SYM(AllReduce, "ncclAllReduce");
-    SMCMI_SYM(AllGather, "ncclAllGather"); SMCMI_SYM(CommDestroy, "ncclCommDestroy"); SMCMI_SYM(GetErrorString, "ncclGetErrorString");
+    SMCMI_SYM(AllGather, "ncclAllGather"); SMCMI_SYM(Send, "ncclSend"); SMCMI_SYM(Recv, "ncclRecv");
+    SMCMI_SYM(GroupStart, "ncclGroupStart"); SMCMI_SYM(GroupEnd, "ncclGroupEnd"); SMCMI_SYM(CommDestroy, "ncclCommDestroy"); SMCMI_SYM(GetErrorString, "ncclGetErrorString");
 #undef SMCMI_SYM
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather)
         return set_err(SMCMI_ERR_UNSUPPORTED, "RCCL library lacks the required entry points");
@@ -137,6 +142,53 @@ struct ShardGroup {
             for (size_t r = 0; r < hs.size(); ++r)
                 HIP_TRY(hipMemcpy(recv(dst) + r * count, send(hs[r]), sizeof(double) * count, hipMemcpyDeviceToDevice));
         }
+        return 0;
+    }
+    // Resample redistribution as an all-to-all-v (systematic resampling: the ancestors of a shard's output slots form one
+    // contiguous global row range [lo[r], hi[r]]).  Every shard receives exactly the rows of that range, column by column, into
+    // the [source shard][column][row] staging layout the all-gather would have produced, so k_resample_gather is unchanged.
+    // ranges = (lo, hi) per shard, identical on every shard (all derive it from the same all-gathered cumulative weights).
+    int exchange_rows(const std::vector<long long> &ranges) {
+        const long long n = hs[0]->n;
+        const int R = hs[0]->R;
+        auto overlap = [&](int needer, int owner, long long &a, long long &b) {     // rows of `owner` that `needer` needs: [a, b)
+            a = std::max(ranges[2 * needer], (long long)owner * n);
+            b = std::min(ranges[2 * needer + 1] + 1, (long long)(owner + 1) * n);
+            return b > a;
+        };
+        if (rccl) {
+            smcmi_handle *h = hs[0];
+            const int me = h->rank;
+            if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+                return set_err(SMCMI_ERR_UNSUPPORTED, "RCCL library lacks send/recv");
+            NCCL_TRY(g_rccl.GroupStart());
+            for (int p = 0; p < world; ++p) {
+                long long a, b;
+                if (overlap(p, me, a, b) && p != me)                                   // my rows that p needs
+                    for (int c = 0; c < R; ++c)
+                        NCCL_TRY(g_rccl.Send(h->cl.buf[0] + (long long)c * n + (a - (long long)me * n), (size_t)(b - a), SMCMI_NCCL_DOUBLE, p, h->nccl, h->stream));
+                if (overlap(me, p, a, b) && p != me)                                   // p's rows that I need
+                    for (int c = 0; c < R; ++c)
+                        NCCL_TRY(g_rccl.Recv(h->d_full_cloud + ((long long)p * R + c) * n + (a - (long long)p * n), (size_t)(b - a), SMCMI_NCCL_DOUBLE, p, h->nccl, h->stream));
+            }
+            NCCL_TRY(g_rccl.GroupEnd());
+            long long a, b;
+            if (overlap(me, me, a, b))
+                HIP_TRY(hipMemcpy2DAsync(h->d_full_cloud + (long long)me * R * n + (a - (long long)me * n), sizeof(double) * n,
+                                         h->cl.buf[0] + (a - (long long)me * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
+                                         hipMemcpyDeviceToDevice, h->stream));
+            return 0;
+        }
+        if (int rc = sync_all()) return rc;
+        for (size_t d = 0; d < hs.size(); ++d)
+            for (size_t o = 0; o < hs.size(); ++o) {
+                long long a, b;
+                if (!overlap((int)d, (int)o, a, b)) continue;
+                HIP_TRY(hipSetDevice(hs[d]->cfg.device));
+                HIP_TRY(hipMemcpy2D(hs[d]->d_full_cloud + (long long)o * R * n + (a - (long long)o * n), sizeof(double) * n,
+                                    hs[o]->cl.buf[0] + (a - (long long)o * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
+                                    hipMemcpyDeviceToDevice));
+            }
         return 0;
     }
 };
@@ -300,7 +352,39 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 HIP_TRY(hipStreamSynchronize(h0->stream));
                 rs = fl[0] && !fl[1];
             }
-            if (rs) {
+            static const char *xchg = getenv("SMCMI_RESAMPLE_EXCHANGE");      // "alltoall": move only the needed rows (development)
+            const bool a2a = rs && xchg && !strcmp(xchg, "alltoall") && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC && g.world > 1;
+            if (rs && a2a) {
+                // all-to-all-v redistribution: weights are all-gathered (N doubles), every shard forms the global cumulative sum and
+                // the ancestor range of every shard's slots; then only the rows inside a shard's range travel to it
+                const size_t nloc = (size_t)h0->n;
+                if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)(h->cl.buf[0] + (long long)(h->R - 1) * h->n); },
+                                          [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return rc2;
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    const long long N = h->cfg.n_parts;
+                    CloudPtrs wcl{};
+                    wcl.buf[0] = wcl.buf[1] = h->d_full_w; wcl.n = N; wcl.R = 1;
+                    k_weight_chunk_sums<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_part_full);
+                    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_full, h->nb_full, h->d_off_full, 0.0, 0);
+                    k_scan_weights<<<h->nb_full, TB, 0, h->stream>>>(wcl, h->d_st, h->d_off_full, h->d_cum_full, 0, h->nb_full);
+                    k_anc_ranges<<<1, 64, 0, h->stream>>>(h->d_st, h->d_cum_full, N, h->n, g.world, h->cfg.seed, h->d_anc);
+                }
+                std::vector<long long> ranges(2 * (size_t)g.world);
+                HIP_TRY(hipSetDevice(h0->cfg.device));
+                HIP_TRY(hipMemcpyAsync(ranges.data(), h0->d_anc, sizeof(long long) * ranges.size(), hipMemcpyDeviceToHost, h0->stream));
+                HIP_TRY(hipStreamSynchronize(h0->stream));
+                if (ranges[0] >= 0) {                      // -1: the device decided not to resample after all
+                    if (int rc2 = g.exchange_rows(ranges)) return rc2;
+                    for (auto *h : g.hs) {
+                        HIP_TRY(hipSetDevice(h->cfg.device));
+                        const long long N = h->cfg.n_parts;
+                        k_resample_gather<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum_full, N, h->cfg.gid0, N,
+                                                                                                rc->resampling_method, h->cfg.seed, 0u, nullptr, h->d_anc,
+                                                                                                h->d_full_cloud, 0, h->n, 1);
+                    }
+                }
+            } else if (rs) {
                 const size_t nloc = (size_t)h0->n;
                 if (int rc2 = g.allgather([](smcmi_handle *h) { return (const double *)(h->cl.buf[0] + (long long)(h->R - 1) * h->n); },
                                           [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return rc2;

@@ -140,3 +140,32 @@ def test_cpp_group_single_shard_equals_the_plain_driver():
         out.append((r["n_stages"], r["logmdd"], e.download_cloud()))
     assert out[0][0] == out[1][0] and out[0][1] == pytest.approx(out[1][1], abs=1e-10)
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-8, atol=1e-10)
+
+
+def test_alltoall_resample_exchange_equals_allgather():
+    """Resample redistribution as an all-to-all-v (only the rows inside a shard's ancestor range travel,
+    SMCMI_RESAMPLE_EXCHANGE=alltoall) must reproduce the all-gather path bit for bit: the gather kernel sees the same rows."""
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+from tests import models
+from smc_jl_amd import Engine, run_group
+spec = models.gauss_spec(d=6)
+n, seed, world = 40000, 13, 4
+engs = []
+for r in range(world):
+    s = Engine(n, 6, seed=seed, max_stages=1500, store_history=False, n_local=n // world, gid0=r * (n // world))
+    s.set_model(spec); s.init_from_prior(); engs.append(s)
+r = run_group(engs, use_fixed_schedule=False, tempering_target=0.9, n_blocks=2, alpha=0.9, n_phi=100)
+full = np.concatenate([s.download_cloud() for s in engs], axis=0)
+print(json.dumps(dict(n=r["n_stages"], rs=r["resamples"], logmdd=r["logmdd"], chk=float(np.sum(full * np.arange(1, full.shape[1] + 1)[None, :])),
+                      chk2=float(np.sum(full[::7] ** 2)))))
+''' % ROOT
+    out = {}
+    for mode in ("allgather", "alltoall"):
+        env = dict(os.environ, SMCMI_RESAMPLE_EXCHANGE=mode)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[mode] = __import__("json").loads(res.stdout.strip().splitlines()[-1])
+    assert out["alltoall"]["rs"] > 3
+    assert out["alltoall"] == out["allgather"]
