@@ -11,7 +11,7 @@ for n in (1000, 5000, 20000):
     best = 1e9
     for rep in range(5):
         e.upload_cloud(P0)
-        r = e.run(use_fixed_schedule=True, n_phi=300)
+        r = e.run(use_fixed_schedule=True, n_phi=300, use_graph=int(os.environ.get("UG", "0")))
         best = min(best, r["seconds"])
     print(n, "stages", r["n_stages"], "resamples", r["resamples"], "ms %.2f" % (1e3 * best), "us/stage %.1f" % (1e6 * best / 299), "logmdd %.4f" % r["logmdd"])
     e.close()
