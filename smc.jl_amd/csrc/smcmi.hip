@@ -923,6 +923,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
     int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
     int dyn_P = solver_passes;                // passes enqueued per stage: raised when stalls are frequent (poorly predictable models)
+    if (rc->solver_passes < 1 && rc->tempering_target < 0.95) dyn_P = 2;   // larger steps: the 8-term model is good to ~1e-3 only, two passes are the norm
     while (launched < max_iter && !done) {
         const int stalls_before = res->solver_stalls;
         const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
