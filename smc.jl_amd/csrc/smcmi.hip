@@ -997,6 +997,9 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 long long pq[32];
                 hipMemcpy(pq, h->d_prof, sizeof(pq), hipMemcpyDeviceToHost);
                 fprintf(stderr, "[smcmi]    prepare phase ticks: %lld %lld %lld %lld %lld %lld\n", pq[26] - pq[25], pq[27] - pq[26], pq[28] - pq[27], pq[29] - pq[28], pq[30] - pq[29], pq[31] - pq[30]);
+                fprintf(stderr, "[smcmi]    mutate phase ticks (block 0):");
+                for (int q = 1; q <= 8; ++q) fprintf(stderr, " %lld", pq[q] - pq[q - 1]);
+                fprintf(stderr, "  total %lld\n", pq[8] - pq[0]);
                 fprintf(stderr, "[smcmi]    begin phase ticks: %lld %lld %lld %lld %lld\n", pr[10] - pr[9], pr[11] - pr[10], pr[12] - pr[11], pr[14] - pr[12], 0ll);
             }
             for (int q = 0; q < 2; ++q)
