@@ -86,6 +86,8 @@ typedef struct {
     int64_t solver_passes;   /* particle passes spent in the adaptive-ϕ solver over the run */
     int32_t solver_stalls;   /* stages that ran out of enqueued solver passes and were resumed by the host */
     int32_t select_stalls;   /* stages enqueued without selection kernels that had to resample after all (host resumed them) */
+    int32_t spec_stalls;     /* stages enqueued without a certificate pass whose predicted ϕ_n was unusable / not verified (resumed) */
+    int32_t reserved_;
 } smcmi_result;
 
 typedef struct {             /* what one correction step reports (smc_main.jl:401-432) */

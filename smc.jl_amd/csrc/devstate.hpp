@@ -14,9 +14,11 @@ constexpr int MAXD = SMCMI_MAX_PARA;
 constexpr int KC = SMCMI_MAX_CAND;          // candidates per ESS pass
 constexpr int NPAIR_MAX = (MAXD + 1) * (MAXD + 2) / 2;
 constexpr int LIK_PAR_MAX = 16;
-constexpr int EK = 8;                       // energy power sums a_0..a_{EK-1}, b_0..b_{EK-1} (ϕ predictor)
-constexpr int ES = 2 * EK;
-constexpr int ESP = ES + 1;                  // per-block partial row: ES energy sums + the block's acceptance sum
+constexpr int ES = 32;                       // doubles per partial row of the mutation epilogue (256 B: two rows per wave-load)
+constexpr int EKA = 16;                      // energy power sums a_0..a_15 = Σ W p^k          (slots 0..15)
+constexpr int EKB = 15;                      //                   b_0..b_14 = Σ W² p^k         (slots 16..30)
+constexpr int EKU = 31;                      // after a resample (all W = 1, b = a): a_0..a_30 (slots 0..30)
+constexpr int EACC = 31;                     // slot 31: the block's acceptance sum
 
 struct LikDev {
     int family;
@@ -71,6 +73,9 @@ struct Solver {
     double lo, hi, glo, ghi;   // bracket with g(lo) >= 0 > g(hi), g = ESS(ϕ) - ESS_bar
     double phi_n;
     double phi0;               // ϕ_{n-1}, the start of the tempering step being solved
+    double gprime;             // dESS/dϕ at the predicted root (Taylor model): turns an ESS mismatch into a ϕ error (spec stages)
+    int spec;                  // 1: ϕ_n is the PREDICTED root, taken without a certificate pass; k_prepare_mutation verifies it
+    int pad2_;
     double cand[KC];
     int cj[KC];                // SCAN: walk step of cand[k] (0 = ϕ_prop, q = schedule[j+q-1]); -1 = predictor ring point
 };

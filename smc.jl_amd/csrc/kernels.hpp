@@ -206,7 +206,7 @@ __device__ inline double *col(const CloudPtrs &c, int which, int column) { retur
 
 // ------------------------------------------------------------------------------------------------ ϕ predictor
 // ESS(ϕ_{n-1} + δ) = A(δ)² / B(δ) with A = Σ W e^{δ e_i}, B = Σ W² e^{2 δ e_i}, e_i = loglh_i - old_loglh_i (helpers.jl:173-181).
-// The mutation epilogue accumulates the power sums a_k = Σ W (e - c)^k, b_k = Σ W² (e - c)^k, k < EK (the common factor
+// The mutation epilogue accumulates the power sums a_k = Σ W (e - c)^k, b_k = Σ W² (e - c)^k, k < 16 / 15 (the common factor
 // e^{δ c} cancels in A²/B), so the next stage can solve the truncated-Taylor model A_K(δ)²/B_K(δ) = ESS_bar for a starting
 // point that is typically within 1e-7..1e-4 of the true root - the solver then only has to certify it with a bracket.
 // uniform = every weight is 1 (the stage resampled): then b_k = a_k and the ES slots hold a_0 .. a_{ES-1} instead, a model of
@@ -218,11 +218,12 @@ __device__ inline void energy_terms(double (&es)[ES], double W, double like, dou
     double pk = 1.0;
     if (uniform) {
 #pragma unroll
-        for (int k = 0; k < ES; ++k) { es[k] = w1 * pk; pk *= pp; }
+        for (int k = 0; k < EKU; ++k) { es[k] = w1 * pk; pk *= pp; }
     } else {
 #pragma unroll
-        for (int k = 0; k < EK; ++k) { es[k] = w1 * pk; es[EK + k] = w2 * pk; pk *= pp; }
+        for (int k = 0; k < EKA; ++k) { es[k] = w1 * pk; if (k < EKB) es[EKA + k] = w2 * pk; pk *= pp; }
     }
+    es[EACC] = 0.0;                          // the caller puts the particle's acceptance value here
 }
 
 // Block-wide fixed-order reduction of ES accumulators for any block of `nw` wavefronts; thread t < ES gets total t.
@@ -241,44 +242,54 @@ __device__ inline double block_reduce_es(double (&a)[ES], double *red, int nw) {
     return tot;
 }
 
-// Root δ > 0 of the Taylor model G(δ) = A_K(δ)² - ESS_bar B_K(δ) (one thread; polynomial Newton, no transcendentals).
-// a[k] = Σ W p^k, b[k] = Σ W² p^k, k < KK.  NaN when the model is unusable.
-template <int KK>
-__device__ inline double predict_delta(const double *a, const double *b, double T) {
+// Root δ > 0 of the Taylor model G(δ) = A(δ)² - ESS_bar B(δ) by one wavefront without serial polynomial evaluation: lane (g, k)
+// owns one coefficient - g = 0: a_k / k! of A, g = 1: b_k 2^k / k! of B (after a resample b_k = a_k and the slots hold 31 orders
+// of a) - forms its term c x^k by binary powering, and the four sums A = Σ term, x A' = Σ k term (same for B) come from 5-step
+// xor butterflies inside the 32-lane halves: a Newton step is ~40 dependent instructions.  Every lane returns the same x (NaN
+// when the model is unusable); *gprime = dESS/dδ at the root of the model.
+__device__ inline double predict_delta_wave(const double *es, bool uniform, double T, double *gprime) {
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    if (!(a[0] > 0.0) || !(b[0] > 0.0) || !(T > 0.0)) return nan;
-    double ca[KK], cb[KK];               // a_k / k!,  b_k 2^k / k!
-    double inv = 1.0, p2 = 1.0;
-#pragma unroll
-    for (int k = 0; k < KK; ++k) {
-        if (k > 0) { inv *= 1.0 / (double)k; p2 *= 2.0; }      // compile-time constants after unrolling
-        ca[k] = a[k] * inv; cb[k] = b[k] * (p2 * inv);
-    }
-    const double G0 = ca[0] * ca[0] - T * cb[0];
+    const int lane = threadIdx.x & 63, grp = lane >> 5, k = lane & 31;
+    const int KT = uniform ? EKU : (grp == 0 ? EKA : EKB);   // terms of this lane's polynomial
+    double inv = 1.0;                                     // 1 / k!
+    for (int q = 2; q <= k; ++q) inv /= (double)q;
+    double c = 0.0;
+    if (k < KT) c = (grp == 0 ? es[k] : (uniform ? es[k] : es[EKA + k])) * inv;
+    if (grp) c = ldexp(c, k);
+    auto bc = [&](double v, int src) { return __shfl(v, src, 64); };
+    const double ca0 = bc(c, 0), ca1 = bc(c, 1), ca2 = bc(c, 2), cb0 = bc(c, 32), cb1 = bc(c, 33), cb2 = bc(c, 34);
+    *gprime = nan;
+    if (!(ca0 > 0.0) || !(cb0 > 0.0) || !(T > 0.0)) return nan;
+    const double G0 = ca0 * ca0 - T * cb0;
     if (!(G0 > 0.0)) return nan;
-    const double G1 = 2.0 * ca[0] * ca[1] - T * cb[1];
-    const double G2h = ca[1] * ca[1] + 2.0 * ca[0] * ca[2] - T * cb[2];
+    const double G1 = 2.0 * ca0 * ca1 - T * cb1;
+    const double G2h = ca1 * ca1 + 2.0 * ca0 * ca2 - T * cb2;
     const double disc = G1 * G1 - 4.0 * G2h * G0;
     double x;
     if (disc >= 0.0 && -G1 + sqrt(disc) > 0.0) x = 2.0 * G0 / (-G1 + sqrt(disc));
     else if (G1 < 0.0) x = -G0 / G1;
     else return nan;
-    for (int it = 0; it < 3; ++it) {
-        double A = ca[KK - 1], B = cb[KK - 1], dA = (double)(KK - 1) * ca[KK - 1], dB = (double)(KK - 1) * cb[KK - 1];
+    const double kd = (double)k;
+    double A = 0.0, SA = 0.0, B = 0.0, SB = 0.0;
+    for (int it = 0; it < 4; ++it) {
+        double p = 1.0, xb = x;
 #pragma unroll
-        for (int k = KK - 2; k >= 0; --k) {
-            A = A * x + ca[k];
-            B = B * x + cb[k];
-            if (k >= 1) { dA = dA * x + (double)k * ca[k]; dB = dB * x + (double)k * cb[k]; }
-        }
-        const double G = A * A - T * B, dG = 2.0 * A * dA - T * dB;
+        for (int bit = 0; bit < 5; ++bit) { if ((k >> bit) & 1) p *= xb; xb *= xb; }
+        double term = c * p, kterm = kd * term;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) { term += __shfl_xor(term, off, 64); kterm += __shfl_xor(kterm, off, 64); }
+        A = bc(term, 0); SA = bc(kterm, 0); B = bc(term, 32); SB = bc(kterm, 32);
+        if (it == 3) break;                               // the last evaluation only refreshes A, B and the slopes at the final x
+        const double G = A * A - T * B, dG = (2.0 * A * SA - T * SB) / x;
         if (!(dG < 0.0) || !(A > 0.0) || !(B > 0.0)) return nan;
         const double xn = x - G / dG;
         if (!(xn > 0.0) || !(xn < 1e300)) return nan;
         x = xn;
     }
+    *gprime = (2.0 * A * (SA / x) * B - A * A * (SB / x)) / (B * B);
     return x;
 }
+
 constexpr int NPR = 3;                       // rings on each side of the predicted root, as fractions of the predicted step
 constexpr double PRING[NPR] = {0x1p-10, 0x1p-20, 0x1p-30};
 constexpr int NRL = 2 * NPR + 1;             // lanes that own ring points in k_stage_begin
@@ -530,7 +541,7 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
 template <int D>
 __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *st, const double *sched, const double *partials_prev,
                                                         double *partials_fin, double *partials_cm, int nb_prev, int p, double *hist_w,
-                                                        long long hist_ld) {
+                                                        long long hist_ld, double *wt_out = nullptr) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
     constexpr int NCH = (NPF + 63) / 64;
     __shared__ double red[(TB / 64) * 64];
@@ -570,7 +581,7 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
         const double v = wi * inc;
         acc[0] += v;
         acc[1] += v * v;
-        w[i] = v;
+        if (wt_out) wt_out[i] = v; else w[i] = v;        // spec stage: W stays intact until the prediction is verified
         if (hist) hist_w[(long long)stage_col * hist_ld + i] = inc;
         int q = 2;
 #pragma unroll
@@ -604,6 +615,23 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
     }
 }
 
+// A spec stage whose prediction could not be used (or failed verification) is resumed by the certificate-pass path: rebuild the
+// plain schedule-walk candidates in solver copy 0 from the loop scalars (ϕ_prop and j are only committed by post_write, so they
+// still are the values the stage started with; ESS_bar / g(ϕ_{n-1}) were stored by k_stage_begin).
+__global__ void k_solver_rearm(DevState *st, const double *sched) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Solver &S = st->sol[0];
+    const int j = st->j, n_phi = st->rp.n_phi;
+    const double phi_prop = st->phi_prop;
+    S.mode = MODE_SCAN; S.spec = 0; S.unconverged = 0;
+    S.lo = st->phi_prev; S.hi = phi_prop; S.ghi = 0.0; S.phi0 = st->phi_prev;
+    S.j = j; S.phi_prop = phi_prop;
+    int nv = 0;
+    S.cand[nv] = phi_prop; S.cj[nv] = 0; ++nv;
+    for (int q = 1; j + q - 2 < n_phi && nv < KC; ++q) { S.cand[nv] = sched[j + q - 2]; S.cj[nv] = q; ++nv; }
+    S.n_valid = nv;
+}
+
 // decision of the last solver pass without a correction (stand-alone smcmi_solve_phi)
 __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double *sched, const double *partials_prev, int nb_prev, int p) {
     __shared__ double scratch[TB];
@@ -618,24 +646,39 @@ __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double
 // schedule or arm the adaptive solver with its first candidates (solver copy 0).
 constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
 __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
-                                                    int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr) {
+                                                    int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
+                                                    int spec_expected = 0) {
     __shared__ double scratch[BT];
     SMCMI_STAMP(prof, 0);
-    __shared__ double s_es[ESP];
+    __shared__ double s_es[ES];
     __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
     // one round of scalar loads
     const int done = st->done, stage0 = st->stage, rs = st->do_resample, n_phi = st->rp.n_phi, fixed = st->rp.use_fixed_schedule;
     const int max_stages = st->rp.max_stages, rl = st->resampled_last, j = st->j;
     const double phi_n = st->phi_n, phi_prop = st->phi_prop, ess_prev = st->ess_prev, target = st->rp.tempering_target;
     const double N = (double)st->rp.n_parts, e_center = st->e_center;
-    // Energy sums and (last column) the acceptance sum of the previous mutation: wave w totals column w (wave 0 also the last
-    // one).  Issued before anything else - the partials come cold from another die (~2.5 µs), the scalars overlap with them.
+    // Energy sums + acceptance sum of the previous mutation: rows of ES = 32 doubles.  Thread t owns column t % 32 of the rows
+    // t / 32, t / 32 + 32, ...: a wave-load reads two whole rows (512 B, no line is fetched twice - one wavefront per COLUMN
+    // fetched every line eight times and was bandwidth-bound on the one CU); all loads of a thread are issued before the first
+    // use, together with the scalar loads above.  The 32 row-groups are combined in fixed order through LDS.
     const bool try_es = esum_partials != nullptr && acc_nb > 0;
-    double es_col = 0.0, es_last = 0.0;
     if (try_es) {
-        const int w = threadIdx.x >> 6;
-        if (w == 0) wave_column_sum2(esum_partials, acc_nb, ESP, 0, ES, es_col, es_last);
-        else if (w < ES) es_col = wave_column_sum(esum_partials, acc_nb, ESP, w);
+        const int colx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = 0.0;
+        int b = rg;
+        for (; b + 15 * 32 < acc_nb; b += 16 * 32) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] += esum_partials[(long long)(b + q * 32) * ES + colx];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (b + q * 32 < acc_nb) a[q] += esum_partials[(long long)(b + q * 32) * ES + colx];
+        double v = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+                   (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+        v += __shfl_xor(v, 32, 64);                      // the wave's two row-groups
+        if ((threadIdx.x & 63) < 32) scratch[(threadIdx.x >> 6) * 32 + colx] = v;
     }
     if (done) return;
     SMCMI_STAMP(prof, 1);
@@ -648,11 +691,14 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     const double ph_fixed = (fixed && i <= n_phi) ? sched[i - 1] : 0.0;
     // Σ accept over blocks of the previous mutation (update_acceptance_rate!, src/particle.jl:466-468)
     const bool have_es = try_es && stage0 > 1 && !fixed;
-    if (have_es && (threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        if (w < ES) s_es[w] = es_col;
-        if (w == 0) s_es[ES] = es_last;
+    __syncthreads();
+    if (have_es && threadIdx.x < ES) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int g = 0; g < BT / 64; ++g) tsum += scratch[g * 32 + threadIdx.x];
+        s_es[threadIdx.x] = tsum;
     }
+    __syncthreads();
     double asum = 0.0;
     if (!have_es && acc_nb > 0) asum = final_sum1(acc_partials, acc_nb, scratch);
     if (threadIdx.x < 64) s_sw[threadIdx.x] = swv;
@@ -661,7 +707,7 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     // Wavefront 0 finishes: the scalar bookkeeping is lane 0's, the candidate set is built by all lanes (no serial loops).
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
-    if (have_es) asum = s_es[ES];
+    if (have_es) asum = s_es[EACC];
     if (lane == 0) {
         if (acc_nb > 0 && stage0 > 1) {
             const double a = asum / N;
@@ -693,9 +739,9 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
         S.j = j; S.phi_prop = phi_prop;
     }
     // predictor: root of the Taylor model (every lane computes the same scalar), then rings around it
-    double pd = __longlong_as_double(0x7ff8000000000000ll);
+    double pd = __longlong_as_double(0x7ff8000000000000ll), gp = pd;
     if (have_es) {
-        pd = rs ? predict_delta<ES>(s_es, s_es, ess_bar) : predict_delta<EK>(s_es, s_es + EK, ess_bar);
+        pd = predict_delta_wave(s_es, rs != 0, ess_bar, &gp);
         const double ec = e_center + s_es[1] / s_es[0];        // weighted mean energy: centre for the next epilogue
         if (lane == 0 && fabs(ec) < 1e300) st->e_center = ec;
     }
@@ -714,6 +760,25 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     const unsigned long long above = __ballot(lane <= 62 && lane <= q_end && wl > ph);
     int qstar = above ? (__ffsll((long long)above) - 1) : (q_end <= 62 ? q_end : -1);
     if (qstar < 0) use_pred = false;                         // prediction beyond the staged window: plain walk
+    if (lane == 0) { S.spec = 0; S.gprime = gp; }
+    if (spec_expected) {
+        // Predict -> correct -> verify: the stage was enqueued WITHOUT a certificate pass.  ϕ_n is the root of the Taylor model
+        // (accurate to ~1e-14 of the step with 16 power sums per weight order); the reference's schedule walk (helpers.jl:29-32:
+        // advance ϕ_prop while ESS(ϕ_prop) >= target) is decided by comparing the walk steps with it - ESS falls with ϕ - and
+        // k_prepare_mutation verifies the ESS the correction actually produced.  No usable prediction: stall, the host resumes
+        // the stage with the certificate-pass path (candidates are prepared below as usual).
+        const bool none_above = !above;
+        if (use_pred && gp < 0.0) {
+            const double step_q = __shfl(wl, qstar, 64);                 // first walk step above the prediction (or the last step)
+            if (lane == 0) {
+                S.mode = MODE_FINAL; S.spec = 1; S.n_valid = 0;
+                S.phi_prop = step_q; S.j = j + qstar;
+                S.phi_n = none_above ? step_q : ph;                      // walk exhausted with ESS still above the target: ϕ_n = ϕ_prop (= 1)
+            }
+            return;
+        }
+        if (lane == 0) st->done = 4;
+    }
     double x = 0.0;
     int cq = -1;
     bool keep = false;
@@ -1439,7 +1504,16 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
             if (pin.smode != MODE_FINAL) { st->err = SMCMI_ERR_BRACKET; st->done = 1; }
             else {
                 const double ess = s_cm[0] * s_cm[0] / s_cm[1];
-                if (!isnan(ess) && ess < pin.thr) st->done = 3;
+                const Solver &Sv = st->sol[sol_slot];
+                bool verified = true;
+                if (Sv.spec) {
+                    // the correction ran at the PREDICTED ϕ_n: accept it only if the ESS it produced puts the true root within
+                    // phi_rtol (|ESS - ESS_bar| / |dESS/dϕ| <= rtol ϕ_n), or, for ϕ_n = 1 by exhaustion, ESS >= ESS_bar
+                    if (Sv.phi_n < 1.0) verified = fabs(ess - Sv.ess_bar) <= fabs(Sv.gprime) * st->rp.phi_rtol * Sv.phi_n;
+                    else verified = ess >= Sv.ess_bar * (1.0 - 1e-13);
+                }
+                if (!verified) st->done = 4;
+                else if (!isnan(ess) && ess < pin.thr) st->done = Sv.spec ? 4 : 3;   // (a spec stage keeps W̃ in scratch: redo it in full)
                 else if (post_write(st, rec, pin, s_cm[0], s_cm[1]) == 0) { s_go = 1; s_c = st->c; }
             }
         }
@@ -1627,6 +1701,7 @@ struct MutArgs {
                                // normalize_weights! (src/particle.jl:362-366) here and write the W history column
     double *hist_W;
     long long hist_ld;
+    const double *wt;          // normalize: read W̃ from here instead of the weight column (spec stages)
 };
 
 template <int MODE>
@@ -1796,15 +1871,15 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     if (MODE == 0 && ma.esum) {                      // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
         energy_terms(es, live ? col(cl, src, d + 4)[i] : 0.0, like, like_prev, st->e_center, live, st->do_resample != 0);
+        es[EACC] = acc_val;
         const double tot = block_reduce_es(es, th, T / 64);          // θ staging area is dead by now ((T/64) ES <= d T)
-        if (tid < ES) ma.esum[(long long)blockIdx.x * ESP + tid] = tot;
+        if (tid < ES) ma.esum[(long long)blockIdx.x * ES + tid] = tot;
     }
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
         for (int w = 0; w < T / 64; ++w) s += red[w];
         acc_partials[blockIdx.x] = s;
-        if (ma.esum) ma.esum[(long long)blockIdx.x * ESP + ES] = s;
     }
 }
 
@@ -1881,7 +1956,7 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
         for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[i];
         like = col(cl, src, D)[i]; lprior = col(cl, src, D + 1)[i]; like_prev = col(cl, src, D + 2)[i];
     }
-    double w_part = (live && (ma.esum || ma.normalize)) ? col(cl, src, D + 4)[i] : 0.0;
+    double w_part = (live && (ma.esum || ma.normalize)) ? ((ma.normalize && ma.wt) ? ma.wt[i] : col(cl, src, D + 4)[i]) : 0.0;
     if (ma.normalize) {
         w_part = (w_part * nrm_N) / nrm_sumw;                             // W·N then /ΣW̃, two roundings like the reference
         if (live) {
@@ -2161,15 +2236,15 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     if (ma.esum) {                                   // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
         energy_terms(es, w_part, like, like_prev, e_center, live, es_uniform);
+        es[EACC] = acc_val;
         const double tot = block_reduce_es(es, l_dat, T / 64);       // likelihood data in LDS is dead by now
-        if (tid < ES) ma.esum[(long long)blockIdx.x * ESP + tid] = tot;
+        if (tid < ES) ma.esum[(long long)blockIdx.x * ES + tid] = tot;
     }
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
         for (int w = 0; w < T / 64; ++w) s += red[w];
         acc_partials[blockIdx.x] = s;
-        if (ma.esum) ma.esum[(long long)blockIdx.x * ESP + ES] = s;
     }
     SMCMI_PROF(9);
 #undef SMCMI_PROF

@@ -196,9 +196,9 @@ struct ShardGroup {
 static int ensure_shard_buffers(smcmi_handle *h) {
     const long long N = h->cfg.n_parts;
     if (!h->d_tot_ess) {
-        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs + 2) || dmalloc(&h->d_tot_acc, ESP))
+        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs + 2) || dmalloc(&h->d_tot_acc, ES))
             return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * ESP));
+        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * ES));
     }
     if (!h->d_cum_full) {
         if (dmalloc(&h->d_cum_full, N)) return SMCMI_ERR_HIP;
@@ -285,7 +285,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 for (auto *h : g.hs) {
                     HIP_TRY(hipSetDevice(h->cfg.device));
                     h->run_adaptive = predict;
-                    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec, predict ? h->d_tot_acc : nullptr);
+                    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + EACC, 1, h->rec, predict ? h->d_tot_acc : nullptr);
                 }
             for (int p = p0; p < P; ++p) {
                 for (auto *h : g.hs) {
@@ -316,11 +316,11 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 launch_prepare_in_run(h, h->d_tot_mom, 1, 3, fin_slot);
                 const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
-                if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ESP, h->d_tot_acc);
-                else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + ES);
+                if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc);
+                else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC);
             }
-            if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ESP)) return rc2; }
-            else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, 1)) return rc2;
+            if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ES)) return rc2; }
+            else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1)) return rc2;
             return 0;
         }
         if (mode == 1) {
@@ -414,11 +414,11 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             HIP_TRY(hipSetDevice(h->cfg.device));
             launch_prepare_in_run(h, h->d_tot_mom, 1, 2);
             const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
-            if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ESP, h->d_tot_acc);
-            else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + ES);
+            if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc);
+            else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC);
         }
-        if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ESP)) return rc2; }
-        else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, 1)) return rc2;
+        if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ES)) return rc2; }
+        else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1)) return rc2;
         return 0;
     };
 
@@ -476,7 +476,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     // fold the last acceptance rate, close the run
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + ES, 1, h->rec);
+        k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + EACC, 1, h->rec);
         if (pull_state(h)) return SMCMI_ERR_HIP;
         h->last_n_stages = h->h_st.stage;
     }

@@ -54,7 +54,7 @@ struct smcmi_handle {
     // scratch
     int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
-    double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
+    double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_wt = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
@@ -71,6 +71,7 @@ struct smcmi_handle {
     int last_n_stages = 1;
     int launch_nb = 1;
     size_t zbuf_cap = 0;         // doubles allocated in d_zbuf (random numbers drawn ahead of the mutation, kernels.hpp RngAhead)
+    bool spec_stage = false;     // the enqueued stage takes the predicted ϕ_n without a certificate pass (W̃ goes to d_wt)
     bool fused_cm = false;       // the enqueued stage ran k_correct_moments: the mutation kernel normalises the weights
     bool rng_ahead = false;      // the enqueued stage's k_prepare_mutation fills d_zbuf and the mutation kernel reads it
     bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
@@ -166,10 +167,10 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;
     h->comm_cap = std::max<long long>(2 * KC, h->npairs) + 8;
     h->prep_lds = (size_t)(((h->npairs + 63) / 64) * 64 + 4 * h->d * h->d + 8) * sizeof(double);
-    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) ||
+    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) || dmalloc(&h->d_wt, n) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ESP) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * ESP) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * ES) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -206,7 +207,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_part_cm, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_zbuf,
+                    h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
@@ -550,7 +551,8 @@ static bool can_fuse_cm(const smcmi_handle *h) { return h->d <= 10; }
 // prev / nb_prev: partials of the last solver pass (or, sharded, their all-reduced totals as one row)
 template <int D>
 static void launch_cm(smcmi_handle *h, int P, const double *prev, int nb_prev) {
-    k_correct_moments<D><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, prev, h->d_part_fin, h->d_part_cm, nb_prev, P, h->d_hist_w, h->n);
+    k_correct_moments<D><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, prev, h->d_part_fin, h->d_part_cm, nb_prev, P, h->d_hist_w, h->n,
+                                                     h->spec_stage ? h->d_wt : nullptr);
 }
 static void launch_correct_moments(smcmi_handle *h, int P, const double *prev = nullptr, int nb_prev = 0) {
     if (!prev) { prev = h->d_part_ess[(P + 1) & 1]; nb_prev = h->nb_e; }
@@ -656,6 +658,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     ma.zbuf = (!standalone && h->rng_ahead && use_reg_mutate(h)) ? h->d_zbuf : nullptr;
     ma.normalize = (!standalone && h->fused_cm) ? 1 : 0;
     ma.hist_W = h->d_hist_W; ma.hist_ld = h->n;
+    ma.wt = (!standalone && h->fused_cm && h->spec_stage) ? h->d_wt : nullptr;
     switch (h->d) {
     case 1: launch_reg<1>(h, ma, standalone); break;
     case 2: launch_reg<2>(h, ma, standalone); break;
@@ -791,10 +794,12 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
 // kernel takes the decision itself and stalls the run (done = 3) if selection is needed after all.
 // tail_only: resume such a stage from k_post_correct on (the correction is already done).
 static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int n_blocks, double alpha, int acc_nb,
-                          hipEvent_t ev0, hipEvent_t ev1, int p0 = 0, bool no_select = false, bool tail_only = false) {
+                          hipEvent_t ev0, hipEvent_t ev1, int p0 = 0, bool no_select = false, bool tail_only = false, bool spec = false,
+                          bool skip_begin = false) {
     const long long n = h->n;
     hipStream_t s = h->stream;
-    const int P = adaptive ? p0 + solver_passes : 0;
+    // spec: predict -> correct -> verify (kernels.hpp k_stage_begin): no certificate pass is enqueued at all - 4 launches
+    const int P = (adaptive && !spec) ? p0 + solver_passes : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     h->run_adaptive = adaptive;
     const int fin_slot = P == 0 ? 0 : (P & 1);
@@ -803,17 +808,19 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     // takes the post-correction decision, the mutation kernel normalises the weights (5 launches per stage)
     const bool cm = no_select && !tail_only && can_fuse_cm(h) && !no_cm;
     h->fused_cm = cm;
+    h->spec_stage = spec && cm;
     if (!tail_only) {
-    if (p0 == 0) {
+    if (p0 == 0 && !skip_begin) {
         const double *es = (adaptive && !no_pred) ? h->d_esum_part : nullptr;
         int es_nb = acc_nb;
         if (es && acc_nb > 2048) {       // one wave per column in k_stage_begin does not scale to tens of thousands of rows
-            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ESP, h->d_esum_red);
+            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red);
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
         }
-        k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr);
+        k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
+                                       h->spec_stage ? 1 : 0);
     }
-    if (adaptive) enqueue_solver(h, P, p0);
+    if (adaptive && !h->spec_stage) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);
     else k_pass<1, true><<<h->nb_e, TB, 0, s>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[(P + 1) & 1], h->d_part_fin, h->nb_e, P, h->d_hist_w, n);
     }
@@ -905,12 +912,15 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     // (Fixed schedules: extrapolating the ESS decay was tried and dropped - CAPM-like posteriors collapse within two or three
     // stages, 19 of 20 resamples stalled, and the per-batch sync it needs makes short stages host-bound.)
     const bool predict_select = adaptive && can_fuse_post(h) && sel_mode != 1;
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};       // [0] full stage, [1] stage without selection kernels
+    static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
+    const bool spec_ok = predict_select && can_fuse_cm(h) && !no_spec && !getenv("SMCMI_NO_PREDICTOR") &&
+                         !getenv("SMCMI_NO_CORRECT_MOMENTS");
+    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // [0] full stage, [1] without selection kernels, [2] predict-correct-verify
     if (rc->use_graph == 1) {
-        for (int v = 0; v < (predict_select ? 2 : 1); ++v) {
+        for (int v = 0; v < (spec_ok ? 3 : predict_select ? 2 : 1); ++v) {
             HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, v == 1);
+            enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, v >= 1, false, v == 2);
             HIP_TRY(hipStreamEndCapture(h->stream, &graph[v]));
             HIP_TRY(hipGraphInstantiate(&gexec[v], graph[v], nullptr, nullptr, 0));
         }
@@ -919,7 +929,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     int pred_rl = 0;                                                                       // resampled_last_period
     const auto t0 = std::chrono::steady_clock::now();
     int launched = 0, done = 0;
-    res->solver_stalls = 0; res->select_stalls = 0;
+    res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0;
     const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
     int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
     int dyn_P = solver_passes;                // passes enqueued per stage: raised when stalls are frequent (poorly predictable models)
@@ -936,18 +946,19 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 no_select = !rs || sel_mode == 2;
                 pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
             }
-            if (gexec[0] && launched > 1 && dyn_P == solver_passes) HIP_TRY(hipGraphLaunch(gexec[no_select ? 1 : 0], h->stream));
+            const bool spec = spec_ok && no_select && launched >= 2;
+            if (gexec[0] && launched > 1 && dyn_P == solver_passes) HIP_TRY(hipGraphLaunch(gexec[spec ? 2 : (no_select ? 1 : 0)], h->stream));
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_iter.push_back(launched); }
                 enqueue_stage(h, adaptive, launched < 2 ? first_passes : dyn_P, rc->resampling_method, rc->n_blocks, rc->alpha,
-                              acc_nb, e0, e1, 0, no_select);
+                              acc_nb, e0, e1, 0, no_select, false, spec);
             }
             ++launched;
         }
         HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        while (done == 2 || done == 3) {
+        while (done == 2 || done == 3 || done == 4) {
             if (pull_state(h)) return SMCMI_ERR_HIP;
             const int st_i = s.stage;
             const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : dyn_P);
@@ -957,7 +968,15 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 if (it >= st_i - 2) it = -1;           // the stalled stage and everything behind it were no-ops
             hipEvent_t r0 = nullptr, r1 = nullptr;
             if (profile) { hipEventCreate(&r0); hipEventCreate(&r1); evs.push_back(r0); evs.push_back(r1); ev_iter.push_back(st_i - 2); }
-            if (done == 2) {
+            if (done == 4) {
+                // A stage enqueued without a certificate pass had no usable prediction, or the ESS its correction produced did
+                // not verify it: nothing of the stage has been committed (W̃ went to scratch).  Re-arm the solver with the plain
+                // schedule walk and run the stage through the certificate-pass path.
+                k_solver_rearm<<<1, 64, 0, h->stream>>>(h->d_st, h->d_sched);
+                enqueue_stage(h, adaptive, first_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, 0, false, false, false, true);
+                stall_stage = st_i; stall_p = first_passes;
+                res->spec_stalls += 1;
+            } else if (done == 2) {
                 // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give
                 // that stage more passes (continuing the same search), and go on from the stage after it.
                 const int more = 8;
@@ -1011,7 +1030,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     const auto t1 = std::chrono::steady_clock::now();
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < 3; ++v)
         if (gexec[v]) { hipGraphExecDestroy(gexec[v]); hipGraphDestroy(graph[v]); }
     res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;
     // An event pair brackets [previous kernel done -> this kernel done]: dispatch of the kernel included.  Calibrate that

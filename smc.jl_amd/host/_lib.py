@@ -41,7 +41,7 @@ class Result(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("resamples", C.c_int32), ("logmdd", C.c_double), ("c", C.c_double),
                 ("accept", C.c_double), ("seconds", C.c_double), ("kernel_ms_mutate", C.c_double),
                 ("n_mutate_launches", C.c_int32), ("solver_passes", C.c_int64), ("solver_stalls", C.c_int32),
-                ("select_stalls", C.c_int32)]
+                ("select_stalls", C.c_int32), ("spec_stalls", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class StageStats(C.Structure):

@@ -181,7 +181,7 @@ class Engine:
         check(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
         return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
                     seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
-                    solver_passes=res.solver_passes, solver_stalls=res.solver_stalls, select_stalls=res.select_stalls)
+                    solver_passes=res.solver_passes, solver_stalls=res.solver_stalls, select_stalls=res.select_stalls, spec_stalls=res.spec_stalls)
 
     def _run_config(self, n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
                     use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, sync_every, use_graph,
@@ -194,7 +194,7 @@ class Engine:
     def _result(res):
         return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
                     seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
-                    solver_passes=res.solver_passes, solver_stalls=res.solver_stalls, select_stalls=res.select_stalls)
+                    solver_passes=res.solver_passes, solver_stalls=res.solver_stalls, select_stalls=res.select_stalls, spec_stalls=res.spec_stalls)
 
     # ---- sharded whole-loop drivers (csrc/sharded.hpp) ---------------------------------------------------
     def comm_init(self, rank, world, unique_id):

@@ -22,8 +22,8 @@ struct RunConfig
 end
 mutable struct Result
     n_stages::Int32; resamples::Int32; logmdd::Float64; c::Float64; accept::Float64; seconds::Float64
-    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32
-    Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0)
+    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32; spec_stalls::Int32; reserved_::Int32
+    Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
 end
 
 check(rc) = rc == 0 ? nothing : error("smcmi error $rc: " * unsafe_string(ccall((:smcmi_last_error, LIB), Cstring, ())))

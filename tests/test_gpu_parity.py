@@ -486,7 +486,8 @@ def test_solver_stall_resume_is_exact():
     for P in (1, 2, 12):
         eng = make_engine(spec, 8192, seed=21, max_stages=2000)
         eng.init_from_prior()
-        r = eng.run(use_fixed_schedule=False, tempering_target=0.9, n_phi=100, solver_passes=P, sync_every=4)
+        # phi_rtol < 0 asks for the root to adjacent floats: more passes than the one or two enqueued -> stalls
+        r = eng.run(use_fixed_schedule=False, tempering_target=0.9, n_phi=100, solver_passes=P, sync_every=4, phi_rtol=-1.0)
         out.append((r, eng.stage_records(r["n_stages"]), eng.download_cloud()))
         eng.close()
     assert out[0][0]["solver_stalls"] > 0 and out[2][0]["solver_stalls"] == 0
@@ -516,7 +517,7 @@ eng.init_from_prior()
 r = eng.run(use_fixed_schedule=False, tempering_target=0.9, n_phi=100, sync_every=8)
 rec = eng.stage_records(r["n_stages"])
 P = eng.download_cloud()
-print(json.dumps(dict(n=r["n_stages"], logmdd=r["logmdd"], resamples=r["resamples"], sel=r["select_stalls"], ess=rec["ess"].tolist(),
+print(json.dumps(dict(n=r["n_stages"], logmdd=r["logmdd"], resamples=r["resamples"], sel=r["select_stalls"] + r["spec_stalls"], ess=rec["ess"].tolist(),
                       chk=float(np.sum(P * np.arange(1, P.shape[1] + 1)[None, :])))))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
@@ -525,7 +526,9 @@ print(json.dumps(dict(n=r["n_stages"], logmdd=r["logmdd"], resamples=r["resample
         res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         out[mode] = json.loads(res.stdout.strip().splitlines()[-1])
-    assert out["0"]["sel"] == 0 and out["1"]["sel"] == 0 and out["2"]["sel"] == out["2"]["resamples"] > 0
+    # (stalls = stages resumed by the host: a wrongly expected "no resample" stage, or - mode 0, first stages - a stage whose
+    # predicted ϕ could not be used)
+    assert out["0"]["sel"] <= 3 and out["1"]["sel"] == 0 and out["2"]["sel"] >= out["2"]["resamples"] > 0
     for mode in ("1", "2"):          # the fused and unfused kernels sum in different orders: agreement to rounding
         assert out[mode]["n"] == out["0"]["n"] and out[mode]["resamples"] == out["0"]["resamples"]
         assert out[mode]["logmdd"] == pytest.approx(out["0"]["logmdd"], abs=1e-9)
