@@ -264,14 +264,17 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     // of passes stalls the run (done = 3 / 2) identically on every rank and is resumed at the next host sync.  Fixed schedules
     // cannot be predicted: they keep one flag read per stage.
     // mode 0: full stage with selection path; 1: no selection expected; 2: tail only (from k_post_correct on; selection path)
-    auto enqueue = [&](int p0, int P, int mode) -> int {
+    // spec: predict -> correct -> verify (no certificate pass, no all-reduce for it: 2 collectives per stage);
+    // skip_begin: resume of such a stage through the certificate path
+    auto enqueue = [&](int p0, int P, int mode, bool spec = false, bool skip_begin = false) -> int {
+        if (spec) P = 0;
         const int fin_slot = P == 0 ? 0 : (P & 1);
         static const int no_cm = getenv("SMCMI_NO_CORRECT_MOMENTS") ? atoi(getenv("SMCMI_NO_CORRECT_MOMENTS")) : 0;   // development only
         // no selection expected + register kernels: the correction pass gathers the moments too, so (ΣW̃, ΣW̃², pair sums) travel
         // in ONE all-reduce (3 collectives per stage instead of 4); k_prepare_mutation decides, the mutation kernel normalises
         const bool cm = mode == 1 && can_fuse_cm(h0) && !no_cm;
         const int npf = h0->npairs + 2;
-        for (auto *h : g.hs) h->fused_cm = cm;
+        for (auto *h : g.hs) { h->fused_cm = cm; h->spec_stage = spec && cm; }
         if (mode == 2) {
             // resume of a stalled stage: its correction left the per-block (ΣW̃, ΣW̃²) partials - total them first
             for (auto *h : g.hs) {
@@ -281,11 +284,12 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_fin; }, 2)) return rc2;
         }
         if (mode != 2) {
-            if (p0 == 0)
+            if (p0 == 0 && !skip_begin)
                 for (auto *h : g.hs) {
                     HIP_TRY(hipSetDevice(h->cfg.device));
                     h->run_adaptive = predict;
-                    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + EACC, 1, h->rec, predict ? h->d_tot_acc : nullptr);
+                    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + EACC, 1, h->rec, predict ? h->d_tot_acc : nullptr, nullptr,
+                                                   h->spec_stage ? 1 : 0);
                 }
             for (int p = p0; p < P; ++p) {
                 for (auto *h : g.hs) {
@@ -429,7 +433,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
     double pred_ess = rc->initial_ess > 0.0 ? rc->initial_ess : N_tot;
     int pred_rl = 0, stall_stage = -1, stall_p = 0;
-    int done = 0, iters = 0, stalls = 0, sel_stalls = 0;
+    int done = 0, iters = 0, stalls = 0, sel_stalls = 0, spec_stalls = 0;
+    static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
+    const bool spec_ok = predict_select && predict && can_fuse_cm(h0) && !no_spec && !getenv("SMCMI_NO_CORRECT_MOMENTS");
     while (iters < max_iter && !done) {
         const int batch = adaptive ? std::min(sync_every, max_iter - iters) : max_iter - iters;
         for (int b = 0; b < batch; ++b) {
@@ -440,14 +446,15 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 mode = (!rs || sel_mode == 2) ? 1 : 0;
                 pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
             }
-            if (int rc2 = enqueue(0, adaptive ? (iters < 2 ? first_passes : P_default) : 0, mode)) return rc2;
+            const bool spec = spec_ok && mode == 1 && iters >= 2;
+            if (int rc2 = enqueue(0, adaptive ? (iters < 2 ? first_passes : P_default) : 0, mode, spec)) return rc2;
             ++iters;
         }
         for (;;) {
             HIP_TRY(hipSetDevice(h0->cfg.device));
             HIP_TRY(hipMemcpyAsync(&done, &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
             HIP_TRY(hipStreamSynchronize(h0->stream));
-            if (done != 2 && done != 3) break;
+            if (done != 2 && done != 3 && done != 4) break;
             // stall (identical on every rank: all decisions come from all-reduced totals): clear it and resume that stage
             if (pull_state(h0)) return SMCMI_ERR_HIP;
             const int st_i = h0->h_st.stage;
@@ -457,7 +464,16 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 const int zero = 0;
                 HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
             }
-            if (done == 2) {
+            if (done == 4) {
+                // a stage without certificate pass had no usable / verified prediction: nothing is committed, redo it in full
+                for (auto *h : g.hs) {
+                    HIP_TRY(hipSetDevice(h->cfg.device));
+                    k_solver_rearm<<<1, 64, 0, h->stream>>>(h->d_st, h->d_sched);
+                }
+                if (int rc2 = enqueue(0, first_passes, 0, false, true)) return rc2;
+                stall_stage = st_i; stall_p = first_passes;
+                ++spec_stalls;
+            } else if (done == 2) {
                 if (int rc2 = enqueue(had, had + 4, 0)) return rc2;
                 stall_stage = st_i; stall_p = had + 4;
                 ++stalls;
@@ -486,7 +502,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
-    res->solver_stalls = stalls; res->select_stalls = sel_stalls;
+    res->solver_stalls = stalls; res->select_stalls = sel_stalls; res->spec_stalls = spec_stalls;
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;
