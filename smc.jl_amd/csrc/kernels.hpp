@@ -242,6 +242,8 @@ __device__ inline double block_reduce_es(double (&a)[ES], double *red, int nw) {
     return tot;
 }
 
+__device__ constexpr double INV_FACTORIAL[32] = {1.00000000000000000e+00, 1.00000000000000000e+00, 5.00000000000000000e-01, 1.66666666666666657e-01, 4.16666666666666644e-02, 8.33333333333333322e-03, 1.38888888888888894e-03, 1.98412698412698413e-04, 2.48015873015873016e-05, 2.75573192239858925e-06, 2.75573192239858883e-07, 2.50521083854417202e-08, 2.08767569878681002e-09, 1.60590438368216133e-10, 1.14707455977297245e-11, 7.64716373181981641e-13, 4.77947733238738525e-14, 2.81145725434552060e-15, 1.56192069685862253e-16, 8.22063524662432950e-18, 4.11031762331216484e-19, 1.95729410633912626e-20, 8.89679139245057408e-22, 3.86817017063068354e-23, 1.61173757109611839e-24, 6.44695028438447359e-26, 2.47959626322479723e-27, 9.18368986379554601e-29, 3.27988923706983776e-30, 1.13099628864477181e-31, 3.76998762881590539e-33, 1.21612504155351811e-34};
+
 // Root δ > 0 of the Taylor model G(δ) = A(δ)² - ESS_bar B(δ) by one wavefront without serial polynomial evaluation: lane (g, k)
 // owns one coefficient - g = 0: a_k / k! of A, g = 1: b_k 2^k / k! of B (after a resample b_k = a_k and the slots hold 31 orders
 // of a) - forms its term c x^k by binary powering, and the four sums A = Σ term, x A' = Σ k term (same for B) come from 5-step
@@ -251,8 +253,7 @@ __device__ inline double predict_delta_wave(const double *es, bool uniform, doub
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     const int lane = threadIdx.x & 63, grp = lane >> 5, k = lane & 31;
     const int KT = uniform ? EKU : (grp == 0 ? EKA : EKB);   // terms of this lane's polynomial
-    double inv = 1.0;                                     // 1 / k!
-    for (int q = 2; q <= k; ++q) inv /= (double)q;
+    const double inv = INV_FACTORIAL[k];                  // 1 / k!
     double c = 0.0;
     if (k < KT) c = (grp == 0 ? es[k] : (uniform ? es[k] : es[EKA + k])) * inv;
     if (grp) c = ldexp(c, k);
