@@ -435,7 +435,8 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     int pred_rl = 0, stall_stage = -1, stall_p = 0;
     int done = 0, iters = 0, stalls = 0, sel_stalls = 0, spec_stalls = 0;
     static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
-    const bool spec_ok = predict_select && predict && can_fuse_cm(h0) && !no_spec && !getenv("SMCMI_NO_CORRECT_MOMENTS");
+    const bool spec_ok = predict_select && predict && can_fuse_cm(h0) && !no_spec && !getenv("SMCMI_NO_CORRECT_MOMENTS") &&
+                         rc->tempered_update_prior_weight == 0.0 && !(rc->phi_rtol < 0.0);
     while (iters < max_iter && !done) {
         const int batch = adaptive ? std::min(sync_every, max_iter - iters) : max_iter - iters;
         for (int b = 0; b < batch; ++b) {

@@ -913,8 +913,10 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     // stages, 19 of 20 resamples stalled, and the per-batch sync it needs makes short stages host-bound.)
     const bool predict_select = adaptive && can_fuse_post(h) && sel_mode != 1;
     static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
+    // (with a prior weight the correction's incremental weight differs from the solver's objective - quirk Q4 - so the ESS it
+    // produces cannot verify a predicted root: those runs keep the certificate pass)
     const bool spec_ok = predict_select && can_fuse_cm(h) && !no_spec && !getenv("SMCMI_NO_PREDICTOR") &&
-                         !getenv("SMCMI_NO_CORRECT_MOMENTS");
+                         !getenv("SMCMI_NO_CORRECT_MOMENTS") && rc->tempered_update_prior_weight == 0.0 && rp.phi_rtol > 0.0;
     hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // [0] full stage, [1] without selection kernels, [2] predict-correct-verify
     if (rc->use_graph == 1) {
