@@ -47,6 +47,7 @@ def main():
                     help="gauss10 = BASELINE config 2 (the bench line); capm = config 4 (examples/capm_model, 3 MH steps, fixed schedule); kalman = config 5 (13-parameter state-space model, Kalman-filter likelihood, old + new data)")
     ap.add_argument("--solver-passes", type=int, default=0)
     ap.add_argument("--sync-every", type=int, default=0)
+    ap.add_argument("--phi-rtol", type=float, default=0.0, help="adaptive-phi root tolerance (0 = library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -109,7 +110,7 @@ def main():
         def one_step(profile=False):
             reset()
             return eng.run(use_graph=(2 if profile else (1 if args.mode == "graph" else 0)), solver_passes=args.solver_passes,
-                           sync_every=args.sync_every, **RUN_KW)
+                           sync_every=args.sync_every, phi_rtol=args.phi_rtol, **RUN_KW)
     else:
         # one process per GPU: equal contiguous shards, RCCL communicator bootstrapped through torch.distributed
         from smc_jl_amd import Engine, comm_unique_id

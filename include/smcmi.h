@@ -72,7 +72,7 @@ typedef struct {
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
     int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
     double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */
-    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-10; <0 => adjacent floats) */
+    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-12; <0 => adjacent floats) */
 } smcmi_run_config;
 
 typedef struct {

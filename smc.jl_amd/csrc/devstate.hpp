@@ -46,6 +46,14 @@ struct ModelDev {
 
 enum SolveMode { MODE_IDLE = 0, MODE_SCAN = 1, MODE_SECTION = 2, MODE_FINAL = 3 };
 
+// Default relative resolution of the adaptive-ϕ root (Roots.fzero's xtol = 0 would be adjacent floats; per-stage errors of the
+// step carry forward through ϕ_n = ϕ_{n-1} + δ, so the default sits two decades above the rounding noise of the ESS sums).
+constexpr double DEFAULT_PHI_RTOL = 1e-12;
+// A predicted root (predict-correct-verify stages) is accepted when the ESS it produced puts it within this relative distance of
+// the true root.  Well-conditioned steps verify at ~1e-14; long steps (tempering_target 0.9) land around 1e-11, and rejecting
+// those costs a host round trip per stage for nothing the 1e-3 log-MDD contract could see.
+constexpr double SPEC_VERIFY_RTOL = 1e-10;
+
 struct RunParams {             // smc() kwargs, uploaded once per run
     long long n_parts;         // global N
     int n_blocks, n_mh_steps;
@@ -100,6 +108,7 @@ struct DevState {
     long long solver_passes;   // diagnostic: number of particle passes spent in the adaptive-ϕ solver
     double e_center;           // centre of the energy power sums the mutation epilogue accumulates (predictor, kernels.hpp)
     double pred_delta;         // diagnostic: predicted ϕ_n - ϕ_{n-1} of the current stage (NaN: no prediction)
+    double e_shift;            // energy shift of this stage's incremental weights (largest loglh - old_loglh of the cloud; 0 = none)
     Solver sol[2];
     // ---- moments / proposal (smc_main.jl:457-469, mutation.jl:81)
     double shift[MAXD];        // centering used by the one-pass moment kernel (previous mean)

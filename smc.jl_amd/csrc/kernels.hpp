@@ -330,7 +330,9 @@ __device__ inline void solver_decide_wave(Solver &S, const double *tot, const do
         const int ms = sneg ? (__ffsll((long long)sneg) - 1) : -1;
         if (ms >= 0) {
             const double cm = __shfl(ck, ms, 64), gm = __shfl(gk, ms, 64);
-            if (gm != gm) { if (lane == 0) *err = SMCMI_ERR_NAN_ESS; return; }
+            // g(ϕ_prop) = NaN ends the reference's walk (NaN >= 0 is false, helpers.jl:29) and Roots.fzero then rejects
+            // [ϕ_n1, ϕ_prop] as a bracket (helpers.jl:50): the run aborts from the solver, not from check_nan_ess.
+            if (gm != gm) { if (lane == 0) *err = SMCMI_ERR_BRACKET; return; }
             hi = cm; ghi = gm;
             const unsigned long long below = smask & ((1ull << ms) - 1ull);
             const int ps = below ? 63 - __clzll((long long)below) : -1;       // previous schedule candidate (g >= 0), if any
@@ -387,7 +389,7 @@ __device__ inline void solver_decide_wave(Solver &S, const double *tot, const do
     // already exact to that resolution - interpolation error ~ h² g''/(8 g') ~ h² / (8 (hi - ϕ_{n-1})), taken with a 64x margin.
     const double h = hi - lo;
     int c = 0;
-    const bool interp_ok = glo > 0.0 && ghi < 0.0 && glo < 1e300 && ghi > -1e300 && 64.0 * h * h <= rtol * hi * (hi - S.phi0);
+    const bool interp_ok = glo >= 0.0 && ghi < 0.0 && glo < 1e300 && ghi > -1e300 && 64.0 * h * h <= rtol * hi * (hi - S.phi0);
     if (h > rtol * hi && !interp_ok) {
         double t = 0.5;
         if (glo > ghi && glo < 1e300 && ghi > -1e300) t = glo / (glo - ghi);
@@ -418,7 +420,7 @@ __device__ inline void solver_decide_wave(Solver &S, const double *tot, const do
         S.lo = lo; S.hi = hi; S.glo = glo; S.ghi = ghi;
         if (c == 0) {   // bracket at the requested resolution (or no representable interior point)
             double pn = (fabs(glo) <= fabs(ghi)) ? lo : hi;
-            if (glo > 0.0 && ghi < 0.0 && glo < 1e300 && ghi > -1e300) {   // interpolate inside the certified bracket
+            if (glo >= 0.0 && ghi < 0.0 && glo < 1e300 && ghi > -1e300) {  // interpolate inside the certified bracket (glo == 0: lo)
                 const double xs = lo + h * (glo / (glo - ghi));
                 if (xs >= lo && xs <= hi) pn = xs;
             }
@@ -476,6 +478,44 @@ __device__ inline void solver_prologue(DevState *st, const double *sched, const 
 // (src/helpers.jl:173-181, always the prior_weight == 0 formula: quirk Q4).
 // FINAL = true is the correction step at the chosen ϕ_n (src/smc_main.jl:401-420): the incremental weight uses the
 // prior-weight variant, the unnormalised weight W̃ = W w̃ is written back and w̃ goes to the history column.
+// Energy shift of the stage.  The incremental weight exp(δ e), e = loglh - old_loglh, is formed as exp(δ (e - e_shift)) with
+// e_shift = the largest e of the live cloud (k_stage_begin, from the maxima the previous mutation / k_energy_max left): every
+// exponent is <= 0, so Σ W̃ and Σ W̃² neither overflow nor lose the whole cloud to underflow when |δ e| runs into the hundreds
+// (large-sample tempered updates) - the reference normalises before squaring (helpers.jl:173-181) and survives to |δ e| ~ 745,
+// unshifted sums of squares give up at ~354.  ESS, normalised weights and moments are ratios and do not see the common factor;
+// log(Σ W̃ / N) gets δ e_shift back (post_load) and the stored incremental weights their factor exp(δ e_shift).
+// Prior-weight corrections (pw != 0) use another exponent and stay unshifted, like the stand-alone calls (e_shift = 0).
+__device__ inline double stage_shift(const DevState *st) { return st->rp.pw == 0.0 ? st->e_shift : 0.0; }
+
+// max over the block of v (-inf for lanes without a value); smem: one double per wavefront; all threads must call
+__device__ inline double block_max(double v, double *smem, int nwaves) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double m = smem[0];
+    for (int w = 1; w < nwaves; ++w) m = fmax(m, smem[w]);
+    return m;
+}
+__device__ inline double energy_or_ninf(double like, double like_prev, double w, bool live) {
+    const double e = like - like_prev;
+    return (live && w > 0.0 && fabs(e) < 1e300) ? e : -__builtin_inf();
+}
+
+// Largest energy of the live cloud per block -> emax_part[blockIdx.x] (run start; afterwards the mutation epilogue keeps it)
+__global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const DevState *st, double *emax_part) {
+    __shared__ double smem[TB / 64];
+    const int R = cl.R, src = st->cur;
+    const double *loglh = col(cl, src, R - 5), *old = col(cl, src, R - 3), *w = col(cl, src, R - 1);
+    long long beg, end;
+    block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
+    double m = -__builtin_inf();
+    for (long long i = beg + threadIdx.x; i < end; i += TB) m = fmax(m, energy_or_ninf(loglh[i], old[i], w[i], true));
+    m = block_max(m, smem, TB / 64);
+    if (threadIdx.x == 0) emax_part[blockIdx.x] = m;
+}
+
 template <int K, bool FINAL>
 __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const double *sched, const double *partials_prev,
                                              double *partials_out, int nb_prev, int p, double *hist_w, long long hist_ld,
@@ -489,7 +529,7 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
     const int done = st->done;
     constexpr int src = 0;             // the current cloud always lives in buffer 0 (k_moments copies a resampled cloud back)
     const double phi_prev = st->phi_prev;
-    const double pw = st->rp.pw, logp_old = st->rp.logp_old;
+    const double pw = st->rp.pw, logp_old = st->rp.logp_old, esh = stage_shift(st);
     const int stage_col = st->stage - 1;
     const bool hist = FINAL && st->rp.store_history && hist_w != nullptr;
     solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, FINAL ? 1 : 0, done);
@@ -506,8 +546,9 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
     for (int k = 0; k < 2 * K; ++k) acc[k] = 0.0;
     long long beg, end;
     block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
+    const double unshift = (FINAL && hist) ? exp((S.phi_n - phi_prev) * esh) : 1.0;     // history keeps the true exp(δ e)
     for (long long i = beg + threadIdx.x; i < end; i += TB) {
-        const double l = loglh[i], o = old[i], wi = w[i];
+        const double l = loglh[i] - esh, o = old[i], wi = w[i];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (!FINAL && k >= nv) continue;
@@ -521,7 +562,7 @@ __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const d
             acc[K + k] += v * v;
             if (FINAL) {
                 w[i] = v;
-                if (hist) hist_w[(long long)stage_col * hist_ld + i] = inc;
+                if (hist) hist_w[(long long)stage_col * hist_ld + i] = inc * unshift;
             }
         }
     }
@@ -551,7 +592,7 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
     __shared__ Solver S;
     const int done = st->done;
     const double phi_prev = st->phi_prev;
-    const double pw = st->rp.pw, logp_old = st->rp.logp_old;
+    const double pw = st->rp.pw, logp_old = st->rp.logp_old, esh = stage_shift(st);
     const int stage_col = st->stage - 1;
     const bool hist = st->rp.store_history && hist_w != nullptr;
     double sh[D];
@@ -569,8 +610,9 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
     for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
     long long beg, end;
     block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
+    const double unshift = hist ? exp((phi - phi_prev) * esh) : 1.0;                      // history keeps the true exp(δ e)
     for (long long i = beg + threadIdx.x; i < end; i += TB) {
-        const double l = loglh[i], o = old[i], wi = w[i];
+        const double l = loglh[i] - esh, o = old[i], wi = w[i];
         double xx[DA];
         xx[0] = 1.0;
 #pragma unroll
@@ -583,7 +625,7 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
         acc[0] += v;
         acc[1] += v * v;
         if (wt_out) wt_out[i] = v; else w[i] = v;        // spec stage: W stays intact until the prediction is verified
-        if (hist) hist_w[(long long)stage_col * hist_ld + i] = inc;
+        if (hist) hist_w[(long long)stage_col * hist_ld + i] = inc * unshift;
         int q = 2;
 #pragma unroll
         for (int a = 0; a < DA; ++a) {
@@ -648,8 +690,9 @@ __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double
 constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
 __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
                                                     int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
-                                                    int spec_expected = 0) {
+                                                    int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0) {
     __shared__ double scratch[BT];
+    __shared__ double s_emx[BT / 64];
     SMCMI_STAMP(prof, 0);
     __shared__ double s_es[ES];
     __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
@@ -681,8 +724,17 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
         v += __shfl_xor(v, 32, 64);                      // the wave's two row-groups
         if ((threadIdx.x & 63) < 32) scratch[(threadIdx.x >> 6) * 32 + colx] = v;
     }
+    // largest energy the previous mutation (or k_energy_max) left: per-block / per-shard maxima -> this stage's energy shift
+    double em = -__builtin_inf();
+    if (emax_part)
+        for (int b = threadIdx.x; b < emax_n; b += BT) em = fmax(em, emax_part[b]);
     if (done) return;
     SMCMI_STAMP(prof, 1);
+    if (emax_part) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
+        if ((threadIdx.x & 63) == 0) s_emx[threadIdx.x >> 6] = em;
+    }
     const int i = stage0 + 1;
     double swv = 2.0;                                  // stays in flight across the reduction's loads; stored to LDS after them
     if (threadIdx.x < 64) {
@@ -717,10 +769,16 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
         }
         if (rs) st->do_resample = 0;
     }
-    if (phi_n >= 1.0) { if (lane == 0) st->done = 1; return; }
+    if (phi_n >= 1.0) { if (lane == 0) { st->done = 1; st->e_shift = 0.0; } return; }
     if (i > max_stages) { if (lane == 0) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; } return; }
     Solver &S = st->sol[0];
     if (lane == 0) { st->stage = i; st->phi_prev = phi_n; S.unconverged = 0; }
+    if (emax_part && lane == 0) {
+        double m = s_emx[0];
+#pragma unroll
+        for (int w = 1; w < BT / 64; ++w) m = fmax(m, s_emx[w]);
+        if (fabs(m) < 1e300) st->e_shift = m;              // no live particle with a finite energy: keep the previous shift
+    }
     if (fixed) {
         if (lane == 0) {
             st->phi_n = ph_fixed;
@@ -865,7 +923,7 @@ __device__ inline void scan_chunk(const double *w, long long n, int n_chunks, in
 // Scalars of the post-correction bookkeeping, loaded by every thread up front (one memory round trip with the partial sums).
 struct PostIn {
     int done, smode, i, jj, resamples;
-    double N, a, tg, c0, thr, phi_n, phi_prop, logz;
+    double N, a, tg, c0, thr, phi_n, phi_prop, logz, dlz;
 };
 __device__ inline PostIn post_load(const DevState *st, int sol_slot) {
     const Solver &S = st->sol[sol_slot];
@@ -873,6 +931,7 @@ __device__ inline PostIn post_load(const DevState *st, int sol_slot) {
     p.done = st->done; p.smode = S.mode; p.i = st->stage; p.jj = S.j; p.resamples = st->resamples;
     p.N = (double)st->rp.n_parts; p.a = st->accept; p.tg = st->rp.target; p.c0 = st->c; p.thr = st->rp.threshold;
     p.phi_n = S.phi_n; p.phi_prop = S.phi_prop; p.logz = st->logz;
+    p.dlz = (S.phi_n - st->phi_prev) * stage_shift(st);          // log of the common factor the shifted weights left out
     return p;
 }
 // ESS, log-MDD increment, resample decision, step-size adaptation, records (src/smc_main.jl:427-455); one thread.
@@ -887,7 +946,7 @@ __device__ inline int post_write(DevState *st, const Records &rec, const PostIn 
     rec.phi[p.i - 1] = p.phi_n;
     rec.ess[p.i - 1] = ess;
     if (bad) { st->err = SMCMI_ERR_NAN_ESS; st->done = 1; return -1; }     // check_nan_ess, helpers.jl:270-305
-    st->logz = p.logz + log(s1 / p.N);
+    st->logz = p.logz + (log(s1 / p.N) + p.dlz);
     st->do_resample = rs;
     rec.resampled[p.i - 1] = rs;
     if (rs) { st->resamples = p.resamples + 1; st->resampled_last = 1; }
@@ -1327,8 +1386,23 @@ __global__ void __launch_bounds__(64) k_finalize_moments(DevState *st, const dou
 }
 
 // generic fixed-order reduction of block partials into out[0..m) (1 block)
-__global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, int nb, int m, double *out) {
+// Optional: also reduce the per-block energy maxima of this shard into its slot of `emax_slots` (the other shards' slots get 0:
+// the sum all-reduce that follows then is a gather of the maxima, k_stage_begin takes the largest).
+__device__ inline void emax_publish(const double *emax_part, int nb, double *emax_slots, int rank, int world, double *smem) {
+    double em = -__builtin_inf();
+    for (int b = threadIdx.x; b < nb; b += TB) em = fmax(em, emax_part[b]);
+    em = block_max(em, smem, TB / 64);
+    if ((int)threadIdx.x < world) emax_slots[threadIdx.x] = ((int)threadIdx.x == rank) ? fmax(em, -1e300) : 0.0;
+}
+__global__ void __launch_bounds__(TB) k_emax_publish(const double *emax_part, int nb, double *emax_slots, int rank, int world) {
+    __shared__ double smem[TB / 64];
+    emax_publish(emax_part, nb, emax_slots, rank, world, smem);
+}
+__global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, int nb, int m, double *out, const double *emax_part = nullptr,
+                                                        int emax_nb = 0, double *emax_slots = nullptr, int rank = 0, int world = 1) {
     __shared__ double scratch[TB];
+    __shared__ double smem[TB / 64];
+    if (emax_part) emax_publish(emax_part, emax_nb, emax_slots, rank, world, smem);
     if (m == 1) {
         const double tot = final_sum1(partials, nb, scratch);
         if (threadIdx.x == 0) out[0] = tot;
@@ -1510,7 +1584,7 @@ __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const Mod
                 if (Sv.spec) {
                     // the correction ran at the PREDICTED ϕ_n: accept it only if the ESS it produced puts the true root within
                     // phi_rtol (|ESS - ESS_bar| / |dESS/dϕ| <= rtol ϕ_n), or, for ϕ_n = 1 by exhaustion, ESS >= ESS_bar
-                    if (Sv.phi_n < 1.0) verified = fabs(ess - Sv.ess_bar) <= fabs(Sv.gprime) * st->rp.phi_rtol * Sv.phi_n;
+                    if (Sv.phi_n < 1.0) verified = fabs(ess - Sv.ess_bar) <= fabs(Sv.gprime) * fmax(st->rp.phi_rtol, SPEC_VERIFY_RTOL) * Sv.phi_n;
                     else verified = ess >= Sv.ess_bar * (1.0 - 1e-13);
                 }
                 if (!verified) st->done = 4;
@@ -1703,6 +1777,7 @@ struct MutArgs {
     double *hist_W;
     long long hist_ld;
     const double *wt;          // normalize: read W̃ from here instead of the weight column (spec stages)
+    double *emax;              // in-run MODE 0: per-block largest loglh - old_loglh of the mutated cloud (next stage's energy shift) or null
 };
 
 template <int MODE>
@@ -1869,6 +1944,12 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     double a1[1] = {acc_val};
     Butterfly<0, 32>::run(a1, tid & 63);
     if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+    if (MODE == 0 && ma.emax) {                      // largest energy of the mutated cloud (energy shift of the next stage)
+        __shared__ double emx[4];
+        const double wl = (live && !st->do_resample) ? col(cl, src, d + 4)[i] : 1.0;
+        const double em = block_max(energy_or_ninf(like, like_prev, wl, live), emx, T / 64);
+        if (tid == 0) ma.emax[blockIdx.x] = em;
+    }
     if (MODE == 0 && ma.esum) {                      // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
         energy_terms(es, live ? col(cl, src, d + 4)[i] : 0.0, like, like_prev, st->e_center, live, st->do_resample != 0);
@@ -2234,6 +2315,11 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     Butterfly<0, 32>::run(a1, tid & 63);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+    if (ma.emax) {                                   // largest energy of the mutated cloud (energy shift of the next stage)
+        __shared__ double emx[4];
+        const double em = block_max(energy_or_ninf(like, like_prev, (ma.esum && !es_uniform) ? w_part : 1.0, live), emx, T / 64);
+        if (tid == 0) ma.emax[blockIdx.x] = em;
+    }
     if (ma.esum) {                                   // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
         energy_terms(es, w_part, like, like_prev, e_center, live, es_uniform);

@@ -96,6 +96,9 @@ extern "C" int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, con
     return 0;
 }
 
+constexpr int MAX_SHARDS = 64;     // slots for the per-shard energy maxima behind the all-reduced epilogue row
+static inline int shard_rank(const smcmi_handle *h) { return (int)(h->cfg.gid0 / h->cfg.n_local); }
+
 // ---- collectives over a group of lock-stepped local handles, optionally extended over ranks by RCCL
 struct ShardGroup {
     std::vector<smcmi_handle *> hs;   // local shards (same process); RCCL mode: exactly one
@@ -196,9 +199,9 @@ struct ShardGroup {
 static int ensure_shard_buffers(smcmi_handle *h) {
     const long long N = h->cfg.n_parts;
     if (!h->d_tot_ess) {
-        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs + 2) || dmalloc(&h->d_tot_acc, ES))
+        if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs + 2) || dmalloc(&h->d_tot_acc, ES + MAX_SHARDS))
             return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * ES));
+        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * (ES + MAX_SHARDS)));
     }
     if (!h->d_cum_full) {
         if (dmalloc(&h->d_cum_full, N)) return SMCMI_ERR_HIP;
@@ -240,7 +243,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
         rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
         rp.stall_on_exhaust = 1;
-        rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
+        rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
         memset(&s, 0, sizeof(DevState));
         s.rp = rp;
         s.stage = 1; s.j = 2; s.c = rc->c; s.accept = rc->target;
@@ -257,6 +260,16 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             HIP_TRY(hipMemcpy(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice));
         }
     }
+    // stage 1's energy shift: largest energy of the initial cloud over all shards (slots after the ES row: a sum all-reduce
+    // in which every shard fills only its own slot is a gather)
+    if (g.world > MAX_SHARDS) return set_err(SMCMI_ERR_ARG, "too many shards");
+    for (auto *h : g.hs) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        const int nb0 = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
+        k_energy_max<<<nb0, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
+        k_emax_publish<<<1, TB, 0, h->stream>>>(h->d_emax_part, nb0, h->d_tot_acc + ES, shard_rank(h), g.world);
+    }
+    if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, g.world)) return rc2;
     // One stage = the single-GPU launch sequence with the collectives in-stream.  Nothing in it needs the host: on an adaptive
     // schedule resampling is predictable (smcmi_run), so the selection path - all-gather of weights and shard clouds, global
     // scan, gather - is enqueued exactly where a resample is expected (its kernels gate themselves on the device's decision)
@@ -289,7 +302,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                     HIP_TRY(hipSetDevice(h->cfg.device));
                     h->run_adaptive = predict;
                     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + EACC, 1, h->rec, predict ? h->d_tot_acc : nullptr, nullptr,
-                                                   h->spec_stage ? 1 : 0);
+                                                   h->spec_stage ? 1 : 0, h->d_tot_acc + ES, g.world);
                 }
             for (int p = p0; p < P; ++p) {
                 for (auto *h : g.hs) {
@@ -320,11 +333,11 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 launch_prepare_in_run(h, h->d_tot_mom, 1, 3, fin_slot);
                 const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
-                if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc);
-                else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC);
+                if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
+                else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
             }
-            if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ES)) return rc2; }
-            else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1)) return rc2;
+            if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ES + g.world)) return rc2; }
+            else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1 + g.world)) return rc2;
             return 0;
         }
         if (mode == 1) {
@@ -418,11 +431,11 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             HIP_TRY(hipSetDevice(h->cfg.device));
             launch_prepare_in_run(h, h->d_tot_mom, 1, 2);
             const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
-            if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc);
-            else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC);
+            if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
+            else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
         }
-        if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ES)) return rc2; }
-        else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1)) return rc2;
+        if (predict) { if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc; }, ES + g.world)) return rc2; }
+        else if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1 + g.world)) return rc2;
         return 0;
     };
 
@@ -437,6 +450,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
     const bool spec_ok = predict_select && predict && can_fuse_cm(h0) && !no_spec && !getenv("SMCMI_NO_CORRECT_MOMENTS") &&
                          rc->tempered_update_prior_weight == 0.0 && !(rc->phi_rtol < 0.0);
+    bool spec_on = spec_ok;                   // switched off after repeated verification failures (see smcmi_run)
+    int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;
+    int dyn_P = P_default;                    // raised when stages keep running out of passes
     while (iters < max_iter && !done) {
         const int batch = adaptive ? std::min(sync_every, max_iter - iters) : max_iter - iters;
         for (int b = 0; b < batch; ++b) {
@@ -447,8 +463,8 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 mode = (!rs || sel_mode == 2) ? 1 : 0;
                 pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
             }
-            const bool spec = spec_ok && mode == 1 && iters >= 2;
-            if (int rc2 = enqueue(0, adaptive ? (iters < 2 ? first_passes : P_default) : 0, mode, spec)) return rc2;
+            const bool spec = spec_on && mode == 1 && iters >= 2;
+            if (int rc2 = enqueue(0, adaptive ? (iters < 2 ? first_passes : dyn_P) : 0, mode, spec)) return rc2;
             ++iters;
         }
         for (;;) {
@@ -459,7 +475,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             // stall (identical on every rank: all decisions come from all-reduced totals): clear it and resume that stage
             if (pull_state(h0)) return SMCMI_ERR_HIP;
             const int st_i = h0->h_st.stage;
-            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : P_default);
+            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : dyn_P);
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 const int zero = 0;
@@ -474,10 +490,15 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 if (int rc2 = enqueue(0, first_passes, 0, false, true)) return rc2;
                 stall_stage = st_i; stall_p = first_passes;
                 ++spec_stalls;
+                if (st_i - last_spec_stall <= 4) { if (++spec_strikes >= 2) spec_on = false; }
+                else spec_strikes = 0;
+                last_spec_stall = st_i;
             } else if (done == 2) {
                 if (int rc2 = enqueue(had, had + 4, 0)) return rc2;
                 stall_stage = st_i; stall_p = had + 4;
                 ++stalls;
+                if (st_i - last_solver_stall <= 4 && dyn_P < 4) ++dyn_P;
+                last_solver_stall = st_i;
             } else {
                 if (int rc2 = enqueue(had, had, 2)) return rc2;
                 ++sel_stalls;

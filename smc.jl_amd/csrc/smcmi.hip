@@ -56,7 +56,7 @@ struct smcmi_handle {
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_wt = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
-    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
+    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_emax_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
     // host-callback split
@@ -90,6 +90,7 @@ static int push_state(smcmi_handle *h) {
 static int pull_state(smcmi_handle *h) {
     HIP_TRY(hipMemcpyAsync(&h->h_st, h->d_st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->h_st.e_shift = 0.0;      // the energy shift belongs to a running stage chain (k_stage_begin): stand-alone calls that push this copy back are unshifted
     return 0;
 }
 static int push_model(smcmi_handle *h) {
@@ -108,7 +109,7 @@ static int err_from_state(int code) {
     case SMCMI_ERR_NAN_ESS: return set_err(code, "No particles have non-zero weight (ESS is NaN)");
     case SMCMI_ERR_POSDEF: return set_err(code, "PosDefException: block proposal covariance is not positive definite");
     case SMCMI_ERR_CAPACITY: return set_err(code, "max_stages exceeded");
-    case SMCMI_ERR_BRACKET: return set_err(code, "adaptive tempering solver did not converge in the allotted passes");
+    case SMCMI_ERR_BRACKET: return set_err(code, "adaptive tempering solver: [phi_n1, phi_prop] does not bracket the ESS target (or the allotted passes ran out)");
     default: return set_err(code, "device error");
     }
 }
@@ -170,7 +171,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) || dmalloc(&h->d_wt, n) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * ES) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * ES) || dmalloc(&h->d_emax_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -178,7 +179,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     }
     memset(&h->h_st, 0, sizeof(DevState));
     h->h_st.rp.n_parts = cfg->n_parts;
-    h->h_st.rp.phi_rtol = 1e-10;
+    h->h_st.rp.phi_rtol = DEFAULT_PHI_RTOL;
     h->h_st.rp.max_stages = ms;
     h->h_st.stage = 1;
     h->h_st.c = 0.5;
@@ -207,7 +208,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->nccl) smcmi_comm_release(h);
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_zbuf,
+                    h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
@@ -408,7 +409,7 @@ extern "C" int smcmi_solve_phi(smcmi_handle *h, const double *sched, int32_t n_p
     s.done = 0; s.err = 0; s.do_resample = 0; s.stage = 1; s.rp.use_fixed_schedule = 0; s.rp.n_phi = n_phi;
     s.rp.tempering_target = tempering_target; s.phi_n = phi_prev; s.phi_prop = *phi_prop; s.j = *j;
     s.resampled_last = *resampled_last; s.ess_prev = ess_prev;
-    if (s.rp.phi_rtol <= 0.0) s.rp.phi_rtol = 1e-10;
+    if (s.rp.phi_rtol <= 0.0) s.rp.phi_rtol = DEFAULT_PHI_RTOL;
     if (upload_sched(h, sched, n_phi) || push_state(h)) return SMCMI_ERR_HIP;
     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, 0, h->rec);
     // enough passes to walk the whole schedule in the worst case plus the bracketing passes
@@ -655,6 +656,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     ma.prof = h->d_prof;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
+    ma.emax = !standalone ? h->d_emax_part : nullptr;
     ma.zbuf = (!standalone && h->rng_ahead && use_reg_mutate(h)) ? h->d_zbuf : nullptr;
     ma.normalize = (!standalone && h->fused_cm) ? 1 : 0;
     ma.hist_W = h->d_hist_W; ma.hist_ld = h->n;
@@ -801,6 +803,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     // spec: predict -> correct -> verify (kernels.hpp k_stage_begin): no certificate pass is enqueued at all - 4 launches
     const int P = (adaptive && !spec) ? p0 + solver_passes : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
+    static const int no_eshift = getenv("SMCMI_NO_ESHIFT") ? atoi(getenv("SMCMI_NO_ESHIFT")) : 0;       // development only
     h->run_adaptive = adaptive;
     const int fin_slot = P == 0 ? 0 : (P & 1);
     static const int no_cm = getenv("SMCMI_NO_CORRECT_MOMENTS") ? atoi(getenv("SMCMI_NO_CORRECT_MOMENTS")) : 0;   // development only
@@ -818,7 +821,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
         }
         k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
-                                       h->spec_stage ? 1 : 0);
+                                       h->spec_stage ? 1 : 0, no_eshift ? nullptr : h->d_emax_part, acc_nb);
     }
     if (adaptive && !h->spec_stage) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);
@@ -872,7 +875,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
     rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
     rp.stall_on_exhaust = 1;
-    rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : 1e-10);
+    rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
     memset(&s, 0, sizeof(DevState));
     s.rp = rp; s.cur = cur;
     s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
@@ -901,6 +904,8 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
     const int max_db = (nf + rc->n_blocks - 1) / rc->n_blocks;
     const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
+    // largest energy of the initial cloud, in the layout the mutation epilogue uses afterwards (stage 1's energy shift)
+    k_energy_max<<<acc_nb, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_iter;      // profile mode: iteration each event pair belongs to, -1 once known to have bracketed a no-op
@@ -935,9 +940,13 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
     int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
     int dyn_P = solver_passes;                // passes enqueued per stage: raised when stalls are frequent (poorly predictable models)
+    // Predict-correct-verify pays only while predictions verify: three failures, each within four stages of the one before
+    // (heavy-tailed energies, steps too long for the 16-term model), switch the rest of the run to the certificate path,
+    // where a miss costs an extra pass instead of a host round trip.
+    bool spec_on = spec_ok;
+    int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;
     if (rc->solver_passes < 1 && rc->tempering_target < 0.95) dyn_P = 2;   // larger steps: the 8-term model is good to ~1e-3 only, two passes are the norm
     while (launched < max_iter && !done) {
-        const int stalls_before = res->solver_stalls;
         const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
             bool no_select = false;
@@ -948,7 +957,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 no_select = !rs || sel_mode == 2;
                 pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
             }
-            const bool spec = spec_ok && no_select && launched >= 2;
+            const bool spec = spec_on && no_select && launched >= 2;
             if (gexec[0] && launched > 1 && dyn_P == solver_passes) HIP_TRY(hipGraphLaunch(gexec[spec ? 2 : (no_select ? 1 : 0)], h->stream));
             else {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -978,6 +987,9 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 enqueue_stage(h, adaptive, first_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, 0, false, false, false, true);
                 stall_stage = st_i; stall_p = first_passes;
                 res->spec_stalls += 1;
+                if (st_i - last_spec_stall <= 4) { if (++spec_strikes >= 2) spec_on = false; }
+                else spec_strikes = 0;
+                last_spec_stall = st_i;
             } else if (done == 2) {
                 // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give
                 // that stage more passes (continuing the same search), and go on from the stage after it.
@@ -985,6 +997,10 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, had);
                 stall_stage = st_i; stall_p = had + more;
                 res->solver_stalls += 1;
+                // a stall flushes the rest of its batch and costs a host round trip, an idle pass launch costs 3 µs: two stalls
+                // within four stages -> enqueue one more pass per stage from here on
+                if (st_i - last_solver_stall <= 4 && dyn_P < 4) ++dyn_P;
+                last_solver_stall = st_i;
             } else {
                 // A stage enqueued without selection kernels needs to resample after all: nothing past its correction has run.
                 // Run the rest of that stage with the full path, then go on from the stage after it.
@@ -995,8 +1011,6 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
-        // two or more stalls in one batch: a stall flushes the rest of the batch, an idle pass launch costs 3 µs - enqueue one more
-        if (res->solver_stalls - stalls_before >= 2 && dyn_P < 4) ++dyn_P;
         if (predict_select) {
             // re-anchor the expectation on the device's ESS / flag after every sync (cheap: the stream is idle here)
             HIP_TRY(hipMemcpy(&s.resampled_last, &h->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost));   // did the last stage resample
@@ -1221,7 +1235,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     DevState &s = h->h_st;
     const DevState saved = s;
     const long long n = h->n;
-    s.done = 0; s.err = 0; s.stage = 2; s.rp.store_history = h->cfg.store_history; s.rp.phi_rtol = 1e-10;
+    s.done = 0; s.err = 0; s.stage = 2; s.rp.store_history = h->cfg.store_history; s.rp.phi_rtol = DEFAULT_PHI_RTOL;
     if (s.rp.n_phi < 2) { s.rp.n_phi = 300; }
     s.phi_prev = 0.0; s.phi_n = 1e-4; s.sumw = (double)h->cfg.n_parts; s.c = 0.5; s.rp.n_blocks = 1; s.rp.n_mh_steps = 1; s.rp.alpha = 1.0;
     s.rp.threshold = 0.5 * (double)h->cfg.n_parts; s.rp.target = 0.25; s.accept = 0.25; s.rp.tempering_target = 0.97; s.ess_prev = (double)h->cfg.n_parts;

@@ -100,7 +100,7 @@ class ShardedSMC:
     # ---- the loop (src/smc_main.jl:377-508) ---------------------------------------------------------------
     def run(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5, c=0.5,
             alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0, log_prob_old_data=0.0,
-            phi_rtol=1e-10):
+            phi_rtol=1e-12):
         e, comm, N, d = self.e, self.comm, float(self.n_parts), self.d
         nf = len(self.free_inds)
         sched = hm.schedule(n_phi, lam)

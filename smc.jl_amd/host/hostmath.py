@@ -80,7 +80,7 @@ class PhiSolver:
     """solve_adaptive_ϕ (src/helpers.jl:9-56) as the same scan + secant/ring bracketing search the device runs
     (csrc/kernels.hpp solver_decide / section_candidates).  `ess_sums(cands) -> (Σv[k], Σv²[k])` evaluates a batch."""
 
-    def __init__(self, sched, rtol=1e-10):
+    def __init__(self, sched, rtol=1e-12):
         self.sched, self.n_phi, self.rtol = np.asarray(sched, dtype=np.float64), len(sched), rtol
 
     def _section(self, lo, hi, glo, ghi):

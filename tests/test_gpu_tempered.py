@@ -129,3 +129,43 @@ def test_reference_bridge_scenario_linear_model():
     assert np.max(np.abs(S.get_vals(new_cloud).mean(axis=1) - truth)) < 0.5
     assert np.max(np.abs(S.weighted_mean(new_cloud) - truth)) < 0.5
     assert np.all(new_cloud.particles[:, 9 + 2] != 0.0)          # old_loglh column filled by initialize_likelihoods!
+
+
+def test_bridge_with_large_energies_keeps_the_reference_range():
+    """A 40-period extension of the linear model: loglh - old_loglh is ~ -600 for every particle and the first stage's schedule
+    walk evaluates ESS up to δ = 1.  The reference normalises the incremental weights before squaring them
+    (src/helpers.jl:173-181), so it survives to |δ e| ~ 745; the device shifts the energies by their maximum (kernels.hpp
+    stage_shift) instead - unshifted sums of squares used to underflow at ~354 and abort this run with a bracket error."""
+    from smc_jl_amd import Engine
+    from oracle import oracle as orc
+
+    n, d, seed = 4096, 9, 779
+    spec = models.linmodel_spec(T=100, old_T=60)
+    e = Engine(n, d, seed=seed, max_stages=400)
+    e.set_model(models.linmodel_spec(T=60))
+    e.init_from_prior()
+    r_old = e.run(n_phi=60, use_fixed_schedule=True, n_mh_steps=2)
+    ess_old = float(e.stage_records(r_old["n_stages"])["ess"][-1])
+    P_old = e.download_cloud()
+    e.close()
+    e = Engine(n, d, seed=seed + 1, max_stages=400)
+    e.set_model(spec)
+    e.upload_cloud(P_old)
+    e.initialize_likelihoods()
+    P0 = e.download_cloud()
+    energy = P0[:, d] - P0[:, d + 2]
+    assert np.max(energy) < -360.0                      # beyond what unshifted squares can hold at δ = 1
+    kw = dict(n_blocks=3, n_mh_steps=2, alpha=0.5, use_fixed_schedule=False, n_phi=30, tempering_target=0.95,
+              resampling_method="multinomial", threshold_ratio=0.8, initial_ess=ess_old)
+    r = e.run(**kw)
+    rec = e.stage_records(r["n_stages"])
+    w, W = e.history(r["n_stages"])
+    e.close()
+    ro = orc.smc_run(models.oracle_model(spec), P0, seed=seed + 1, n_threads=8, max_stages=400, **kw)
+    assert r["n_stages"] == ro["n_stages"] and r["resamples"] == ro["resamples"]
+    assert r["logmdd"] == pytest.approx(ro["logmdd"], abs=1e-8)
+    np.testing.assert_allclose(rec["schedule"], ro["schedule"], rtol=1e-9)
+    np.testing.assert_allclose(rec["ess"], ro["ess"], rtol=1e-8)
+    # the stored incremental weights are the reference's exp(δ e), not the shifted ones
+    np.testing.assert_allclose(w[:, 1], ro["w"][:, 1], rtol=1e-9, atol=0.0)
+    np.testing.assert_allclose(W[:, 1], ro["W"][:, 1], rtol=1e-9, atol=1e-300)
