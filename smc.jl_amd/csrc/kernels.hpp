@@ -2314,12 +2314,12 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     double a1[1] = {acc_val};
     Butterfly<0, 32>::run(a1, tid & 63);
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = a1[0];
-    if (ma.emax) {                                   // largest energy of the mutated cloud (energy shift of the next stage)
-        __shared__ double emx[4];
-        const double em = block_max(energy_or_ninf(like, like_prev, (ma.esum && !es_uniform) ? w_part : 1.0, live), emx, T / 64);
-        if (tid == 0) ma.emax[blockIdx.x] = em;
-    }
+    // largest energy of the mutated cloud (energy shift of the next stage): wave maxima ride along with the acceptance sums
+    __shared__ double emx[4];
+    double em = energy_or_ninf(like, like_prev, (ma.esum && !es_uniform) ? w_part : 1.0, live);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
+    if ((tid & 63) == 0) { red[tid >> 6] = a1[0]; emx[tid >> 6] = em; }
     if (ma.esum) {                                   // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
         energy_terms(es, w_part, like, like_prev, e_center, live, es_uniform);
@@ -2329,9 +2329,11 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     }
     __syncthreads();
     if (tid == 0) {
-        double s = 0.0;
+        double s = 0.0, m = emx[0];
         for (int w = 0; w < T / 64; ++w) s += red[w];
+        for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
         acc_partials[blockIdx.x] = s;
+        if (ma.emax) ma.emax[blockIdx.x] = m;
     }
     SMCMI_PROF(9);
 #undef SMCMI_PROF
