@@ -73,6 +73,10 @@ typedef struct {
     int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
     double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */
     double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-12; <0 => adjacent floats) */
+    int32_t stop_after_stage;              /* > 0: return (result.paused = 1) once cloud.stage_index has reached it - the save point of
+                                              `save_intermediate` / `intermediate_stage_increment` (smc_main.jl:499-507); single-GPU driver */
+    int32_t continue_run;                  /* 1: go on from the handle's loop state (after a pause, or after smcmi_set_loop_state:
+                                              `continue_intermediate`, smc_main.jl:334-335,355-361) instead of starting at stage 1 */
 } smcmi_run_config;
 
 typedef struct {
@@ -87,8 +91,20 @@ typedef struct {
     int32_t solver_stalls;   /* stages that ran out of enqueued solver passes and were resumed by the host */
     int32_t select_stalls;   /* stages enqueued without selection kernels that had to resample after all (host resumed them) */
     int32_t spec_stalls;     /* stages enqueued without a certificate pass whose predicted ϕ_n was unusable / not verified (resumed) */
-    int32_t reserved_;
+    int32_t paused;          /* 1: stopped at stop_after_stage with ϕ_n < 1; continue with continue_run = 1 */
 } smcmi_result;
+
+typedef struct {             /* the loop scalars an intermediate save holds (smc_main.jl:499-507: cloud fields + j) */
+    int32_t stage_index;     /* cloud.stage_index (i) */
+    int32_t j;               /* 1-based position in the proposed fixed schedule */
+    int32_t resampled_last_period;   /* the reference does not save this one: it continues with false */
+    int32_t resamples;       /* cloud.resamples */
+    double phi_n;            /* cloud.tempering_schedule[i] */
+    double phi_prop;         /* proposed_fixed_schedule[j] when continuing (smc_main.jl:361) */
+    double c, accept;        /* cloud.c, cloud.accept */
+    double ess;              /* cloud.ESS[i] */
+    double logmdd;           /* running Σ log((1/N) Σ w W) over the stages done so far */
+} smcmi_loop_state;
 
 typedef struct {             /* what one correction step reports (smc_main.jl:401-432) */
     double ess, sum_unnorm, logz_inc;
@@ -158,6 +174,13 @@ int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
 /* per-stage records: cloud.tempering_schedule, cloud.ESS, c, accept, resample flags; arrays of n_stages */
 int smcmi_get_stage_records(smcmi_handle *h, double *phi, double *ess, double *c, double *accept, int32_t *resampled);
 int smcmi_get_history(smcmi_handle *h, double *w, double *W);           /* n_local x n_stages each, column-major */
+/* intermediate save / continue (smc_main.jl:334-361, 499-507): the loop scalars, and - for a continuation in a fresh
+ * handle - the records and history columns of the stages already done (the cloud itself goes through smcmi_upload_cloud) */
+int smcmi_get_loop_state(smcmi_handle *h, smcmi_loop_state *out);
+int smcmi_set_loop_state(smcmi_handle *h, const smcmi_loop_state *in);
+int smcmi_set_stage_records(smcmi_handle *h, int32_t n_stages, const double *phi, const double *ess, const double *c,
+                            const double *accept, const int32_t *resampled);
+int smcmi_set_history(smcmi_handle *h, int32_t n_stages, const double *w, const double *W);
 
 /* ---- shard-level pieces for multi-GPU hosts (one handle per GPU; host does the collective) ----- */
 /* Every stage step is split as: partial (kernel writes this shard's partial sums into the comm buffer) ->

@@ -63,6 +63,8 @@ struct RunParams {             // smc() kwargs, uploaded once per run
     int max_stages;
     int store_history;
     int stall_on_exhaust;      // out of solver passes: 1 = stall the run (done = 2) for the host to resume, 0 = accept the bracket
+    int stop_stage;            // > 0: pause (done = 5) once stage_index has reached it (intermediate saves, smc_main.jl:499-507)
+    int pad_;
     double threshold;          // threshold_ratio * n_parts (:203)
     double alpha, target;
     double tempering_target;
@@ -109,6 +111,8 @@ struct DevState {
     double e_center;           // centre of the energy power sums the mutation epilogue accumulates (predictor, kernels.hpp)
     double pred_delta;         // diagnostic: predicted ϕ_n - ϕ_{n-1} of the current stage (NaN: no prediction)
     double e_shift;            // energy shift of this stage's incremental weights (largest loglh - old_loglh of the cloud; 0 = none)
+    int skip_fold;             // continued run: the acceptance / energy sums of the last mutation are already folded (or were never here)
+    int pad2_;
     Solver sol[2];
     // ---- moments / proposal (smc_main.jl:457-469, mutation.jl:81)
     double shift[MAXD];        // centering used by the one-pass moment kernel (previous mean)

@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
     // one round of scalar loads
     const int done = st->done, stage0 = st->stage, rs = st->do_resample, n_phi = st->rp.n_phi, fixed = st->rp.use_fixed_schedule;
-    const int max_stages = st->rp.max_stages, rl = st->resampled_last, j = st->j;
+    const int max_stages = st->rp.max_stages, rl = st->resampled_last, j = st->j, skip_fold = st->skip_fold, stop_stage = st->rp.stop_stage;
     const double phi_n = st->phi_n, phi_prop = st->phi_prop, ess_prev = st->ess_prev, target = st->rp.tempering_target;
     const double N = (double)st->rp.n_parts, e_center = st->e_center;
     // Energy sums + acceptance sum of the previous mutation: rows of ES = 32 doubles.  Thread t owns column t % 32 of the rows
@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     }
     const double ph_fixed = (fixed && i <= n_phi) ? sched[i - 1] : 0.0;
     // Σ accept over blocks of the previous mutation (update_acceptance_rate!, src/particle.jl:466-468)
-    const bool have_es = try_es && stage0 > 1 && !fixed;
+    const bool have_es = try_es && stage0 > 1 && !fixed && !skip_fold;
     __syncthreads();
     if (have_es && threadIdx.x < ES) {
         double tsum = 0.0;
@@ -762,14 +762,18 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     const int lane = threadIdx.x;
     if (have_es) asum = s_es[EACC];
     if (lane == 0) {
-        if (acc_nb > 0 && stage0 > 1) {
+        if (acc_nb > 0 && stage0 > 1 && !skip_fold) {
             const double a = asum / N;
             st->accept = a;
             rec.accept[stage0 - 1] = a;
         }
         if (rs) st->do_resample = 0;
+        if (skip_fold) st->skip_fold = 0;
     }
     if (phi_n >= 1.0) { if (lane == 0) { st->done = 1; st->e_shift = 0.0; } return; }
+    // intermediate save point: stage `stage0` is complete (its acceptance rate folded above); the host downloads what it wants
+    // and continues the same chain with smcmi_run(continue_run = 1)
+    if (stop_stage > 0 && stage0 >= stop_stage) { if (lane == 0) { st->done = 5; st->e_shift = 0.0; } return; }
     if (i > max_stages) { if (lane == 0) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; } return; }
     Solver &S = st->sol[0];
     if (lane == 0) { st->stage = i; st->phi_prev = phi_n; S.unconverged = 0; }

@@ -221,6 +221,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
     if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
+    if (rc->stop_after_stage > 0 || rc->continue_run) return set_err(SMCMI_ERR_UNSUPPORTED, "stop_after_stage / continue_run: single-GPU driver only");
     const bool adaptive = !rc->use_fixed_schedule;
     const int P_default = adaptive ? (rc->solver_passes >= 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only

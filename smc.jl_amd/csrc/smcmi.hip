@@ -876,14 +876,25 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
     rp.stall_on_exhaust = 1;
     rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
-    memset(&s, 0, sizeof(DevState));
-    s.rp = rp; s.cur = cur;
-    s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
-    s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
-    s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;   // tempered update: ESS of the old cloud (initialization.jl:199-200)
+    rp.stop_stage = rc->stop_after_stage > 0 ? rc->stop_after_stage : 0;
+    // continue_run (continue_intermediate, smc_main.jl:334-335,355-361): keep the loop scalars, records and history the handle
+    // holds (left by a paused run, or put there by smcmi_set_loop_state / _set_stage_records / _set_history)
+    const bool cont = rc->continue_run != 0;
+    if (cont) {
+        if (s.stage < 1 || s.stage >= h->cfg.max_stages) return set_err(SMCMI_ERR_STATE, "no loop state to continue from");
+        if (s.phi_n >= 1.0) return set_err(SMCMI_ERR_STATE, "the run to continue has already reached phi = 1");
+        s.rp = rp; s.done = 0; s.err = 0; s.skip_fold = 1; s.do_resample = 0;
+    } else {
+        memset(&s, 0, sizeof(DevState));
+        s.rp = rp; s.cur = cur;
+        s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
+        s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
+        s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;   // tempered update: ESS of the old cloud (initialization.jl:199-200)
+    }
+    const int base = cont ? s.stage - 1 : 0;                // stages completed before this call
     if (push_state(h)) return SMCMI_ERR_HIP;
     // stage-1 records and history columns (w[:,1] = 0, W[:,1] = weights; smc_main.jl:363-366)
-    {
+    if (!cont) {
         const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};
         HIP_TRY(hipMemcpyAsync(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -932,12 +943,12 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             HIP_TRY(hipGraphInstantiate(&gexec[v], graph[v], nullptr, nullptr, 0));
         }
     }
-    double pred_ess = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;   // ESS after the last completed stage
-    int pred_rl = 0;                                                                       // resampled_last_period
+    double pred_ess = cont ? s.ess_prev : (rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts);   // ESS after the last completed stage
+    int pred_rl = cont ? s.resampled_last : 0;                                             // resampled_last_period
     const auto t0 = std::chrono::steady_clock::now();
     int launched = 0, done = 0;
     res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0;
-    const int max_iter = adaptive ? h->cfg.max_stages : rc->n_phi - 1;
+    const int max_iter = (adaptive ? h->cfg.max_stages : rc->n_phi - 1) - base;
     int stall_stage = -1, stall_p = 0;        // stage that last ran out of solver passes and how many it has had so far
     int dyn_P = solver_passes;                // passes enqueued per stage: raised when stalls are frequent (poorly predictable models)
     // Predict-correct-verify pays only while predictions verify: three failures, each within four stages of the one before
@@ -972,13 +983,13 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         while (done == 2 || done == 3 || done == 4) {
             if (pull_state(h)) return SMCMI_ERR_HIP;
             const int st_i = s.stage;
-            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : dyn_P);
+            const int had = (st_i == stall_stage) ? stall_p : (st_i - base <= 3 ? first_passes : dyn_P);
             const int zero = 0;
             HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
             for (int &it : ev_iter)
-                if (it >= st_i - 2) it = -1;           // the stalled stage and everything behind it were no-ops
+                if (it >= st_i - 2 - base) it = -1;           // the stalled stage and everything behind it were no-ops
             hipEvent_t r0 = nullptr, r1 = nullptr;
-            if (profile) { hipEventCreate(&r0); hipEventCreate(&r1); evs.push_back(r0); evs.push_back(r1); ev_iter.push_back(st_i - 2); }
+            if (profile) { hipEventCreate(&r0); hipEventCreate(&r1); evs.push_back(r0); evs.push_back(r1); ev_iter.push_back(st_i - 2 - base); }
             if (done == 4) {
                 // A stage enqueued without a certificate pass had no usable prediction, or the ESS its correction produced did
                 // not verify it: nothing of the stage has been committed (W̃ went to scratch).  Re-arm the solver with the plain
@@ -1007,7 +1018,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 enqueue_stage(h, adaptive, 0, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, had, false, true);
                 res->select_stalls += 1;                   // selection stalls (diagnostic)
             }
-            launched = st_i - 1;
+            launched = st_i - 1 - base;
             HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
@@ -1074,12 +1085,13 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     }
     for (size_t k = 0; k + 1 < evs.size(); k += 2) {
         float ms = 0.f;
-        if (ev_iter[k / 2] >= 0 && ev_iter[k / 2] < s.stage - 1 && hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) { res->kernel_ms_mutate += std::max(0.0, (double)ms - ev_overhead_ms); res->n_mutate_launches += 1; }
+        if (ev_iter[k / 2] >= 0 && ev_iter[k / 2] < s.stage - 1 - base && hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) { res->kernel_ms_mutate += std::max(0.0, (double)ms - ev_overhead_ms); res->n_mutate_launches += 1; }
     }
     for (hipEvent_t e : evs) hipEventDestroy(e);
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
+    res->paused = (s.done == 5) ? 1 : 0;
     h->last_n_stages = s.stage;
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
@@ -1105,6 +1117,54 @@ extern "C" int smcmi_get_history(smcmi_handle *h, double *w, double *W) {
     const size_t bytes = sizeof(double) * (size_t)h->n * h->last_n_stages;
     if (w) HIP_TRY(hipMemcpy(w, h->d_hist_w, bytes, hipMemcpyDeviceToHost));
     if (W) HIP_TRY(hipMemcpy(W, h->d_hist_W, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- intermediate save / continue (smc_main.jl:334-361, 499-507)
+extern "C" int smcmi_get_loop_state(smcmi_handle *h, smcmi_loop_state *out) {
+    if (!h || !out) return set_err(SMCMI_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    const DevState &s = h->h_st;
+    out->stage_index = s.stage; out->j = s.j; out->resampled_last_period = s.resampled_last; out->resamples = s.resamples;
+    out->phi_n = s.phi_n; out->phi_prop = s.phi_prop; out->c = s.c; out->accept = s.accept; out->ess = s.ess_prev; out->logmdd = s.logz;
+    return 0;
+}
+
+extern "C" int smcmi_set_loop_state(smcmi_handle *h, const smcmi_loop_state *in) {
+    if (!h || !in) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (in->stage_index < 1 || in->stage_index > h->cfg.max_stages || in->j < 1 || !(in->phi_n >= 0.0 && in->phi_n <= 1.0))
+        return set_err(SMCMI_ERR_ARG, "loop state out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    s.stage = in->stage_index; s.j = in->j; s.resampled_last = in->resampled_last_period ? 1 : 0; s.resamples = in->resamples;
+    s.phi_n = in->phi_n; s.phi_prop = in->phi_prop; s.c = in->c; s.accept = in->accept;
+    s.ess = in->ess; s.ess_prev = in->ess; s.logz = in->logmdd;
+    s.done = 0; s.err = 0; s.do_resample = 0; s.cur = 0;
+    h->last_n_stages = in->stage_index;
+    return push_state(h);
+}
+
+extern "C" int smcmi_set_stage_records(smcmi_handle *h, int32_t n_stages, const double *phi, const double *ess, const double *c,
+                                       const double *accept, const int32_t *resampled) {
+    if (!h || n_stages < 1 || n_stages > h->cfg.max_stages) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (phi) HIP_TRY(hipMemcpy(h->rec.phi, phi, sizeof(double) * n_stages, hipMemcpyHostToDevice));
+    if (ess) HIP_TRY(hipMemcpy(h->rec.ess, ess, sizeof(double) * n_stages, hipMemcpyHostToDevice));
+    if (c) HIP_TRY(hipMemcpy(h->rec.c, c, sizeof(double) * n_stages, hipMemcpyHostToDevice));
+    if (accept) HIP_TRY(hipMemcpy(h->rec.accept, accept, sizeof(double) * n_stages, hipMemcpyHostToDevice));
+    if (resampled) HIP_TRY(hipMemcpy(h->rec.resampled, resampled, sizeof(int) * n_stages, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int smcmi_set_history(smcmi_handle *h, int32_t n_stages, const double *w, const double *W) {
+    if (!h || n_stages < 1 || n_stages > h->cfg.max_stages) return set_err(SMCMI_ERR_ARG, "bad argument");
+    if (!h->cfg.store_history) return set_err(SMCMI_ERR_STATE, "history is not stored (store_history = 0)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t bytes = sizeof(double) * (size_t)h->n * n_stages;
+    if (w) HIP_TRY(hipMemcpy(h->d_hist_w, w, bytes, hipMemcpyHostToDevice));
+    if (W) HIP_TRY(hipMemcpy(h->d_hist_W, W, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 

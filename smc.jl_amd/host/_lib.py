@@ -34,14 +34,21 @@ class RunConfig(C.Structure):
                 ("alpha", C.c_double), ("target", C.c_double), ("use_fixed_schedule", C.c_int32),
                 ("tempering_target", C.c_double), ("tempered_update_prior_weight", C.c_double),
                 ("log_prob_old_data", C.c_double), ("solver_passes", C.c_int32), ("sync_every", C.c_int32),
-                ("use_graph", C.c_int32), ("initial_ess", C.c_double), ("phi_rtol", C.c_double)]
+                ("use_graph", C.c_int32), ("initial_ess", C.c_double), ("phi_rtol", C.c_double),
+                ("stop_after_stage", C.c_int32), ("continue_run", C.c_int32)]
 
 
 class Result(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("resamples", C.c_int32), ("logmdd", C.c_double), ("c", C.c_double),
                 ("accept", C.c_double), ("seconds", C.c_double), ("kernel_ms_mutate", C.c_double),
                 ("n_mutate_launches", C.c_int32), ("solver_passes", C.c_int64), ("solver_stalls", C.c_int32),
-                ("select_stalls", C.c_int32), ("spec_stalls", C.c_int32), ("reserved_", C.c_int32)]
+                ("select_stalls", C.c_int32), ("spec_stalls", C.c_int32), ("paused", C.c_int32)]
+
+
+class LoopState(C.Structure):
+    _fields_ = [("stage_index", C.c_int32), ("j", C.c_int32), ("resampled_last_period", C.c_int32), ("resamples", C.c_int32),
+                ("phi_n", C.c_double), ("phi_prop", C.c_double), ("c", C.c_double), ("accept", C.c_double),
+                ("ess", C.c_double), ("logmdd", C.c_double)]
 
 
 class StageStats(C.Structure):
@@ -77,6 +84,10 @@ SYMBOLS = [
     ("smcmi_run", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),
     ("smcmi_get_stage_records", C.c_int, [_H, dp, dp, dp, dp, ip]),
     ("smcmi_get_history", C.c_int, [_H, dp, dp]),
+    ("smcmi_get_loop_state", C.c_int, [_H, C.POINTER(LoopState)]),
+    ("smcmi_set_loop_state", C.c_int, [_H, C.POINTER(LoopState)]),
+    ("smcmi_set_stage_records", C.c_int, [_H, C.c_int32, dp, dp, dp, dp, ip]),
+    ("smcmi_set_history", C.c_int, [_H, C.c_int32, dp, dp]),
     ("smcmi_comm_buffer", C.c_int, [_H, C.POINTER(C.c_void_p), lp]),
     ("smcmi_comm_read", C.c_int, [_H, dp, C.c_int64]),
     ("smcmi_shard_ess_partial", C.c_int, [_H, dp, C.c_int32, C.c_double]),

@@ -13,6 +13,7 @@ kernel) or any Python callable f(theta: ndarray, data: ndarray) -> float, which 
 (device proposal + prior + MH decision, host likelihood) exactly as a Julia closure would.
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -224,8 +225,9 @@ def cloud_isempty(c):
 def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300,
         resampling_method="systematic", threshold_ratio=0.5, c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True,
         tempering_target=0.97, old_data=None, old_loglikelihood=None, tempered_update_prior_weight=0.0,
-        log_prob_old_data=0.0, old_cloud=None, savepath=None, seed=0, device=0, max_stages=None, initial_cloud=None,
-        use_graph=0):
+        log_prob_old_data=0.0, old_cloud=None, savepath=None, particle_store_path=None, loadpath="",
+        continue_intermediate=False, save_intermediate=False, intermediate_stage_increment=10, seed=0, device=0,
+        max_stages=None, initial_cloud=None, use_graph=0):
     """Sequential Monte Carlo on one MI355X.  Keyword names follow src/smc_main.jl:119-161 (λ -> lam, n_Φ -> n_phi,
     α -> alpha).  Returns (cloud, w, W) - the three objects the reference writes to `savepath` - and, when `savepath`
     is given, stores them as a numpy .npz (the reference's JLD2/HDF5 writers are outside the hot path).
@@ -233,7 +235,13 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     Tempered update (src/smc_main.jl:244-333): pass `old_data` (and `old_loglikelihood` if it differs) together with
     `old_cloud`, the Cloud of the previous estimation; the initial cloud is then built on the device from the old cloud
     (same-size continuation, or bridge resample + prior draws when tempered_update_prior_weight > 0 / sizes differ).
-    `initial_cloud` instead starts the recursion from a ready-made cloud."""
+    `initial_cloud` instead starts the recursion from a ready-made cloud.
+
+    Intermediate saves (src/smc_main.jl:499-507): with `save_intermediate`, every `intermediate_stage_increment` stages the
+    device loop pauses and {cloud, w, W, j} go to `savepath` with `_stage=<i>` inserted before the extension;
+    `continue_intermediate` + `loadpath` resumes from such a file (src/smc_main.jl:334-335, 355-361: stage index, c, ϕ_prop =
+    schedule[j] are restored, `resampled_last_period` restarts as false like the reference's).  Files are numpy .npz here;
+    `particle_store_path` receives the n_parts x n_para draws (the reference's HDF5 `smcparams`) as .npy."""
     if verbose not in VERBOSITY:
         raise ValueError("verbose must be one of :none, :low, :high")
     if resampling_method not in ("systematic", "multinomial", "polyalgo"):
@@ -286,7 +294,19 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             w0 = eng.download_cloud()[:, d + 4].copy()
         else:
             eng.init_from_prior()
-        r = eng.run(use_graph=use_graph, **kw)
+        cont = False
+        if continue_intermediate:
+            cont = _load_intermediate(eng, loadpath, n_phi, lam, d)
+        while True:
+            stop = 0
+            if save_intermediate:
+                i_now = eng.get_loop_state()["stage_index"] if cont else 1
+                stop = (i_now // intermediate_stage_increment + 1) * intermediate_stage_increment
+            r = eng.run(use_graph=use_graph, stop_after_stage=stop, continue_run=cont, **kw)
+            if not r["paused"]:
+                break
+            _save_intermediate(eng, savepath, r, n_phi)
+            cont = True
         rec = eng.stage_records(r["n_stages"])
         w, W = eng.history(r["n_stages"])
         if w0 is not None:                       # W_matrix[:, 1] of a tempered update (smc_main.jl:364-365)
@@ -313,12 +333,55 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             mu, sd = weighted_mean(cloud), weighted_std(cloud)
             for p, m_, s_ in zip(parameters, mu, sd):
                 print("   %-12s mean %12.6f  std %12.6f" % (p.key, m_, s_))
+    if particle_store_path:
+        np.save(particle_store_path, np.ascontiguousarray(cloud.particles[:, :d]))        # `smcparams`, smc_main.jl:514-520
     if savepath:
         np.savez(savepath, particles=cloud.particles, tempering_schedule=cloud.tempering_schedule, ESS=cloud.ESS,
                  stage_index=cloud.stage_index, n_Phi=n_phi, resamples=cloud.resamples, c=cloud.c, accept=cloud.accept,
                  total_sampling_time=cloud.total_sampling_time, w=w, W=W)
     eng.close()
     return cloud, w, W
+
+
+def _stage_path(savepath, stage):
+    """replace(savepath, ".jld2" => "_stage=$(cloud.stage_index).jld2") (src/smc_main.jl:500) for any extension."""
+    root, ext = os.path.splitext(savepath if savepath else "smc_cloud.npz")
+    return "%s_stage=%d%s" % (root, stage, ext or ".npz")
+
+
+def _save_intermediate(eng, savepath, r, n_phi):
+    """{cloud, w, W, j} of a paused run (src/smc_main.jl:499-507)."""
+    ls = eng.get_loop_state()
+    ns = ls["stage_index"]
+    rec = eng.stage_records(ns)
+    w, W = eng.history(ns)
+    np.savez(_stage_path(savepath, ns), particles=eng.download_cloud(), tempering_schedule=rec["schedule"], ESS=rec["ess"],
+             c_hist=rec["c_hist"], accept_hist=rec["accept_hist"], resampled=rec["resampled"], stage_index=ns, n_Phi=n_phi,
+             resamples=ls["resamples"], c=ls["c"], accept=ls["accept"], total_sampling_time=r["seconds"], w=w, W=W, j=ls["j"],
+             logmdd=ls["logmdd"])
+
+
+def _load_intermediate(eng, loadpath, n_phi, lam, d):
+    """continue_intermediate (src/smc_main.jl:334-335, 355-361): cloud, w, W, j from `loadpath`; i = cloud.stage_index,
+    c = cloud.c, ϕ_prop = proposed_fixed_schedule[j]; resampled_last_period is not part of the file and restarts as false."""
+    if not loadpath:
+        raise ValueError("continue_intermediate needs loadpath")
+    z = np.load(loadpath)
+    P = np.asfortranarray(z["particles"], dtype=np.float64)
+    if P.shape != (eng.n, d + 5):
+        raise ValueError("cloud in %s has shape %r, expected %r" % (loadpath, P.shape, (eng.n, d + 5)))
+    ns, j = int(z["stage_index"]), int(z["j"])
+    w, W = np.asfortranarray(z["w"]), np.asfortranarray(z["W"])
+    sched = (np.arange(n_phi) / (n_phi - 1.0)) ** lam
+    # log-MDD so far = Σ_n log((1/N) Σ_i w[i,n] W[i,n-1]) - the reference evaluates it from the matrices at the end
+    logmdd = float(z["logmdd"]) if "logmdd" in z else float(np.sum(np.log(np.sum(w[:, 1:ns] * W[:, :ns - 1], axis=0) / eng.n)))
+    eng.upload_cloud(P)
+    eng.set_stage_records(z["tempering_schedule"], z["ESS"], z["c_hist"], z["accept_hist"], z["resampled"])
+    eng.set_history(w[:, :ns], W[:, :ns])
+    eng.set_loop_state(stage_index=ns, j=j, resampled_last_period=0, resamples=int(z["resamples"]),
+                       phi_n=float(z["tempering_schedule"][ns - 1]), phi_prop=float(sched[j - 1]), c=float(z["c"]),
+                       accept=float(z["accept"]), ess=float(z["ESS"][ns - 1]), logmdd=logmdd)
+    return True
 
 
 def _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, prior_weight, resampling_method, seed, device):

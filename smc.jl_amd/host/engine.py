@@ -173,15 +173,40 @@ class Engine:
     # ---- whole loop --------------------------------------------------------------------------------
     def run(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
             c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
-            log_prob_old_data=0.0, solver_passes=0, sync_every=0, use_graph=0, phi_rtol=0.0, initial_ess=0.0):
+            log_prob_old_data=0.0, solver_passes=0, sync_every=0, use_graph=0, phi_rtol=0.0, initial_ess=0.0,
+            stop_after_stage=0, continue_run=False):
+        """The whole loop on the device.  `stop_after_stage` = k pauses once cloud.stage_index has reached k (result["paused"]);
+        `continue_run` goes on from the handle's loop state (after a pause or set_loop_state) - the device side of
+        save_intermediate / continue_intermediate (src/smc_main.jl:334-361, 499-507)."""
         rc = self._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
                               use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, sync_every,
                               use_graph, phi_rtol, initial_ess)
+        rc.stop_after_stage, rc.continue_run = int(stop_after_stage), int(bool(continue_run))
         res = _lib.Result()
         check(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
-        return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
-                    seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
-                    solver_passes=res.solver_passes, solver_stalls=res.solver_stalls, select_stalls=res.select_stalls, spec_stalls=res.spec_stalls)
+        out = self._result(res)
+        out["paused"] = bool(res.paused)
+        return out
+
+    def get_loop_state(self):
+        s = _lib.LoopState()
+        check(self._L.smcmi_get_loop_state(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _lib.LoopState._fields_}
+
+    def set_loop_state(self, **fields):
+        s = _lib.LoopState()
+        for k, v in fields.items():
+            setattr(s, k, v)
+        check(self._L.smcmi_set_loop_state(self._h, C.byref(s)))
+
+    def set_stage_records(self, schedule, ess, c_hist, accept_hist, resampled):
+        a = [_f64(x) for x in (schedule, ess, c_hist, accept_hist)]
+        rs = np.ascontiguousarray(resampled, dtype=np.int32)
+        check(self._L.smcmi_set_stage_records(self._h, a[0].size, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _i(rs)))
+
+    def set_history(self, w, W):
+        w, W = np.asfortranarray(w, dtype=np.float64), np.asfortranarray(W, dtype=np.float64)
+        check(self._L.smcmi_set_history(self._h, w.shape[1], _d(w), _d(W)))
 
     def _run_config(self, n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
                     use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, sync_every, use_graph,

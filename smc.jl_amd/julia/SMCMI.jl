@@ -19,10 +19,11 @@ struct RunConfig
     threshold_ratio::Float64; c::Float64; alpha::Float64; target::Float64; use_fixed_schedule::Int32
     tempering_target::Float64; tempered_update_prior_weight::Float64; log_prob_old_data::Float64
     solver_passes::Int32; sync_every::Int32; use_graph::Int32; initial_ess::Float64; phi_rtol::Float64
+    stop_after_stage::Int32; continue_run::Int32   # save_intermediate / continue_intermediate (smc_main.jl:334-361, 499-507)
 end
 mutable struct Result
     n_stages::Int32; resamples::Int32; logmdd::Float64; c::Float64; accept::Float64; seconds::Float64
-    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32; spec_stalls::Int32; reserved_::Int32
+    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32; spec_stalls::Int32; paused::Int32
     Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
 end
 
@@ -86,7 +87,7 @@ function smc(loglikelihood::DeviceLikelihood, parameters::ParameterVector, data:
             check(ccall((:smcmi_upload_cloud, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], initial_cloud))
         end
         rc = RunConfig(n_blocks, n_mh_steps, λ, n_Φ, RESAMPLER[resampling_method], threshold_ratio, c, α, target,
-                       use_fixed_schedule ? 1 : 0, tempering_target, tempered_update_prior_weight, log_prob_old_data, 0, 0, 0, 0.0, 0.0)
+                       use_fixed_schedule ? 1 : 0, tempering_target, tempered_update_prior_weight, log_prob_old_data, 0, 0, 0, 0.0, 0.0, 0, 0)
         res = Result()
         check(ccall((:smcmi_run, LIB), Cint, (Ptr{Cvoid}, Ref{RunConfig}, Ref{Result}), h[], rc, res))
         particles = Matrix{Float64}(undef, n_parts, d + 5)

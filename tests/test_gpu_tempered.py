@@ -169,3 +169,40 @@ def test_bridge_with_large_energies_keeps_the_reference_range():
     # the stored incremental weights are the reference's exp(δ e), not the shifted ones
     np.testing.assert_allclose(w[:, 1], ro["w"][:, 1], rtol=1e-9, atol=0.0)
     np.testing.assert_allclose(W[:, 1], ro["W"][:, 1], rtol=1e-9, atol=1e-300)
+
+
+def test_intermediate_save_and_continue(tmp_path):
+    """save_intermediate / continue_intermediate (src/smc_main.jl:334-361, 499-507): the device loop pauses at every save point,
+    the host stores {cloud, w, W, j}, and a new process continues from the file.  Pausing must not change the run; a
+    continuation restores i, j, c, ϕ_prop = schedule[j] (resampled_last_period restarts as false, like the reference's)."""
+    import smc_jl_amd as S
+
+    data = models.regression_spec()["lik"][2]
+    base = dict(n_parts=4000, n_phi=40, tempering_target=0.9, seed=21, verbose="none")
+    for fixed in (True, False):
+        c0, w0, W0 = S.smc(S.LinReg(1.0), _pars(S), data, use_fixed_schedule=fixed, **base)
+        sp = str(tmp_path / ("run_%d.npz" % fixed))
+        c1, w1, W1 = S.smc(S.LinReg(1.0), _pars(S), data, use_fixed_schedule=fixed, save_intermediate=True,
+                           intermediate_stage_increment=7, savepath=sp, particle_store_path=str(tmp_path / "draws.npy"), **base)
+        # pausing only re-enters the stage chain: same stages, same resamples, results to rounding (the first stage after a
+        # pause runs the certificate path instead of predict-correct-verify)
+        assert c1.stage_index == c0.stage_index and c1.resamples == c0.resamples
+        np.testing.assert_allclose(c1.tempering_schedule, c0.tempering_schedule, rtol=1e-9)
+        np.testing.assert_allclose(c1.ESS, c0.ESS, rtol=1e-8)
+        assert c1.logmdd == pytest.approx(c0.logmdd, abs=1e-8)
+        np.testing.assert_allclose(W1, W0, rtol=1e-7, atol=1e-12)
+        assert np.load(str(tmp_path / "draws.npy")).shape == (4000, 2)
+        saved = sorted(int(p.name.split("_stage=")[1].split(".")[0]) for p in tmp_path.glob("run_%d_stage=*.npz" % fixed))
+        assert saved == list(range(7, c0.stage_index, 7))
+        # continue from a file whose stage did not resample (the flag the reference drops would matter otherwise)
+        rs_flags = np.load(sp)["ESS"]            # final file exists and holds the whole ESS path
+        assert rs_flags.size == c0.stage_index
+        k = next(s for s in saved if np.load(str(tmp_path / ("run_%d_stage=%d.npz" % (fixed, s))))["resampled"][s - 1] == 0)
+        lp = str(tmp_path / ("run_%d_stage=%d.npz" % (fixed, k)))
+        c2, w2, W2 = S.smc(S.LinReg(1.0), _pars(S), data, use_fixed_schedule=fixed, continue_intermediate=True, loadpath=lp, **base)
+        assert c2.stage_index == c0.stage_index and c2.resamples == c0.resamples
+        np.testing.assert_allclose(c2.tempering_schedule, c0.tempering_schedule, rtol=1e-9)
+        np.testing.assert_allclose(c2.ESS, c0.ESS, rtol=1e-8)
+        assert c2.logmdd == pytest.approx(c0.logmdd, abs=1e-8)
+        np.testing.assert_allclose(w2[:, :k], w0[:, :k], rtol=0, atol=0)          # history of the stages done before the save
+        np.testing.assert_allclose(S.weighted_mean(c2), S.weighted_mean(c0), rtol=1e-7)
