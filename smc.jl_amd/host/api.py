@@ -336,9 +336,8 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     if particle_store_path:
         np.save(particle_store_path, np.ascontiguousarray(cloud.particles[:, :d]))        # `smcparams`, smc_main.jl:514-520
     if savepath:
-        np.savez(savepath, particles=cloud.particles, tempering_schedule=cloud.tempering_schedule, ESS=cloud.ESS,
-                 stage_index=cloud.stage_index, n_Phi=n_phi, resamples=cloud.resamples, c=cloud.c, accept=cloud.accept,
-                 total_sampling_time=cloud.total_sampling_time, w=w, W=W)
+        from .cloudio import save_cloud
+        save_cloud(savepath, cloud, w, W)                          # write(file, "cloud"/"w"/"W"), smc_main.jl:521-525
     eng.close()
     return cloud, w, W
 
