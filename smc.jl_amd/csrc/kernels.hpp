@@ -1418,12 +1418,20 @@ __global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, 
 
 // First level of a two-level row reduction for very many partial rows (N >= ~3e5: one row per 256 particles): block g totals the
 // rows of its contiguous chunk in fixed order -> out[g][m]; the consumer then totals gridDim.x rows instead of nb.
-__global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int nb, int m, double *out) {
+__global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int nb, int m, double *out, const double *emax_in = nullptr,
+                                                    double *emax_out = nullptr) {
     __shared__ double scratch[TB];
+    __shared__ double smem[TB / 64];
     const int per = (nb + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * per, rows = (r0 + per <= nb) ? per : (nb > r0 ? nb - r0 : 0);
     const double tot = final_sum(partials + (long long)r0 * m, rows, m, scratch);
     if (threadIdx.x < m) out[(long long)blockIdx.x * m + threadIdx.x] = tot;
+    if (emax_in) {                      // the chunk's energy maximum rides along (one value per row)
+        double em = -__builtin_inf();
+        for (int b = threadIdx.x; b < rows; b += TB) em = fmax(em, emax_in[r0 + b]);
+        em = block_max(em, smem, TB / 64);
+        if (threadIdx.x == 0) emax_out[blockIdx.x] = em;
+    }
 }
 
 // normalize_weights! as its own pass (src/particle.jl:362-366) for the stand-alone correction call
@@ -1976,7 +1984,7 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
 // at ~1.5 wavefronts per SIMD (N = 1e5) every LDS / global round trip is exposed latency, a select is not.
 // The block factor L, the block constants and the model constants are staged once into LDS (uniform-address reads).
 template <int D, bool ALPHA1>
-__global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
+__global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
                                                    double *acc_partials, int standalone, int nb, int nf) {
 #pragma clang fp contract(fast)
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -2320,9 +2328,13 @@ __global__ void __launch_bounds__(256, 2) k_mutate_reg(CloudPtrs cl, const DevSt
     __syncthreads();
     // largest energy of the mutated cloud (energy shift of the next stage): wave maxima ride along with the acceptance sums
     __shared__ double emx[4];
+#ifdef SMCMI_EXP_NOEMAX
+    double em = 0.0;
+#else
     double em = energy_or_ninf(like, like_prev, (ma.esum && !es_uniform) ? w_part : 1.0, live);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
+#endif
     if ((tid & 63) == 0) { red[tid >> 6] = a1[0]; emx[tid >> 6] = em; }
     if (ma.esum) {                                   // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];

@@ -171,7 +171,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) || dmalloc(&h->d_wt, n) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * ES) || dmalloc(&h->d_emax_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * (ES + 1)) || dmalloc(&h->d_emax_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -815,13 +815,15 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     if (!tail_only) {
     if (p0 == 0 && !skip_begin) {
         const double *es = (adaptive && !no_pred) ? h->d_esum_part : nullptr;
-        int es_nb = acc_nb;
+        int es_nb = acc_nb, em_nb = acc_nb;
+        const double *em = h->d_emax_part;
         if (es && acc_nb > 2048) {       // one wave per column in k_stage_begin does not scale to tens of thousands of rows
-            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red);
+            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red, h->d_emax_part, h->d_esum_red + (size_t)ESUM_RED_ROWS * ES);
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
+            em = h->d_esum_red + (size_t)ESUM_RED_ROWS * ES; em_nb = ESUM_RED_ROWS;
         }
         k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
-                                       h->spec_stage ? 1 : 0, no_eshift ? nullptr : h->d_emax_part, acc_nb);
+                                       h->spec_stage ? 1 : 0, no_eshift ? nullptr : em, em_nb);
     }
     if (adaptive && !h->spec_stage) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);

@@ -52,3 +52,21 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle-backed", "").replace("the oracle", "").replace("oracle's", "").replace("oracle (", ""), os.path.join(dp, f)
+
+
+def test_mutation_kernel_keeps_three_waves_per_simd(libmod):
+    """k_mutate_reg<10, α=1> (the kernel `roofline` is quoted on) sits two registers below an occupancy step: at 170 VGPRs only two
+    wavefronts fit a SIMD and the kernel loses a quarter of its speed at N >= 1e6 (VALU-issue bound there).  The build keeps
+    the compiler's resource report next to the library (csrc/Makefile); a change that pushes the kernel over the step, or into
+    scratch, fails here instead of in a benchmark three rounds later."""
+    rep = os.path.join(ROOT, "smc.jl_amd", "csrc", "resource_usage.txt")
+    if not os.path.exists(rep):
+        pytest.skip("library was built without the resource report")
+    txt = open(rep).read()
+    for key, min_occ, max_scratch in (("k_mutate_regILi10ELb1E", 3, 64), ("k_mutate_regILi9ELb1E", 3, 64)):
+        m = re.search(r"Function Name: _ZN5smcmi\d+" + key + r"[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*Occupancy \[waves/SIMD\]: (\d+)", txt)
+        assert m, key
+        blk = txt[m.start():m.end()]
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+        assert int(m.group(1)) >= min_occ, (key, m.group(1))
+        assert scratch <= max_scratch, (key, scratch)
