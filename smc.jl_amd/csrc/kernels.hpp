@@ -2328,13 +2328,9 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
     __syncthreads();
     // largest energy of the mutated cloud (energy shift of the next stage): wave maxima ride along with the acceptance sums
     __shared__ double emx[4];
-#ifdef SMCMI_EXP_NOEMAX
-    double em = 0.0;
-#else
     double em = energy_or_ninf(like, like_prev, (ma.esum && !es_uniform) ? w_part : 1.0, live);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
-#endif
     if ((tid & 63) == 0) { red[tid >> 6] = a1[0]; emx[tid >> 6] = em; }
     if (ma.esum) {                                   // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
