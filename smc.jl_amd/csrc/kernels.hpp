@@ -2213,42 +2213,38 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
                 sub[e] = sv;
             }
             const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
-            if (comp == 1 || (ma.debug & 4)) {
-#pragma unroll
-                for (int e = 0; e < D; ++e) dr[e] = sub[e] + sdd_s[e] * z[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < D; ++e) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k <= e; ++k) s += Ls[e * D + k] * z[k];
-                    dr[e] = ((comp == 0) ? sub[e] : mu_s[e]) + s;
-                }
-            }
+            const bool diag_draw = comp == 1 || (ma.debug & 4);
             SMCMI_PROF(5);
-            // ---- compute_proposal_densities (src/helpers.jl:128-164)
+            // ---- mixture draw (src/helpers.jl:87-100) and compute_proposal_densities (src/helpers.jl:128-164) in ONE sweep over the
+            // rows of the factor: row e gives the draw ϑ_e = centre_e + Σ_{k<=e} L_ek z_k and then row e of the three forward
+            // substitutions L⁻¹(θ_b - ϑ_b), L⁻¹(θ_b - θ̄_b), L⁻¹(ϑ_b - θ̄_b) - each in the arithmetic order of a separate solve, so
+            // the results are bit for bit those of four passes over L; but one row of L is live at a time instead of the whole
+            // factor (55 values = 110 VGPRs, which used to push 100 doubles per lane into scratch).
             const double cst = (double)db * LOG2PI + logdet_s[b];
             double zz2 = 0.0;
 #pragma unroll
             for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
-            if constexpr (ALPHA1) {
-                // α = 1 (launch-time dispatch): q0 = q1 = log N(θ_b; ϑ_b, c²Σ) bit for bit (the quadratic form is
-                // sign-symmetric) and the other mixture terms carry weight 0, so q0 - q1 == 0 - unless exp() underflows to 0
-                // (log-density < -745.13), where the reference gets log(0) - log(0) = NaN and rejects.  |L⁻¹(θ_b-ϑ_b)|² = Σz².
-                q0 = 0.0;
-                q1 = (-(cst + zz2) / 2.0 < -745.1332191019412) ? __builtin_nan("") : 0.0;
-            } else {
-                double v[D];
-                double quad = 0.0;
+            {
+                double v1[D], v2[D], v3[D];
+                double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
 #pragma unroll
-                for (int e = 0; e < D; ++e) {            // L⁻¹(θ_b - ϑ_b): forward == reverse density
-                    double s = sub[e] - dr[e];
+                for (int e = 0; e < D; ++e) {
+                    double Lr[D];
 #pragma unroll
-                    for (int k = 0; k < e; ++k) s -= Ls[e * D + k] * v[k];
-                    v[e] = s / Ls[e * D + e];
-                    quad += v[e] * v[e];
+                    for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
+                    double sd = 0.0;
+#pragma unroll
+                    for (int k = 0; k <= e; ++k) sd += Lr[k] * z[k];
+                    dr[e] = diag_draw ? sub[e] + sdd_s[e] * z[e] : ((comp == 0) ? sub[e] : mu_s[e]) + sd;
+                    double s1 = sub[e] - dr[e], s2 = sub[e] - mu_s[e], s3 = dr[e] - mu_s[e];
+#pragma unroll
+                    for (int k = 0; k < e; ++k) { s1 -= Lr[k] * v1[k]; s2 -= Lr[k] * v2[k]; s3 -= Lr[k] * v3[k]; }
+                    v1[e] = s1 / Lr[e]; v2[e] = s2 / Lr[e]; v3[e] = s3 / Lr[e];
+                    quad += v1[e] * v1[e]; quad_s += v2[e] * v2[e]; quad_d += v3[e] * v3[e];
+                    // pin the row's results: otherwise the optimiser interleaves the rows and keeps the whole factor live
+                    asm volatile("" : "+v"(v1[e]), "+v"(v2[e]), "+v"(v3[e]), "+v"(dr[e]));
                 }
-                q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;
+                q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;          // forward == reverse density of the random-walk component
                 double ind_pdf = 1.0;
 #pragma unroll
                 for (int e = 0; e < D; ++e) {
@@ -2260,23 +2256,6 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
                 }
                 q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
                 q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                double quad_s = 0.0, quad_d = 0.0;
-#pragma unroll
-                for (int e = 0; e < D; ++e) {            // log N(θ_b; θ̄_b, c²Σ)
-                    double s = sub[e] - mu_s[e];
-#pragma unroll
-                    for (int k = 0; k < e; ++k) s -= Ls[e * D + k] * v[k];
-                    v[e] = s / Ls[e * D + e];
-                    quad_s += v[e] * v[e];
-                }
-#pragma unroll
-                for (int e = 0; e < D; ++e) {            // log N(ϑ_b; θ̄_b, c²Σ)
-                    double s = dr[e] - mu_s[e];
-#pragma unroll
-                    for (int k = 0; k < e; ++k) s -= Ls[e * D + k] * v[k];
-                    v[e] = s / Ls[e * D + e];
-                    quad_d += v[e] * v[e];
-                }
                 q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
                 q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
                 q0 = log(q0);
