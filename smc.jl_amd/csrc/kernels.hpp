@@ -2215,8 +2215,8 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
             const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
             const bool diag_draw = comp == 1 || (ma.debug & 4);
             SMCMI_PROF(5);
-            // ---- mixture draw (src/helpers.jl:87-100) and compute_proposal_densities (src/helpers.jl:128-164) in ONE sweep over the
-            // rows of the factor: row e gives the draw ϑ_e = centre_e + Σ_{k<=e} L_ek z_k and then row e of the three forward
+            // ---- mixture draw (src/helpers.jl:87-100) and compute_proposal_densities (src/helpers.jl:128-164) in row sweeps over
+            // the factor: row e gives the draw ϑ_e = centre_e + Σ_{k<=e} L_ek z_k and then row e of the three forward
             // substitutions L⁻¹(θ_b - ϑ_b), L⁻¹(θ_b - θ̄_b), L⁻¹(ϑ_b - θ̄_b) - each in the arithmetic order of a separate solve, so
             // the results are bit for bit those of four passes over L; but one row of L is live at a time instead of the whole
             // factor (55 values = 110 VGPRs, which used to push 100 doubles per lane into scratch).
@@ -2225,24 +2225,41 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
 #pragma unroll
             for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
             {
-                double v1[D], v2[D], v3[D];
                 double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
+                {
+                    double v1[D];
 #pragma unroll
-                for (int e = 0; e < D; ++e) {
-                    double Lr[D];
+                    for (int e = 0; e < D; ++e) {       // sweep A: the draw and L⁻¹(θ_b - ϑ_b); the normals die here
+                        double Lr[D];
 #pragma unroll
-                    for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
-                    double sd = 0.0;
+                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
+                        double sd = 0.0;
 #pragma unroll
-                    for (int k = 0; k <= e; ++k) sd += Lr[k] * z[k];
-                    dr[e] = diag_draw ? sub[e] + sdd_s[e] * z[e] : ((comp == 0) ? sub[e] : mu_s[e]) + sd;
-                    double s1 = sub[e] - dr[e], s2 = sub[e] - mu_s[e], s3 = dr[e] - mu_s[e];
+                        for (int k = 0; k <= e; ++k) sd += Lr[k] * z[k];
+                        dr[e] = diag_draw ? sub[e] + sdd_s[e] * z[e] : ((comp == 0) ? sub[e] : mu_s[e]) + sd;
+                        double s1 = sub[e] - dr[e];
 #pragma unroll
-                    for (int k = 0; k < e; ++k) { s1 -= Lr[k] * v1[k]; s2 -= Lr[k] * v2[k]; s3 -= Lr[k] * v3[k]; }
-                    v1[e] = s1 / Lr[e]; v2[e] = s2 / Lr[e]; v3[e] = s3 / Lr[e];
-                    quad += v1[e] * v1[e]; quad_s += v2[e] * v2[e]; quad_d += v3[e] * v3[e];
-                    // pin the row's results: otherwise the optimiser interleaves the rows and keeps the whole factor live
-                    asm volatile("" : "+v"(v1[e]), "+v"(v2[e]), "+v"(v3[e]), "+v"(dr[e]));
+                        for (int k = 0; k < e; ++k) s1 -= Lr[k] * v1[k];
+                        v1[e] = s1 / Lr[e];
+                        quad += v1[e] * v1[e];
+                        // pin the row's results: otherwise the optimiser interleaves the rows and keeps the whole factor live
+                        asm volatile("" : "+v"(v1[e]), "+v"(dr[e]));
+                    }
+                }
+                {
+                    double v2[D], v3[D];
+#pragma unroll
+                    for (int e = 0; e < D; ++e) {       // sweep B: L⁻¹(θ_b - θ̄_b) and L⁻¹(ϑ_b - θ̄_b)
+                        double Lr[D];
+#pragma unroll
+                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
+                        double s2 = sub[e] - mu_s[e], s3 = dr[e] - mu_s[e];
+#pragma unroll
+                        for (int k = 0; k < e; ++k) { s2 -= Lr[k] * v2[k]; s3 -= Lr[k] * v3[k]; }
+                        v2[e] = s2 / Lr[e]; v3[e] = s3 / Lr[e];
+                        quad_s += v2[e] * v2[e]; quad_d += v3[e] * v3[e];
+                        asm volatile("" : "+v"(v2[e]), "+v"(v3[e]));
+                    }
                 }
                 q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;          // forward == reverse density of the random-walk component
                 double ind_pdf = 1.0;
