@@ -169,3 +169,47 @@ print(json.dumps(dict(n=r["n_stages"], rs=r["resamples"], logmdd=r["logmdd"], ch
         out[mode] = __import__("json").loads(res.stdout.strip().splitlines()[-1])
     assert out["alltoall"]["rs"] > 3
     assert out["alltoall"] == out["allgather"]
+
+
+def test_group_driver_shares_one_energy_shift_across_shards():
+    """The large-energy bridge of test_gpu_tempered (loglh - old_loglh ~ -600 everywhere) on two in-process shards: every shard
+    must correct with the SAME energy shift (the largest energy over all shards travels in the epilogue all-reduce), or the
+    summed weights of the shards would carry different factors."""
+    from smc_jl_amd import Engine, run_group
+
+    n, d, seed = 4096, 9, 779
+    spec = models.linmodel_spec(T=100, old_T=60)
+    e = Engine(n, d, seed=seed, max_stages=400)
+    e.set_model(models.linmodel_spec(T=60))
+    e.init_from_prior()
+    r_old = e.run(n_phi=60, use_fixed_schedule=True, n_mh_steps=2)
+    ess_old = float(e.stage_records(r_old["n_stages"])["ess"][-1])
+    P_old = e.download_cloud()
+    e.close()
+    e = Engine(n, d, seed=seed + 1, max_stages=400)
+    e.set_model(spec)
+    e.upload_cloud(P_old)
+    e.initialize_likelihoods()
+    P0 = e.download_cloud()
+    kw = dict(n_blocks=3, n_mh_steps=2, alpha=0.5, use_fixed_schedule=False, n_phi=30, tempering_target=0.95,
+              resampling_method="systematic", threshold_ratio=0.8, initial_ess=ess_old)
+    g = e.run(**kw)
+    rec = e.stage_records(g["n_stages"])
+    P = e.download_cloud()
+    e.close()
+    # make the shards' maxima differ: the best particle lives in shard 1
+    assert np.argmax(P0[:, d] - P0[:, d + 2]) >= n // 2 or np.max((P0[:, d] - P0[:, d + 2])[: n // 2]) != np.max((P0[:, d] - P0[:, d + 2])[n // 2:])
+    engs = []
+    for r in range(2):
+        s = Engine(n, d, seed=seed + 1, max_stages=400, n_local=n // 2, gid0=r * (n // 2))
+        s.set_model(spec)
+        s.upload_cloud(np.asfortranarray(P0[r * (n // 2):(r + 1) * (n // 2)]))
+        engs.append(s)
+    rg = run_group(engs, **kw)
+    assert rg["n_stages"] == g["n_stages"] and rg["resamples"] == g["resamples"]
+    assert rg["logmdd"] == pytest.approx(g["logmdd"], abs=1e-8)
+    np.testing.assert_allclose(engs[0].stage_records(rg["n_stages"])["ess"], rec["ess"], rtol=1e-8)
+    full = np.concatenate([s.download_cloud() for s in engs], axis=0)
+    np.testing.assert_allclose(full, P, rtol=1e-7, atol=1e-9)
+    for s in engs:
+        s.close()
