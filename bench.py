@@ -127,7 +127,7 @@ def main():
         def one_step(profile=False):
             eng.cloud_tensor().copy_(snap)
             torch.cuda.synchronize()
-            return eng.run_sharded(solver_passes=args.solver_passes, **RUN_KW)
+            return eng.run_sharded(solver_passes=args.solver_passes, use_graph=2 if profile else 0, **RUN_KW)
 
     for _ in range(args.warmup):
         one_step()
@@ -161,13 +161,22 @@ def main():
         "logmdd_exact": models.gauss_logmdd(D) if args.workload == "gauss10" else None, "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
     }
 
-    if rank == 0 and world == 1 and not force_sharded:
-        # ---- roofline of the dominant kernel (mutation): HIP events around every k_mutate launch of one more
-        # identical run on the engine's stream (smcmi_run use_graph = 2), algorithmic bytes / mean duration
+    sharded = world > 1 or force_sharded
+    prof = None
+    if sharded:
+        # every rank takes part in the profiled run (it holds collectives); rank 0 reports its own GPU's kernel
         prof = one_step(profile=True)
+        barrier()
+    if rank == 0:
+        # ---- roofline of the dominant kernel (mutation): HIP events around every k_mutate launch of one more
+        # identical run on the engine's stream (use_graph = 2), algorithmic bytes / mean duration.  Multi-GPU lines quote the
+        # kernel of rank 0's GPU on its shard (n_local particles): per-GPU figures, like `peak`.
+        if prof is None:
+            prof = one_step(profile=True)
+        n_k = n_local if sharded else n_total
         nl = max(prof["n_mutate_launches"], 1)
         mean_ms = prof["kernel_ms_mutate"] / nl
-        bytes_per_launch = mutate_bytes_per_particle(D) * n_total      # all MH steps of a stage are fused in the one launch
+        bytes_per_launch = mutate_bytes_per_particle(D) * n_k          # all MH steps of a stage are fused in the one launch
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read correction):
         # profiles/pmc_extract.py -> profiles/r01_pmc_traffic.json, bytes per particle of this kernel x particles
@@ -177,7 +186,7 @@ def main():
                 pm = json.load(f)
             k = [v for name, v in pm["kernels"].items() if "k_mutate_reg<%d," % D in name]
             if k:
-                traffic = k[0]["bytes_per_particle"] * n_total
+                traffic = k[0]["bytes_per_particle"] * n_k
         except OSError:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": ("k_mutate_reg<%d,true>" % D) if D <= 10 else "k_mutate<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -193,7 +202,7 @@ def main():
                 ahead = n_local * RUN_KW.get("n_mh_steps", 1) * RUN_KW.get("n_blocks", 1) <= 500000 and not os.environ.get("SMCMI_NO_RNG_AHEAD")
                 isa = json.load(f).get(("k_mutate_reg<%d,true>" % D) + (" rng_ahead" if ahead else ""))
             if isa and RUN_KW.get("n_mh_steps", 1) == 1 and mean_ms > 0:
-                waves = -(-n_total // 64)
+                waves = -(-n_k // 64)
                 # SIMD-32: a wave64 VALU instruction issues over 2 cycles, FP64 over 4 (half rate), 32x32-bit multiplies over 8
                 cyc = 4 * isa["valu_f64"] + 2 * isa["valu_other"] + 8 * isa.get("valu_int_mul", 0)
                 peak = 256 * 4 * 2.4e9                # SIMD issue cycles / s
@@ -208,7 +217,7 @@ def main():
             # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s
             # (vector = matrix rate for FP64 on gfx950)
             steps = spec["lik"][2].shape[1] + (spec["old_lik"][2].shape[1] if spec["old_lik"] else 0)
-            flops = 3300.0 * steps * RUN_KW["n_mh_steps"] * n_total
+            flops = 3300.0 * steps * RUN_KW["n_mh_steps"] * n_k
             tf = flops / (mean_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_mutate<0> / kalman_lgss (FP64 vector FMA)", "achieved": tf, "peak": 78.6,
                                "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None, "flops_per_launch": flops,
@@ -216,7 +225,7 @@ def main():
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages
         stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
         out["stage_gbs"] = stage_bytes * args.steps / dt / 1e9
-        if not args.no_cpu:
+        if not args.no_cpu and not sharded:          # CPU baseline: rank 0 at N = 1 only
             from oracle import oracle as orc
 
             orc.build()

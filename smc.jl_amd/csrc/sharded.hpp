@@ -280,6 +280,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     // mode 0: full stage with selection path; 1: no selection expected; 2: tail only (from k_post_correct on; selection path)
     // spec: predict -> correct -> verify (no certificate pass, no all-reduce for it: 2 collectives per stage);
     // skip_begin: resume of such a stage through the certificate path
+    // use_graph == 2: HIP events around the first local shard's mutation launches (the `roofline` figure of a multi-GPU bench line)
+    const bool profile = rc->use_graph == 2;
+    std::vector<hipEvent_t> mut_evs;
     auto enqueue = [&](int p0, int P, int mode, bool spec = false, bool skip_begin = false) -> int {
         if (spec) P = 0;
         const int fin_slot = P == 0 ? 0 : (P & 1);
@@ -333,7 +336,10 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 launch_prepare_in_run(h, h->d_tot_mom, 1, 3, fin_slot);
+                hipEvent_t pe0 = nullptr, pe1 = nullptr;
+                if (profile && h == h0) { hipEventCreate(&pe0); hipEventCreate(&pe1); mut_evs.push_back(pe0); mut_evs.push_back(pe1); hipEventRecord(pe0, h->stream); }
                 const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
+                if (pe1) hipEventRecord(pe1, h->stream);
                 if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
                 else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
             }
@@ -431,7 +437,10 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             launch_prepare_in_run(h, h->d_tot_mom, 1, 2);
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            if (profile && h == h0) { hipEventCreate(&pe0); hipEventCreate(&pe1); mut_evs.push_back(pe0); mut_evs.push_back(pe1); hipEventRecord(pe0, h->stream); }
             const int nbl = launch_mutate(h, rc->n_blocks, 0, rc->alpha);
+            if (pe1) hipEventRecord(pe1, h->stream);
             if (predict) k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_esum_part, nbl, ES, h->d_tot_acc, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
             else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, nbl, 1, h->d_tot_acc + EACC, h->d_emax_part, nbl, h->d_tot_acc + ES, shard_rank(h), g.world);
         }
@@ -526,6 +535,31 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
     res->solver_stalls = stalls; res->select_stalls = sel_stalls; res->spec_stalls = spec_stalls;
+    if (!mut_evs.empty()) {
+        // event pairs bracket dispatch + kernel; launches of stalled (no-op) stages are short and rare - they stay in the mean.
+        // The dispatch part is calibrated like in smcmi_run: pairs around an empty kernel of the same grid, minus its own ~2.5 µs.
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        hipEvent_t c0, c1;
+        hipEventCreate(&c0); hipEventCreate(&c1);
+        double acc_ms = 0.0;
+        int got = 0;
+        for (int r = 0; r < 64; ++r) {
+            k_noop<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(h0->d_st);
+            hipEventRecord(c0, h0->stream);
+            k_noop<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(h0->d_st);
+            hipEventRecord(c1, h0->stream);
+            hipStreamSynchronize(h0->stream);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c0, c1) == hipSuccess) { acc_ms += ms; ++got; }
+        }
+        hipEventDestroy(c0); hipEventDestroy(c1);
+        const double over = got ? std::max(0.0, acc_ms / got - 0.0025) : 0.0;
+        for (size_t k = 0; k + 1 < mut_evs.size(); k += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, mut_evs[k], mut_evs[k + 1]) == hipSuccess) { res->kernel_ms_mutate += std::max(0.0, (double)ms - over); res->n_mutate_launches += 1; }
+        }
+        for (hipEvent_t e : mut_evs) hipEventDestroy(e);
+    }
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;

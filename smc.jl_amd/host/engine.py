@@ -228,9 +228,9 @@ class Engine:
 
     def run_sharded(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
                     c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
-                    log_prob_old_data=0.0, solver_passes=0, phi_rtol=0.0, initial_ess=0.0):
+                    log_prob_old_data=0.0, solver_passes=0, phi_rtol=0.0, initial_ess=0.0, use_graph=0):
         rc = self._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
-                              use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, 0, 0, phi_rtol,
+                              use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, 0, use_graph, phi_rtol,
                               initial_ess)
         res = _lib.Result()
         check(self._L.smcmi_run_sharded(self._h, C.byref(rc), C.byref(res)))
