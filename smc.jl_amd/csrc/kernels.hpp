@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
                                                     int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
                                                     int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0) {
     __shared__ double scratch[BT];
-    __shared__ double s_emx[BT / 64];
+    __shared__ double s_em[BT], s_em2[64], s_em3[8];     // energy maxima: reduced through LDS behind the barriers the sums need anyway
     SMCMI_STAMP(prof, 0);
     __shared__ double s_es[ES];
     __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
@@ -730,11 +730,7 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
         for (int b = threadIdx.x; b < emax_n; b += BT) em = fmax(em, emax_part[b]);
     if (done) return;
     SMCMI_STAMP(prof, 1);
-    if (emax_part) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
-        if ((threadIdx.x & 63) == 0) s_emx[threadIdx.x >> 6] = em;
-    }
+    s_em[threadIdx.x] = em;
     const int i = stage0 + 1;
     double swv = 2.0;                                  // stays in flight across the reduction's loads; stored to LDS after them
     if (threadIdx.x < 64) {
@@ -751,7 +747,21 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
         for (int g = 0; g < BT / 64; ++g) tsum += scratch[g * 32 + threadIdx.x];
         s_es[threadIdx.x] = tsum;
     }
+    if (threadIdx.x >= 64 && threadIdx.x < 128) {        // wave 1: 1024 -> 64 maxima
+        const int c = threadIdx.x - 64;
+        double m = s_em[c];
+#pragma unroll
+        for (int q = 1; q < BT / 64; ++q) m = fmax(m, s_em[c + 64 * q]);
+        s_em2[c] = m;
+    }
     __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 72) {         // 64 -> 8
+        const int c = threadIdx.x - 64;
+        double m = s_em2[c * 8];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) m = fmax(m, s_em2[c * 8 + q]);
+        s_em3[c] = m;
+    }
     double asum = 0.0;
     if (!have_es && acc_nb > 0) asum = final_sum1(acc_partials, acc_nb, scratch);
     if (threadIdx.x < 64) s_sw[threadIdx.x] = swv;
@@ -778,9 +788,9 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
     Solver &S = st->sol[0];
     if (lane == 0) { st->stage = i; st->phi_prev = phi_n; S.unconverged = 0; }
     if (emax_part && lane == 0) {
-        double m = s_emx[0];
+        double m = s_em3[0];
 #pragma unroll
-        for (int w = 1; w < BT / 64; ++w) m = fmax(m, s_emx[w]);
+        for (int w = 1; w < 8; ++w) m = fmax(m, s_em3[w]);
         if (fabs(m) < 1e300) st->e_shift = m;              // no live particle with a finite energy: keep the previous shift
     }
     if (fixed) {
