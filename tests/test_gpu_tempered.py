@@ -206,3 +206,28 @@ def test_intermediate_save_and_continue(tmp_path):
         assert c2.logmdd == pytest.approx(c0.logmdd, abs=1e-8)
         np.testing.assert_allclose(w2[:, :k], w0[:, :k], rtol=0, atol=0)          # history of the stages done before the save
         np.testing.assert_allclose(S.weighted_mean(c2), S.weighted_mean(c0), rtol=1e-7)
+
+
+def test_continue_run_error_paths():
+    """continue_run needs loop state to continue from; a finished run cannot be continued; the sharded drivers refuse pause / continue."""
+    from smc_jl_amd import Engine, run_group
+    from smc_jl_amd.host._lib import SMCMIError
+
+    spec = models.gauss_spec(d=3)
+    e = Engine(2048, 3, seed=4, max_stages=400)
+    e.set_model(spec)
+    e.init_from_prior()
+    r = e.run(n_phi=20, use_fixed_schedule=True, stop_after_stage=5)
+    assert r["paused"] and r["n_stages"] == 5
+    ls = e.get_loop_state()
+    assert ls["stage_index"] == 5 and 0.0 < ls["phi_n"] < 1.0 and ls["j"] >= 2
+    r = e.run(n_phi=20, use_fixed_schedule=True, continue_run=True)
+    assert not r["paused"] and r["n_stages"] == 20
+    with pytest.raises(SMCMIError, match="STATE"):
+        e.run(n_phi=20, use_fixed_schedule=True, continue_run=True)          # already at phi = 1
+    with pytest.raises(SMCMIError, match="ARG"):
+        e.set_loop_state(stage_index=0, j=2, phi_n=0.1)
+    e.init_from_prior()
+    with pytest.raises(SMCMIError, match="UNSUPPORTED"):
+        run_group([e], n_phi=20, use_fixed_schedule=True, stop_after_stage=5)
+    e.close()
