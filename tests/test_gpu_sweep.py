@@ -40,3 +40,29 @@ def test_random_configurations_match_oracle():
         np.testing.assert_allclose(rec["ess"], ro["ess"], rtol=1e-8, err_msg=tag)
         np.testing.assert_allclose(rec["schedule"], ro["schedule"], rtol=1e-9, err_msg=tag)
     assert len(seen_d) >= 8
+
+
+@pytest.mark.parametrize("n", [33, 65, 1023, 100003])
+def test_ragged_cloud_sizes_match_oracle(n):
+    """Cloud sizes that are no multiple of a wavefront, a block or a chunk (and one below a single wavefront): both schedules,
+    two parameter blocks."""
+    from smc_jl_amd import Engine
+    from oracle import oracle as orc
+
+    spec = models.regression_spec()
+    for fixed in (True, False):
+        e = Engine(n, 2, seed=9, max_stages=600)
+        e.set_model(spec)
+        e.init_from_prior()
+        P0 = e.download_cloud()
+        kw = dict(use_fixed_schedule=fixed, n_phi=40, tempering_target=0.9, n_blocks=2)
+        r = e.run(**kw)
+        rec = e.stage_records(r["n_stages"])
+        P = e.download_cloud()
+        e.close()
+        ro = orc.smc_run(models.oracle_model(spec), P0, seed=9, n_threads=4, max_stages=600, **kw)
+        assert r["n_stages"] == ro["n_stages"] and r["resamples"] == ro["resamples"]
+        assert r["logmdd"] == pytest.approx(ro["logmdd"], abs=1e-9)
+        np.testing.assert_allclose(rec["ess"], ro["ess"], rtol=1e-9)
+        same = np.all(np.abs(P - ro["particles"]) <= 1e-8 * (1.0 + np.abs(ro["particles"])), axis=1)
+        assert same.mean() > 0.999
