@@ -6,6 +6,8 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # the oracle's idle OpenMP threads must not spin into the next GPU run's launch path
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smc_jl_amd import Engine  # noqa: E402
 from tests import models  # noqa: E402

@@ -8,6 +8,7 @@ cd $ROOT
 python bench.py --steps 8 --warmup 2 2>/dev/null | tail -1 > $OUT/bench.json
 python bench.py --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_1e6.json
 python bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_1e7.json
+python bench.py --nparts 100000000 --no-history --no-cpu --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_1e8.json
 python bench.py --workload capm --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_capm.json
 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_kalman.json
 python tools/config2_seeds.py > $OUT/config2_seeds.json 2>/dev/null
