@@ -2288,7 +2288,7 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
                 q0 = log(q0);
                 q1 = log(q1);
                 if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
-                        }
+            }
             SMCMI_PROF(6);
             // ---- para_new: scatter the proposal into the parameter vector (the old vector stays in xo[])
 #pragma unroll

@@ -327,7 +327,6 @@ __device__ inline double loglik(const L &l, int d, Th th) {
 
 template <int D, class L, class Th>
 __device__ inline double loglik_s(const L &l, Th th) {
-    constexpr int d = D;
     switch (l.family) {
     case SMCMI_LIK_GAUSS_ISO: {
         const double sig = l.par[0];

@@ -351,7 +351,6 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 // the moments kernel decides from the all-reduced (ΣW̃, ΣW̃²) handed over as the partials of one block
-                float dummy = 0.f; (void)dummy;
                 switch (h->d) {
 #define SMCMI_FUSED_CASE(D) case D: k_moments_reg<D><<<h->nb_mr, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_mom, h->d_hist_W, h->n, 0, h->d_tot_fin, 1, fin_slot, h->rec); break;
                 SMCMI_FUSED_CASE(1) SMCMI_FUSED_CASE(2) SMCMI_FUSED_CASE(3) SMCMI_FUSED_CASE(4) SMCMI_FUSED_CASE(5) SMCMI_FUSED_CASE(6)

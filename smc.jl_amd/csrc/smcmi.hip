@@ -915,7 +915,6 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
-    const int max_db = (nf + rc->n_blocks - 1) / rc->n_blocks;
     const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
     // largest energy of the initial cloud, in the layout the mutation epilogue uses afterwards (stage 1's energy shift)
     k_energy_max<<<acc_nb, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
