@@ -138,12 +138,31 @@ inline double lik_const_host(int family, const double *par, int d) {
 // filter state lives in registers: the covariance as a packed symmetric upper triangle (36 doubles, two copies), one row of
 // Tm P at a time, P Z' (24) and its triangular solve (24).  C, Rm, Z are uniform across the wavefront (scalar loads); Tm and
 // R Q R' are never stored: Tm[i][k] = κ C[i][k] (+ ρ_i on the diagonal) and the 36 entries of R Q R' are rebuilt from the three
-// σ² each step (cheaper than 72 more registers).  Out of line so the callers' other likelihood families stay small.
-__device__ constexpr int ksym(int i, int j) { return i <= j ? i * 8 - i * (i - 1) / 2 + (j - i) : j * 8 - j * (j - 1) / 2 + (i - j); }
+// σ² each step (cheaper than 72 more registers).  The wave-uniform products κ C[i][k] and Rm[i][m] Rm[j][m] are formed once on
+// the host when the likelihood is set (smcmi_set_likelihood appends them to the structure block: KALMAN_AUX_*), so they
+// arrive as scalar operands instead of costing ~800 FP64 multiplies per filter step and lane - same roundings, same bits.
+// Out of line so the callers' other likelihood families stay small.
+constexpr int KALMAN_AUX_USER = 112;               // [C 8x8 | Rm 8x3 | Z 3x8] as the caller hands them over
+constexpr int KALMAN_AUX_KC = KALMAN_AUX_USER;     // κ C, 64 doubles
+constexpr int KALMAN_AUX_RR = KALMAN_AUX_KC + 64;  // Rm[i][m] Rm[j][m], (i <= j packed like P) x 3
+constexpr int KALMAN_AUX_TOTAL = KALMAN_AUX_RR + 36 * 3;
+__host__ __device__ constexpr int ksym(int i, int j) { return i <= j ? i * 8 - i * (i - 1) / 2 + (j - i) : j * 8 - j * (j - 1) / 2 + (i - j); }
 
 __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv, const double *ydat, long long nt, const double *aux, double kappa) {
 #pragma clang fp contract(fast)
-    const double *Cm = aux, *Rm = aux + 64, *Zm = aux + 88;
+    // The structure block and the data are the same for every lane, but an out-of-line function receives its pointers in VGPRs and
+    // would fetch them with vector loads (105 flat loads and a dozen full waits per filter step): pin the addresses to SGPRs and
+    // to the constant address space, so the values arrive through the scalar cache as SGPR operands of the FMAs.
+    using cdp = const double __attribute__((address_space(4))) *;
+    auto uniform_ptr = [](const double *p) -> cdp {
+        const unsigned long long a = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (cdp)(((unsigned long long)hi << 32) | lo);
+    };
+    const cdp Zm = uniform_ptr(aux + 88), kC = uniform_ptr(aux + KALMAN_AUX_KC), RR = uniform_ptr(aux + KALMAN_AUX_RR), yd = uniform_ptr(ydat);
+    nt = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
+                     __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
+    (void)kappa;
     double rho[8], s2[3];
 #pragma unroll
     for (int i = 0; i < 8; ++i) rho[i] = thv[i];
@@ -160,12 +179,14 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
     double ll = 0.0;
 #pragma nounroll
     for (long long t = 0; t < nt; ++t) {
+        // (the 196 structure values are loop-invariant; the compiler hoists their scalar loads and parks what does not fit the SGPR
+        // file in VGPR lanes - a v_readlane per use.  Reloading them every step instead was measured: 603 µs against 576 µs.)
         double xp[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             double s = rho[i] * x[i];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (kappa * Cm[i * 8 + j]) * x[j];
+            for (int j = 0; j < 8; ++j) s += kC[i * 8 + j] * x[j];
             xp[i] = s;
         }
         // P_{t|t-1} = Tm P Tm' + R Q R', upper triangle, one row of Tm P at a time
@@ -176,15 +197,15 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
             for (int j = 0; j < 8; ++j) {
                 double s = rho[i] * P[ksym(i, j)];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += (kappa * Cm[i * 8 + k]) * P[ksym(k, j)];
+                for (int k = 0; k < 8; ++k) s += kC[i * 8 + k] * P[ksym(k, j)];
                 tp[j] = s;
             }
 #pragma unroll
             for (int j = i; j < 8; ++j) {
-                double s = (Rm[i * 3 + 0] * Rm[j * 3 + 0]) * s2[0] + (Rm[i * 3 + 1] * Rm[j * 3 + 1]) * s2[1] + (Rm[i * 3 + 2] * Rm[j * 3 + 2]) * s2[2];
+                double s = RR[ksym(i, j) * 3 + 0] * s2[0] + RR[ksym(i, j) * 3 + 1] * s2[1] + RR[ksym(i, j) * 3 + 2] * s2[2];
                 s += tp[j] * rho[j];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += tp[k] * (kappa * Cm[j * 8 + k]);
+                for (int k = 0; k < 8; ++k) s += tp[k] * kC[j * 8 + k];
                 Pn[ksym(i, j)] = s;
             }
         }
@@ -194,7 +215,7 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += Zm[a * 8 + j] * xp[j];
-            v[a] = ydat[a + 3 * t] - mu - s;
+            v[a] = yd[a + 3 * t] - mu - s;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -289,7 +310,7 @@ __device__ inline double loglik(const L &l, int d, Th th) {
         return lp;
     }
     case SMCMI_LIK_LGSS_KALMAN: {  // config 5: dense linear state-space model, Kalman filter per particle
-        if (d != 13 || l.rows != 3 || l.aux_rows * l.aux_cols < 112) return NAN;
+        if (d != 13 || l.rows != 3 || l.aux_rows * l.aux_cols < KALMAN_AUX_TOTAL) return NAN;
         double thv[13];
         for (int k = 0; k < 13; ++k) thv[k] = th(k);
         return kalman_lgss(thv, l.data, l.cols, l.aux, l.par[0]);

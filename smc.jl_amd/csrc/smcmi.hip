@@ -273,7 +273,19 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
         if (dmalloc(&h->d_data[which], (size_t)(rows * cols))) return SMCMI_ERR_HIP;
         HIP_TRY(hipMemcpy(h->d_data[which], data, sizeof(double) * rows * cols, hipMemcpyHostToDevice));
     }
-    if (aux && aux_rows * aux_cols > 0) {
+    if (family == SMCMI_LIK_LGSS_KALMAN) {
+        // structure block + the wave-uniform products the filter would otherwise rebuild every step (model.hpp kalman_lgss)
+        std::vector<double> ext(KALMAN_AUX_TOTAL);
+        for (int k = 0; k < KALMAN_AUX_USER; ++k) ext[k] = aux[k];
+        const double kappa = par[0], *Rm = aux + 64;
+        for (int k = 0; k < 64; ++k) ext[KALMAN_AUX_KC + k] = kappa * aux[k];
+        for (int i = 0; i < 8; ++i)
+            for (int j = i; j < 8; ++j)
+                for (int m = 0; m < 3; ++m) ext[KALMAN_AUX_RR + ksym(i, j) * 3 + m] = Rm[i * 3 + m] * Rm[j * 3 + m];
+        if (dmalloc(&h->d_aux[which], ext.size())) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemcpy(h->d_aux[which], ext.data(), sizeof(double) * ext.size(), hipMemcpyHostToDevice));
+        aux_rows = 1; aux_cols = KALMAN_AUX_TOTAL;
+    } else if (aux && aux_rows * aux_cols > 0) {
         if (dmalloc(&h->d_aux[which], (size_t)(aux_rows * aux_cols))) return SMCMI_ERR_HIP;
         HIP_TRY(hipMemcpy(h->d_aux[which], aux, sizeof(double) * aux_rows * aux_cols, hipMemcpyHostToDevice));
     }
