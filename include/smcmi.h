@@ -74,7 +74,7 @@ typedef struct {
     double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */
     double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-12; <0 => adjacent floats) */
     int32_t stop_after_stage;              /* > 0: return (result.paused = 1) once cloud.stage_index has reached it - the save point of
-                                              `save_intermediate` / `intermediate_stage_increment` (smc_main.jl:499-507); single-GPU driver */
+                                              `save_intermediate` / `intermediate_stage_increment` (smc_main.jl:499-507); shards pause in lock step */
     int32_t continue_run;                  /* 1: go on from the handle's loop state (after a pause, or after smcmi_set_loop_state:
                                               `continue_intermediate`, smc_main.jl:334-335,355-361) instead of starting at stage 1 */
 } smcmi_run_config;

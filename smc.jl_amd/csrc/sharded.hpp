@@ -221,7 +221,6 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
     if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
-    if (rc->stop_after_stage > 0 || rc->continue_run) return set_err(SMCMI_ERR_UNSUPPORTED, "stop_after_stage / continue_run: single-GPU driver only");
     const bool adaptive = !rc->use_fixed_schedule;
     const int P_default = adaptive ? (rc->solver_passes >= 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
@@ -245,6 +244,17 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
         rp.stall_on_exhaust = 1;
         rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
+        rp.stop_stage = rc->stop_after_stage > 0 ? rc->stop_after_stage : 0;
+        if (rc->continue_run) {
+            // continue_intermediate (smc_main.jl:334-335,355-361): every shard keeps the loop scalars, records and history it holds
+            // (a paused run, or smcmi_set_loop_state / _set_stage_records / _set_history with the same scalars on every shard)
+            if (s.stage < 1 || s.stage >= h->cfg.max_stages) return set_err(SMCMI_ERR_STATE, "no loop state to continue from");
+            if (s.phi_n >= 1.0) return set_err(SMCMI_ERR_STATE, "the run to continue has already reached phi = 1");
+            if (s.stage != h0->h_st.stage) return set_err(SMCMI_ERR_STATE, "shards hold different loop states");
+            s.rp = rp; s.done = 0; s.err = 0; s.skip_fold = 1; s.do_resample = 0;
+            if (push_state(h)) return SMCMI_ERR_HIP;
+            continue;
+        }
         memset(&s, 0, sizeof(DevState));
         s.rp = rp;
         s.stage = 1; s.j = 2; s.c = rc->c; s.accept = rc->target;
@@ -449,12 +459,14 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     };
 
     const auto t0 = std::chrono::steady_clock::now();
-    const int max_iter = adaptive ? h0->cfg.max_stages : rc->n_phi - 1;
+    const bool cont = rc->continue_run != 0;
+    const int base = cont ? h0->h_st.stage - 1 : 0;      // stages completed before this call
+    const int max_iter = (adaptive ? h0->cfg.max_stages : rc->n_phi - 1) - base;
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
     const int first_passes = std::max(P_default, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
-    double pred_ess = rc->initial_ess > 0.0 ? rc->initial_ess : N_tot;
-    int pred_rl = 0, stall_stage = -1, stall_p = 0;
+    double pred_ess = cont ? h0->h_st.ess_prev : (rc->initial_ess > 0.0 ? rc->initial_ess : N_tot);
+    int pred_rl = cont ? h0->h_st.resampled_last : 0, stall_stage = -1, stall_p = 0;
     int done = 0, iters = 0, stalls = 0, sel_stalls = 0, spec_stalls = 0;
     static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
     const bool spec_ok = predict_select && predict && can_fuse_cm(h0) && !no_spec && !getenv("SMCMI_NO_CORRECT_MOMENTS") &&
@@ -484,7 +496,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             // stall (identical on every rank: all decisions come from all-reduced totals): clear it and resume that stage
             if (pull_state(h0)) return SMCMI_ERR_HIP;
             const int st_i = h0->h_st.stage;
-            const int had = (st_i == stall_stage) ? stall_p : (st_i <= 3 ? first_passes : dyn_P);
+            const int had = (st_i == stall_stage) ? stall_p : (st_i - base <= 3 ? first_passes : dyn_P);
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 const int zero = 0;
@@ -512,7 +524,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 if (int rc2 = enqueue(had, had, 2)) return rc2;
                 ++sel_stalls;
             }
-            iters = st_i - 1;
+            iters = st_i - 1 - base;
         }
         if (predict_select) {
             HIP_TRY(hipSetDevice(h0->cfg.device));
@@ -534,6 +546,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
     res->solver_stalls = stalls; res->select_stalls = sel_stalls; res->spec_stalls = spec_stalls;
+    res->paused = (s.done == 5) ? 1 : 0;
     if (!mut_evs.empty()) {
         // event pairs bracket dispatch + kernel; launches of stalled (no-op) stages are short and rare - they stay in the mean.
         // The dispatch part is calibrated like in smcmi_run: pairs around an empty kernel of the same grid, minus its own ~2.5 µs.

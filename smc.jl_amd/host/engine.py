@@ -228,13 +228,17 @@ class Engine:
 
     def run_sharded(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
                     c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
-                    log_prob_old_data=0.0, solver_passes=0, phi_rtol=0.0, initial_ess=0.0, use_graph=0):
+                    log_prob_old_data=0.0, solver_passes=0, phi_rtol=0.0, initial_ess=0.0, use_graph=0, stop_after_stage=0,
+                    continue_run=False):
         rc = self._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target,
                               use_fixed_schedule, tempering_target, prior_weight, log_prob_old_data, solver_passes, 0, use_graph, phi_rtol,
                               initial_ess)
+        rc.stop_after_stage, rc.continue_run = int(stop_after_stage), int(bool(continue_run))
         res = _lib.Result()
         check(self._L.smcmi_run_sharded(self._h, C.byref(rc), C.byref(res)))
-        return self._result(res)
+        out = self._result(res)
+        out["paused"] = bool(res.paused)
+        return out
 
     def stage_records(self, n_stages):
         phi, ess, c, acc = (np.empty(n_stages) for _ in range(4))
@@ -318,13 +322,15 @@ def comm_unique_id():
 
 def run_group(engines, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5, c=0.5,
               alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0, log_prob_old_data=0.0,
-              solver_passes=0, phi_rtol=0.0, initial_ess=0.0, stop_after_stage=0):
+              solver_passes=0, phi_rtol=0.0, initial_ess=0.0, stop_after_stage=0, continue_run=False):
     """Drive several shard engines of this process in lock step (smcmi_run_group)."""
     e0 = engines[0]
     rc = e0._run_config(n_blocks, n_mh_steps, lam, n_phi, resampling_method, threshold_ratio, c, alpha, target, use_fixed_schedule,
                         tempering_target, prior_weight, log_prob_old_data, solver_passes, 0, 0, phi_rtol, initial_ess)
-    rc.stop_after_stage = int(stop_after_stage)          # (refused by the sharded drivers: single-GPU feature so far)
+    rc.stop_after_stage, rc.continue_run = int(stop_after_stage), int(bool(continue_run))
     res = _lib.Result()
     arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
     check(_lib.lib().smcmi_run_group(arr, len(engines), C.byref(rc), C.byref(res)))
-    return Engine._result(res)
+    out = Engine._result(res)
+    out["paused"] = bool(res.paused)
+    return out

@@ -213,3 +213,58 @@ def test_group_driver_shares_one_energy_shift_across_shards():
     np.testing.assert_allclose(full, P, rtol=1e-7, atol=1e-9)
     for s in engs:
         s.close()
+
+
+@pytest.mark.parametrize("fixed", [True, False])
+def test_group_driver_pause_and_continue(fixed):
+    """Intermediate save points with shards (smc_main.jl:499-507, 334-361): the lock-stepped shards pause at the same stage and
+    continue in place, or in fresh handles restored from what the paused ones hand out; the run is the uninterrupted one."""
+    from smc_jl_amd import Engine, run_group
+
+    spec = models.gauss_spec(d=4)
+    n, seed, world = 20000, 3, 2
+    kw = dict(use_fixed_schedule=fixed, n_phi=40, tempering_target=0.9, n_blocks=2)
+
+    def shards():
+        out = []
+        for r in range(world):
+            s = Engine(n, 4, seed=seed, max_stages=600, n_local=n // world, gid0=r * (n // world))
+            s.set_model(spec)
+            out.append(s)
+        return out
+
+    ref = shards()
+    for s in ref:
+        s.init_from_prior()
+    g = run_group(ref, **kw)
+    rec = ref[0].stage_records(g["n_stages"])
+    full = np.concatenate([s.download_cloud() for s in ref], axis=0)
+
+    a = shards()
+    for s in a:
+        s.init_from_prior()
+    r = run_group(a, stop_after_stage=9, **kw)
+    assert r["paused"] and r["n_stages"] == 9
+    states = [s.get_loop_state() for s in a]
+    assert states[0] == states[1]
+    # (1) continue in place
+    saved = [(s.download_cloud(), s.stage_records(9), s.history(9)) for s in a]
+    r1 = run_group(a, continue_run=True, **kw)
+    assert not r1["paused"] and r1["n_stages"] == g["n_stages"] and r1["resamples"] == g["resamples"]
+    assert r1["logmdd"] == pytest.approx(g["logmdd"], abs=1e-8)
+    np.testing.assert_allclose(a[0].stage_records(r1["n_stages"])["ess"], rec["ess"], rtol=1e-8)
+    np.testing.assert_allclose(np.concatenate([s.download_cloud() for s in a], axis=0), full, rtol=1e-7, atol=1e-9)
+    # (2) continue in fresh handles from the saved pieces
+    b = shards()
+    for s, (P, rc9, (w9, W9)) in zip(b, saved):
+        s.upload_cloud(P)
+        s.set_stage_records(rc9["schedule"], rc9["ess"], rc9["c_hist"], rc9["accept_hist"], rc9["resampled"])
+        s.set_history(w9, W9)
+        s.set_loop_state(**states[0])
+    r2 = run_group(b, continue_run=True, **kw)
+    assert r2["n_stages"] == g["n_stages"] and r2["resamples"] == g["resamples"]
+    assert r2["logmdd"] == pytest.approx(g["logmdd"], abs=1e-8)
+    np.testing.assert_allclose(b[1].stage_records(r2["n_stages"])["schedule"], rec["schedule"], rtol=1e-9)
+    np.testing.assert_allclose(np.concatenate([s.download_cloud() for s in b], axis=0), full, rtol=1e-7, atol=1e-9)
+    for s in ref + a + b:
+        s.close()

@@ -209,8 +209,8 @@ def test_intermediate_save_and_continue(tmp_path):
 
 
 def test_continue_run_error_paths():
-    """continue_run needs loop state to continue from; a finished run cannot be continued; the sharded drivers refuse pause / continue."""
-    from smc_jl_amd import Engine, run_group
+    """continue_run needs loop state to continue from; a finished run cannot be continued."""
+    from smc_jl_amd import Engine
     from smc_jl_amd.host._lib import SMCMIError
 
     spec = models.gauss_spec(d=3)
@@ -227,7 +227,4 @@ def test_continue_run_error_paths():
         e.run(n_phi=20, use_fixed_schedule=True, continue_run=True)          # already at phi = 1
     with pytest.raises(SMCMIError, match="ARG"):
         e.set_loop_state(stage_index=0, j=2, phi_n=0.1)
-    e.init_from_prior()
-    with pytest.raises(SMCMIError, match="UNSUPPORTED"):
-        run_group([e], n_phi=20, use_fixed_schedule=True, stop_after_stage=5)
     e.close()
