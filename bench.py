@@ -35,6 +35,11 @@ def mutate_bytes_per_particle(d):
 
 
 def main():
+    # A collective that never completes (a rank died, a transport misbehaves) must not hold the GPUs until somebody's outer limit
+    # fires: dump the Python stacks and exit after SMCMI_BENCH_WATCHDOG seconds (default 15 min; the default run takes ~1 min).
+    import faulthandler
+
+    faulthandler.dump_traceback_later(int(os.environ.get("SMCMI_BENCH_WATCHDOG", "900")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -243,6 +248,7 @@ def main():
             out["gpu_over_cpu"] = value / cpu_value
     if rank == 0:
         print(json.dumps(out))
+    faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         dist.destroy_process_group()
 
