@@ -841,7 +841,10 @@ __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *
         // k_prepare_mutation verifies the ESS the correction actually produced.  No usable prediction: stall, the host resumes
         // the stage with the certificate-pass path (candidates are prepared below as usual).
         const bool none_above = !above;
-        if (use_pred && gp < 0.0) {
+        // (a predicted root at or beyond 1 is the last stage: no walk step lies above it, ϕ_n = ϕ_prop = 1, and the verification is
+        // ESS(1) >= ESS_bar - the stage that used to stall once per run)
+        const bool beyond = pd > 0.0 && ph >= 1.0 && qstar >= 0 && none_above;
+        if ((use_pred || beyond) && gp < 0.0) {
             const double step_q = __shfl(wl, qstar, 64);                 // first walk step above the prediction (or the last step)
             if (lane == 0) {
                 S.mode = MODE_FINAL; S.spec = 1; S.n_valid = 0;
