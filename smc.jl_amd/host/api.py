@@ -292,8 +292,11 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             kw["initial_ess"] = _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, tempered_update_prior_weight,
                                                        resampling_method, seed, device)
             w0 = eng.download_cloud()[:, d + 4].copy()
-        else:
+        elif all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
             eng.init_from_prior()
+        else:
+            from .cloudio import host_initial_draw
+            host_initial_draw(eng, parameters, seed)          # other prior families: host draws, device likelihoods
         cont = False
         if continue_intermediate:
             cont = _load_intermediate(eng, loadpath, n_phi, lam, d)

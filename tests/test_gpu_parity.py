@@ -534,3 +534,48 @@ print(json.dumps(dict(n=r["n_stages"], logmdd=r["logmdd"], resamples=r["resample
         assert out[mode]["logmdd"] == pytest.approx(out["0"]["logmdd"], abs=1e-9)
         np.testing.assert_allclose(out[mode]["ess"], out["0"]["ess"], rtol=1e-9)
         assert out[mode]["chk"] == pytest.approx(out["0"]["chk"], rel=1e-7)
+
+
+def test_other_prior_families_host_draw_and_device_mutation(orc):
+    """Gamma / Beta / InverseGamma / RootInverseGamma priors: the initial draw happens on the host (`host_initial_draw`, device
+    likelihoods), the recursion - prior densities included - on the device, and must follow the oracle from the same cloud.
+    Through `smc()` the same model runs end to end."""
+    import smc_jl_amd as S
+    from smc_jl_amd import Engine
+    from smc_jl_amd.host import api, cloudio
+
+    pars = [S.parameter("g", 1.0, (1e-8, 1e5), prior=S.Gamma(2.0, 1.0)),
+            S.parameter("b", 0.5, (0.0, 1.0), prior=S.Beta(2.0, 2.0)),
+            S.parameter("ig", 1.0, (1e-8, 1e5), prior=S.InverseGamma(3.0, 2.0)),
+            S.parameter("rig", 0.5, (1e-8, 1e5), prior=S.RootInverseGamma(4.0, 0.5)),
+            S.parameter("n", 0.0, prior=S.Normal(0.0, 2.0))]
+    data = np.array([1.5, 0.4, 1.2, 0.6, -0.3])
+    lik = S.GaussIso(0.3)
+    spec = api._spec_from(pars, lik.spec(data), None)
+    n, seed = 8192, 5
+    e = Engine(n, 5, seed=seed, max_stages=800)
+    e.set_model(spec)
+    P0 = cloudio.host_initial_draw(e, pars, seed)
+    assert np.all(P0[:, 0] > 0) and np.all((P0[:, 1] > 0) & (P0[:, 1] < 1)) and np.all(P0[:, 2] > 0) and np.all(P0[:, 3] > 0)
+    assert np.all(np.isfinite(P0[:, 5])) and np.all(P0[:, 9] == 1.0)
+    m = models.oracle_model(spec)
+    for i in (0, 100, n - 1):                                    # host densities == the oracle's restatement
+        assert P0[i, 6] == pytest.approx(orc.logprior(m, P0[i, :5]), abs=1e-12)
+    assert abs(P0[:, 0].mean() - 2.0) < 0.1 and abs(P0[:, 1].mean() - 0.5) < 0.02 and abs(P0[:, 2].mean() - 1.0) < 0.1
+    kw = dict(use_fixed_schedule=False, tempering_target=0.95, n_phi=100, n_blocks=2, alpha=0.9)
+    r = e.run(**kw)
+    rec = e.stage_records(r["n_stages"])
+    P = e.download_cloud()
+    e.close()
+    ro = orc.smc_run(m, P0, seed=seed, n_threads=8, max_stages=800, **kw)
+    assert r["n_stages"] == ro["n_stages"] and r["resamples"] == ro["resamples"]
+    assert r["logmdd"] == pytest.approx(ro["logmdd"], abs=1e-8)
+    np.testing.assert_allclose(rec["ess"], ro["ess"], rtol=1e-8)
+    same = np.all(np.abs(P - ro["particles"]) <= 1e-8 * (1.0 + np.abs(ro["particles"])), axis=1)
+    assert same.mean() > 0.999
+    assert np.all(P[:, 0] > 0) and np.all((P[:, 1] > 0) & (P[:, 1] < 1))
+    # end to end through the mirror
+    c, w, W = S.smc(lik, pars, data, n_parts=4096, n_phi=60, use_fixed_schedule=False, tempering_target=0.95, seed=2, verbose="none")
+    mu = S.weighted_mean(c)
+    assert c.tempering_schedule[-1] == 1.0 and np.all(np.isfinite(c.particles))
+    np.testing.assert_allclose(mu, data, atol=0.15)              # σ = 0.3 dominates every prior here
