@@ -227,7 +227,9 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
         tempering_target=0.97, old_data=None, old_loglikelihood=None, tempered_update_prior_weight=0.0,
         log_prob_old_data=0.0, old_cloud=None, savepath=None, particle_store_path=None, loadpath="",
         continue_intermediate=False, save_intermediate=False, intermediate_stage_increment=10, seed=0, device=0,
-        max_stages=None, initial_cloud=None, use_graph=0):
+        max_stages=None, initial_cloud=None, use_graph=0, testing=False, parallel=False, data_vintage="", old_vintage="",
+        smc_iteration=1, run_test=False, filestring_addl=(), intermediate_stage_start=0, regime_switching=False, toggle=True,
+        debug_assertion=False):
     """Sequential Monte Carlo on one MI355X.  Keyword names follow src/smc_main.jl:119-161 (λ -> lam, n_Φ -> n_phi,
     α -> alpha).  Returns (cloud, w, W) - the three objects the reference writes to `savepath` - and, when `savepath`
     is given, stores them as a numpy .npz (the reference's JLD2/HDF5 writers are outside the hot path).
@@ -236,6 +238,12 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     `old_cloud`, the Cloud of the previous estimation; the initial cloud is then built on the device from the old cloud
     (same-size continuation, or bridge resample + prior draws when tempered_update_prior_weight > 0 / sizes differ).
     `initial_cloud` instead starts the recursion from a ready-made cloud.
+
+    The remaining reference keywords are accepted for call compatibility: `testing` suppresses the file output like the
+    reference's (src/smc_main.jl:513); `parallel` is moot (the device is the parallelism); `data_vintage`, `old_vintage`,
+    `smc_iteration`, `run_test`, `filestring_addl`, `intermediate_stage_start`, `toggle`, `debug_assertion` only label or
+    guard things that do not exist here; `regime_switching=True` is not supported.  A tempered update without `old_cloud`
+    loads the old cloud from `loadpath` (src/smc_main.jl:245-246).
 
     Intermediate saves (src/smc_main.jl:499-507): with `save_intermediate`, every `intermediate_stage_increment` stages the
     device loop pauses and {cloud, w, W, j} go to `savepath` with `_stage=<i>` inserted before the extension;
@@ -252,8 +260,13 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     d = len(parameters)
     if all(p.fixed for p in parameters):
         raise AssertionError("All model parameters are fixed!")
-    if old_data is not None and np.size(old_data) and initial_cloud is None and old_cloud is None:
-        raise ValueError("a tempered update (non-empty old_data) needs old_cloud = the Cloud of the old estimation")
+    if regime_switching:
+        raise NotImplementedError("regime_switching = true is outside this build (ModelConstructors regime parameters)")
+    if old_data is not None and np.size(old_data) and initial_cloud is None and old_cloud is None and not continue_intermediate:
+        if not loadpath:
+            raise ValueError("a tempered update (non-empty old_data) needs old_cloud = the Cloud of the old estimation, or loadpath")
+        from .cloudio import load_cloud
+        old_cloud = load_cloud(loadpath)[0]                       # cloud_isempty(old_cloud) ? load(loadpath, "cloud") : old_cloud
     data = np.asarray(data, dtype=np.float64)
     device_lik = isinstance(loglikelihood, DeviceLikelihood)
     lik = loglikelihood.spec(data) if device_lik else ("host_callback", [], None, None)
@@ -336,9 +349,9 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             mu, sd = weighted_mean(cloud), weighted_std(cloud)
             for p, m_, s_ in zip(parameters, mu, sd):
                 print("   %-12s mean %12.6f  std %12.6f" % (p.key, m_, s_))
-    if particle_store_path:
+    if particle_store_path and not testing:
         np.save(particle_store_path, np.ascontiguousarray(cloud.particles[:, :d]))        # `smcparams`, smc_main.jl:514-520
-    if savepath:
+    if savepath and not testing:
         from .cloudio import save_cloud
         save_cloud(savepath, cloud, w, W)                          # write(file, "cloud"/"w"/"W"), smc_main.jl:521-525
     eng.close()

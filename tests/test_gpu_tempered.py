@@ -228,3 +228,20 @@ def test_continue_run_error_paths():
     with pytest.raises(SMCMIError, match="ARG"):
         e.set_loop_state(stage_index=0, j=2, phi_n=0.1)
     e.close()
+
+
+def test_tempered_update_loads_old_cloud_from_loadpath(tmp_path, old_run):
+    """cloud_isempty(old_cloud) ? load(loadpath, "cloud") : old_cloud (src/smc_main.jl:245-246); `testing` suppresses the files."""
+    import smc_jl_amd as S
+
+    data, old, cloud = old_run
+    path = str(tmp_path / "old_cloud.npz")
+    S.save_cloud(path, cloud, np.zeros((len(cloud), 1)), np.ones((len(cloud), 1)))
+    kw = dict(n_parts=4000, n_phi=40, use_fixed_schedule=True, seed=11, verbose="none", old_data=old)
+    a, _, _ = S.smc(S.LinReg(1.0), _pars(S), data, old_cloud=cloud, savepath=str(tmp_path / "a.npz"), testing=True, **kw)
+    b, _, _ = S.smc(S.LinReg(1.0), _pars(S), data, loadpath=path, data_vintage="200101", smc_iteration=2, parallel=True, **kw)
+    assert not (tmp_path / "a.npz").exists()
+    assert a.stage_index == b.stage_index and a.logmdd == b.logmdd
+    np.testing.assert_array_equal(a.particles, b.particles)
+    with pytest.raises(NotImplementedError):
+        S.smc(S.LinReg(1.0), _pars(S), data, regime_switching=True, **kw)
