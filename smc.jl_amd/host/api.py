@@ -536,3 +536,113 @@ def _run_host_callback(eng, loglikelihood, parameters, data, spec, initial_cloud
     rec = dict(schedule=np.array(phi_h), ess=np.array(ess_h), c_hist=np.array(c_h), accept_hist=np.array(acc_h),
                resampled=np.array(rs_h, dtype=np.int32))
     return r, rec, np.asfortranarray(np.stack(w_cols, 1)), np.asfortranarray(np.stack(W_cols, 1)), eng.download_cloud()
+
+
+# ----------------------------------------------------------------------------------------------- the other exported functions
+# (src/SMC.jl:14-17: mutation, resample, mvnormal_mixture_draw, initial_draw!, get_cloud).  They run on the device through
+# small one-off engines; inside smc() the same steps are fused kernels of the stage loop.
+def get_cloud(filepath):
+    """src/util.jl:113-115."""
+    from .cloudio import load_cloud
+    return load_cloud(filepath)[0]
+
+
+def resample(weights, n_parts=None, method="systematic", parallel=False, seed=0, stage=0, device=0):
+    """src/resample.jl:23-72: ancestor indices (0-based) of `n_parts` slots drawn from `weights`.  RNG: the build's Philox contract
+    (systematic: one offset; multinomial: one uniform per slot), keyed by `seed` / `stage`."""
+    if method == "polyalgo":
+        method = "multinomial"
+    if method not in ("systematic", "multinomial"):
+        raise ValueError("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
+    w = np.ascontiguousarray(weights, dtype=np.float64).ravel()
+    n_out = int(n_parts) if n_parts is not None else w.size
+    src = Engine(w.size, 1, seed=seed, device=device, max_stages=2, store_history=False)
+    dst = src if n_out == w.size else Engine(n_out, 1, seed=seed, device=device, max_stages=2, store_history=False)
+    try:
+        P = np.zeros((w.size, 6), order="F")
+        P[:, 5] = w
+        src.upload_cloud(P)
+        if dst is src:
+            return src.resample(method, stage=stage)
+        return dst.bridge_resample_from(src, n_out, method=method, stage=stage)
+    finally:
+        src.close()
+        if dst is not src:
+            dst.close()
+
+
+def _one_particle_engine(parameters, lik, old_lik, seed, device):
+    spec = _spec_from(parameters, lik, old_lik)
+    eng = Engine(1, len(parameters), seed=seed, device=device, max_stages=2, store_history=False)
+    eng.set_model(spec)
+    return eng
+
+
+def mvnormal_mixture_draw(theta_old, mu, Sigma, c=1.0, alpha=1.0, seed=0, pid=0, stage=0, t=0, device=0):
+    """src/helpers.jl:87-100 for one parameter block: θ_new from the mixture of N(θ_old, c²Σ), N(θ_old, diag c²Σ) and N(μ, c²Σ) with
+    weights α, (1-α)/2, (1-α)/2.  The draw belongs to the stream of particle `pid` at (stage, t) of the RNG contract."""
+    th = np.ascontiguousarray(theta_old, dtype=np.float64)
+    d = th.size
+    pars = [parameter("p%d" % k, 0.0, (-1e300, 1e300), prior=Normal(0.0, 1.0)) for k in range(d)]
+    eng = Engine(pid + 1, d, seed=seed, device=device, max_stages=2, store_history=False)
+    try:
+        eng.set_model(_spec_from(pars, ("gauss_iso", [1.0], np.zeros(d), None), None))
+        P = np.zeros((pid + 1, d + 5), order="F")
+        P[pid, :d] = th
+        eng.upload_cloud(P)
+        prop, _, _ = eng.propose(np.asarray(mu, dtype=np.float64), np.asarray(Sigma, dtype=np.float64), [0, d], np.arange(d), 0, t, c, alpha, stage)
+        return prop[pid].copy()
+    finally:
+        eng.close()
+
+
+def mutation(loglikelihood, parameters, data, p, d_mu, d_Sigma, n_free_para, blocks_free, blocks_all, phi_n, phi_n1, c=1.0, alpha=1.0,
+             n_mh_steps=1, old_data=None, old_loglikelihood=None, seed=0, pid=0, stage=2, device=0):
+    """src/mutation.jl:56-138 for ONE particle row `p` (length n_para + 5): n_mh_steps x blocks of mixture random-walk MH moves at
+    ϕ_n.  `blocks_free` / `blocks_all` are the reference's lists of index lists (0-based here).  Device likelihoods only.
+    Returns the mutated row; the acceptance column holds Σ accepted block lengths / n_free (quirk Q2)."""
+    if not isinstance(loglikelihood, DeviceLikelihood):
+        raise NotImplementedError("mutation() takes a device likelihood; host callbacks run through smc()")
+    parameters = list(parameters)
+    d = len(parameters)
+    row = np.ascontiguousarray(p, dtype=np.float64)
+    lik = loglikelihood.spec(np.asarray(data, dtype=np.float64))
+    old_lik = None
+    if old_data is not None and np.size(old_data):
+        ol = old_loglikelihood if old_loglikelihood is not None else loglikelihood
+        old_lik = ol.spec(np.asarray(old_data, dtype=np.float64))
+    eng = Engine(pid + 1, d, seed=seed, device=device, max_stages=2, store_history=False)
+    try:
+        eng.set_model(_spec_from(parameters, lik, old_lik))
+        P = np.zeros((pid + 1, d + 5), order="F")
+        P[pid] = row
+        eng.upload_cloud(P)
+        bf = np.concatenate([np.asarray(b, dtype=np.int32) for b in blocks_free])
+        bp = np.concatenate([[0], np.cumsum([len(b) for b in blocks_free])]).astype(np.int32)
+        eng.mutate(np.asarray(d_mu, dtype=np.float64), np.asarray(d_Sigma, dtype=np.float64), bp, bf, phi_n, phi_n1, c, alpha, n_mh_steps, stage)
+        return eng.download_cloud()[pid].copy()
+    finally:
+        eng.close()
+
+
+def initial_draw(loglikelihood, parameters, data, cloud, parallel=False, regime_switching=False, toggle=True, seed=0, device=0):
+    """initial_draw! (src/initialization.jl:88-119): fills `cloud` (n_parts x n_para + 5) with prior draws whose log-likelihood is
+    finite, their loglh / logprior, old_loglh = 0, weight 1.  Device likelihoods only; returns the cloud."""
+    if regime_switching:
+        raise NotImplementedError("regime_switching = true is outside this build")
+    if not isinstance(loglikelihood, DeviceLikelihood):
+        raise NotImplementedError("initial_draw() takes a device likelihood; host callbacks run through smc()")
+    parameters = list(parameters)
+    n, d = len(cloud), len(parameters)
+    eng = Engine(n, d, seed=seed, device=device, max_stages=2, store_history=False)
+    try:
+        eng.set_model(_spec_from(parameters, loglikelihood.spec(np.asarray(data, dtype=np.float64)), None))
+        if all(q.fixed or q.prior.family in ("normal", "uniform") for q in parameters):
+            eng.init_from_prior()
+        else:
+            from .cloudio import host_initial_draw
+            host_initial_draw(eng, parameters, seed)
+        cloud.particles = eng.download_cloud()
+    finally:
+        eng.close()
+    return cloud

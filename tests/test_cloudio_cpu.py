@@ -41,6 +41,7 @@ def test_split_and_join_cloud_round_trip(tmp_path):
     assert (j.stage_index, j.n_Phi, j.total_sampling_time) == (7, 7, 1.5)
     back, wb, Wb = S.load_cloud(path)                             # save_cloud = true wrote the joined file
     np.testing.assert_array_equal(back.particles, c.particles)
+    np.testing.assert_array_equal(S.get_cloud(path).ESS, c.ESS)   # src/util.jl:113-115
     with pytest.raises(AssertionError):
         S.split_cloud(path, 7)                                    # @assert mod(n_part, n_pieces) == 0
 

@@ -579,3 +579,39 @@ def test_other_prior_families_host_draw_and_device_mutation(orc):
     mu = S.weighted_mean(c)
     assert c.tempering_schedule[-1] == 1.0 and np.all(np.isfinite(c.particles))
     np.testing.assert_allclose(mu, data, atol=0.15)              # σ = 0.3 dominates every prior here
+
+
+def test_exported_function_wrappers_vs_oracle(orc):
+    """The reference's other exports (src/SMC.jl:14-17) as device-backed calls: resample, mvnormal_mixture_draw, mutation,
+    initial_draw, get_cloud - each against the oracle's restatement on the same Philox streams."""
+    import smc_jl_amd as S
+
+    rs = np.random.RandomState(4)
+    w = rs.rand(500)
+    for method in ("systematic", "multinomial"):
+        for n_out in (None, 320):
+            got = S.resample(w, n_parts=n_out, method=method, seed=7, stage=3)
+            want = orc.resample(w, method=method, seed=7, stage=3, n_parts=n_out)
+            np.testing.assert_array_equal(got, want)
+    # one mixture draw of particle 5 at (stage 9, t = 1)
+    A = rs.randn(4, 4)
+    Sig = A @ A.T + 4 * np.eye(4)
+    mu, th = rs.randn(4), rs.randn(4)
+    for alpha in (1.0, 0.6):
+        got = S.mvnormal_mixture_draw(th, mu, Sig, c=0.4, alpha=alpha, seed=3, pid=5, stage=9, t=1)
+        want = orc.mixture_draw(th, mu, Sig, 0.4, alpha, 3, 5, 9, 1)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    # mutation of one particle row of the regression model
+    spec = models.regression_spec()
+    data = spec["lik"][2]
+    pars = [S.parameter("a", 0.0, prior=S.Normal(0, 10)), S.parameter("b", 0.0, prior=S.Normal(0, 10))]
+    m = models.oracle_model(dict(priors=[("normal", 0.0, 10.0)] * 2, bounds=[(-1e5, 1e5)] * 2, fixed=[0, 0], lik=("linreg", [1.0], data, None), old_lik=None))
+    P = orc.initial_draw(m, 8, 11)
+    mu2, S2 = orc.weighted_mean(P), orc.weighted_cov(P)
+    bf, ba, bp = orc.generate_blocks(2, 1, np.arange(2, dtype=np.int32), 11, 6)
+    Q = orc.mutate_cloud(m, P.copy(order="F"), mu2, S2, bf, ba, bp, 0.3, 0.2, 0.5, 0.9, 2, 11, 6)
+    row = S.mutation(S.LinReg(1.0), pars, data, P[3], mu2, S2, 2, [list(bf)], [list(ba)], 0.3, 0.2, c=0.5, alpha=0.9, n_mh_steps=2, seed=11, pid=3, stage=6)
+    np.testing.assert_allclose(row, Q[3], rtol=1e-11, atol=1e-12)
+    # initial_draw fills a Cloud; get_cloud reads one back
+    c = S.initial_draw(S.LinReg(1.0), pars, data, S.Cloud(2, 64), seed=11)
+    np.testing.assert_allclose(c.particles, orc.initial_draw(m, 64, 11), rtol=1e-11, atol=1e-11)
