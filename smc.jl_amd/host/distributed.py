@@ -92,7 +92,12 @@ class ShardedSMC:
         self._snap = self.e.cloud_tensor().clone()
 
     def restore(self):
-        self.e.cloud_tensor().copy_(self._snap)
+        t = self.e.cloud_tensor()
+        t.copy_(self._snap)
+        if getattr(t, "is_cuda", False):          # torch's stream wrote the cloud; the handle's non-blocking stream would not wait for it
+            import torch
+
+            torch.cuda.current_stream(t.device).synchronize()
 
     def download_cloud(self):
         return self.e.download_cloud()

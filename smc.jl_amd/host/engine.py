@@ -307,6 +307,11 @@ class Engine:
 
     def shard_resample(self, full_weights, full_cloud, method, stage):
         """full_weights: torch cuda tensor [N]; full_cloud: torch cuda tensor [R, N] (all-gathered)."""
+        if getattr(full_cloud, "is_cuda", False):
+            # the gathered tensors were produced on torch's stream; the handle's own stream is non-blocking and would not wait for it
+            import torch
+
+            torch.cuda.current_stream(full_cloud.device).synchronize()
         anc = np.empty(self.n, dtype=np.int64)
         check(self._L.smcmi_shard_resample(self._h, C.c_void_p(full_weights.data_ptr()), C.c_void_p(full_cloud.data_ptr()),
                                            _lib.RESAMPLE[method], stage, anc.ctypes.data_as(lp)))
