@@ -201,7 +201,7 @@ static int ensure_shard_buffers(smcmi_handle *h) {
     if (!h->d_tot_ess) {
         if (dmalloc(&h->d_tot_ess, 2 * KC) || dmalloc(&h->d_tot_fin, 2) || dmalloc(&h->d_tot_mom, h->npairs + 2) || dmalloc(&h->d_tot_acc, ES + MAX_SHARDS))
             return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemset(h->d_tot_acc, 0, sizeof(double) * (ES + MAX_SHARDS)));
+        HIP_TRY(hipMemsetAsync(h->d_tot_acc, 0, sizeof(double) * (ES + MAX_SHARDS), h->stream));   // (the handle's stream is non-blocking: keep its work on it)
     }
     if (!h->d_cum_full) {
         if (dmalloc(&h->d_cum_full, N)) return SMCMI_ERR_HIP;
@@ -265,10 +265,10 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         HIP_TRY(hipMemcpy(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->rec.accept, &v0[3], sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemset(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages));
+        HIP_TRY(hipMemsetAsync(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages, h->stream));
         if (h->cfg.store_history) {
-            HIP_TRY(hipMemset(h->d_hist_w, 0, sizeof(double) * h->n));
-            HIP_TRY(hipMemcpy(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemsetAsync(h->d_hist_w, 0, sizeof(double) * h->n, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
         }
     }
     // stage 1's energy shift: largest energy of the initial cloud over all shards (slots after the ES row: a sum all-reduce
