@@ -1519,6 +1519,7 @@ constexpr int PT = 1024;  // threads of the single prepare block
 // then just loads.  Layout: zbuf[(t ZS + slot) n + i], t = mh_step n_blocks + block, ZS = D + 2 slots: MH uniform, mixture
 // uniform, D normals (zero beyond the block length).  Same tags and the same expressions as the in-kernel path -> same bits.
 constexpr int RA_T = 256;
+constexpr int RA_SKIP = 8;      // blocks 1..7 of k_prepare_mutation idle (block 0 prepares): see rng_ahead_block
 struct RngAhead {
     double *zbuf;            // null: disabled
     long long n, gid0;
@@ -1528,7 +1529,10 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
     // RA_T particles per block although the launch has PT threads per block (block 0 needs them): 4 wavefronts per CU spread the
     // draws over the whole chip instead of 16 per CU on a quarter of it
     if (threadIdx.x >= RA_T) return;
-    const long long i = (long long)(blockIdx.x - 1) * RA_T + threadIdx.x;
+    // chunk c of RA_T particles is drawn by block c + RA_SKIP: workgroups go round-robin over the 8 XCDs, so the block that draws a
+    // chunk sits on the XCD whose L2 the mutation block c (same chunking, blockIdx = c) will read the numbers from
+    if (blockIdx.x < RA_SKIP) return;
+    const long long i = (long long)(blockIdx.x - RA_SKIP) * RA_T + threadIdx.x;
     if (i >= ra.n) return;
     const int nf = md->n_free, nb = st->rp.n_blocks, n_steps = st->rp.n_mh_steps, D = ra.D, ZS = D + 2;
     const unsigned stage = (unsigned)st->stage;

@@ -794,7 +794,7 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
     unsigned grid = 1;
     if (h->rng_ahead) {
         ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d;
-        grid = 1 + (unsigned)((h->n + RA_T - 1) / RA_T);
+        grid = RA_SKIP + (unsigned)((h->n + RA_T - 1) / RA_T);
     }
     k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, h->d_prof ? h->d_prof + 25 : nullptr, ra,
                                                              sol_slot, h->rec);
