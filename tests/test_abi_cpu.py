@@ -70,3 +70,20 @@ def test_mutation_kernel_keeps_three_waves_per_simd(libmod):
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
         assert int(m.group(1)) >= min_occ, (key, m.group(1))
         assert scratch <= max_scratch, (key, scratch)
+
+
+def test_header_is_plain_c_and_the_c_example_links(libmod, tmp_path):
+    """include/smcmi.h is C99 (-pedantic), and examples/c_abi_config2.c - the boundary used from plain C, no Python / torch -
+    compiles and links against libsmcmi.so."""
+    import subprocess
+
+    t = tmp_path / "t.c"
+    t.write_text('#include "smcmi.h"\nint main(void) { return (int)sizeof(smcmi_run_config) == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(t)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "c_abi_config2"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_abi_config2.c"), "-L", os.path.join(ROOT, "smc.jl_amd", "csrc"), "-lsmcmi", "-lm",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

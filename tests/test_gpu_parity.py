@@ -615,3 +615,32 @@ def test_exported_function_wrappers_vs_oracle(orc):
     # initial_draw fills a Cloud; get_cloud reads one back
     c = S.initial_draw(S.LinReg(1.0), pars, data, S.Cloud(2, 64), seed=11)
     np.testing.assert_allclose(c.particles, orc.initial_draw(m, 64, 11), rtol=1e-11, atol=1e-11)
+
+
+def test_c_abi_example_matches_the_python_binding(tmp_path):
+    """examples/c_abi_config2.c (plain C over include/smcmi.h, its own process, the system HIP runtime) reproduces the run the
+    ctypes binding makes with the same seed: same kernels, same Philox streams, same bits."""
+    import json
+    import os
+    import subprocess
+
+    from smc_jl_amd import Engine
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_config2"
+    r = subprocess.run(["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_config2.c"),
+                        "-L", os.path.join(ROOT, "smc.jl_amd", "csrc"), "-lsmcmi", "-lm", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "smc.jl_amd", "csrc") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([str(exe), "20000", "7"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    c = json.loads(p.stdout.strip().splitlines()[-1])
+    e = Engine(20000, 10, seed=7, max_stages=1500, store_history=False)
+    e.set_model(models.gauss_spec(10))
+    e.init_from_prior()
+    g = e.run(use_fixed_schedule=False, tempering_target=0.97, n_phi=300)
+    e.close()
+    assert c["n_stages"] == g["n_stages"] and c["resamples"] == g["resamples"]
+    assert c["logmdd"] == g["logmdd"] and c["phi_last"] == 1.0
+    assert abs(c["mean0"] - (-1.0) * 25 / 25.0625) < 0.02          # posterior mean of θ_0: m_0 s_p² / (s_p² + σ²)
