@@ -488,10 +488,14 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             if (int rc2 = enqueue(0, adaptive ? (iters < 2 ? first_passes : dyn_P) : 0, mode, spec)) return rc2;
             ++iters;
         }
+        // one 64-byte copy per sync: done flag, resample flag and ESS of the last stage are contiguous in DevState (smcmi_run)
+        DevState head;
+        constexpr size_t head_off = offsetof(DevState, stage), head_len = offsetof(DevState, ess) - offsetof(DevState, stage);
         for (;;) {
             HIP_TRY(hipSetDevice(h0->cfg.device));
-            HIP_TRY(hipMemcpyAsync(&done, &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h0->d_st + head_off, head_len, hipMemcpyDeviceToHost, h0->stream));
             HIP_TRY(hipStreamSynchronize(h0->stream));
+            done = head.done;
             if (done != 2 && done != 3 && done != 4) break;
             // stall (identical on every rank: all decisions come from all-reduced totals): clear it and resume that stage
             if (pull_state(h0)) return SMCMI_ERR_HIP;
@@ -526,11 +530,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             }
             iters = st_i - 1 - base;
         }
-        if (predict_select) {
-            HIP_TRY(hipSetDevice(h0->cfg.device));
-            HIP_TRY(hipMemcpy(&pred_rl, &h0->d_st->resampled_last, sizeof(int), hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(&pred_ess, &h0->d_st->ess_prev, sizeof(double), hipMemcpyDeviceToHost));
-        }
+        if (predict_select) { pred_rl = head.resampled_last; pred_ess = head.ess_prev; }    // (the copy that ended the loop above)
     }
     // fold the last acceptance rate, close the run
     for (auto *h : g.hs) {

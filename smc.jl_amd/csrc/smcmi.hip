@@ -991,9 +991,16 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             }
             ++launched;
         }
-        HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        // one copy per sync: the loop scalars from `stage` to `ess_prev` are contiguous in DevState (64 bytes) - the done flag, the
+        // last stage's resample decision and its ESS used to be three copies (each a ~2.5 µs copy kernel plus a host round trip)
+        DevState head;
+        constexpr size_t head_off = offsetof(DevState, stage), head_len = offsetof(DevState, ess) - offsetof(DevState, stage);
+        HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        done = head.done;
+        bool resumed = false;
         while (done == 2 || done == 3 || done == 4) {
+            resumed = true;
             if (pull_state(h)) return SMCMI_ERR_HIP;
             const int st_i = s.stage;
             const int had = (st_i == stall_stage) ? stall_p : (st_i - base <= 3 ? first_passes : dyn_P);
@@ -1036,9 +1043,13 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
         if (predict_select) {
-            // re-anchor the expectation on the device's ESS / flag after every sync (cheap: the stream is idle here)
-            HIP_TRY(hipMemcpy(&s.resampled_last, &h->d_st->do_resample, sizeof(int), hipMemcpyDeviceToHost));   // did the last stage resample
-            HIP_TRY(hipMemcpy(&s.ess_prev, &h->d_st->ess_prev, sizeof(double), hipMemcpyDeviceToHost));
+            // re-anchor the expectation on the device's ESS / flag after every sync
+            if (resumed) {               // a resumed stage ran after the copy above
+                HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            }
+            s.resampled_last = head.do_resample;       // did the last stage resample
+            s.ess_prev = head.ess_prev;
             pred_ess = s.ess_prev;
             pred_rl = s.resampled_last;
         }
