@@ -644,3 +644,29 @@ def test_c_abi_example_matches_the_python_binding(tmp_path):
     assert c["n_stages"] == g["n_stages"] and c["resamples"] == g["resamples"]
     assert c["logmdd"] == g["logmdd"] and c["phi_last"] == 1.0
     assert abs(c["mean0"] - (-1.0) * 25 / 25.0625) < 0.02          # posterior mean of θ_0: m_0 s_p² / (s_p² + σ²)
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads, `roofline` included (small cloud, no CPU leg)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nparts", "20000", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "particle-stages/sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["value"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
