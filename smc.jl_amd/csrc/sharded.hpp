@@ -530,6 +530,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             }
             iters = st_i - 1 - base;
         }
+        if (!done && head.phi_n >= 1.0) break;      // the last stage of the batch reached ϕ = 1: the closing k_stage_begin finishes (smcmi_run)
         if (predict_select) { pred_rl = head.resampled_last; pred_ess = head.ess_prev; }    // (the copy that ended the loop above)
     }
     // fold the last acceptance rate, close the run

@@ -1042,12 +1042,16 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
             HIP_TRY(hipMemcpyAsync(&done, &h->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
+        if (resumed) {               // a resumed stage ran after the copy above
+            HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        // The stage that reaches ϕ = 1 raises `done` only through the NEXT stage's k_stage_begin.  When it was the last one of its
+        // batch (config 2: 256 stages = 16 batches of 16) nothing has raised it yet - do not enqueue a whole batch of no-ops (64
+        // launches and a sync) to find out: the closing k_stage_begin below does the same bookkeeping.
+        if (!done && head.phi_n >= 1.0) break;
         if (predict_select) {
             // re-anchor the expectation on the device's ESS / flag after every sync
-            if (resumed) {               // a resumed stage ran after the copy above
-                HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));
-                HIP_TRY(hipStreamSynchronize(h->stream));
-            }
             s.resampled_last = head.do_resample;       // did the last stage resample
             s.ess_prev = head.ess_prev;
             pred_ess = s.ess_prev;
