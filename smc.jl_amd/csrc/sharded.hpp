@@ -474,8 +474,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     bool spec_on = spec_ok;                   // switched off after repeated verification failures (see smcmi_run)
     int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;
     int dyn_P = P_default;                    // raised when stages keep running out of passes
+    int stages_left_est = 1 << 30;            // (1 - ϕ_n) / (ϕ_n - ϕ_{n-1}) at the last sync (smcmi_run)
     while (iters < max_iter && !done) {
-        const int batch = adaptive ? std::min(sync_every, max_iter - iters) : max_iter - iters;
+        const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), max_iter - iters) : max_iter - iters;
         for (int b = 0; b < batch; ++b) {
             int mode = 0;
             if (predict_select) {
@@ -531,6 +532,10 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             iters = st_i - 1 - base;
         }
         if (!done && head.phi_n >= 1.0) break;      // the last stage of the batch reached ϕ = 1: the closing k_stage_begin finishes (smcmi_run)
+        if (head.phi_n > head.phi_prev && head.phi_n < 1.0) {
+            const double left = (1.0 - head.phi_n) / (head.phi_n - head.phi_prev);
+            stages_left_est = left < 1e6 ? (int)left + 1 : 1 << 30;
+        }
         if (predict_select) { pred_rl = head.resampled_last; pred_ess = head.ess_prev; }    // (the copy that ended the loop above)
     }
     // fold the last acceptance rate, close the run

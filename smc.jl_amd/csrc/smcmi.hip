@@ -970,8 +970,10 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     bool spec_on = spec_ok;
     int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;
     if (rc->solver_passes < 1 && rc->tempering_target < 0.95) dyn_P = 2;   // larger steps: the 8-term model is good to ~1e-3 only, two passes are the norm
+    int stages_left_est = 1 << 30;             // from the last sync: (1 - ϕ_n) / (ϕ_n - ϕ_{n-1}), an over-estimate while the steps grow
     while (launched < max_iter && !done) {
-        const int batch = adaptive ? std::min(sync_every, max_iter - launched) : max_iter - launched;
+        // near the end of the run the batch shrinks to what is left, so that few no-op stages trail the one that reaches ϕ = 1
+        const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
             bool no_select = false;
             if (predict_select) {
@@ -1050,6 +1052,10 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         // batch (config 2: 256 stages = 16 batches of 16) nothing has raised it yet - do not enqueue a whole batch of no-ops (64
         // launches and a sync) to find out: the closing k_stage_begin below does the same bookkeeping.
         if (!done && head.phi_n >= 1.0) break;
+        if (head.phi_n > head.phi_prev && head.phi_n < 1.0) {
+            const double left = (1.0 - head.phi_n) / (head.phi_n - head.phi_prev);
+            stages_left_est = left < 1e6 ? (int)left + 1 : 1 << 30;
+        }
         if (predict_select) {
             // re-anchor the expectation on the device's ESS / flag after every sync
             s.resampled_last = head.do_resample;       // did the last stage resample
