@@ -6,8 +6,9 @@
 A "step" is one complete pass of the hot path over one batch: a full smc() run (all tempering stages) of
 BASELINE config 2 - 10-dim isotropic-Gaussian log-likelihood, n_parts = 100k per GPU, adaptive ϕ
 (tempering_target 0.97, n_Φ = 300, λ = 2.1), systematic resampling, 1 block, 1 MH step - on synthetic
-prior draws already resident in HBM.  value = n_parts * (n_stages - 1) * K / wall, the reference's metric
-(stage bracket src/smc_main.jl:378,489-490; initialisation and file I/O excluded).  For N > 1 the driver
+prior draws made on the device at the start of every step (`initial_draw!`; same seed => the same cloud in every step,
+nothing crosses PCIe).  value = n_parts * (n_stages - 1) * K / wall: the reference's metric (stage bracket
+src/smc_main.jl:378,489-490) with the device-side initial draw inside the wall time as well; file I/O excluded.  For N > 1 the driver
 launches one rank per GPU (torch.distributed, RCCL); particles are sharded (weak scaling: 100k per GPU) with
 small all-reduces per stage and an exchange on resample stages.
 Prints ONE JSON line on rank 0.
@@ -105,12 +106,12 @@ def main():
         eng = Engine(n_total, D, seed=seed, device=local_rank, max_stages=max_stages, store_history=not args.no_history)
         eng.set_model(spec)
         eng.init_from_prior()
-        P0 = eng.download_cloud()            # pristine initial cloud (prior draws + log-likelihoods)
-        dev0 = torch.from_numpy(np.ascontiguousarray(P0.T)).cuda()   # resident copy; rows = columns of the cloud
+        P0 = eng.download_cloud()            # pristine initial cloud (prior draws + log-likelihoods): the CPU baseline starts from it
 
         def reset():
-            # device-to-device restore of the initial cloud (12 MB) - inputs stay resident in HBM
-            eng.upload_cloud_from_device(dev0.data_ptr())
+            # every step is a whole job: the device draws the initial cloud again (same seed, same Philox streams => the same cloud,
+            # bit for bit) and runs the tempering loop on it - nothing comes from the host
+            eng.init_from_prior()
 
         def one_step(profile=False):
             reset()
@@ -127,11 +128,9 @@ def main():
         uid = [comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(rank, world, uid[0])
-        snap = eng.cloud_tensor().clone()
 
         def one_step(profile=False):
-            eng.cloud_tensor().copy_(snap)
-            torch.cuda.synchronize()
+            eng.init_from_prior()            # every step is a whole job: each rank draws its shard again (global particle ids)
             return eng.run_sharded(solver_passes=args.solver_passes, use_graph=2 if profile else 0, **RUN_KW)
 
     for _ in range(args.warmup):
