@@ -3,14 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete pass of the hot path over one batch: a full smc() run (all tempering stages) of
-BASELINE config 2 - 10-dim isotropic-Gaussian log-likelihood, n_parts = 100k per GPU, adaptive ϕ
-(tempering_target 0.97, n_Φ = 300, λ = 2.1), systematic resampling, 1 block, 1 MH step - on synthetic
-prior draws made on the device at the start of every step (`initial_draw!`; same seed => the same cloud in every step,
-nothing crosses PCIe).  value = n_parts * (n_stages - 1) * K / wall: the reference's metric (stage bracket
-src/smc_main.jl:378,489-490) with the device-side initial draw inside the wall time as well; file I/O excluded.  For N > 1 the driver
-launches one rank per GPU (torch.distributed, RCCL); particles are sharded (weak scaling: 100k per GPU) with
-small all-reduces per stage and an exchange on resample stages.
+A "step" is one complete pass of the hot path over one batch: a full smc() run (all tempering stages) of the
+10-dim isotropic-Gaussian log-likelihood with adaptive ϕ (tempering_target 0.97, n_Φ = 300, λ = 2.1), systematic
+resampling, 1 block, 1 MH step - on synthetic prior draws made on the device at the start of every step (`initial_draw!`;
+same seed => the same cloud in every step, nothing crosses PCIe).
+  --gpus 1 : BASELINE config 2, n_parts = 100 000 on one MI355X (the headline line);
+  --gpus N : BASELINE config 3, n_parts = 1 000 000 IN TOTAL sharded over N GPUs (strong scaling: 1e6 / N particles per rank,
+             one rank per GPU, RCCL over xGMI; small all-gathers of block sums per stage, all-to-all-v of rows on resample stages).
+value = n_parts * (n_stages - 1) * K / wall: the reference's metric (stage bracket src/smc_main.jl:378,489-490) with the
+device-side initial draw inside the wall time as well; file I/O excluded.
+When --gpus N > 1 is given without a torch.distributed environment (WORLD_SIZE unset) the script re-launches itself under
+`python -m torch.distributed.run --nproc-per-node N`; it refuses to run with a world size other than N.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -22,9 +25,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The CPU-baseline leg runs OpenMP regions back to back with serial stretches in between (the reference's serial bisection):
+# spinning worker threads (libgomp's default wait policy) slow the serial part 5x on a 256-thread host.  Must be in the
+# environment before the first OpenMP runtime is loaded (torch brings one).
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 D = 10
-N_PER_GPU = 100_000
+N_PER_GPU = 100_000            # config 2 (the --gpus 1 line)
+N_TOTAL_SHARDED = 1_000_000    # config 3 (--gpus N > 1): this many particles IN TOTAL, 1e6 / N per GPU
 RUN_KW = dict(use_fixed_schedule=False, tempering_target=0.97, n_phi=300, lam=2.1, resampling_method="systematic",
               n_blocks=1, n_mh_steps=1, alpha=1.0, c=0.5, target=0.25, threshold_ratio=0.5)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -33,6 +41,33 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def mutate_bytes_per_particle(d):
     # mutate reads θ(d), ℓ, π, ℓ_old and writes θ(d), ℓ, π, ℓ_old, accept = 16 d + 56 bytes (FP64)
     return 16 * d + 56
+
+
+def spawn_ranks(n_gpus, argv, environ=None, run=None):
+    """`python bench.py --gpus N` outside torch.distributed (no WORLD_SIZE): re-launch this script with one rank per GPU, exactly
+    as the driver does for N > 1.  Returns the launcher's exit code.  `run` is injectable for the CPU-side unit test."""
+    import socket
+    import subprocess
+
+    env = dict(os.environ if environ is None else environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return (run or subprocess.call)(cmd, env=env)
+
+
+def resolve_world(n_gpus, environ):
+    """(world, must_spawn): the world size this process runs in and whether bench.py has to launch the ranks itself.
+    Raises SystemExit when the environment's world size contradicts --gpus (a silent 1-GPU run must never be reported as N)."""
+    if "WORLD_SIZE" not in environ:
+        return (n_gpus, n_gpus > 1)
+    world = int(environ["WORLD_SIZE"])
+    if world != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to run (the line would misreport n_gpus)" % (n_gpus, world))
+    return (world, False)
 
 
 def main():
@@ -45,10 +80,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nparts", type=int, default=N_PER_GPU, help="particles per GPU")
+    ap.add_argument("--nparts", type=int, default=0, help="particles in total (default: 100 000 at --gpus 1, 1 000 000 at --gpus N > 1)")
     ap.add_argument("--mode", default="direct", choices=["direct", "graph"], help="stage launch mode")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-history", action="store_true")
+    ap.add_argument("--no-ref", action="store_true", help="--gpus N > 1: skip the single-GPU run of the same workload on rank 0")
     ap.add_argument("--workload", default="gauss10", choices=["gauss10", "capm", "kalman"],
                     help="gauss10 = BASELINE config 2 (the bench line); capm = config 4 (examples/capm_model, 3 MH steps, fixed schedule); kalman = config 5 (13-parameter state-space model, Kalman-filter likelihood, old + new data)")
     ap.add_argument("--solver-passes", type=int, default=0)
@@ -56,16 +92,20 @@ def main():
     ap.add_argument("--phi-rtol", type=float, default=0.0, help="adaptive-phi root tolerance (0 = library default)")
     args = ap.parse_args()
 
+    world, must_spawn = resolve_world(args.gpus, os.environ)
+    if must_spawn:
+        faulthandler.cancel_dump_traceback_later()
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import numpy as np
     import torch
 
     from tests import models
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("SMCMI_FORCE_SHARDED") == "1"
@@ -80,19 +120,20 @@ def main():
         spec, D = models.capm_spec(), 9
         RUN_KW = dict(use_fixed_schedule=True, n_phi=300, lam=2.1, resampling_method="systematic", n_blocks=1, n_mh_steps=3,
                       alpha=1.0, c=0.5, target=0.25, threshold_ratio=0.5)
-        if args.nparts == N_PER_GPU:
-            args.nparts = 200_000
+        default_total = 200_000
     elif args.workload == "kalman":
         spec, D = models.kalman_spec(T=80, old_T=40), 13
         RUN_KW = dict(use_fixed_schedule=False, tempering_target=0.95, n_phi=100, lam=2.1, resampling_method="systematic", n_blocks=1,
                       n_mh_steps=1, alpha=0.9, c=0.5, target=0.25, threshold_ratio=0.5)
-        if args.nparts == N_PER_GPU:
-            args.nparts = 50_000
+        default_total = 50_000
     else:
         spec = models.gauss_spec(D)
+        default_total = N_PER_GPU if world == 1 else N_TOTAL_SHARDED
     seed = 1
-    n_local = args.nparts
-    n_total = n_local * world
+    n_total = args.nparts if args.nparts > 0 else default_total
+    if n_total % world:
+        raise SystemExit("bench.py: n_parts = %d is not divisible by --gpus %d (equal contiguous shards)" % (n_total, world))
+    n_local = n_total // world
     max_stages = 1500
 
     def barrier():
@@ -153,11 +194,13 @@ def main():
     out = {
         "metric": "particle-stages/sec", "value": value, "unit": "particle-stages/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("gauss%d_isotropic_adaptive_phi_n%dk_per_gpu" % (D, n_local // 1000)) if args.workload == "gauss10"
-                   else ("capm_literal_fixed_schedule_3mh_n%dk_per_gpu" % (n_local // 1000) if args.workload == "capm"
-                         else "lgss_kalman13_old40_new80_adaptive_phi_n%dk_per_gpu" % (n_local // 1000)),
-                   "n_parts_total": n_total, "n_para": D, "tempering_target": RUN_KW.get("tempering_target", 0.97),
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (("gauss%d_isotropic_adaptive_phi_n%dk" % (D, n_total // 1000)) +
+                                (" (BASELINE config 3: %d particles in total, strong scaling over %d GPUs, %d per GPU)" % (n_total, world, n_local)
+                                 if world > 1 else " (BASELINE config 2)")) if args.workload == "gauss10"
+                   else ("capm_literal_fixed_schedule_3mh_n%dk" % (n_total // 1000) if args.workload == "capm"
+                         else "lgss_kalman13_old40_new80_adaptive_phi_n%dk" % (n_total // 1000)),
+                   "n_parts_total": n_total, "n_parts_per_gpu": n_local, "n_para": D, "tempering_target": RUN_KW.get("tempering_target", 0.97),
                    "n_phi": RUN_KW.get("n_phi", 300), "lambda": 2.1,
                    "resampling": "systematic", "n_blocks": 1, "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
@@ -182,40 +225,32 @@ def main():
         mean_ms = prof["kernel_ms_mutate"] / nl
         bytes_per_launch = mutate_bytes_per_particle(D) * n_k          # all MH steps of a stage are fused in the one launch
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
-        # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read correction):
-        # profiles/pmc_extract.py -> profiles/r01_pmc_traffic.json, bytes per particle of this kernel x particles
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        # Counter figures for this kernel at THIS cloud size: profiles/rNN_pmc_<workload>_n<particles per GPU>.json, written by
+        # profiles/pmc_extract.py from three separate rocprofv3 --pmc passes of this very command (FETCH_SIZE; WRITE_SIZE; SQ
+        # counters).  traffic = HBM bytes per launch (gfx950 x2 read correction); VALU fraction = SQ_ACTIVE_INST_VALU quad-cycles
+        # x 4 / (kernel duration x 1024 SIMDs x clock).  No file for this size => null (never scaled from another size).
+        import glob
+        import re
+
+        kname = ("k_mutate_reg<%d," % D) if D <= 10 else "k_mutate<0>"
+        traffic, valu = None, None
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_n%d.json" % (args.workload, n_k))),
+                           key=lambda f: int(re.search(r"r(\d+)", os.path.basename(f)).group(1)))
+        pmc_file = pmc_files[-1] if pmc_files else None
+        if pmc_file:
+            with open(pmc_file) as f:
                 pm = json.load(f)
-            k = [v for name, v in pm["kernels"].items() if "k_mutate_reg<%d," % D in name]
+            k = [v for name, v in pm["kernels"].items() if kname in name or ("k2_mutate<%d," % D) in name]
             if k:
-                traffic = k[0]["bytes_per_particle"] * n_k
-        except OSError:
-            pass
-        out["roofline"] = {"bound": "hbm", "kernel": ("k_mutate_reg<%d,true>" % D) if D <= 10 else "k_mutate<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                traffic = k[0].get("total_bytes")
+                valu = k[0].get("valu")
+        # The mutation kernel does ~30 FP64 flop per byte it moves (SURVEY ridge: ~10): it is bound by FP64 VALU issue, not by HBM.
+        # `achieved`/`peak` stay the algorithmic-bytes-over-duration figure the contract defines; `bound` names the real limiter
+        # and `valu` carries the counter-derived issue fraction (null without a PMC file for this size).
+        out["roofline"] = {"bound": "valu" if D <= 10 else "hbm", "kernel": last.get("mutate_kernel", kname), "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl}
-        # The kernel is FP64-VALU bound, not HBM bound: express it against the VALU issue rate as well.
-        # One VALU instruction of a wave64 occupies a SIMD for 4 cycles; instr_per_wave is the static count of the
-        # straight-line kernel body from its gfx950 ISA (profiles/isa_count.py -> r01_isa_counts.json; an upper bound on
-        # the dynamic count, the MH loop is unrolled for one step x one block).
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_isa_counts.json")) as f:
-                # below 5e5 draws per stage the random numbers are drawn ahead by k_prepare_mutation's idle CUs (csrc ensure_zbuf)
-                ahead = n_local * RUN_KW.get("n_mh_steps", 1) * RUN_KW.get("n_blocks", 1) <= 500000 and not os.environ.get("SMCMI_NO_RNG_AHEAD")
-                isa = json.load(f).get(("k_mutate_reg<%d,true>" % D) + (" rng_ahead" if ahead else ""))
-            if isa and RUN_KW.get("n_mh_steps", 1) == 1 and mean_ms > 0:
-                waves = -(-n_k // 64)
-                # SIMD-32: a wave64 VALU instruction issues over 2 cycles, FP64 over 4 (half rate), 32x32-bit multiplies over 8
-                cyc = 4 * isa["valu_f64"] + 2 * isa["valu_other"] + 8 * isa.get("valu_int_mul", 0)
-                peak = 256 * 4 * 2.4e9                # SIMD issue cycles / s
-                ach = waves * cyc / (mean_ms * 1e-3)
-                out["roofline"]["valu_issue"] = {"valu_instr_per_wave": isa["valu_total"], "issue_cycles_per_wave": cyc, "waves": waves,
-                                                 "achieved": ach, "peak": peak, "unit": "SIMD issue cycles/s", "frac": ach / peak,
-                                                 "waves_per_simd": waves / 1024.0, "rng_drawn_ahead": bool(ahead)}
-        except OSError:
-            pass
+                           "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl,
+                           "valu": valu, "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None}
         if args.workload == "kalman" and mean_ms > 0:
             # config 5 is compute bound: ~3300 FP64 flops per filter step (FMA = 2; csrc/model.hpp kalman_lgss), steps = new + old
             # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s
@@ -230,25 +265,61 @@ def main():
         stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
         out["stage_gbs"] = stage_bytes * args.steps / dt / 1e9
         if not args.no_cpu and not sharded:          # CPU baseline: rank 0 at N = 1 only
+            # Two variants of the CPU port on all host cores (BASELINE.md §3 / SURVEY §8d-ii), each on the full workload once
+            # (same cloud, same Philox seed):
+            #  "faithful"  - the reference's cost structure: MvNormal re-factorised for every particle (mutation.jl:81), the
+            #                adaptive-phi root by serial bisection to adjacent floats (helpers.jl:49, ~60 ESS passes per stage on
+            #                ONE core), the mutation loop over all cores like `@distributed` (smc_main.jl:472-476);
+            #  "optimised" - block factors hoisted out of the particle loop, every ESS evaluation reduced over OpenMP threads.
+            # `value` is the faithful one (the ">= 10x" target is judged against it); both are reported.
             from oracle import oracle as orc
 
             orc.build()
             m = models.oracle_model(spec)
             cores = os.cpu_count() or 1
-            r = orc.smc_run(m, P0, seed=seed, n_threads=cores, history=False, max_stages=max_stages, **RUN_KW)
-            cpu_value = n_total * (r["n_stages"] - 1) / r["seconds"]
-            out["cpu_baseline"] = {"value": cpu_value, "unit": "particle-stages/s", "cores": cores, "kind": "port",
-                                   "sample": "the full workload once (n_parts=%d, %d stages, same Philox seed); OpenMP over "
-                                             "particles in the mutation step only, like the reference's @distributed "
-                                             "mutation (src/smc_main.jl:472-476)" % (n_total, r["n_stages"] - 1),
-                                   "seconds": r["seconds"], "logmdd": r["logmdd"]}
-            out["logmdd_cpu"] = r["logmdd"]
-            out["logmdd_abs_err"] = abs(last["logmdd"] - r["logmdd"])
-            out["gpu_over_cpu"] = value / cpu_value
+            variants = {}
+            for name, var in (("faithful", 1), ("optimised", 2)):
+                r = orc.smc_run(m, P0, seed=seed, n_threads=cores, history=False, max_stages=max_stages, variant=var, **RUN_KW)
+                variants[name] = {"value": n_total * (r["n_stages"] - 1) / r["seconds"], "seconds": r["seconds"], "cores": cores,
+                                  "n_stages": r["n_stages"], "logmdd": r["logmdd"]}
+            rf = variants["faithful"]
+            out["cpu_baseline"] = {"value": rf["value"], "unit": "particle-stages/s", "cores": cores, "kind": "port",
+                                   "sample": "the full workload once per variant (n_parts=%d, %d stages, same Philox seed, "
+                                             "OMP_WAIT_POLICY=%s); value = the reference-faithful variant (per-particle "
+                                             "re-factorisation mutation.jl:81, serial bisection helpers.jl:49, mutation over all cores "
+                                             "like @distributed smc_main.jl:472-476)" % (n_total, rf["n_stages"] - 1,
+                                                                                         os.environ.get("OMP_WAIT_POLICY", "default")),
+                                   "seconds": rf["seconds"], "logmdd": rf["logmdd"], "variants": variants}
+            out["logmdd_cpu"] = rf["logmdd"]
+            out["logmdd_abs_err"] = abs(last["logmdd"] - rf["logmdd"])
+            out["gpu_over_cpu"] = value / rf["value"]
+            out["gpu_over_cpu_optimised"] = value / variants["optimised"]["value"]
+        if world > 1 and not args.no_ref:
+            # strong-scaling reference measured in the same job: the same n_total particles on rank 0's GPU alone
+            from smc_jl_amd import Engine
+
+            ref = Engine(n_total, D, seed=seed, device=local_rank, max_stages=max_stages, store_history=False)
+            ref.set_model(spec)
+            for it in range(3):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    tr0, st_ref = time.perf_counter(), 0
+                ref.init_from_prior()
+                rr = ref.run(solver_passes=args.solver_passes, sync_every=args.sync_every, phi_rtol=args.phi_rtol, **RUN_KW)
+                if it >= 1:
+                    st_ref += rr["n_stages"] - 1
+            torch.cuda.synchronize()
+            dtr = time.perf_counter() - tr0
+            out["single_gpu_same_workload"] = {"value": n_total * st_ref / dtr, "ms_per_step": 1e3 * dtr / 2, "n_stages": rr["n_stages"],
+                                               "logmdd": rr["logmdd"], "note": "rank 0 alone, history off, 2 timed steps"}
+            out["speedup_vs_single_gpu"] = value / out["single_gpu_same_workload"]["value"]
+            out["logmdd_abs_diff_vs_single_gpu"] = abs(last["logmdd"] - rr["logmdd"])
+            ref.close() if hasattr(ref, "close") else None
     if rank == 0:
         print(json.dumps(out))
     faulthandler.cancel_dump_traceback_later()
     if dist is not None:
+        dist.barrier()                # rank 0 may still be in its single-GPU reference run
         dist.destroy_process_group()
 
 

@@ -40,7 +40,8 @@ class _RunConfig(C.Structure):
                 ("n_phi", C.c_int32), ("resampling_method", C.c_int32), ("threshold_ratio", C.c_double),
                 ("c", C.c_double), ("alpha", C.c_double), ("target", C.c_double), ("use_fixed_schedule", C.c_int32),
                 ("tempering_target", C.c_double), ("prior_weight", C.c_double), ("log_prob_old_data", C.c_double),
-                ("seed", C.c_uint64), ("max_stages", C.c_int32), ("n_threads", C.c_int32), ("initial_ess", C.c_double)]
+                ("seed", C.c_uint64), ("max_stages", C.c_int32), ("n_threads", C.c_int32), ("initial_ess", C.c_double),
+                ("variant", C.c_int32), ("pad_", C.c_int32)]
 
 
 class _RunResult(C.Structure):
@@ -310,7 +311,8 @@ def tempered_update_cloud(model, old_particles, old_ess_last, n_parts, prior_wei
 
 def smc_run(model, particles, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic",
             threshold_ratio=0.5, c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97,
-            prior_weight=0.0, log_prob_old_data=0.0, seed=0, max_stages=None, n_threads=1, history=True, initial_ess=0.0):
+            prior_weight=0.0, log_prob_old_data=0.0, seed=0, max_stages=None, n_threads=1, history=True, initial_ess=0.0,
+            variant=0):
     """The reference's while-loop (src/smc_main.jl:377-508) on an initial cloud.  Returns a dict."""
     p = fcloud(particles)
     n = p.shape[0]
@@ -318,7 +320,7 @@ def smc_run(model, particles, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resa
         max_stages = n_phi if use_fixed_schedule else 20 * n_phi
     cfg = _RunConfig(n, n_blocks, n_mh_steps, lam, n_phi, RESAMPLE[resampling_method], threshold_ratio, c, alpha,
                      target, int(use_fixed_schedule), tempering_target, prior_weight, log_prob_old_data, seed,
-                     max_stages, n_threads, initial_ess)
+                     max_stages, n_threads, initial_ess, int(variant), 0)
     sched, ess, cs, acc = (np.zeros(max_stages) for _ in range(4))
     res_flags = np.zeros(max_stages, dtype=np.int32)
     wh = Wh = None

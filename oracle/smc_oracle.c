@@ -106,6 +106,24 @@ double orc_compute_ess(const double *loglh, const double *w, const double *old_l
     return N * N / s2;
 }
 
+/* compute_ESS with the two sums reduced over OpenMP threads (CPU-baseline variant 2 only): ESS = (Σv)²/Σv², the same quantity
+   as N²/Σ(N v/Σv)² without the temporary */
+static int g_ess_threads = 1;
+static double compute_ess_omp(const double *loglh, const double *w, const double *old_loglh, int64_t n, double phi_n,
+                              double phi_n1) {
+    double s = 0.0, s2 = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_ess_threads) reduction(+ : s, s2)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        double old = old_loglh ? old_loglh[i] : 0.0;
+        double v = w[i] * exp((phi_n1 - phi_n) * old + (phi_n - phi_n1) * loglh[i]);
+        s += v;
+        s2 += v * v;
+    }
+    return s * s / s2;
+}
+
 static double bit_middle(double a, double b) { /* Roots.jl exact bisection midpoint over the bit pattern, a,b >= 0 */
     uint64_t ia, ib;
     memcpy(&ia, &a, 8);
@@ -126,7 +144,7 @@ int orc_solve_adaptive_phi(const double *particles, int64_t n, int32_t R, double
     int evals = 0;
     if (*resampled_last) { ess_bar = target * (double)n; *resampled_last = 0; }   /* helpers.jl:14-20 */
     else ess_bar = target * ess_prev;
-#define G(phi) (evals++, orc_compute_ess(loglh, w, old, n, (phi), phi_n1) - ess_bar)
+#define G(phi) (evals++, (g_ess_threads > 1 ? compute_ess_omp(loglh, w, old, n, (phi), phi_n1) : orc_compute_ess(loglh, w, old, n, (phi), phi_n1)) - ess_bar)
     while (G(*phi_prop) >= 0.0 && *j <= n_phi) { *phi_prop = sched[*j - 1]; *j += 1; } /* helpers.jl:29-32 */
     if (*phi_prop != 1.0 || G(*phi_prop) < 0.0) {                                 /* helpers.jl:48-50 */
         /* Roots.fzero(g, [ϕ_n1, ϕ_prop], xtol = 0.): bisection over the bit pattern to adjacent floats */
@@ -618,6 +636,7 @@ int orc_mutation(const orc_model *m, double *p, int64_t stride, const double *mu
     return rc;
 }
 
+static int g_refactor_per_particle = 0;   /* CPU-baseline variant 1 (orc_run_config.variant) */
 /* the reference's `[mutation_closure(cloud.particles[k,:], ...) for k=1:n_parts]` (smc_main.jl:472-481).
    The per-particle MvNormal/Cholesky of the reference (mutation.jl:81) is hoisted: same value for all k. */
 int orc_mutate_cloud(const orc_model *m, double *particles, int64_t n, int64_t pid0, const double *mu_free,
@@ -628,13 +647,23 @@ int orc_mutate_cloud(const orc_model *m, double *particles, int64_t n, int64_t p
     (void)phi_n1;
     blk_factor *bf = make_factors(mu_free, Sigma_free, n_free, blocks_free, block_ptr, n_blocks, c);
     int rc = 0;
+    const int refactor = g_refactor_per_particle;
 #ifdef _OPENMP
     if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for schedule(static) num_threads(n_threads) reduction(| : rc)
 #endif
-    for (int64_t i = 0; i < n; ++i)
+    for (int64_t i = 0; i < n; ++i) {
+        if (refactor) {
+            /* the reference's cost: MvNormal(θ̄_b, Σ_b) is built inside mutation(), i.e. once per particle (mutation.jl:81); the
+               factors are the same bits as the hoisted ones, so the results do not change */
+            blk_factor *bp = make_factors(mu_free, Sigma_free, n_free, blocks_free, block_ptr, n_blocks, c);
+            rc |= mutation_core(m, particles + i, n, bp, n_free, blocks_all, block_ptr, n_blocks, phi_n, c, alpha,
+                                n_mh_steps, seed, (uint64_t)(pid0 + i), stage) != 0;
+            free_factors(bp, n_blocks);
+        } else
         rc |= mutation_core(m, particles + i, n, bf, n_free, blocks_all, block_ptr, n_blocks, phi_n, c, alpha,
                             n_mh_steps, seed, (uint64_t)(pid0 + i), stage) != 0;
+    }
     free_factors(bf, n_blocks);
     (void)n_threads;
     return rc ? fail("mutation: block covariance not positive definite (PosDefException)") : 0;
@@ -725,6 +754,9 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
     int32_t bfree[ORC_MAXD], ball[ORC_MAXD], bptr[ORC_MAXD + 1];
     double *wcol = particles + (int64_t)(R - 1) * n, *acol = particles + (int64_t)(R - 2) * n;
 
+    g_refactor_per_particle = cfg->variant == 1;
+    g_ess_threads = (cfg->variant == 2 && cfg->n_threads > 1) ? cfg->n_threads : 1;
+    if (g_ess_threads > 1 && (int64_t)g_ess_threads > n / 4096) g_ess_threads = n / 4096 > 1 ? (int)(n / 4096) : 1;   /* a few thousand exps per thread at least */
     int i = 1, j = 2, rc = 0, resampled_last = 0, resamples = 0;
     double phi_n = 0.0, phi_prop = 0.0, c = cfg->c, accept = cfg->target, logmdd = 0.0, secs = 0.0;
     const double threshold = cfg->threshold_ratio * (double)n;
@@ -779,6 +811,7 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
     }
     res->n_stages = i; res->resamples = resamples; res->logmdd = logmdd; res->c = c; res->accept = accept;
     res->seconds = secs;
+    g_refactor_per_particle = 0; g_ess_threads = 1;
     free(sched); free(inc_w); free(norm_w); free(tmp); free(rw); free(idx); free(mean); free(cov); free(mu_f); free(Sig_f);
     return rc;
 }

@@ -71,6 +71,13 @@ typedef struct {
     int32_t max_stages;          /* capacity of per-stage outputs (incl. stage 1) */
     int32_t n_threads;           /* OpenMP threads for the mutation loop (results do not depend on it) */
     double initial_ess;          /* cloud.ESS[1] when continuing from an old cloud (tempered update); 0 => n_parts */
+    int32_t variant;             /* CPU-baseline variants (bench.py; results of 0 and 1 are bit-identical):
+                                    0 = default: block factors hoisted out of the particle loop, serial ESS evaluations;
+                                    1 = "reference-faithful" cost model: MvNormal(...) re-factorised for every particle
+                                        (mutation.jl:81), serial bisection (helpers.jl:49), mutation over n_threads workers;
+                                    2 = "optimised OpenMP": hoisted factors + every ESS evaluation reduced over n_threads
+                                        (summation order differs => phi_n agrees to rounding only) */
+    int32_t pad_;
 } orc_run_config;
 
 typedef struct {

@@ -385,8 +385,10 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                 HIP_TRY(hipStreamSynchronize(h0->stream));
                 rs = fl[0] && !fl[1];
             }
-            static const char *xchg = getenv("SMCMI_RESAMPLE_EXCHANGE");      // "alltoall": move only the needed rows (development)
-            const bool a2a = rs && xchg && !strcmp(xchg, "alltoall") && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC && g.world > 1;
+            // resample redistribution: all-to-all-v of exactly the rows each shard's slots descend from (systematic resampling; the
+            // default), or an all-gather of the whole cloud (multinomial resampling, or SMCMI_RESAMPLE_EXCHANGE=allgather)
+            static const char *xchg = getenv("SMCMI_RESAMPLE_EXCHANGE");
+            const bool a2a = rs && !(xchg && !strcmp(xchg, "allgather")) && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC && g.world > 1;
             if (rs && a2a) {
                 // all-to-all-v redistribution: weights are all-gathered (N doubles), every shard forms the global cumulative sum and
                 // the ancestor range of every shard's slots; then only the rows inside a shard's range travel to it
