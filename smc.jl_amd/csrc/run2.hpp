@@ -1,0 +1,478 @@
+// run2.hpp - host driver of engine 2 (stage2.hpp): the two-launch stage for one handle, for a group of lock-stepped handles in one
+// process and for one handle per process with RCCL.  Included by smcmi.hip after sharded.hpp (ShardGroup, RCCL loader).
+//
+// Per stage (src/smc_main.jl:377-508) the driver enqueues
+//     K1 k2_correct -> [k2_scan -> k2_gather where a resample is possible] -> K2 k2_mutate
+// (with k2_begin -> P x k2_pass -> k2_finish in front where no verified prediction of ϕ_n is available), never reads the device
+// inside a batch of stages, and resumes a stage that stalled (Status2::code 2 / 3 / 4) at its next sync.  With more than one
+// handle every row set is first totalled per virtual shard (k2_reduce) and all-gathered (V x m doubles: RCCL over xGMI, or
+// device copies inside a process); every handle then totals the same V rows in the same order, so all take the same decisions
+// and the results do not depend on the number of handles.
+#pragma once
+
+struct Eng2 {
+    Geo2 g{};
+    Ctl2 *d_ctl = nullptr;
+    double *rows_mut = nullptr, *rows_cm = nullptr, *csum = nullptr, *csum_full = nullptr, *rows_gm = nullptr, *rows_pass[2] = {nullptr, nullptr};
+    double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
+    long long *d_ranges = nullptr;
+    int world = 0;
+};
+
+static void free_eng2(Eng2 *e) {
+    if (!e) return;
+    void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
+                    e->vt_gm, e->vt_pass, e->d_ranges};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    delete e;
+}
+
+// virtual-shard geometry of a handle that is shard `rank` of `world` (a function of N and the shard count's divisibility only)
+static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, Geo2 *out) {
+    Geo2 g{};
+    g.N = h->cfg.n_parts; g.n = h->n;
+    if (world < 1 || g.n * world != g.N) return false;
+    int V = 0;
+    for (int cand : {8, 4, 2, 1})
+        if (cand % world == 0 && g.n % (cand / world) == 0) { V = cand; break; }
+    if (!V) { if (world <= V2_MAXV) V = world; else return false; }
+    g.V = V; g.Vl = V / world; g.v0 = rank * g.Vl; g.nv = g.n / g.Vl;
+    if (g.nv < 1) return false;
+    g.nb2 = (int)((g.nv + 255) / 256);
+    g.direct = (single && world == 1 && g.nb2 <= GRP) ? 1 : 0;
+    if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
+    const long long want1 = (g.nv + 1023) / 1024;
+    g.nb1 = (int)std::max<long long>(1, std::min<long long>(want1, g.direct ? 16 : 128));
+    g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + 255) / 256 * 256;
+    g.nbg = std::min(2 * g.nb1, g.direct ? GRP : 256);
+    g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
+    if ((long long)g.V * g.nb1 > 1024) return false;
+    *out = g;
+    return true;
+}
+
+static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
+    Geo2 g;
+    if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
+    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.v0 == g.v0) return 0;
+    if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
+    Eng2 *e = new Eng2();
+    e->g = g; e->world = world;
+    const int npf = h->npairs + 2;
+    const size_t n1 = (size_t)g.Vl * g.nb1, n2 = (size_t)g.Vl * g.nb2, ng = (size_t)g.Vl * g.nbg;
+    if (dmalloc(&e->d_ctl, 1) || dmalloc(&e->rows_mut, n2 * RMUT) || dmalloc(&e->rows_cm, n1 * npf) || dmalloc(&e->csum, n1) ||
+        dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * h->npairs) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
+        dmalloc(&e->rows_pass[1], n1 * 2 * KC) || dmalloc(&e->vt_mut, (size_t)g.V * RMUT) || dmalloc(&e->vt_cm, (size_t)g.V * npf) ||
+        dmalloc(&e->vt_gm, (size_t)g.V * h->npairs) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2)) {
+        free_eng2(e);
+        return SMCMI_ERR_HIP;
+    }
+    HIP_TRY(hipMemsetAsync(e->rows_mut, 0, n2 * RMUT * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(e->csum, 0, n1 * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(e->csum_full, 0, (size_t)g.V * g.nb1 * sizeof(double), h->stream));
+    h->e2 = e;
+    return 0;
+}
+
+static bool eng2_eligible(const smcmi_handle *h, int world) {
+    static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 2;   // development: 1 = the eight-launch engine of kernels.hpp
+    if (eng == 1 || h->d > 10) return false;
+    Geo2 g;
+    return make_geo2(h, world, 0, world == 1, &g);
+}
+
+template <int D>
+static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows) {
+    Eng2 *e = h->e2;
+    k2_correct<D><<<e->g.Vl * e->g.nb1, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n);
+}
+template <int D>
+static void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full) {
+    Eng2 *e = h->e2;
+    k2_gather<D><<<e->g.Vl * e->g.nbg, TB, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
+                                                          h->n, e->rows_gm);
+}
+template <int D>
+static void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {
+    Eng2 *e = h->e2;
+    const size_t lds = k2_lds_bytes(D);
+    if (alpha1) k2_mutate<D, true><<<e->g.Vl * e->g.nb2, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    else k2_mutate<D, false><<<e->g.Vl * e->g.nb2, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+}
+#define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
+    switch (d) {                                                                                                                          \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
+    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break; default: CALL(10); break;              \
+    }
+
+static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res) {
+    smcmi_handle *h0 = g.hs[0];
+    const int nf = h0->h_model.n_free, d = h0->d;
+    if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
+        return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
+    if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
+    if (rc->resampling_method != SMCMI_RESAMPLE_SYSTEMATIC && rc->resampling_method != SMCMI_RESAMPLE_MULTINOMIAL)
+        return set_err(SMCMI_ERR_ARG, "Invalid resampler in SMC. Options are systematic or multinomial");
+    const bool adaptive = !rc->use_fixed_schedule;
+    const bool multi = g.world > 1;
+    const bool cont = rc->continue_run != 0;
+    std::vector<double> sched(rc->n_phi);
+    for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
+    // ---- per-handle set-up: run parameters and the stage-1 state in DevState (as engine 1), then imported into Ctl2
+    for (auto *h : g.hs) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
+        const int rank = multi ? (g.rccl ? h->rank : shard_rank(h)) : 0;
+        if (int e = ensure_eng2(h, g.world, rank, g.hs.size() == 1 && !g.rccl)) return e;
+        if (multi && ensure_shard_buffers(h)) return SMCMI_ERR_HIP;
+        if (pull_state(h) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
+        DevState &s = h->h_st;
+        RunParams rp{};
+        rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
+        rp.resampling_method = rc->resampling_method; rp.use_fixed_schedule = rc->use_fixed_schedule;
+        rp.threshold = rc->threshold_ratio * (double)h->cfg.n_parts;
+        rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
+        rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
+        rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+        rp.stall_on_exhaust = 1;
+        rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
+        rp.stop_stage = rc->stop_after_stage > 0 ? rc->stop_after_stage : 0;
+        if (cont) {
+            if (s.stage < 1 || s.stage >= h->cfg.max_stages) return set_err(SMCMI_ERR_STATE, "no loop state to continue from");
+            if (s.phi_n >= 1.0) return set_err(SMCMI_ERR_STATE, "the run to continue has already reached phi = 1");
+            if (s.stage != h0->h_st.stage) return set_err(SMCMI_ERR_STATE, "shards hold different loop states");
+            s.rp = rp; s.done = 0; s.err = 0; s.skip_fold = 1; s.do_resample = 0;
+        } else {
+            const int cur = s.cur;
+            memset(&s, 0, sizeof(DevState));
+            s.rp = rp; s.cur = cur;
+            s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
+            s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
+            s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;
+        }
+        if (push_state(h)) return SMCMI_ERR_HIP;
+        if (!cont) {
+            const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};
+            HIP_TRY(hipMemcpyAsync(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->rec.accept, &v0[3], sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemsetAsync(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages, h->stream));
+            if (h->cfg.store_history) {
+                HIP_TRY(hipMemsetAsync(h->d_hist_w, 0, sizeof(double) * h->n, h->stream));
+                HIP_TRY(hipMemcpyAsync(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
+    }
+    const Geo2 g0 = h0->e2->g;
+    const int npf = h0->npairs + 2, np = h0->npairs;
+    const bool direct = g0.direct != 0;
+    // ---- row-set plumbing
+    auto view = [&](smcmi_handle *, const double *rows, const double *vt, int nr, int m) {
+        return direct ? Rows2{rows, g0.Vl, nr, m} : Rows2{vt, g0.V, 1, m};
+    };
+    // total this handle's rows per virtual shard and (several handles) all-gather the V x m totals
+    auto publish = [&](double *Eng2::*rows, double *Eng2::*vt, int nr, int m, int max_idx) -> int {
+        if (direct) return 0;
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            Eng2 *e = h->e2;
+            k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->*rows, nr, m, max_idx, e->*vt + (size_t)e->g.v0 * m);
+        }
+        if (!multi) return 0;
+        return g.allgather([=](smcmi_handle *h) { return (const double *)(h->e2->*vt + (size_t)h->e2->g.v0 * m); },
+                           [=](smcmi_handle *h) { return h->e2->*vt; }, (size_t)g0.Vl * m);
+    };
+    auto publish_pass = [&](int slot) -> int {
+        if (direct) return 0;
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            Eng2 *e = h->e2;
+            k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->rows_pass[slot], e->g.nb1, 2 * KC, -1, e->vt_pass + (size_t)e->g.v0 * 2 * KC);
+        }
+        if (!multi) return 0;
+        return g.allgather([=](smcmi_handle *h) { return (const double *)(h->e2->vt_pass + (size_t)h->e2->g.v0 * 2 * KC); },
+                           [=](smcmi_handle *h) { return h->e2->vt_pass; }, (size_t)g0.Vl * 2 * KC);
+    };
+    auto mut_rows = [&](smcmi_handle *h) { return view(h, h->e2->rows_mut, h->e2->vt_mut, g0.nb2, RMUT); };
+    auto cm_rows = [&](smcmi_handle *h) { return view(h, h->e2->rows_cm, h->e2->vt_cm, g0.nb1, npf); };
+    auto gm_rows = [&](smcmi_handle *h) { return view(h, h->e2->rows_gm, h->e2->vt_gm, g0.nbg, np); };
+    // energy maximum of the initial cloud in the mutation-row layout (stage 2's energy shift)
+    for (auto *h : g.hs) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        k2_energy_max<<<g0.Vl * g0.nb2, 256, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
+    }
+    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX)) return e;
+
+    const bool profile = rc->use_graph == 2;
+    std::vector<hipEvent_t> evs;
+    std::vector<int> ev_stage;
+    static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
+    // ---- pieces of a stage
+    auto enq_K1 = [&](int n, int begin_done, int spec_expected) -> int {
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            const Rows2 mr = mut_rows(h);
+#define SMCMI_CALL(D) launch_k2_correct<D>(h, n, begin_done, spec_expected, mr)
+            SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+        }
+        return publish(&Eng2::rows_cm, &Eng2::vt_cm, g0.nb1, npf, -1);
+    };
+    auto enq_select = [&](int n) -> int {
+        if (!multi) {
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                Eng2 *e = h->e2;
+                const Rows2 cr = cm_rows(h);
+                k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cr, h->d_wt, e->csum, h->d_cum);
+#define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum, rc->resampling_method, nullptr)
+                SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+            }
+            return publish(&Eng2::rows_gm, &Eng2::vt_gm, g0.nbg, np, -1);
+        }
+        // several handles: every handle scans the all-gathered weights itself (same chunks, same chunk sums -> the same cumulative
+        // weights everywhere), then receives the rows its slots descend from
+        const size_t nloc = (size_t)h0->n;
+        if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->d_wt; }, [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return e;
+        if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->e2->csum; }, [](smcmi_handle *h) { return h->e2->csum_full; },
+                                (size_t)g0.Vl * g0.nb1)) return e;
+        static const char *xchg = getenv("SMCMI_RESAMPLE_EXCHANGE");
+        const bool a2a = !(xchg && !strcmp(xchg, "allgather")) && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC;
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            Eng2 *e = h->e2;
+            k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_full_w, e->csum_full, h->d_cum_full);
+            if (a2a) k2_anc_ranges<<<1, 64, 0, h->stream>>>(e->d_ctl, h->d_st, n, cm_rows(h), h->d_cum_full, h->cfg.n_parts, h->n, g.world, h->cfg.seed, e->d_ranges);
+        }
+        bool rs = true;
+        if (a2a) {
+            // all-to-all-v: only the rows inside a handle's ancestor range travel to it (the one host read of a resample stage)
+            std::vector<long long> ranges(2 * (size_t)g.world);
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(ranges.data(), h0->e2->d_ranges, sizeof(long long) * ranges.size(), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipStreamSynchronize(h0->stream));
+            rs = ranges[0] >= 0;                       // -1: the device decided not to resample after all (or the stage is a no-op)
+            if (rs) { if (int e = g.exchange_rows(ranges)) return e; }
+        } else {
+            if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->cl.buf[0]; }, [](smcmi_handle *h) { return h->d_full_cloud; },
+                                    nloc * h0->R)) return e;
+        }
+        if (rs)
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                const Rows2 cr = cm_rows(h);
+#define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum_full, rc->resampling_method, h->d_full_cloud)
+                SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+            }
+        return publish(&Eng2::rows_gm, &Eng2::vt_gm, g0.nbg, np, -1);
+    };
+    auto enq_K2 = [&](int n, int sel_enqueued) -> int {
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            Eng2 *e = h->e2;
+            Mut2Args ma{};
+            ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n; ma.sel_enqueued = sel_enqueued; ma.adaptive = adaptive ? 1 : 0;
+            ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
+            ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (profile && h == h0) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_stage.push_back(n); hipEventRecord(e0, h->stream); }
+#define SMCMI_CALL(D) launch_k2_mutate<D>(h, ma, rc->n_blocks, rc->alpha == 1.0)
+            SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+            if (e1) hipEventRecord(e1, h->stream);
+        }
+        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX);
+    };
+    auto enq_passes = [&](int n, int p0, int P) -> int {           // passes p0 .. P-1, then the closing decision
+        for (int p = p0; p < P; ++p) {
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                Eng2 *e = h->e2;
+                const Rows2 prev = view(h, e->rows_pass[(p + 1) & 1], e->vt_pass, g0.nb1, 2 * KC);
+                k2_pass<<<g0.Vl * g0.nb1, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, p, prev, h->d_sched, e->rows_pass[p & 1]);
+            }
+            if (int e = publish_pass(p & 1)) return e;
+        }
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            Eng2 *e = h->e2;
+            const Rows2 prev = view(h, e->rows_pass[(P + 1) & 1], e->vt_pass, g0.nb1, 2 * KC);
+            k2_finish<<<1, T1, 0, h->stream>>>(h->d_st, e->d_ctl, n, P, prev, h->d_sched);
+        }
+        return 0;
+    };
+    auto enq_begin = [&](int n) -> int {
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            k2_begin<<<1, T1, 0, h->stream>>>(h->d_st, h->e2->d_ctl, n, mut_rows(h), h->d_sched, h->rec);
+        }
+        return 0;
+    };
+    // a whole stage; cert: certificate passes instead of a predicted ϕ_n (adaptive schedules only)
+    auto enq_stage = [&](int n, bool cert, int P, bool sel) -> int {
+        if (cert) {
+            if (int e = enq_begin(n)) return e;
+            if (int e = enq_passes(n, 0, P)) return e;
+            if (int e = enq_K1(n, 1, 0)) return e;
+        } else if (int e = enq_K1(n, 0, adaptive ? 1 : 0)) return e;
+        if (sel) { if (int e = enq_select(n)) return e; }
+        return enq_K2(n, sel ? 1 : 0);
+    };
+    auto read_ctl = [&](Ctl2 *c) -> int {
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        HIP_TRY(hipMemcpyAsync(c, h0->e2->d_ctl, sizeof(Ctl2), hipMemcpyDeviceToHost, h0->stream));
+        HIP_TRY(hipStreamSynchronize(h0->stream));
+        if (g.hs.size() > 1)                                          // in-process groups: the other streams are done when the collectives' syncs are
+            for (auto *h : g.hs) { HIP_TRY(hipSetDevice(h->cfg.device)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+        return 0;
+    };
+    auto clear_status = [&]() -> int {
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            HIP_TRY(hipMemsetAsync(&h->e2->d_ctl->status, 0, 2 * sizeof(int), h->stream));      // code, stage
+        }
+        return 0;
+    };
+
+    const int base = cont ? h0->h_st.stage - 1 : 0;           // stages completed before this call
+    const int max_iter = (adaptive ? h0->cfg.max_stages : rc->n_phi - 1) - base;
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
+    const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
+    const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
+    const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
+    static const int sel_mode = getenv("SMCMI_NO_SELECT_PREDICT") ? atoi(getenv("SMCMI_NO_SELECT_PREDICT")) : 0;   // development only
+    static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;                       // development only
+    const bool predict_select = adaptive && sel_mode != 1;
+    // predicted ϕ_n needs the solver's objective to be the correction's ESS (no prior weight, quirk Q4) and a tolerance to verify against
+    const bool spec_ok = adaptive && !no_spec && !getenv("SMCMI_NO_PREDICTOR") && rc->tempered_update_prior_weight == 0.0 && !(rc->phi_rtol < 0.0);
+    bool spec_on = spec_ok;
+    int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;
+    int dyn_P = solver_passes;
+    if (rc->solver_passes < 1 && rc->tempering_target < 0.95) dyn_P = 2;
+    double pred_ess = cont ? h0->h_st.ess_prev : (rc->initial_ess > 0.0 ? rc->initial_ess : N_tot);
+    int pred_rl = cont ? h0->h_st.resampled_last : 0;
+    int stall_stage = -1, stall_p = 0, stages_left_est = 1 << 30;
+    int launched = 0;
+    res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0;
+    Ctl2 c{};
+    const auto t0 = std::chrono::steady_clock::now();
+    bool finished = false;
+    while (!finished) {
+        const int room = max_iter - launched;
+        const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), room) : room;
+        for (int b = 0; b < batch; ++b) {
+            const int n = base + launched + 2;
+            bool sel = true;
+            if (predict_select) {
+                // ESS this stage will end at (helpers.jl:14-20), with a margin: a wrong "resample" guess only costs two idle launches
+                const double ess_bar = rc->tempering_target * (pred_rl ? N_tot : pred_ess);
+                const bool rs = ess_bar < thr * (1.0 + 1e-6);
+                sel = rs && sel_mode != 2;
+                pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
+            }
+            // stages that follow a resample or have no mutation rows yet (first stage of a run / a continuation) get certificate
+            // passes; so does everything once predictions have stopped verifying
+            const bool cert = adaptive && (!spec_on || sel || launched < 2);
+            if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
+            ++launched;
+        }
+        if (int e = read_ctl(&c)) return e;
+        while (c.status.code == 2 || c.status.code == 3 || c.status.code == 4) {
+            const int sn = c.status.stage, code = c.status.code;
+            for (int &s : ev_stage) if (s >= sn) s = -1;           // the stalled stage's mutation launch and everything behind it were no-ops
+            if (int e = clear_status()) return e;
+            if (code == 4) {
+                // predicted ϕ_n unusable or not verified: nothing of the stage is committed; run it through the certificate path
+                if (int e = enq_stage(sn, true, first_passes, true)) return e;
+                stall_stage = sn; stall_p = first_passes;
+                res->spec_stalls += 1;
+                if (sn - last_spec_stall <= 4) { if (++spec_strikes >= 2) spec_on = false; }
+                else spec_strikes = 0;
+                last_spec_stall = sn;
+            } else if (code == 2) {
+                const int had = (sn == stall_stage) ? stall_p : (sn - base <= 3 ? first_passes : dyn_P);
+                const int more = 8;
+                if (int e = enq_passes(sn, had, had + more)) return e;
+                if (int e = enq_K1(sn, 1, 0)) return e;
+                if (int e = enq_select(sn)) return e;
+                if (int e = enq_K2(sn, 1)) return e;
+                stall_stage = sn; stall_p = had + more;
+                res->solver_stalls += 1;
+                if (sn - last_solver_stall <= 4 && dyn_P < 4) ++dyn_P;
+                last_solver_stall = sn;
+            } else {
+                // the stage must resample but its selection kernels were not enqueued: run the rest of it
+                if (int e = enq_select(sn)) return e;
+                if (int e = enq_K2(sn, 1)) return e;
+                res->select_stalls += 1;
+            }
+            launched = sn - 1 - base;
+            if (int e = read_ctl(&c)) return e;
+        }
+        if (c.status.code == 1 || c.status.code == 5 || c.status.code == 9) break;
+        const Post2 &p = c.ps[0].stage >= c.ps[1].stage ? c.ps[0] : c.ps[1];
+        if (p.phi_n >= 1.0 || launched >= max_iter) {
+            // the last enqueued stage reached ϕ = 1 (or the capacity is used up): the next stage's begin folds the last acceptance
+            // rate and closes the run
+            if (int e = enq_begin(p.stage + 1)) return e;
+            if (int e = read_ctl(&c)) return e;
+            finished = true;
+            break;
+        }
+        if (c.bg.stage == p.stage && c.bg.phi_n > c.bg.phi_prev && p.phi_n < 1.0) {
+            const double left = (1.0 - p.phi_n) / (c.bg.phi_n - c.bg.phi_prev);
+            stages_left_est = left < 1e6 ? (int)left + 1 : 1 << 30;
+        }
+        if (predict_select) { pred_ess = p.ess; pred_rl = p.do_resample; }
+    }
+    for (auto *h : g.hs) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        k2_export<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
+        if (pull_state(h)) return SMCMI_ERR_HIP;
+        h->last_n_stages = h->h_st.stage;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const DevState &s = h0->h_st;
+    res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;
+    if (profile && !evs.empty()) {
+        // event pairs bracket dispatch + kernel: calibrate the fixed part around an empty kernel of the same grid (smcmi_run)
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        hipEvent_t c0, c1;
+        hipEventCreate(&c0); hipEventCreate(&c1);
+        double acc_ms = 0.0;
+        int got = 0;
+        for (int r = 0; r < 64; ++r) {
+            k_noop<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(h0->d_st);
+            hipEventRecord(c0, h0->stream);
+            k_noop<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(h0->d_st);
+            hipEventRecord(c1, h0->stream);
+            hipStreamSynchronize(h0->stream);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c0, c1) == hipSuccess) { acc_ms += ms; ++got; }
+        }
+        hipEventDestroy(c0); hipEventDestroy(c1);
+        const double over = got ? std::max(0.0, acc_ms / got - 0.0025) : 0.0;
+        for (size_t k = 0; k + 1 < evs.size(); k += 2) {
+            float ms = 0.f;
+            if (ev_stage[k / 2] >= 0 && ev_stage[k / 2] <= s.stage && hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) {
+                res->kernel_ms_mutate += std::max(0.0, (double)ms - over);
+                res->n_mutate_launches += 1;
+            }
+        }
+    }
+    for (hipEvent_t e : evs) hipEventDestroy(e);
+    res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
+    res->seconds = std::chrono::duration<double>(t1 - t0).count();
+    res->solver_passes = s.solver_passes;
+    res->paused = (s.done == 5) ? 1 : 0;
+    if (s.err) return err_from_state(s.err);
+    if (!(c.status.code == 1 || c.status.code == 5)) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
+    return 0;
+}

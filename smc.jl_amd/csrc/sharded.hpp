@@ -196,6 +196,7 @@ struct ShardGroup {
     }
 };
 
+static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res);
 static int ensure_shard_buffers(smcmi_handle *h) {
     const long long N = h->cfg.n_parts;
     if (!h->d_tot_ess) {
@@ -591,6 +592,7 @@ extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, sm
     if (!h->nccl) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init has not been called on this handle");
     ShardGroup g;
     g.hs = {h}; g.world = h->world; g.rccl = true;
+    if (eng2_eligible(h, g.world)) return run2_impl(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
     return run_sharded_impl(g, rc, res);
 }
 
@@ -607,5 +609,6 @@ extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_con
     }
     if (expect != hs[0]->cfg.n_parts) return set_err(SMCMI_ERR_ARG, "group handles do not cover n_parts");
     g.world = n; g.rccl = false;
+    if (eng2_eligible(hs[0], g.world)) return run2_impl(g, rc, res);
     return run_sharded_impl(g, rc, res);
 }

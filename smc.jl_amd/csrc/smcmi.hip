@@ -20,8 +20,11 @@
 #include "../../include/smcmi.h"
 #include "devstate.hpp"
 #include "kernels.hpp"
+#include "stage2.hpp"
 
 using namespace smcmi;
+struct Eng2;                       // engine 2's per-handle buffers (run2.hpp)
+static void free_eng2(Eng2 *e);
 
 static thread_local std::string g_err;
 extern "C" const char *smcmi_last_error(void) { return g_err.c_str(); }
@@ -80,6 +83,7 @@ struct smcmi_handle {
     long long *d_prof = nullptr;   // development only (smcmi_debug_time_kernel with which = 9 and SMCMI_PROF_MUT=1)
     hipGraphExec_t graph_exec = nullptr;
     int graph_sig = 0;
+    Eng2 *e2 = nullptr;            // engine 2 (stage2.hpp / run2.hpp): rows, virtual-shard totals, Ctl2
 };
 
 static int push_state(smcmi_handle *h) {
@@ -206,6 +210,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->nccl) smcmi_comm_release(h);
+    if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
                     h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
@@ -862,10 +867,15 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     if (ev1) hipEventRecord(ev1, s);
 }
 
+struct ShardGroup;
+static bool eng2_eligible(const smcmi_handle *h, int world);
+static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
+
 extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
     if (int e = need_model(h, true)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
+    if (eng2_eligible(h, 1)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
     const int nf = h->h_model.n_free;
     if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
@@ -1318,6 +1328,12 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
 }
 
 #include "sharded.hpp"
+#include "run2.hpp"
+static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
+    ShardGroup g;
+    g.hs = {h}; g.world = 1; g.rccl = false;
+    return run2_impl(g, rc, res);
+}
 
 // ------------------------------------------------------------------------------------------------ development aid
 __global__ void k_empty(const DevState *st) { if (st->done == 12345) printf("x"); }

@@ -1,0 +1,1283 @@
+// stage2.hpp - the two-launch stage ("engine 2") for models with n_para <= 10.
+//
+// A tempering stage of the reference (src/smc_main.jl:377-508) needs two chip-wide hand-overs: the correction's weight sums and
+// moments must be complete before the proposal can be built (smc_main.jl:427-469), and the mutated cloud's energies must be
+// complete before the next ϕ can be chosen (helpers.jl:9-56).  Engine 1 (kernels.hpp) spends a single-block kernel on each of
+// them (k_prepare_mutation, k_stage_begin: 44 % of the stage at N = 1e5).  Here both hand-overs are *launch-boundary reduces*:
+//
+//   k2_correct<D>  (K1)  prologue: every block totals the mutation's per-block rows (energy power sums, Σ accept, energy max) in a
+//                        fixed order and runs the stage-begin logic itself (acceptance fold, energy shift, ϕ predictor / fixed
+//                        schedule); block 0 records it.  Body: correction + moments at ϕ_n -> one row of sums per block.
+//   k2_mutate<D,α1> (K2) prologue: every block totals the correction rows, takes the post-correction decision (ESS, verification
+//                        of a predicted ϕ_n, resample?, c, log-MDD), builds the proposal (covariance, random blocks, Cholesky)
+//                        in LDS; block 0 records it.  Body: the register-resident mutation -> one row of energy sums per block.
+//
+// No single-block launches, no in-kernel fences or atomics, no DevState round trips between the kernels of a stage; the kernel
+// boundary is the only synchronisation.  Resample stages add k2_scan + k2_gather<D> (selection + moments of the resampled
+// cloud) between the two; stages without a usable prediction run certificate passes k2_begin -> P x k2_pass -> k2_finish first.
+//
+// State discipline: a kernel never reads a word another block of the SAME launch may write.  K1 reads Post2[(n-1)&1] and rows,
+// writes Begin2; K2 reads Begin2, Post2[(n-1)&1] and rows, writes Post2[n&1].  Every kernel carries its stage index n as a launch
+// argument and does nothing unless the state it reads belongs to that stage - so a stage that stalls (prediction not verified,
+// selection needed but not enqueued, solver out of passes) turns everything enqueued behind it into no-ops without a flag.
+//
+// Shard-count invariance: the N particles are cut into V = 8 *virtual shards* (fixed global ranges); every per-block quantity is
+// defined per virtual shard, rows are totalled per virtual shard in a canonical order (groups of 64 rows; inside a group 8
+// interleaved slices combined as a fixed tree; groups, then virtual shards, in ascending order) - so 1, 2, 4 or 8 GPUs holding
+// 8, 4, 2 or 1 virtual shards each produce bit-identical sums, hence identical ϕ schedules, ancestors and clouds.
+#pragma once
+#include "kernels.hpp"
+
+namespace smcmi {
+
+constexpr int V2_MAXV = 8;        // virtual shards
+constexpr int RMUT = 34;          // mutation row: ES = 32 sums (energy power sums | Σ accept), [32] = energy maximum, [33] unused
+constexpr int RMAX_IDX = 32;
+constexpr int T1 = 512;           // threads of a correction block
+constexpr int GRP = 64;           // rows per canonical reduction group
+
+struct Geo2 {
+    long long N, n, nv;           // global / local / per-virtual-shard particles
+    int V, Vl, v0;                // virtual shards in total / held by this handle / global index of the first local one
+    int nb1, nb2, nbg;            // blocks per virtual shard: correction (and scan chunks) / mutation / gather
+    long long per1, perg;         // particles per correction / gather block
+    int direct;                   // consumers total the per-block rows themselves (one handle, <= GRP rows per virtual shard)
+};
+
+struct Rows2 {                    // rows[(v * nr + r) * ld + idx], v < nvs, r < nr
+    const double *p;
+    int nvs, nr, ld;
+};
+
+struct Begin2 {                   // stage n as decided at its begin (K1 / k2_begin / k2_finish, block 0)
+    int stage, final, spec, j;
+    double phi_prev, phi_n, phi_prop, ess_bar, gprime, pred_delta;
+    double accept;                // cloud.accept: acceptance rate of stage n-1's mutation (particle.jl:466-468)
+    double e_shift, e_center;
+};
+struct Post2 {                    // stage n after its correction (K2, block 0); two copies, indexed by n & 1
+    int stage, j, resampled_last, do_resample, resamples, fold_valid;
+    double phi_n, phi_prop, ess, sumw, sumw2, logz, c, accept, e_center, e_shift;
+    double shift[MAXD >= 16 ? 16 : MAXD];
+};
+struct Status2 {
+    int code;                     // 0 running, 1 finished (ϕ = 1 reached, last acceptance rate folded), 2 solver out of passes,
+                                  // 3 selection needed but not enqueued, 4 predicted ϕ_n unusable / not verified, 5 paused, 9 error
+    int stage, err, pad;
+    long long solver_passes;
+    double accept;                // cloud.accept at the end of the run / at the pause
+};
+struct Ctl2 {
+    Status2 status;
+    Begin2 bg;
+    Post2 ps[2];
+};
+static_assert(sizeof(Begin2) % 8 == 0 && sizeof(Post2) % 8 == 0, "state structs are copied as doubles");
+
+// ------------------------------------------------------------------------------------------------ canonical row totals
+template <int SL>
+__device__ inline double slice_tree(const double (&a)[SL]) {
+    if constexpr (SL == 8) return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    else if constexpr (SL == 4) return (a[0] + a[1]) + (a[2] + a[3]);
+    else if constexpr (SL == 2) return a[0] + a[1];
+    else return a[0];
+}
+template <int SL>
+__device__ inline double slice_tree_max(const double (&a)[SL]) {
+    double m = a[0];
+#pragma unroll
+    for (int q = 1; q < SL; ++q) m = fmax(m, a[q]);
+    return m;
+}
+
+// Totals of M columns over R.nvs (<= V2_MAXV) virtual shards x R.nr (<= NRMAX <= GRP) rows in the canonical order, by the whole
+// block of T threads.  H threads share one (virtual shard, column) unit, each owning 8 / H of the 8 slices (slice s = rows s, s + 8,
+// ... in ascending order); the result does not depend on H, T or NRMAX.  Column max_idx (if >= 0) is a maximum instead of a sum.
+// Every load is unconditional (rows beyond nr re-read the last row and contribute the identity): a load under a run-time
+// condition makes the compiler wait for each one separately, i.e. one memory round trip per row instead of one per call.
+// vt: LDS scratch of V2_MAXV * M * H doubles; tot: LDS, M doubles.  All threads must call; ends with a barrier.
+template <int M, int H, int NRMAX, int T>
+__device__ inline void reduce_rows_ct(const Rows2 &R, double *vt, double *tot, int max_idx = -1) {
+    constexpr int SL = 8 / H, NJ = NRMAX / 8, UPT = (V2_MAXV * M * H + T - 1) / T;
+    static_assert(NRMAX % 8 == 0 && NRMAX <= GRP, "NRMAX: multiple of 8, at most one group");
+    const int units = R.nvs * M * H, nr = R.nr;
+    // (one unit's loads in flight at a time: unrolling over k as well would need > 100 VGPRs of load targets and spill in K2)
+#pragma unroll 1
+    for (int k = 0; k < UPT; ++k) {
+        const int u = (int)threadIdx.x + k * T;
+        if (k * T >= units) break;                     // block-uniform
+        const int uc = u < units ? u : 0;
+        const int h = uc % H, idx = (uc / H) % M, v = uc / (H * M);
+        const bool mx = idx == max_idx;
+        const double ident = mx ? -__builtin_inf() : 0.0;
+        const double *base = R.p + ((long long)v * nr) * R.ld + idx;
+        double a[SL];
+#pragma unroll
+        for (int q = 0; q < SL; ++q) a[q] = ident;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int q = 0; q < SL; ++q) {
+                const int r = h * SL + q + 8 * j;
+                const int rc = r < nr ? r : nr - 1;
+                const double x = base[(long long)rc * R.ld];
+                const double xv = r < nr ? x : ident;
+                a[q] = mx ? fmax(a[q], xv) : a[q] + xv;
+            }
+        }
+        if (u < units) vt[u] = mx ? slice_tree_max<SL>(a) : slice_tree<SL>(a);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < M; idx += T) {
+        const bool mx = idx == max_idx;
+        double t = mx ? -__builtin_inf() : 0.0;
+        for (int v = 0; v < R.nvs; ++v) {
+            double p[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) p[h] = vt[(v * M + idx) * H + h];
+            const double vs = mx ? slice_tree_max<H>(p) : slice_tree<H>(p);
+            t = mx ? fmax(t, vs) : t + vs;
+        }
+        tot[idx] = t;
+    }
+    __syncthreads();
+}
+// the same with the row capacity picked at run time (8 / 16 / 32 / 64)
+template <int M, int H, int T>
+__device__ inline void reduce_rows(const Rows2 &R, double *vt, double *tot, int max_idx = -1) {
+    if (R.nr <= 8) reduce_rows_ct<M, H, 8, T>(R, vt, tot, max_idx);
+    else if (R.nr <= 16) reduce_rows_ct<M, H, 16, T>(R, vt, tot, max_idx);
+    else if (R.nr <= 32) reduce_rows_ct<M, H, 32, T>(R, vt, tot, max_idx);
+    else reduce_rows_ct<M, H, 64, T>(R, vt, tot, max_idx);
+}
+
+// Virtual-shard totals of a row set with any number of rows (sharded runs and large clouds): block v totals the nr rows of its
+// virtual shard in the canonical order (groups of GRP rows by slice tree, groups in ascending order) -> out[v][m].
+constexpr int RT = 1024;
+__global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr, int m, int max_idx, double *out) {
+    __shared__ double gs[16 * 72];                      // 16 group sums x up to 72 columns
+    const int v = blockIdx.x;
+    const double *base0 = rows + (long long)v * nr * m;
+    const int ng = (nr + GRP - 1) / GRP;
+    double run = (int)threadIdx.x == max_idx ? -__builtin_inf() : 0.0;
+    for (int g0 = 0; g0 < ng; g0 += 16) {
+        const int gb = (ng - g0) < 16 ? (ng - g0) : 16;
+        for (int u = threadIdx.x; u < gb * m; u += RT) {
+            const int idx = u % m, g = g0 + u / m;
+            const bool mx = idx == max_idx;
+            const int r_beg = g * GRP, r_end = (r_beg + GRP < nr) ? r_beg + GRP : nr;
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = mx ? -__builtin_inf() : 0.0;
+            const double *base = base0 + idx;
+            for (int r0 = r_beg; r0 < r_end; r0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (r0 + q < r_end) {
+                        const double x = base[(long long)(r0 + q) * m];
+                        a[q] = mx ? fmax(a[q], x) : a[q] + x;
+                    }
+            }
+            gs[(u / m) * 72 + idx] = mx ? slice_tree_max<8>(a) : slice_tree<8>(a);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < m) {
+            const bool mx = (int)threadIdx.x == max_idx;
+            for (int g = 0; g < gb; ++g) run = mx ? fmax(run, gs[g * 72 + threadIdx.x]) : run + gs[g * 72 + threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < m) out[(long long)v * m + threadIdx.x] = run;
+}
+
+// block-wide fixed-order reduction of M accumulators per thread for a block of NW wavefronts; thread t < M gets total t.
+// red: NW * M doubles of LDS.
+template <int M, int NW>
+__device__ inline double block_reduce_nw(double (&a)[M], double *red) {
+    static_assert(M >= 1 && M <= 64 && (M & (M - 1)) == 0, "M must be a power of two <= 64");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Butterfly<M / 2, 32>::run(a, lane);
+    constexpr int SH = 6 - ilog2(M);
+    if ((lane & ((1 << SH) - 1)) == 0) red[wave * M + (lane >> SH)] = a[0];
+    __syncthreads();
+    double tot = 0.0;
+    if ((int)threadIdx.x < M) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[w * M + threadIdx.x];
+    }
+    __syncthreads();
+    return tot;
+}
+
+// particle range of block r of local virtual shard vl (per = particles per block)
+__device__ inline void vchunk(const Geo2 &g, int vl, int r, long long per, long long &beg, long long &end) {
+    const long long v_beg = (long long)vl * g.nv, v_end = v_beg + g.nv;
+    beg = v_beg + (long long)r * per;
+    end = beg + per < v_end ? beg + per : v_end;
+    if (beg > v_end) beg = v_end;
+}
+
+// ------------------------------------------------------------------------------------------------ state import / export
+// Engine 2 keeps its loop state in Ctl2; the C ABI's stand-alone calls, pause / continue and the result read DevState.  One
+// thread copies one into the other at the start / end of a run.
+__global__ void k2_import(const DevState *st, Ctl2 *ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctl2 c;
+    memset(&c, 0, sizeof(c));
+    Post2 &p = c.ps[st->stage & 1];
+    p.stage = st->stage; p.j = st->j; p.resampled_last = st->resampled_last; p.do_resample = 0; p.resamples = st->resamples;
+    p.fold_valid = 0;                                  // no mutation rows of this chain exist yet (fresh or continued run)
+    p.phi_n = st->phi_n; p.phi_prop = st->phi_prop; p.ess = st->ess_prev; p.sumw = st->sumw; p.sumw2 = st->sumw2;
+    p.logz = st->logz; p.c = st->c; p.accept = st->accept; p.e_center = st->e_center; p.e_shift = 0.0;
+    for (int a = 0; a < (int)(sizeof(p.shift) / sizeof(double)); ++a) p.shift[a] = st->shift[a];
+    c.ps[(st->stage & 1) ^ 1].stage = -1;
+    c.bg.stage = -1;
+    c.status.solver_passes = st->solver_passes;
+    *ctl = c;
+}
+__global__ void k2_export(DevState *st, const Ctl2 *ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Post2 &p = ctl->ps[0].stage >= ctl->ps[1].stage ? ctl->ps[0] : ctl->ps[1];
+    const Status2 &s = ctl->status;
+    st->stage = p.stage; st->j = p.j; st->resampled_last = p.resampled_last; st->do_resample = p.do_resample; st->resamples = p.resamples;
+    st->phi_n = p.phi_n; st->phi_prop = p.phi_prop; st->ess_prev = p.ess; st->ess = p.ess; st->sumw = p.sumw; st->sumw2 = p.sumw2;
+    st->logz = p.logz; st->c = p.c; st->accept = (s.code == 1 || s.code == 5) ? s.accept : p.accept; st->e_center = p.e_center;
+    if (ctl->bg.stage == p.stage) st->phi_prev = ctl->bg.phi_prev;
+    for (int a = 0; a < (int)(sizeof(p.shift) / sizeof(double)); ++a) { st->shift[a] = p.shift[a]; st->mean[a] = p.shift[a]; }
+    st->solver_passes = s.solver_passes;
+    st->err = s.err;
+    st->done = s.code == 1 ? 1 : (s.code == 5 ? 5 : (s.code == 9 ? 1 : (s.code ? s.code : 0)));
+    st->skip_fold = 0;
+}
+
+// largest energy of the live cloud per mutation block -> rows_mut[b][RMAX_IDX] (run start; afterwards the mutation epilogue)
+__global__ void __launch_bounds__(256) k2_energy_max(CloudPtrs cl, Geo2 g, double *rows_mut) {
+    __shared__ double smem[4];
+    const int vl = blockIdx.x / g.nb2, r = blockIdx.x % g.nb2;
+    long long beg, end;
+    vchunk(g, vl, r, 256, beg, end);
+    const int R = cl.R;
+    const long long i = beg + threadIdx.x;
+    double m = -__builtin_inf();
+    if (i < end) m = energy_or_ninf(col(cl, 0, R - 5)[i], col(cl, 0, R - 3)[i], col(cl, 0, R - 1)[i], true);
+    m = block_max(m, smem, 4);
+    if (threadIdx.x == 0) rows_mut[(long long)blockIdx.x * RMUT + RMAX_IDX] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ stage begin
+// src/smc_main.jl:378-396 + src/helpers.jl:9-56 (see k_stage_begin in kernels.hpp for the predictor and the candidate set): run
+// by wavefront 0 of EVERY block of the stage's first kernel from the same inputs; `writer` (block 0) alone stores to global
+// memory.  s_es: totals of the previous mutation's rows (valid iff rows_valid); s_sw: window of the proposed schedule,
+// s_sw[q] = schedule[j + q] (1-based j), 2.0 beyond the end.  Result in *bg (LDS, written by lane 0).
+// Returns: 0 ϕ_n decided (bg->final), 1 run finished, 5 paused, 9 capacity error, 4 no usable prediction (spec_expected),
+//          6 solver armed in *arm (certificate passes follow).
+__device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, const double *s_es, double emax_tot, bool rows_valid,
+                                  int spec_expected, const double *sched, const double *s_sw, Begin2 *bg, Solver *arm, bool writer,
+                                  const Records &rec, Status2 *status) {
+    const int lane = threadIdx.x & 63;
+    const int stage0 = n - 1, n_phi = rp.n_phi, fixed = rp.use_fixed_schedule, j = po.j;
+    const double N = (double)rp.n_parts, phi_n = po.phi_n, phi_prop = po.phi_prop, target = rp.tempering_target;
+    const bool fold = rows_valid && po.fold_valid && stage0 > 1;
+    const bool have_es = fold && !fixed;
+    const double accept = fold ? s_es[EACC] / N : po.accept;
+    if (writer && lane == 0 && fold) rec.accept[stage0 - 1] = accept;
+    if (phi_n >= 1.0) { if (writer && lane == 0) { status->accept = accept; status->stage = stage0; status->code = 1; } return 1; }
+    if (rp.stop_stage > 0 && stage0 >= rp.stop_stage) { if (writer && lane == 0) { status->accept = accept; status->stage = stage0; status->code = 5; } return 5; }
+    if (n > rp.max_stages) { if (writer && lane == 0) { status->err = SMCMI_ERR_CAPACITY; status->stage = stage0; status->code = 9; } return 9; }
+    Begin2 b;
+    b.stage = n; b.final = 0; b.spec = 0; b.j = j;
+    b.phi_prev = phi_n; b.phi_n = phi_n; b.phi_prop = phi_prop; b.ess_bar = 0.0;
+    b.gprime = __longlong_as_double(0x7ff8000000000000ll); b.pred_delta = b.gprime;
+    b.accept = accept;
+    b.e_shift = fabs(emax_tot) < 1e300 ? emax_tot : po.e_shift;     // no live particle with a finite energy: keep the previous shift
+    b.e_center = po.e_center;
+    if (fixed) {
+        b.phi_n = (n <= n_phi) ? sched[n - 1] : 1.0;
+        b.final = 1;
+        if (lane == 0) *bg = b;
+        return 0;
+    }
+    const int rl = po.resampled_last;
+    const double ess_bar = target * (rl ? N : po.ess), ess_now = rl ? N : po.ess;      // helpers.jl:14-20
+    b.ess_bar = ess_bar;
+    double pd = b.gprime, gp = b.gprime;
+    if (have_es) {
+        pd = predict_delta_wave(s_es, po.do_resample != 0, ess_bar, &gp);
+        const double ec = po.e_center + s_es[1] / s_es[0];         // weighted mean energy: centre for the next epilogue
+        if (fabs(ec) < 1e300) b.e_center = ec;
+    }
+    b.pred_delta = pd; b.gprime = gp;
+    const int q_end = n_phi - j + 1;                         // last existing walk step
+    const double ph = phi_n + pd;
+    bool use_pred = pd > 0.0 && ph < 1.0;
+    const double wl = lane == 0 ? phi_prop : s_sw[lane - 1];
+    const unsigned long long above = __ballot(lane <= 62 && lane <= q_end && wl > ph);
+    int qstar = above ? (__ffsll((long long)above) - 1) : (q_end <= 62 ? q_end : -1);
+    if (qstar < 0) use_pred = false;
+    if (spec_expected) {
+        const bool none_above = !above;
+        const bool beyond = pd > 0.0 && ph >= 1.0 && qstar >= 0 && none_above;
+        if ((use_pred || beyond) && gp < 0.0) {
+            const double step_q = __shfl(wl, qstar, 64);
+            b.final = 1; b.spec = 1;
+            b.phi_prop = step_q; b.j = j + qstar;
+            b.phi_n = none_above ? step_q : ph;
+            if (lane == 0) *bg = b;
+            return 0;
+        }
+        if (writer && lane == 0) { status->stage = n; status->code = 4; }
+        return 4;
+    }
+    // certificate path: arm the solver with the walk steps (and the rings around a prediction) - block 0 only
+    if (lane == 0) *bg = b;
+    if (!writer) return 6;
+    Solver &S = *arm;
+    if (lane == 0) {
+        S.unconverged = 0; S.ess_bar = ess_bar; S.lo = phi_n; S.phi0 = phi_n; S.glo = ess_now - ess_bar; S.hi = phi_prop; S.ghi = 0.0;
+        S.j = j; S.phi_prop = phi_prop; S.spec = 0; S.gprime = gp;
+    }
+    double x = 0.0;
+    int cq = -1;
+    bool keep = false;
+    if (use_pred) {
+        if (lane < 2 * NPR + 1) {
+            const double r = lane < NPR ? -PRING[lane < NPR ? lane : 0] : (lane == NPR ? 0.0 : PRING[2 * NPR - lane]);
+            x = ph + pd * r;
+            keep = x > phi_n && x < 1.0;
+        }
+        const unsigned long long ringm = __ballot(keep);
+        if (!ringm) use_pred = false;
+        const int nr = __popcll(ringm);
+        if (lane == NRL) { cq = 0; keep = true; }
+        if (lane == NRL + 1) { cq = qstar - 1; keep = cq > 0; }
+        if (lane == NRL + 2) { cq = qstar; keep = cq > 0; }
+        const int nq3 = 1 + (qstar - 1 > 0 ? 1 : 0) + (qstar > 0 ? 1 : 0);
+        if (lane == NRL + 3) { cq = qstar + 1; keep = cq <= q_end && nq3 < KC - nr; }
+        if (lane >= NRL && lane <= NRL + 3 && keep) x = cq == 0 ? phi_prop : s_sw[cq - 1];
+    }
+    if (!use_pred) {
+        cq = lane; keep = lane < KC && lane <= q_end;
+        x = keep ? wl : 0.0;
+    } else {
+        bool dup = false;
+#pragma unroll
+        for (int o = 0; o < NLANE; ++o) {
+            const double xo = __shfl(x, o, 64);
+            const bool ko = (bool)__shfl((int)keep, o, 64);
+            if (ko && lane < NRL && xo == x && (o < lane || o >= NRL)) dup = true;
+        }
+        if (dup) keep = false;
+    }
+    int rank = 0;
+#pragma unroll
+    for (int o = 0; o < NLANE; ++o) {
+        const double xo = __shfl(x, o, 64);
+        const bool ko = (bool)__shfl((int)keep, o, 64);
+        if (ko && xo < x) ++rank;
+    }
+    const int nv = __popcll(__ballot(keep));
+    if (keep) { S.cand[rank] = x; S.cj[rank] = use_pred ? (lane >= NRL ? cq : -1) : cq; }
+    if (lane == 0) { S.n_valid = nv; S.mode = MODE_SCAN; }
+    return 6;
+}
+
+// Shared front of K1 and k2_begin: load Post2[(n-1)&1], total the mutation rows, run begin2_wave.  Returns the action code to all
+// threads; s_bg holds stage n's Begin2 when the action is 0 or 6.  LDS: s_po, s_bg, s_vt (V2_MAXV * RMUT * 4 doubles), s_tot (RMUT),
+// s_sw (64), s_act.
+template <int T>
+__device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &mrows, int spec_expected, const double *sched,
+                                   const Records &rec, Post2 *s_po, Begin2 *s_bg, double *s_vt, double *s_tot, double *s_sw, int *s_act) {
+    const int t = threadIdx.x;
+    constexpr int NWP = sizeof(Post2) / sizeof(double);
+    if (t < NWP) reinterpret_cast<double *>(s_po)[t] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[t];
+    if (t == 0) *s_act = -1;
+    __syncthreads();
+    if (s_po->stage != n - 1) return -1;                 // the state this launch was enqueued for is not there: no-op
+    if (t < 64) {
+        const int jj = s_po->j - 1 + t;                  // 0-based index of walk step t + 1
+        s_sw[t] = (!st->rp.use_fixed_schedule && jj < st->rp.n_phi) ? sched[jj] : 2.0;
+    }
+    const bool rows_valid = mrows.p != nullptr;
+    if (rows_valid) reduce_rows<RMUT, 4, T>(mrows, s_vt, s_tot, RMAX_IDX);
+    else {
+        if (t < RMUT) s_tot[t] = t == RMAX_IDX ? -__builtin_inf() : 0.0;
+        __syncthreads();
+    }
+    if (t < 64) {
+        const int act = begin2_wave(n, *s_po, st->rp, s_tot, s_tot[RMAX_IDX], rows_valid && s_po->fold_valid, spec_expected, sched, s_sw, s_bg,
+                                    &st->sol[0], blockIdx.x == 0, rec, &ctl->status);
+        if (t == 0) *s_act = act;
+    }
+    __syncthreads();
+    const int act = *s_act;
+    constexpr int NWB = sizeof(Begin2) / sizeof(double);
+    if ((act == 0 || act == 6) && blockIdx.x == 0 && t < NWB) reinterpret_cast<double *>(&ctl->bg)[t] = reinterpret_cast<const double *>(s_bg)[t];
+    return act;
+}
+
+// stage begin as its own launch (certificate path: the solver is armed in DevState::sol[0]); 1 block
+__global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, int n, Rows2 mrows, const double *sched, Records rec) {
+    __shared__ Post2 s_po;
+    __shared__ Begin2 s_bg;
+    __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[RMUT], s_sw[64];
+    __shared__ int s_act;
+    begin2_block<T1>(n, st, ctl, mrows, 0, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act);
+}
+
+// ------------------------------------------------------------------------------------------------ certificate passes
+// One pass over (loglh, old_loglh, weight) for the <= KC candidates of solver copy (p-1)&1 (see k_pass in kernels.hpp); the
+// decision of pass p-1 is taken in the prologue of pass p by every block from the canonically totalled rows.
+// s_flag: 0 go on, 2 out of passes (stall), < 0 error.
+__device__ inline void solver_prologue2(DevState *st, const double *sched, const Rows2 &prev, int p, Solver *S, double *vt, double *tot,
+                                        double *srt, int force_final, int *s_flag, int T) {
+    const int t = threadIdx.x;
+    constexpr int NW = sizeof(Solver) / sizeof(double);
+    const Solver *src = &st->sol[p == 0 ? 0 : ((p - 1) & 1)];
+    if (t < NW) reinterpret_cast<double *>(S)[t] = reinterpret_cast<const double *>(src)[t];
+    if (t == 0) *s_flag = 0;
+    __syncthreads();
+    if (p == 0) return;
+    const int mode = S->mode;
+    if (mode == MODE_SCAN || mode == MODE_SECTION) {
+        if (T == T1) reduce_rows<2 * KC, 2, T1>(prev, vt, tot); else reduce_rows<2 * KC, 2, TB>(prev, vt, tot);
+        __shared__ int s_err;
+        if (t == 0) s_err = 0;
+        __syncthreads();
+        if (t < 64) solver_decide_wave(*S, tot, sched, st->rp.n_phi, st->rp.phi_rtol, &s_err, srt);
+        __syncthreads();
+        if (t == 0) {
+            if (s_err) { *s_flag = s_err; S->mode = MODE_IDLE; }
+            else if (force_final && S->mode != MODE_FINAL) *s_flag = 2;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && t < NW && *s_flag != 2) reinterpret_cast<double *>(&st->sol[p & 1])[t] = reinterpret_cast<const double *>(S)[t];
+}
+
+__global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int p, Rows2 prev, const double *sched,
+                                              double *rows_out) {
+    constexpr int K = KC;
+    __shared__ double red[(T1 / 64) * 2 * K];
+    __shared__ double s_vt[V2_MAXV * 2 * K * 2], s_tot[2 * K], s_srt[K];
+    __shared__ Solver S;
+    __shared__ int s_flag;
+    const int bstage = ctl->bg.stage, bfinal = ctl->bg.final;
+    const double phi_prev = ctl->bg.phi_prev, esh = st->rp.pw == 0.0 ? ctl->bg.e_shift : 0.0;
+    if (bstage != n || bfinal) return;
+    solver_prologue2(st, sched, prev, p, &S, s_vt, s_tot, s_srt, 0, &s_flag, T1);
+    if (s_flag) return;                                   // an error: k2_finish reports it
+    const int mode = S.mode;
+    if (mode != MODE_SCAN && mode != MODE_SECTION) return;
+    const int nv = S.n_valid, R = cl.R;
+    const double *loglh = col(cl, 0, R - 5), *old = col(cl, 0, R - 3), *w = col(cl, 0, R - 1);
+    double acc[2 * K];
+#pragma unroll
+    for (int k = 0; k < 2 * K; ++k) acc[k] = 0.0;
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nb1, blockIdx.x % g.nb1, g.per1, beg, end);
+    for (long long i = beg + threadIdx.x; i < end; i += T1) {
+        const double l = loglh[i] - esh, o = old[i], wi = w[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k >= nv) continue;
+            const double phi = S.cand[k];
+            const double v = wi * exp((phi_prev - phi) * o + (phi - phi_prev) * l);      // always the prior_weight = 0 formula (quirk Q4)
+            acc[k] += v;
+            acc[K + k] += v * v;
+        }
+    }
+    const double total = block_reduce_nw<2 * K, T1 / 64>(acc, red);
+    if (threadIdx.x < 2 * K) rows_out[(long long)blockIdx.x * (2 * K) + threadIdx.x] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status.solver_passes += 1;
+}
+
+// decision of the last enqueued pass: ϕ_n certified -> Begin2 becomes final; otherwise the stage stalls (code 2) until the host
+// enqueues more passes (which continue the same search from solver copy (P-1)&1 and its rows).  1 block.
+__global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, int n, int P, Rows2 prev, const double *sched) {
+    __shared__ double s_vt[V2_MAXV * 2 * KC * 2], s_tot[2 * KC], s_srt[KC];
+    __shared__ Solver S;
+    __shared__ int s_flag;
+    if (ctl->bg.stage != n || ctl->bg.final) return;
+    solver_prologue2(st, sched, prev, P, &S, s_vt, s_tot, s_srt, 1, &s_flag, T1);
+    if (threadIdx.x != 0) return;
+    if (s_flag < 0) { ctl->status.err = s_flag; ctl->status.stage = n; ctl->status.code = 9; return; }
+    if (s_flag == 2 || S.mode != MODE_FINAL) { ctl->status.stage = n; ctl->status.code = 2; return; }
+    ctl->bg.phi_n = S.phi_n; ctl->bg.j = S.j; ctl->bg.phi_prop = S.phi_prop; ctl->bg.spec = 0;
+    __threadfence();
+    ctl->bg.final = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ K1: correction + moments
+// src/smc_main.jl:401-420 (incremental weights, update_weights!) fused with the sums of weighted_mean / weighted_cov
+// (particle.jl:481-483, 526-529) of the corrected cloud, as k_correct_moments - but the unnormalised weights W̃ always go to the
+// scratch column `wt` (the cloud's weight column is rewritten by K2 / the gather once the stage is decided), the block's ΣW̃
+// also goes to csum[b] (chunk sums of the selection scan), and the stage-begin logic runs in the prologue (begin_done = 0).
+template <int D>
+__global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int begin_done, int spec_expected,
+                                                 Rows2 mrows, const double *sched, Records rec, double *rows_cm, double *csum, double *wt,
+                                                 double *hist_w, long long hist_ld) {
+    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
+    constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
+    __shared__ double red[NW * 64];
+    __shared__ Post2 s_po;
+    __shared__ Begin2 s_bg;
+    __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[RMUT], s_sw[64];
+    __shared__ int s_act;
+    const double pw = st->rp.pw, logp_old = st->rp.logp_old;
+    const bool hist = st->rp.store_history && hist_w != nullptr;
+    if (!begin_done) {
+        const int act = begin2_block<T1>(n, st, ctl, mrows, spec_expected, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act);
+        if (act != 0) return;
+    } else {
+        constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double);
+        if (threadIdx.x < NWB) reinterpret_cast<double *>(&s_bg)[threadIdx.x] = reinterpret_cast<const double *>(&ctl->bg)[threadIdx.x];
+        if (threadIdx.x < NWP) reinterpret_cast<double *>(&s_po)[threadIdx.x] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[threadIdx.x];
+        __syncthreads();
+        if (s_bg.stage != n || !s_bg.final || s_po.stage != n - 1) return;
+    }
+    const double phi = s_bg.phi_n, phi_prev = s_bg.phi_prev, esh = pw == 0.0 ? s_bg.e_shift : 0.0;
+    double sh[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) sh[a] = s_po.shift[a];
+    const int R = cl.R;
+    const double *loglh = col(cl, 0, R - 5), *old = col(cl, 0, R - 3), *w = col(cl, 0, R - 1);
+    double acc[NCH * 64];
+#pragma unroll
+    for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nb1, blockIdx.x % g.nb1, g.per1, beg, end);
+    const double unshift = hist ? exp((phi - phi_prev) * esh) : 1.0;                      // history keeps the true exp(δ e)
+    for (long long i = beg + threadIdx.x; i < end; i += T1) {
+        const double l = loglh[i] - esh, o = old[i], wi = w[i];
+        double xx[DA];
+        xx[0] = 1.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) xx[a + 1] = col(cl, 0, a)[i] - sh[a];
+        double inc;
+        if (pw == 0.0) inc = exp((phi_prev - phi) * o + (phi - phi_prev) * l);
+        else if (pw == 1.0) inc = exp((phi - phi_prev) * l);
+        else inc = exp((phi_prev - phi) * log(exp(o - logp_old + log(1.0 - pw)) + pw) + (phi - phi_prev) * l);
+        const double v = wi * inc;
+        acc[0] += v;
+        acc[1] += v * v;
+        wt[i] = v;
+        if (hist) hist_w[(long long)(n - 1) * hist_ld + i] = inc * unshift;
+        int q = 2;
+#pragma unroll
+        for (int a = 0; a < DA; ++a) {
+            const double wx = v * xx[a];
+#pragma unroll
+            for (int b = a; b < DA; ++b) { acc[q] += wx * xx[b]; ++q; }
+        }
+    }
+    double *out = rows_cm + (long long)blockIdx.x * NPF;
+    constexpr int REM = NPF - 64 * (NCH - 1);
+    constexpr int REMP = REM <= 1 ? 1 : REM <= 2 ? 2 : REM <= 4 ? 4 : REM <= 8 ? 8 : REM <= 16 ? 16 : REM <= 32 ? 32 : 64;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch < NCH - 1 || REMP == 64) {
+            double a64[64];
+#pragma unroll
+            for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
+            const double t64 = block_reduce_nw<64, NW>(a64, red);
+            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = t64;
+            if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = t64;
+        } else {
+            double ar[REMP];
+#pragma unroll
+            for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
+            const double tr = block_reduce_nw<REMP, NW>(ar, red);
+            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = tr;
+            if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = tr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ post-correction decision
+// ESS of the corrected weights, verification of a predicted ϕ_n (see k_prepare_mutation), selection decision
+// (src/smc_main.jl:427-435).  Same inputs -> same result in every block / kernel that calls it.
+// 0: go, no resampling; 1: go, resample; 4: prediction not verified; < 0: error code
+__device__ inline int decide2(const Begin2 &bg, const RunParams &rp, double s1, double s2, double *ess_out) {
+    const double ess = s1 * s1 / s2;
+    *ess_out = ess;
+    if (bg.spec) {
+        bool verified;
+        if (bg.phi_n < 1.0) verified = fabs(ess - bg.ess_bar) <= fabs(bg.gprime) * fmax(rp.phi_rtol, SPEC_VERIFY_RTOL) * bg.phi_n;
+        else verified = ess >= bg.ess_bar * (1.0 - 1e-13);
+        if (!verified) return 4;
+    }
+    if (isnan(ess)) return SMCMI_ERR_NAN_ESS;                      // check_nan_ess, helpers.jl:270-305
+    return ess < rp.threshold ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ selection: scan
+// Inclusive scan of W̃ / ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) over the WHOLE cloud (sharded runs hand in the
+// all-gathered W̃ and chunk sums) in the correction's chunks: one block per chunk, chunk offsets = running sum of the chunk sums
+// in chunk order.  Does nothing unless this stage resamples (the decision is re-derived from the correction rows).
+__global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
+                                              const double *csum_full, double *cum) {
+    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2], scratch[TB], s_off[4 * TB];
+    __shared__ Begin2 s_bg;
+    constexpr int NWB = sizeof(Begin2) / sizeof(double);
+    if (threadIdx.x < NWB) reinterpret_cast<double *>(&s_bg)[threadIdx.x] = reinterpret_cast<const double *>(&ctl->bg)[threadIdx.x];
+    __syncthreads();
+    if (s_bg.stage != n || !s_bg.final || ctl->ps[(n - 1) & 1].stage != n - 1) return;
+    reduce_rows<2, 8, TB>(cmrows, s_vt, s_tot);
+    double ess;
+    if (decide2(s_bg, st->rp, s_tot[0], s_tot[1], &ess) != 1) return;
+    const int nchunks = g.V * g.nb1, t = threadIdx.x;
+    // exclusive prefix of the chunk sums in chunk order: 256 threads x 4 chunks each, then a sequential carry (<= 1024 chunks)
+    double loc[4], run = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; loc[q] = run; run += (b < nchunks) ? csum_full[b] : 0.0; }
+    scratch[t] = run;
+    __syncthreads();
+    if (t == 0) { double carry = 0.0; for (int q = 0; q < TB; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_off[t * 4 + q] = scratch[t] + loc[q];
+    __syncthreads();
+    const double total = s_tot[0];
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int v = c / g.nb1, r = c % g.nb1;
+        const long long v_beg = (long long)v * g.nv, v_end = v_beg + g.nv;
+        long long beg = v_beg + (long long)r * g.per1, end = beg + g.per1 < v_end ? beg + g.per1 : v_end;
+        if (beg > v_end) beg = v_end;
+        constexpr int IPT = 4;
+        double carry = s_off[c];
+        for (long long base = beg; base < end; base += (long long)TB * IPT) {
+            const long long i0 = base + (long long)t * IPT;
+            double vv[IPT], rr = 0.0;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) { vv[k] = (i0 + k < end) ? wt_full[i0 + k] : 0.0; rr += vv[k]; vv[k] = rr; }
+            scratch[t] = rr;
+            __syncthreads();
+            for (int off = 1; off < TB; off <<= 1) {
+                const double add = (t >= off) ? scratch[t - off] : 0.0;
+                __syncthreads();
+                scratch[t] += add;
+                __syncthreads();
+            }
+            const double excl = (t > 0 ? scratch[t - 1] : 0.0) + carry;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k)
+                if (i0 + k < end) cum[i0 + k] = (excl + vv[k]) / total;
+            carry += scratch[TB - 1];
+            __syncthreads();
+        }
+    }
+}
+
+// Systematic resampling, sharded: ancestor (global row) of the first and of the last output slot of every handle r - the rows a
+// handle must receive form the contiguous range [out[2r], out[2r+1]].  out[0] = -1 when this stage does not resample.
+__global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows, const double *cum, long long N, long long n_local, int world,
+                              unsigned long long seed, long long *out) {
+    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
+    const int r = threadIdx.x;
+    const Begin2 bg = ctl->bg;
+    bool go = bg.stage == n && bg.final && ctl->ps[(n - 1) & 1].stage == n - 1;
+    reduce_rows<2, 8, 64>(cmrows, s_vt, s_tot);
+    double ess;
+    if (go) go = decide2(bg, st->rp, s_tot[0], s_tot[1], &ess) == 1;
+    if (!go) { if (r == 0) out[0] = -1; return; }
+    if (r >= world) return;
+    double ua, ub;
+    uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
+    for (int e = 0; e < 2; ++e) {
+        const long long slot = e == 0 ? (long long)r * n_local : (long long)(r + 1) * n_local - 1;
+        const double thr = ((double)slot + ua) / (double)N;
+        long long lo = 0, hi = N;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (cum[mid] > thr) hi = mid; else lo = mid + 1;
+        }
+        out[2 * r + e] = lo < N ? lo : N - 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ selection: gather + moments
+// Output slot k: ancestor = first j with cum[j] > threshold (src/resample.jl:33-70; fall-through clamps to the last index), its
+// R-1 columns are copied into cloud buffer 1 (K2 reads the resampled cloud from there and writes buffer 0), and the moments of
+// the resampled cloud (all weights 1; smc_main.jl:440-446, 457-465) are accumulated on the way -> one row of pair sums per block.
+// full: rows come from the per-handle [R][full_shard_n] shard buffers of an exchange (sharded runs), else from buffer 0.
+template <int D>
+__global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *cum,
+                                                int method, unsigned long long seed, long long gid0, long long *anc, const double *full,
+                                                long long full_shard_n, double *rows_gm) {
+    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NCH = (NP + 63) / 64;
+    __shared__ double red[(TB / 64) * 64];
+    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
+    __shared__ Begin2 s_bg;
+    __shared__ double s_sh[D];
+    constexpr int NWB = sizeof(Begin2) / sizeof(double);
+    if (threadIdx.x < NWB) reinterpret_cast<double *>(&s_bg)[threadIdx.x] = reinterpret_cast<const double *>(&ctl->bg)[threadIdx.x];
+    const Post2 &po = ctl->ps[(n - 1) & 1];
+    const int pstage = po.stage;
+    if (threadIdx.x < D) s_sh[threadIdx.x] = po.shift[threadIdx.x];
+    __syncthreads();
+    if (s_bg.stage != n || !s_bg.final || pstage != n - 1) return;
+    reduce_rows<2, 8, TB>(cmrows, s_vt, s_tot);
+    double ess;
+    if (decide2(s_bg, st->rp, s_tot[0], s_tot[1], &ess) != 1) return;
+    const int R = cl.R;
+    const long long N = g.N;
+    double acc[NCH * 64];
+#pragma unroll
+    for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nbg, blockIdx.x % g.nbg, g.perg, beg, end);
+    double u_sys = 0.0, ub;
+    if (method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub);
+    for (long long k = beg + threadIdx.x; k < end; k += TB) {
+        const long long slot = gid0 + k;
+        double ua;
+        if (method == SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, (unsigned long long)slot, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
+        else ua = ((double)slot + u_sys) / (double)N;                       // (i - 1 + offset) / n_parts
+        long long lo = 0, hi = N;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (cum[mid] > ua) hi = mid; else lo = mid + 1;
+        }
+        const long long a = lo < N ? lo : N - 1;
+        if (anc) anc[k] = a;
+        const double *from = cl.buf[0];
+        long long ldf = cl.n, a_row = a;
+        if (full) {
+            from = full + (a / full_shard_n) * (long long)R * full_shard_n;
+            ldf = full_shard_n;
+            a_row = a % full_shard_n;
+        }
+        double row[D + 3];
+#pragma unroll
+        for (int q = 0; q < D + 3; ++q) row[q] = from[(long long)q * ldf + a_row];
+#pragma unroll
+        for (int q = 0; q < D + 3; ++q) col(cl, 1, q)[k] = row[q];
+        col(cl, 1, D + 3)[k] = from[(long long)(D + 3) * ldf + a_row];
+        double xx[DA];
+        xx[0] = 1.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - s_sh[q];
+        int p = 0;
+#pragma unroll
+        for (int a2 = 0; a2 < DA; ++a2) {
+#pragma unroll
+            for (int b = a2; b < DA; ++b) { acc[p] += xx[a2] * xx[b]; ++p; }
+        }
+    }
+    double *out = rows_gm + (long long)blockIdx.x * NP;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double a64[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
+        const double tot = block_reduce_many<64>(a64, red);
+        if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NP) out[ch * 64 + threadIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K2: decision + proposal + mutation
+struct Mut2Args {
+    unsigned long long seed;
+    long long gid0;
+    int n;                     // stage index of this launch
+    int sel_enqueued;          // k2_scan / k2_gather were enqueued in front of this launch
+    int adaptive;              // leave energy power sums for the next stage's ϕ predictor
+    Rows2 cmrows, gmrows;
+    const double *wt;          // unnormalised weights W̃ of the correction
+    double *rows_mut;          // [blocks][RMUT]
+    double *hist_W;
+    long long hist_ld;
+    Records rec;
+    int debug;
+};
+
+// Post-correction bookkeeping of stage n (src/smc_main.jl:427-455; see post_write in kernels.hpp); one thread per block
+// computes it into LDS, block 0 stores it and the per-stage records.
+__device__ inline void post2(int n, const Begin2 &bg, const Post2 &po, const RunParams &rp, double s1, double s2, double ess, int rs, Post2 *out) {
+    const double a = bg.accept, tg = rp.target;
+    Post2 p = po;
+    p.stage = n; p.j = bg.j; p.resampled_last = rs; p.do_resample = rs; p.resamples = po.resamples + rs; p.fold_valid = 1;
+    p.phi_n = bg.phi_n; p.phi_prop = bg.phi_prop; p.ess = ess; p.sumw = s1; p.sumw2 = s2;
+    const double dlz = (bg.phi_n - bg.phi_prev) * (rp.pw == 0.0 ? bg.e_shift : 0.0);      // log of the common factor the shifted weights left out
+    p.logz = po.logz + (log(s1 / (double)rp.n_parts) + dlz);
+    p.c = po.c * (0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))));
+    p.accept = a; p.e_center = bg.e_center; p.e_shift = bg.e_shift;
+    *out = p;
+}
+
+// The proposal of stage n from the moment totals T (augmented pair sums about `shift`, T[0] = Σ weights): θ̄, R, free subset +
+// symmetrisation (smc_main.jl:457-465), random blocks (helpers.jl:215-260, Fisher-Yates on Philox), per block c²Σ_b = L Lᵀ
+// (mutation.jl:81, once per stage) - the arithmetic of k_prepare_mutation, by a block of T threads, results in LDS only.
+struct Prop2 {                 // LDS pointers (k2_mutate carves them out of its dynamic LDS)
+    double *covl, *sig_f, *A, *Lw, *mean, *mu_f;
+    int *bfree, *bptr, *fi, *fi_j;
+    double *Lraw, *logdet, *mub, *sdd, *sdn;
+    int *ball, *loff;
+};
+__device__ inline bool proposal2(const double *T, const double *shift, const ModelDev *md, int d, int nf, int nb, double c, unsigned long long seed,
+                                 unsigned stage, const Prop2 &P, int *s_fail, int TT) {
+    const int t = threadIdx.x, da = d + 1;
+    const double sw = T[0];
+    if (t == 0) *s_fail = 0;
+    if (t < nf) P.fi[t] = md->free_inds[t];
+    for (int e = t; e < d * d; e += TT) {
+        int a = e / d, b = e % d;
+        if (a > b) { const int tmp = a; a = b; b = tmp; }
+        const int ra = a + 1, rb = b + 1;
+        const int p = ra * da - ra * (ra - 1) / 2 + (rb - ra);
+        P.covl[e] = T[p] / sw - (T[a + 1] / sw) * (T[b + 1] / sw);
+    }
+    for (int a = t; a < d; a += TT) P.mean[a] = shift[a] + T[a + 1] / sw;
+    if (t >= 64 && t < 128) {            // wave 1 shuffles while the others finish the covariance
+        const int i0 = t - 64;
+        if (i0 < nf) {
+            P.bfree[i0] = i0;
+            int jx = 0;
+            if (i0 >= 1) {
+                double ua, ub;
+                uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i0, 0), ua, ub);
+                jx = (int)(ua * (double)(i0 + 1));
+                if (jx > i0) jx = i0;
+            }
+            P.fi_j[i0] = jx;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (t == 64) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            for (int i = nf - 1; i >= 1; --i) {
+                const int jx = P.fi_j[i];
+                const int tmp = P.bfree[i]; P.bfree[i] = P.bfree[jx]; P.bfree[jx] = tmp;
+            }
+            const int sub = (nf + nb - 1) / nb;
+            for (int b = 0; b < nb; ++b) P.bptr[b] = b * sub;
+            P.bptr[nb] = nf;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < nf * nf; e += TT) {
+        const int a = P.fi[e / nf], b = P.fi[e % nf];
+        P.sig_f[e] = (P.covl[a * d + b] + P.covl[b * d + a]) / 2.0;
+    }
+    for (int a = t; a < nf; a += TT) P.mu_f[a] = P.mean[P.fi[a]];
+    __syncthreads();
+    for (int i = t; i < nf; i += TT) {
+        const int f = P.bfree[i];
+        P.ball[i] = P.fi[f];
+        P.mub[i] = P.mu_f[f];
+        P.sdd[i] = sqrt(c * c * P.sig_f[f * nf + f]);
+        P.sdn[i] = sqrt(P.sig_f[f * nf + f]);
+    }
+    int off = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int p0 = P.bptr[b], db = P.bptr[b + 1] - p0;
+        for (int e = t; e < db * db; e += TT) {
+            P.A[e] = c * c * P.sig_f[P.bfree[p0 + e / db] * nf + P.bfree[p0 + e % db]];
+            P.Lw[e] = 0.0;
+        }
+        __syncthreads();
+        if (t < 64) {
+            double r[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) r[k] = (t < db && k < db) ? P.A[t * db + k] : 0.0;
+            const bool ok = chol_rows_in_regs<12>(r, db, t);
+            if (!ok && t == 0) *s_fail = 1;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (t < db && k <= t) P.Lw[t * db + k] = r[k];
+        }
+        __syncthreads();
+        if (*s_fail) break;
+        for (int e = t; e < db * db; e += TT) P.Lraw[off + e] = P.Lw[e];
+        if (t < 64) {
+            const double lg = (t < db) ? log(P.Lw[t * db + t]) : 0.0;
+            double ld = 0.0;
+            for (int i = 0; i < db; ++i) ld += __shfl(lg, i, 64);
+            if (t == 0) { P.logdet[b] = 2.0 * ld; P.loff[b] = off; }
+        }
+        off += db * db;
+        __syncthreads();
+    }
+    return *s_fail == 0;
+}
+
+constexpr size_t k2_prologue_doubles(int D) {
+    // s_vt (V2_MAXV * NPF) + tot (NPF + 2) + covl, sig_f, A, Lw (4 D²) + mean, mu_f (2 D) + ints (4 D + 8 -> doubles)
+    return (size_t)V2_MAXV * ((D + 1) * (D + 2) / 2 + 2) + (size_t)((D + 1) * (D + 2) / 2 + 4) + 4 * D * D + 2 * D + (4 * D + 8) / 2 + 4;
+}
+
+// LDS arrays of k2_mutate (the mutation's, as in k_mutate_reg, then the prologue's scratch)
+template <int D>
+struct Mut2Lds {
+    static constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
+    double *Ls, *mu_s, *sdd_s, *sdn_s, *red, *m_lo, *m_hi, *m_a, *m_b, *m_k, *l_par, *l_dat, *Lraw, *logdet_s, *mub_raw, *sdd_raw, *sdn_raw;
+    int *ball_s, *m_fix, *m_fam, *bptr_s, *loff_s, *ball_raw;
+    double *s_vt, *s_tot, *covl, *sig_f, *Aw, *Lw, *mean_s, *mu_f;
+    int *bfree, *fi, *fi_j;
+    __device__ explicit Mut2Lds(double *sm) {
+        Ls = sm; mu_s = Ls + D * D; sdd_s = mu_s + D; sdn_s = sdd_s + D; red = sdn_s + D;
+        m_lo = red + 4; m_hi = m_lo + D; m_a = m_hi + D; m_b = m_a + D; m_k = m_b + D;
+        l_par = m_k + D; l_dat = l_par + 2 * LIK_PAR_MAX; Lraw = l_dat + LIK_LDS_CAP; logdet_s = Lraw + D * D;
+        mub_raw = logdet_s + D; sdd_raw = mub_raw + D; sdn_raw = sdd_raw + D;
+        ball_s = (int *)(sdn_raw + D); m_fix = ball_s + D + (D & 1); m_fam = m_fix + D;
+        bptr_s = m_fam + D; loff_s = bptr_s + D + 1; ball_raw = loff_s + D;
+        s_vt = (double *)(((uintptr_t)(ball_raw + D + 1) + 15) & ~(uintptr_t)15);
+        s_tot = s_vt + V2_MAXV * NPF;
+        covl = s_tot + NPF + 2; sig_f = covl + D * D; Aw = sig_f + D * D; Lw = Aw + D * D;
+        mean_s = Lw + D * D; mu_f = mean_s + D;
+        bfree = (int *)(mu_f + D); fi = bfree + D; fi_j = fi + D;
+    }
+};
+constexpr size_t k2_lds_bytes(int D) {
+    const size_t np = (size_t)(D + 1) * (D + 2) / 2, npf = np + 2;
+    return (size_t)(2 * D * D + 12 * D + 4 + 2 * LIK_PAR_MAX + LIK_LDS_CAP) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32 +
+           (V2_MAXV * npf + npf + 2 + 4 * D * D + 2 * D) * sizeof(double) + (size_t)(3 * D + 4) * sizeof(int) + 32;
+}
+
+struct Mut2Stage {             // what the prologue hands to the mutation body (LDS)
+    Begin2 bg;
+    Post2 po, ps;
+    int go, rs, fail;
+};
+
+// Prologue of K2, every block: state + model constants into LDS, totals of the correction rows, decision, bookkeeping, proposal.
+// Returns false when the block must not mutate (stale launch, stall, error).
+template <int D>
+__device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, const Mut2Args &ma, const Mut2Lds<D> &L, Mut2Stage *S, int nb, int nf) {
+    constexpr int NP = Mut2Lds<D>::NP, NPF = Mut2Lds<D>::NPF, T = 256;
+    const int tid = threadIdx.x, n = ma.n;
+    constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double);
+    if (tid < NWB) reinterpret_cast<double *>(&S->bg)[tid] = reinterpret_cast<const double *>(&ctl->bg)[tid];
+    if (tid < NWP) reinterpret_cast<double *>(&S->po)[tid] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[tid];
+    for (int k = tid; k < D; k += T) {
+        L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
+        L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
+    }
+    for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
+    __syncthreads();
+    if (S->bg.stage != n || !S->bg.final || S->po.stage != n - 1) return false;
+    reduce_rows<NPF, 1, T>(ma.cmrows, L.s_vt, L.s_tot);
+    if (tid == 0) {
+        double ess;
+        const int dec = decide2(S->bg, st->rp, L.s_tot[0], L.s_tot[1], &ess);
+        int go = 1;
+        if (dec == 4) { go = 0; if (blockIdx.x == 0) { ctl->status.stage = n; ctl->status.code = 4; } }
+        else if (dec < 0) {
+            go = 0;
+            if (blockIdx.x == 0) {
+                ma.rec.phi[n - 1] = S->bg.phi_n; ma.rec.ess[n - 1] = ess;
+                ctl->status.err = dec; ctl->status.stage = n; ctl->status.code = 9;
+            }
+        } else if (dec == 1 && !ma.sel_enqueued) { go = 0; if (blockIdx.x == 0) { ctl->status.stage = n; ctl->status.code = 3; } }
+        if (go) post2(n, S->bg, S->po, st->rp, L.s_tot[0], L.s_tot[1], ess, dec == 1 ? 1 : 0, &S->ps);
+        S->go = go; S->rs = dec == 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!S->go) return false;
+    // moments of the resampled cloud (k2_gather's rows) replace the correction's on resample stages
+    if (S->rs) reduce_rows<NP, 1, T>(ma.gmrows, L.s_vt, L.s_tot + 2);
+    Prop2 P{L.covl, L.sig_f, L.Aw, L.Lw, L.mean_s, L.mu_f, L.bfree, L.bptr_s, L.fi, L.fi_j, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw,
+            L.ball_raw, L.loff_s};
+    if (!proposal2(L.s_tot + 2, S->po.shift, md, D, nf, nb, S->ps.c, ma.seed, (unsigned)n, P, &S->fail, T)) {
+        // PosDefException aborts the run (mutation.jl:81)
+        if (blockIdx.x == 0 && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
+        return false;
+    }
+    if (blockIdx.x == 0) {
+        if (tid < D) { S->ps.shift[tid] = L.mean_s[tid]; st->mean[tid] = L.mean_s[tid]; }     // st->mean / cov: diagnostics, stand-alone readers
+        for (int e = tid; e < D * D; e += T) st->cov[e] = L.covl[e];
+        __syncthreads();
+        if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&S->ps)[tid];
+        if (tid == 0) {
+            ma.rec.phi[n - 1] = S->ps.phi_n; ma.rec.ess[n - 1] = S->ps.ess; ma.rec.resampled[n - 1] = S->rs; ma.rec.c[n - 1] = S->ps.c;
+        }
+    }
+    return true;
+}
+
+// K2.  The mutation body is k_mutate_reg's (src/mutation.jl:56-138, helpers.jl:87-164; same arithmetic in the same order), fed
+// from LDS by the prologue instead of from DevState; it reads the particle from buffer 0 (buffer 1 on resample stages: the
+// gathered cloud) and always writes buffer 0, applies normalize_weights! (particle.jl:362-366: W̃ N / ΣW̃, two roundings; 1 after a
+// resample) to the weight column and its history, and leaves one row of RMUT sums for the next stage's begin.
+template <int D, bool ALPHA1>
+__global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma,
+                                                                int nb, int nf) {
+#pragma clang fp contract(fast)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ Mut2Stage S;
+    const Mut2Lds<D> L(sm);
+    const int T = 256, tid = threadIdx.x, n = ma.n;
+    const int n_steps = st->rp.n_mh_steps;
+    const double c_alpha = st->rp.alpha, nrm_N = (double)st->rp.n_parts;
+    const int nrm_hist = st->rp.store_history;
+    const LikDev ld0 = md->lik[0], ld1 = md->lik[1];
+    const int has_other = md->has_other_priors;
+    if (!k2_prologue<D>(st, ctl, md, ma, L, &S, nb, nf)) return;
+    const int rs = S.rs, src = rs ? 1 : 0;
+    const double phi_n = S.bg.phi_n, e_center = S.bg.e_center, nrm_sumw = L.s_tot[0];
+    const unsigned stage = (unsigned)n;
+    double *Ls = L.Ls, *mu_s = L.mu_s, *sdd_s = L.sdd_s, *sdn_s = L.sdn_s, *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
+    double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
+    int *ball_s = L.ball_s, *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
+    // ---- the particle and the likelihood data
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, 256, beg, end);
+    const long long i = beg + tid;
+    const bool live = i < end;
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = 0.0;
+    double w_part = 0.0;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[i];
+        like = col(cl, src, D)[i]; lprior = col(cl, src, D + 1)[i]; like_prev = col(cl, src, D + 2)[i];
+        w_part = rs ? 1.0 : (ma.wt[i] * nrm_N) / nrm_sumw;                  // W·N then /ΣW̃, two roundings like the reference
+        col(cl, 0, D + 4)[i] = w_part;
+        if (ma.hist_W && nrm_hist) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = w_part;
+    }
+    ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
+    LikView lv[2];
+    {
+        int used = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const LikDev &ld = q == 0 ? ld0 : ld1;
+            const long long nd = ld.rows * ld.cols, na = ld.aux_rows * ld.aux_cols;
+            const bool fits = ld.family >= 0 && used + nd + na <= LIK_LDS_CAP;
+            if (fits) {
+                for (long long k = tid; k < nd; k += T) l_dat[used + k] = ld.data[k];
+                for (long long k = tid; k < na; k += T) l_dat[used + nd + k] = ld.aux[k];
+            }
+            lv[q] = LikView{ld.family, L.l_par + q * LIK_PAR_MAX, ld.c0, fits ? l_dat + used : ld.data, ld.rows, ld.cols,
+                            fits ? l_dat + used + nd : ld.aux, ld.aux_rows, ld.aux_cols};
+            if (fits) used += (int)(nd + na);
+        }
+    }
+    auto XN = [&](int k) { return x[k]; };
+    for (int step = 0; step < n_steps; ++step) {
+        for (int b = 0; b < nb; ++b) {
+            if (nb > 1 || step == 0) __syncthreads();   // prologue's arrays (first pass) / previous block's readers (later passes)
+            const int p0 = bptr_s[b], db = bptr_s[b + 1] - p0;
+            if (nb > 1 || step == 0) {              // expand this block's constants to the padded D x D form
+                const double *Lb = Lraw + loff_s[b];
+                if constexpr (ALPHA1) {
+                    for (int e = tid; e < D * D; e += T) Ls[e] = 0.0;
+                    __syncthreads();
+                    for (int e = tid; e < db * db; e += T) {
+                        const int r = e / db, cidx = e % db;
+                        if (cidx <= r) Ls[cidx * D + ball_raw[p0 + r]] = Lb[r * db + cidx];   // transposed: Ls[e][k] = M[k][e]
+                    }
+                } else
+                for (int e = tid; e < D * D; e += T) {
+                    const int r = e / D, cidx = e % D;
+                    Ls[e] = (r < db && cidx < db) ? Lb[r * db + cidx] : (r == cidx ? 1.0 : 0.0);
+                }
+                for (int e = tid; e < D; e += T) {
+                    const bool in = e < db;
+                    mu_s[e] = in ? mub_raw[p0 + e] : 0.0;
+                    sdd_s[e] = in ? sdd_raw[p0 + e] : 0.0;
+                    sdn_s[e] = in ? sdn_raw[p0 + e] : 1.0;
+                    ball_s[e] = in ? ball_raw[p0 + e] : -1;
+                }
+                __syncthreads();
+            }
+            if (!live) continue;
+            const unsigned t = (unsigned)(step * nb + b);
+            double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
+            double uc, unext;
+            double z[D], sub[D], dr[D];
+            if (t == 0) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
+            else uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
+            // ---- mvnormal_mixture_draw (src/helpers.jl:87-100)
+            uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
+            {
+                constexpr int NP2 = (D + 1) / 2;
+                constexpr int GRPB = 3;
+                double ua[NP2], ub[NP2], rr[NP2], sn[NP2], cs[NP2];
+#pragma unroll
+                for (int q = 0; q < NP2; ++q) {
+                    ua[q] = 0.5; ub[q] = 0.0;
+                    if (2 * q < db) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua[q], ub[q]);
+                }
+#pragma unroll
+                for (int g0 = 0; g0 < NP2; g0 += GRPB) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = log(ua[q]);
+#pragma unroll
+                    for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = sqrt(-2.0 * rr[q]);
+#pragma unroll
+                    for (int q = g0; q < g0 + GRPB && q < NP2; ++q) sincospi(2.0 * ub[q], &sn[q], &cs[q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NP2; ++q) {
+                    if (ma.debug & 1) { rr[q] = 1.0; cs[q] = uc - 0.5; sn[q] = unext - 0.5; }
+                    z[2 * q] = (2 * q < db) ? rr[q] * cs[q] : 0.0;
+                    if (2 * q + 1 < D) z[2 * q + 1] = (2 * q + 1 < db) ? rr[q] * sn[q] : 0.0;
+                }
+#pragma unroll
+                for (int e = 0; e < D; ++e) asm volatile("" : "+v"(z[e]));
+            }
+            double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
+            double q0 = 0.0, q1 = 0.0;
+            double xo[D];
+            if constexpr (ALPHA1) {
+                double zz2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
+                q1 = (-((double)db * LOG2PI + logdet_s[b] + zz2) / 2.0 < -745.1332191019412) ? __builtin_nan("") : 0.0;
+                double sacc[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { xo[k] = x[k]; sacc[k] = 0.0; }
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc[k] += Ls[e * D + k] * z[e];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) asm volatile("" : "+v"(sacc[k]));
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] = xo[k] + sacc[k];
+                if (ma.debug & 2) { prior_new = lprior - 0.1 * zz2; like_new = like - 0.2; like_old_data = 0.0; }
+                else if (in_bounds_s<D>(mv, XN)) {
+                    prior_new = logprior_s<D>(mv, XN, has_other);
+                    like_new = loglik_s<D>(lv[0], XN);
+                    if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
+                    like_old_data = (lv[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik_s<D>(lv[1], XN);
+                }
+            } else {
+            int bal[D];
+#pragma unroll
+            for (int e = 0; e < D; ++e) bal[e] = ball_s[e];
+#pragma unroll
+            for (int e = 0; e < D; ++e) {
+                double sv = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) sv = (bal[e] == k) ? x[k] : sv;
+                sub[e] = sv;
+            }
+            const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
+            const bool diag_draw = comp == 1 || (ma.debug & 4);
+            const double cst = (double)db * LOG2PI + logdet_s[b];
+            double zz2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
+            {
+                double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
+                {
+                    double v1[D];
+#pragma unroll
+                    for (int e = 0; e < D; ++e) {       // sweep A: the draw and L⁻¹(θ_b - ϑ_b)
+                        double Lr[D];
+#pragma unroll
+                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
+                        double sd = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= e; ++k) sd += Lr[k] * z[k];
+                        dr[e] = diag_draw ? sub[e] + sdd_s[e] * z[e] : ((comp == 0) ? sub[e] : mu_s[e]) + sd;
+                        double s1 = sub[e] - dr[e];
+#pragma unroll
+                        for (int k = 0; k < e; ++k) s1 -= Lr[k] * v1[k];
+                        v1[e] = s1 / Lr[e];
+                        quad += v1[e] * v1[e];
+                        asm volatile("" : "+v"(v1[e]), "+v"(dr[e]));
+                    }
+                }
+                {
+                    double v2[D], v3[D];
+#pragma unroll
+                    for (int e = 0; e < D; ++e) {       // sweep B: L⁻¹(θ_b - θ̄_b) and L⁻¹(ϑ_b - θ̄_b)
+                        double Lr[D];
+#pragma unroll
+                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
+                        double s2 = sub[e] - mu_s[e], s3 = dr[e] - mu_s[e];
+#pragma unroll
+                        for (int k = 0; k < e; ++k) { s2 -= Lr[k] * v2[k]; s3 -= Lr[k] * v3[k]; }
+                        v2[e] = s2 / Lr[e]; v3[e] = s3 / Lr[e];
+                        quad_s += v2[e] * v2[e]; quad_d += v3[e] * v3[e];
+                        asm volatile("" : "+v"(v2[e]), "+v"(v3[e]));
+                    }
+                }
+                q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;
+                double ind_pdf = 1.0;
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+                    if (e < db) {
+                        const double sii = sdn_s[e];
+                        const double zz = (sub[e] - dr[e]) / sii;
+                        ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * zz * zz);
+                    }
+                }
+                q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+                q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+                q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
+                q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
+                q0 = log(q0);
+                q1 = log(q1);
+                if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) xo[k] = x[k];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+#pragma unroll
+                for (int e = 0; e < D; ++e) x[k] = (bal[e] == k) ? dr[e] : x[k];
+            }
+            if (ma.debug & 2) { prior_new = lprior - 0.1 * zz2; like_new = like - 0.2; like_old_data = 0.0; }
+            else if (in_bounds_s<D>(mv, XN)) {
+                prior_new = logprior_s<D>(mv, XN, has_other);
+                like_new = loglik_s<D>(lv[0], XN);
+                if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
+                like_old_data = (lv[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik_s<D>(lv[1], XN);
+            }
+            }
+            const double eta = exp(phi_n * (like_new - like) + (1.0 - phi_n) * (like_old_data - like_prev) +
+                                   (prior_new - lprior) + (q0 - q1));
+            if (step_prob < eta) {
+                like = like_new; lprior = prior_new; like_prev = like_old_data;
+                accept += (double)db;
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] = xo[k];
+            }
+        }
+    }
+    double acc_val = 0.0;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = x[k];
+        col(cl, 0, D)[i] = like;
+        col(cl, 0, D + 1)[i] = lprior;
+        col(cl, 0, D + 2)[i] = like_prev;
+        acc_val = accept / (double)nf;                      // quirk Q2: normalised by n_free only
+        col(cl, 0, D + 3)[i] = acc_val;
+    }
+    // ---- this block's row for the next stage's begin: energy power sums (adaptive schedules), Σ accept, energy maximum
+    __syncthreads();
+    double em = energy_or_ninf(like, like_prev, rs ? 1.0 : w_part, live);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
+    __shared__ double emx[4];
+    if ((tid & 63) == 0) emx[tid >> 6] = em;
+    double *row = ma.rows_mut + (long long)blockIdx.x * RMUT;
+    if (ma.adaptive) {
+        double es[ES];
+        energy_terms(es, w_part, like, like_prev, e_center, live, rs != 0);
+        es[EACC] = acc_val;
+        const double tot = block_reduce_es(es, l_dat, T / 64);       // likelihood data in LDS is dead by now
+        if (tid < ES) row[tid] = tot;
+    } else {
+        double a1[1] = {acc_val};
+        Butterfly<0, 32>::run(a1, tid & 63);
+        if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+        __syncthreads();
+        if (tid < ES) row[tid] = tid == EACC ? ((red[0] + red[1]) + (red[2] + red[3])) : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) row[RMAX_IDX] = fmax(fmax(emx[0], emx[1]), fmax(emx[2], emx[3]));
+}
+
+}  // namespace smcmi
