@@ -33,16 +33,64 @@ constexpr int TB = 256;  // threads per block for streaming kernels (4 wavefront
 // Butterfly "reduce-scatter" across the 64 lanes of a wavefront: M accumulators per lane go in, and lane l
 // comes out holding (in a[0]) the wavefront total of accumulator  l >> (6 - log2 M).  M-1 shuffles instead
 // of 6 M for M independent all-reduces.
+// Lane exchanges without the LDS crossbar (ds_bpermute: what __shfl_xor compiles to): gfx950's v_permlane32_swap /
+// v_permlane16_swap exchange register halves / odd-even 16-lane rows between two VGPRs in one instruction, DPP moves cover the
+// distances inside a row.  Same values, same order of the additions as the __shfl_xor formulation (bit-identical results).
+template <int CTRL, int BANK>
+__device__ inline double dpp_mov_f64(double old, double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+// value of lane (l ^ DIST), DIST = 1, 2, 4, 8
+template <int DIST>
+__device__ inline double fetch_xor(double x) {
+    static_assert(DIST == 1 || DIST == 2 || DIST == 4 || DIST == 8, "row-local distances only");
+    if constexpr (DIST == 1) return dpp_mov_f64<0xB1, 0xf>(x, x);            // quad_perm [1,0,3,2]
+    else if constexpr (DIST == 2) return dpp_mov_f64<0x4E, 0xf>(x, x);       // quad_perm [2,3,0,1]
+    else if constexpr (DIST == 8) return dpp_mov_f64<0x128, 0xf>(x, x);      // row_ror:8
+    else {
+        const double t = dpp_mov_f64<0x104, 0x5>(x, x);                      // banks 0, 2 (lane & 4 == 0) read lane + 4: row_shl:4
+        return dpp_mov_f64<0x114, 0xA>(t, x);                                // banks 1, 3 read lane - 4: row_shr:4
+    }
+}
+// a: the accumulator the lower lanes (lane & DIST == 0) keep, b: the one the upper lanes keep.  Returns, in every lane, its kept
+// accumulator plus the partner lane's copy of the same accumulator.  DIST = 16 or 32.
+template <int DIST>
+__device__ inline double swap_add(double a, double b) {
+    static_assert(DIST == 16 || DIST == 32, "row / half-wave exchanges only");
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (DIST == 32) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    } else {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+}
+template <int DIST>
+__device__ inline double xor_add(double x) {         // x + (x of lane ^ DIST)
+    if constexpr (DIST >= 16) return swap_add<DIST>(x, x);
+    else return x + fetch_xor<DIST>(x);
+}
+
 template <int HALF, int DIST>
 struct Butterfly {
     template <int M>
     __device__ static inline void run(double (&a)[M], int lane) {
-        const bool upper = (lane & DIST) != 0;
+        if constexpr (DIST >= 16) {
 #pragma unroll
-        for (int i = 0; i < HALF; ++i) {
-            const double keep = upper ? a[HALF + i] : a[i];
-            const double send = upper ? a[i] : a[HALF + i];
-            a[i] = keep + __shfl_xor(send, DIST, 64);
+            for (int i = 0; i < HALF; ++i) a[i] = swap_add<DIST>(a[i], a[HALF + i]);
+        } else {
+            const bool upper = (lane & DIST) != 0;
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+                const double keep = upper ? a[HALF + i] : a[i];
+                const double send = upper ? a[i] : a[HALF + i];
+                a[i] = keep + fetch_xor<DIST>(send);
+            }
         }
         Butterfly<HALF / 2, DIST / 2>::run(a, lane);
     }
@@ -50,9 +98,9 @@ struct Butterfly {
 template <int DIST>
 struct Butterfly<0, DIST> {
     template <int M>
-    __device__ static inline void run(double (&a)[M], int) {
-#pragma unroll
-        for (int dist = DIST; dist >= 1; dist >>= 1) a[0] += __shfl_xor(a[0], dist, 64);
+    __device__ static inline void run(double (&a)[M], int lane) {
+        a[0] = xor_add<DIST>(a[0]);
+        Butterfly<0, DIST / 2>::run(a, lane);
     }
 };
 template <>
@@ -249,11 +297,11 @@ __device__ constexpr double INV_FACTORIAL[32] = {1.00000000000000000e+00, 1.0000
 // of a) - forms its term c x^k by binary powering, and the four sums A = Σ term, x A' = Σ k term (same for B) come from 5-step
 // xor butterflies inside the 32-lane halves: a Newton step is ~40 dependent instructions.  Every lane returns the same x (NaN
 // when the model is unusable); *gprime = dESS/dδ at the root of the model.
-__device__ inline double predict_delta_wave(const double *es, bool uniform, double T, double *gprime) {
+__device__ inline double predict_delta_wave(const double *es, bool uniform, double T, double *gprime, double inv_pre = -1.0) {
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     const int lane = threadIdx.x & 63, grp = lane >> 5, k = lane & 31;
     const int KT = uniform ? EKU : (grp == 0 ? EKA : EKB);   // terms of this lane's polynomial
-    const double inv = INV_FACTORIAL[k];                  // 1 / k!
+    const double inv = inv_pre >= 0.0 ? inv_pre : INV_FACTORIAL[k];      // 1 / k! (callers on a latency budget load it ahead)
     double c = 0.0;
     if (k < KT) c = (grp == 0 ? es[k] : (uniform ? es[k] : es[EKA + k])) * inv;
     if (grp) c = ldexp(c, k);

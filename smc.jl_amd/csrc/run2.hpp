@@ -16,13 +16,17 @@ struct Eng2 {
     double *rows_mut = nullptr, *rows_cm = nullptr, *csum = nullptr, *csum_full = nullptr, *rows_gm = nullptr, *rows_pass[2] = {nullptr, nullptr};
     double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
     long long *d_ranges = nullptr;
+    long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage
+    int prof_stage = 0;
     int world = 0;
+    bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
+    int n_steps = 1, n_blocks = 1;
 };
 
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete e;
@@ -39,13 +43,21 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     if (!V) { if (world <= V2_MAXV) V = world; else return false; }
     g.V = V; g.Vl = V / world; g.v0 = rank * g.Vl; g.nv = g.n / g.Vl;
     if (g.nv < 1) return false;
-    g.nb2 = (int)((g.nv + 255) / 256);
+    g.t2 = 512;
+    g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
     g.direct = (single && world == 1 && g.nb2 <= GRP) ? 1 : 0;
     if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
-    const long long want1 = (g.nv + 1023) / 1024;
-    g.nb1 = (int)std::max<long long>(1, std::min<long long>(want1, g.direct ? 16 : 128));
-    g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + 255) / 256 * 256;
-    g.nbg = std::min(2 * g.nb1, g.direct ? GRP : 256);
+    if (!g.direct || getenv("SMCMI_E2_T256")) {                                      // large clouds / several handles: 256-thread mutation blocks (3 wavefronts per SIMD)
+        g.t2 = 256;
+        g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
+        if (g.direct && g.nb2 > GRP) g.direct = 0;
+    }
+    // correction blocks per virtual shard: 1024 particles per block (two passes of its 512 threads), at most 16 rows per virtual shard for
+    // K2's prologue to total while the cloud is small
+    g.nb1 = (int)std::max<long long>(1, g.direct ? std::min<long long>((g.nv + 1023) / 1024, 16) : std::min<long long>((g.nv + 1023) / 1024, 128));
+    if (getenv("SMCMI_E2_NB1")) g.nb1 = std::max(1, std::min(atoi(getenv("SMCMI_E2_NB1")), g.direct ? 64 : 128));   // development only
+    g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;                        // whole passes of the block
+    g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? 32 : 256));
     g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
     if ((long long)g.V * g.nb1 > 1024) return false;
     *out = g;
@@ -55,20 +67,22 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
 static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     Geo2 g;
     if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
-    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.v0 == g.v0) return 0;
+    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1) return 0;
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     Eng2 *e = new Eng2();
     e->g = g; e->world = world;
-    const int npf = h->npairs + 2;
+    const int npf = pad2(h->npairs + 2), npp = pad2(h->npairs);
     const size_t n1 = (size_t)g.Vl * g.nb1, n2 = (size_t)g.Vl * g.nb2, ng = (size_t)g.Vl * g.nbg;
     if (dmalloc(&e->d_ctl, 1) || dmalloc(&e->rows_mut, n2 * RMUT) || dmalloc(&e->rows_cm, n1 * npf) || dmalloc(&e->csum, n1) ||
-        dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * h->npairs) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
+        dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * npp) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
         dmalloc(&e->rows_pass[1], n1 * 2 * KC) || dmalloc(&e->vt_mut, (size_t)g.V * RMUT) || dmalloc(&e->vt_cm, (size_t)g.V * npf) ||
-        dmalloc(&e->vt_gm, (size_t)g.V * h->npairs) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2)) {
+        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2)) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
     }
     HIP_TRY(hipMemsetAsync(e->rows_mut, 0, n2 * RMUT * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(e->rows_cm, 0, n1 * npf * sizeof(double), h->stream));        // (the pad columns stay zero)
+    HIP_TRY(hipMemsetAsync(e->rows_gm, 0, ng * npp * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(e->csum, 0, n1 * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(e->csum_full, 0, (size_t)g.V * g.nb1 * sizeof(double), h->stream));
     h->e2 = e;
@@ -85,8 +99,14 @@ static bool eng2_eligible(const smcmi_handle *h, int world) {
 template <int D>
 static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows) {
     Eng2 *e = h->e2;
-    k2_correct<D><<<e->g.Vl * e->g.nb1, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
-                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n);
+    Rng2 ra{};
+    unsigned grid = (unsigned)(e->g.Vl * e->g.nb1);
+    if (e->rng_ahead) {              // extra blocks, one per mutation block, draw the stage's random numbers on the idle CUs
+        ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
+        grid += (unsigned)((e->g.Vl * e->g.nb2 + RNG_CHUNKS - 1) / RNG_CHUNKS);
+    }
+    k2_correct<D><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
 }
 template <int D>
 static void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full) {
@@ -98,8 +118,14 @@ template <int D>
 static void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {
     Eng2 *e = h->e2;
     const size_t lds = k2_lds_bytes(D);
-    if (alpha1) k2_mutate<D, true><<<e->g.Vl * e->g.nb2, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-    else k2_mutate<D, false><<<e->g.Vl * e->g.nb2, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
+    if (e->g.t2 == 512) {
+        if (alpha1) k2_mutate<D, true, 512><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 512><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    } else {
+        if (alpha1) k2_mutate<D, true, 256><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 256><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    }
 }
 #define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
     switch (d) {                                                                                                                          \
@@ -167,9 +193,27 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
         k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
+        // random numbers drawn ahead: while K1 leaves most CUs idle (small clouds = the direct geometry with 512-thread mutation blocks)
+        static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
+        Eng2 *e = h->e2;
+        e->rng_ahead = false; e->n_steps = rc->n_mh_steps; e->n_blocks = rc->n_blocks;
+        if (!no_ra && e->g.direct && e->g.t2 == 512) {
+            const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)rc->n_mh_steps * (size_t)rc->n_blocks;
+            if (need > h->zbuf_cap) {
+                if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
+                if (dmalloc(&h->d_zbuf, need)) return SMCMI_ERR_HIP;
+                h->zbuf_cap = need;
+            }
+            e->rng_ahead = true;
+        }
+    }
+    if (getenv("SMCMI_PROF2") && !h0->e2->d_prof) {
+        if (dmalloc(&h0->e2->d_prof, 128)) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemset(h0->e2->d_prof, 0, 128 * sizeof(long long)));
+        h0->e2->prof_stage = atoi(getenv("SMCMI_PROF2"));
     }
     const Geo2 g0 = h0->e2->g;
-    const int npf = h0->npairs + 2, np = h0->npairs;
+    const int npf = pad2(h0->npairs + 2), np = pad2(h0->npairs);
     const bool direct = g0.direct != 0;
     // ---- row-set plumbing
     auto view = [&](smcmi_handle *, const double *rows, const double *vt, int nr, int m) {
@@ -204,7 +248,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // energy maximum of the initial cloud in the mutation-row layout (stage 2's energy shift)
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        k2_energy_max<<<g0.Vl * g0.nb2, 256, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
+        k2_energy_max<<<g0.Vl * g0.nb2, g0.t2, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
     }
     if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX)) return e;
 
@@ -280,7 +324,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             Mut2Args ma{};
             ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n; ma.sel_enqueued = sel_enqueued; ma.adaptive = adaptive ? 1 : 0;
             ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
+            ma.zbuf = e->rng_ahead ? h->d_zbuf : nullptr;
             ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
+            ma.prof = (e->d_prof && n == e->prof_stage) ? e->d_prof + 64 : nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profile && h == h0) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_stage.push_back(n); hipEventRecord(e0, h->stream); }
 #define SMCMI_CALL(D) launch_k2_mutate<D>(h, ma, rc->n_blocks, rc->alpha == 1.0)
@@ -431,6 +477,17 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             stages_left_est = left < 1e6 ? (int)left + 1 : 1 << 30;
         }
         if (predict_select) { pred_ess = p.ess; pred_rl = p.do_resample; }
+    }
+    if (h0->e2->d_prof) {
+        long long pr[128];
+        HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));
+        for (int blk = 0; blk < 2; ++blk) {
+            fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");
+            for (int q = 1; q <= 5; ++q) fprintf(stderr, " %lld", pr[blk * 32 + q] - pr[blk * 32 + q - 1]);
+            fprintf(stderr, "  total %lld\n[smcmi2] K2 %s block ticks:", pr[blk * 32 + 5] - pr[blk * 32], blk ? "mid" : "0");
+            for (int q = 1; q <= 11; ++q) fprintf(stderr, " %lld", pr[64 + blk * 32 + q] - pr[64 + blk * 32 + q - 1]);
+            fprintf(stderr, "  total %lld\n", pr[64 + blk * 32 + 10] - pr[64 + blk * 32]);
+        }
     }
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));

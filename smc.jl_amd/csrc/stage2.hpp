@@ -35,12 +35,25 @@ constexpr int RMUT = 34;          // mutation row: ES = 32 sums (energy power su
 constexpr int RMAX_IDX = 32;
 constexpr int T1 = 512;           // threads of a correction block
 constexpr int GRP = 64;           // rows per canonical reduction group
+constexpr int pad2(int m) { return (m + 1) & ~1; }   // row widths are even: rows are totalled with 16-byte loads (pad column = 0)
+
+// development aid (SMCMI_PROF2=1): shader-clock stamps of thread 0 of block 0 (slots 0..31) and of the middle block (32..63)
+#define K2_STAMP(prof, slot)                                                                                                   \
+    do {                                                                                                                      \
+        if ((prof) != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {                       \
+            unsigned long long tt_;                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");       \
+            (prof)[(blockIdx.x == 0 ? 0 : 32) + (slot)] = (long long)tt_;                                                      \
+        }                                                                                                                     \
+    } while (0)
 
 struct Geo2 {
     long long N, n, nv;           // global / local / per-virtual-shard particles
     int V, Vl, v0;                // virtual shards in total / held by this handle / global index of the first local one
     int nb1, nb2, nbg;            // blocks per virtual shard: correction (and scan chunks) / mutation / gather
     long long per1, perg;         // particles per correction / gather block
+    int t2;                       // threads (= particles) of a mutation block: 512 while the cloud is small (half as many rows for the
+                                  // next stage's begin to total, one block per CU), 256 beyond (3 wavefronts per SIMD)
     int direct;                   // consumers total the per-block rows themselves (one handle, <= GRP rows per virtual shard)
 };
 
@@ -54,6 +67,7 @@ struct Begin2 {                   // stage n as decided at its begin (K1 / k2_be
     double phi_prev, phi_n, phi_prop, ess_bar, gprime, pred_delta;
     double accept;                // cloud.accept: acceptance rate of stage n-1's mutation (particle.jl:466-468)
     double e_shift, e_center;
+    double cfac;                  // step-size multiplier 0.95 + 0.10 e^{16(a-t)} / (1 + e^{16(a-t)}) (smc_main.jl:453-455), stored by K1's block 0
 };
 struct Post2 {                    // stage n after its correction (K2, block 0); two copies, indexed by n & 1
     int stage, j, resampled_last, do_resample, resamples, fold_valid;
@@ -90,47 +104,64 @@ __device__ inline double slice_tree_max(const double (&a)[SL]) {
     return m;
 }
 
-// Totals of M columns over R.nvs (<= V2_MAXV) virtual shards x R.nr (<= NRMAX <= GRP) rows in the canonical order, by the whole
-// block of T threads.  H threads share one (virtual shard, column) unit, each owning 8 / H of the 8 slices (slice s = rows s, s + 8,
-// ... in ascending order); the result does not depend on H, T or NRMAX.  Column max_idx (if >= 0) is a maximum instead of a sum.
-// Every load is unconditional (rows beyond nr re-read the last row and contribute the identity): a load under a run-time
-// condition makes the compiler wait for each one separately, i.e. one memory round trip per row instead of one per call.
+// Totals of M (even) columns over R.nvs (<= V2_MAXV) virtual shards x R.nr (<= NRMAX <= GRP) rows in the canonical order, by the
+// whole block of T threads.  A unit = (virtual shard, pair of adjacent columns, h): H threads share a (shard, pair), each owning
+// 8 / H of the 8 slices (slice s = rows s, s + 8, ... in ascending order); the result does not depend on H, T or NRMAX.  Column
+// max_idx (if >= 0) is a maximum instead of a sum.  Loads are 16 bytes wide and unconditional (rows beyond nr re-read the last
+// row and contribute the identity): a load under a run-time condition makes the compiler wait for each one separately, i.e. one
+// memory round trip per row instead of one per call; with few rows all of a thread's loads are in flight at once.
 // vt: LDS scratch of V2_MAXV * M * H doubles; tot: LDS, M doubles.  All threads must call; ends with a barrier.
 template <int M, int H, int NRMAX, int T>
 __device__ inline void reduce_rows_ct(const Rows2 &R, double *vt, double *tot, int max_idx = -1) {
-    constexpr int SL = 8 / H, NJ = NRMAX / 8, UPT = (V2_MAXV * M * H + T - 1) / T;
+    static_assert(M % 2 == 0, "columns are totalled in pairs (16-byte loads)");
     static_assert(NRMAX % 8 == 0 && NRMAX <= GRP, "NRMAX: multiple of 8, at most one group");
-    const int units = R.nvs * M * H, nr = R.nr;
-    // (one unit's loads in flight at a time: unrolling over k as well would need > 100 VGPRs of load targets and spill in K2)
-#pragma unroll 1
-    for (int k = 0; k < UPT; ++k) {
+    constexpr int MP = M / 2, SL = 8 / H, NJ = NRMAX / 8, UPT = (V2_MAXV * MP * H + T - 1) / T;
+    constexpr bool FULL = UPT * NJ * SL <= 16;           // all units' loads in one batch while the load targets stay <= 64 VGPRs
+    const int units = R.nvs * MP * H, nr = R.nr;
+    const double ninf = -__builtin_inf();
+    auto unit = [&](int k) {
         const int u = (int)threadIdx.x + k * T;
-        if (k * T >= units) break;                     // block-uniform
+        if ((u & ~63) >= units) return;                  // the whole wavefront has no unit in this batch
         const int uc = u < units ? u : 0;
-        const int h = uc % H, idx = (uc / H) % M, v = uc / (H * M);
-        const bool mx = idx == max_idx;
-        const double ident = mx ? -__builtin_inf() : 0.0;
-        const double *base = R.p + ((long long)v * nr) * R.ld + idx;
-        double a[SL];
+        const int h = uc % H, pr = (uc / H) % MP, v = uc / (H * MP);
+        const bool mx0 = 2 * pr == max_idx, mx1 = 2 * pr + 1 == max_idx;
+        const double id0 = mx0 ? ninf : 0.0, id1 = mx1 ? ninf : 0.0;
+        const double2 *base = reinterpret_cast<const double2 *>(R.p + ((long long)v * nr) * R.ld + 2 * pr);
+        const long long ldp = R.ld / 2;
+        double a0[SL], a1[SL];
 #pragma unroll
-        for (int q = 0; q < SL; ++q) a[q] = ident;
+        for (int q = 0; q < SL; ++q) { a0[q] = id0; a1[q] = id1; }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int q = 0; q < SL; ++q) {
                 const int r = h * SL + q + 8 * j;
                 const int rc = r < nr ? r : nr - 1;
-                const double x = base[(long long)rc * R.ld];
-                const double xv = r < nr ? x : ident;
-                a[q] = mx ? fmax(a[q], xv) : a[q] + xv;
+                const double2 x = base[(long long)rc * ldp];
+                const double x0 = r < nr ? x.x : id0, x1 = r < nr ? x.y : id1;
+                a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
+                a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
             }
         }
-        if (u < units) vt[u] = mx ? slice_tree_max<SL>(a) : slice_tree<SL>(a);
+        if (u < units) {
+            vt[(v * M + 2 * pr) * H + h] = mx0 ? slice_tree_max<SL>(a0) : slice_tree<SL>(a0);
+            vt[(v * M + 2 * pr + 1) * H + h] = mx1 ? slice_tree_max<SL>(a1) : slice_tree<SL>(a1);
+        }
+    };
+    if constexpr (FULL) {
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) unit(k);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < UPT; ++k) {
+            if (k * T >= units) break;                     // block-uniform
+            unit(k);
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < M; idx += T) {
         const bool mx = idx == max_idx;
-        double t = mx ? -__builtin_inf() : 0.0;
+        double t = mx ? ninf : 0.0;
         for (int v = 0; v < R.nvs; ++v) {
             double p[H];
 #pragma unroll
@@ -251,16 +282,16 @@ __global__ void k2_export(DevState *st, const Ctl2 *ctl) {
 }
 
 // largest energy of the live cloud per mutation block -> rows_mut[b][RMAX_IDX] (run start; afterwards the mutation epilogue)
-__global__ void __launch_bounds__(256) k2_energy_max(CloudPtrs cl, Geo2 g, double *rows_mut) {
-    __shared__ double smem[4];
+__global__ void __launch_bounds__(512) k2_energy_max(CloudPtrs cl, Geo2 g, double *rows_mut) {
+    __shared__ double smem[8];
     const int vl = blockIdx.x / g.nb2, r = blockIdx.x % g.nb2;
     long long beg, end;
-    vchunk(g, vl, r, 256, beg, end);
+    vchunk(g, vl, r, g.t2, beg, end);
     const int R = cl.R;
     const long long i = beg + threadIdx.x;
     double m = -__builtin_inf();
     if (i < end) m = energy_or_ninf(col(cl, 0, R - 5)[i], col(cl, 0, R - 3)[i], col(cl, 0, R - 1)[i], true);
-    m = block_max(m, smem, 4);
+    m = block_max(m, smem, (int)blockDim.x / 64);
     if (threadIdx.x == 0) rows_mut[(long long)blockIdx.x * RMUT + RMAX_IDX] = m;
 }
 
@@ -273,7 +304,7 @@ __global__ void __launch_bounds__(256) k2_energy_max(CloudPtrs cl, Geo2 g, doubl
 //          6 solver armed in *arm (certificate passes follow).
 __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, const double *s_es, double emax_tot, bool rows_valid,
                                   int spec_expected, const double *sched, const double *s_sw, Begin2 *bg, Solver *arm, bool writer,
-                                  const Records &rec, Status2 *status) {
+                                  const Records &rec, Status2 *status, double inv_pre = -1.0) {
     const int lane = threadIdx.x & 63;
     const int stage0 = n - 1, n_phi = rp.n_phi, fixed = rp.use_fixed_schedule, j = po.j;
     const double N = (double)rp.n_parts, phi_n = po.phi_n, phi_prop = po.phi_prop, target = rp.tempering_target;
@@ -302,7 +333,7 @@ __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, c
     b.ess_bar = ess_bar;
     double pd = b.gprime, gp = b.gprime;
     if (have_es) {
-        pd = predict_delta_wave(s_es, po.do_resample != 0, ess_bar, &gp);
+        pd = predict_delta_wave(s_es, po.do_resample != 0, ess_bar, &gp, inv_pre);
         const double ec = po.e_center + s_es[1] / s_es[0];         // weighted mean energy: centre for the next epilogue
         if (fabs(ec) < 1e300) b.e_center = ec;
     }
@@ -386,29 +417,38 @@ __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, c
 // s_sw (64), s_act.
 template <int T>
 __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &mrows, int spec_expected, const double *sched,
-                                   const Records &rec, Post2 *s_po, Begin2 *s_bg, double *s_vt, double *s_tot, double *s_sw, int *s_act) {
+                                   const Records &rec, Post2 *s_po, Begin2 *s_bg, double *s_vt, double *s_tot, double *s_sw, int *s_act,
+                                   long long *prof = nullptr) {
     const int t = threadIdx.x;
     constexpr int NWP = sizeof(Post2) / sizeof(double);
     if (t < NWP) reinterpret_cast<double *>(s_po)[t] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[t];
     if (t == 0) *s_act = -1;
-    __syncthreads();
-    if (s_po->stage != n - 1) return -1;                 // the state this launch was enqueued for is not there: no-op
-    if (t < 64) {
-        const int jj = s_po->j - 1 + t;                  // 0-based index of walk step t + 1
-        s_sw[t] = (!st->rp.use_fixed_schedule && jj < st->rp.n_phi) ? sched[jj] : 2.0;
-    }
+    // every load of the prologue is issued before the first wait: the state copy above, the schedule window (index from a direct
+    // read of j instead of the LDS copy: one round trip less) and the rows
+    const int j_direct = ctl->ps[(n - 1) & 1].j;
+    const double inv_pre = INV_FACTORIAL[t & 31];        // 1 / k! of the predictor's lane (a dependent global load if taken there)
+    K2_STAMP(prof, 1);
     const bool rows_valid = mrows.p != nullptr;
-    if (rows_valid) reduce_rows<RMUT, 4, T>(mrows, s_vt, s_tot, RMAX_IDX);
+    double swv = 2.0;
+    if (t < 64) {
+        const int jj = j_direct - 1 + t;                 // 0-based index of walk step t + 1
+        if (!st->rp.use_fixed_schedule && jj >= 0 && jj < st->rp.n_phi) swv = sched[jj];
+    }
+    if (rows_valid) reduce_rows<RMUT, 2, T>(mrows, s_vt, s_tot, RMAX_IDX);
     else {
         if (t < RMUT) s_tot[t] = t == RMAX_IDX ? -__builtin_inf() : 0.0;
         __syncthreads();
     }
+    if (s_po->stage != n - 1) return -1;                 // the state this launch was enqueued for is not there: no-op
+    if (t < 64) s_sw[t] = swv;                           // (read by wavefront 0 only, which wrote it)
+    K2_STAMP(prof, 2);
     if (t < 64) {
         const int act = begin2_wave(n, *s_po, st->rp, s_tot, s_tot[RMAX_IDX], rows_valid && s_po->fold_valid, spec_expected, sched, s_sw, s_bg,
-                                    &st->sol[0], blockIdx.x == 0, rec, &ctl->status);
+                                    &st->sol[0], blockIdx.x == 0, rec, &ctl->status, inv_pre);
         if (t == 0) *s_act = act;
     }
     __syncthreads();
+    K2_STAMP(prof, 3);
     const int act = *s_act;
     constexpr int NWB = sizeof(Begin2) / sizeof(double);
     if ((act == 0 || act == 6) && blockIdx.x == 0 && t < NWB) reinterpret_cast<double *>(&ctl->bg)[t] = reinterpret_cast<const double *>(s_bg)[t];
@@ -507,6 +547,83 @@ __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, int n, 
     ctl->bg.final = 1;
 }
 
+// Random numbers of proposal t (mh_step * n_blocks + block) of one particle (src/mutation.jl:66,133, helpers.jl:87-100; RNG
+// contract in DESIGN.md): the MH uniform of this decision, the mixture-component uniform and the block's normals.  Box-Muller is
+// written stage by stage over the pairs so the independent log / sqrt / sincospi chains interleave.
+template <int D>
+__device__ inline void draw2(unsigned long long seed, unsigned long long pid, unsigned stage, unsigned t, int db, int debug, double &step_prob,
+                             double &uc, double (&z)[D]) {
+#pragma clang fp contract(fast)
+    double u_dummy, unext;
+    if (t == 0) uniform_pair(seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);       // quirk Q3: drawn before the proposal
+    else uniform_pair(seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
+    uniform_pair(seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
+    constexpr int NP2 = (D + 1) / 2;
+    constexpr int GRPB = 3;                     // pairs interleaved at a time (more raises register pressure)
+    double ua[NP2], ub[NP2], rr[NP2], sn[NP2], cs[NP2];
+#pragma unroll
+    for (int q = 0; q < NP2; ++q) {
+        ua[q] = 0.5; ub[q] = 0.0;
+        if (2 * q < db) uniform_pair(seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua[q], ub[q]);
+    }
+#pragma unroll
+    for (int g0 = 0; g0 < NP2; g0 += GRPB) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = log(ua[q]);
+#pragma unroll
+        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = sqrt(-2.0 * rr[q]);
+#pragma unroll
+        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) sincospi(2.0 * ub[q], &sn[q], &cs[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NP2; ++q) {
+        if (debug & 1) { rr[q] = 1.0; cs[q] = uc - 0.5; sn[q] = unext - 0.5; }
+        z[2 * q] = (2 * q < db) ? rr[q] * cs[q] : 0.0;
+        if (2 * q + 1 < D) z[2 * q + 1] = (2 * q + 1 < db) ? rr[q] * sn[q] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < D; ++e) asm volatile("" : "+v"(z[e]));   // materialise the normals here
+}
+
+// ------------------------------------------------------------------------------------------------ random numbers drawn ahead
+// The mutation's draws depend only on (seed, particle id, stage, proposal index).  K1 keeps <= 64 of the 256 CUs busy while the
+// cloud is small, so the same launch carries extra blocks (behind the correction blocks in dispatch order) that draw the stage's
+// random numbers into zbuf on the idle CUs; K2 then loads D + 2 coalesced values per proposal instead of running Philox +
+// Box-Muller (~40 % of its arithmetic).  Layout: zbuf[(t ZS + slot) n + i], t = mh_step n_blocks + block, ZS = D + 2 slots:
+// MH uniform, mixture uniform, D normals.  Same expressions as draw2 -> same bits.
+struct Rng2 {
+    double *zbuf;            // null: disabled
+    int n_steps, nb, nf;
+    unsigned long long seed;
+    long long gid0;
+};
+constexpr int RNG_CHUNKS = 2;      // mutation-block chunks drawn per extra block (correction blocks + extra blocks must fit the 256 CUs at one block each)
+template <int D>
+__device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int block, int debug) {
+    const int sub = (ra.nf + ra.nb - 1) / ra.nb;
+    for (int cb = block * RNG_CHUNKS; cb < (block + 1) * RNG_CHUNKS && cb < g.Vl * g.nb2; ++cb) {
+    long long beg, end;
+    vchunk(g, cb / g.nb2, cb % g.nb2, g.t2, beg, end);
+    for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const unsigned long long pid = (unsigned long long)(ra.gid0 + i);
+        for (int step = 0; step < ra.n_steps; ++step)
+            for (int b = 0; b < ra.nb; ++b) {
+                const unsigned t = (unsigned)(step * ra.nb + b);
+                const int db = (b < ra.nb - 1) ? sub : ra.nf - sub * (ra.nb - 1);
+                double step_prob, uc, z[D];
+                draw2<D>(ra.seed, pid, (unsigned)n, t, db, debug, step_prob, uc, z);
+                double *zt = ra.zbuf + (long long)t * (D + 2) * g.n + i;
+                zt[0] = step_prob;
+                zt[g.n] = uc;
+#pragma unroll
+                for (int e = 0; e < D; ++e) zt[(long long)(2 + e) * g.n] = z[e];
+            }
+    }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1: correction + moments
 // src/smc_main.jl:401-420 (incremental weights, update_weights!) fused with the sums of weighted_mean / weighted_cov
 // (particle.jl:481-483, 526-529) of the corrected cloud, as k_correct_moments - but the unnormalised weights W̃ always go to the
@@ -515,18 +632,28 @@ __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, int n, 
 template <int D>
 __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int begin_done, int spec_expected,
                                                  Rows2 mrows, const double *sched, Records rec, double *rows_cm, double *csum, double *wt,
-                                                 double *hist_w, long long hist_ld) {
+                                                 double *hist_w, long long hist_ld, Rng2 ra, long long *prof = nullptr) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
     constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
+    if ((int)blockIdx.x >= g.Vl * g.nb1) {               // the idle CUs draw the mutation's random numbers (Rng2)
+        // (drawn whether or not the stage goes ahead: a stalled stage is redone with the same numbers)
+        if (ra.zbuf && ctl->ps[(n - 1) & 1].stage == n - 1) rng2_block<D>(g, ra, n, (int)blockIdx.x - g.Vl * g.nb1, 0);
+        return;
+    }
     __shared__ double red[NW * 64];
     __shared__ Post2 s_po;
     __shared__ Begin2 s_bg;
     __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[RMUT], s_sw[64];
     __shared__ int s_act;
+    K2_STAMP(prof, 0);
     const double pw = st->rp.pw, logp_old = st->rp.logp_old;
     const bool hist = st->rp.store_history && hist_w != nullptr;
+    const int R = cl.R;
+    const double *loglh = col(cl, 0, R - 5), *old = col(cl, 0, R - 3), *w = col(cl, 0, R - 1);
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nb1, blockIdx.x % g.nb1, g.per1, beg, end);
     if (!begin_done) {
-        const int act = begin2_block<T1>(n, st, ctl, mrows, spec_expected, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act);
+        const int act = begin2_block<T1>(n, st, ctl, mrows, spec_expected, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act, prof);
         if (act != 0) return;
     } else {
         constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double);
@@ -536,17 +663,13 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
         if (s_bg.stage != n || !s_bg.final || s_po.stage != n - 1) return;
     }
     const double phi = s_bg.phi_n, phi_prev = s_bg.phi_prev, esh = pw == 0.0 ? s_bg.e_shift : 0.0;
-    double sh[D];
-#pragma unroll
-    for (int a = 0; a < D; ++a) sh[a] = s_po.shift[a];
-    const int R = cl.R;
-    const double *loglh = col(cl, 0, R - 5), *old = col(cl, 0, R - 3), *w = col(cl, 0, R - 1);
+    const double *sh = s_po.shift;           // read from LDS where used (uniform address): twenty registers the accumulators need
     double acc[NCH * 64];
 #pragma unroll
     for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
-    long long beg, end;
-    vchunk(g, blockIdx.x / g.nb1, blockIdx.x % g.nb1, g.per1, beg, end);
     const double unshift = hist ? exp((phi - phi_prev) * esh) : 1.0;                      // history keeps the true exp(δ e)
+    // (the geometry gives a thread at most two particles while the cloud is small; requesting the first one ahead of the prologue
+    // was tried: the 68 accumulator pairs leave no registers to carry it, the spills inside the loop cost more than the round trip)
     for (long long i = beg + threadIdx.x; i < end; i += T1) {
         const double l = loglh[i] - esh, o = old[i], wi = w[i];
         double xx[DA];
@@ -570,7 +693,8 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
             for (int b = a; b < DA; ++b) { acc[q] += wx * xx[b]; ++q; }
         }
     }
-    double *out = rows_cm + (long long)blockIdx.x * NPF;
+    K2_STAMP(prof, 4);
+    double *out = rows_cm + (long long)blockIdx.x * pad2(NPF);
     constexpr int REM = NPF - 64 * (NCH - 1);
     constexpr int REMP = REM <= 1 ? 1 : REM <= 2 ? 2 : REM <= 4 ? 4 : REM <= 8 ? 8 : REM <= 16 ? 16 : REM <= 32 ? 32 : 64;
 #pragma unroll
@@ -591,23 +715,29 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
             if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = tr;
         }
     }
+    K2_STAMP(prof, 5);
+    // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double a = s_bg.accept, tg = st->rp.target;
+        ctl->bg.cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ post-correction decision
 // ESS of the corrected weights, verification of a predicted ϕ_n (see k_prepare_mutation), selection decision
 // (src/smc_main.jl:427-435).  Same inputs -> same result in every block / kernel that calls it.
 // 0: go, no resampling; 1: go, resample; 4: prediction not verified; < 0: error code
-__device__ inline int decide2(const Begin2 &bg, const RunParams &rp, double s1, double s2, double *ess_out) {
+__device__ inline int decide2(const Begin2 &bg, double threshold, double phi_rtol, double s1, double s2, double *ess_out) {
     const double ess = s1 * s1 / s2;
     *ess_out = ess;
     if (bg.spec) {
         bool verified;
-        if (bg.phi_n < 1.0) verified = fabs(ess - bg.ess_bar) <= fabs(bg.gprime) * fmax(rp.phi_rtol, SPEC_VERIFY_RTOL) * bg.phi_n;
+        if (bg.phi_n < 1.0) verified = fabs(ess - bg.ess_bar) <= fabs(bg.gprime) * fmax(phi_rtol, SPEC_VERIFY_RTOL) * bg.phi_n;
         else verified = ess >= bg.ess_bar * (1.0 - 1e-13);
         if (!verified) return 4;
     }
     if (isnan(ess)) return SMCMI_ERR_NAN_ESS;                      // check_nan_ess, helpers.jl:270-305
-    return ess < rp.threshold ? 1 : 0;
+    return ess < threshold ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ selection: scan
@@ -624,7 +754,7 @@ __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo
     if (s_bg.stage != n || !s_bg.final || ctl->ps[(n - 1) & 1].stage != n - 1) return;
     reduce_rows<2, 8, TB>(cmrows, s_vt, s_tot);
     double ess;
-    if (decide2(s_bg, st->rp, s_tot[0], s_tot[1], &ess) != 1) return;
+    if (decide2(s_bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) != 1) return;
     const int nchunks = g.V * g.nb1, t = threadIdx.x;
     // exclusive prefix of the chunk sums in chunk order: 256 threads x 4 chunks each, then a sequential carry (<= 1024 chunks)
     double loc[4], run = 0.0;
@@ -678,7 +808,7 @@ __global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows
     bool go = bg.stage == n && bg.final && ctl->ps[(n - 1) & 1].stage == n - 1;
     reduce_rows<2, 8, 64>(cmrows, s_vt, s_tot);
     double ess;
-    if (go) go = decide2(bg, st->rp, s_tot[0], s_tot[1], &ess) == 1;
+    if (go) go = decide2(bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) == 1;
     if (!go) { if (r == 0) out[0] = -1; return; }
     if (r >= world) return;
     double ua, ub;
@@ -718,7 +848,7 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
     if (s_bg.stage != n || !s_bg.final || pstage != n - 1) return;
     reduce_rows<2, 8, TB>(cmrows, s_vt, s_tot);
     double ess;
-    if (decide2(s_bg, st->rp, s_tot[0], s_tot[1], &ess) != 1) return;
+    if (decide2(s_bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) != 1) return;
     const int R = cl.R;
     const long long N = g.N;
     double acc[NCH * 64];
@@ -764,7 +894,7 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
             for (int b = a2; b < DA; ++b) { acc[p] += xx[a2] * xx[b]; ++p; }
         }
     }
-    double *out = rows_gm + (long long)blockIdx.x * NP;
+    double *out = rows_gm + (long long)blockIdx.x * pad2(NP);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         double a64[64];
@@ -783,43 +913,45 @@ struct Mut2Args {
     int sel_enqueued;          // k2_scan / k2_gather were enqueued in front of this launch
     int adaptive;              // leave energy power sums for the next stage's ϕ predictor
     Rows2 cmrows, gmrows;
+    const double *zbuf;        // random numbers drawn ahead by K1's extra blocks (Rng2 layout) or null
     const double *wt;          // unnormalised weights W̃ of the correction
     double *rows_mut;          // [blocks][RMUT]
     double *hist_W;
     long long hist_ld;
     Records rec;
     int debug;
+    long long *prof;           // development only (K2_STAMP)
 };
 
 // Post-correction bookkeeping of stage n (src/smc_main.jl:427-455; see post_write in kernels.hpp); one thread per block
 // computes it into LDS, block 0 stores it and the per-stage records.
 __device__ inline void post2(int n, const Begin2 &bg, const Post2 &po, const RunParams &rp, double s1, double s2, double ess, int rs, Post2 *out) {
-    const double a = bg.accept, tg = rp.target;
+    const double a = bg.accept;
     Post2 p = po;
     p.stage = n; p.j = bg.j; p.resampled_last = rs; p.do_resample = rs; p.resamples = po.resamples + rs; p.fold_valid = 1;
     p.phi_n = bg.phi_n; p.phi_prop = bg.phi_prop; p.ess = ess; p.sumw = s1; p.sumw2 = s2;
     const double dlz = (bg.phi_n - bg.phi_prev) * (rp.pw == 0.0 ? bg.e_shift : 0.0);      // log of the common factor the shifted weights left out
     p.logz = po.logz + (log(s1 / (double)rp.n_parts) + dlz);
-    p.c = po.c * (0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))));
+    p.c = po.c * bg.cfac;
     p.accept = a; p.e_center = bg.e_center; p.e_shift = bg.e_shift;
     *out = p;
 }
 
 // The proposal of stage n from the moment totals T (augmented pair sums about `shift`, T[0] = Σ weights): θ̄, R, free subset +
 // symmetrisation (smc_main.jl:457-465), random blocks (helpers.jl:215-260, Fisher-Yates on Philox), per block c²Σ_b = L Lᵀ
-// (mutation.jl:81, once per stage) - the arithmetic of k_prepare_mutation, by a block of T threads, results in LDS only.
+// (mutation.jl:81, once per stage) - the arithmetic of k_prepare_mutation, by a block of TT >= 128 threads, results in LDS only.
+// Three barriers: [covariance | shuffle] -> [block matrices, marginal scales] -> [Cholesky, one wavefront per block] -> done.
 struct Prop2 {                 // LDS pointers (k2_mutate carves them out of its dynamic LDS)
-    double *covl, *sig_f, *A, *Lw, *mean, *mu_f;
-    int *bfree, *bptr, *fi, *fi_j;
+    double *covl, *A, *mean;
+    int *bfree, *bptr, *fi;
     double *Lraw, *logdet, *mub, *sdd, *sdn;
     int *ball, *loff;
 };
-__device__ inline bool proposal2(const double *T, const double *shift, const ModelDev *md, int d, int nf, int nb, double c, unsigned long long seed,
-                                 unsigned stage, const Prop2 &P, int *s_fail, int TT) {
+__device__ inline bool proposal2(const double *T, const double *shift, int d, int nf, int nb, double c, unsigned long long seed,
+                                 unsigned stage, const Prop2 &P, int *s_fail, int TT, long long *prof = nullptr) {
     const int t = threadIdx.x, da = d + 1;
     const double sw = T[0];
     if (t == 0) *s_fail = 0;
-    if (t < nf) P.fi[t] = md->free_inds[t];
     for (int e = t; e < d * d; e += TT) {
         int a = e / d, b = e % d;
         if (a > b) { const int tmp = a; a = b; b = tmp; }
@@ -829,80 +961,75 @@ __device__ inline bool proposal2(const double *T, const double *shift, const Mod
     }
     for (int a = t; a < d; a += TT) P.mean[a] = shift[a] + T[a + 1] / sw;
     if (t >= 64 && t < 128) {            // wave 1 shuffles while the others finish the covariance
+        // Fisher-Yates (helpers.jl:216: i = nf-1 .. 1, swap(i, j_i)) without a serial pass over memory: lane l traces position l
+        // back through the swaps in reverse order of application; what it ends at is the identity's entry that lands on l.
         const int i0 = t - 64;
-        if (i0 < nf) {
-            P.bfree[i0] = i0;
-            int jx = 0;
-            if (i0 >= 1) {
-                double ua, ub;
-                uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i0, 0), ua, ub);
-                jx = (int)(ua * (double)(i0 + 1));
-                if (jx > i0) jx = i0;
-            }
-            P.fi_j[i0] = jx;
+        int jx = 0;
+        if (i0 >= 1 && i0 < nf) {
+            double ua, ub;
+            uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i0, 0), ua, ub);
+            jx = (int)(ua * (double)(i0 + 1));
+            if (jx > i0) jx = i0;
         }
-        __builtin_amdgcn_wave_barrier();
-        if (t == 64) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            for (int i = nf - 1; i >= 1; --i) {
-                const int jx = P.fi_j[i];
-                const int tmp = P.bfree[i]; P.bfree[i] = P.bfree[jx]; P.bfree[jx] = tmp;
-            }
-            const int sub = (nf + nb - 1) / nb;
-            for (int b = 0; b < nb; ++b) P.bptr[b] = b * sub;
-            P.bptr[nb] = nf;
+        int pos = i0;
+        for (int i = 1; i < nf; ++i) {
+            const int ji = __shfl(jx, i, 64);
+            pos = pos == i ? ji : (pos == ji ? i : pos);
         }
+        if (i0 < nf) P.bfree[i0] = pos;
+        const int sub = (nf + nb - 1) / nb;
+        if (i0 < nb) P.bptr[i0] = i0 * sub;
+        if (i0 == nb) P.bptr[nb] = nf;
     }
     __syncthreads();
-    for (int e = t; e < nf * nf; e += TT) {
-        const int a = P.fi[e / nf], b = P.fi[e % nf];
-        P.sig_f[e] = (P.covl[a * d + b] + P.covl[b * d + a]) / 2.0;
-    }
-    for (int a = t; a < nf; a += TT) P.mu_f[a] = P.mean[P.fi[a]];
-    __syncthreads();
+    K2_STAMP(prof, 4);
+    // R_fr[f][g] = (R[fi f][fi g] + R[fi g][fi f]) / 2 (smc_main.jl:462-465), formed where it is used
+    auto sig = [&](int f, int g2) { const int a = P.fi[f], b = P.fi[g2]; return (P.covl[a * d + b] + P.covl[b * d + a]) / 2.0; };
     for (int i = t; i < nf; i += TT) {
         const int f = P.bfree[i];
+        const double sff = sig(f, f);
         P.ball[i] = P.fi[f];
-        P.mub[i] = P.mu_f[f];
-        P.sdd[i] = sqrt(c * c * P.sig_f[f * nf + f]);
-        P.sdn[i] = sqrt(P.sig_f[f * nf + f]);
+        P.mub[i] = P.mean[P.fi[f]];
+        P.sdd[i] = sqrt(c * c * sff);
+        P.sdn[i] = sqrt(sff);
     }
-    int off = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int p0 = P.bptr[b], db = P.bptr[b + 1] - p0;
-        for (int e = t; e < db * db; e += TT) {
-            P.A[e] = c * c * P.sig_f[P.bfree[p0 + e / db] * nf + P.bfree[p0 + e % db]];
-            P.Lw[e] = 0.0;
+    {
+        const int sub = (nf + nb - 1) / nb;          // every block but the last has `sub` entries: block b's matrix starts at b sub²
+        for (int e = t; e < nf * nf; e += TT) {      // (generous bound; entries beyond the packed total are skipped below)
+            int b = 0, rem = e;
+            while (b < nb - 1 && rem >= sub * sub) { rem -= sub * sub; ++b; }
+            const int p0 = P.bptr[b], db = P.bptr[b + 1] - p0;
+            if (rem < db * db) P.A[b * sub * sub + rem] = c * c * sig(P.bfree[p0 + rem / db], P.bfree[p0 + rem % db]);
         }
-        __syncthreads();
-        if (t < 64) {
+    }
+    __syncthreads();
+    K2_STAMP(prof, 5);
+    // Right-looking Cholesky of block b inside ONE wavefront (wave b mod 4; lane i owns row i in registers, pivots and multipliers
+    // broadcast with v_readlane): same k-ascending subtraction order per entry as the oracle's left-looking loop.
+    {
+        const int sub = (nf + nb - 1) / nb, wave = t >> 6, lane = t & 63, nwv = TT >> 6;
+        for (int b = wave; b < nb; b += nwv) {
+            const int p0 = P.bptr[b], db = P.bptr[b + 1] - p0, off = b * sub * sub;
             double r[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) r[k] = (t < db && k < db) ? P.A[t * db + k] : 0.0;
-            const bool ok = chol_rows_in_regs<12>(r, db, t);
-            if (!ok && t == 0) *s_fail = 1;
+            for (int k = 0; k < 12; ++k) r[k] = (lane < db && k < db) ? P.A[off + lane * db + k] : 0.0;
+            const bool ok = chol_rows_in_regs<12>(r, db, lane);
+            if (!ok && lane == 0) *s_fail = 1;
 #pragma unroll
             for (int k = 0; k < 12; ++k)
-                if (t < db && k <= t) P.Lw[t * db + k] = r[k];
-        }
-        __syncthreads();
-        if (*s_fail) break;
-        for (int e = t; e < db * db; e += TT) P.Lraw[off + e] = P.Lw[e];
-        if (t < 64) {
-            const double lg = (t < db) ? log(P.Lw[t * db + t]) : 0.0;
+                if (lane < db && k < db) P.Lraw[off + lane * db + k] = k <= lane ? r[k] : 0.0;
+            double dg = 1.0;                        // own diagonal entry L[lane][lane]
+#pragma unroll
+            for (int k = 0; k < 12; ++k) dg = (k == lane) ? r[k] : dg;
+            const double lg = (lane < db) ? log(dg) : 0.0;
             double ld = 0.0;
             for (int i = 0; i < db; ++i) ld += __shfl(lg, i, 64);
-            if (t == 0) { P.logdet[b] = 2.0 * ld; P.loff[b] = off; }
+            if (lane == 0) { P.logdet[b] = 2.0 * ld; P.loff[b] = off; }
         }
-        off += db * db;
-        __syncthreads();
     }
+    __syncthreads();
+    K2_STAMP(prof, 6);
     return *s_fail == 0;
-}
-
-constexpr size_t k2_prologue_doubles(int D) {
-    // s_vt (V2_MAXV * NPF) + tot (NPF + 2) + covl, sig_f, A, Lw (4 D²) + mean, mu_f (2 D) + ints (4 D + 8 -> doubles)
-    return (size_t)V2_MAXV * ((D + 1) * (D + 2) / 2 + 2) + (size_t)((D + 1) * (D + 2) / 2 + 4) + 4 * D * D + 2 * D + (4 * D + 8) / 2 + 4;
 }
 
 // LDS arrays of k2_mutate (the mutation's, as in k_mutate_reg, then the prologue's scratch)
@@ -915,128 +1042,132 @@ struct Mut2Lds {
     int *bfree, *fi, *fi_j;
     __device__ explicit Mut2Lds(double *sm) {
         Ls = sm; mu_s = Ls + D * D; sdd_s = mu_s + D; sdn_s = sdd_s + D; red = sdn_s + D;
-        m_lo = red + 4; m_hi = m_lo + D; m_a = m_hi + D; m_b = m_a + D; m_k = m_b + D;
+        m_lo = red + 8; m_hi = m_lo + D; m_a = m_hi + D; m_b = m_a + D; m_k = m_b + D;
         l_par = m_k + D; l_dat = l_par + 2 * LIK_PAR_MAX; Lraw = l_dat + LIK_LDS_CAP; logdet_s = Lraw + D * D;
         mub_raw = logdet_s + D; sdd_raw = mub_raw + D; sdn_raw = sdd_raw + D;
         ball_s = (int *)(sdn_raw + D); m_fix = ball_s + D + (D & 1); m_fam = m_fix + D;
         bptr_s = m_fam + D; loff_s = bptr_s + D + 1; ball_raw = loff_s + D;
         s_vt = (double *)(((uintptr_t)(ball_raw + D + 1) + 15) & ~(uintptr_t)15);
-        s_tot = s_vt + V2_MAXV * NPF;
-        covl = s_tot + NPF + 2; sig_f = covl + D * D; Aw = sig_f + D * D; Lw = Aw + D * D;
+        s_tot = s_vt + V2_MAXV * pad2(NPF);
+        covl = s_tot + pad2(NPF) + 4; sig_f = covl + D * D; Aw = sig_f + D * D; Lw = Aw + D * D;
         mean_s = Lw + D * D; mu_f = mean_s + D;
         bfree = (int *)(mu_f + D); fi = bfree + D; fi_j = fi + D;
     }
 };
 constexpr size_t k2_lds_bytes(int D) {
     const size_t np = (size_t)(D + 1) * (D + 2) / 2, npf = np + 2;
-    return (size_t)(2 * D * D + 12 * D + 4 + 2 * LIK_PAR_MAX + LIK_LDS_CAP) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32 +
-           (V2_MAXV * npf + npf + 2 + 4 * D * D + 2 * D) * sizeof(double) + (size_t)(3 * D + 4) * sizeof(int) + 32;
+    return (size_t)(2 * D * D + 12 * D + 8 + 2 * LIK_PAR_MAX + LIK_LDS_CAP) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32 +
+           (V2_MAXV * (npf + 1) + npf + 5 + 4 * D * D + 2 * D) * sizeof(double) + (size_t)(3 * D + 4) * sizeof(int) + 32;
 }
 
 struct Mut2Stage {             // what the prologue hands to the mutation body (LDS)
     Begin2 bg;
-    Post2 po, ps;
-    int go, rs, fail;
+    Post2 po;
+    int fail;
 };
 
-// Prologue of K2, every block: state + model constants into LDS, totals of the correction rows, decision, bookkeeping, proposal.
-// Returns false when the block must not mutate (stale launch, stall, error).
-template <int D>
-__device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, const Mut2Args &ma, const Mut2Lds<D> &L, Mut2Stage *S, int nb, int nf) {
-    constexpr int NP = Mut2Lds<D>::NP, NPF = Mut2Lds<D>::NPF, T = 256;
+// Prologue of K2, every block: state + model constants into LDS, totals of the correction rows, decision, proposal.  Nothing in
+// it goes through a single thread: every thread derives the (identical) decision from the totals itself.  Returns false when
+// the block must not mutate (stale launch, stall, error); *rs_out = this stage resamples.
+template <int D, int T>
+__device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, const Mut2Args &ma, const Mut2Lds<D> &L, Mut2Stage *S, int nb, int nf,
+                                   int *rs_out) {
+    constexpr int NP = Mut2Lds<D>::NP, NPF = Mut2Lds<D>::NPF;
     const int tid = threadIdx.x, n = ma.n;
     constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double);
     if (tid < NWB) reinterpret_cast<double *>(&S->bg)[tid] = reinterpret_cast<const double *>(&ctl->bg)[tid];
     if (tid < NWP) reinterpret_cast<double *>(&S->po)[tid] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[tid];
+    const double thr = st->rp.threshold, rtol = st->rp.phi_rtol;
     for (int k = tid; k < D; k += T) {
         L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
         L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
     }
     for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
-    __syncthreads();
+    if (tid < nf) L.fi[tid] = md->free_inds[tid];
+    K2_STAMP(ma.prof, 1);
+    reduce_rows<pad2(NPF), 1, T>(ma.cmrows, L.s_vt, L.s_tot);          // (its barriers also publish the LDS copies above)
+    K2_STAMP(ma.prof, 2);
     if (S->bg.stage != n || !S->bg.final || S->po.stage != n - 1) return false;
-    reduce_rows<NPF, 1, T>(ma.cmrows, L.s_vt, L.s_tot);
-    if (tid == 0) {
-        double ess;
-        const int dec = decide2(S->bg, st->rp, L.s_tot[0], L.s_tot[1], &ess);
-        int go = 1;
-        if (dec == 4) { go = 0; if (blockIdx.x == 0) { ctl->status.stage = n; ctl->status.code = 4; } }
-        else if (dec < 0) {
-            go = 0;
-            if (blockIdx.x == 0) {
-                ma.rec.phi[n - 1] = S->bg.phi_n; ma.rec.ess[n - 1] = ess;
-                ctl->status.err = dec; ctl->status.stage = n; ctl->status.code = 9;
-            }
-        } else if (dec == 1 && !ma.sel_enqueued) { go = 0; if (blockIdx.x == 0) { ctl->status.stage = n; ctl->status.code = 3; } }
-        if (go) post2(n, S->bg, S->po, st->rp, L.s_tot[0], L.s_tot[1], ess, dec == 1 ? 1 : 0, &S->ps);
-        S->go = go; S->rs = dec == 1 ? 1 : 0;
+    double ess;
+    const int dec = decide2(S->bg, thr, rtol, L.s_tot[0], L.s_tot[1], &ess);
+    const bool stall = dec == 4 || dec < 0 || (dec == 1 && !ma.sel_enqueued);
+    if (stall) {
+        if (blockIdx.x == 0 && tid == 0) {
+            if (dec < 0) { ma.rec.phi[n - 1] = S->bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
+            ctl->status.stage = n;
+            ctl->status.code = dec == 4 ? 4 : (dec < 0 ? 9 : 3);
+        }
+        return false;
     }
-    __syncthreads();
-    if (!S->go) return false;
+    const int rs = dec == 1 ? 1 : 0;
+    *rs_out = rs;
+    K2_STAMP(ma.prof, 3);
     // moments of the resampled cloud (k2_gather's rows) replace the correction's on resample stages
-    if (S->rs) reduce_rows<NP, 1, T>(ma.gmrows, L.s_vt, L.s_tot + 2);
-    Prop2 P{L.covl, L.sig_f, L.Aw, L.Lw, L.mean_s, L.mu_f, L.bfree, L.bptr_s, L.fi, L.fi_j, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw,
-            L.ball_raw, L.loff_s};
-    if (!proposal2(L.s_tot + 2, S->po.shift, md, D, nf, nb, S->ps.c, ma.seed, (unsigned)n, P, &S->fail, T)) {
+    if (rs) reduce_rows<pad2(NP), 1, T>(ma.gmrows, L.s_vt, L.s_tot + 2);
+    Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
+    if (!proposal2(L.s_tot + 2, S->po.shift, D, nf, nb, S->po.c * S->bg.cfac, ma.seed, (unsigned)n, P, &S->fail, T, ma.prof)) {
         // PosDefException aborts the run (mutation.jl:81)
         if (blockIdx.x == 0 && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
         return false;
     }
-    if (blockIdx.x == 0) {
-        if (tid < D) { S->ps.shift[tid] = L.mean_s[tid]; st->mean[tid] = L.mean_s[tid]; }     // st->mean / cov: diagnostics, stand-alone readers
-        for (int e = tid; e < D * D; e += T) st->cov[e] = L.covl[e];
-        __syncthreads();
-        if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&S->ps)[tid];
-        if (tid == 0) {
-            ma.rec.phi[n - 1] = S->ps.phi_n; ma.rec.ess[n - 1] = S->ps.ess; ma.rec.resampled[n - 1] = S->rs; ma.rec.c[n - 1] = S->ps.c;
-        }
-    }
+    K2_STAMP(ma.prof, 7);
     return true;
+}
+
+// Block 0, after its mutation: the stage's bookkeeping (src/smc_main.jl:427-455) - nothing in this launch reads it, so the
+// logarithm of the log-MDD increment and the records stay off every block's critical path.
+template <int D, int T>
+__device__ inline void k2_bookkeeping(DevState *st, Ctl2 *ctl, const Mut2Args &ma, const Mut2Lds<D> &L, const Mut2Stage *S, int rs) {
+    const int tid = threadIdx.x, n = ma.n;
+    __shared__ Post2 s_ps;
+    if (tid == 0) {
+        const double s1 = L.s_tot[0], s2 = L.s_tot[1];
+        post2(n, S->bg, S->po, st->rp, s1, s2, s1 * s1 / s2, rs, &s_ps);
+        ma.rec.phi[n - 1] = s_ps.phi_n; ma.rec.ess[n - 1] = s_ps.ess; ma.rec.resampled[n - 1] = rs; ma.rec.c[n - 1] = s_ps.c;
+    }
+    __syncthreads();
+    if (tid < D) { s_ps.shift[tid] = L.mean_s[tid]; st->mean[tid] = L.mean_s[tid]; }       // st->mean / cov: diagnostics, stand-alone readers
+    for (int e = tid; e < D * D; e += T) st->cov[e] = L.covl[e];
+    __syncthreads();
+    constexpr int NWP = sizeof(Post2) / sizeof(double);
+    if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&s_ps)[tid];
 }
 
 // K2.  The mutation body is k_mutate_reg's (src/mutation.jl:56-138, helpers.jl:87-164; same arithmetic in the same order), fed
 // from LDS by the prologue instead of from DevState; it reads the particle from buffer 0 (buffer 1 on resample stages: the
 // gathered cloud) and always writes buffer 0, applies normalize_weights! (particle.jl:362-366: W̃ N / ΣW̃, two roundings; 1 after a
 // resample) to the weight column and its history, and leaves one row of RMUT sums for the next stage's begin.
-template <int D, bool ALPHA1>
-__global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma,
-                                                                int nb, int nf) {
+template <int D, bool ALPHA1, int T>
+__global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
+                                                                               Mut2Args ma, int nb, int nf) {
 #pragma clang fp contract(fast)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ Mut2Stage S;
     const Mut2Lds<D> L(sm);
-    const int T = 256, tid = threadIdx.x, n = ma.n;
+    const int tid = threadIdx.x, n = ma.n;
+    K2_STAMP(ma.prof, 0);
     const int n_steps = st->rp.n_mh_steps;
     const double c_alpha = st->rp.alpha, nrm_N = (double)st->rp.n_parts;
     const int nrm_hist = st->rp.store_history;
     const LikDev ld0 = md->lik[0], ld1 = md->lik[1];
     const int has_other = md->has_other_priors;
-    if (!k2_prologue<D>(st, ctl, md, ma, L, &S, nb, nf)) return;
-    const int rs = S.rs, src = rs ? 1 : 0;
-    const double phi_n = S.bg.phi_n, e_center = S.bg.e_center, nrm_sumw = L.s_tot[0];
-    const unsigned stage = (unsigned)n;
     double *Ls = L.Ls, *mu_s = L.mu_s, *sdd_s = L.sdd_s, *sdn_s = L.sdn_s, *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
     double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
     int *ball_s = L.ball_s, *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
-    // ---- the particle and the likelihood data
+    // ---- the particle (speculatively from buffer 0: only resample stages read the gathered cloud in buffer 1) and the likelihood
+    // data: none of it depends on the stage's decision, so the loads are in flight while the prologue totals rows and factorises
     long long beg, end;
-    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, 256, beg, end);
+    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, T, beg, end);
     const long long i = beg + tid;
     const bool live = i < end;
+    const long long il = live ? i : (end > beg ? end - 1 : 0);           // unconditional loads (clamped row)
     const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
-    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    double like, lprior, like_prev, accept = 0.0, wt_i;
     double x[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = 0.0;
-    double w_part = 0.0;
-    if (live) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[i];
-        like = col(cl, src, D)[i]; lprior = col(cl, src, D + 1)[i]; like_prev = col(cl, src, D + 2)[i];
-        w_part = rs ? 1.0 : (ma.wt[i] * nrm_N) / nrm_sumw;                  // W·N then /ΣW̃, two roundings like the reference
-        col(cl, 0, D + 4)[i] = w_part;
-        if (ma.hist_W && nrm_hist) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = w_part;
-    }
+    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
+    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
+    wt_i = ma.wt[il];
     ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
     LikView lv[2];
     {
@@ -1055,10 +1186,42 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, D
             if (fits) used += (int)(nd + na);
         }
     }
+    // ---- the first proposal's random numbers depend on (seed, particle, stage) only: drawing them here puts ~40 % of the mutation's
+    // arithmetic under the latency of the loads above and of the prologue's row totals
+    // (512-thread blocks only: with 3 wavefronts per SIMD the 168-register budget has no room to carry them across the prologue)
+    constexpr bool PREDRAW = T == 512;
+    double step_prob, uc, z[D];
+    if (ma.zbuf) {                 // drawn ahead by K1's extra blocks: D + 2 coalesced loads
+        const double *zt = ma.zbuf + il;
+        step_prob = zt[0];
+        uc = zt[g.n];
+#pragma unroll
+        for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * g.n];
+    } else if constexpr (PREDRAW) draw2<D>(ma.seed, pid, (unsigned)n, 0u, nb == 1 ? nf : (nf + nb - 1) / nb, ma.debug, step_prob, uc, z);
+    int rs = 0;
+    if (!k2_prologue<D, T>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;
+    const double phi_n = S.bg.phi_n, e_center = S.bg.e_center, nrm_sumw = L.s_tot[0];
+    const unsigned stage = (unsigned)n;
+    if (rs) {                       // the resampled cloud is in buffer 1 (k2_gather)
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = col(cl, 1, k)[il];
+        like = col(cl, 1, D)[il]; lprior = col(cl, 1, D + 1)[il]; like_prev = col(cl, 1, D + 2)[il];
+    }
+    double w_part = 0.0;
+    if (live) {
+        w_part = rs ? 1.0 : (wt_i * nrm_N) / nrm_sumw;                      // W·N then /ΣW̃, two roundings like the reference
+        col(cl, 0, D + 4)[i] = w_part;
+        if (ma.hist_W && nrm_hist) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = w_part;
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = 0.0;
+        like = lprior = like_prev = 0.0;
+    }
     auto XN = [&](int k) { return x[k]; };
+    K2_STAMP(ma.prof, 8);
     for (int step = 0; step < n_steps; ++step) {
         for (int b = 0; b < nb; ++b) {
-            if (nb > 1 || step == 0) __syncthreads();   // prologue's arrays (first pass) / previous block's readers (later passes)
+            if ((nb > 1 || step == 0) && (step | b) != 0) __syncthreads();   // previous block's readers (the prologue ends with a barrier)
             const int p0 = bptr_s[b], db = bptr_s[b + 1] - p0;
             if (nb > 1 || step == 0) {              // expand this block's constants to the padded D x D form
                 const double *Lb = Lraw + loff_s[b];
@@ -1085,42 +1248,16 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, D
             }
             if (!live) continue;
             const unsigned t = (unsigned)(step * nb + b);
-            double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
-            double uc, unext;
-            double z[D], sub[D], dr[D];
-            if (t == 0) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
-            else uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
-            // ---- mvnormal_mixture_draw (src/helpers.jl:87-100)
-            uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
-            {
-                constexpr int NP2 = (D + 1) / 2;
-                constexpr int GRPB = 3;
-                double ua[NP2], ub[NP2], rr[NP2], sn[NP2], cs[NP2];
+            double sub[D], dr[D];
+            if (ma.zbuf) {
+                if (t != 0) {
+                    const double *zt = ma.zbuf + (long long)t * (D + 2) * g.n + i;
+                    step_prob = zt[0];
+                    uc = zt[g.n];
 #pragma unroll
-                for (int q = 0; q < NP2; ++q) {
-                    ua[q] = 0.5; ub[q] = 0.0;
-                    if (2 * q < db) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua[q], ub[q]);
+                    for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * g.n];
                 }
-#pragma unroll
-                for (int g0 = 0; g0 < NP2; g0 += GRPB) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = log(ua[q]);
-#pragma unroll
-                    for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = sqrt(-2.0 * rr[q]);
-#pragma unroll
-                    for (int q = g0; q < g0 + GRPB && q < NP2; ++q) sincospi(2.0 * ub[q], &sn[q], &cs[q]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < NP2; ++q) {
-                    if (ma.debug & 1) { rr[q] = 1.0; cs[q] = uc - 0.5; sn[q] = unext - 0.5; }
-                    z[2 * q] = (2 * q < db) ? rr[q] * cs[q] : 0.0;
-                    if (2 * q + 1 < D) z[2 * q + 1] = (2 * q + 1 < db) ? rr[q] * sn[q] : 0.0;
-                }
-#pragma unroll
-                for (int e = 0; e < D; ++e) asm volatile("" : "+v"(z[e]));
-            }
+            } else if (!PREDRAW || t != 0) draw2<D>(ma.seed, pid, stage, t, db, ma.debug, step_prob, uc, z);   // (proposal 0 may have been drawn ahead of the prologue)
             double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
             double q0 = 0.0, q1 = 0.0;
             double xo[D];
@@ -1245,6 +1382,7 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, D
             }
         }
     }
+    K2_STAMP(ma.prof, 9);
     double acc_val = 0.0;
     if (live) {
 #pragma unroll
@@ -1260,7 +1398,7 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, D
     double em = energy_or_ninf(like, like_prev, rs ? 1.0 : w_part, live);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
-    __shared__ double emx[4];
+    __shared__ double emx[T / 64];
     if ((tid & 63) == 0) emx[tid >> 6] = em;
     double *row = ma.rows_mut + (long long)blockIdx.x * RMUT;
     if (ma.adaptive) {
@@ -1274,10 +1412,23 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k2_mutate(CloudPtrs cl, D
         Butterfly<0, 32>::run(a1, tid & 63);
         if ((tid & 63) == 0) red[tid >> 6] = a1[0];
         __syncthreads();
-        if (tid < ES) row[tid] = tid == EACC ? ((red[0] + red[1]) + (red[2] + red[3])) : 0.0;
+        if (tid < ES) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int w = 0; w < T / 64; ++w) sacc += red[w];
+            row[tid] = tid == EACC ? sacc : 0.0;
+        }
     }
     __syncthreads();
-    if (tid == 0) row[RMAX_IDX] = fmax(fmax(emx[0], emx[1]), fmax(emx[2], emx[3]));
+    if (tid == 0) {
+        double m = emx[0];
+#pragma unroll
+        for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
+        row[RMAX_IDX] = m;
+    }
+    K2_STAMP(ma.prof, 10);
+    if (blockIdx.x == 0) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);
+    K2_STAMP(ma.prof, 11);
 }
 
 }  // namespace smcmi
