@@ -252,6 +252,13 @@ struct CloudPtrs {
 
 __device__ inline double *col(const CloudPtrs &c, int which, int column) { return c.buf[which] + (long long)column * c.n; }
 
+// broadcast lane `src`'s double to the whole wavefront through SGPRs (v_readlane_b32 x2): a few cycles, no LDS latency
+__device__ inline double bcast_lane(double x, int src) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(x), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)__double2hiint(x), src);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 // ------------------------------------------------------------------------------------------------ ϕ predictor
 // ESS(ϕ_{n-1} + δ) = A(δ)² / B(δ) with A = Σ W e^{δ e_i}, B = Σ W² e^{2 δ e_i}, e_i = loglh_i - old_loglh_i (helpers.jl:173-181).
 // The mutation epilogue accumulates the power sums a_k = Σ W (e - c)^k, b_k = Σ W² (e - c)^k, k < 16 / 15 (the common factor
@@ -297,7 +304,7 @@ __device__ constexpr double INV_FACTORIAL[32] = {1.00000000000000000e+00, 1.0000
 // of a) - forms its term c x^k by binary powering, and the four sums A = Σ term, x A' = Σ k term (same for B) come from 5-step
 // xor butterflies inside the 32-lane halves: a Newton step is ~40 dependent instructions.  Every lane returns the same x (NaN
 // when the model is unusable); *gprime = dESS/dδ at the root of the model.
-__device__ inline double predict_delta_wave(const double *es, bool uniform, double T, double *gprime, double inv_pre = -1.0) {
+__device__ inline double predict_delta_wave(const double *es, bool uniform, double T, double *gprime, double inv_pre = -1.0, bool refresh = true) {
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     const int lane = threadIdx.x & 63, grp = lane >> 5, k = lane & 31;
     const int KT = uniform ? EKU : (grp == 0 ? EKA : EKB);   // terms of this lane's polynomial
@@ -305,8 +312,8 @@ __device__ inline double predict_delta_wave(const double *es, bool uniform, doub
     double c = 0.0;
     if (k < KT) c = (grp == 0 ? es[k] : (uniform ? es[k] : es[EKA + k])) * inv;
     if (grp) c = ldexp(c, k);
-    auto bc = [&](double v, int src) { return __shfl(v, src, 64); };
-    const double ca0 = bc(c, 0), ca1 = bc(c, 1), ca2 = bc(c, 2), cb0 = bc(c, 32), cb1 = bc(c, 33), cb2 = bc(c, 34);
+    // broadcasts through SGPRs (v_readlane) and butterflies on DPP / v_permlane16_swap: no LDS-crossbar round trips in the Newton loop
+    const double ca0 = bcast_lane(c, 0), ca1 = bcast_lane(c, 1), ca2 = bcast_lane(c, 2), cb0 = bcast_lane(c, 32), cb1 = bcast_lane(c, 33), cb2 = bcast_lane(c, 34);
     *gprime = nan;
     if (!(ca0 > 0.0) || !(cb0 > 0.0) || !(T > 0.0)) return nan;
     const double G0 = ca0 * ca0 - T * cb0;
@@ -325,10 +332,25 @@ __device__ inline double predict_delta_wave(const double *es, bool uniform, doub
 #pragma unroll
         for (int bit = 0; bit < 5; ++bit) { if ((k >> bit) & 1) p *= xb; xb *= xb; }
         double term = c * p, kterm = kd * term;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) { term += __shfl_xor(term, off, 64); kterm += __shfl_xor(kterm, off, 64); }
-        A = bc(term, 0); SA = bc(kterm, 0); B = bc(term, 32); SB = bc(kterm, 32);
-        if (it == 3) break;                               // the last evaluation only refreshes A, B and the slopes at the final x
+        term = xor_add<16>(term); kterm = xor_add<16>(kterm);
+        term = xor_add<8>(term); kterm = xor_add<8>(kterm);
+        term = xor_add<4>(term); kterm = xor_add<4>(kterm);
+        term = xor_add<2>(term); kterm = xor_add<2>(kterm);
+        term = xor_add<1>(term); kterm = xor_add<1>(kterm);
+        A = bcast_lane(term, 0); SA = bcast_lane(kterm, 0); B = bcast_lane(term, 32); SB = bcast_lane(kterm, 32);
+        // the last evaluation only refreshes A, B and the slopes at the final x; without it (refresh = false: engine 2) the slope
+        // dESS/dδ is the one at the last-but-one iterate, 1e-8 away - it only scales the verification tolerance
+        if (it == (refresh ? 3 : 2)) {
+            if (!refresh) {
+                const double G = A * A - T * B, dG = (2.0 * A * SA - T * SB) / x;
+                if (!(dG < 0.0) || !(A > 0.0) || !(B > 0.0)) return nan;
+                const double xn = x - G / dG;
+                if (!(xn > 0.0) || !(xn < 1e300)) return nan;
+                *gprime = (2.0 * A * (SA / x) * B - A * A * (SB / x)) / (B * B);
+                return xn;
+            }
+            break;
+        }
         const double G = A * A - T * B, dG = (2.0 * A * SA - T * SB) / x;
         if (!(dG < 0.0) || !(A > 0.0) || !(B > 0.0)) return nan;
         const double xn = x - G / dG;
@@ -1531,14 +1553,10 @@ __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 // Cholesky of a db x db matrix (db <= DBM) held one row per lane in registers: column j's pivot and multipliers are
 // broadcast with v_readlane (no LDS round trips); same k-ascending subtraction order per entry as the oracle's loop.
 // Returns false when a pivot is not positive.  On return lane i holds row i of L in r[0..i].
-// broadcast lane `src`'s double to the whole wavefront through SGPRs (v_readlane_b32 x2): a few cycles, no LDS latency
-__device__ inline double bcast_lane(double x, int src) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(x), src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)__double2hiint(x), src);
-    return __hiloint2double((int)hi, (int)lo);
-}
-
-template <int DBM>
+// RSQ = true (engine 2): the pivot's reciprocal square root (hardware estimate + two Newton steps, ~1 ulp) replaces the
+// correctly rounded sqrt and division - the column's critical path is a third as long (the factorisation is ten dependent
+// columns, every block of a launch waits for it); L differs from the oracle's in the last bit or two.
+template <int DBM, bool RSQ = false>
 __device__ inline bool chol_rows_in_regs(double (&r)[DBM], int db, int lane) {
     bool ok = true;
 #pragma unroll
@@ -1546,8 +1564,18 @@ __device__ inline bool chol_rows_in_regs(double (&r)[DBM], int db, int lane) {
         if (j < db) {
             const double ajj = bcast_lane(r[j], j);
             if (!(ajj > 0.0)) ok = false;
-            const double ljj = sqrt(ajj);
-            const double lij = (lane == j) ? ljj : r[j] / ljj;      // column j of L (valid for lanes >= j)
+            double ljj, lij;
+            if constexpr (RSQ) {
+                double y = __builtin_amdgcn_rsq(ajj);               // ~1e-8 relative
+                const double h0 = 0.5 * ajj;
+                y = y * (1.5 - h0 * y * y);                         // Newton: y <- y (3 - a y²) / 2
+                y = y * (1.5 - h0 * y * y);
+                ljj = ajj * y;
+                lij = (lane == j) ? ljj : r[j] * y;
+            } else {
+                ljj = sqrt(ajj);
+                lij = (lane == j) ? ljj : r[j] / ljj;               // column j of L (valid for lanes >= j)
+            }
 #pragma unroll
             for (int k = j + 1; k < DBM; ++k) {
                 const double lkj = bcast_lane(lij, k);

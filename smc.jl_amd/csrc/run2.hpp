@@ -16,6 +16,7 @@ struct Eng2 {
     double *rows_mut = nullptr, *rows_cm = nullptr, *csum = nullptr, *csum_full = nullptr, *rows_gm = nullptr, *rows_pass[2] = {nullptr, nullptr};
     double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
     long long *d_ranges = nullptr;
+    Prop2Glob *d_pre = nullptr;      // decision + proposal of the current stage (k2_prepare; large clouds / several handles)
     long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage
     int prof_stage = 0;
     int world = 0;
@@ -26,7 +27,7 @@ struct Eng2 {
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete e;
@@ -45,7 +46,9 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     if (g.nv < 1) return false;
     g.t2 = 512;
     g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
-    g.direct = (single && world == 1 && g.nb2 <= GRP) ? 1 : 0;
+    // direct: every block totals the per-block rows itself - one handle, <= GRP rows per virtual shard, and the 512-thread mutation
+    // blocks (one per CU) resident at once
+    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= 256) ? 1 : 0;
     if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
     if (!g.direct || getenv("SMCMI_E2_T256")) {                                      // large clouds / several handles: 256-thread mutation blocks (3 wavefronts per SIMD)
         g.t2 = 256;
@@ -76,10 +79,11 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     if (dmalloc(&e->d_ctl, 1) || dmalloc(&e->rows_mut, n2 * RMUT) || dmalloc(&e->rows_cm, n1 * npf) || dmalloc(&e->csum, n1) ||
         dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * npp) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
         dmalloc(&e->rows_pass[1], n1 * 2 * KC) || dmalloc(&e->vt_mut, (size_t)g.V * RMUT) || dmalloc(&e->vt_cm, (size_t)g.V * npf) ||
-        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2)) {
+        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_pre, 1)) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
     }
+    HIP_TRY(hipMemsetAsync(e->d_pre, 0, sizeof(Prop2Glob), h->stream));
     HIP_TRY(hipMemsetAsync(e->rows_mut, 0, n2 * RMUT * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(e->rows_cm, 0, n1 * npf * sizeof(double), h->stream));        // (the pad columns stay zero)
     HIP_TRY(hipMemsetAsync(e->rows_gm, 0, ng * npp * sizeof(double), h->stream));
@@ -89,11 +93,17 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     return 0;
 }
 
+// Engine 2 serves n_para <= 10: one handle while its cloud is small enough for the direct geometry (every block totals the rows
+// itself: the latency-bound regime engine 2 was built for), and every multi-handle run (one all-gather of V rows per hand-over,
+// results independent of the number of handles).  A single handle with a larger cloud keeps engine 1: its kernels fill the chip
+// there and one-block set-up launches are cheap next to them (engine 2's reduced geometry measured 10-15 % behind at N >= 1e6).
+// SMCMI_ENGINE=1 / =2 force one engine wherever it can run (development, tests).
 static bool eng2_eligible(const smcmi_handle *h, int world) {
-    static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 2;   // development: 1 = the eight-launch engine of kernels.hpp
+    static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 0;
     if (eng == 1 || h->d > 10) return false;
     Geo2 g;
-    return make_geo2(h, world, 0, world == 1, &g);
+    if (!make_geo2(h, world, 0, world == 1, &g)) return false;
+    return eng == 2 || world > 1 || g.direct;
 }
 
 template <int D>
@@ -103,7 +113,7 @@ static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_e
     unsigned grid = (unsigned)(e->g.Vl * e->g.nb1);
     if (e->rng_ahead) {              // extra blocks, one per mutation block, draw the stage's random numbers on the idle CUs
         ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
-        grid += (unsigned)((e->g.Vl * e->g.nb2 + RNG_CHUNKS - 1) / RNG_CHUNKS);
+        grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
     }
     k2_correct<D><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
                                                            e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
@@ -325,8 +335,19 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n; ma.sel_enqueued = sel_enqueued; ma.adaptive = adaptive ? 1 : 0;
             ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
             ma.zbuf = e->rng_ahead ? h->d_zbuf : nullptr;
+            ma.pre = direct ? nullptr : e->d_pre;
+            ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
+            ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
+            ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
             ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
             ma.prof = (e->d_prof && n == e->prof_stage) ? e->d_prof + 64 : nullptr;
+            if (!direct) {               // decision + proposal once, by one block
+                Mut2Args mp = ma;
+                mp.pre = nullptr;
+#define SMCMI_CALL(D) k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, rc->n_blocks, h->h_model.n_free, e->d_pre)
+                SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+            }
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profile && h == h0) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_stage.push_back(n); hipEventRecord(e0, h->stream); }
 #define SMCMI_CALL(D) launch_k2_mutate<D>(h, ma, rc->n_blocks, rc->alpha == 1.0)
@@ -354,10 +375,10 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         return 0;
     };
-    auto enq_begin = [&](int n) -> int {
+    auto enq_begin = [&](int n, int spec_expected = 0) -> int {
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
-            k2_begin<<<1, T1, 0, h->stream>>>(h->d_st, h->e2->d_ctl, n, mut_rows(h), h->d_sched, h->rec);
+            k2_begin<<<1, T1, 0, h->stream>>>(h->d_st, h->e2->d_ctl, n, mut_rows(h), h->d_sched, h->rec, spec_expected);
         }
         return 0;
     };
@@ -366,6 +387,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (cert) {
             if (int e = enq_begin(n)) return e;
             if (int e = enq_passes(n, 0, P)) return e;
+            if (int e = enq_K1(n, 1, 0)) return e;
+        } else if (!direct) {              // many blocks per CU: the stage-begin logic once, by one block
+            if (int e = enq_begin(n, adaptive ? 1 : 0)) return e;
             if (int e = enq_K1(n, 1, 0)) return e;
         } else if (int e = enq_K1(n, 0, adaptive ? 1 : 0)) return e;
         if (sel) { if (int e = enq_select(n)) return e; }

@@ -183,33 +183,49 @@ __device__ inline void reduce_rows(const Rows2 &R, double *vt, double *tot, int 
 }
 
 // Virtual-shard totals of a row set with any number of rows (sharded runs and large clouds): block v totals the nr rows of its
-// virtual shard in the canonical order (groups of GRP rows by slice tree, groups in ascending order) -> out[v][m].
+// virtual shard in the canonical order (groups of GRP rows by slice tree, groups in ascending order) -> out[v][m].  Four adjacent
+// lanes share a (group, column pair): each owns two of the eight slices (sixteen unconditional 16-byte loads in flight), the
+// slice tree is finished with two DPP exchanges inside the quad.  m even, <= 72.
 constexpr int RT = 1024;
 __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr, int m, int max_idx, double *out) {
-    __shared__ double gs[16 * 72];                      // 16 group sums x up to 72 columns
-    const int v = blockIdx.x;
+    constexpr int GB = 7;                               // groups per batch: GB * (m / 2) * 4 <= RT for m <= 72
+    __shared__ double gs[GB * 72];
+    const int v = blockIdx.x, mp = m / 2;
     const double *base0 = rows + (long long)v * nr * m;
     const int ng = (nr + GRP - 1) / GRP;
-    double run = (int)threadIdx.x == max_idx ? -__builtin_inf() : 0.0;
-    for (int g0 = 0; g0 < ng; g0 += 16) {
-        const int gb = (ng - g0) < 16 ? (ng - g0) : 16;
-        for (int u = threadIdx.x; u < gb * m; u += RT) {
-            const int idx = u % m, g = g0 + u / m;
-            const bool mx = idx == max_idx;
+    const double ninf = -__builtin_inf();
+    double run = (int)threadIdx.x == max_idx ? ninf : 0.0;
+    for (int g0 = 0; g0 < ng; g0 += GB) {
+        const int gb = (ng - g0) < GB ? (ng - g0) : GB;
+        const int units = gb * mp * 4, u = threadIdx.x;
+        if ((u & ~63) < units) {                        // wave-uniform: idle wavefronts skip the loads
+            const int uc = u < units ? u : 0;
+            const int h = uc & 3, pr = (uc >> 2) % mp, gl = (uc >> 2) / mp, g = g0 + gl;
+            const bool mx0 = 2 * pr == max_idx, mx1 = 2 * pr + 1 == max_idx;
+            const double id0 = mx0 ? ninf : 0.0, id1 = mx1 ? ninf : 0.0;
             const int r_beg = g * GRP, r_end = (r_beg + GRP < nr) ? r_beg + GRP : nr;
-            double a[8];
+            const double2 *base = reinterpret_cast<const double2 *>(base0 + 2 * pr);
+            const long long ldp = m / 2;
+            double a0[2] = {id0, id0}, a1[2] = {id1, id1};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = mx ? -__builtin_inf() : 0.0;
-            const double *base = base0 + idx;
-            for (int r0 = r_beg; r0 < r_end; r0 += 8) {
+            for (int j = 0; j < GRP / 8; ++j) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (r0 + q < r_end) {
-                        const double x = base[(long long)(r0 + q) * m];
-                        a[q] = mx ? fmax(a[q], x) : a[q] + x;
-                    }
+                for (int q = 0; q < 2; ++q) {
+                    const int r = r_beg + 2 * h + q + 8 * j;
+                    const int rc = r < r_end ? r : r_end - 1;
+                    const double2 x = base[(long long)rc * ldp];
+                    const double x0 = r < r_end ? x.x : id0, x1 = r < r_end ? x.y : id1;
+                    a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
+                    a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
+                }
             }
-            gs[(u / m) * 72 + idx] = mx ? slice_tree_max<8>(a) : slice_tree<8>(a);
+            // slices 2h, 2h+1 -> ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) across the quad
+            double p0 = mx0 ? fmax(a0[0], a0[1]) : a0[0] + a0[1], p1 = mx1 ? fmax(a1[0], a1[1]) : a1[0] + a1[1];
+            const double q0 = fetch_xor<1>(p0), q1 = fetch_xor<1>(p1);
+            p0 = mx0 ? fmax(p0, q0) : p0 + q0; p1 = mx1 ? fmax(p1, q1) : p1 + q1;
+            const double r0 = fetch_xor<2>(p0), r1 = fetch_xor<2>(p1);
+            p0 = mx0 ? fmax(p0, r0) : p0 + r0; p1 = mx1 ? fmax(p1, r1) : p1 + r1;
+            if (u < units && h == 0) { gs[gl * 72 + 2 * pr] = p0; gs[gl * 72 + 2 * pr + 1] = p1; }
         }
         __syncthreads();
         if ((int)threadIdx.x < m) {
@@ -333,7 +349,7 @@ __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, c
     b.ess_bar = ess_bar;
     double pd = b.gprime, gp = b.gprime;
     if (have_es) {
-        pd = predict_delta_wave(s_es, po.do_resample != 0, ess_bar, &gp, inv_pre);
+        pd = predict_delta_wave(s_es, po.do_resample != 0, ess_bar, &gp, inv_pre, false);
         const double ec = po.e_center + s_es[1] / s_es[0];         // weighted mean energy: centre for the next epilogue
         if (fabs(ec) < 1e300) b.e_center = ec;
     }
@@ -456,12 +472,12 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
 }
 
 // stage begin as its own launch (certificate path: the solver is armed in DevState::sol[0]); 1 block
-__global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, int n, Rows2 mrows, const double *sched, Records rec) {
+__global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, int n, Rows2 mrows, const double *sched, Records rec, int spec_expected = 0) {
     __shared__ Post2 s_po;
     __shared__ Begin2 s_bg;
     __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[RMUT], s_sw[64];
     __shared__ int s_act;
-    begin2_block<T1>(n, st, ctl, mrows, 0, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act);
+    begin2_block<T1>(n, st, ctl, mrows, spec_expected, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act);
 }
 
 // ------------------------------------------------------------------------------------------------ certificate passes
@@ -599,11 +615,12 @@ struct Rng2 {
     unsigned long long seed;
     long long gid0;
 };
-constexpr int RNG_CHUNKS = 2;      // mutation-block chunks drawn per extra block (correction blocks + extra blocks must fit the 256 CUs at one block each)
+// Extra block `block` of `nblocks` draws the mutation-block chunks block, block + nblocks, ...: the host sizes nblocks so that
+// correction blocks + extra blocks fit the 256 CUs at one block each (this kernel's register budget admits no more).
 template <int D>
-__device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int block, int debug) {
+__device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int block, int nblocks, int debug) {
     const int sub = (ra.nf + ra.nb - 1) / ra.nb;
-    for (int cb = block * RNG_CHUNKS; cb < (block + 1) * RNG_CHUNKS && cb < g.Vl * g.nb2; ++cb) {
+    for (int cb = block; cb < g.Vl * g.nb2; cb += nblocks) {
     long long beg, end;
     vchunk(g, cb / g.nb2, cb % g.nb2, g.t2, beg, end);
     for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
@@ -637,7 +654,7 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
     constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
     if ((int)blockIdx.x >= g.Vl * g.nb1) {               // the idle CUs draw the mutation's random numbers (Rng2)
         // (drawn whether or not the stage goes ahead: a stalled stage is redone with the same numbers)
-        if (ra.zbuf && ctl->ps[(n - 1) & 1].stage == n - 1) rng2_block<D>(g, ra, n, (int)blockIdx.x - g.Vl * g.nb1, 0);
+        if (ra.zbuf && ctl->ps[(n - 1) & 1].stage == n - 1) rng2_block<D>(g, ra, n, (int)blockIdx.x - g.Vl * g.nb1, (int)gridDim.x - g.Vl * g.nb1, 0);
         return;
     }
     __shared__ double red[NW * 64];
@@ -906,6 +923,15 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
 }
 
 // ------------------------------------------------------------------------------------------------ K2: decision + proposal + mutation
+// Decision and proposal of one stage as ONE block computed them (k2_prepare): large clouds run many rounds of mutation blocks per
+// CU, and a prologue every block repeats (row totals, covariance, Cholesky: ~10 µs of latency) then costs more than a launch.
+struct Prop2Glob {
+    int stage, go, rs, pad_;
+    double s1, phi_n, e_center;
+    double Lraw[100], logdet[10], mub[10], sdd[10], sdn[10];
+    int ball[10], bptr[12], loff[10];
+};
+
 struct Mut2Args {
     unsigned long long seed;
     long long gid0;
@@ -913,6 +939,11 @@ struct Mut2Args {
     int sel_enqueued;          // k2_scan / k2_gather were enqueued in front of this launch
     int adaptive;              // leave energy power sums for the next stage's ϕ predictor
     Rows2 cmrows, gmrows;
+    Prop2Glob *pre;            // non-null: the stage's decision / proposal were computed by k2_prepare - load them
+    LikDev lik[2];             // the model's likelihood descriptors (copies of ModelDev::lik: kernel arguments arrive in SGPRs, a
+                               // descriptor read from memory would put two dependent round trips in front of the data loads)
+    int n_steps, store_history, has_other;
+    double alpha, n_parts;
     const double *zbuf;        // random numbers drawn ahead by K1's extra blocks (Rng2 layout) or null
     const double *wt;          // unnormalised weights W̃ of the correction
     double *rows_mut;          // [blocks][RMUT]
@@ -1013,7 +1044,7 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
             double r[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) r[k] = (lane < db && k < db) ? P.A[off + lane * db + k] : 0.0;
-            const bool ok = chol_rows_in_regs<12>(r, db, lane);
+            const bool ok = chol_rows_in_regs<12, true>(r, db, lane);
             if (!ok && lane == 0) *s_fail = 1;
 #pragma unroll
             for (int k = 0; k < 12; ++k)
@@ -1023,7 +1054,9 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
             for (int k = 0; k < 12; ++k) dg = (k == lane) ? r[k] : dg;
             const double lg = (lane < db) ? log(dg) : 0.0;
             double ld = 0.0;
-            for (int i = 0; i < db; ++i) ld += __shfl(lg, i, 64);
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < db) ld += bcast_lane(lg, i);
             if (lane == 0) { P.logdet[b] = 2.0 * ld; P.loff[b] = off; }
         }
     }
@@ -1146,11 +1179,11 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
     const Mut2Lds<D> L(sm);
     const int tid = threadIdx.x, n = ma.n;
     K2_STAMP(ma.prof, 0);
-    const int n_steps = st->rp.n_mh_steps;
-    const double c_alpha = st->rp.alpha, nrm_N = (double)st->rp.n_parts;
-    const int nrm_hist = st->rp.store_history;
-    const LikDev ld0 = md->lik[0], ld1 = md->lik[1];
-    const int has_other = md->has_other_priors;
+    const int n_steps = ma.n_steps;
+    const double c_alpha = ma.alpha, nrm_N = ma.n_parts;
+    const int nrm_hist = ma.store_history;
+    const LikDev &ld0 = ma.lik[0], &ld1 = ma.lik[1];
+    const int has_other = ma.has_other;
     double *Ls = L.Ls, *mu_s = L.mu_s, *sdd_s = L.sdd_s, *sdn_s = L.sdn_s, *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
     double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
     int *ball_s = L.ball_s, *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
@@ -1199,8 +1232,27 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
         for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * g.n];
     } else if constexpr (PREDRAW) draw2<D>(ma.seed, pid, (unsigned)n, 0u, nb == 1 ? nf : (nf + nb - 1) / nb, ma.debug, step_prob, uc, z);
     int rs = 0;
-    if (!k2_prologue<D, T>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;
-    const double phi_n = S.bg.phi_n, e_center = S.bg.e_center, nrm_sumw = L.s_tot[0];
+    double phi_n, e_center, nrm_sumw;
+    if (ma.pre) {
+        // decision and proposal from k2_prepare: model constants + the proposal's arrays into LDS, one barrier
+        const Prop2Glob *G = ma.pre;
+        const int pstage = G->stage, pgo = G->go;
+        rs = G->rs; nrm_sumw = G->s1; phi_n = G->phi_n; e_center = G->e_center;
+        for (int k = tid; k < D; k += T) {
+            L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
+            L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
+        }
+        for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
+        for (int e = tid; e < nf * nf; e += T) Lraw[e] = G->Lraw[e];
+        for (int e = tid; e < nf; e += T) { mub_raw[e] = G->mub[e]; sdd_raw[e] = G->sdd[e]; sdn_raw[e] = G->sdn[e]; ball_raw[e] = G->ball[e]; }
+        for (int b = tid; b < nb; b += T) { loff_s[b] = G->loff[b]; logdet_s[b] = G->logdet[b]; }
+        for (int b = tid; b <= nb; b += T) bptr_s[b] = G->bptr[b];
+        if (pstage != n || !pgo) return;
+        __syncthreads();
+    } else {
+        if (!k2_prologue<D, T>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;
+        phi_n = S.bg.phi_n; e_center = S.bg.e_center; nrm_sumw = L.s_tot[0];
+    }
     const unsigned stage = (unsigned)n;
     if (rs) {                       // the resampled cloud is in buffer 1 (k2_gather)
 #pragma unroll
@@ -1427,8 +1479,26 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
         row[RMAX_IDX] = m;
     }
     K2_STAMP(ma.prof, 10);
-    if (blockIdx.x == 0) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);
+    if (blockIdx.x == 0 && !ma.pre) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);
     K2_STAMP(ma.prof, 11);
+}
+
+// Decision, bookkeeping and proposal of stage n by one block (large clouds, sharded runs): K2's prologue as its own launch.
+template <int D>
+__global__ void __launch_bounds__(256) k2_prepare(DevState *st, Ctl2 *ctl, const ModelDev *md, Mut2Args ma, int nb, int nf, Prop2Glob *out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ Mut2Stage S;
+    const Mut2Lds<D> L(sm);
+    const int tid = threadIdx.x, n = ma.n;
+    int rs = 0;
+    ma.pre = nullptr;
+    if (!k2_prologue<D, 256>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;      // (a stall leaves out->stage stale: K2 does nothing)
+    for (int e = tid; e < nf * nf; e += 256) out->Lraw[e] = L.Lraw[e];
+    for (int e = tid; e < nf; e += 256) { out->mub[e] = L.mub_raw[e]; out->sdd[e] = L.sdd_raw[e]; out->sdn[e] = L.sdn_raw[e]; out->ball[e] = L.ball_raw[e]; }
+    for (int b = tid; b < nb; b += 256) { out->loff[b] = L.loff_s[b]; out->logdet[b] = L.logdet_s[b]; }
+    for (int b = tid; b <= nb; b += 256) out->bptr[b] = L.bptr_s[b];
+    if (tid == 0) { out->rs = rs; out->s1 = L.s_tot[0]; out->phi_n = S.bg.phi_n; out->e_center = S.bg.e_center; out->go = 1; out->stage = n; }
+    k2_bookkeeping<D, 256>(st, ctl, ma, L, &S, rs);
 }
 
 }  // namespace smcmi
