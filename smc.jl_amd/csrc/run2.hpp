@@ -50,7 +50,7 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     // blocks (one per CU) resident at once
     g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= 256) ? 1 : 0;
     if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
-    if (!g.direct || getenv("SMCMI_E2_T256")) {                                      // large clouds / several handles: 256-thread mutation blocks (3 wavefronts per SIMD)
+    if (!g.direct) {                                      // large clouds / several handles: 256-thread mutation blocks (3 wavefronts per SIMD)
         g.t2 = 256;
         g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
         if (g.direct && g.nb2 > GRP) g.direct = 0;
@@ -230,12 +230,12 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return direct ? Rows2{rows, g0.Vl, nr, m} : Rows2{vt, g0.V, 1, m};
     };
     // total this handle's rows per virtual shard and (several handles) all-gather the V x m totals
-    auto publish = [&](double *Eng2::*rows, double *Eng2::*vt, int nr, int m, int max_idx) -> int {
+    auto publish = [&](double *Eng2::*rows, double *Eng2::*vt, int nr, int m, int max_idx, int pair = 0) -> int {
         if (direct) return 0;
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             Eng2 *e = h->e2;
-            k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->*rows, nr, m, max_idx, e->*vt + (size_t)e->g.v0 * m);
+            k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->*rows, nr, m, max_idx, e->*vt + (size_t)e->g.v0 * m, pair);
         }
         if (!multi) return 0;
         return g.allgather([=](smcmi_handle *h) { return (const double *)(h->e2->*vt + (size_t)h->e2->g.v0 * m); },
@@ -246,7 +246,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             Eng2 *e = h->e2;
-            k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->rows_pass[slot], e->g.nb1, 2 * KC, -1, e->vt_pass + (size_t)e->g.v0 * 2 * KC);
+            k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->rows_pass[slot], e->g.nb1, 2 * KC, -1, e->vt_pass + (size_t)e->g.v0 * 2 * KC, 0);
         }
         if (!multi) return 0;
         return g.allgather([=](smcmi_handle *h) { return (const double *)(h->e2->vt_pass + (size_t)h->e2->g.v0 * 2 * KC); },
@@ -260,7 +260,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         HIP_TRY(hipSetDevice(h->cfg.device));
         k2_energy_max<<<g0.Vl * g0.nb2, g0.t2, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
     }
-    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX)) return e;
+    // (mutation rows of 256-thread blocks are paired: the canonical row stands for 512 particles, whatever the block size)
+    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256)) return e;
 
     const bool profile = rc->use_graph == 2;
     std::vector<hipEvent_t> evs;
@@ -355,7 +356,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 #undef SMCMI_CALL
             if (e1) hipEventRecord(e1, h->stream);
         }
-        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX);
+        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256);
     };
     auto enq_passes = [&](int n, int p0, int P) -> int {           // passes p0 .. P-1, then the closing decision
         for (int p = p0; p < P; ++p) {

@@ -187,11 +187,14 @@ __device__ inline void reduce_rows(const Rows2 &R, double *vt, double *tot, int 
 // lanes share a (group, column pair): each owns two of the eight slices (sixteen unconditional 16-byte loads in flight), the
 // slice tree is finished with two DPP exchanges inside the quad.  m even, <= 72.
 constexpr int RT = 1024;
-__global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr, int m, int max_idx, double *out) {
+// pair = 1 (mutation rows written by 256-thread blocks): a logical row is raw row 2r + raw row 2r+1 - the row a 512-thread
+// block over the same particles writes (block_reduce_es2).
+__global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
     constexpr int GB = 7;                               // groups per batch: GB * (m / 2) * 4 <= RT for m <= 72
     __shared__ double gs[GB * 72];
     const int v = blockIdx.x, mp = m / 2;
-    const double *base0 = rows + (long long)v * nr * m;
+    const double *base0 = rows + (long long)v * nr_raw * m;
+    const int nr = pair ? (nr_raw + 1) / 2 : nr_raw;
     const int ng = (nr + GRP - 1) / GRP;
     const double ninf = -__builtin_inf();
     double run = (int)threadIdx.x == max_idx ? ninf : 0.0;
@@ -213,7 +216,14 @@ __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr, int 
                 for (int q = 0; q < 2; ++q) {
                     const int r = r_beg + 2 * h + q + 8 * j;
                     const int rc = r < r_end ? r : r_end - 1;
-                    const double2 x = base[(long long)rc * ldp];
+                    double2 x;
+                    if (pair) {                         // (uniform condition; both loads unconditional)
+                        const int ra = 2 * rc, rb = 2 * rc + 1 < nr_raw ? 2 * rc + 1 : ra;
+                        const double2 xa = base[(long long)ra * ldp], xb = base[(long long)rb * ldp];
+                        const bool hb = 2 * rc + 1 < nr_raw;
+                        x.x = mx0 ? fmax(xa.x, hb ? xb.x : id0) : xa.x + (hb ? xb.x : 0.0);
+                        x.y = mx1 ? fmax(xa.y, hb ? xb.y : id1) : xa.y + (hb ? xb.y : 0.0);
+                    } else x = base[(long long)rc * ldp];
                     const double x0 = r < r_end ? x.x : id0, x1 = r < r_end ? x.y : id1;
                     a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
                     a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
@@ -251,6 +261,28 @@ __device__ inline double block_reduce_nw(double (&a)[M], double *red) {
     if ((int)threadIdx.x < M) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) tot += red[w * M + threadIdx.x];
+    }
+    __syncthreads();
+    return tot;
+}
+
+// Block-wide fixed-order reduction of the ES = 32 epilogue sums for a mutation block of NW = 4 or 8 wavefronts.  A row stands
+// for 256 particles = four wavefronts summed in wavefront order; an 8-wavefront block adds its two halves, which is exactly how
+// the rows of two 4-wavefront blocks over the same particles are paired by k2_reduce - the canonical order does not depend on
+// the block size.  red: NW * ES doubles of LDS; thread t < ES gets total t.
+template <int NW>
+__device__ inline double block_reduce_es2(double (&a)[ES], double *red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Butterfly<ES / 2, 32>::run(a, lane);
+    constexpr int SH = 6 - ilog2(ES);
+    __syncthreads();
+    if ((lane & ((1 << SH) - 1)) == 0) red[wave * ES + (lane >> SH)] = a[0];
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < ES) {
+        const int t = threadIdx.x;
+        tot = ((red[t] + red[ES + t]) + red[2 * ES + t]) + red[3 * ES + t];
+        if constexpr (NW == 8) tot += ((red[4 * ES + t] + red[5 * ES + t]) + red[6 * ES + t]) + red[7 * ES + t];
     }
     __syncthreads();
     return tot;
@@ -1457,7 +1489,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
         double es[ES];
         energy_terms(es, w_part, like, like_prev, e_center, live, rs != 0);
         es[EACC] = acc_val;
-        const double tot = block_reduce_es(es, l_dat, T / 64);       // likelihood data in LDS is dead by now
+        const double tot = block_reduce_es2<T / 64>(es, l_dat);      // likelihood data in LDS is dead by now
         if (tid < ES) row[tid] = tot;
     } else {
         double a1[1] = {acc_val};
@@ -1465,9 +1497,8 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
         if ((tid & 63) == 0) red[tid >> 6] = a1[0];
         __syncthreads();
         if (tid < ES) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int w = 0; w < T / 64; ++w) sacc += red[w];
+            double sacc = ((red[0] + red[1]) + red[2]) + red[3];
+            if constexpr (T == 512) sacc += ((red[4] + red[5]) + red[6]) + red[7];
             row[tid] = tid == EACC ? sacc : 0.0;
         }
     }

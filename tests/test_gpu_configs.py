@@ -1,0 +1,170 @@
+"""BASELINE configs at their full sizes on one MI355X, and the shard-count invariance SURVEY §8(e) asks of config 3:
+the same seed must give the identical ϕ schedule, ancestors and cloud on 1, 2, 4 and 8 shards.
+
+Engine 2 (csrc/stage2.hpp) totals every per-block quantity per *virtual shard* (8 fixed global particle ranges) in a canonical
+order, so a handle that holds 8, 4, 2 or 1 virtual shards produces the same bits.  The in-process group driver runs exactly the
+code of the RCCL driver with device copies instead of ncclAllGather / ncclSend / ncclRecv (one GPU is all a gpurun box has).
+Every run here goes through the C ABI (smcmi_run / smcmi_run_group); the oracle is only the checker."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import models
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import json, os, sys, hashlib
+import numpy as np
+sys.path.insert(0, %(root)r)
+from smc_jl_amd import Engine, run_group
+from tests import models
+n, d, seed, worlds, kw = %(n)d, %(d)d, %(seed)d, %(worlds)r, %(kw)r
+spec = models.gauss_spec(d)
+out = {}
+for world in worlds:
+    nl = n // world
+    engs = []
+    for r in range(world):
+        e = Engine(n, d, seed=seed, max_stages=1500, store_history=False, n_local=nl, gid0=r * nl)
+        e.set_model(spec)
+        e.init_from_prior()
+        engs.append(e)
+    res = run_group(engs, **kw) if world > 1 else engs[0].run(**kw)
+    rec = engs[0].stage_records(res["n_stages"])
+    cloud = np.concatenate([e.download_cloud() for e in engs], axis=0)
+    anc = np.concatenate([e.last_ancestors() for e in engs]) if hasattr(engs[0], "last_ancestors") else np.zeros(0)
+    out[str(world)] = dict(n_stages=res["n_stages"], resamples=res["resamples"], logmdd=res["logmdd"].hex() if hasattr(res["logmdd"], "hex") else float(res["logmdd"]).hex(),
+                           schedule=hashlib.sha256(np.ascontiguousarray(rec["schedule"]).tobytes()).hexdigest(),
+                           ess=hashlib.sha256(np.ascontiguousarray(rec["ess"]).tobytes()).hexdigest(),
+                           accept=hashlib.sha256(np.ascontiguousarray(rec["accept_hist"]).tobytes()).hexdigest(),
+                           cloud=hashlib.sha256(np.ascontiguousarray(cloud).tobytes()).hexdigest(),
+                           mean0=float(cloud[:, 0].mean()), stalls=[res.get("solver_stalls", 0), res.get("select_stalls", 0), res.get("spec_stalls", 0)])
+    for e in engs:
+        e.close()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _invariance(n, d, seed, worlds, kw, extra_env=None):
+    env = dict(os.environ, SMCMI_ENGINE="2")          # world = 1 takes engine 2 as well (the default there is size-dependent)
+    env.update(extra_env or {})
+    code = _WORKER % dict(root=ROOT, n=n, d=d, seed=seed, worlds=list(worlds), kw=kw)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+@pytest.mark.parametrize("kw", [
+    dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=2, alpha=0.9),
+    dict(use_fixed_schedule=True, n_phi=60, n_mh_steps=2),
+    dict(use_fixed_schedule=False, tempering_target=0.97, resampling_method="multinomial"),
+])
+def test_results_do_not_depend_on_the_shard_count(kw):
+    """1, 2, 4 and 8 in-process shards of one population: bit-identical schedule, ESS path, acceptance rates, log-MDD and cloud
+    (hence identical ancestors on every resample stage: a differing ancestor would show in the cloud)."""
+    out = _invariance(40000, 6, 13, (1, 2, 4, 8), kw)
+    ref = out["1"]
+    assert ref["resamples"] >= 2 and ref["n_stages"] > 10
+    for w in ("2", "4", "8"):
+        for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+            assert out[w][key] == ref[key], (w, key, out[w], ref)
+
+
+def test_direct_and_reduced_geometry_agree_bitwise():
+    """One handle: every block totalling the per-block rows itself (small clouds) and the k2_reduce / one-block set-up path used
+    for large clouds and shards are two implementations of the same canonical order."""
+    kw = dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=2, alpha=0.9)
+    a = _invariance(40000, 6, 13, (1,), kw)["1"]
+    b = _invariance(40000, 6, 13, (1,), kw, extra_env={"SMCMI_E2_REDUCED": "1"})["1"]
+    for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+        assert a[key] == b[key], key
+
+
+def test_config3_workload_on_eight_shards_equals_one_handle():
+    """BASELINE config 3's workload (10-dim Gaussian, adaptive ϕ, 0.97) sharded over 8 handles of one process vs one handle: the
+    same bits, the analytic log-MDD within Monte-Carlo error."""
+    n = 400000                        # 50 000 per shard (config 3 itself is 125 000 per GPU: bench.py --gpus 8)
+    kw = dict(use_fixed_schedule=False, tempering_target=0.97, n_phi=300)
+    out = _invariance(n, 10, 1, (1, 8), kw)
+    for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+        assert out["8"][key] == out["1"][key], key
+    assert abs(float.fromhex(out["1"]["logmdd"]) - models.gauss_logmdd(10)) < 0.1
+    assert abs(out["1"]["mean0"] - (-1.0) * 25 / 25.0625) < 0.01
+
+
+def test_config2_workload_at_one_million_particles():
+    """Config 2's workload at 10x its size on one GPU against the CPU oracle on the same Philox streams: identical stage and
+    resample counts, ϕ and ESS paths to 1e-9, log-MDD to 1e-9 (the tolerance north_star states is 1e-3)."""
+    from oracle import oracle as orc
+    from smc_jl_amd import Engine
+
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    n = 1_000_000
+    spec = models.gauss_spec(10)
+    eng = Engine(n, 10, seed=1, max_stages=1500, store_history=False)
+    eng.set_model(spec)
+    eng.init_from_prior()
+    P0 = eng.download_cloud()
+    kw = dict(use_fixed_schedule=False, tempering_target=0.97, n_phi=300, lam=2.1)
+    r = eng.run(**kw)
+    rec = eng.stage_records(r["n_stages"])
+    P = eng.download_cloud()
+    eng.close()
+    # size-independent properties
+    assert rec["schedule"][0] == 0.0 and rec["schedule"][-1] == 1.0 and np.all(np.diff(rec["schedule"]) > 0)
+    assert np.all(rec["ess"] > 0) and np.all(rec["ess"] <= n * (1 + 1e-12))
+    assert abs(r["logmdd"] - models.gauss_logmdd(10)) < 0.05
+    w = P[:, -1]
+    assert abs(w.sum() - n) < 1e-6 * n
+    assert abs((P[:, 0] * w).sum() / w.sum() - (-1.0) * 25 / 25.0625) < 0.005
+    ro = orc.smc_run(models.oracle_model(spec), P0, seed=1, n_threads=os.cpu_count(), history=False, max_stages=1500, **kw)
+    assert r["n_stages"] == ro["n_stages"] and r["resamples"] == ro["resamples"]
+    np.testing.assert_allclose(rec["schedule"], ro["schedule"], rtol=1e-9)
+    np.testing.assert_allclose(rec["ess"], ro["ess"], rtol=1e-9)
+    assert abs(r["logmdd"] - ro["logmdd"]) < 1e-9
+
+
+def test_config5_at_fifty_thousand_particles_and_on_four_shards():
+    """Config 5 (13-parameter state-space model, Kalman-filter likelihood, old 40 -> new 80 periods) at its full N = 50 000:
+    properties of the run, and 4 in-process shards against the single handle."""
+    from smc_jl_amd import Engine, run_group
+
+    sp = models.kalman_spec(T=80, old_T=40)
+    n = 50_000
+    kw = dict(n_phi=100, use_fixed_schedule=False, tempering_target=0.95, n_blocks=1, alpha=0.9)
+    e1 = Engine(n, 13, seed=1, max_stages=600, store_history=False)
+    e1.set_model(sp)
+    e1.init_from_prior()
+    P0 = e1.download_cloud()
+    r1 = e1.run(**kw)
+    rec = e1.stage_records(r1["n_stages"])
+    P1 = e1.download_cloud()
+    e1.close()
+    assert rec["schedule"][-1] == 1.0 and np.all(np.diff(rec["schedule"]) > 0)
+    assert np.all(np.isfinite(P1)) and r1["resamples"] >= 1
+    w = P1[:, -1]
+    assert abs(w.sum() - n) < 1e-6 * n
+    mu = (P1[:, :13] * w[:, None]).sum(0) / w.sum()
+    assert abs(mu[12] - 1.0) < 0.5                       # measurement mean of the data-generating process
+    assert np.all(P1[:, :8] >= -0.95) and np.all(P1[:, :8] <= 0.95)
+    shards = []
+    for k in range(4):
+        e = Engine(n, 13, seed=1, n_local=n // 4, gid0=k * (n // 4), max_stages=600, store_history=False)
+        e.set_model(sp)
+        e.upload_cloud(P0[k * (n // 4):(k + 1) * (n // 4)])
+        shards.append(e)
+    r4 = run_group(shards, **kw)
+    P4 = np.vstack([e.download_cloud() for e in shards])
+    for e in shards:
+        e.close()
+    assert r1["n_stages"] == r4["n_stages"] and r1["resamples"] == r4["resamples"]
+    assert r4["logmdd"] == pytest.approx(r1["logmdd"], abs=1e-7)
+    same = np.all(np.abs(P1 - P4) <= 1e-8 * (1 + np.abs(P1)), axis=1)
+    assert same.mean() > 0.99          # (n_para = 13 runs on engine 1: shard sums differ by rounding, a handful of MH decisions may flip)
