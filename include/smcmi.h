@@ -31,7 +31,8 @@ extern "C" {
 #define SMCMI_MAX_CAND 16      /* tempering candidates evaluated per ESS pass */
 
 enum { SMCMI_OK = 0, SMCMI_ERR_ARG = -1, SMCMI_ERR_HIP = -2, SMCMI_ERR_NAN_ESS = -3, SMCMI_ERR_POSDEF = -4,
-       SMCMI_ERR_CAPACITY = -5, SMCMI_ERR_BRACKET = -6, SMCMI_ERR_UNSUPPORTED = -7, SMCMI_ERR_STATE = -8 };
+       SMCMI_ERR_CAPACITY = -5, SMCMI_ERR_BRACKET = -6, SMCMI_ERR_UNSUPPORTED = -7, SMCMI_ERR_STATE = -8,
+       SMCMI_ERR_CALLBACK = -9 };
 
 /* prior families: Distributions.jl / ModelConstructors priors reachable from `prior(parameters)` (src/mutation.jl:95) */
 enum { SMCMI_PRIOR_NORMAL = 0, SMCMI_PRIOR_UNIFORM = 1, SMCMI_PRIOR_GAMMA = 2, SMCMI_PRIOR_BETA = 3,
@@ -123,6 +124,22 @@ int smcmi_set_parameters(smcmi_handle *h, const int32_t *fixed, const double *lo
 int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const double *par, int64_t n_par,
                          const double *data, int64_t rows, int64_t cols, const double *aux, int64_t aux_rows,
                          int64_t aux_cols);
+
+/* ---- user likelihood on the host: the reference's `loglikelihood::Function` argument of smc() (src/smc_main.jl:118), called
+   inside mutation() after update!/prior (src/mutation.jl:93-121).  Batch form: theta is m x d column-major (proposal k =
+   theta[k + m*j], j < d) holding only proposals that passed the bounds check; write out[k] = log-likelihood (-Inf allowed, NaN is
+   taken as -Inf like the reference's try/catch); return 0, anything else aborts smcmi_run with SMCMI_ERR_CALLBACK.  Invoked
+   synchronously on the thread that called smcmi_run / smcmi_initialize_likelihoods / smcmi_eval_cloud_callback, once per MH step x
+   block (twice with an old-data callback), never from another thread.  which = SMCMI_WHICH_NEW: loglikelihood(parameters, data);
+   SMCMI_WHICH_OLD: old_loglikelihood(parameters, old_data) (tempered updates; leave unset when old_data is empty).  fn = NULL
+   unregisters.  With a callback registered smcmi_run keeps ϕ solver, correction, selection, moments, proposal and the MH decision
+   on the device and ships only the n x d proposals and the n log-likelihoods across PCIe per step. */
+typedef int (*smcmi_lik_callback)(const double *theta, int64_t m, int64_t d, double *out, void *user_data);
+int smcmi_set_likelihood_callback(smcmi_handle *h, int32_t which, smcmi_lik_callback fn, void *user_data);
+/* loglh (column = n_para, which = NEW) or old_loglh (column = n_para + 2, which = OLD) of the uploaded cloud from the callback:
+   rows whose logprior column is -Inf are skipped (-Inf).  For initial clouds drawn by the caller (initial_draw!). */
+int smcmi_eval_cloud_callback(smcmi_handle *h, int32_t which, int32_t column);
+int smcmi_callback_stats(smcmi_handle *h, int64_t *calls, int64_t *evaluations);   /* of the last smcmi_run */
 
 /* ---- cloud transfer (cloud.particles; get_vals/get_loglh/... read columns of the download) ---- */
 int smcmi_upload_cloud(smcmi_handle *h, const double *particles);       /* n_local x R, column-major */

@@ -1,0 +1,211 @@
+// callback.hpp - smcmi_run for a USER likelihood on the host (included by smcmi.hip).
+//
+// The reference's entry point takes a closure: smc(loglikelihood::Function, parameters, data; ...) (src/smc_main.jl:118) evaluated
+// per proposal inside mutation() (src/mutation.jl:93-121).  With smcmi_set_likelihood_callback the device loop keeps everything
+// but that evaluation: ϕ solver, correction, selection, moments, proposal and the Metropolis-Hastings decision stay HIP kernels;
+// per MH step x block the n x d proposals come to the host once (k_mutate<1>), the callback is invoked ONCE on the batch of
+// proposals that passed the bounds check (the reference never calls the likelihood on a vector update! rejected, mutation.jl:93),
+// synchronously on the thread that called smcmi_run (Julia @cfunction safety), and the log-likelihoods go back for the decision
+// (k_mutate<2>).  Contract of the callback (include/smcmi.h): out[k] = log-likelihood of theta[k + n * j], j < d; -Inf allowed
+// (mutation.jl:102-104); a non-zero return aborts the run with SMCMI_ERR_CALLBACK.
+#pragma once
+
+struct CallbackBuffers {
+    double *h_prop = nullptr, *h_lp = nullptr, *h_pack = nullptr, *h_lik[2] = {nullptr, nullptr}, *h_out = nullptr;
+    long long *h_idx = nullptr;
+    long long n = 0;
+    int d = 0;
+};
+static void free_callback_buffers(CallbackBuffers *b) {
+    if (!b) return;
+    void *ptrs[] = {b->h_prop, b->h_lp, b->h_pack, b->h_lik[0], b->h_lik[1], b->h_out, b->h_idx};
+    for (void *p : ptrs)
+        if (p) hipHostFree(p);
+    delete b;
+}
+static int ensure_callback_buffers(smcmi_handle *h) {
+    if (h->cbuf && h->cbuf->n == h->n && h->cbuf->d == h->d) return 0;
+    if (h->cbuf) { free_callback_buffers(h->cbuf); h->cbuf = nullptr; }
+    CallbackBuffers *b = new CallbackBuffers();
+    b->n = h->n; b->d = h->d;
+    const size_t n = (size_t)h->n, d = (size_t)h->d;
+    if (hipHostMalloc((void **)&b->h_prop, n * d * 8) != hipSuccess || hipHostMalloc((void **)&b->h_lp, n * 8) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_pack, n * d * 8) != hipSuccess || hipHostMalloc((void **)&b->h_lik[0], n * 8) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_lik[1], n * 8) != hipSuccess || hipHostMalloc((void **)&b->h_out, n * 8) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_idx, n * 8) != hipSuccess) {
+        free_callback_buffers(b);
+        return set_err(SMCMI_ERR_HIP, "hipHostMalloc failed (callback staging buffers)");
+    }
+    h->cbuf = b;
+    return 0;
+}
+
+// evaluate callback `which` on the rows of theta (n x d, column-major, leading dimension n) whose `gate` is finite; others get -Inf
+static int eval_callback(smcmi_handle *h, int which, const double *theta, const double *gate, double *lik_out) {
+    CallbackBuffers *b = h->cbuf;
+    const long long n = h->n;
+    const int d = h->d;
+    long long m = 0;
+    for (long long i = 0; i < n; ++i)
+        if (!gate || gate[i] != -HUGE_VAL) b->h_idx[m++] = i;
+    for (int j = 0; j < d; ++j) {
+        const double *col = theta + (long long)j * n;
+        double *dst = b->h_pack + (long long)j * m;
+        for (long long k = 0; k < m; ++k) dst[k] = col[b->h_idx[k]];
+    }
+    if (m > 0) {
+        const int rc = h->cb[which](b->h_pack, (int64_t)m, (int64_t)d, b->h_out, h->cb_ud[which]);
+        if (rc != 0) return set_err(SMCMI_ERR_CALLBACK, "the likelihood callback returned " + std::to_string(rc));
+    }
+    for (long long i = 0; i < n; ++i) lik_out[i] = -HUGE_VAL;
+    for (long long k = 0; k < m; ++k) {
+        const double v = b->h_out[k];
+        lik_out[b->h_idx[k]] = (v != v) ? -HUGE_VAL : v;          // NaN: the reference's `try ... catch` turns a failed evaluation into -Inf
+    }
+    h->cb_calls += 1; h->cb_evals += m;
+    return 0;
+}
+
+// all MH steps x blocks of one stage's mutation with the host callback (src/mutation.jl:56-138); the proposal was set up by
+// k_prepare_mutation of this stage
+static int host_mutation(smcmi_handle *h, const smcmi_run_config *rc, bool tempered) {
+    CallbackBuffers *b = h->cbuf;
+    const long long n = h->n;
+    const int d = h->d;
+    if (ensure_split_buffers(h)) return SMCMI_ERR_HIP;
+    for (int step = 0; step < rc->n_mh_steps; ++step)
+        for (int blk = 0; blk < rc->n_blocks; ++blk) {
+            MutArgs ma{};
+            ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.proposals = h->d_prop; ma.prop_logprior = h->d_prop_lp;
+            ma.prop_qdiff = h->d_prop_q; ma.acc_count = h->d_acc_count; ma.block = blk; ma.step = step;
+            k_mutate<1><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
+            HIP_TRY(hipMemcpyAsync(b->h_prop, h->d_prop, sizeof(double) * n * d, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(b->h_lp, h->d_prop_lp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (int e = eval_callback(h, 0, b->h_prop, b->h_lp, b->h_lik[0])) return e;
+            if (tempered) { if (int e = eval_callback(h, 1, b->h_prop, b->h_lp, b->h_lik[1])) return e; }
+            HIP_TRY(hipMemcpyAsync(h->d_lik_new, b->h_lik[0], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+            if (tempered) HIP_TRY(hipMemcpyAsync(h->d_lik_old, b->h_lik[1], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+            ma.lik_new = h->d_lik_new; ma.lik_old_new = tempered ? h->d_lik_old : nullptr;
+            ma.last = (step == rc->n_mh_steps - 1 && blk == rc->n_blocks - 1) ? 1 : 0;
+            k_mutate<2><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
+        }
+    return 0;
+}
+
+// loglh (and old_loglh) columns of the handle's cloud from the callbacks: initial clouds whose parameter columns were uploaded
+// without likelihood values (`smcmi_eval_cloud_callback`), and initialize_likelihoods! (src/initialization.jl:153-186)
+static int callback_fill_loglh(smcmi_handle *h, int which, int column) {
+    if (int e = ensure_callback_buffers(h)) return e;
+    CallbackBuffers *b = h->cbuf;
+    const long long n = h->n;
+    const int d = h->d;
+    HIP_TRY(hipMemcpyAsync(b->h_prop, h->cl.buf[0], sizeof(double) * n * d, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_lp, h->cl.buf[0] + (long long)(d + 1) * n, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));   // logprior: -Inf = out of bounds
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int e = eval_callback(h, which, b->h_prop, b->h_lp, b->h_lik[0])) return e;
+    HIP_TRY(hipMemcpyAsync(h->cl.buf[0] + (long long)column * n, b->h_lik[0], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// The whole loop with host likelihoods: engine 1's full stage (src/smc_main.jl:377-508 in its kernel sequence) up to the proposal
+// set-up, the callback mutation, one host sync per stage (the callback needs the proposals on the host anyway).
+static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
+    const int nf = h->h_model.n_free;
+    if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
+        return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
+    if (rc->n_phi < 2 || rc->n_mh_steps < 1) return set_err(SMCMI_ERR_ARG, "bad n_phi / n_mh_steps");
+    if (rc->resampling_method != SMCMI_RESAMPLE_SYSTEMATIC && rc->resampling_method != SMCMI_RESAMPLE_MULTINOMIAL)
+        return set_err(SMCMI_ERR_ARG, "Invalid resampler in SMC. Options are systematic or multinomial");
+    const bool adaptive = !rc->use_fixed_schedule;
+    const bool tempered = h->cb[1] != nullptr;
+    if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
+    if (int e = ensure_callback_buffers(h)) return e;
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    std::vector<double> sched(rc->n_phi);
+    for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
+    if (upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
+    DevState &s = h->h_st;
+    RunParams rp{};
+    rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
+    rp.resampling_method = rc->resampling_method; rp.use_fixed_schedule = rc->use_fixed_schedule;
+    rp.threshold = rc->threshold_ratio * (double)h->cfg.n_parts;
+    rp.alpha = rc->alpha; rp.target = rc->target; rp.tempering_target = rc->tempering_target;
+    rp.pw = rc->tempered_update_prior_weight; rp.logp_old = rc->log_prob_old_data;
+    rp.max_stages = h->cfg.max_stages; rp.store_history = h->cfg.store_history;
+    rp.stall_on_exhaust = 1;
+    rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
+    rp.stop_stage = rc->stop_after_stage > 0 ? rc->stop_after_stage : 0;
+    const bool cont = rc->continue_run != 0;
+    if (cont) {
+        if (s.stage < 1 || s.stage >= h->cfg.max_stages) return set_err(SMCMI_ERR_STATE, "no loop state to continue from");
+        if (s.phi_n >= 1.0) return set_err(SMCMI_ERR_STATE, "the run to continue has already reached phi = 1");
+        s.rp = rp; s.done = 0; s.err = 0; s.skip_fold = 1; s.do_resample = 0;
+    } else {
+        const int cur = s.cur;
+        memset(&s, 0, sizeof(DevState));
+        s.rp = rp; s.cur = cur;
+        s.stage = 1; s.j = 2;
+        s.c = rc->c; s.accept = rc->target;
+        s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;
+    }
+    const int base = cont ? s.stage - 1 : 0;
+    if (push_state(h)) return SMCMI_ERR_HIP;
+    if (!cont) {
+        const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};
+        HIP_TRY(hipMemcpyAsync(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->rec.accept, &v0[3], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages, h->stream));
+        if (h->cfg.store_history) {
+            HIP_TRY(hipMemsetAsync(h->d_hist_w, 0, sizeof(double) * h->n, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->rng_ahead = false;
+    const int acc_nb = h->nb_mut;                       // the split kernels are the generic (LDS) mutation kernels
+    k_energy_max<<<acc_nb, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
+    const int first_passes = std::max(rc->solver_passes, FIRST_SOLVER_PASSES);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int max_iter = (adaptive ? h->cfg.max_stages : rc->n_phi - 1) - base;
+    h->cb_calls = 0; h->cb_evals = 0;
+    res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0;
+    int launched = 0, done = 0, had = first_passes;
+    DevState head;
+    constexpr size_t head_off = offsetof(DevState, stage), head_len = offsetof(DevState, ess) - offsetof(DevState, stage);
+    while (launched < max_iter && !done) {
+        // the stage up to the proposal set-up (no mutation kernel: host_mutation below); no energy sums exist for a predictor
+        enqueue_stage(h, adaptive, first_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, false, false, false, false, true);
+        had = first_passes;
+        for (;;) {
+            HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            done = head.done;
+            if (done != 2) break;
+            // the solver ran out of passes: continue the same search with more (smcmi_run)
+            const int zero = 0;
+            HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            enqueue_stage(h, adaptive, 8, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, had, false, false, false, false, true);
+            had += 8;
+            res->solver_stalls += 1;
+        }
+        if (done) break;                                 // ϕ = 1 was reached by the previous stage (its begin raised the flag), a pause, or an error
+        if (int e = host_mutation(h, rc, tempered)) return e;
+        ++launched;
+    }
+    k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
+    if (pull_state(h)) return SMCMI_ERR_HIP;
+    const auto t1 = std::chrono::steady_clock::now();
+    res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;
+    res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
+    res->seconds = std::chrono::duration<double>(t1 - t0).count();
+    res->solver_passes = s.solver_passes;
+    res->paused = (s.done == 5) ? 1 : 0;
+    h->last_n_stages = s.stage;
+    if (s.err) return err_from_state(s.err);
+    if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
+    return 0;
+}

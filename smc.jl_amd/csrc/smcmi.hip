@@ -25,6 +25,8 @@
 using namespace smcmi;
 struct Eng2;                       // engine 2's per-handle buffers (run2.hpp)
 static void free_eng2(Eng2 *e);
+struct CallbackBuffers;            // pinned staging buffers of the host-likelihood path (callback.hpp)
+static void free_callback_buffers(CallbackBuffers *b);
 
 static thread_local std::string g_err;
 extern "C" const char *smcmi_last_error(void) { return g_err.c_str(); }
@@ -84,6 +86,11 @@ struct smcmi_handle {
     hipGraphExec_t graph_exec = nullptr;
     int graph_sig = 0;
     Eng2 *e2 = nullptr;            // engine 2 (stage2.hpp / run2.hpp): rows, virtual-shard totals, Ctl2
+    // host likelihoods (callback.hpp)
+    smcmi_lik_callback cb[2] = {nullptr, nullptr};
+    void *cb_ud[2] = {nullptr, nullptr};
+    CallbackBuffers *cbuf = nullptr;
+    long long cb_calls = 0, cb_evals = 0;
 };
 
 static int push_state(smcmi_handle *h) {
@@ -211,6 +218,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->nccl) smcmi_comm_release(h);
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
+    if (h->cbuf) { free_callback_buffers(h->cbuf); h->cbuf = nullptr; }
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
                     h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
@@ -261,6 +269,7 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
     if (h->d_aux[which]) { hipFree(h->d_aux[which]); h->d_aux[which] = nullptr; }
     memset(&l, 0, sizeof(LikDev));
     l.family = family;
+    h->cb[which] = nullptr; h->cb_ud[which] = nullptr;            // a device family (or none) replaces a registered host callback
     if (family == SMCMI_LIK_NONE || family == SMCMI_LIK_HOST_CALLBACK) { if (which == 0) h->have_lik = true; return push_model(h); }
     if (family < SMCMI_LIK_GAUSS_ISO || family > SMCMI_LIK_LGSS_KALMAN) return set_err(SMCMI_ERR_ARG, "unknown likelihood family");
     if (family == SMCMI_LIK_LGSS_KALMAN && (n_par < 1 || rows != 3 || h->d != 13 || !aux || aux_rows * aux_cols < 112))
@@ -338,11 +347,14 @@ extern "C" int smcmi_sync(smcmi_handle *h) {
     return 0;
 }
 
-static int need_model(smcmi_handle *h, bool lik) {
+static inline int lik_level(int lik) { return lik; }
+static int need_model(smcmi_handle *h, int lik) {
     if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
     if (!h->have_params) return set_err(SMCMI_ERR_STATE, "smcmi_set_parameters has not been called");
-    if (lik && (!h->have_lik || h->h_model.lik[0].family < 0 || h->h_model.lik[0].family == SMCMI_LIK_HOST_CALLBACK))
-        return set_err(SMCMI_ERR_STATE, "no device likelihood set (smcmi_set_likelihood)");
+    // lik: 1 = a device family is required (kernels evaluate it), 2 = a device family or a registered host callback
+    const bool dev_ok = h->have_lik && h->h_model.lik[0].family >= 0 && h->h_model.lik[0].family != SMCMI_LIK_HOST_CALLBACK;
+    if (lik && !(dev_ok || (lik_level(lik) == 2 && h->cb[0] != nullptr)))
+        return set_err(SMCMI_ERR_STATE, "no likelihood set (smcmi_set_likelihood; smcmi_set_likelihood_callback for smcmi_run / smcmi_initialize_likelihoods)");
     hipError_t e = hipSetDevice(h->cfg.device);
     if (e != hipSuccess) return set_err(SMCMI_ERR_HIP, "hipSetDevice failed");
     return 0;
@@ -362,10 +374,38 @@ extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
     return 0;
 }
 
+static int callback_fill_loglh(smcmi_handle *h, int which, int column);
 extern "C" int smcmi_initialize_likelihoods(smcmi_handle *h) {
-    if (int rc = need_model(h, true)) return rc;
+    if (int rc = need_model(h, 2)) return rc;
     k_initialize_likelihoods<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model);
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->cb[0]) return callback_fill_loglh(h, 0, h->d);            // host likelihood: the kernel retired loglh and evaluated the prior
+    return 0;
+}
+
+// ---- host likelihoods: the reference's `loglikelihood::Function` (src/smc_main.jl:118, src/mutation.jl:93-121)
+extern "C" int smcmi_set_likelihood_callback(smcmi_handle *h, int32_t which, smcmi_lik_callback fn, void *user_data) {
+    if (!h || which < 0 || which > 1) return set_err(SMCMI_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    h->cb[which] = fn; h->cb_ud[which] = user_data;
+    LikDev &l = h->h_model.lik[which];
+    if (h->d_data[which]) { hipFree(h->d_data[which]); h->d_data[which] = nullptr; }
+    if (h->d_aux[which]) { hipFree(h->d_aux[which]); h->d_aux[which] = nullptr; }
+    memset(&l, 0, sizeof(LikDev));
+    l.family = fn ? SMCMI_LIK_HOST_CALLBACK : SMCMI_LIK_NONE;
+    if (which == 0) h->have_lik = fn != nullptr;
+    return push_model(h);
+}
+extern "C" int smcmi_eval_cloud_callback(smcmi_handle *h, int32_t which, int32_t column) {
+    if (int rc = need_model(h, false)) return rc;
+    if (which < 0 || which > 1 || !h->cb[which]) return set_err(SMCMI_ERR_STATE, "no likelihood callback registered");
+    if (column != h->d && column != h->d + 2) return set_err(SMCMI_ERR_ARG, "column must be the loglh (n_para) or old_loglh (n_para + 2) column");
+    return callback_fill_loglh(h, which, column);
+}
+extern "C" int smcmi_callback_stats(smcmi_handle *h, int64_t *calls, int64_t *evaluations) {
+    if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
+    if (calls) *calls = h->cb_calls;
+    if (evaluations) *evaluations = h->cb_evals;
     return 0;
 }
 
@@ -814,7 +854,7 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
 // tail_only: resume such a stage from k_post_correct on (the correction is already done).
 static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int method, int n_blocks, double alpha, int acc_nb,
                           hipEvent_t ev0, hipEvent_t ev1, int p0 = 0, bool no_select = false, bool tail_only = false, bool spec = false,
-                          bool skip_begin = false) {
+                          bool skip_begin = false, bool host_mut = false) {
     const long long n = h->n;
     hipStream_t s = h->stream;
     // spec: predict -> correct -> verify (kernels.hpp k_stage_begin): no certificate pass is enqueued at all - 4 launches
@@ -831,9 +871,10 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     h->spec_stage = spec && cm;
     if (!tail_only) {
     if (p0 == 0 && !skip_begin) {
-        const double *es = (adaptive && !no_pred) ? h->d_esum_part : nullptr;
+        // (host-callback mutation leaves neither energy sums nor energy maxima: plain schedule walk, unshifted weights)
+        const double *es = (adaptive && !no_pred && !host_mut) ? h->d_esum_part : nullptr;
         int es_nb = acc_nb, em_nb = acc_nb;
-        const double *em = h->d_emax_part;
+        const double *em = host_mut ? nullptr : h->d_emax_part;
         if (es && acc_nb > 2048) {       // one wave per column in k_stage_begin does not scale to tens of thousands of rows
             k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red, h->d_emax_part, h->d_esum_red + (size_t)ESUM_RED_ROWS * ES);
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
@@ -862,19 +903,22 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
         nbm = launch_moments(h, h->d_hist_W, 0);
     }
     launch_prepare_in_run(h, h->d_part_mom, nbm, 1);
+    if (host_mut) return;                   // the mutation runs through the host callback (callback.hpp)
     if (ev0) hipEventRecord(ev0, s);
     launch_mutate(h, n_blocks, 0, alpha);
     if (ev1) hipEventRecord(ev1, s);
 }
 
 struct ShardGroup;
+static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
 static bool eng2_eligible(const smcmi_handle *h, int world);
 static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
 
 extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
-    if (int e = need_model(h, true)) return e;
+    if (int e = need_model(h, 2)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
+    if (h->cb[0]) return run_callback(h, rc, res);                    // user likelihood on the host (callback.hpp)
     if (eng2_eligible(h, 1)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
     const int nf = h->h_model.n_free;
     if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
@@ -1327,6 +1371,7 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
     return err_from_state(s.err);
 }
 
+#include "callback.hpp"
 #include "sharded.hpp"
 #include "run2.hpp"
 static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {

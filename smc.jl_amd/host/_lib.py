@@ -55,6 +55,9 @@ class StageStats(C.Structure):
     _fields_ = [("ess", C.c_double), ("sum_unnorm", C.c_double), ("logz_inc", C.c_double), ("resample", C.c_int32)]
 
 
+# int (*smcmi_lik_callback)(const double *theta, int64_t m, int64_t d, double *out, void *user_data)
+LIK_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
+
 # every symbol include/smcmi.h declares: (name, restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = [
@@ -64,6 +67,9 @@ SYMBOLS = [
     ("smcmi_version", C.c_int, []),
     ("smcmi_set_parameters", C.c_int, [_H, ip, dp, dp, ip, dp, dp]),
     ("smcmi_set_likelihood", C.c_int, [_H, C.c_int32, C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int64, dp, C.c_int64, C.c_int64]),
+    ("smcmi_set_likelihood_callback", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("smcmi_eval_cloud_callback", C.c_int, [_H, C.c_int32, C.c_int32]),
+    ("smcmi_callback_stats", C.c_int, [_H, lp, lp]),
     ("smcmi_upload_cloud", C.c_int, [_H, dp]),
     ("smcmi_download_cloud", C.c_int, [_H, dp]),
     ("smcmi_upload_cloud_device", C.c_int, [_H, C.c_void_p]),

@@ -279,58 +279,77 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
         max_stages = n_phi if use_fixed_schedule else 20 * n_phi
     spec = _spec_from(parameters, lik, old_lik)
     eng = Engine(n_parts, d, seed=seed, device=device, max_stages=max_stages, store_history=True)
-    eng.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
-    if device_lik:
-        eng.set_likelihood(*lik, which=0)
-        if old_lik is not None and old_lik[0] != "host_callback":
-            eng.set_likelihood(*old_lik, which=1)
+
+    def set_model_on(e, new_lik, new_fn, old_lik_, old_fn, old_dat):
+        """priors + the (new, old) likelihood pair on engine e: device families through smcmi_set_likelihood, Python callables
+        through smcmi_set_likelihood_callback (the reference's per-particle closure, batched by a trampoline)."""
+        e.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
+        if new_lik[0] == "host_callback":
+            e.set_likelihood_callback(_batch(new_fn, data), which=0)
         else:
-            eng.set_likelihood("none", which=1)
-    else:
-        eng.set_likelihood("host_callback", which=0)
-        eng.set_likelihood("none", which=1)
+            e.set_likelihood(*new_lik, which=0)
+        if old_lik_ is None:
+            e.set_likelihood("none", which=1)
+        elif old_lik_[0] == "host_callback":
+            e.set_likelihood_callback(_batch(old_fn, old_dat), which=1)
+        else:
+            e.set_likelihood(*old_lik_, which=1)
+
+    old_fn = (old_loglikelihood if old_loglikelihood is not None else loglikelihood) if tempered else None
+    old_dat = np.asarray(old_data, dtype=np.float64) if tempered else None
+    set_model_on(eng, lik, loglikelihood, old_lik, old_fn, old_dat)
     kw = dict(n_blocks=n_blocks, n_mh_steps=n_mh_steps, lam=lam, n_phi=n_phi, resampling_method=resampling_method,
               threshold_ratio=threshold_ratio, c=c, alpha=alpha, target=target, use_fixed_schedule=use_fixed_schedule,
               tempering_target=tempering_target, prior_weight=tempered_update_prior_weight,
               log_prob_old_data=log_prob_old_data)
     if verbose != "none":
         print("\n\n SMC starts ....\n")
-    if device_lik:
-        w0 = None
-        if initial_cloud is not None:
-            eng.upload_cloud(initial_cloud.particles if isinstance(initial_cloud, Cloud) else initial_cloud)
-        elif tempered and old_cloud is not None:
-            if not (old_lik is not None and old_lik[0] != "host_callback"):
-                raise NotImplementedError("tempered updates need a device old_loglikelihood")
-            kw["initial_ess"] = _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, tempered_update_prior_weight,
-                                                       resampling_method, seed, device)
-            w0 = eng.download_cloud()[:, d + 4].copy()
-        elif all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
-            eng.init_from_prior()
-        else:
-            from .cloudio import host_initial_draw
-            host_initial_draw(eng, parameters, seed)          # other prior families: host draws, device likelihoods
-        cont = False
-        if continue_intermediate:
-            cont = _load_intermediate(eng, loadpath, n_phi, lam, d)
-        while True:
-            stop = 0
-            if save_intermediate:
-                i_now = eng.get_loop_state()["stage_index"] if cont else 1
-                stop = (i_now // intermediate_stage_increment + 1) * intermediate_stage_increment
-            r = eng.run(use_graph=use_graph, stop_after_stage=stop, continue_run=cont, **kw)
-            if not r["paused"]:
-                break
-            _save_intermediate(eng, savepath, r, n_phi)
-            cont = True
-        rec = eng.stage_records(r["n_stages"])
-        w, W = eng.history(r["n_stages"])
-        if w0 is not None:                       # W_matrix[:, 1] of a tempered update (smc_main.jl:364-365)
-            W = np.array(W)
-            W[:, 0] = w0 * n_parts if w0.sum() <= 1.0 else w0
-        P = eng.download_cloud()
+    w0 = None
+    if initial_cloud is not None:
+        eng.upload_cloud(initial_cloud.particles if isinstance(initial_cloud, Cloud) else initial_cloud)
+    elif tempered and old_cloud is not None:
+        def prior_engine(n_pr):
+            # prior draws scored by the OLD likelihood on the old data (smc_main.jl:288-291)
+            pri = Engine(n_pr, d, seed=seed, device=device, max_stages=2, store_history=False)
+            pri.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
+            if old_lik[0] == "host_callback":
+                pri.set_likelihood_callback(_batch(old_fn, old_dat), which=0)
+            else:
+                pri.set_likelihood(*old_lik, which=0)
+            pri.set_likelihood("none", which=1)
+            if old_lik[0] != "host_callback" and all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
+                pri.init_from_prior()
+            else:
+                from .cloudio import host_initial_draw
+                host_initial_draw(pri, parameters, seed)
+            return pri
+        kw["initial_ess"] = _tempered_update_cloud(eng, old_cloud, n_parts, tempered_update_prior_weight, resampling_method, seed,
+                                                   device, prior_engine)
+        w0 = eng.download_cloud()[:, d + 4].copy()
+    elif device_lik and all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
+        eng.init_from_prior()
     else:
-        r, rec, w, W, P = _run_host_callback(eng, loglikelihood, parameters, data, spec, initial_cloud, seed, max_stages, kw)
+        from .cloudio import host_initial_draw
+        host_initial_draw(eng, parameters, seed)          # host draws; likelihoods by the device family or the callback
+    cont = False
+    if continue_intermediate:
+        cont = _load_intermediate(eng, loadpath, n_phi, lam, d)
+    while True:
+        stop = 0
+        if save_intermediate:
+            i_now = eng.get_loop_state()["stage_index"] if cont else 1
+            stop = (i_now // intermediate_stage_increment + 1) * intermediate_stage_increment
+        r = eng.run(use_graph=use_graph, stop_after_stage=stop, continue_run=cont, **kw)
+        if not r["paused"]:
+            break
+        _save_intermediate(eng, savepath, r, n_phi)
+        cont = True
+    rec = eng.stage_records(r["n_stages"])
+    w, W = eng.history(r["n_stages"])
+    if w0 is not None:                       # W_matrix[:, 1] of a tempered update (smc_main.jl:364-365)
+        W = np.array(W)
+        W[:, 0] = w0 * n_parts if w0.sum() <= 1.0 else w0
+    P = eng.download_cloud()
     cloud = Cloud(d, n_parts)
     cloud.particles = P
     cloud.tempering_schedule = rec["schedule"]
@@ -399,7 +418,7 @@ def _load_intermediate(eng, loadpath, n_phi, lam, d):
     return True
 
 
-def _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, prior_weight, resampling_method, seed, device):
+def _tempered_update_cloud(eng, old_cloud, n_parts, prior_weight, resampling_method, seed, device, prior_engine):
     """Initial cloud of a tempered update, built on the device (src/smc_main.jl:244-333).  Returns cloud.ESS[1].
     RNG contract: bridge resample = stage 0, clean-up resample = stage 1, prior draws = init streams of ids 0.."""
     oldP = np.asfortranarray(old_cloud.particles, dtype=np.float64)
@@ -418,12 +437,8 @@ def _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, prior_weight,
         finally:
             old.close()
     if n_pr > 0:
-        pri = Engine(n_pr, d, seed=seed, device=device, max_stages=2, store_history=False)
+        pri = prior_engine(n_pr)                                            # old_loglikelihood on old_data, :288-291
         try:
-            pri.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
-            pri.set_likelihood(*old_lik, which=0)                           # old_loglikelihood on old_data, :288-291
-            pri.set_likelihood("none", which=1)
-            pri.init_from_prior()
             eng.copy_rows_from(pri, n_pr, dst_row0=n_to)                    # vcat, :296
         finally:
             pri.close()
@@ -431,41 +446,6 @@ def _tempered_update_cloud(eng, old_cloud, spec, old_lik, n_parts, prior_weight,
     eng.normalize_weights(zero_bad_loglh=True)                              # :313-314
     eng.resample(resampling_method, stage=1)                                # :317-322 (incl. reset_weights!)
     return float(n_parts)                                                   # push!(cloud.ESS, n_parts), :325
-
-
-def _host_initial_draw(eng, loglikelihood, parameters, data, spec, seed):
-    """initial_draw! (src/initialization.jl:88-119) with a host likelihood: prior draws on the host RNG contract."""
-    n, d = eng.n, eng.d
-    P = np.zeros((n, d + 5), order="F")
-    for i in range(n):
-        for attempt in range(100000):
-            th = np.empty(d)
-            for k, p in enumerate(parameters):
-                if p.fixed:
-                    th[k] = p.value
-                    continue
-                fam, a, b = p.prior.triple()
-                if fam not in ("normal", "uniform"):
-                    raise NotImplementedError("host prior sampling supports Normal/Uniform")
-                for r in range(100000):
-                    ua, ub = hm.uniform_pair(seed, i, attempt, hm.rng_tag(hm.P_INIT, r, k))
-                    x = a + b * (math.sqrt(-2.0 * math.log(ua)) * math.cos(2.0 * math.pi * ub)) if fam == "normal" else a + (b - a) * ua
-                    if p.valuebounds[0] < x < p.valuebounds[1]:
-                        th[k] = x
-                        break
-            ll = _safe_call(loglikelihood, th, data)
-            if not math.isinf(ll):
-                break
-        P[i, :d] = th
-        P[i, d] = ll
-        P[i, d + 4] = 1.0
-    eng.upload_cloud(P)
-    # log-priors through the device prior table (zero-width proposal: returns prior(θ))
-    nf = int(sum(1 for p in parameters if not p.fixed))
-    _, lpr, _ = eng.propose(np.zeros(nf), np.eye(nf), [0, nf], np.arange(nf), 0, 0, 1e-150, 1.0, 0)
-    P[:, d + 1] = lpr
-    eng.upload_cloud(P)
-    return P
 
 
 def _safe_call(f, th, data):
@@ -478,64 +458,13 @@ def _safe_call(f, th, data):
     return -math.inf if math.isnan(v) else v
 
 
-def _run_host_callback(eng, loglikelihood, parameters, data, spec, initial_cloud, seed, max_stages, kw):
-    """The loop of src/smc_main.jl:377-508 with the mutation split around a host likelihood:
-    device ϕ-solve / correction / selection / moments / proposals / MH decision, host loglikelihood(θ', data)."""
-    n, d = eng.n, eng.d
-    N = float(n)
-    if initial_cloud is not None:
-        eng.upload_cloud(initial_cloud.particles if isinstance(initial_cloud, Cloud) else initial_cloud)
-    else:
-        _host_initial_draw(eng, loglikelihood, parameters, data, spec, seed)
-    free = np.array([k for k, p in enumerate(parameters) if not p.fixed], dtype=np.int32)
-    nf = len(free)
-    sched = hm.schedule(kw["n_phi"], kw["lam"])
-    i, j, phi_n, phi_prop, resampled_last = 1, 2, 0.0, 0.0, False
-    c, accept, logz, resamples = kw["c"], kw["target"], 0.0, 0
-    phi_h, ess_h, c_h, acc_h, rs_h = [0.0], [N], [c], [accept], [0]
-    w_cols, W_cols = [np.zeros(n)], [eng.download_cloud()[:, d + 4].copy()]
-    t0 = time.perf_counter()
-    while phi_n < 1.0:
-        i += 1
-        if i > max_stages:
-            raise SMCMIError(-5, "max_stages exceeded")
-        phi_prev = phi_n
-        if kw["use_fixed_schedule"]:
-            phi_n = float(sched[i - 1])
-        else:
-            phi_n, resampled_last, j, phi_prop = eng.solve_phi(sched, j, phi_prop, phi_prev, kw["tempering_target"], ess_h[-1],
-                                                               resampled_last)
-        before = eng.download_cloud()[:, d + 4]
-        st = eng.correct(phi_n, phi_prev, kw["prior_weight"], kw["log_prob_old_data"], kw["threshold_ratio"])
-        after = eng.download_cloud()[:, d + 4]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            w_cols.append(np.where(before > 0, after * st["sum_unnorm"] / N / before, 0.0))
-        logz += st["logz_inc"]
-        rs = st["resample"]
-        if rs:
-            eng.resample("multinomial" if kw["resampling_method"] == "polyalgo" else kw["resampling_method"], stage=i)
-            resamples += 1
-            resampled_last = True
-            W_cols.append(np.ones(n))
-        else:
-            W_cols.append(after.copy())
-        c = hm.update_c(c, accept, kw["target"])
-        mean, cov = eng.moments()
-        mu_f, S_f = mean[free], (cov[np.ix_(free, free)] + cov[np.ix_(free, free)].T) / 2.0
-        bf, ba, bp = hm.generate_blocks(nf, kw["n_blocks"], free, seed, i)
-        for step in range(kw["n_mh_steps"]):
-            for b in range(kw["n_blocks"]):
-                prop, lpr, qd = eng.propose(mu_f, S_f, bp, bf, b, step, c, kw["alpha"], i)
-                ll = np.array([_safe_call(loglikelihood, prop[k], data) if np.isfinite(lpr[k]) else -math.inf for k in range(n)])
-                eng.accept(ll, None, phi_n, b, step, kw["n_blocks"], i,
-                           last=(step == kw["n_mh_steps"] - 1 and b == kw["n_blocks"] - 1))
-        accept = float(eng.download_cloud()[:, d + 3].mean())
-        phi_h.append(phi_n); ess_h.append(st["ess"]); c_h.append(c); acc_h.append(accept); rs_h.append(int(rs))
-    secs = time.perf_counter() - t0
-    r = dict(n_stages=i, resamples=resamples, logmdd=logz, c=c, accept=accept, seconds=secs)
-    rec = dict(schedule=np.array(phi_h), ess=np.array(ess_h), c_hist=np.array(c_h), accept_hist=np.array(acc_h),
-               resampled=np.array(rs_h, dtype=np.int32))
-    return r, rec, np.asfortranarray(np.stack(w_cols, 1)), np.asfortranarray(np.stack(W_cols, 1)), eng.download_cloud()
+def _batch(fn, data):
+    """Batch form of the reference's closure `loglikelihood(parameters, data)` for smcmi_set_likelihood_callback: one call per
+    proposal that passed the bounds check (the engine packs them), exceptions the reference maps to -Inf handled per particle.
+    A callable with a true `batched` attribute is handed the whole (m, d) array at once."""
+    if getattr(fn, "batched", False):
+        return lambda th: fn(th, data)
+    return lambda th: np.array([_safe_call(fn, th[k], data) for k in range(th.shape[0])])
 
 
 # ----------------------------------------------------------------------------------------------- the other exported functions

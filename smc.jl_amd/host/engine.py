@@ -67,6 +67,39 @@ class Engine:
             None if data is None else _d(data), 0 if data is None else data.shape[0], 0 if data is None else data.shape[1],
             None if aux is None else _d(aux), 0 if aux is None else aux.shape[0], 0 if aux is None else aux.shape[1]))
 
+    def set_likelihood_callback(self, fn, which=0):
+        """Register a host likelihood (smcmi_set_likelihood_callback): fn(theta) with theta an (m, d) array of proposals that
+        passed the bounds check, returning m log-likelihoods (-inf allowed).  fn = None unregisters.  The engine keeps the ctypes
+        trampoline alive; exceptions inside fn abort the run (SMCMI_ERR_CALLBACK) and are re-raised by run()."""
+        if not hasattr(self, "_cb"):
+            self._cb, self._cb_exc = [None, None], None
+        if fn is None:
+            self._cb[which] = None
+            check(self._L.smcmi_set_likelihood_callback(self._h, which, None, None))
+            return
+
+        def tramp(theta_p, m, d, out_p, _ud):
+            try:
+                th = np.ctypeslib.as_array(theta_p, shape=(d, m)).T          # column-major m x d
+                out = np.ctypeslib.as_array(out_p, shape=(m,))
+                out[:] = np.asarray(fn(th), dtype=np.float64).reshape(m)
+                return 0
+            except BaseException as ex:   # noqa: BLE001 - must not unwind through the C frames
+                self._cb_exc = ex
+                return 1
+
+        cb = _lib.LIK_CALLBACK(tramp)
+        self._cb[which] = cb
+        check(self._L.smcmi_set_likelihood_callback(self._h, which, C.cast(cb, C.c_void_p), None))
+
+    def eval_cloud_callback(self, which=0, column=None):
+        self._checked(self._L.smcmi_eval_cloud_callback(self._h, which, self.d if column is None else int(column)))
+
+    def callback_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self._L.smcmi_callback_stats(self._h, C.byref(a), C.byref(b)))
+        return dict(calls=a.value, evaluations=b.value)
+
     def set_model(self, spec):
         """spec: dict(priors, bounds, fixed, lik=(family, par, data, aux), old_lik=None|(...))."""
         self.set_parameters(spec["priors"], spec["bounds"], spec.get("fixed"))
@@ -98,7 +131,7 @@ class Engine:
 
     def initialize_likelihoods(self):
         """initialize_likelihoods!: old_loglh <- loglh, then loglh / logprior on the (new) data."""
-        check(self._L.smcmi_initialize_likelihoods(self._h))
+        self._checked(self._L.smcmi_initialize_likelihoods(self._h))
 
     # ---- stage primitives --------------------------------------------------------------------------
     def ess_at(self, phis, phi_prev):
@@ -183,10 +216,19 @@ class Engine:
                               use_graph, phi_rtol, initial_ess)
         rc.stop_after_stage, rc.continue_run = int(stop_after_stage), int(bool(continue_run))
         res = _lib.Result()
-        check(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
+        self._checked(self._L.smcmi_run(self._h, C.byref(rc), C.byref(res)))
         out = self._result(res)
         out["paused"] = bool(res.paused)
         return out
+
+    def _checked(self, rc):
+        """check(rc); an exception raised inside a Python likelihood callback travels through the C frames as SMCMI_ERR_CALLBACK
+        and is re-raised here."""
+        exc = getattr(self, "_cb_exc", None)
+        if rc != 0 and exc is not None:
+            self._cb_exc = None
+            raise exc
+        check(rc)
 
     def get_loop_state(self):
         s = _lib.LoopState()

@@ -1,0 +1,132 @@
+"""The reference's real entry point - smc(loglikelihood::Function, ...) (src/smc_main.jl:118), a user closure called per proposal
+inside mutation() (src/mutation.jl:93-121) - through smcmi_set_likelihood_callback: the device keeps the loop, the host evaluates
+the batch of in-bounds proposals.  Checked against the fused device kernels on the same Philox streams."""
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import models
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gauss_batch(m, sig):
+    c0 = -0.5 * len(m) * math.log(2.0 * math.pi * sig * sig)
+
+    def f(th):
+        acc = np.zeros(th.shape[0])
+        for k in range(th.shape[1]):                # the device's summation order (model.hpp loglik GAUSS_ISO)
+            e = th[:, k] - m[k]
+            acc += e * e
+        return c0 - acc / (2.0 * sig * sig)
+    return f
+
+
+@pytest.mark.parametrize("kw", [dict(use_fixed_schedule=False, tempering_target=0.95),
+                                dict(use_fixed_schedule=True, n_phi=40, n_blocks=2, n_mh_steps=2, alpha=0.9)])
+def test_callback_run_matches_the_device_likelihood(kw):
+    from smc_jl_amd import Engine
+
+    d, n, seed = 6, 20000, 7
+    spec = models.gauss_spec(d)
+    m, sig = np.asarray(spec["lik"][2]).ravel(), float(spec["lik"][1][0])
+    out = []
+    for mode in ("device", "callback"):
+        e = Engine(n, d, seed=seed, max_stages=800, store_history=True)
+        e.set_model(spec)
+        e.init_from_prior()                           # the same initial cloud for both (device family)
+        P0 = e.download_cloud()
+        if mode == "callback":
+            e.set_likelihood_callback(_gauss_batch(m, sig), which=0)
+            e.upload_cloud(P0)
+        # engine 1 for the device run: the callback path drives engine 1's kernels around the host evaluation
+        r = e.run(**kw)
+        rec = e.stage_records(r["n_stages"])
+        out.append((r, rec, e.download_cloud(), e.callback_stats()))
+        e.close()
+    (r0, rec0, P_dev, _), (r1, rec1, P_cb, st) = out
+    assert r0["n_stages"] == r1["n_stages"] and r0["resamples"] == r1["resamples"]
+    np.testing.assert_allclose(rec1["schedule"], rec0["schedule"], rtol=1e-8)
+    np.testing.assert_allclose(rec1["ess"], rec0["ess"], rtol=1e-7)
+    assert abs(r1["logmdd"] - r0["logmdd"]) < 1e-7
+    same = np.all(np.abs(P_cb - P_dev) <= 1e-9 * (1 + np.abs(P_dev)), axis=1)
+    assert same.mean() > 0.999                       # (an MH decision within an ulp of its threshold may flip)
+    steps = kw.get("n_mh_steps", 1) * kw.get("n_blocks", 1)
+    assert st["calls"] == steps * (r1["n_stages"] - 1) and 0 < st["evaluations"] <= st["calls"] * n
+
+
+def test_callback_sees_only_in_bounds_proposals_and_errors_abort():
+    from smc_jl_amd import Engine
+
+    d, n = 3, 4096
+    spec = models.gauss_spec(d)
+    spec = dict(spec, bounds=[(-0.5, 0.5)] * d, priors=[("uniform", -0.5, 0.5)] * d)
+    m, sig = np.asarray(spec["lik"][2]).ravel()[:d], float(spec["lik"][1][0])
+    seen = dict(lo=np.inf, hi=-np.inf, calls=0)
+    base = _gauss_batch(m, sig)
+
+    def f(th):
+        seen["lo"], seen["hi"], seen["calls"] = min(seen["lo"], th.min()), max(seen["hi"], th.max()), seen["calls"] + 1
+        return base(th)
+
+    e = Engine(n, d, seed=3, max_stages=200, store_history=False)
+    e.set_model(spec)
+    e.init_from_prior()
+    e.set_likelihood_callback(f, which=0)
+    r = e.run(use_fixed_schedule=True, n_phi=20, c=2.0)              # wide proposals: many leave the bounds
+    assert seen["calls"] == r["n_stages"] - 1 and -0.5 <= seen["lo"] and seen["hi"] <= 0.5
+    assert e.callback_stats()["evaluations"] < seen["calls"] * n     # out-of-bounds proposals were never evaluated
+
+    def boom(th):
+        raise FloatingPointError("user likelihood failed")
+
+    e.init_from_prior() if False else None
+    e.set_likelihood_callback(boom, which=0)
+    with pytest.raises(FloatingPointError):
+        e.run(use_fixed_schedule=True, n_phi=20)
+    e.close()
+
+
+def test_smc_entry_point_with_a_python_closure_tempered_update():
+    """api.smc(loglikelihood=callable, ..., old_data=, old_cloud=): the keyword combinations the round-1 host path silently ignored
+    (ADVICE: tempered update, save_intermediate) now run through the same device loop as the built-in families."""
+    import smc_jl_amd as S
+
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=60)
+    y = 1.0 + 1.0 * X + rng.normal(size=60)
+    data = np.column_stack([y, X])
+
+    def loglik(theta, dat):
+        e = dat[:, 0] - theta[0] - theta[1] * dat[:, 1]
+        return -0.5 * dat.shape[0] * math.log(2.0 * math.pi) - 0.5 * float(e @ e)
+
+    pars = [S.parameter("a", 0.0, (-1e5, 1e5), prior=S.Normal(0.0, 10.0)), S.parameter("b", 0.0, (-1e5, 1e5), prior=S.Normal(0.0, 10.0))]
+    kw = dict(n_parts=4000, n_phi=50, verbose="none", seed=5)
+    c_old, _, _ = S.smc(loglik, pars, data[:30], **kw)
+    c_new, w, W = S.smc(loglik, pars, data, old_data=data[:30], old_cloud=c_old, **kw)
+    c_dev, _, _ = S.smc(S.LinReg(1.0), pars, data, old_data=data[:30],
+                        old_cloud=c_old, **kw)          # the same update with the device family
+    assert c_new.stage_index == c_dev.stage_index == 50
+    assert c_new.logmdd == pytest.approx(c_dev.logmdd, abs=1e-6)
+    np.testing.assert_allclose(S.weighted_mean(c_new), S.weighted_mean(c_dev), atol=1e-6)
+    assert w.shape == (4000, 50) and W.shape == (4000, 50)
+
+
+def test_c_callback_example_builds_and_matches():
+    """examples/c_abi_callback.c: the callback ABI from plain C (a function pointer computing the 10-dim Gaussian log-likelihood)
+    against the fused device family, and the callback path's throughput."""
+    exe = os.path.join(ROOT, "examples", "c_abi_callback")
+    src = os.path.join(ROOT, "examples", "c_abi_callback.c")
+    lib = os.path.join(ROOT, "smc.jl_amd", "csrc")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
+                           "-L", lib, "-lsmcmi", "-lm", "-Wl,-rpath," + lib])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "OK" in p.stdout
