@@ -276,7 +276,10 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
         ol = old_loglikelihood if old_loglikelihood is not None else loglikelihood
         old_lik = ol.spec(np.asarray(old_data, dtype=np.float64)) if isinstance(ol, DeviceLikelihood) else ("host_callback", [], None, None)
     if max_stages is None:
-        max_stages = n_phi if use_fixed_schedule else 20 * n_phi
+        # capacity of the per-stage records and of the two N x max_stages history matrices (16 N max_stages bytes on the device): an
+        # adaptive run at the default tempering target takes ~0.9 n_phi stages, so 4 n_phi + 64 is generous; a run that needs
+        # more fails with the capacity error and can be repeated with max_stages= (the reference grows its matrices by hcat)
+        max_stages = n_phi if use_fixed_schedule else 4 * n_phi + 64
     spec = _spec_from(parameters, lik, old_lik)
     eng = Engine(n_parts, d, seed=seed, device=device, max_stages=max_stages, store_history=True)
 
@@ -331,15 +334,19 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     else:
         from .cloudio import host_initial_draw
         host_initial_draw(eng, parameters, seed)          # host draws; likelihoods by the device family or the callback
-    cont = False
+    cont, elapsed = False, 0.0
     if continue_intermediate:
         cont = _load_intermediate(eng, loadpath, n_phi, lam, d)
+        from .cloudio import load_arrays
+        elapsed = float(load_arrays(loadpath).get("total_sampling_time", 0.0))
     while True:
         stop = 0
         if save_intermediate:
             i_now = eng.get_loop_state()["stage_index"] if cont else 1
             stop = (i_now // intermediate_stage_increment + 1) * intermediate_stage_increment
         r = eng.run(use_graph=use_graph, stop_after_stage=stop, continue_run=cont, **kw)
+        elapsed += r["seconds"]                  # cloud.total_sampling_time accumulates over the stages (smc_main.jl:489-490)
+        r["seconds"] = elapsed
         if not r["paused"]:
             break
         _save_intermediate(eng, savepath, r, n_phi)
@@ -369,7 +376,8 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             for p, m_, s_ in zip(parameters, mu, sd):
                 print("   %-12s mean %12.6f  std %12.6f" % (p.key, m_, s_))
     if particle_store_path and not testing:
-        np.save(particle_store_path, np.ascontiguousarray(cloud.particles[:, :d]))        # `smcparams`, smc_main.jl:514-520
+        from .cloudio import save_smcparams
+        save_smcparams(particle_store_path, cloud.particles, d)                            # `smcparams`, smc_main.jl:514-520
     if savepath and not testing:
         from .cloudio import save_cloud
         save_cloud(savepath, cloud, w, W)                          # write(file, "cloud"/"w"/"W"), smc_main.jl:521-525
@@ -389,10 +397,11 @@ def _save_intermediate(eng, savepath, r, n_phi):
     ns = ls["stage_index"]
     rec = eng.stage_records(ns)
     w, W = eng.history(ns)
-    np.savez(_stage_path(savepath, ns), particles=eng.download_cloud(), tempering_schedule=rec["schedule"], ESS=rec["ess"],
-             c_hist=rec["c_hist"], accept_hist=rec["accept_hist"], resampled=rec["resampled"], stage_index=ns, n_Phi=n_phi,
-             resamples=ls["resamples"], c=ls["c"], accept=ls["accept"], total_sampling_time=r["seconds"], w=w, W=W, j=ls["j"],
-             logmdd=ls["logmdd"])
+    from .cloudio import save_arrays
+    save_arrays(_stage_path(savepath, ns), cloud_particles=eng.download_cloud(), cloud_tempering_schedule=rec["schedule"], cloud_ESS=rec["ess"],
+                c_hist=rec["c_hist"], accept_hist=rec["accept_hist"], resampled=rec["resampled"], cloud_stage_index=ns, cloud_n_Phi=n_phi,
+                cloud_resamples=ls["resamples"], cloud_c=ls["c"], cloud_accept=ls["accept"], cloud_total_sampling_time=r["seconds"], w=w, W=W,
+                j=ls["j"], logmdd=ls["logmdd"])
 
 
 def _load_intermediate(eng, loadpath, n_phi, lam, d):
@@ -400,7 +409,8 @@ def _load_intermediate(eng, loadpath, n_phi, lam, d):
     c = cloud.c, ϕ_prop = proposed_fixed_schedule[j]; resampled_last_period is not part of the file and restarts as false."""
     if not loadpath:
         raise ValueError("continue_intermediate needs loadpath")
-    z = np.load(loadpath)
+    from .cloudio import load_arrays
+    z = load_arrays(loadpath)
     P = np.asfortranarray(z["particles"], dtype=np.float64)
     if P.shape != (eng.n, d + 5):
         raise ValueError("cloud in %s has shape %r, expected %r" % (loadpath, P.shape, (eng.n, d + 5)))

@@ -22,14 +22,63 @@ def _cloud_cls():
     return Cloud
 
 
+_H5_EXT = (".h5", ".hdf5", ".jld2")
+
+
+def save_arrays(path, **arrays):
+    """One file of named arrays at EXACTLY `path`: HDF5 (h5min, Julia array convention) for .h5 / .hdf5 / .jld2 names - the
+    reference's `savepath` convention, readable by HDF5.jl / h5py; `cloud_*` keys form the group `cloud` - numpy .npz otherwise
+    (written through an open handle: np.savez(path) would append ".npz" to a foreign extension)."""
+    if str(path).lower().endswith(_H5_EXT):
+        from . import h5min
+        items, grp = {}, {}
+        for k, v in arrays.items():
+            (grp if k.startswith("cloud_") else items)[k[6:] if k.startswith("cloud_") else k] = np.asarray(v)
+        if grp:
+            items["cloud"] = grp
+        h5min.write_julia(path, items)
+    else:
+        with open(path, "wb") as f:
+            np.savez(f, **{(k[6:] if k.startswith("cloud_") else k): v for k, v in arrays.items()})
+
+
+def load_arrays(path):
+    """-> dict of arrays, from either format of save_arrays (sniffed from the file's first bytes)."""
+    with open(path, "rb") as f:
+        head = f.read(8)
+    if head == b"\x89HDF\r\n\x1a\n":
+        from . import h5min
+        z = h5min.read(path, julia=True)
+        out = {k: v for k, v in z.items() if not isinstance(v, dict)}
+        out.update(z.get("cloud", {}))
+        return out
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
 def save_cloud(path, cloud, w, W, **extra):
-    np.savez(path, particles=np.asarray(cloud.particles), w=np.asarray(w), W=np.asarray(W),
-             **{k: getattr(cloud, k) for k in _FIELDS}, **extra)
+    """write(file, "cloud", cloud); write(file, "w", w); write(file, "W", W) (src/smc_main.jl:521-525).  In an HDF5 file the Cloud's
+    fields are the datasets of the group `cloud` (particles as an N x (n_para + 5) Julia matrix); true JLD2 struct encoding is the
+    Julia shim's job (smc.jl_amd/julia/SMCMI.jl writes through JLD2.jl itself)."""
+    save_arrays(path, cloud_particles=np.asarray(cloud.particles), w=np.asarray(w), W=np.asarray(W),
+                **{"cloud_" + k: getattr(cloud, k) for k in _FIELDS}, **extra)
+
+
+def save_smcparams(path, particles, n_para):
+    """`particle_store_path`: the n_parts x n_para draws as HDF5 dataset "smcparams" (src/smc_main.jl:514-520) for .h5 names,
+    a .npy array otherwise."""
+    P = np.ascontiguousarray(np.asarray(particles)[:, :n_para])
+    if str(path).lower().endswith(_H5_EXT):
+        from . import h5min
+        h5min.write_julia(path, {"smcparams": P})
+    else:
+        with open(path, "wb") as f:
+            np.save(f, P)
 
 
 def load_cloud(path):
     """-> (cloud, w, W) as `load(path, "cloud")`, `load(path, "w")`, `load(path, "W")`."""
-    z = np.load(path)
+    z = load_arrays(path)
     P = np.asfortranarray(z["particles"], dtype=np.float64)
     cloud = _cloud_cls()(P.shape[1] - 5, P.shape[0])
     cloud.particles = P

@@ -1,43 +1,102 @@
-# SMCMI.jl - Julia `ccall` shim over libsmcmi.so (include/smcmi.h).
+# SMCMI.jl - the reference-side binding: Julia `ccall` shim over libsmcmi.so (include/smcmi.h).
 #
-# Keeps the reference entry point `smc(loglikelihood, parameters, data; kwargs...)` (src/smc_main.jl:118-161) and hands the
-# correction / selection / mutation loop to the MI355X engine.  Julia is not available in the build image, so this file has
-# never been executed; it only marshals arguments (a `Cloud`'s `particles` matrix is already the column-major N x (d+5)
-# buffer the C ABI expects, so uploads/downloads are zero-conversion).  See INTEGRATION.md.
+# Keeps the reference's entry point and types for the correction / selection / mutation loop:
+#
+#     smc(loglikelihood::Function, parameters::ParameterVector, data::Matrix; kwargs...)      src/smc_main.jl:118-161
+#     Cloud, get_vals / get_loglh / ... / weighted_mean / weighted_cov                          src/particle.jl
+#
+# and hands the loop (src/smc_main.jl:377-508) to the MI355X engine.  The user's closure is bound through
+# `smcmi_set_likelihood_callback`: one `@cfunction` trampoline evaluates the closure on the batch of proposals that passed the
+# bounds check, synchronously on the calling thread (the library never calls back from another thread).  `DeviceLikelihood`
+# structs select a built-in device family instead (no PCIe traffic inside the loop).
+#
+# Julia is not part of the build image, so this file has not been executed here; every `ccall` spells out the C signature of
+# include/smcmi.h and the structs mirror its layout field by field (tests/test_abi_cpu.py pins the C side).  See INTEGRATION.md.
 module SMCMI
 
-using ModelConstructors, Distributions
+using ModelConstructors, Distributions, Random, Dates
+import JLD2, HDF5
+
+export smc, Cloud, get_vals, get_loglh, get_logprior, get_old_loglh, get_logpost, get_accept, get_weights, weighted_mean, weighted_cov,
+       weighted_std, cloud_isempty, GaussIso, LinReg, LinModel3, CapmLiteral, LGSSKalman
 
 const LIB = get(ENV, "SMCMI_LIB", joinpath(@__DIR__, "..", "csrc", "libsmcmi.so"))
+const Handle = Ptr{Cvoid}
 
-struct Config
+# ---- struct mirrors of include/smcmi.h (field order and widths are the ABI)
+struct Config                 # smcmi_config
     n_parts::Int64; n_local::Int64; gid0::Int64; n_para::Int32; device::Int32
     seed::UInt64; max_stages::Int32; store_history::Int32
 end
-struct RunConfig
+struct RunConfig              # smcmi_run_config
     n_blocks::Int32; n_mh_steps::Int32; lambda::Float64; n_phi::Int32; resampling_method::Int32
     threshold_ratio::Float64; c::Float64; alpha::Float64; target::Float64; use_fixed_schedule::Int32
     tempering_target::Float64; tempered_update_prior_weight::Float64; log_prob_old_data::Float64
     solver_passes::Int32; sync_every::Int32; use_graph::Int32; initial_ess::Float64; phi_rtol::Float64
-    stop_after_stage::Int32; continue_run::Int32   # save_intermediate / continue_intermediate (smc_main.jl:334-361, 499-507)
+    stop_after_stage::Int32; continue_run::Int32
 end
-mutable struct Result
+mutable struct Result         # smcmi_result
     n_stages::Int32; resamples::Int32; logmdd::Float64; c::Float64; accept::Float64; seconds::Float64
-    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32; spec_stalls::Int32; paused::Int32
+    kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32
+    spec_stalls::Int32; paused::Int32
     Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
+end
+mutable struct LoopState      # smcmi_loop_state
+    stage_index::Int32; j::Int32; resampled_last_period::Int32; resamples::Int32
+    phi_n::Float64; phi_prop::Float64; c::Float64; accept::Float64; ess::Float64; logmdd::Float64
+    LoopState() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
 end
 
 check(rc) = rc == 0 ? nothing : error("smcmi error $rc: " * unsafe_string(ccall((:smcmi_last_error, LIB), Cstring, ())))
 
-# device likelihood families standing in for the user closure (SMCMI_LIK_* in smcmi.h)
+# ---- Cloud: the reference's container (src/particle.jl:31-63), same fields, same column map
+mutable struct Cloud
+    particles::Matrix{Float64}            # N x (n_para + 5): params | loglh | logprior | old_loglh | accept | weight
+    tempering_schedule::Vector{Float64}
+    ESS::Vector{Float64}
+    stage_index::Int
+    n_Φ::Int
+    resamples::Int
+    c::Float64
+    accept::Float64
+    total_sampling_time::Float64
+end
+Cloud(n_params::Int, n_parts::Int) = Cloud(Matrix{Float64}(undef, n_parts, n_params + 5), [0.], [0.], 1, 0, 0, 0., 0.25, 0.)
+cloud_isempty(c::Cloud) = isempty(c.particles)
+Base.length(c::Cloud) = size(c.particles, 1)
+n_para(c::Cloud) = size(c.particles, 2) - 5
+get_vals(c::Cloud; transpose::Bool = true) = transpose ? collect(c.particles[:, 1:n_para(c)]') : c.particles[:, 1:n_para(c)]
+get_loglh(c::Cloud) = c.particles[:, n_para(c) + 1]
+get_logprior(c::Cloud) = c.particles[:, n_para(c) + 2]
+get_old_loglh(c::Cloud) = c.particles[:, n_para(c) + 3]
+get_logpost(c::Cloud) = get_loglh(c) .+ get_logprior(c)
+get_accept(c::Cloud) = c.particles[:, n_para(c) + 4]
+get_weights(c::Cloud) = c.particles[:, n_para(c) + 5]
+function weighted_mean(c::Cloud)
+    w = get_weights(c); X = c.particles[:, 1:n_para(c)]
+    vec(sum(X .* w, dims = 1) ./ sum(w))
+end
+function weighted_cov(c::Cloud)                      # StatsBase.cov(X, Weights(w), corrected = false)
+    w = get_weights(c) ./ sum(get_weights(c)); X = c.particles[:, 1:n_para(c)]
+    Xc = X .- sum(X .* w, dims = 1)
+    (Xc .* w)' * Xc
+end
+weighted_std(c::Cloud) = sqrt.(diag_of(weighted_cov(c)))
+diag_of(A) = [A[i, i] for i in 1:size(A, 1)]
+
+# ---- device likelihood families standing in for the closure (SMCMI_LIK_* in smcmi.h)
 struct GaussIso; sigma::Float64; end
 struct LinReg; sigma2::Float64; end
 struct LinModel3; X::Matrix{Float64}; end
 struct CapmLiteral; market::Matrix{Float64}; end
-const DeviceLikelihood = Union{GaussIso, LinReg, LinModel3, CapmLiteral}
+struct LGSSKalman; C::Matrix{Float64}; R::Matrix{Float64}; Z::Matrix{Float64}; kappa::Float64; end
+const DeviceLikelihood = Union{GaussIso, LinReg, LinModel3, CapmLiteral, LGSSKalman}
 family(::GaussIso) = Int32(0); family(::LinReg) = Int32(1); family(::LinModel3) = Int32(2); family(::CapmLiteral) = Int32(3)
-lik_par(l::GaussIso) = [l.sigma]; lik_par(l::LinReg) = [l.sigma2]; lik_par(::Any) = Float64[]
-lik_aux(l::LinModel3) = l.X; lik_aux(l::CapmLiteral) = l.market; lik_aux(::Any) = zeros(0, 0)
+family(::LGSSKalman) = Int32(4)
+lik_par(l::GaussIso) = [l.sigma]; lik_par(l::LinReg) = [l.sigma2]; lik_par(l::LGSSKalman) = [l.kappa]; lik_par(::Any) = Float64[]
+lik_aux(l::LinModel3) = l.X; lik_aux(l::CapmLiteral) = l.market
+lik_aux(l::LGSSKalman) = reshape(vcat(vec(l.C'), vec(l.R'), vec(l.Z')), 1, :)          # [C 8x8 | R 8x3 | Z 3x8] row-major, 112 doubles
+lik_aux(::Any) = zeros(0, 0)
 
 prior_code(d::Normal) = (Int32(0), d.μ, d.σ)
 prior_code(d::Uniform) = (Int32(1), d.a, d.b)
@@ -47,57 +106,256 @@ prior_code(d::InverseGamma) = (Int32(4), shape(d), scale(d))
 prior_code(d::ModelConstructors.RootInverseGamma) = (Int32(5), d.ν, d.τ)
 
 const RESAMPLER = Dict(:systematic => Int32(0), :multinomial => Int32(1), :polyalgo => Int32(1))
+const CALLBACK_ERRORS = (ParamBoundsError, LinearAlgebra.LAPACKException, LinearAlgebra.PosDefException,
+                         LinearAlgebra.SingularException, DomainError)          # the five the reference maps to -Inf (mutation.jl:112-121)
+import LinearAlgebra
 
-"""
-    smc(loglikelihood, parameters, data; kwargs...) -> (particles, w, W, result)
-
-Same keyword arguments as SMC.smc.  `loglikelihood` is a `DeviceLikelihood`; arbitrary Julia closures go through
-`smcmi_propose` / `smcmi_accept` (see `smc_callback` below).  The caller wraps `particles` into `SMC.Cloud` and saves
-`{cloud, w, W}` exactly as src/smc_main.jl:513-526 does.
-"""
-function smc(loglikelihood::DeviceLikelihood, parameters::ParameterVector, data::Matrix{Float64};
-             n_parts::Int = 5_000, n_blocks::Int = 1, n_mh_steps::Int = 1, λ::Float64 = 2.1, n_Φ::Int = 300,
-             resampling_method::Symbol = :systematic, threshold_ratio::Float64 = 0.5, c::Float64 = 0.5, α::Float64 = 1.0,
-             target::Float64 = 0.25, use_fixed_schedule::Bool = true, tempering_target::Float64 = 0.97,
-             tempered_update_prior_weight::Float64 = 0.0, log_prob_old_data::Float64 = 0.0, seed::Integer = 0,
-             device::Integer = 0, initial_cloud::Union{Nothing, Matrix{Float64}} = nothing)
-    haskey(RESAMPLER, resampling_method) || throw("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
-    d = length(parameters)
-    max_stages = use_fixed_schedule ? n_Φ : 20 * n_Φ
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    cfg = Config(n_parts, n_parts, 0, d, device, seed, max_stages, 1)
-    check(ccall((:smcmi_create, LIB), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h))
+# ---- the closure as a batch callback: int (*)(const double *theta, int64_t m, int64_t d, double *out, void *user_data)
+struct CallbackEnv
+    f::Function
+    parameters::ParameterVector
+    data::Matrix{Float64}
+end
+function lik_trampoline(theta::Ptr{Float64}, m::Int64, d::Int64, out::Ptr{Float64}, ud::Ptr{Cvoid})::Cint
+    env = unsafe_pointer_to_objref(ud)::CallbackEnv
     try
-        fixed = Int32[p.fixed ? 1 : 0 for p in parameters]
-        lo = Float64[p.valuebounds[1] for p in parameters]; hi = Float64[p.valuebounds[2] for p in parameters]
-        codes = [p.fixed ? (Int32(0), p.value, 1.0) : prior_code(p.prior.value) for p in parameters]
-        fam = Int32[x[1] for x in codes]; pa = Float64[x[2] for x in codes]; pb = Float64[x[3] for x in codes]
-        check(ccall((:smcmi_set_parameters, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
-                    h[], fixed, lo, hi, fam, pa, pb))
-        par = lik_par(loglikelihood); aux = lik_aux(loglikelihood)
-        check(ccall((:smcmi_set_likelihood, LIB), Cint,
-                    (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64),
-                    h[], 0, family(loglikelihood), par, length(par), data, size(data, 1), size(data, 2), aux, size(aux, 1), size(aux, 2)))
-        check(ccall((:smcmi_set_likelihood, LIB), Cint,
-                    (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64),
-                    h[], 1, -1, C_NULL, 0, C_NULL, 0, 0, C_NULL, 0, 0))
-        if initial_cloud === nothing
-            check(ccall((:smcmi_init_from_prior, LIB), Cint, (Ptr{Cvoid},), h[]))      # initial_draw!
-        else
-            check(ccall((:smcmi_upload_cloud, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], initial_cloud))
+        th = unsafe_wrap(Array, theta, (m, d))              # column-major m x d, as the C side packs it
+        o = unsafe_wrap(Array, out, (m,))
+        p = deepcopy(env.parameters)
+        for k in 1:m
+            o[k] = try
+                update!(p, th[k, :])                        # mutation.jl:93 (cannot throw: only in-bounds proposals arrive)
+                env.f(p, env.data)                          # mutation.jl:96
+            catch err
+                isa(err, Union{CALLBACK_ERRORS...}) ? -Inf : rethrow(err)
+            end
         end
-        rc = RunConfig(n_blocks, n_mh_steps, λ, n_Φ, RESAMPLER[resampling_method], threshold_ratio, c, α, target,
-                       use_fixed_schedule ? 1 : 0, tempering_target, tempered_update_prior_weight, log_prob_old_data, 0, 0, 0, 0.0, 0.0, 0, 0)
-        res = Result()
-        check(ccall((:smcmi_run, LIB), Cint, (Ptr{Cvoid}, Ref{RunConfig}, Ref{Result}), h[], rc, res))
-        particles = Matrix{Float64}(undef, n_parts, d + 5)
-        check(ccall((:smcmi_download_cloud, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], particles))
-        w = Matrix{Float64}(undef, n_parts, res.n_stages); W = similar(w)
-        check(ccall((:smcmi_get_history, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], w, W))
-        return particles, w, W, res
-    finally
-        ccall((:smcmi_destroy, LIB), Cint, (Ptr{Cvoid},), h[])
+        return Cint(0)
+    catch err
+        @error "SMCMI: the likelihood callback threw" exception = (err, catch_backtrace())
+        return Cint(1)                                      # -> SMCMI_ERR_CALLBACK, nothing unwinds through the C frames
     end
+end
+
+function set_model!(h::Handle, parameters, lik, data, which::Integer, keep::Vector{Any})
+    if lik === nothing
+        check(ccall((:smcmi_set_likelihood, LIB), Cint,
+                    (Handle, Int32, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64),
+                    h, which, -1, C_NULL, 0, C_NULL, 0, 0, C_NULL, 0, 0))
+    elseif lik isa DeviceLikelihood
+        par = lik_par(lik); aux = lik_aux(lik)
+        check(ccall((:smcmi_set_likelihood, LIB), Cint,
+                    (Handle, Int32, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64),
+                    h, which, family(lik), par, length(par), data, size(data, 1), size(data, 2), aux, size(aux, 1), size(aux, 2)))
+    else
+        env = CallbackEnv(lik, parameters, data)
+        push!(keep, env)                                    # rooted for the lifetime of the handle
+        fptr = @cfunction(lik_trampoline, Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}))
+        check(ccall((:smcmi_set_likelihood_callback, LIB), Cint, (Handle, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                    h, which, fptr, pointer_from_objref(env)))
+    end
+end
+
+function create(n_parts, d, seed, device, max_stages)
+    h = Ref{Handle}(C_NULL)
+    check(ccall((:smcmi_create, LIB), Cint, (Ref{Config}, Ref{Handle}), Config(n_parts, n_parts, 0, d, device, seed, max_stages, 1), h))
+    h[]
+end
+destroy(h::Handle) = ccall((:smcmi_destroy, LIB), Cint, (Handle,), h)
+
+function set_parameters!(h::Handle, parameters)
+    fixed = Int32[p.fixed ? 1 : 0 for p in parameters]
+    lo = Float64[p.valuebounds[1] for p in parameters]; hi = Float64[p.valuebounds[2] for p in parameters]
+    codes = [p.fixed ? (Int32(0), p.value, 1.0) : prior_code(p.prior.value) for p in parameters]
+    fam = Int32[x[1] for x in codes]; pa = Float64[x[2] for x in codes]; pb = Float64[x[3] for x in codes]
+    check(ccall((:smcmi_set_parameters, LIB), Cint, (Handle, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+                h, fixed, lo, hi, fam, pa, pb))
+end
+
+# initial_draw! (src/initialization.jl:88-119): device sampler for Normal / Uniform priors with a device family; otherwise prior
+# draws on the host (rand(parameters, n), re-drawn until the log-likelihood is finite, :23-63) scored through the handle
+function initial_draw!(h::Handle, parameters, lik, n_parts::Int, d::Int)
+    simple = all(p -> p.fixed || p.prior.value isa Union{Normal, Uniform}, parameters)
+    if lik isa DeviceLikelihood && simple
+        return check(ccall((:smcmi_init_from_prior, LIB), Cint, (Handle,), h))
+    end
+    P = zeros(n_parts, d + 5)
+    todo = collect(1:n_parts)
+    while !isempty(todo)
+        draws = rand(parameters, length(todo))               # d x length(todo), inside the bounds (ModelConstructors)
+        P[todo, 1:d] = draws'
+        P[:, d + 5] .= 1.0
+        check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+        check(ccall((:smcmi_initialize_likelihoods, LIB), Cint, (Handle,), h))      # logprior on the device, loglh by family / callback
+        check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+        todo = findall(!isfinite, P[:, d + 1])
+    end
+    P[:, d + 3] .= 0.0; P[:, d + 4] .= 0.0; P[:, d + 5] .= 1.0
+    check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+end
+
+stage_path(savepath, i) = replace(savepath, ".jld2" => "_stage=$(i).jld2")         # smc_main.jl:500
+
+"""
+    smc(loglikelihood, parameters, data; kwargs...)
+
+Drop-in for `SMC.smc` (src/smc_main.jl:118-161): same positional arguments, same keyword list, same files - `savepath` receives
+`cloud`, `w`, `W` (JLD2) and `particle_store_path` the `smcparams` matrix (HDF5), intermediate saves go to
+`savepath` with `_stage=i` (smc_main.jl:499-507, 513-526).  `loglikelihood` is the user's closure
+`loglikelihood(parameters::ParameterVector, data::Matrix{Float64})::Float64` or one of the `DeviceLikelihood` structs.
+Returns `(cloud, w, W)` in addition to writing the files (the reference returns nothing, quirk Q8).
+Not supported: `regime_switching = true`; `parallel` is moot (the device is the parallelism).
+"""
+function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
+             verbose::Symbol = :low, testing::Bool = false, data_vintage::String = Dates.format(today(), "yymmdd"),
+             parallel::Bool = false, n_parts::Int = 5_000, n_blocks::Int = 1, n_mh_steps::Int = 1,
+             λ::Float64 = 2.1, n_Φ::Int64 = 300, resampling_method::Symbol = :systematic, threshold_ratio::Float64 = 0.5,
+             c::Float64 = 0.5, α::Float64 = 1.0, target::Float64 = 0.25,
+             use_fixed_schedule::Bool = true, tempering_target::Float64 = 0.97,
+             old_data::Matrix{Float64} = Matrix{Float64}(undef, size(data, 1), 0), old_cloud::Cloud = Cloud(0, 0),
+             old_loglikelihood = loglikelihood, old_vintage::String = "", smc_iteration::Int = 1,
+             run_test::Bool = false, filestring_addl::Vector{String} = Vector{String}(),
+             loadpath::String = "", savepath::String = "smc_cloud.jld2", particle_store_path::String = "smcsave.h5",
+             save_intermediate::Bool = false, intermediate_stage_increment::Int = 10, continue_intermediate::Bool = false,
+             intermediate_stage_start::Int = 0, tempered_update_prior_weight::Float64 = 0.0,
+             regime_switching::Bool = false, toggle::Bool = true, debug_assertion::Bool = false,
+             log_prob_old_data::Float64 = 0.0, seed::Integer = rand(UInt64), device::Integer = 0)
+    haskey(RESAMPLER, resampling_method) || throw("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
+    regime_switching && throw(ArgumentError("regime_switching = true is not supported by the MI355X engine"))
+    0.0 <= tempered_update_prior_weight <= 1.0 ||
+        throw(DomainError("The keyword tempered_update_prior_weight must be within the interval [0, 1] but " *
+                          "is currently set to $(tempered_update_prior_weight)"))
+    d = length(parameters)
+    all(p -> p.fixed, parameters) && throw(AssertionError("All model parameters are fixed!"))      # smc_main.jl:236-239
+    tempered_update = !isempty(old_data)
+    max_stages = use_fixed_schedule ? n_Φ : 20 * n_Φ
+    method = RESAMPLER[resampling_method]
+    keep = Any[]                                             # callback environments (GC roots)
+    h = create(n_parts, d, seed, device, max_stages)
+    try
+        set_parameters!(h, parameters)
+        set_model!(h, parameters, loglikelihood, data, 0, keep)
+        set_model!(h, parameters, tempered_update ? old_loglikelihood : nothing, old_data, 1, keep)
+        initial_ess = 0.0
+        W1 = nothing                                         # W_matrix[:, 1] of a tempered update (smc_main.jl:364-365)
+        cont = false
+        if tempered_update
+            cloud0 = cloud_isempty(old_cloud) ? JLD2.load(loadpath, "cloud") : old_cloud              # :245-246
+            initial_ess = tempered_cloud!(h, cloud0, parameters, old_loglikelihood, old_data, n_parts, tempered_update_prior_weight,
+                                          method, seed, device, keep)
+            P0 = Matrix{Float64}(undef, n_parts, d + 5)
+            check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P0))
+            W1 = P0[:, d + 5]
+        elseif continue_intermediate
+            cont = load_intermediate!(h, loadpath, n_Φ, λ, d)                                            # :334-335, 355-361
+        else
+            initial_draw!(h, parameters, loglikelihood, n_parts, d)
+        end
+        res = Result()
+        while true
+            stop = 0
+            if save_intermediate
+                ls = LoopState()
+                cont && check(ccall((:smcmi_get_loop_state, LIB), Cint, (Handle, Ref{LoopState}), h, ls))
+                i_now = cont ? Int(ls.stage_index) : 1
+                stop = (div(i_now, intermediate_stage_increment) + 1) * intermediate_stage_increment
+            end
+            rc = RunConfig(n_blocks, n_mh_steps, λ, n_Φ, method, threshold_ratio, c, α, target, use_fixed_schedule ? 1 : 0,
+                           tempering_target, tempered_update_prior_weight, log_prob_old_data, 0, 0, 0, initial_ess, 0.0, stop, cont ? 1 : 0)
+            check(ccall((:smcmi_run, LIB), Cint, (Handle, Ref{RunConfig}, Ref{Result}), h, rc, res))
+            res.paused == 0 && break
+            cl, w, W, j = collect_cloud(h, n_parts, d, n_Φ, res)
+            JLD2.jldopen(stage_path(savepath, cl.stage_index), true, true, true, JLD2.IOStream) do file          # :499-507
+                write(file, "cloud", cl); write(file, "w", w); write(file, "W", W); write(file, "j", j)
+            end
+            cont = true
+        end
+        cloud, w, W, _ = collect_cloud(h, n_parts, d, n_Φ, res)
+        W1 === nothing || (W[:, 1] = sum(W1) <= 1.0 ? W1 .* n_parts : W1)
+        if !testing                                                                                          # :513-526
+            HDF5.h5open(particle_store_path, "w") do simfile
+                simfile["smcparams"] = cloud.particles[:, 1:d]
+            end
+            JLD2.jldopen(savepath, true, true, true, JLD2.IOStream) do file
+                write(file, "cloud", cloud); write(file, "w", w); write(file, "W", W)
+            end
+        end
+        return cloud, w, W
+    finally
+        destroy(h)
+    end
+end
+
+function collect_cloud(h::Handle, n_parts, d, n_Φ, res::Result)
+    ns = Int(res.n_stages)
+    cloud = Cloud(d, n_parts)
+    check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, cloud.particles))
+    phi = Vector{Float64}(undef, ns); ess = similar(phi)
+    check(ccall((:smcmi_get_stage_records, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                h, phi, ess, C_NULL, C_NULL, C_NULL))
+    cloud.tempering_schedule = phi; cloud.ESS = ess; cloud.stage_index = ns; cloud.n_Φ = n_Φ
+    cloud.resamples = res.resamples; cloud.c = res.c; cloud.accept = res.accept; cloud.total_sampling_time = res.seconds
+    w = Matrix{Float64}(undef, n_parts, ns); W = similar(w)
+    check(ccall((:smcmi_get_history, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}), h, w, W))
+    ls = LoopState()
+    check(ccall((:smcmi_get_loop_state, LIB), Cint, (Handle, Ref{LoopState}), h, ls))
+    return cloud, w, W, Int(ls.j)
+end
+
+# continue_intermediate (smc_main.jl:334-335, 355-361): cloud, w, W, j from the intermediate file back into the handle
+function load_intermediate!(h::Handle, loadpath, n_Φ, λ, d)
+    cloud = JLD2.load(loadpath, "cloud"); w = JLD2.load(loadpath, "w"); W = JLD2.load(loadpath, "W"); j = JLD2.load(loadpath, "j")
+    ns = cloud.stage_index
+    check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, cloud.particles))
+    zs = zeros(ns)
+    check(ccall((:smcmi_set_stage_records, LIB), Cint, (Handle, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                h, ns, cloud.tempering_schedule, cloud.ESS, zs, zs, zeros(Int32, ns)))
+    check(ccall((:smcmi_set_history, LIB), Cint, (Handle, Int32, Ptr{Float64}, Ptr{Float64}), h, ns, w[:, 1:ns], W[:, 1:ns]))
+    sched = ((collect(1:n_Φ) .- 1) ./ (n_Φ - 1)) .^ λ
+    logmdd = sum(log.(vec(sum(w[:, 2:ns] .* W[:, 1:ns-1], dims = 1)) ./ length(cloud)))        # SURVEY §8 a-9
+    ls = LoopState()
+    ls.stage_index = ns; ls.j = j; ls.resampled_last_period = 0; ls.resamples = cloud.resamples
+    ls.phi_n = cloud.tempering_schedule[ns]; ls.phi_prop = sched[j]; ls.c = cloud.c; ls.accept = cloud.accept
+    ls.ess = cloud.ESS[ns]; ls.logmdd = logmdd
+    check(ccall((:smcmi_set_loop_state, LIB), Cint, (Handle, Ref{LoopState}), h, ls))
+    return true
+end
+
+# Initial cloud of a tempered update on the device (smc_main.jl:244-333).  Returns cloud.ESS[1] of the new run.
+function tempered_cloud!(h::Handle, old::Cloud, parameters, old_lik, old_data, n_parts, pw, method, seed, device, keep)
+    old_n = length(old); d = n_para(old)
+    if pw == 0.0 && old_n == n_parts                                                             # :249-260
+        check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, old.particles))
+        check(ccall((:smcmi_initialize_likelihoods, LIB), Cint, (Handle,), h))
+        return old.ESS[end]
+    end
+    n_to = Int(round((1 - pw) * n_parts)); n_pr = n_parts - n_to                               # :262-264
+    if n_to > 0
+        ho = create(old_n, d, seed, device, 2)
+        try
+            check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), ho, old.particles))
+            check(ccall((:smcmi_bridge_resample, LIB), Cint, (Handle, Handle, Int32, UInt32, Int64, Ptr{Float64}, Ptr{Int64}),
+                        h, ho, method, 0, n_to, C_NULL, C_NULL))                                 # :266-279
+        finally
+            destroy(ho)
+        end
+    end
+    if n_pr > 0                                                                                  # :288-296
+        hp = create(n_pr, d, seed, device, 2)
+        try
+            set_parameters!(hp, parameters)
+            set_model!(hp, parameters, old_lik, old_data, 0, keep)
+            set_model!(hp, parameters, nothing, old_data, 1, keep)
+            initial_draw!(hp, parameters, old_lik, n_pr, d)
+            check(ccall((:smcmi_copy_rows, LIB), Cint, (Handle, Int64, Handle, Int64, Int64), h, n_to, hp, 0, n_pr))
+        finally
+            destroy(hp)
+        end
+    end
+    check(ccall((:smcmi_initialize_likelihoods, LIB), Cint, (Handle,), h))                       # :308
+    check(ccall((:smcmi_normalize_weights, LIB), Cint, (Handle, Int32), h, 1))                   # :313-314
+    check(ccall((:smcmi_resample, LIB), Cint, (Handle, Int32, UInt32, Ptr{Float64}, Ptr{Int64}), h, method, 1, C_NULL, C_NULL))   # :317-322
+    return Float64(n_parts)                                                                      # :325
 end
 
 end # module

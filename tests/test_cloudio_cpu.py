@@ -1,4 +1,5 @@
 """Cloud files and cloud utilities of the host mirror (src/particle.jl:542-648, 705-760; src/smc_main.jl:521-525): no GPU needed."""
+import os
 import numpy as np
 import pytest
 from scipy import stats
@@ -101,3 +102,44 @@ def test_add_parameters_to_cloud_layout():
     np.testing.assert_array_equal(c2.particles, c.particles)
     with pytest.raises(ValueError):
         S.add_parameters_to_cloud(old, pars, np.array([True, False, False, False, False]))
+
+
+def test_hdf5_outputs_round_trip(tmp_path):
+    """`particle_store_path` = HDF5 dataset "smcparams" and `savepath` with the reference's .jld2 / .h5 names (src/smc_main.jl:513-526)
+    through the built-in minimal HDF5 writer: exact paths (no appended extension), contents back through load_cloud, and - where
+    an HDF5 library is importable - through h5py with the Julia array convention (dims reversed, column-major bytes)."""
+    from smc_jl_amd.host import cloudio, h5min
+    from smc_jl_amd.host.api import Cloud
+
+    rng = np.random.default_rng(3)
+    n, d, ns = 50, 3, 7
+    c = Cloud(d, n)
+    c.particles = np.asfortranarray(rng.normal(size=(n, d + 5)))
+    c.tempering_schedule, c.ESS = np.linspace(0, 1, ns), rng.uniform(10, n, ns)
+    c.stage_index, c.n_Phi, c.resamples, c.c, c.accept, c.total_sampling_time = ns, 300, 2, 0.31, 0.24, 1.5
+    w, W = rng.uniform(size=(n, ns)), rng.uniform(size=(n, ns))
+    for name in ("run.jld2", "run.h5", "run.npz", "run.weird"):
+        path = str(tmp_path / name)
+        cloudio.save_cloud(path, c, w, W)
+        assert os.path.exists(path) and not os.path.exists(path + ".npz")           # the exact path is honoured
+        c2, w2, W2 = cloudio.load_cloud(path)
+        np.testing.assert_array_equal(c2.particles, c.particles)
+        np.testing.assert_array_equal(w2, w)
+        np.testing.assert_array_equal(W2, W)
+        assert (c2.stage_index, c2.n_Phi, c2.resamples, c2.c, c2.accept) == (ns, 300, 2, 0.31, 0.24)
+    store = str(tmp_path / "smcsave.h5")
+    cloudio.save_smcparams(store, c.particles, d)
+    back = h5min.read(store, julia=True)["smcparams"]
+    np.testing.assert_array_equal(back, c.particles[:, :d])
+    with open(store, "rb") as f:
+        assert f.read(8) == b"\x89HDF\r\n\x1a\n"
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(store, "r") as f:
+            np.testing.assert_array_equal(np.asarray(f["smcparams"]).T, c.particles[:, :d])      # HDF5.jl reads it as N x d
+        with h5py.File(str(tmp_path / "run.jld2"), "r") as f:
+            np.testing.assert_array_equal(np.asarray(f["cloud/particles"]).T, c.particles)
+            assert int(np.asarray(f["cloud/stage_index"])) == ns
