@@ -109,6 +109,45 @@ static int callback_fill_loglh(smcmi_handle *h, int which, int column) {
     return 0;
 }
 
+// initial_draw! (src/initialization.jl:88-119) with a host likelihood: the device draws the priors on the build's RNG contract
+// (attempt a of particle i = the draws k_init_prior makes on its a-th outer attempt), the callback scores them, particles without
+// a finite log-likelihood are redrawn (one_draw's loop, :23-63) - the cloud a device family with the same values would start from.
+static int callback_init_from_prior(smcmi_handle *h) {
+    for (int k = 0; k < h->d; ++k)
+        if (!h->h_model.fixed[k] && h->h_model.prior_family[k] != SMCMI_PRIOR_NORMAL && h->h_model.prior_family[k] != SMCMI_PRIOR_UNIFORM)
+            return set_err(SMCMI_ERR_UNSUPPORTED, "device prior sampling supports Normal/Uniform priors; draw on the host and upload");
+    if (int e = ensure_callback_buffers(h)) return e;
+    if (ensure_split_buffers(h)) return SMCMI_ERR_HIP;
+    CallbackBuffers *b = h->cbuf;
+    const long long n = h->n;
+    const int d = h->d;
+    std::vector<int> attempt((size_t)n, 0);
+    std::vector<double> gate((size_t)n);
+    long long todo = n;
+    for (int round = 0; todo > 0; ++round) {
+        if (round > 100000) return set_err(SMCMI_ERR_STATE, "initial draw: no finite-likelihood draw found");
+        HIP_TRY(hipMemcpyAsync(h->d_acc_count, attempt.data(), sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+        k_draw_prior<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model, h->cfg.seed, h->cfg.gid0, h->d_acc_count);
+        HIP_TRY(hipMemcpyAsync(b->h_prop, h->cl.buf[0], sizeof(double) * n * d, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_lp, h->cl.buf[0] + (long long)(d + 1) * n, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (long long i = 0; i < n; ++i) gate[i] = (attempt[i] >= 0 && b->h_lp[i] != -HUGE_VAL) ? 0.0 : -HUGE_VAL;     // evaluate the fresh, in-bounds draws only
+        std::vector<double> keep(b->h_lik[1], b->h_lik[1] + n);           // log-likelihoods of the particles already done
+        if (int e = eval_callback(h, 0, b->h_prop, gate.data(), b->h_lik[0])) return e;
+        todo = 0;
+        for (long long i = 0; i < n; ++i) {
+            if (attempt[i] < 0) { b->h_lik[0][i] = keep[i]; continue; }
+            const double ll = b->h_lik[0][i];
+            if (ll == -HUGE_VAL || ll != ll) { attempt[i] += 1; ++todo; }
+            else attempt[i] = -1;
+        }
+        memcpy(b->h_lik[1], b->h_lik[0], sizeof(double) * n);
+    }
+    HIP_TRY(hipMemcpyAsync(h->cl.buf[0] + (long long)d * n, b->h_lik[0], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // The whole loop with host likelihoods: engine 1's full stage (src/smc_main.jl:377-508 in its kernel sequence) up to the proposal
 // set-up, the callback mutation, one host sync per stage (the callback needs the proposals on the host anyway).
 static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {

@@ -2480,6 +2480,34 @@ __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState 
     col(cl, dst, d + 4)[i] = 1.0;
 }
 
+// Prior draw of the particles whose attempt[i] >= 0 - the draws k_init_prior makes on outer attempt attempt[i] (same Philox tags, same
+// bounds redraws) - with the log-prior; the likelihood comes from the host (callback.hpp): initial_draw! with a user closure.
+__global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const ModelDev *md, unsigned long long seed, long long gid0, const int *attempt) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= cl.n || attempt[i] < 0) return;
+    const int d = md->d;
+    const unsigned long long pid = (unsigned long long)(gid0 + i);
+    double thl[MAXD];
+    auto TH = [&](int k) { return thl[k]; };
+    for (int k = 0; k < d; ++k) {
+        if (md->fixed[k]) { thl[k] = md->prior_a[k]; continue; }
+        for (unsigned r = 0;; ++r) {
+            double ua, ub, x;
+            uniform_pair(seed, pid, (unsigned)attempt[i], rng_tag(P_INIT, r, (unsigned)k), ua, ub);
+            if (md->prior_family[k] == SMCMI_PRIOR_NORMAL)
+                x = md->prior_a[k] + md->prior_b[k] * (sqrt(-2.0 * log(ua)) * cos(6.283185307179586476925286766559 * ub));
+            else x = md->prior_a[k] + (md->prior_b[k] - md->prior_a[k]) * ua;
+            if ((md->lo[k] < x && x < md->hi[k]) || r > 100000u) { thl[k] = x; break; }
+        }
+    }
+    for (int k = 0; k < d; ++k) col(cl, 0, k)[i] = thl[k];
+    col(cl, 0, d)[i] = 0.0;
+    col(cl, 0, d + 1)[i] = in_bounds(*md, TH) ? logprior(*md, TH) : SMCMI_NEG_INF;
+    col(cl, 0, d + 2)[i] = 0.0;
+    col(cl, 0, d + 3)[i] = 0.0;
+    col(cl, 0, d + 4)[i] = 1.0;
+}
+
 // initialize_likelihoods! (src/initialization.jl:153-186): retire loglh to old_loglh, then evaluate the (new-data) likelihood
 // and the prior at every particle.  Out-of-bounds parameters give -Inf (the reference would throw ParamBoundsError here).
 __global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, const ModelDev *md) {

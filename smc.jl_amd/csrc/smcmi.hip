@@ -360,8 +360,10 @@ static int need_model(smcmi_handle *h, int lik) {
     return 0;
 }
 
+static int callback_init_from_prior(smcmi_handle *h);
 extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
-    if (int rc = need_model(h, true)) return rc;
+    if (int rc = need_model(h, 2)) return rc;
+    if (h->cb[0]) return callback_init_from_prior(h);                 // user likelihood: device draws, host scores
     for (int k = 0; k < h->d; ++k)
         if (!h->h_model.fixed[k] && h->h_model.prior_family[k] != SMCMI_PRIOR_NORMAL && h->h_model.prior_family[k] != SMCMI_PRIOR_UNIFORM)
             return set_err(SMCMI_ERR_UNSUPPORTED, "device prior sampling supports Normal/Uniform priors; draw on the host and upload");

@@ -320,7 +320,7 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             else:
                 pri.set_likelihood(*old_lik, which=0)
             pri.set_likelihood("none", which=1)
-            if old_lik[0] != "host_callback" and all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
+            if all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
                 pri.init_from_prior()
             else:
                 from .cloudio import host_initial_draw
@@ -329,8 +329,8 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
         kw["initial_ess"] = _tempered_update_cloud(eng, old_cloud, n_parts, tempered_update_prior_weight, resampling_method, seed,
                                                    device, prior_engine)
         w0 = eng.download_cloud()[:, d + 4].copy()
-    elif device_lik and all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
-        eng.init_from_prior()
+    elif all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
+        eng.init_from_prior()                             # device prior draws; log-likelihoods by the device family or the callback
     else:
         from .cloudio import host_initial_draw
         host_initial_draw(eng, parameters, seed)          # host draws; likelihoods by the device family or the callback

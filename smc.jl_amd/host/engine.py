@@ -127,7 +127,7 @@ class Engine:
         return p
 
     def init_from_prior(self):
-        check(self._L.smcmi_init_from_prior(self._h))
+        self._checked(self._L.smcmi_init_from_prior(self._h))
 
     def initialize_likelihoods(self):
         """initialize_likelihoods!: old_loglh <- loglh, then loglh / logprior on the (new) data."""

@@ -172,11 +172,12 @@ function set_parameters!(h::Handle, parameters)
                 h, fixed, lo, hi, fam, pa, pb))
 end
 
-# initial_draw! (src/initialization.jl:88-119): device sampler for Normal / Uniform priors with a device family; otherwise prior
-# draws on the host (rand(parameters, n), re-drawn until the log-likelihood is finite, :23-63) scored through the handle
+# initial_draw! (src/initialization.jl:88-119): device sampler for Normal / Uniform priors (log-likelihoods by the device family or,
+# for a closure, by the callback: smcmi_init_from_prior); otherwise prior draws on the host (rand(parameters, n), re-drawn until
+# the log-likelihood is finite, :23-63) scored through the handle
 function initial_draw!(h::Handle, parameters, lik, n_parts::Int, d::Int)
     simple = all(p -> p.fixed || p.prior.value isa Union{Normal, Uniform}, parameters)
-    if lik isa DeviceLikelihood && simple
+    if simple
         return check(ccall((:smcmi_init_from_prior, LIB), Cint, (Handle,), h))
     end
     P = zeros(n_parts, d + 5)

@@ -50,7 +50,15 @@ def test_tempered_initial_cloud_vs_oracle(old_run, n_parts, pw, method):
     eng.set_parameters(sp["priors"], sp["bounds"], sp["fixed"])
     eng.set_likelihood(*sp["lik"], which=0)
     eng.set_likelihood(*sp["old_lik"], which=1)
-    ess0 = api._tempered_update_cloud(eng, cloud, sp, sp["old_lik"], n_parts, pw, method, 11, 0)
+    def prior_engine(n_pr):                 # prior draws scored by the old likelihood on the old data (smc_main.jl:288-291)
+        pri = Engine(n_pr, 2, seed=11, max_stages=2, store_history=False)
+        pri.set_parameters(sp["priors"], sp["bounds"], sp["fixed"])
+        pri.set_likelihood(*sp["old_lik"], which=0)
+        pri.set_likelihood("none", which=1)
+        pri.init_from_prior()
+        return pri
+
+    ess0 = api._tempered_update_cloud(eng, cloud, n_parts, pw, method, 11, 0, prior_engine)
     P = eng.download_cloud()
     eng.close()
     m = models.oracle_model(sp)
