@@ -1,25 +1,29 @@
 #!/bin/bash
 # End-of-round measurement pipeline (one MI355X): every file profiles/README.md lists, into gpurun_out/final/.
-# usage (GPU box): bash tools/measure_round.sh
+# usage (GPU box): bash tools/measure_round.sh [rNN]
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
 cd $ROOT
-python bench.py --steps 8 --warmup 2 2>/dev/null | tail -1 > $OUT/bench.json
-python bench.py --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_1e6.json
-python bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_1e7.json
-python bench.py --nparts 100000000 --no-history --no-cpu --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_1e8.json
-python bench.py --workload capm --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_capm.json
-python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_kalman.json
-python tools/config2_seeds.py > $OUT/config2_seeds.json 2>/dev/null
+python bench.py --steps 8 --warmup 2 2>/dev/null | tail -1 > $OUT/${R}_bench.json
+python bench.py --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6.json
+python bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e7.json
+python bench.py --workload capm --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_capm.json
+python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
+LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu 2>/dev/null | tail -1 > $OUT/bench_under_rocprof.json
-rocprofv3 --kernel-trace --stats -d $OUT/kt7 -o kt7 -- python $ROOT/bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_1e7_under_rocprof.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_f -o f -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_w -o w -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
-cd $ROOT
-python profiles/summarize_rocpd.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.txt
-python profiles/summarize_rocpd.py $(find $OUT/kt7 -name "*.db" | head -1) > $OUT/kernel_stats_n1e7.txt
-python profiles/pmc_extract.py $(find $OUT/pmc_f -name "*.db" | head -1) $(find $OUT/pmc_w -name "*.db" | head -1) 100000 > $OUT/pmc_traffic.json
-rm -rf $OUT/kt $OUT/kt7 $OUT/pmc_f $OUT/pmc_w
+pmc() {   # pmc <tag> <n> <bench args...>: kernel table + the three counter passes of one configuration
+    local tag=$1 n=$2; shift 2
+    rocprofv3 --kernel-trace --stats -d $OUT/kt_$tag -o kt -- python $ROOT/bench.py --no-cpu "$@" 2>/dev/null | tail -1 > $OUT/${R}_bench_${tag}_under_rocprof.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf_$tag -o f -- python $ROOT/bench.py --no-cpu "$@" > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw_$tag -o w -- python $ROOT/bench.py --no-cpu "$@" > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/ps_$tag -o s -- python $ROOT/bench.py --no-cpu "$@" > /dev/null 2>&1
+    python $ROOT/profiles/summarize_rocpd.py $(find $OUT/kt_$tag -name "*.db" | head -1) > $OUT/${R}_kernel_stats_${tag}.txt
+    python $ROOT/profiles/pmc_extract.py $(find $OUT/pf_$tag -name "*.db" | head -1) $(find $OUT/pw_$tag -name "*.db" | head -1) $n $(find $OUT/ps_$tag -name "*.db" | head -1) > $OUT/${R}_pmc_${tag}.json
+    rm -rf $OUT/kt_$tag $OUT/pf_$tag $OUT/pw_$tag $OUT/ps_$tag
+}
+pmc gauss10_n100000 100000 --steps 3 --warmup 1
+pmc gauss10_n1000000 1000000 --nparts 1000000 --no-history --steps 1 --warmup 1
+pmc gauss10_n10000000 10000000 --nparts 10000000 --no-history --steps 1 --warmup 0
 ls -la $OUT
