@@ -6,9 +6,12 @@ MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).
            Calibration on known byte counts of this code base's own 8-byte-per-lane column accesses (N = 100000, round 1):
            a pass reading 3 columns = 2343.75 KiB: counter 1233.25 -> x1.90; writing 2 columns = 1562.5 KiB: counter 1568.8 -> x1.00;
            hipMemcpy D2D of 11718.75 KiB: WRITE 11764.5 (x1.00), FETCH 5886.5 (x1.99).
-  valu:    SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends issuing VALU instructions, summed over the chip;
-           frac = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE * 1024 SIMDs) = share of the launch's SIMD-cycles spent on VALU issue
-           (the bound of the mutation kernel: ~30 FP64 flop per byte).  SQ_INSTS_VALU / SQ_WAVES = VALU instructions per wavefront.
+  valu:    SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends issuing VALU instructions, summed over the chip; GRBM_GUI_ACTIVE
+           counts the launch's active cycles summed over the 8 XCDs (calibration: 16 852 030 for an 873.28 µs launch = 8 x 2.41 GHz;
+           SQ_BUSY_CYCLES likewise sums 32 shader engines).  frac = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+           = share of the launch's SIMD-cycles spent issuing VALU instructions (the bound of the mutation kernel: ~30 FP64 flop per
+           byte); for launches of a few tens of µs GRBM_GUI_ACTIVE includes the ramp around the kernel, so the share is a lower
+           bound there.  SQ_INSTS_VALU / SQ_WAVES = VALU instructions per wavefront.
 
 usage: python profiles/pmc_extract.py <fetch.db> <write.db> <n_particles> [<sq.db>] > profiles/rNN_pmc_<workload>_n<N>.json"""
 import json
@@ -49,9 +52,9 @@ if sq:
     for k in sorted(cnt["SQ_ACTIVE_INST_VALU"]):
         name = k.split("(")[0]
         m = {c: active_mean(v.get(k, [0.0]))[0] for c, v in cnt.items()}
-        frac = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (m["GRBM_GUI_ACTIVE"] * 1024.0) if m["GRBM_GUI_ACTIVE"] else None
+        frac = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0) if m["GRBM_GUI_ACTIVE"] else None
         res["kernels"].setdefault(name, {})["valu"] = {
-            "frac": frac, "unit": "share of SIMD cycles issuing VALU (4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE x 1024))",
+            "frac": frac, "unit": "share of SIMD cycles issuing VALU: 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
             "SQ_ACTIVE_INST_VALU": m["SQ_ACTIVE_INST_VALU"], "SQ_INSTS_VALU": m["SQ_INSTS_VALU"], "SQ_WAVES": m["SQ_WAVES"],
             "GRBM_GUI_ACTIVE": m["GRBM_GUI_ACTIVE"], "SQ_BUSY_CYCLES": m["SQ_BUSY_CYCLES"], "SQ_WAVE_CYCLES": m["SQ_WAVE_CYCLES"],
             "valu_insts_per_wave": m["SQ_INSTS_VALU"] / m["SQ_WAVES"] if m["SQ_WAVES"] else None}
