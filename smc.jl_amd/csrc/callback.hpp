@@ -244,6 +244,7 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
     res->solver_passes = s.solver_passes;
     res->paused = (s.done == 5) ? 1 : 0;
     h->last_n_stages = s.stage;
+    if (s.err == SMCMI_ERR_NAN_ESS) return nan_ess_error(h, h->cl.buf[0] + (long long)(h->R - 1) * h->n);
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;

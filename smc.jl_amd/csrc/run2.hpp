@@ -554,6 +554,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
     res->paused = (s.done == 5) ? 1 : 0;
+    if (s.err == SMCMI_ERR_NAN_ESS) return nan_ess_error(h0, h0->d_wt);
     if (s.err) return err_from_state(s.err);
     if (!(c.status.code == 1 || c.status.code == 5)) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;

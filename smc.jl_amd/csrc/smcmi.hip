@@ -125,6 +125,30 @@ static int err_from_state(int code) {
     }
 }
 
+// check_nan_ess (src/helpers.jl:270-305): the reference's diagnosis of "ESS is NaN", from the unnormalised weights W̃ the failing
+// correction left (`wbuf`: the scratch column of engine 2 / of a predicted stage, else the cloud's weight column) and the stage's
+// incremental weights where the history is stored.
+static int nan_ess_error(smcmi_handle *h, const double *wbuf) {
+    std::string msg = "No particles have non-zero weight.";
+    const long long n = h->n;
+    std::vector<double> w((size_t)n);
+    bool ok = hipMemcpy(w.data(), wbuf, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok) {
+        bool any_inf = false, any_nan = false;
+        double s = 0.0, s2 = 0.0;
+        for (long long i = 0; i < n; ++i) { any_inf |= std::isinf(w[i]); any_nan |= std::isnan(w[i]); s += w[i]; }
+        for (long long i = 0; i < n; ++i) { const double v = (double)h->cfg.n_parts * w[i] / s; s2 += v * v; }
+        if (any_inf) msg += " Some particles have approximately infinite log-likelihoods.";
+        if (any_nan) msg += " Some particles have approximately NaN log-likelihoods.";
+        if (s2 <= 2.220446049250313e-16) msg += " The squared sum of the normalized weights is at machine-error.";
+        if (std::isnan(s2)) {
+            msg += " The squared sum of the normalized weights is returning a NaN.";
+            if (any_nan || !(s > 0.0)) msg += " Part of the reason is that one of the normalized weights is a NaN";
+        }
+    }
+    return set_err(SMCMI_ERR_NAN_ESS, msg + " (ESS is NaN)");
+}
+
 static int set_mutate_attrs(smcmi_handle *h);
 static void smcmi_comm_release(smcmi_handle *h);
 
@@ -1183,6 +1207,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     res->solver_passes = s.solver_passes;
     res->paused = (s.done == 5) ? 1 : 0;
     h->last_n_stages = s.stage;
+    if (s.err == SMCMI_ERR_NAN_ESS) return nan_ess_error(h, h->spec_stage ? h->d_wt : h->cl.buf[0] + (long long)(h->R - 1) * h->n);
     if (s.err) return err_from_state(s.err);
     if (!s.done) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;

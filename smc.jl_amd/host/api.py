@@ -61,8 +61,44 @@ class RootInverseGamma(_Prior):  # ModelConstructors.RootInverseGamma(ν, τ)
 
 
 class Parameter:
+    """ModelConstructors.Parameter as far as SMC reads it.  `regimes` (ModelConstructors' regime-switching values, set with
+    set_regime_val! / set_regime_prior! / set_regime_fixed! / set_regime_valuebounds!): regime 1 is the parameter itself, regime i >= 2
+    is regimes[i - 2] = Parameter-like entry with its own value, prior, bounds and fixedness."""
+
     def __init__(self, key, value, valuebounds, prior, fixed=False):
         self.key, self.value, self.valuebounds, self.prior, self.fixed = key, float(value), tuple(valuebounds), prior, bool(fixed)
+        self.regimes = []
+
+    def add_regime(self, value, prior=None, valuebounds=None, fixed=None):
+        """One more regime value of this parameter (defaults: the parameter's own prior / bounds / fixedness)."""
+        fx = self.fixed if fixed is None else bool(fixed)
+        r = Parameter("%s_reg%d" % (self.key, len(self.regimes) + 2), value, self.valuebounds if valuebounds is None else valuebounds,
+                      self.prior if prior is None else prior, fx)
+        self.regimes.append(r)
+        return self
+
+
+def flatten_regimes(parameters, regime_switching=True):
+    """The parameter vector SMC samples when regime_switching = true (src/smc_main.jl:207-234): the regime-1 entries of all parameters
+    in order, then, parameter by parameter, the values of regimes 2, 3, ... - each a column of cloud.particles with its own prior,
+    bounds and fixedness (para_symbols: key, ..., key_reg2, ...).  Without regime switching: the parameters themselves."""
+    parameters = list(parameters)
+    if not regime_switching:
+        return parameters
+    return parameters + [r for p in parameters for r in getattr(p, "regimes", [])]
+
+
+def regime_values(parameters, theta):
+    """What update!(parameters, theta) leaves in a regime-switching ParameterVector (src/mutation.jl:93): key -> [value in regime 1,
+    regime 2, ...] for a flattened draw `theta`.  A likelihood closure uses it to read the regime-dependent parameters."""
+    parameters = list(parameters)
+    out = {p.key: [float(theta[k])] for k, p in enumerate(parameters)}
+    pos = len(parameters)
+    for p in parameters:
+        for _ in getattr(p, "regimes", []):
+            out[p.key].append(float(theta[pos]))
+            pos += 1
+    return out
 
 
 def parameter(key, value, valuebounds=(-1e5, 1e5), transform_parameterization=None, transform=None, prior=None, fixed=False):
@@ -256,12 +292,15 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
         raise ValueError("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
     if not 0.0 <= tempered_update_prior_weight <= 1.0:
         raise ValueError("The keyword tempered_update_prior_weight must be within the interval [0, 1]")
-    parameters = list(parameters)
+    # regime switching (src/smc_main.jl:207-234, src/mutation.jl:98-110): every regime value beyond the first is one more column of the
+    # cloud with its own prior / bounds / fixedness; the likelihood closure receives the flattened vector (regime_values() splits
+    # it per key).  `toggle` only concerns ModelConstructors' internal regime pointer, which this mirror does not have.
+    parameters = flatten_regimes(parameters, regime_switching)
     d = len(parameters)
     if all(p.fixed for p in parameters):
         raise AssertionError("All model parameters are fixed!")
-    if regime_switching:
-        raise NotImplementedError("regime_switching = true is outside this build (ModelConstructors regime parameters)")
+    if regime_switching and isinstance(loglikelihood, DeviceLikelihood):
+        raise ValueError("regime_switching = true needs a likelihood closure (the device families take a fixed parameter layout)")
     if old_data is not None and np.size(old_data) and initial_cloud is None and old_cloud is None and not continue_intermediate:
         if not loadpath:
             raise ValueError("a tempered update (non-empty old_data) needs old_cloud = the Cloud of the old estimation, or loadpath")

@@ -115,6 +115,7 @@ struct CallbackEnv
     f::Function
     parameters::ParameterVector
     data::Matrix{Float64}
+    toggle::Bool              # toggle_regime!(parameters, 1) after the evaluation (src/mutation.jl:98-110)
 end
 function lik_trampoline(theta::Ptr{Float64}, m::Int64, d::Int64, out::Ptr{Float64}, ud::Ptr{Cvoid})::Cint
     env = unsafe_pointer_to_objref(ud)::CallbackEnv
@@ -125,7 +126,9 @@ function lik_trampoline(theta::Ptr{Float64}, m::Int64, d::Int64, out::Ptr{Float6
         for k in 1:m
             o[k] = try
                 update!(p, th[k, :])                        # mutation.jl:93 (cannot throw: only in-bounds proposals arrive)
-                env.f(p, env.data)                          # mutation.jl:96
+                v = env.f(p, env.data)                      # mutation.jl:96
+                env.toggle && ModelConstructors.toggle_regime!(p, 1)      # mutation.jl:98-100, 108-110
+                v
             catch err
                 isa(err, Union{CALLBACK_ERRORS...}) ? -Inf : rethrow(err)
             end
@@ -137,7 +140,7 @@ function lik_trampoline(theta::Ptr{Float64}, m::Int64, d::Int64, out::Ptr{Float6
     end
 end
 
-function set_model!(h::Handle, parameters, lik, data, which::Integer, keep::Vector{Any})
+function set_model!(h::Handle, parameters, lik, data, which::Integer, keep::Vector{Any}; toggle::Bool = false)
     if lik === nothing
         check(ccall((:smcmi_set_likelihood, LIB), Cint,
                     (Handle, Int32, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64),
@@ -148,7 +151,7 @@ function set_model!(h::Handle, parameters, lik, data, which::Integer, keep::Vect
                     (Handle, Int32, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64),
                     h, which, family(lik), par, length(par), data, size(data, 1), size(data, 2), aux, size(aux, 1), size(aux, 2)))
     else
-        env = CallbackEnv(lik, parameters, data)
+        env = CallbackEnv(lik, parameters, data, toggle)
         push!(keep, env)                                    # rooted for the lifetime of the handle
         fptr = @cfunction(lik_trampoline, Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}))
         check(ccall((:smcmi_set_likelihood_callback, LIB), Cint, (Handle, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
@@ -163,10 +166,30 @@ function create(n_parts, d, seed, device, max_stages)
 end
 destroy(h::Handle) = ccall((:smcmi_destroy, LIB), Cint, (Handle,), h)
 
-function set_parameters!(h::Handle, parameters)
-    fixed = Int32[p.fixed ? 1 : 0 for p in parameters]
-    lo = Float64[p.valuebounds[1] for p in parameters]; hi = Float64[p.valuebounds[2] for p in parameters]
-    codes = [p.fixed ? (Int32(0), p.value, 1.0) : prior_code(p.prior.value) for p in parameters]
+# One entry per column of cloud.particles: (fixed, value, bounds, prior).  With regime_switching = true the regime-1 values of all
+# parameters come first, then, parameter by parameter, the values of regimes 2, 3, ... (src/smc_main.jl:207-234: n_para counts them,
+# para_symbols names them key_reg<i>) - the layout ModelConstructors.update!(parameters, θ) expects for a regime-switching vector.
+function flat_entries(parameters, regime_switching::Bool)
+    ent = Any[(p.fixed, p.value, p.valuebounds, p.fixed ? nothing : p.prior.value) for p in parameters]
+    if regime_switching
+        for p in parameters
+            isempty(p.regimes) && continue
+            for i in 2:length(p.regimes[:value])
+                fx = haskey(p.regimes, :fixed) && haskey(p.regimes[:fixed], i) ? p.regimes[:fixed][i] : p.fixed
+                vb = haskey(p.regimes, :valuebounds) && haskey(p.regimes[:valuebounds], i) ? p.regimes[:valuebounds][i] : p.valuebounds
+                pr = haskey(p.regimes, :prior) && haskey(p.regimes[:prior], i) ? p.regimes[:prior][i].value : (p.fixed ? nothing : p.prior.value)
+                push!(ent, (fx, p.regimes[:value][i], vb, fx ? nothing : pr))
+            end
+        end
+    end
+    ent
+end
+
+function set_parameters!(h::Handle, parameters; regime_switching::Bool = false)
+    ent = flat_entries(parameters, regime_switching)
+    fixed = Int32[e[1] ? 1 : 0 for e in ent]
+    lo = Float64[e[3][1] for e in ent]; hi = Float64[e[3][2] for e in ent]
+    codes = [e[1] ? (Int32(0), e[2], 1.0) : prior_code(e[4]) for e in ent]
     fam = Int32[x[1] for x in codes]; pa = Float64[x[2] for x in codes]; pb = Float64[x[3] for x in codes]
     check(ccall((:smcmi_set_parameters, LIB), Cint, (Handle, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
                 h, fixed, lo, hi, fam, pa, pb))
@@ -205,7 +228,8 @@ Drop-in for `SMC.smc` (src/smc_main.jl:118-161): same positional arguments, same
 `savepath` with `_stage=i` (smc_main.jl:499-507, 513-526).  `loglikelihood` is the user's closure
 `loglikelihood(parameters::ParameterVector, data::Matrix{Float64})::Float64` or one of the `DeviceLikelihood` structs.
 Returns `(cloud, w, W)` in addition to writing the files (the reference returns nothing, quirk Q8).
-Not supported: `regime_switching = true`; `parallel` is moot (the device is the parallelism).
+`regime_switching = true` (closures only) samples the extra regime values as additional columns; `parallel` is moot (the device is
+the parallelism).
 """
 function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
              verbose::Symbol = :low, testing::Bool = false, data_vintage::String = Dates.format(today(), "yymmdd"),
@@ -222,21 +246,22 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
              regime_switching::Bool = false, toggle::Bool = true, debug_assertion::Bool = false,
              log_prob_old_data::Float64 = 0.0, seed::Integer = rand(UInt64), device::Integer = 0)
     haskey(RESAMPLER, resampling_method) || throw("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
-    regime_switching && throw(ArgumentError("regime_switching = true is not supported by the MI355X engine"))
+    regime_switching && loglikelihood isa DeviceLikelihood &&
+        throw(ArgumentError("regime_switching = true needs a likelihood closure (the device families take a fixed parameter layout)"))
     0.0 <= tempered_update_prior_weight <= 1.0 ||
         throw(DomainError("The keyword tempered_update_prior_weight must be within the interval [0, 1] but " *
                           "is currently set to $(tempered_update_prior_weight)"))
-    d = length(parameters)
-    all(p -> p.fixed, parameters) && throw(AssertionError("All model parameters are fixed!"))      # smc_main.jl:236-239
+    d = length(flat_entries(parameters, regime_switching))                                         # n_para incl. the regime columns, :207-216
+    all(e -> e[1], flat_entries(parameters, regime_switching)) && throw(AssertionError("All model parameters are fixed!"))      # :236-239
     tempered_update = !isempty(old_data)
     max_stages = use_fixed_schedule ? n_Φ : 20 * n_Φ
     method = RESAMPLER[resampling_method]
     keep = Any[]                                             # callback environments (GC roots)
     h = create(n_parts, d, seed, device, max_stages)
     try
-        set_parameters!(h, parameters)
-        set_model!(h, parameters, loglikelihood, data, 0, keep)
-        set_model!(h, parameters, tempered_update ? old_loglikelihood : nothing, old_data, 1, keep)
+        set_parameters!(h, parameters; regime_switching = regime_switching)
+        set_model!(h, parameters, loglikelihood, data, 0, keep; toggle = regime_switching && toggle)
+        set_model!(h, parameters, tempered_update ? old_loglikelihood : nothing, old_data, 1, keep; toggle = regime_switching && toggle)
         initial_ess = 0.0
         W1 = nothing                                         # W_matrix[:, 1] of a tempered update (smc_main.jl:364-365)
         cont = false

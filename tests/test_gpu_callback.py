@@ -130,3 +130,34 @@ def test_c_callback_example_builds_and_matches():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "OK" in p.stdout
+
+
+def test_regime_switching_columns():
+    """regime_switching = true (src/smc_main.jl:207-234, src/mutation.jl:98-110): a parameter with two regimes contributes two columns
+    (key, key_reg2) with their own priors; the closure reads the values per regime.  Model: y_t = mu_{r(t)} + e_t with the regime
+    switching at mid-sample - the posterior means of the two columns must find the two levels."""
+    import smc_jl_amd as S
+
+    rng = np.random.default_rng(4)
+    T = 80
+    y = np.concatenate([0.5 + 0.3 * rng.normal(size=T // 2), 2.0 + 0.3 * rng.normal(size=T // 2)])
+    data = y.reshape(1, T)
+    mu = S.parameter("mu", 0.0, (-10.0, 10.0), prior=S.Normal(0.0, 3.0)).add_regime(0.0, prior=S.Normal(0.0, 3.0))
+    sig = S.parameter("sig", 0.3, (1e-3, 5.0), prior=S.Uniform(0.0, 5.0), fixed=True)
+    pars = [mu, sig]
+    flat = S.flatten_regimes(pars)
+    assert [p.key for p in flat] == ["mu", "sig", "mu_reg2"]
+
+    def loglik(theta, dat):
+        v = S.regime_values(pars, theta)
+        m = np.where(np.arange(T) < T // 2, v["mu"][0], v["mu"][1])
+        e = dat[0] - m
+        s = v["sig"][0]
+        return -0.5 * T * math.log(2.0 * math.pi * s * s) - 0.5 * float(e @ e) / (s * s)
+
+    cloud, w, W = S.smc(loglik, pars, data, regime_switching=True, n_parts=3000, n_phi=60, verbose="none", seed=2)
+    assert cloud.particles.shape == (3000, 3 + 5)
+    m = S.weighted_mean(cloud)
+    assert abs(m[0] - y[:T // 2].mean()) < 0.1 and abs(m[2] - y[T // 2:].mean()) < 0.1 and abs(m[1] - 0.3) < 1e-12
+    with pytest.raises(ValueError):
+        S.smc(S.GaussIso(0.25), pars, data, regime_switching=True, n_parts=100, verbose="none")

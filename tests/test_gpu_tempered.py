@@ -251,5 +251,5 @@ def test_tempered_update_loads_old_cloud_from_loadpath(tmp_path, old_run):
     assert not (tmp_path / "a.npz").exists()
     assert a.stage_index == b.stage_index and a.logmdd == b.logmdd
     np.testing.assert_array_equal(a.particles, b.particles)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         S.smc(S.LinReg(1.0), _pars(S), data, regime_switching=True, **kw)
