@@ -1556,12 +1556,13 @@ __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 // RSQ = true (engine 2): the pivot's reciprocal square root (hardware estimate + two Newton steps, ~1 ulp) replaces the
 // correctly rounded sqrt and division - the column's critical path is a third as long (the factorisation is ten dependent
 // columns, every block of a launch waits for it); L differs from the oracle's in the last bit or two.
-template <int DBM, bool RSQ = false>
+// FULL = true: db == DBM, no per-column run-time test.
+template <int DBM, bool RSQ = false, bool FULL = false>
 __device__ inline bool chol_rows_in_regs(double (&r)[DBM], int db, int lane) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < DBM; ++j) {
-        if (j < db) {
+        if (FULL || j < db) {
             const double ajj = bcast_lane(r[j], j);
             if (!(ajj > 0.0)) ok = false;
             double ljj, lij;

@@ -1010,8 +1010,41 @@ struct Prop2 {                 // LDS pointers (k2_mutate carves them out of its
     double *Lraw, *logdet, *mub, *sdd, *sdn;
     int *ball, *loff;
 };
+// chol_rows_in_regs with the dimension as a compile-time constant: straight-line code the scheduler can overlap across columns
+template <int DB>
+__device__ inline bool chol_full(double (&r)[12], int lane) {
+    double q[DB];
+#pragma unroll
+    for (int k = 0; k < DB; ++k) q[k] = r[k];
+    const bool ok = chol_rows_in_regs<DB, true, true>(q, DB, lane);
+#pragma unroll
+    for (int k = 0; k < DB; ++k) r[k] = q[k];
+    return ok;
+}
+__device__ inline bool chol_full_dispatch(double (&r)[12], int d, int lane) {
+    switch (d) {
+    case 2: return chol_full<2>(r, lane); case 3: return chol_full<3>(r, lane); case 4: return chol_full<4>(r, lane);
+    case 5: return chol_full<5>(r, lane); case 6: return chol_full<6>(r, lane); case 7: return chol_full<7>(r, lane);
+    case 8: return chol_full<8>(r, lane); case 9: return chol_full<9>(r, lane); default: return chol_full<10>(r, lane);
+    }
+}
+
+// Fisher-Yates partner of position i (helpers.jl:216) for lane i of a wavefront: depends on (seed, stage) only, so callers draw it
+// while their loads are in flight
+__device__ inline int shuffle_partner(unsigned long long seed, unsigned stage, int i0, int nf) {
+    int jx = 0;
+    if (i0 >= 1 && i0 < nf) {
+        double ua, ub;
+        uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i0, 0), ua, ub);
+        jx = (int)(ua * (double)(i0 + 1));
+        if (jx > i0) jx = i0;
+    }
+    return jx;
+}
+
+// jx_pre: shuffle_partner() of lane (threadIdx.x & 63), valid in wavefront 1 (threads 64..127)
 __device__ inline bool proposal2(const double *T, const double *shift, int d, int nf, int nb, double c, unsigned long long seed,
-                                 unsigned stage, const Prop2 &P, int *s_fail, int TT, long long *prof = nullptr) {
+                                 unsigned stage, const Prop2 &P, int *s_fail, int TT, int jx_pre, long long *prof = nullptr) {
     const int t = threadIdx.x, da = d + 1;
     const double sw = T[0];
     if (t == 0) *s_fail = 0;
@@ -1027,13 +1060,7 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
         // Fisher-Yates (helpers.jl:216: i = nf-1 .. 1, swap(i, j_i)) without a serial pass over memory: lane l traces position l
         // back through the swaps in reverse order of application; what it ends at is the identity's entry that lands on l.
         const int i0 = t - 64;
-        int jx = 0;
-        if (i0 >= 1 && i0 < nf) {
-            double ua, ub;
-            uniform_pair(seed, 0ull, stage, rng_tag(P_BLK, (unsigned)i0, 0), ua, ub);
-            jx = (int)(ua * (double)(i0 + 1));
-            if (jx > i0) jx = i0;
-        }
+        const int jx = jx_pre;
         int pos = i0;
         for (int i = 1; i < nf; ++i) {
             const int ji = __shfl(jx, i, 64);
@@ -1076,7 +1103,9 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
             double r[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) r[k] = (lane < db && k < db) ? P.A[off + lane * db + k] : 0.0;
-            const bool ok = chol_rows_in_regs<12, true>(r, db, lane);
+            bool ok;
+            if (db == d && d <= 10 && d >= 2) ok = chol_full_dispatch(r, d, lane);      // one block over all parameters: no per-column branches
+            else ok = chol_rows_in_regs<12, true>(r, db, lane);
             if (!ok && lane == 0) *s_fail = 1;
 #pragma unroll
             for (int k = 0; k < 12; ++k)
@@ -1149,6 +1178,7 @@ __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, 
     }
     for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
     if (tid < nf) L.fi[tid] = md->free_inds[tid];
+    const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // under the loads' latency
     K2_STAMP(ma.prof, 1);
     reduce_rows<pad2(NPF), 1, T>(ma.cmrows, L.s_vt, L.s_tot);          // (its barriers also publish the LDS copies above)
     K2_STAMP(ma.prof, 2);
@@ -1170,7 +1200,7 @@ __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, 
     // moments of the resampled cloud (k2_gather's rows) replace the correction's on resample stages
     if (rs) reduce_rows<pad2(NP), 1, T>(ma.gmrows, L.s_vt, L.s_tot + 2);
     Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
-    if (!proposal2(L.s_tot + 2, S->po.shift, D, nf, nb, S->po.c * S->bg.cfac, ma.seed, (unsigned)n, P, &S->fail, T, ma.prof)) {
+    if (!proposal2(L.s_tot + 2, S->po.shift, D, nf, nb, S->po.c * S->bg.cfac, ma.seed, (unsigned)n, P, &S->fail, T, jx_pre, ma.prof)) {
         // PosDefException aborts the run (mutation.jl:81)
         if (blockIdx.x == 0 && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
         return false;
@@ -1469,11 +1499,16 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
     K2_STAMP(ma.prof, 9);
     double acc_val = 0.0;
     if (live) {
+        // a particle that accepted nothing still holds what buffer 0 holds (three quarters of the cloud at the target acceptance
+        // rate): its 13 value columns are not written again - the stage's HBM write traffic drops by two thirds.  After a resample
+        // the particle came from buffer 1 and every column is written.
+        if (accept > 0.0 || rs) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = x[k];
-        col(cl, 0, D)[i] = like;
-        col(cl, 0, D + 1)[i] = lprior;
-        col(cl, 0, D + 2)[i] = like_prev;
+            for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = x[k];
+            col(cl, 0, D)[i] = like;
+            col(cl, 0, D + 1)[i] = lprior;
+            col(cl, 0, D + 2)[i] = like_prev;
+        }
         acc_val = accept / (double)nf;                      // quirk Q2: normalised by n_free only
         col(cl, 0, D + 3)[i] = acc_val;
     }
