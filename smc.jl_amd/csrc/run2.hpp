@@ -414,7 +414,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 
     const int base = cont ? h0->h_st.stage - 1 : 0;           // stages completed before this call
     const int max_iter = (adaptive ? h0->cfg.max_stages : rc->n_phi - 1) - base;
-    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 32;     // stages per host sync (a stalled stage wastes the rest of its batch: two idle launches per stage)
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
