@@ -73,7 +73,12 @@ typedef struct {
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
     int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
     double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */
-    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root (0 => 1e-12; <0 => adjacent floats) */
+    double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root on stages that run certificate
+                                              passes (0 => 1e-12; <0 => adjacent floats, and no stage is predicted).  Stages on the
+                                              predict -> correct -> verify path (most adaptive stages when n_para <= 10) accept the
+                                              predicted ϕ_n when the ESS measured by the correction is within max(phi_rtol, 1e-10)
+                                              of the target in ϕ units; values below 1e-10 therefore need phi_rtol < 0 to hold on
+                                              every stage */
     int32_t stop_after_stage;              /* > 0: return (result.paused = 1) once cloud.stage_index has reached it - the save point of
                                               `save_intermediate` / `intermediate_stage_increment` (smc_main.jl:499-507); shards pause in lock step */
     int32_t continue_run;                  /* 1: go on from the handle's loop state (after a pause, or after smcmi_set_loop_state:
