@@ -252,7 +252,8 @@ def main():
         out["roofline"] = {"bound": "valu" if D <= 10 else "hbm", "kernel": kname_run, "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl,
-                           "valu": valu, "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None}
+                           "valu_frac": valu.get("frac") if valu else None, "valu": valu,
+                           "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None}
         if args.workload == "kalman" and mean_ms > 0:
             # config 5 is compute bound: ~3300 FP64 flops per filter step (FMA = 2; csrc/model.hpp kalman_lgss), steps = new + old
             # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s
