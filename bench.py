@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--solver-passes", type=int, default=0)
     ap.add_argument("--sync-every", type=int, default=0)
     ap.add_argument("--phi-rtol", type=float, default=0.0, help="adaptive-phi root tolerance (0 = library default)")
+    ap.add_argument("--alpha", type=float, default=None, help="mixture weight of the proposal (default: the workload's own)")
+    ap.add_argument("--n-blocks", type=int, default=None, help="random parameter blocks per MH step (default: the workload's own)")
     args = ap.parse_args()
 
     world, must_spawn = resolve_world(args.gpus, os.environ)
@@ -129,6 +131,10 @@ def main():
     else:
         spec = models.gauss_spec(D)
         default_total = N_PER_GPU if world == 1 else N_TOTAL_SHARDED
+    if args.alpha is not None:
+        RUN_KW["alpha"] = args.alpha
+    if args.n_blocks is not None:
+        RUN_KW["n_blocks"] = args.n_blocks
     seed = 1
     n_total = args.nparts if args.nparts > 0 else default_total
     if n_total % world:
@@ -202,7 +208,7 @@ def main():
                          else "lgss_kalman13_old40_new80_adaptive_phi_n%dk" % (n_total // 1000)),
                    "n_parts_total": n_total, "n_parts_per_gpu": n_local, "n_para": D, "tempering_target": RUN_KW.get("tempering_target", 0.97),
                    "n_phi": RUN_KW.get("n_phi", 300), "lambda": 2.1,
-                   "resampling": "systematic", "n_blocks": 1, "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
+                   "resampling": "systematic", "n_blocks": RUN_KW["n_blocks"], "alpha": RUN_KW["alpha"], "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
         "logmdd_exact": models.gauss_logmdd(D) if args.workload == "gauss10" else None, "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),

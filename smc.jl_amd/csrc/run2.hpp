@@ -48,12 +48,15 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
     // direct: every block totals the per-block rows itself - one handle, <= GRP rows per virtual shard, and the 512-thread mutation
     // blocks (one per CU) resident at once
-    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= 256) ? 1 : 0;
+    static const int direct_max = getenv("SMCMI_E2_DIRECT_MAX") ? atoi(getenv("SMCMI_E2_DIRECT_MAX")) : 256;   // development only
+    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= direct_max) ? 1 : 0;
     if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
-    if (!g.direct) {                                      // large clouds / several handles: 256-thread mutation blocks (3 wavefronts per SIMD)
+    // several handles with small shards: one 512-thread mutation block per CU as well, prologues in the kernels, fed by the gathered totals
+    static const int no_inker = getenv("SMCMI_E2_NO_INKER") ? atoi(getenv("SMCMI_E2_NO_INKER")) : 0;              // development only
+    g.inker = (g.direct || (!single && !no_inker && (long long)g.nb2 * g.Vl <= 256)) ? 1 : 0;
+    if (!g.inker) {                                       // large clouds: 256-thread mutation blocks (3 wavefronts per SIMD)
         g.t2 = 256;
         g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
-        if (g.direct && g.nb2 > GRP) g.direct = 0;
     }
     // correction blocks per virtual shard: 1024 particles per block (two passes of its 512 threads), at most 16 rows per virtual shard for
     // K2's prologue to total while the cloud is small
@@ -70,7 +73,7 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
 static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     Geo2 g;
     if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
-    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1) return 0;
+    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1) return 0;
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     Eng2 *e = new Eng2();
     e->g = g; e->world = world;
@@ -207,7 +210,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
         Eng2 *e = h->e2;
         e->rng_ahead = false; e->n_steps = rc->n_mh_steps; e->n_blocks = rc->n_blocks;
-        if (!no_ra && e->g.direct && e->g.t2 == 512) {
+        if (!no_ra && e->g.inker && e->g.t2 == 512 && e->g.Vl * e->g.nb1 <= 160) {
             const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)rc->n_mh_steps * (size_t)rc->n_blocks;
             if (need > h->zbuf_cap) {
                 if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
@@ -224,7 +227,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     }
     const Geo2 g0 = h0->e2->g;
     const int npf = pad2(h0->npairs + 2), np = pad2(h0->npairs);
-    const bool direct = g0.direct != 0;
+    const bool direct = g0.direct != 0, inker = g0.inker != 0;
     // ---- row-set plumbing
     auto view = [&](smcmi_handle *, const double *rows, const double *vt, int nr, int m) {
         return direct ? Rows2{rows, g0.Vl, nr, m} : Rows2{vt, g0.V, 1, m};
@@ -336,13 +339,13 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n; ma.sel_enqueued = sel_enqueued; ma.adaptive = adaptive ? 1 : 0;
             ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
             ma.zbuf = e->rng_ahead ? h->d_zbuf : nullptr;
-            ma.pre = direct ? nullptr : e->d_pre;
+            ma.pre = inker ? nullptr : e->d_pre;
             ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
             ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
             ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
             ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
             ma.prof = (e->d_prof && n == e->prof_stage) ? e->d_prof + 64 : nullptr;
-            if (!direct) {               // decision + proposal once, by one block
+            if (!inker) {                // decision + proposal once, by one block
                 Mut2Args mp = ma;
                 mp.pre = nullptr;
 #define SMCMI_CALL(D) k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, rc->n_blocks, h->h_model.n_free, e->d_pre)
@@ -389,7 +392,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             if (int e = enq_begin(n)) return e;
             if (int e = enq_passes(n, 0, P)) return e;
             if (int e = enq_K1(n, 1, 0)) return e;
-        } else if (!direct) {              // many blocks per CU: the stage-begin logic once, by one block
+        } else if (!inker) {               // many blocks per CU: the stage-begin logic once, by one block
             if (int e = enq_begin(n, adaptive ? 1 : 0)) return e;
             if (int e = enq_K1(n, 1, 0)) return e;
         } else if (int e = enq_K1(n, 0, adaptive ? 1 : 0)) return e;

@@ -55,6 +55,8 @@ struct Geo2 {
     int t2;                       // threads (= particles) of a mutation block: 512 while the cloud is small (half as many rows for the
                                   // next stage's begin to total, one block per CU), 256 beyond (3 wavefronts per SIMD)
     int direct;                   // consumers total the per-block rows themselves (one handle, <= GRP rows per virtual shard)
+    int inker;                    // every block runs the begin / decision / proposal logic in its prologue (<= one 512-thread block per CU):
+                                  // direct, or several handles with small shards (the rows then are the all-gathered V x m totals)
 };
 
 struct Rows2 {                    // rows[(v * nr + r) * ld + idx], v < nvs, r < nr
