@@ -1884,6 +1884,8 @@ struct MutArgs {
     long long hist_ld;
     const double *wt;          // normalize: read W̃ from here instead of the weight column (spec stages)
     double *emax;              // in-run MODE 0: per-block largest loglh - old_loglh of the mutated cloud (next stage's energy shift) or null
+    const double *mix;         // register kernel, α < 1: the blocks' dense mixture matrices from k_mix_prepare ([n_blocks][MixDense::DOUBLES])
+    const int *mixpos;         //                         and parameter positions ([n_blocks][D])
 };
 
 template <int MODE>
@@ -2071,6 +2073,181 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     }
 }
 
+// ------------------------------------------------------------------------------------------------ mixture proposal, dense form
+// The α < 1 proposal (src/helpers.jl:87-100 draw, :128-164 densities) of the register-resident kernels, arranged so that nothing
+// is indexed by block position at run time and nothing divides per particle.  Per random block b with factor L (c²Σ_b = L Lᵀ,
+// block order e) and W = L⁻¹, the block's constants are expanded, in NATURAL parameter order k, to
+//   LsT[e][k] = L[pos(k)][e]         draw of the full-covariance components:  Σ_e LsT[e][k] z_e      (zero rows/columns outside b)
+//   WsT[k][e] = W[e][pos(k)]         L⁻¹ r for r in parameter order:          v_e = Σ_k WsT[k][e] r_k
+//   mu_p, sdd_p, isd_p = θ̄_b, sd_draw, 1/sd_dens in parameter order (0 outside b), pos(k), ind_c = Π_e 1/(sd_dens_e √(2π)),
+//   cst = d_b log 2π + log|c²Σ_b|.
+// A proposal is then two dense D x D sweeps with compile-time register indices (the draw; the two solves L⁻¹(θ-ϑ), L⁻¹(θ-θ̄) in
+// two halves of the rows, L⁻¹(ϑ-θ̄) being their difference), the diagonal component's z_pos(k) through a private LDS column,
+// one exponential for the diagonal density and one logarithm of the forward/reverse ratio - against three forward substitutions
+// with 3 d divisions, d exponentials + d square roots + 2 d divisions in the diagonal density, two d x d select chains for the
+// gather / scatter of θ_b and two logarithms in the literal restatement (k_mutate MODE 0 keeps that one).  Deviation: the sums run
+// in a different order (differences ~1e-16 cond(L) relative in the log density ratio; a literal/dense run pair flips an MH
+// decision with probability ~1e-9 per proposal).
+template <int D, class PD, class PI>
+struct MixDenseT {
+    PD LsT, WsT;                  // [D*D] each
+    PD mu_p, sdd_p, isd_p;        // [D]
+    PD sc;                        // [0] = ind_c, [1] = cst
+    PI pos;                       // [D] position of parameter k in the block, or -1
+    static constexpr int DOUBLES = 2 * D * D + 3 * D + 2;
+    __device__ MixDenseT(PD buf, PI ibuf) : LsT(buf), WsT(buf + D * D), mu_p(buf + 2 * D * D), sdd_p(mu_p + D), isd_p(sdd_p + D), sc(isd_p + D), pos(ibuf) {}
+};
+template <int D> using MixDense = MixDenseT<D, double *, int *>;          // LDS / global memory, writable (mix_expand)
+// the same block read through the constant address space: wave-uniform scalar loads, the matrix entries arrive as SGPR operands
+// of the FMAs (no LDS traffic, no vector registers) - for matrices a previous launch wrote (k_mix_prepare)
+using mix_cdp = const double __attribute__((address_space(4))) *;
+using mix_cip = const int __attribute__((address_space(4))) *;
+template <int D> using MixDenseC = MixDenseT<D, mix_cdp, mix_cip>;
+// W_b = L_b⁻¹ for every block of the stage: wave w inverts blocks w, w + NW, ...; lane j builds column j by forward substitution
+// (L read from LDS at uniform addresses).  Lraw / Wraw: packed d_b x d_b row-major at loff[b].  Ends with a barrier.
+template <int D, int T>
+__device__ inline void mix_invert_factors(const double *Lraw, double *Wraw, const int *loff, const int *bptr, int nb, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int b = wave; b < nb; b += T / 64) {
+        const int db = bptr[b + 1] - bptr[b];
+        const double *L = Lraw + loff[b];
+        double w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            w[i] = 0.0;
+            if (i < db) {
+                double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) s -= L[i * db + k] * w[k];
+                w[i] = (i >= lane) ? s / L[i * db + i] : 0.0;
+            }
+        }
+        if (lane < db) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if (i < db) Wraw[loff[b] + i * db + lane] = w[i];
+        }
+    }
+    __syncthreads();
+}
+// expansion of block b (all T threads; the caller has synchronised the previous readers; ends with a barrier)
+template <int D, int T>
+__device__ inline void mix_expand(const MixDense<D> &M, const double *Lb, const double *Wb, const int *ball_b, const double *mub_b, const double *sdd_b,
+                                  const double *sdn_b, int db, double logdet, int tid) {
+    for (int k = tid; k < D; k += T) M.pos[k] = -1;
+    __syncthreads();
+    for (int e = tid; e < db; e += T) M.pos[ball_b[e]] = e;
+    __syncthreads();
+    for (int idx = tid; idx < D * D; idx += T) {
+        const int a = idx / D, k = idx % D;                  // LsT: a = block position e, k = parameter
+        const int pk = M.pos[k];
+        M.LsT[idx] = (pk >= 0 && a <= pk) ? Lb[pk * db + a] : 0.0;
+        const int pa = M.pos[a];                             // WsT: a = parameter, k = block position e
+        M.WsT[idx] = (pa >= 0 && pa <= k && k < db) ? Wb[k * db + pa] : 0.0;
+    }
+    for (int k = tid; k < D; k += T) {
+        const int pk = M.pos[k];
+        M.mu_p[k] = pk >= 0 ? mub_b[pk] : 0.0;
+        M.sdd_p[k] = pk >= 0 ? sdd_b[pk] : 0.0;
+        M.isd_p[k] = pk >= 0 ? 1.0 / sdn_b[pk] : 0.0;
+    }
+    if (tid == 0) {
+        double ic = 1.0;
+        for (int e = 0; e < db; ++e) ic = ic / (sdn_b[e] * sqrt(2.0 * M_PI));     // the reference's running product (helpers.jl:150-154)
+        M.sc[0] = ic;
+        M.sc[1] = (double)db * LOG2PI + logdet;
+    }
+    __syncthreads();
+}
+// rows [E0, E1) of the two solves and their contribution to the three quadratic forms
+template <int D, int E0, int E1, class MX>
+__device__ inline void mix_solve_rows(const MX &M, const double (&x)[D], const double (&xn)[D], double &quad, double &quad_s, double &quad_d) {
+#pragma clang fp contract(fast)
+    constexpr int NE = E1 - E0;
+    if constexpr (NE > 0) {
+        double v1[NE], v2[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { v1[e] = 0.0; v2[e] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double xk = x[k];
+            asm volatile("" : "+v"(xk));                   // (a fresh value: otherwise x - xn and x - θ̄ of all k stay live from the first use on)
+            const double r1 = xk - xn[k], r2 = xk - M.mu_p[k];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { const double wv = M.WsT[k * D + E0 + e]; v1[e] += wv * r1; v2[e] += wv * r2; }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(v1[e]), "+v"(v2[e]));      // one matrix row live at a time
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const double v3 = v2[e] - v1[e];
+            quad += v1[e] * v1[e]; quad_s += v2[e] * v2[e]; quad_d += v3 * v3;
+        }
+    }
+}
+// One proposal: x (current θ, parameter order) -> xn, and log q(θ|ϑ) - log q(ϑ|θ) as the MH ratio uses it (NaN when both
+// densities vanish, like the reference's log 0 - log 0).  z: the block's standard normals (block order, zero beyond d_b);
+// zt: this thread's private LDS column (stride T), D entries.
+template <int D, int T, class MX>
+__device__ inline double mix_propose(const MX &M, const double (&x)[D], const double (&z)[D], double uc, double c_alpha, bool force_diag,
+                                     double *zt, double (&xn)[D]) {
+#pragma clang fp contract(fast)
+    const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
+    const bool diag_draw = comp == 1 || force_diag;
+#pragma unroll
+    for (int e = 0; e < D; ++e) zt[e * T] = z[e];
+    double u[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = 0.0;
+#pragma unroll
+    for (int e = 0; e < D; ++e) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] += M.LsT[e * D + k] * z[e];
+#pragma unroll
+        for (int k = 0; k < D; ++k) asm volatile("" : "+v"(u[k]));      // one matrix row live at a time
+    }
+    double ssq = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const int pk = M.pos[k];
+        const double zp = zt[(pk >= 0 ? pk : 0) * T];                       // z_pos(k): the diagonal component's draw (sdd_p = 0 outside b)
+        const double centre = (comp == 2 && pk >= 0) ? M.mu_p[k] : x[k];
+        xn[k] = diag_draw ? x[k] + M.sdd_p[k] * zp : centre + u[k];
+        const double zz = (x[k] - xn[k]) * M.isd_p[k];
+        ssq += zz * zz;
+    }
+    double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
+    constexpr int HALF = (D + 1) / 2;
+    mix_solve_rows<D, 0, HALF, MX>(M, x, xn, quad, quad_s, quad_d);
+    mix_solve_rows<D, HALF, D, MX>(M, x, xn, quad, quad_s, quad_d);
+    const double cst = M.sc[1];
+    const double common = c_alpha * exp(-(cst + quad) / 2.0) + (1.0 - c_alpha) / 2.0 * (M.sc[0] * exp(-0.5 * ssq));
+    const double q0 = common + (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
+    const double q1 = common + (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
+    return log(q0 / q1);
+}
+
+// The dense mixture matrices of every block of the stage, once per stage by one block (the register kernel's blocks hold 256
+// particles each: inverting and expanding per block costs more than the mutation itself once the cloud is large).
+template <int D>
+__global__ void __launch_bounds__(256) k_mix_prepare(const DevState *st, int nb, int nf, double *mix, int *mixpos) {
+    constexpr int T = 256;
+    __shared__ double Lraw[D * D], Wraw[D * D], mub[D], sdd[D], sdn[D], logdet[D];
+    __shared__ int ball[D], bptr[D + 1], loff[D];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < nf * nf; e += T) Lraw[e] = st->L[e];
+    for (int e = tid; e < nf; e += T) { mub[e] = st->mu_b[e]; sdd[e] = st->sd_draw[e]; sdn[e] = st->sd_dens[e]; ball[e] = st->blocks_all[e]; }
+    for (int b = tid; b < nb; b += T) { loff[b] = st->l_off[b]; logdet[b] = st->logdet[b]; }
+    for (int b = tid; b <= nb; b += T) bptr[b] = st->block_ptr[b];
+    __syncthreads();
+    mix_invert_factors<D, T>(Lraw, Wraw, loff, bptr, nb, tid);
+    for (int b = 0; b < nb; ++b) {
+        const MixDense<D> G(mix + (long long)b * MixDense<D>::DOUBLES, mixpos + b * D);
+        const int p0 = bptr[b], db = bptr[b + 1] - p0;
+        mix_expand<D, T>(G, Lraw + loff[b], Wraw + loff[b], ball + p0, mub + p0, sdd + p0, sdn + p0, db, logdet[b], tid);
+    }
+}
+
 // Register-resident mutation for models with D = n_para <= 10 (MODE 0 of k_mutate, same arithmetic in the same order).
 // Everything per-particle lives in VGPRs with compile-time indices: the parameter vector x[D], and the block's z / draw /
 // solve vectors (padded to D entries; identity-padded factor).  Block membership is a run-time (but wave-uniform) index,
@@ -2078,7 +2255,7 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
 // at ~1.5 wavefronts per SIMD (N = 1e5) every LDS / global round trip is exposed latency, a select is not.
 // The block factor L, the block constants and the model constants are staged once into LDS (uniform-address reads).
 template <int D, bool ALPHA1>
-__global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
+__global__ void __launch_bounds__(256, 3) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
                                                    double *acc_partials, int standalone, int nb, int nf) {
 #pragma clang fp contract(fast)
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -2172,6 +2349,7 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
     }
     SMCMI_PROF(2);
     auto XN = [&](int k) { return x[k]; };
+    __shared__ double mixzt[ALPHA1 ? 1 : 256 * D];             // private z columns of the diagonal component's draw
     for (int step = 0; step < n_steps; ++step) {
         for (int b = 0; b < nb; ++b) {
             if (nb > 1 || step == 0) __syncthreads();   // raw copies (first pass) / previous block's readers (later passes)
@@ -2189,17 +2367,6 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
                         const int r = e / db, cidx = e % db;
                         if (cidx <= r) Ls[cidx * D + ball_raw[p0 + r]] = L[r * db + cidx];   // transposed: Ls[e][k] = M[k][e]
                     }
-                } else
-                for (int e = tid; e < D * D; e += T) {
-                    const int r = e / D, cidx = e % D;
-                    Ls[e] = (r < db && cidx < db) ? L[r * db + cidx] : (r == cidx ? 1.0 : 0.0);
-                }
-                for (int e = tid; e < D; e += T) {
-                    const bool in = e < db;
-                    mu_s[e] = in ? mub_raw[p0 + e] : 0.0;
-                    sdd_s[e] = in ? sdd_raw[p0 + e] : 0.0;
-                    sdn_s[e] = in ? sdn_raw[p0 + e] : 1.0;
-                    ball_s[e] = in ? ball_raw[p0 + e] : -1;
                 }
                 __syncthreads();
             }
@@ -2208,7 +2375,7 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
             const unsigned t = (unsigned)(step * nb + b);
             double step_prob, u_dummy;     // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
             double uc, unext;
-            double z[D], sub[D], dr[D];
+            double z[D];
 #ifdef SMCMI_COUNT_RNG_AHEAD   // profiles/isa_count.py: instruction mix of the path that loads the draws (dead-codes the in-kernel RNG)
             constexpr bool z_only = true;
 #else
@@ -2295,93 +2462,18 @@ __global__ void __launch_bounds__(256, ALPHA1 ? 3 : 2) k_mutate_reg(CloudPtrs cl
                     like_old_data = (lv[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik_s<D>(lv[1], XN);
                 }
             } else {
-            // gather θ_b = x[blocks_all[..]]: uniform selects over the register-resident parameter vector
-            int bal[D];
-#pragma unroll
-            for (int e = 0; e < D; ++e) bal[e] = ball_s[e];
-#pragma unroll
-            for (int e = 0; e < D; ++e) {
-                double sv = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) sv = (bal[e] == k) ? x[k] : sv;
-                sub[e] = sv;
-            }
-            const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
-            const bool diag_draw = comp == 1 || (ma.debug & 4);
-            SMCMI_PROF(5);
-            // ---- mixture draw (src/helpers.jl:87-100) and compute_proposal_densities (src/helpers.jl:128-164) in row sweeps over
-            // the factor: row e gives the draw ϑ_e = centre_e + Σ_{k<=e} L_ek z_k and then row e of the three forward
-            // substitutions L⁻¹(θ_b - ϑ_b), L⁻¹(θ_b - θ̄_b), L⁻¹(ϑ_b - θ̄_b) - each in the arithmetic order of a separate solve, so
-            // the results are bit for bit those of four passes over L; but one row of L is live at a time instead of the whole
-            // factor (55 values = 110 VGPRs, which used to push 100 doubles per lane into scratch).
-            const double cst = (double)db * LOG2PI + logdet_s[b];
+            // mixture draw + proposal densities in parameter order (mix_propose above): no gather / scatter, no division
             double zz2 = 0.0;
 #pragma unroll
             for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
-            {
-                double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
-                {
-                    double v1[D];
-#pragma unroll
-                    for (int e = 0; e < D; ++e) {       // sweep A: the draw and L⁻¹(θ_b - ϑ_b); the normals die here
-                        double Lr[D];
-#pragma unroll
-                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
-                        double sd = 0.0;
-#pragma unroll
-                        for (int k = 0; k <= e; ++k) sd += Lr[k] * z[k];
-                        dr[e] = diag_draw ? sub[e] + sdd_s[e] * z[e] : ((comp == 0) ? sub[e] : mu_s[e]) + sd;
-                        double s1 = sub[e] - dr[e];
-#pragma unroll
-                        for (int k = 0; k < e; ++k) s1 -= Lr[k] * v1[k];
-                        v1[e] = s1 / Lr[e];
-                        quad += v1[e] * v1[e];
-                        // pin the row's results: otherwise the optimiser interleaves the rows and keeps the whole factor live
-                        asm volatile("" : "+v"(v1[e]), "+v"(dr[e]));
-                    }
-                }
-                {
-                    double v2[D], v3[D];
-#pragma unroll
-                    for (int e = 0; e < D; ++e) {       // sweep B: L⁻¹(θ_b - θ̄_b) and L⁻¹(ϑ_b - θ̄_b)
-                        double Lr[D];
-#pragma unroll
-                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
-                        double s2 = sub[e] - mu_s[e], s3 = dr[e] - mu_s[e];
-#pragma unroll
-                        for (int k = 0; k < e; ++k) { s2 -= Lr[k] * v2[k]; s3 -= Lr[k] * v3[k]; }
-                        v2[e] = s2 / Lr[e]; v3[e] = s3 / Lr[e];
-                        quad_s += v2[e] * v2[e]; quad_d += v3[e] * v3[e];
-                        asm volatile("" : "+v"(v2[e]), "+v"(v3[e]));
-                    }
-                }
-                q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;          // forward == reverse density of the random-walk component
-                double ind_pdf = 1.0;
-#pragma unroll
-                for (int e = 0; e < D; ++e) {
-                    if (e < db) {
-                        const double sii = sdn_s[e];
-                        const double zz = (sub[e] - dr[e]) / sii;
-                        ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * zz * zz);
-                    }
-                }
-                q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
-                q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
-                q0 = log(q0);
-                q1 = log(q1);
-                if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
-            }
+            SMCMI_PROF(5);
+            double xn[D];
+            // (this block's dense matrices, written by k_mix_prepare, read as wave-uniform scalars)
+            const MixDenseC<D> MX((mix_cdp)(unsigned long long)(ma.mix + (long long)b * MixDenseC<D>::DOUBLES), (mix_cip)(unsigned long long)(ma.mixpos + b * D));
+            q0 = mix_propose<D, 256>(MX, x, z, uc, c_alpha, (ma.debug & 4) != 0, mixzt + tid, xn);       // q0 - q1 as one number
             SMCMI_PROF(6);
-            // ---- para_new: scatter the proposal into the parameter vector (the old vector stays in xo[])
 #pragma unroll
-            for (int k = 0; k < D; ++k) xo[k] = x[k];
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-#pragma unroll
-                for (int e = 0; e < D; ++e) x[k] = (bal[e] == k) ? dr[e] : x[k];
-            }
+            for (int k = 0; k < D; ++k) { xo[k] = x[k]; x[k] = xn[k]; }
             if (ma.debug & 2) { prior_new = lprior - 0.1 * zz2; like_new = like - 0.2; like_old_data = 0.0; }
             else if (in_bounds_s<D>(mv, XN)) {
                 prior_new = logprior_s<D>(mv, XN, has_other);

@@ -64,6 +64,8 @@ struct smcmi_handle {
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_emax_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
+    double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
+    int *d_mixpos = nullptr;
     // host-callback split
     double *d_prop = nullptr, *d_prop_lp = nullptr, *d_prop_q = nullptr, *d_lik_new = nullptr, *d_lik_old = nullptr;
     int *d_acc_count = nullptr, *d_flag = nullptr;
@@ -207,7 +209,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
         dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * (ES + 1)) || dmalloc(&h->d_emax_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
-        dmalloc(&h->d_flag, 4))
+        dmalloc(&h->d_flag, 4) || dmalloc(&h->d_mix, (size_t)10 * (3 * 100 + 22)) || dmalloc(&h->d_mixpos, 100))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
         if (dmalloc(&h->d_hist_w, (size_t)n * ms) || dmalloc(&h->d_hist_W, (size_t)n * ms)) return SMCMI_ERR_HIP;
@@ -248,7 +250,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
                     h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
-                    h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof};
+                    h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof, h->d_mix, h->d_mixpos};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -722,9 +724,14 @@ static void launch_reg(smcmi_handle *h, const MutArgs &ma, int standalone) {
     if (h->launch_alpha1)
         k_mutate_reg<D, true><<<h->nb_reg, h->reg_T, reg_lds_bytes(D), h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone,
                                                                                     h->launch_nb, h->h_model.n_free);
-    else
-    k_mutate_reg<D, false><<<h->nb_reg, h->reg_T, reg_lds_bytes(D), h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone,
-                                                                           h->launch_nb, h->h_model.n_free);
+    else {
+        // α < 1: the blocks' dense mixture matrices once per stage (k_mix_prepare), then the particles
+        MutArgs mb = ma;
+        mb.mix = h->d_mix; mb.mixpos = h->d_mixpos;
+        k_mix_prepare<D><<<1, 256, 0, h->stream>>>(h->d_st, h->launch_nb, h->h_model.n_free, h->d_mix, h->d_mixpos);
+        k_mutate_reg<D, false><<<h->nb_reg, h->reg_T, reg_lds_bytes(D), h->stream>>>(h->cl, h->d_st, h->d_model, mb, h->d_acc_part, standalone,
+                                                                               h->launch_nb, h->h_model.n_free);
+    }
 }
 static int set_mutate_attrs(smcmi_handle *) { return 0; }   // the register kernel needs < 64 KiB of dynamic LDS
 static bool use_reg_mutate(const smcmi_handle *h) { return h->d <= 10; }

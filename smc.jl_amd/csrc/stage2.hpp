@@ -1235,7 +1235,7 @@ __device__ inline void k2_bookkeeping(DevState *st, Ctl2 *ctl, const Mut2Args &m
 // gathered cloud) and always writes buffer 0, applies normalize_weights! (particle.jl:362-366: W̃ N / ΣW̃, two roundings; 1 after a
 // resample) to the weight column and its history, and leaves one row of RMUT sums for the next stage's begin.
 template <int D, bool ALPHA1, int T>
-__global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
+__global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
                                                                                Mut2Args ma, int nb, int nf) {
 #pragma clang fp contract(fast)
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1334,6 +1334,12 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
         like = lprior = like_prev = 0.0;
     }
     auto XN = [&](int k) { return x[k]; };
+    __shared__ double mixbuf[ALPHA1 ? 1 : MixDense<D>::DOUBLES + D * D];
+    __shared__ int mixpos[ALPHA1 ? 1 : D];
+    __shared__ double mixzt[ALPHA1 ? 1 : T * D];               // private z columns of the diagonal component's draw
+    const MixDense<D> MX(mixbuf, mixpos);
+    double *Wraw = mixbuf + (ALPHA1 ? 0 : MixDense<D>::DOUBLES);
+    if constexpr (!ALPHA1) mix_invert_factors<D, T>(Lraw, Wraw, loff_s, bptr_s, nb, tid);     // (prologue / pre-load ended with a barrier)
     K2_STAMP(ma.prof, 8);
     for (int step = 0; step < n_steps; ++step) {
         for (int b = 0; b < nb; ++b) {
@@ -1349,22 +1355,11 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
                         if (cidx <= r) Ls[cidx * D + ball_raw[p0 + r]] = Lb[r * db + cidx];   // transposed: Ls[e][k] = M[k][e]
                     }
                 } else
-                for (int e = tid; e < D * D; e += T) {
-                    const int r = e / D, cidx = e % D;
-                    Ls[e] = (r < db && cidx < db) ? Lb[r * db + cidx] : (r == cidx ? 1.0 : 0.0);
-                }
-                for (int e = tid; e < D; e += T) {
-                    const bool in = e < db;
-                    mu_s[e] = in ? mub_raw[p0 + e] : 0.0;
-                    sdd_s[e] = in ? sdd_raw[p0 + e] : 0.0;
-                    sdn_s[e] = in ? sdn_raw[p0 + e] : 1.0;
-                    ball_s[e] = in ? ball_raw[p0 + e] : -1;
-                }
+                    mix_expand<D, T>(MX, Lb, Wraw + loff_s[b], ball_raw + p0, mub_raw + p0, sdd_raw + p0, sdn_raw + p0, db, logdet_s[b], tid);
                 __syncthreads();
             }
             if (!live) continue;
             const unsigned t = (unsigned)(step * nb + b);
-            double sub[D], dr[D];
             if (ma.zbuf) {
                 if (t != 0) {
                     const double *zt = ma.zbuf + (long long)t * (D + 2) * g.n + i;
@@ -1402,83 +1397,14 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : (ALPHA1 ? 3 : 2)) k2_mutate(
                     like_old_data = (lv[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik_s<D>(lv[1], XN);
                 }
             } else {
-            int bal[D];
-#pragma unroll
-            for (int e = 0; e < D; ++e) bal[e] = ball_s[e];
-#pragma unroll
-            for (int e = 0; e < D; ++e) {
-                double sv = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) sv = (bal[e] == k) ? x[k] : sv;
-                sub[e] = sv;
-            }
-            const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
-            const bool diag_draw = comp == 1 || (ma.debug & 4);
-            const double cst = (double)db * LOG2PI + logdet_s[b];
+            // mixture draw + proposal densities in parameter order (mix_propose, kernels.hpp): no gather / scatter, no division
             double zz2 = 0.0;
 #pragma unroll
             for (int e = 0; e < D; ++e) zz2 += z[e] * z[e];
-            {
-                double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
-                {
-                    double v1[D];
+            double xn[D];
+            q0 = mix_propose<D, T>(MX, x, z, uc, c_alpha, (ma.debug & 4) != 0, mixzt + tid, xn);       // q0 - q1 as one number
 #pragma unroll
-                    for (int e = 0; e < D; ++e) {       // sweep A: the draw and L⁻¹(θ_b - ϑ_b)
-                        double Lr[D];
-#pragma unroll
-                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
-                        double sd = 0.0;
-#pragma unroll
-                        for (int k = 0; k <= e; ++k) sd += Lr[k] * z[k];
-                        dr[e] = diag_draw ? sub[e] + sdd_s[e] * z[e] : ((comp == 0) ? sub[e] : mu_s[e]) + sd;
-                        double s1 = sub[e] - dr[e];
-#pragma unroll
-                        for (int k = 0; k < e; ++k) s1 -= Lr[k] * v1[k];
-                        v1[e] = s1 / Lr[e];
-                        quad += v1[e] * v1[e];
-                        asm volatile("" : "+v"(v1[e]), "+v"(dr[e]));
-                    }
-                }
-                {
-                    double v2[D], v3[D];
-#pragma unroll
-                    for (int e = 0; e < D; ++e) {       // sweep B: L⁻¹(θ_b - θ̄_b) and L⁻¹(ϑ_b - θ̄_b)
-                        double Lr[D];
-#pragma unroll
-                        for (int k = 0; k <= e; ++k) Lr[k] = Ls[e * D + k];
-                        double s2 = sub[e] - mu_s[e], s3 = dr[e] - mu_s[e];
-#pragma unroll
-                        for (int k = 0; k < e; ++k) { s2 -= Lr[k] * v2[k]; s3 -= Lr[k] * v3[k]; }
-                        v2[e] = s2 / Lr[e]; v3[e] = s3 / Lr[e];
-                        quad_s += v2[e] * v2[e]; quad_d += v3[e] * v3[e];
-                        asm volatile("" : "+v"(v2[e]), "+v"(v3[e]));
-                    }
-                }
-                q0 = c_alpha * exp(-(cst + quad) / 2.0); q1 = q0;
-                double ind_pdf = 1.0;
-#pragma unroll
-                for (int e = 0; e < D; ++e) {
-                    if (e < db) {
-                        const double sii = sdn_s[e];
-                        const double zz = (sub[e] - dr[e]) / sii;
-                        ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * zz * zz);
-                    }
-                }
-                q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
-                q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
-                q0 = log(q0);
-                q1 = log(q1);
-                if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < D; ++k) xo[k] = x[k];
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-#pragma unroll
-                for (int e = 0; e < D; ++e) x[k] = (bal[e] == k) ? dr[e] : x[k];
-            }
+            for (int k = 0; k < D; ++k) { xo[k] = x[k]; x[k] = xn[k]; }
             if (ma.debug & 2) { prior_new = lprior - 0.1 * zz2; like_new = like - 0.2; like_old_data = 0.0; }
             else if (in_bounds_s<D>(mv, XN)) {
                 prior_new = logprior_s<D>(mv, XN, has_other);
