@@ -17,6 +17,7 @@ struct Eng2 {
     double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
     long long *d_ranges = nullptr;
     Prop2Glob *d_pre = nullptr;      // decision + proposal of the current stage (k2_prepare; large clouds / several handles)
+    int *d_tick = nullptr;           // ticket counters of the fused row totals (Tail2): [0, V) correction rows, [V, 2V) mutation rows
     long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage
     int prof_stage = 0;
     int world = 0;
@@ -27,7 +28,7 @@ struct Eng2 {
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre, e->d_tick};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete e;
@@ -82,11 +83,12 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     if (dmalloc(&e->d_ctl, 1) || dmalloc(&e->rows_mut, n2 * RMUT) || dmalloc(&e->rows_cm, n1 * npf) || dmalloc(&e->csum, n1) ||
         dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * npp) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
         dmalloc(&e->rows_pass[1], n1 * 2 * KC) || dmalloc(&e->vt_mut, (size_t)g.V * RMUT) || dmalloc(&e->vt_cm, (size_t)g.V * npf) ||
-        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_pre, 1)) {
+        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_pre, 1) || dmalloc(&e->d_tick, 2 * V2_MAXV)) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
     }
     HIP_TRY(hipMemsetAsync(e->d_pre, 0, sizeof(Prop2Glob), h->stream));
+    HIP_TRY(hipMemsetAsync(e->d_tick, 0, 2 * V2_MAXV * sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(e->rows_mut, 0, n2 * RMUT * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(e->rows_cm, 0, n1 * npf * sizeof(double), h->stream));        // (the pad columns stay zero)
     HIP_TRY(hipMemsetAsync(e->rows_gm, 0, ng * npp * sizeof(double), h->stream));
@@ -109,6 +111,12 @@ static bool eng2_eligible(const smcmi_handle *h, int world) {
     return eng == 2 || world > 1 || g.direct;
 }
 
+// the row totals of K1 / K2 are taken by the last block of each virtual shard instead of a k2_reduce launch (every geometry in which
+// consumers do not read the rows themselves); SMCMI_E2_NO_TAIL=1 keeps the launches (development, tests)
+static bool fused_tails(const Eng2 *e) {
+    static const int no_tail = getenv("SMCMI_E2_NO_TAIL") ? atoi(getenv("SMCMI_E2_NO_TAIL")) : 0;
+    return !e->g.direct && !no_tail;
+}
 template <int D>
 static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows) {
     Eng2 *e = h->e2;
@@ -118,8 +126,9 @@ static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_e
         ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
         grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
     }
+    const Tail2 tail = fused_tails(e) ? Tail2{e->d_tick, e->vt_cm + (size_t)e->g.v0 * pad2(h->npairs + 2)} : Tail2{nullptr, nullptr};
     k2_correct<D><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
-                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
 }
 template <int D>
 static void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full) {
@@ -206,6 +215,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
         k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
+        HIP_TRY(hipMemsetAsync(h->e2->d_tick, 0, 2 * V2_MAXV * sizeof(int), h->stream));
         // random numbers drawn ahead: while K1 leaves most CUs idle (small clouds = the direct geometry with 512-thread mutation blocks)
         static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
         Eng2 *e = h->e2;
@@ -233,8 +243,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return direct ? Rows2{rows, g0.Vl, nr, m} : Rows2{vt, g0.V, 1, m};
     };
     // total this handle's rows per virtual shard and (several handles) all-gather the V x m totals
-    auto publish = [&](double *Eng2::*rows, double *Eng2::*vt, int nr, int m, int max_idx, int pair = 0) -> int {
+    auto publish = [&](double *Eng2::*rows, double *Eng2::*vt, int nr, int m, int max_idx, int pair = 0, bool fused = false) -> int {
         if (direct) return 0;
+        if (!(fused && fused_tails(h0->e2)))             // (fused: the producing kernel's last blocks wrote the totals)
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             Eng2 *e = h->e2;
@@ -279,7 +290,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
         }
-        return publish(&Eng2::rows_cm, &Eng2::vt_cm, g0.nb1, npf, -1);
+        return publish(&Eng2::rows_cm, &Eng2::vt_cm, g0.nb1, npf, -1, 0, true);
     };
     auto enq_select = [&](int n) -> int {
         if (!multi) {
@@ -339,6 +350,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n; ma.sel_enqueued = sel_enqueued; ma.adaptive = adaptive ? 1 : 0;
             ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
             ma.zbuf = e->rng_ahead ? h->d_zbuf : nullptr;
+            ma.tail = fused_tails(e) ? Tail2{e->d_tick + V2_MAXV, e->vt_mut + (size_t)e->g.v0 * RMUT} : Tail2{nullptr, nullptr};
             ma.pre = inker ? nullptr : e->d_pre;
             ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
             ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
@@ -359,7 +371,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 #undef SMCMI_CALL
             if (e1) hipEventRecord(e1, h->stream);
         }
-        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256);
+        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256, true);
     };
     auto enq_passes = [&](int n, int p0, int P) -> int {           // passes p0 .. P-1, then the closing decision
         for (int p = p0; p < P; ++p) {

@@ -191,11 +191,23 @@ __device__ inline void reduce_rows(const Rows2 &R, double *vt, double *tot, int 
 constexpr int RT = 1024;
 // pair = 1 (mutation rows written by 256-thread blocks): a logical row is raw row 2r + raw row 2r+1 - the row a 512-thread
 // block over the same particles writes (block_reduce_es2).
-__global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
-    constexpr int GB = 7;                               // groups per batch: GB * (m / 2) * 4 <= RT for m <= 72
+// By a whole block of NT threads (k2_reduce: its own launch; or the last block of a virtual shard to finish, Tail2 below): the
+// result does not depend on NT (groups are totalled in ascending order however many fit a batch).
+// COH: the rows were written by other blocks of the SAME launch (Tail2): read them with agent-scope loads that bypass this die's L2.
+__device__ inline double2 load_pair(const double2 *p, bool coh) {
+    if (!coh) return *p;
+    const double *q = reinterpret_cast<const double *>(p);
+    double2 x;
+    x.x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return x;
+}
+template <int NT, bool COH = false>
+__device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int max_idx, double *out_v, int pair) {
+    constexpr int GB = NT / (36 * 4) > 0 ? NT / (36 * 4) : 1;      // groups per batch: GB * (m / 2) * 4 <= NT for m <= 72
+    static_assert(NT >= 36 * 4, "a group needs (m / 2) * 4 <= 144 threads");
     __shared__ double gs[GB * 72];
-    const int v = blockIdx.x, mp = m / 2;
-    const double *base0 = rows + (long long)v * nr_raw * m;
+    const int mp = m / 2;
     const int nr = pair ? (nr_raw + 1) / 2 : nr_raw;
     const int ng = (nr + GRP - 1) / GRP;
     const double ninf = -__builtin_inf();
@@ -221,11 +233,11 @@ __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, 
                     double2 x;
                     if (pair) {                         // (uniform condition; both loads unconditional)
                         const int ra = 2 * rc, rb = 2 * rc + 1 < nr_raw ? 2 * rc + 1 : ra;
-                        const double2 xa = base[(long long)ra * ldp], xb = base[(long long)rb * ldp];
+                        const double2 xa = load_pair(base + (long long)ra * ldp, COH), xb = load_pair(base + (long long)rb * ldp, COH);
                         const bool hb = 2 * rc + 1 < nr_raw;
                         x.x = mx0 ? fmax(xa.x, hb ? xb.x : id0) : xa.x + (hb ? xb.x : 0.0);
                         x.y = mx1 ? fmax(xa.y, hb ? xb.y : id1) : xa.y + (hb ? xb.y : 0.0);
-                    } else x = base[(long long)rc * ldp];
+                    } else x = load_pair(base + (long long)rc * ldp, COH);
                     const double x0 = r < r_end ? x.x : id0, x1 = r < r_end ? x.y : id1;
                     a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
                     a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
@@ -246,7 +258,39 @@ __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, 
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < m) out[(long long)v * m + threadIdx.x] = run;
+    if ((int)threadIdx.x < m) out_v[threadIdx.x] = run;
+}
+__global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
+    const int v = blockIdx.x;
+    reduce_vshard<RT>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
+}
+
+// The same totals without a launch of their own (sharded runs, large clouds): every block of a row-producing kernel takes a
+// ticket of its virtual shard once its row is stored; the block that draws the last ticket totals the shard's rows - in the
+// canonical order, so the result is the one k2_reduce gives - and re-arms the counter.  No fence: an agent-scope release would
+// write back everything the kernel has left dirty in its die's L2 (the particle columns) once per block - measured 23 -> 58 µs for
+// the mutation kernel; instead the rows themselves are stored and read with agent-scope accesses (write-through / L2 bypass,
+// `row_store`, `load_pair`), ordered by the wait for their completion, the block barrier and the relaxed ticket.  Blocks that
+// leave early (a stage that does not run) take no ticket.  All threads of the block call, after the row is stored.
+struct Tail2 {
+    int *tick;                 // [Vl] counters, zero between launches; null: no tail (direct geometry: consumers read the rows)
+    double *vt;                // this handle's slice of the V x m table: vt[v * m]
+};
+__device__ inline void row_store(double *p, double v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int NT>
+__device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, int nr_raw, int m, int max_idx, int pair) {
+    if (!t.tick) return;
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (waits for this wavefront's row stores to complete)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&t.tick[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr_raw - 1;
+    __syncthreads();
+    if (!s_last) return;
+    reduce_vshard<NT, true>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, t.vt + (long long)v * m, pair);
+    if (threadIdx.x == 0) __hip_atomic_store(&t.tick[v], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // block-wide fixed-order reduction of M accumulators per thread for a block of NW wavefronts; thread t < M gets total t.
@@ -683,7 +727,7 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
 template <int D>
 __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int begin_done, int spec_expected,
                                                  Rows2 mrows, const double *sched, Records rec, double *rows_cm, double *csum, double *wt,
-                                                 double *hist_w, long long hist_ld, Rng2 ra, long long *prof = nullptr) {
+                                                 double *hist_w, long long hist_ld, Rng2 ra, Tail2 tail, long long *prof = nullptr) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
     constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
     if ((int)blockIdx.x >= g.Vl * g.nb1) {               // the idle CUs draw the mutation's random numbers (Rng2)
@@ -755,18 +799,19 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
 #pragma unroll
             for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
             const double t64 = block_reduce_nw<64, NW>(a64, red);
-            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = t64;
+            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, t64, tail.tick != nullptr);
             if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = t64;
         } else {
             double ar[REMP];
 #pragma unroll
             for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
             const double tr = block_reduce_nw<REMP, NW>(ar, red);
-            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) out[ch * 64 + threadIdx.x] = tr;
+            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, tr, tail.tick != nullptr);
             if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = tr;
         }
     }
     K2_STAMP(prof, 5);
+    tail_reduce<T1>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
     // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double a = s_bg.accept, tg = st->rp.target;
@@ -981,6 +1026,7 @@ struct Mut2Args {
     const double *zbuf;        // random numbers drawn ahead by K1's extra blocks (Rng2 layout) or null
     const double *wt;          // unnormalised weights W̃ of the correction
     double *rows_mut;          // [blocks][RMUT]
+    Tail2 tail;                // the last block of a virtual shard totals its mutation rows (sharded runs, large clouds)
     double *hist_W;
     long long hist_ld;
     Records rec;
@@ -1248,9 +1294,9 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
     const int nrm_hist = ma.store_history;
     const LikDev &ld0 = ma.lik[0], &ld1 = ma.lik[1];
     const int has_other = ma.has_other;
-    double *Ls = L.Ls, *mu_s = L.mu_s, *sdd_s = L.sdd_s, *sdn_s = L.sdn_s, *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
+    double *Ls = L.Ls, *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
     double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
-    int *ball_s = L.ball_s, *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
+    int *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
     // ---- the particle (speculatively from buffer 0: only resample stages read the gathered cloud in buffer 1) and the likelihood
     // data: none of it depends on the stage's decision, so the loads are in flight while the prologue totals rows and factorises
     long long beg, end;
@@ -1453,7 +1499,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         energy_terms(es, w_part, like, like_prev, e_center, live, rs != 0);
         es[EACC] = acc_val;
         const double tot = block_reduce_es2<T / 64>(es, l_dat);      // likelihood data in LDS is dead by now
-        if (tid < ES) row[tid] = tot;
+        if (tid < ES) row_store(row + tid, tot, ma.tail.tick != nullptr);
     } else {
         double a1[1] = {acc_val};
         Butterfly<0, 32>::run(a1, tid & 63);
@@ -1462,7 +1508,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         if (tid < ES) {
             double sacc = ((red[0] + red[1]) + red[2]) + red[3];
             if constexpr (T == 512) sacc += ((red[4] + red[5]) + red[6]) + red[7];
-            row[tid] = tid == EACC ? sacc : 0.0;
+            row_store(row + tid, tid == EACC ? sacc : 0.0, ma.tail.tick != nullptr);
         }
     }
     __syncthreads();
@@ -1470,9 +1516,10 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         double m = emx[0];
 #pragma unroll
         for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
-        row[RMAX_IDX] = m;
+        row_store(row + RMAX_IDX, m, ma.tail.tick != nullptr);
     }
     K2_STAMP(ma.prof, 10);
+    tail_reduce<T>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, T == 256 ? 1 : 0);
     if (blockIdx.x == 0 && !ma.pre) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);
     K2_STAMP(ma.prof, 11);
 }
