@@ -264,12 +264,20 @@ def main():
             # config 5 is compute bound: ~3300 FP64 flops per filter step (FMA = 2; csrc/model.hpp kalman_lgss), steps = new + old
             # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s
             # (vector = matrix rate for FP64 on gfx950)
-            steps = spec["lik"][2].shape[1] + (spec["old_lik"][2].shape[1] if spec["old_lik"] else 0)
+            # The old vintage (40 periods) is a prefix of the data (80 periods) and the old likelihood the same model: the library
+            # takes both log-likelihoods from ONE pass over the data (bit for bit what two passes give; SMCMI_NO_LIK_PREFIX=1 runs
+            # two) - the flops counted are those of the filter steps actually executed.
+            t_new = spec["lik"][2].shape[1]
+            t_old = spec["old_lik"][2].shape[1] if spec["old_lik"] else 0
+            shared = bool(spec["old_lik"]) and os.environ.get("SMCMI_NO_LIK_PREFIX", "0") in ("", "0") and \
+                np.array_equal(spec["old_lik"][2], spec["lik"][2][:, :t_old])
+            steps = t_new if shared else t_new + t_old
             flops = 3300.0 * steps * RUN_KW["n_mh_steps"] * n_k
             tf = flops / (mean_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_mutate<0> / kalman_lgss (FP64 vector FMA)", "achieved": tf, "peak": 78.6,
                                "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None, "flops_per_launch": flops,
-                               "mean_launch_us": 1e3 * mean_ms, "launches": nl}
+                               "mean_launch_us": 1e3 * mean_ms, "launches": nl,
+                               "filter_steps_per_proposal": steps, "old_data_prefix_shared": shared}
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages
         stage_bytes = n_total * ((24 * D + 96) * (last["n_stages"] - 1) + (16 * D + 104) * last["resamples"])
         out["stage_gbs"] = stage_bytes * args.steps / dt / 1e9

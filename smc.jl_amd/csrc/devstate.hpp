@@ -34,7 +34,8 @@ struct LikDev {
 struct ModelDev {
     int d, n_free;
     int has_other_priors;      // some free parameter has a prior family other than Normal / Uniform
-    int pad_;
+    int lik_prefix;            // > 0: lik[1] is the lgss_kalman family on the first lik_prefix columns of lik[0]'s data (same structure
+                               // block): one filter pass yields both log-likelihoods (model.hpp kalman_lgss2)
     int fixed[MAXD];
     int free_inds[MAXD];
     double lo[MAXD], hi[MAXD];

@@ -2001,9 +2001,17 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
                         continue;
                     }
                     if (inb) {
-                        like_new = loglik(md->lik[0], d, TN);
+                        if (md->lik_prefix > 0) {
+                            // old data = a prefix of the data, same state-space structure: both log-likelihoods from one filter pass
+                            double thv[13];
+                            for (int k = 0; k < 13; ++k) thv[k] = TN(k);
+                            const KalmanLL r = kalman_lgss2(thv, md->lik[0].data, md->lik[0].cols, md->lik_prefix, md->lik[0].aux, md->lik[0].par[0]);
+                            like_new = r.ll; like_old_data = r.ll_mid;
+                        } else {
+                            like_new = loglik(md->lik[0], d, TN);
+                            like_old_data = (md->lik[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik(md->lik[1], d, TN);
+                        }
                         if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
-                        like_old_data = (md->lik[1].family == SMCMI_LIK_NONE) ? 0.0 : loglik(md->lik[1], d, TN);
                     }
                 } else {
                     for (int k = 0; k < d; ++k) tn[k * T + tid] = ma.proposals[(long long)k * cl.n + i];

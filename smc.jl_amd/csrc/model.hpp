@@ -148,7 +148,11 @@ constexpr int KALMAN_AUX_RR = KALMAN_AUX_KC + 64;  // Rm[i][m] Rm[j][m], (i <= j
 constexpr int KALMAN_AUX_TOTAL = KALMAN_AUX_RR + 36 * 3;
 __host__ __device__ constexpr int ksym(int i, int j) { return i <= j ? i * 8 - i * (i - 1) / 2 + (j - i) : j * 8 - j * (j - 1) / 2 + (i - j); }
 
-__device__ __attribute__((noinline)) static double kalman_lgss(const double *thv, const double *ydat, long long nt, const double *aux, double kappa) {
+// nt_mid: also report the log-likelihood of the first nt_mid observations (0 < nt_mid <= nt; a filter started from the same x_0, P_0
+// on a prefix of the data performs exactly the first nt_mid steps of this one, so the value is bit for bit what a separate pass
+// over the prefix returns) - the tempered update's old_loglikelihood when the old vintage is a prefix of the new one.
+struct KalmanLL { double ll, ll_mid; };
+__device__ __attribute__((noinline)) static KalmanLL kalman_lgss2(const double *thv, const double *ydat, long long nt, long long nt_mid, const double *aux, double kappa) {
 #pragma clang fp contract(fast)
     // The structure block and the data are the same for every lane, but an out-of-line function receives its pointers in VGPRs and
     // would fetch them with vector loads (105 flat loads and a dozen full waits per filter step): pin the addresses to SGPRs and
@@ -162,6 +166,8 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
     const cdp Zm = uniform_ptr(aux + 88), kC = uniform_ptr(aux + KALMAN_AUX_KC), RR = uniform_ptr(aux + KALMAN_AUX_RR), yd = uniform_ptr(ydat);
     nt = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
                      __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
+    nt_mid = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt_mid >> 32)) << 32) |
+                         __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt_mid));
     (void)kappa;
     double rho[8], s2[3];
 #pragma unroll
@@ -176,7 +182,7 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
 #pragma unroll
         for (int j = i; j < 8; ++j) P[ksym(i, j)] = (i == j) ? 1.0 : 0.0;
     }
-    double ll = 0.0;
+    double ll = 0.0, ll_mid = SMCMI_NEG_INF;
 #pragma nounroll
     for (long long t = 0; t < nt; ++t) {
         // (the 196 structure values are loop-invariant; the compiler hoists their scalar loads and parks what does not fit the SGPR
@@ -236,16 +242,17 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
                 for (int i = 0; i < 8; ++i) s += Zm[a * 8 + i] * PZ[i * 3 + b];
                 F[a * (a + 1) / 2 + b] = s;
             }
-        if (!(F[0] > 0.0)) return SMCMI_NEG_INF;
+        if (!(F[0] > 0.0)) return KalmanLL{SMCMI_NEG_INF, ll_mid};
         const double l00 = sqrt(F[0]), l10 = F[1] / l00, l20 = F[3] / l00;
         const double p11 = F[2] - l10 * l10;
-        if (!(p11 > 0.0)) return SMCMI_NEG_INF;
+        if (!(p11 > 0.0)) return KalmanLL{SMCMI_NEG_INF, ll_mid};
         const double l11 = sqrt(p11), l21 = (F[4] - l20 * l10) / l11;
         const double p22 = F[5] - l20 * l20 - l21 * l21;
-        if (!(p22 > 0.0)) return SMCMI_NEG_INF;
+        if (!(p22 > 0.0)) return KalmanLL{SMCMI_NEG_INF, ll_mid};
         const double l22 = sqrt(p22);
         const double w0 = v[0] / l00, w1 = (v[1] - l10 * w0) / l11, w2 = (v[2] - l20 * w0 - l21 * w1) / l22;
         ll += -1.5 * log(2.0 * M_PI) - log(l00 * l11 * l22) - 0.5 * (w0 * w0 + w1 * w1 + w2 * w2);
+        if (t + 1 == nt_mid) ll_mid = ll;                       // (wave-uniform)
         const double u2 = w2 / l22, u1 = (w1 - l21 * u2) / l11, u0 = (w0 - l10 * u1 - l20 * u2) / l00;
         const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
         double G[24];
@@ -261,7 +268,10 @@ __device__ __attribute__((noinline)) static double kalman_lgss(const double *thv
             for (int j = i; j < 8; ++j)
                 P[ksym(i, j)] = Pn[ksym(i, j)] - (G[i * 3 + 0] * G[j * 3 + 0] + G[i * 3 + 1] * G[j * 3 + 1] + G[i * 3 + 2] * G[j * 3 + 2]);
     }
-    return ll;
+    return KalmanLL{ll, ll_mid};
+}
+__device__ inline double kalman_lgss(const double *thv, const double *ydat, long long nt, const double *aux, double kappa) {
+    return kalman_lgss2(thv, ydat, nt, 0, aux, kappa).ll;
 }
 
 template <class L, class Th>

@@ -64,6 +64,7 @@ struct smcmi_handle {
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_emax_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
+    std::vector<double> lik_host_data[2], lik_host_aux[2];   // host copies (lgss_kalman only): is the old vintage a prefix of the new one?
     double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
     int *d_mixpos = nullptr;
     // host-callback split
@@ -284,6 +285,20 @@ extern "C" int smcmi_set_parameters(smcmi_handle *h, const int32_t *fixed, const
     return push_model(h);
 }
 
+// Tempered updates whose old vintage is a prefix of the new data (the reference's use case: new observations appended) and whose
+// old likelihood is the same state-space model: the Kalman filter over the data passes through the old data's log-likelihood on
+// its way (bit for bit: same x_0, P_0, same steps), so the mutation evaluates one filter instead of two (SMCMI_NO_LIK_PREFIX=1 keeps two).
+static void update_lik_prefix(smcmi_handle *h) {
+    static const int off = getenv("SMCMI_NO_LIK_PREFIX") ? atoi(getenv("SMCMI_NO_LIK_PREFIX")) : 0;
+    const LikDev &a = h->h_model.lik[0], &b = h->h_model.lik[1];
+    const std::vector<double> &da = h->lik_host_data[0], &db = h->lik_host_data[1];
+    bool ok = !off && a.family == SMCMI_LIK_LGSS_KALMAN && b.family == SMCMI_LIK_LGSS_KALMAN && a.rows == b.rows && b.cols >= 1 && b.cols <= a.cols &&
+              a.n_par == b.n_par && !da.empty() && !db.empty() && h->lik_host_aux[0] == h->lik_host_aux[1];
+    for (int k = 0; ok && k < a.n_par; ++k) ok = a.par[k] == b.par[k];
+    if (ok) ok = memcmp(da.data(), db.data(), sizeof(double) * db.size()) == 0;
+    h->h_model.lik_prefix = ok ? (int)b.cols : 0;
+}
+
 extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const double *par, int64_t n_par,
                                     const double *data, int64_t rows, int64_t cols, const double *aux, int64_t aux_rows,
                                     int64_t aux_cols) {
@@ -296,7 +311,12 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
     memset(&l, 0, sizeof(LikDev));
     l.family = family;
     h->cb[which] = nullptr; h->cb_ud[which] = nullptr;            // a device family (or none) replaces a registered host callback
-    if (family == SMCMI_LIK_NONE || family == SMCMI_LIK_HOST_CALLBACK) { if (which == 0) h->have_lik = true; return push_model(h); }
+    if (family == SMCMI_LIK_NONE || family == SMCMI_LIK_HOST_CALLBACK) {
+        h->lik_host_data[which].clear(); h->lik_host_aux[which].clear();
+        update_lik_prefix(h);
+        if (which == 0) h->have_lik = true;
+        return push_model(h);
+    }
     if (family < SMCMI_LIK_GAUSS_ISO || family > SMCMI_LIK_LGSS_KALMAN) return set_err(SMCMI_ERR_ARG, "unknown likelihood family");
     if (family == SMCMI_LIK_LGSS_KALMAN && (n_par < 1 || rows != 3 || h->d != 13 || !aux || aux_rows * aux_cols < 112))
         return set_err(SMCMI_ERR_ARG, "lgss_kalman needs kappa, data 3 x T, aux = [C 8x8 | R 8x3 | Z 3x8] (112 doubles), d = 13");
@@ -331,6 +351,12 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
     }
     l.data = h->d_data[which]; l.rows = rows; l.cols = cols;
     l.aux = h->d_aux[which]; l.aux_rows = aux_rows; l.aux_cols = aux_cols;
+    h->lik_host_data[which].clear(); h->lik_host_aux[which].clear();
+    if (family == SMCMI_LIK_LGSS_KALMAN) {
+        h->lik_host_data[which].assign(data, data + rows * cols);
+        h->lik_host_aux[which].assign(aux, aux + KALMAN_AUX_USER);
+    }
+    update_lik_prefix(h);
     if (which == 0) h->have_lik = true;
     return push_model(h);
 }

@@ -106,3 +106,42 @@ def test_config5_sharded_group_matches_single():
     assert r2["logmdd"] == pytest.approx(r1["logmdd"], abs=1e-8)
     same = np.all(np.abs(P1 - P2) <= 1e-8 * (1 + np.abs(P1)), axis=1)
     assert same.mean() > 0.99
+
+
+_PREFIX_WORKER = r'''
+import sys, json, hashlib
+sys.path.insert(0, %(root)r)
+import numpy as np
+from smc_jl_amd import Engine
+from tests import models
+sp = models.kalman_spec(T=80, old_T=40)
+if %(shift)d:                       # an old vintage that is NOT a prefix of the data: two filter passes whatever the switch says
+    y = models.kalman_data(80)
+    sp["old_lik"] = (sp["old_lik"][0], sp["old_lik"][1], np.ascontiguousarray(y[:, 1:41]), sp["old_lik"][3])
+e = Engine(4000, 13, seed=17, max_stages=400, store_history=False)
+e.set_model(sp); e.init_from_prior()
+r = e.run(n_phi=60, use_fixed_schedule=False, tempering_target=0.9, n_blocks=3, alpha=0.9)
+P = e.download_cloud()
+print("RESULT " + json.dumps(dict(n_stages=r["n_stages"], logmdd=float(r["logmdd"]).hex(), cloud=hashlib.sha256(np.ascontiguousarray(P).tobytes()).hexdigest())))
+'''
+
+
+@pytest.mark.parametrize("shift", [0, 1])
+def test_old_data_prefix_takes_one_filter_pass_with_identical_bits(shift):
+    """Tempered update whose old vintage is the first 40 of the 80 periods: the mutation takes both log-likelihoods from one pass
+    over the data (csrc/model.hpp kalman_lgss2) - same stages, log-MDD and cloud, bit for bit, as two separate passes
+    (SMCMI_NO_LIK_PREFIX=1).  shift = 1: the old vintage is not a prefix; the switch must make no difference."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for off in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", _PREFIX_WORKER % dict(root=root, shift=shift)], env=dict(os.environ, SMCMI_NO_LIK_PREFIX=off),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
+    assert out[0] == out[1]
+    assert out[0]["n_stages"] > 5
