@@ -111,11 +111,12 @@ static bool eng2_eligible(const smcmi_handle *h, int world) {
     return eng == 2 || world > 1 || g.direct;
 }
 
-// the row totals of K1 / K2 are taken by the last block of each virtual shard instead of a k2_reduce launch (every geometry in which
-// consumers do not read the rows themselves); SMCMI_E2_NO_TAIL=1 keeps the launches (development, tests)
+// the row totals of K1 / K2 are taken by the last block of each virtual shard instead of a k2_reduce launch, while the mutation
+// kernel has at most ~4 blocks per CU (the ticket costs every block two barriers and an atomic: 48.1 vs 50.8 µs per stage at
+// 125 000 particles per handle, but 52.7 vs 46.7 ms per run at 10⁶ on one handle); SMCMI_E2_NO_TAIL=1 keeps the launches
 static bool fused_tails(const Eng2 *e) {
     static const int no_tail = getenv("SMCMI_E2_NO_TAIL") ? atoi(getenv("SMCMI_E2_NO_TAIL")) : 0;
-    return !e->g.direct && !no_tail;
+    return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= 1024;
 }
 template <int D>
 static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows) {

@@ -12,6 +12,11 @@ python bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 1 2>/
 python bench.py --workload capm --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_capm.json
 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
 LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
+python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
+python bench.py --alpha 0.9 --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6_alpha09.json
+# one rank's share of config 3 on 8 GPUs (125 000 particles, every hand-over through the all-gather path of a 1-rank RCCL communicator)
+HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu --no-history --nparts 125000 2>/dev/null | grep '^{' | tail -1 > $OUT/${R}_shard_rank_125k.json
 cd /tmp && export TMPDIR=/tmp
 pmc() {   # pmc <tag> <n> <bench args...>: kernel table + the three counter passes of one configuration
     local tag=$1 n=$2; shift 2
@@ -23,6 +28,15 @@ pmc() {   # pmc <tag> <n> <bench args...>: kernel table + the three counter pass
     python $ROOT/profiles/pmc_extract.py $(find $OUT/pf_$tag -name "*.db" | head -1) $(find $OUT/pw_$tag -name "*.db" | head -1) $n $(find $OUT/ps_$tag -name "*.db" | head -1) > $OUT/${R}_pmc_${tag}.json
     rm -rf $OUT/kt_$tag $OUT/pf_$tag $OUT/pw_$tag $OUT/ps_$tag
 }
+kt() {    # kt <tag> <bench args...>: kernel table only
+    local tag=$1; shift
+    rocprofv3 --kernel-trace --stats -d $OUT/kt_$tag -o kt -- python $ROOT/bench.py --no-cpu "$@" > /dev/null 2>&1
+    python $ROOT/profiles/summarize_rocpd.py $(find $OUT/kt_$tag -name "*.db" | head -1) > $OUT/${R}_kernel_stats_${tag}.txt
+    rm -rf $OUT/kt_$tag
+}
+kt capm --workload capm --steps 2 --warmup 1
+kt kalman --workload kalman --steps 2 --warmup 1
+kt gauss10_n1000000_alpha09 --alpha 0.9 --nparts 1000000 --no-history --steps 1 --warmup 1
 pmc gauss10_n100000 100000 --steps 3 --warmup 1
 pmc gauss10_n1000000 1000000 --nparts 1000000 --no-history --steps 1 --warmup 1
 pmc gauss10_n10000000 10000000 --nparts 10000000 --no-history --steps 1 --warmup 0
