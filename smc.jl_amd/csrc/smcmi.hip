@@ -352,7 +352,7 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
     l.data = h->d_data[which]; l.rows = rows; l.cols = cols;
     l.aux = h->d_aux[which]; l.aux_rows = aux_rows; l.aux_cols = aux_cols;
     h->lik_host_data[which].clear(); h->lik_host_aux[which].clear();
-    if (family == SMCMI_LIK_LGSS_KALMAN) {
+    if (family == SMCMI_LIK_LGSS_KALMAN && data && rows * cols > 0) {
         h->lik_host_data[which].assign(data, data + rows * cols);
         h->lik_host_aux[which].assign(aux, aux + KALMAN_AUX_USER);
     }
