@@ -180,6 +180,34 @@ def main():
             eng.init_from_prior()            # every step is a whole job: each rank draws its shard again (global particle ids)
             return eng.run_sharded(solver_passes=args.solver_passes, use_graph=2 if profile else 0, **RUN_KW)
 
+    hand_over = None
+    if world > 1 or force_sharded:
+        # Pre-flight on the hardware at hand, outside every timed region: one run with the per-stage hand-overs as RCCL all-gathers and
+        # one with the library's default - the peer mailbox over xGMI when every rank could map and test it (include/smcmi.h).  Both
+        # paths total the same rows in the same order, so their stage counts, resample counts and log-MDD bits must be identical; if
+        # they are not on any rank, or the mailbox run fails anywhere, every rank falls back to the all-gathers for the timed steps.
+        user_choice = os.environ.get("SMCMI_MAILBOX")
+        os.environ["SMCMI_MAILBOX"] = "0"
+        ra = one_step()
+        if user_choice is None:
+            os.environ.pop("SMCMI_MAILBOX")
+        else:
+            os.environ["SMCMI_MAILBOX"] = user_choice
+        ok, used = 1, 0
+        try:
+            rb = one_step()
+            used = 1 if eng.mailbox_active() else 0
+            if (rb["n_stages"], rb["resamples"], float(rb["logmdd"]).hex()) != (ra["n_stages"], ra["resamples"], float(ra["logmdd"]).hex()):
+                ok = 0
+        except Exception as ex:   # noqa: BLE001
+            ok = 0
+            sys.stderr.write("bench.py: rank %d: run with the default hand-over failed (%s): falling back to all-gathers\n" % (rank, ex))
+        flags = torch.tensor([ok, used], device="cuda", dtype=torch.int32)
+        if dist is not None:
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        if int(flags[0].item()) == 0:
+            os.environ["SMCMI_MAILBOX"] = "0"
+        hand_over = "peer mailbox (xGMI)" if int(flags[0].item()) == 1 and int(flags[1].item()) == 1 else "RCCL all-gather"
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -209,7 +237,8 @@ def main():
                    "n_parts_total": n_total, "n_parts_per_gpu": n_local, "n_para": D, "tempering_target": RUN_KW.get("tempering_target", 0.97),
                    "n_phi": RUN_KW.get("n_phi", 300), "lambda": 2.1,
                    "resampling": "systematic", "n_blocks": RUN_KW["n_blocks"], "alpha": RUN_KW["alpha"], "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
-                   "history": not args.no_history, "parallelism": "particles sharded x%d" % world},
+                   "history": not args.no_history, "parallelism": "particles sharded x%d" % world,
+                   "hand_over": hand_over},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
         "logmdd_exact": models.gauss_logmdd(D) if args.workload == "gauss10" else None, "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
     }

@@ -230,6 +230,18 @@ int smcmi_sync(smcmi_handle *h);
 int smcmi_comm_unique_id(uint8_t *id_out /* 128 bytes */);
 int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *id);
 int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
+/* Peer mailbox (n_para <= 10, at most 8 handles): the two per-stage hand-overs of a sharded run (correction sums, mutation sums:
+   8 x 70 and 8 x 34 doubles) written straight into every peer's fine-grained table over xGMI instead of two all-gathers.
+   smcmi_run_sharded sets it up by itself on its first call - it exchanges the tables' IPC handles through the communicator, runs
+   256 test exchanges on every rank and keeps the all-gathers unless all of that succeeded everywhere (SMCMI_MAILBOX=0, read at every
+   run, keeps the all-gathers).  Results are the same bits either way.
+   The three calls below do the same by hand for callers that exchange the 64-byte handles themselves (and for the tests):
+   export -> all-gather the handles by any means -> import (rank-ordered, 64 bytes each) -> selftest on all ranks at once
+   (errors_out = mismatches + time-outs of `rounds` exchanges with every peer). */
+int smcmi_mailbox_export(smcmi_handle *h, uint8_t *handle_out /* 64 bytes */);
+int smcmi_mailbox_import(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *all_handles /* world x 64 bytes */);
+int smcmi_mailbox_selftest(smcmi_handle *h, int32_t rank, int32_t world, int32_t rounds, int32_t *errors_out);
+int smcmi_mailbox_active(smcmi_handle *h, int32_t *active_out);   /* 1: the last sharded run handed its per-stage sums over through the mailbox */
 int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res);
 /* development aid: mean duration (µs, HIP events on the handle's stream) of `reps` back-to-back launches of one stage kernel on
    the current cloud.  which: 0 pass16(p=0) 1 pass16(p=1, with decision prologue) 2 correction 3 post_correct 4 scan 5 resample_gather

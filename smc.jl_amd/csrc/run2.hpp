@@ -9,6 +9,7 @@
 // device copies inside a process); every handle then totals the same V rows in the same order, so all take the same decisions
 // and the results do not depend on the number of handles.
 #pragma once
+#include <map>
 
 struct Eng2 {
     Geo2 g{};
@@ -119,7 +120,7 @@ static bool fused_tails(const Eng2 *e) {
     return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= 1024;
 }
 template <int D>
-static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows) {
+static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows, const Tail2 &tail) {
     Eng2 *e = h->e2;
     Rng2 ra{};
     unsigned grid = (unsigned)(e->g.Vl * e->g.nb1);
@@ -127,8 +128,9 @@ static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_e
         ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
         grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
     }
-    const Tail2 tail = fused_tails(e) ? Tail2{e->d_tick, e->vt_cm + (size_t)e->g.v0 * pad2(h->npairs + 2)} : Tail2{nullptr, nullptr};
-    k2_correct<D><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+    if (tail.tick) k2_correct<D, true><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
+    else k2_correct<D, false><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
                                                            e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
 }
 template <int D>
@@ -142,12 +144,15 @@ static void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool a
     Eng2 *e = h->e2;
     const size_t lds = k2_lds_bytes(D);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
-    if (e->g.t2 == 512) {
-        if (alpha1) k2_mutate<D, true, 512><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-        else k2_mutate<D, false, 512><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    if (e->g.t2 == 512 && !ma.tail.tick) {             // the direct geometry (config 2): no hand-over code in the instantiation
+        if (alpha1) k2_mutate<D, true, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    } else if (e->g.t2 == 512) {
+        if (alpha1) k2_mutate<D, true, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
     } else {
-        if (alpha1) k2_mutate<D, true, 256><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-        else k2_mutate<D, false, 256><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        if (alpha1) k2_mutate<D, true, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
     }
 }
 #define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
@@ -155,6 +160,142 @@ static void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool a
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break; default: CALL(10); break;              \
     }
+
+// ---- peer mailbox (stage2.hpp): allocation and the table of peer addresses
+static int mbox_alloc(smcmi_handle *h) {
+    if (h->d_mbox) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    // fine-grained: stores from a peer GPU and this GPU's polling loads meet in memory, not in a die's L2
+    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * MB_WORDS, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_WORDS));
+    return 0;
+}
+static int mbox_set_peers(smcmi_handle *h, const std::vector<unsigned long long *> &peers) {
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->d_peers) { hipFree(h->d_peers); h->d_peers = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_peers, sizeof(unsigned long long *) * peers.size()));
+    HIP_TRY(hipMemcpy(h->d_peers, peers.data(), sizeof(unsigned long long *) * peers.size(), hipMemcpyHostToDevice));
+    h->h_peers = peers;
+    return 0;
+}
+// several handles of one process (tests; SMCMI_MAILBOX=1): every handle sees the others' tables directly
+static int mbox_setup_group(ShardGroup &g) {
+    std::vector<unsigned long long *> peers(g.hs.size());
+    for (auto *h : g.hs) {
+        if (int e = mbox_alloc(h)) return e;
+        peers[shard_rank(h)] = h->d_mbox;
+    }
+    for (auto *h : g.hs)
+        if (h->h_peers != peers) { if (int e = mbox_set_peers(h, peers)) return e; }
+    return 0;
+}
+// ---- peer mailbox across processes: HIP IPC handles of the tables, exchanged by the caller or through the communicator
+// One block: `rounds` exchanges of a (rank, round)-dependent row with every peer over the real transport; errs += mismatches / time-outs.
+__global__ void k_mbox_selftest(unsigned long long *const *peers, const unsigned long long *mine, int world, int rank, int rounds, int *errs) {
+    const int t = threadIdx.x;
+    int bad = 0;
+    for (int q = 0; q < rounds; ++q) {
+        const unsigned tag = 0x7F000000u | (unsigned)q;
+        const long long table = (long long)(q & 1) * MB_TABLE_WORDS;
+        if (t < 16)
+            for (int r = 0; r < world; ++r) mb_store(peers[r] + table + ((long long)rank * MB_LD + t) * 2, 1000.0 * rank + q + t / 16.0, tag);
+        for (int idx = t; idx < world * 16; idx += blockDim.x) {
+            const int r = idx / 16, k = idx % 16;
+            const double x = mb_load(mine + table + ((long long)r * MB_LD + k) * 2, tag);
+            if (!(x == 1000.0 * r + q + k / 16.0)) ++bad;
+        }
+        __syncthreads();                     // (a rank re-uses a table two rounds later: only after it has read it)
+    }
+    if (bad) atomicAdd(errs, bad);
+}
+static void mbox_close_peers(smcmi_handle *h) {
+    for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);
+    h->ipc_opened.clear();
+    h->h_peers.clear();
+}
+static int mbox_export(smcmi_handle *h, uint8_t *out64) {
+    if (int e = mbox_alloc(h)) return e;
+    hipIpcMemHandle_t hd;
+    HIP_TRY(hipIpcGetMemHandle(&hd, h->d_mbox));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+    memcpy(out64, &hd, 64);
+    return 0;
+}
+static int mbox_import(smcmi_handle *h, int world, int rank, const uint8_t *all) {
+    if (world < 1 || world > V2_MAXV || rank < 0 || rank >= world) return set_err(SMCMI_ERR_ARG, "mailbox: bad (rank, world)");
+    if (int e = mbox_alloc(h)) return e;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    mbox_close_peers(h);
+    std::vector<unsigned long long *> peers((size_t)world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) { peers[r] = h->d_mbox; continue; }
+        hipIpcMemHandle_t hd;
+        memcpy(&hd, all + 64 * (size_t)r, 64);
+        void *p = nullptr;
+        if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            mbox_close_peers(h);
+            return set_err(SMCMI_ERR_HIP, "mailbox: hipIpcOpenMemHandle failed for rank " + std::to_string(r));
+        }
+        h->ipc_opened.push_back(p);
+        peers[r] = (unsigned long long *)p;
+    }
+    return mbox_set_peers(h, peers);
+}
+// errors (mismatches + time-outs) of `rounds` exchanges with every peer; every rank must call it at the same time
+static int mbox_selftest(smcmi_handle *h, int world, int rank, int rounds, int *errs_out) {
+    if (!h->d_peers || (int)h->h_peers.size() != world) return set_err(SMCMI_ERR_STATE, "mailbox: peers not imported");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int *d_err = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_err, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), h->stream));
+    k_mbox_selftest<<<1, 128, 0, h->stream>>>(h->d_peers, h->d_mbox, world, rank, rounds, d_err);
+    int e = 0;
+    HIP_TRY(hipMemcpyAsync(&e, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    hipFree(d_err);
+    *errs_out = e;
+    return 0;
+}
+// RCCL driver: map every rank's table through the communicator and test the transport; all ranks reach the same verdict
+// (h->mbox_ok) - anything short of a clean self-test on every rank leaves the all-gathers in place.
+static int mbox_setup_rccl(smcmi_handle *h) {
+    if (h->mbox_tried) return 0;
+    h->mbox_tried = true; h->mbox_ok = false;
+    if (h->world > V2_MAXV) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int world = h->world, rank = h->rank;
+    uint8_t mine[64] = {0};
+    double fail = mbox_export(h, mine) ? 1.0 : 0.0;
+    double *d_send = nullptr, *d_recv = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_send, 64));
+    HIP_TRY(hipMalloc((void **)&d_recv, 64 * (size_t)world));
+    HIP_TRY(hipMemcpyAsync(d_send, mine, 64, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(g_rccl.AllGather(d_send, d_recv, (size_t)8, SMCMI_NCCL_DOUBLE, h->nccl, h->stream));      // 64 bytes = 8 doubles per rank
+    std::vector<uint8_t> all(64 * (size_t)world);
+    HIP_TRY(hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    hipFree(d_send); hipFree(d_recv);
+    if (fail == 0.0 && mbox_import(h, world, rank, all.data())) fail = 1.0;
+    auto agree = [&](double mine_bad, double *total) -> int {           // sum of the ranks' failure counts
+        HIP_TRY(hipMemcpyAsync(h->d_comm, &mine_bad, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NCCL_TRY(g_rccl.AllReduce(h->d_comm, h->d_comm, (size_t)1, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
+        HIP_TRY(hipMemcpyAsync(total, h->d_comm, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return 0;
+    };
+    double total = 0.0;
+    if (int e = agree(fail, &total)) return e;
+    if (total != 0.0) { mbox_close_peers(h); return 0; }               // some rank could not map: everybody keeps the all-gathers
+    int errs = 0;
+    if (mbox_selftest(h, world, rank, 256, &errs)) errs = 1;
+    if (int e = agree((double)errs, &total)) return e;
+    if (total != 0.0) { mbox_close_peers(h); return 0; }
+    h->mbox_ok = true;
+    return 0;
+}
+static long long mbox_table(int kind, unsigned cnt) { return (long long)(kind * 2 + (int)(cnt & 1u)) * MB_TABLE_WORDS; }
+static unsigned mbox_tag(unsigned epoch, unsigned cnt) { return ((epoch & 0x7Fu) << 24) | (cnt & 0xFFFFFFu); }      // (never 0xFFFFFFFF: a cleared word)
 
 static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res) {
     smcmi_handle *h0 = g.hs[0];
@@ -239,6 +380,48 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     const Geo2 g0 = h0->e2->g;
     const int npf = pad2(h0->npairs + 2), np = pad2(h0->npairs);
     const bool direct = g0.direct != 0, inker = g0.inker != 0;
+    // ---- peer mailbox instead of the two all-gathers of a stage: RCCL driver when smcmi_comm_init mapped and tested it everywhere;
+    // in-process groups only on request (their kernels share one GPU: a consumer spinning on every CU could starve its producers)
+    bool mbox = false;
+    // (read at every run: a caller that has validated - or lost confidence in - the transport can switch it between runs)
+    const int want = getenv("SMCMI_MAILBOX") ? atoi(getenv("SMCMI_MAILBOX")) : -1;                 // -1: default; 2: also with one rank (tests)
+    for (auto *h : g.hs) h->mbox_used = false;
+    if ((multi || (g.rccl && want == 2)) && fused_tails(h0->e2)) {
+        if (g.rccl) { if (want != 0) { if (int e = mbox_setup_rccl(h0)) return e; } mbox = h0->mbox_ok && want != 0; }
+        else if (want == 1) { if (int e = mbox_setup_group(g)) return e; mbox = true; }
+    }
+    unsigned mb_cnt[MB_KINDS] = {0, 0};               // counter (-> tag, parity) of the post the next consumer of that kind reads
+    unsigned mb_next[MB_KINDS] = {0, 0};              // counters are never reused: a resumed stage posts under fresh tags
+    bool mb_live[MB_KINDS] = {false, false};          // the latest rows of that kind were posted to the mailboxes
+    std::map<int, unsigned> mb_cm_at, mb_mut_at;      // stage -> counter of its latest K1 / K2 launch (to rewind after a stall)
+    if (mbox) {
+        for (auto *h : g.hs) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            h->mbox_used = true;
+            h->mbox_epoch += 1;
+            HIP_TRY(hipMemsetAsync(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_WORDS, h->stream));
+            const int zero = 0;
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mb_timed_out), &zero, sizeof(int), 0, hipMemcpyHostToDevice, h->stream));
+        }
+        if (int e = g.barrier()) return e;            // nobody posts before every table is cleared
+    }
+    auto mb_rows = [&](smcmi_handle *h, int kind, const double *vt, int m) {
+        Rows2 r{vt, g0.V, 1, m};
+        r.mb = h->d_mbox + mbox_table(kind, mb_cnt[kind]);
+        r.tag = mbox_tag(h->mbox_epoch, mb_cnt[kind]);
+        return r;
+    };
+    auto mb_tail = [&](smcmi_handle *h, int kind, double *vt_slice) {
+        Eng2 *e = h->e2;
+        Tail2 t{};
+        if (!fused_tails(e)) return t;
+        t.tick = e->d_tick + kind * V2_MAXV; t.vt = vt_slice;
+        if (mbox) {
+            t.peers = h->d_peers; t.world = g.world; t.gv0 = e->g.v0;
+            t.table = mbox_table(kind, mb_cnt[kind]); t.tag = mbox_tag(h->mbox_epoch, mb_cnt[kind]);
+        }
+        return t;
+    };
     // ---- row-set plumbing
     auto view = [&](smcmi_handle *, const double *rows, const double *vt, int nr, int m) {
         return direct ? Rows2{rows, g0.Vl, nr, m} : Rows2{vt, g0.V, 1, m};
@@ -252,7 +435,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             Eng2 *e = h->e2;
             k2_reduce<<<e->g.Vl, RT, 0, h->stream>>>(e->*rows, nr, m, max_idx, e->*vt + (size_t)e->g.v0 * m, pair);
         }
-        if (!multi) return 0;
+        if (!multi || (fused && mbox)) return 0;        // (mailbox: the tails posted the totals to every handle)
         return g.allgather([=](smcmi_handle *h) { return (const double *)(h->e2->*vt + (size_t)h->e2->g.v0 * m); },
                            [=](smcmi_handle *h) { return h->e2->*vt; }, (size_t)g0.Vl * m);
     };
@@ -267,8 +450,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return g.allgather([=](smcmi_handle *h) { return (const double *)(h->e2->vt_pass + (size_t)h->e2->g.v0 * 2 * KC); },
                            [=](smcmi_handle *h) { return h->e2->vt_pass; }, (size_t)g0.Vl * 2 * KC);
     };
-    auto mut_rows = [&](smcmi_handle *h) { return view(h, h->e2->rows_mut, h->e2->vt_mut, g0.nb2, RMUT); };
-    auto cm_rows = [&](smcmi_handle *h) { return view(h, h->e2->rows_cm, h->e2->vt_cm, g0.nb1, npf); };
+    auto mut_rows = [&](smcmi_handle *h) { return mb_live[1] ? mb_rows(h, 1, h->e2->vt_mut, RMUT) : view(h, h->e2->rows_mut, h->e2->vt_mut, g0.nb2, RMUT); };
+    auto cm_rows = [&](smcmi_handle *h) { return mb_live[0] ? mb_rows(h, 0, h->e2->vt_cm, npf) : view(h, h->e2->rows_cm, h->e2->vt_cm, g0.nb1, npf); };
     auto gm_rows = [&](smcmi_handle *h) { return view(h, h->e2->rows_gm, h->e2->vt_gm, g0.nbg, np); };
     // energy maximum of the initial cloud in the mutation-row layout (stage 2's energy shift)
     for (auto *h : g.hs) {
@@ -284,10 +467,15 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
     // ---- pieces of a stage
     auto enq_K1 = [&](int n, int begin_done, int spec_expected) -> int {
-        for (auto *h : g.hs) {
+        std::vector<Rows2> mrs;
+        for (auto *h : g.hs) mrs.push_back(mut_rows(h));                 // (the mutation rows this launch consumes)
+        if (mbox) { mb_cnt[0] = ++mb_next[0]; mb_live[0] = true; mb_cm_at[n] = mb_cnt[0]; }   // its own rows go out under a fresh correction tag
+        for (size_t k = 0; k < g.hs.size(); ++k) {
+            smcmi_handle *h = g.hs[k];
             HIP_TRY(hipSetDevice(h->cfg.device));
-            const Rows2 mr = mut_rows(h);
-#define SMCMI_CALL(D) launch_k2_correct<D>(h, n, begin_done, spec_expected, mr)
+            const Rows2 mr = mrs[k];
+            const Tail2 tail = mb_tail(h, 0, h->e2->vt_cm + (size_t)h->e2->g.v0 * npf);
+#define SMCMI_CALL(D) launch_k2_correct<D>(h, n, begin_done, spec_expected, mr, tail)
             SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
         }
@@ -344,14 +532,18 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return publish(&Eng2::rows_gm, &Eng2::vt_gm, g0.nbg, np, -1);
     };
     auto enq_K2 = [&](int n, int sel_enqueued) -> int {
-        for (auto *h : g.hs) {
+        std::vector<Rows2> crs;
+        for (auto *h : g.hs) crs.push_back(cm_rows(h));                  // (the correction rows this launch consumes)
+        if (mbox) { mb_cnt[1] = ++mb_next[1]; mb_live[1] = true; mb_mut_at[n] = mb_cnt[1]; }
+        for (size_t hk = 0; hk < g.hs.size(); ++hk) {
+            smcmi_handle *h = g.hs[hk];
             HIP_TRY(hipSetDevice(h->cfg.device));
             Eng2 *e = h->e2;
             Mut2Args ma{};
             ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n; ma.sel_enqueued = sel_enqueued; ma.adaptive = adaptive ? 1 : 0;
-            ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
+            ma.cmrows = crs[hk]; ma.gmrows = gm_rows(h); ma.wt = h->d_wt; ma.rows_mut = e->rows_mut;
             ma.zbuf = e->rng_ahead ? h->d_zbuf : nullptr;
-            ma.tail = fused_tails(e) ? Tail2{e->d_tick + V2_MAXV, e->vt_mut + (size_t)e->g.v0 * RMUT} : Tail2{nullptr, nullptr};
+            ma.tail = mb_tail(h, 1, e->vt_mut + (size_t)e->g.v0 * RMUT);
             ma.pre = inker ? nullptr : e->d_pre;
             ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
             ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
@@ -473,6 +665,16 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (int e = read_ctl(&c)) return e;
         while (c.status.code == 2 || c.status.code == 3 || c.status.code == 4) {
             const int sn = c.status.stage, code = c.status.code;
+            // mailbox: a resumed stage posts under fresh tags into tables a slower handle may still be polling for the stalled
+            // stage's - every handle must have left the stalled batch first
+            if (mbox) {
+                if (int e = g.barrier()) return e;
+                // the posts that were actually made: stage sn - 1's mutation rows; stage sn's correction rows if only its selection is missing
+                const auto it = mb_mut_at.find(sn - 1);
+                mb_live[1] = it != mb_mut_at.end();
+                if (mb_live[1]) mb_cnt[1] = it->second;
+                if (code == 3) { mb_cnt[0] = mb_cm_at[sn]; mb_live[0] = true; }
+            }
             for (int &s : ev_stage) if (s >= sn) s = -1;           // the stalled stage's mutation launch and everything behind it were no-ops
             if (int e = clear_status()) return e;
             if (code == 4) {

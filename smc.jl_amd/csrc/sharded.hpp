@@ -131,6 +131,15 @@ struct ShardGroup {
         }
         return 0;
     }
+    // every handle's stream has reached this point before any goes on (RCCL: an in-stream all-reduce of one double)
+    int barrier() {
+        if (rccl) {
+            smcmi_handle *h = hs[0];
+            NCCL_TRY(g_rccl.AllReduce(h->d_comm, h->d_comm, (size_t)1, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
+            return 0;
+        }
+        return sync_all();
+    }
     // recv(h)[r * count .. (r+1) * count) = send(shard r)
     template <class FS, class FR>
     int allgather(FS send, FR recv, size_t count) {

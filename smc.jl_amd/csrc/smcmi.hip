@@ -65,6 +65,15 @@ struct smcmi_handle {
     long long comm_cap = 0;
     double *d_hist_w = nullptr, *d_hist_W = nullptr;
     std::vector<double> lik_host_data[2], lik_host_aux[2];   // host copies (lgss_kalman only): is the old vintage a prefix of the new one?
+    // peer mailbox of sharded engine-2 runs (stage2.hpp Mailbox): this handle's table, the peers' tables as mapped here
+    unsigned long long *d_mbox = nullptr;
+    unsigned long long **d_peers = nullptr;
+    std::vector<unsigned long long *> h_peers;
+    std::vector<void *> ipc_opened;           // peers' tables opened through hipIpcOpenMemHandle (closed with the handle)
+    bool mbox_ok = false;                     // RCCL driver: every rank mapped every table and the self-test passed everywhere
+    bool mbox_tried = false;
+    bool mbox_used = false;                   // the last engine-2 run of this handle handed its sums over through the mailbox
+    unsigned mbox_epoch = 0;
     double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
     int *d_mixpos = nullptr;
     // host-callback split
@@ -245,6 +254,10 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->nccl) smcmi_comm_release(h);
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
+    for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);
+    h->ipc_opened.clear();
+    if (h->d_mbox) { hipFree(h->d_mbox); h->d_mbox = nullptr; }
+    if (h->d_peers) { hipFree(h->d_peers); h->d_peers = nullptr; }
     if (h->cbuf) { free_callback_buffers(h->cbuf); h->cbuf = nullptr; }
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
@@ -1525,4 +1538,26 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     }
     h->h_st = saved;
     return push_state(h);
+}
+
+// ---- peer mailbox across processes (include/smcmi.h): the caller may exchange the 64-byte table handles itself
+extern "C" int smcmi_mailbox_export(smcmi_handle *h, uint8_t *handle_out) {
+    if (!h || !handle_out) return set_err(SMCMI_ERR_ARG, "null argument");
+    return mbox_export(h, handle_out);
+}
+extern "C" int smcmi_mailbox_import(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *all_handles) {
+    if (!h || !all_handles) return set_err(SMCMI_ERR_ARG, "null argument");
+    return mbox_import(h, world, rank, all_handles);
+}
+extern "C" int smcmi_mailbox_selftest(smcmi_handle *h, int32_t rank, int32_t world, int32_t rounds, int32_t *errors_out) {
+    if (!h || !errors_out || rounds < 1) return set_err(SMCMI_ERR_ARG, "bad argument");
+    int e = 0;
+    if (int rc = mbox_selftest(h, world, rank, rounds, &e)) return rc;
+    *errors_out = e;
+    return 0;
+}
+extern "C" int smcmi_mailbox_active(smcmi_handle *h, int32_t *active_out) {
+    if (!h || !active_out) return set_err(SMCMI_ERR_ARG, "null argument");
+    *active_out = h->mbox_used ? 1 : 0;
+    return 0;
 }

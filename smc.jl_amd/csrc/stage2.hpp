@@ -62,7 +62,65 @@ struct Geo2 {
 struct Rows2 {                    // rows[(v * nr + r) * ld + idx], v < nvs, r < nr
     const double *p;
     int nvs, nr, ld;
+    const unsigned long long *mb; // non-null: the V x m totals arrive in this handle's mailbox table (Mailbox2 below) under `tag`
+    unsigned tag;
 };
+
+// ------------------------------------------------------------------------------------------------ peer mailbox (several GPUs)
+// The two hand-overs of a stage (correction sums K1 -> K2, mutation sums K2 -> K1) between handles without a collective call: the
+// block that totals a virtual shard (Tail2) writes the m totals straight into every peer's mailbox table - over xGMI into the
+// peer's fine-grained memory when the handles sit on different GPUs - and every consumer block polls its own GPU's table.  The
+// transport is the low-latency protocol collectives libraries use for small messages: every 64-bit word carries 32 bits of payload
+// and a 32-bit tag (a double = two words), a word is stored and loaded atomically, so a reader that sees the expected tag in a
+// word has that word's payload - no fence, no ordering assumption between words; a word not yet there is polled again.
+// Table of one (kind, parity): [V2_MAXV][MB_LD] doubles = 2 words each.  Tags are unique per hand-over (run epoch | counter) and
+// consecutive hand-overs of a kind alternate parity: a handle can only post hand-over c + 2 after every handle has consumed c.
+constexpr int MB_LD = 72;                                      // row capacity in doubles (m <= 72)
+constexpr int MB_TABLE_WORDS = V2_MAXV * MB_LD * 2;            // words of one (kind, parity) table
+constexpr int MB_KINDS = 2;                                    // 0: correction rows, 1: mutation rows
+constexpr int MB_WORDS = MB_KINDS * 2 * MB_TABLE_WORDS;        // a handle's whole mailbox
+constexpr long long MB_TIMEOUT_TICKS = 100000000ll;            // ~1 s of the 100 MHz wall clock: a peer that never posts poisons the totals with NaN
+__device__ inline void mb_store(unsigned long long *w, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, ((unsigned long long)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ int g_mb_timed_out = 0;          // sticky: after the first time-out every wait gives up at once (the run ends with NaN sums)
+__device__ inline double mb_load(const unsigned long long *w, unsigned tag) {
+    unsigned long long a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag) {
+        const long long t0 = wall_clock64();
+        do {
+            if (__hip_atomic_load(&g_mb_timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return __builtin_nan("");
+            __builtin_amdgcn_s_sleep(2);
+            a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (wall_clock64() - t0 > MB_TIMEOUT_TICKS) {
+                __hip_atomic_store(&g_mb_timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return __builtin_nan("");
+            }
+        } while ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag);
+    }
+    return __longlong_as_double((long long)((b << 32) | (a & 0xffffffffull)));
+}
+// totals of columns [0, M) over the R.nvs virtual shards from the mailbox: the order of reduce_rows on a one-row-per-shard table
+// (0 + x_0 + x_1 + ...), so the result is the one the all-gathered table gives.  All T threads call; ends with a barrier.
+template <int M, int T>
+__device__ inline void mbox_totals(const Rows2 &R, double *vt, double *tot, int max_idx) {
+    for (int idx = threadIdx.x; idx < R.nvs * M; idx += T) {
+        const int v = idx / M, k = idx % M;
+        vt[idx] = mb_load(R.mb + ((long long)v * MB_LD + k) * 2, R.tag);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < M; k += T) {
+        const bool mx = k == max_idx;
+        double t = mx ? -__builtin_inf() : 0.0;
+        for (int v = 0; v < R.nvs; ++v) { const double x = vt[v * M + k]; t = mx ? fmax(t, x) : t + x; }
+        tot[k] = t;
+    }
+    __syncthreads();
+}
 
 struct Begin2 {                   // stage n as decided at its begin (K1 / k2_begin / k2_finish, block 0)
     int stage, final, spec, j;
@@ -178,6 +236,7 @@ __device__ inline void reduce_rows_ct(const Rows2 &R, double *vt, double *tot, i
 // the same with the row capacity picked at run time (8 / 16 / 32 / 64)
 template <int M, int H, int T>
 __device__ inline void reduce_rows(const Rows2 &R, double *vt, double *tot, int max_idx = -1) {
+    if (R.mb) { mbox_totals<M, T>(R, vt, tot, max_idx); return; }
     if (R.nr <= 8) reduce_rows_ct<M, H, 8, T>(R, vt, tot, max_idx);
     else if (R.nr <= 16) reduce_rows_ct<M, H, 16, T>(R, vt, tot, max_idx);
     else if (R.nr <= 32) reduce_rows_ct<M, H, 32, T>(R, vt, tot, max_idx);
@@ -275,6 +334,10 @@ __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, 
 struct Tail2 {
     int *tick;                 // [Vl] counters, zero between launches; null: no tail (direct geometry: consumers read the rows)
     double *vt;                // this handle's slice of the V x m table: vt[v * m]
+    unsigned long long *const *peers;   // non-null: post the totals into every handle's mailbox (peers[r], r < world) instead of an all-gather
+    int world, gv0;            // handles; global index of this handle's first virtual shard
+    long long table;           // word offset of the (kind, parity) table inside a mailbox
+    unsigned tag;
 };
 __device__ inline void row_store(double *p, double v, bool coh) {
     if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -284,12 +347,19 @@ template <int NT>
 __device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, int nr_raw, int m, int max_idx, int pair) {
     if (!t.tick) return;
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (waits for this wavefront's row stores to complete)
+    // every wavefront waits for its own row stores to be acknowledged before the barrier that precedes the ticket (a workgroup-scope
+    // release fence does not: outside tgsplit mode the compiler omits the vmcnt wait there, and the ticket could overtake a row)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&t.tick[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr_raw - 1;
     __syncthreads();
     if (!s_last) return;
     reduce_vshard<NT, true>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, t.vt + (long long)v * m, pair);
+    if (t.peers && (int)threadIdx.x < m) {             // (thread k < m stored total k just above)
+        const double x = t.vt[(long long)v * m + threadIdx.x];
+        const long long w = t.table + ((long long)(t.gv0 + v) * MB_LD + threadIdx.x) * 2;
+        for (int r = 0; r < t.world; ++r) mb_store(t.peers[r] + w, x, t.tag);
+    }
     if (threadIdx.x == 0) __hip_atomic_store(&t.tick[v], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -528,6 +598,10 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
         const int jj = j_direct - 1 + t;                 // 0-based index of walk step t + 1
         if (!st->rp.use_fixed_schedule && jj >= 0 && jj < st->rp.n_phi) swv = sched[jj];
     }
+    if (mrows.mb) {                                      // mailbox: a launch that will not run must not wait for rows nobody posts
+        __syncthreads();
+        if (s_po->stage != n - 1) return -1;
+    }
     if (rows_valid) reduce_rows<RMUT, 2, T>(mrows, s_vt, s_tot, RMAX_IDX);
     else {
         if (t < RMUT) s_tot[t] = t == RMAX_IDX ? -__builtin_inf() : 0.0;
@@ -724,7 +798,8 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
 // (particle.jl:481-483, 526-529) of the corrected cloud, as k_correct_moments - but the unnormalised weights W̃ always go to the
 // scratch column `wt` (the cloud's weight column is rewritten by K2 / the gather once the stage is decided), the block's ΣW̃
 // also goes to csum[b] (chunk sums of the selection scan), and the stage-begin logic runs in the prologue (begin_done = 0).
-template <int D>
+// TAIL: the geometry hands its rows over through Tail2 (sharded runs, large clouds); the direct geometry's instantiation carries none of it
+template <int D, bool TAIL>
 __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int begin_done, int spec_expected,
                                                  Rows2 mrows, const double *sched, Records rec, double *rows_cm, double *csum, double *wt,
                                                  double *hist_w, long long hist_ld, Rng2 ra, Tail2 tail, long long *prof = nullptr) {
@@ -799,19 +874,19 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
 #pragma unroll
             for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
             const double t64 = block_reduce_nw<64, NW>(a64, red);
-            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, t64, tail.tick != nullptr);
+            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, t64, TAIL && tail.tick != nullptr);
             if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = t64;
         } else {
             double ar[REMP];
 #pragma unroll
             for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
             const double tr = block_reduce_nw<REMP, NW>(ar, red);
-            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, tr, tail.tick != nullptr);
+            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, tr, TAIL && tail.tick != nullptr);
             if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = tr;
         }
     }
     K2_STAMP(prof, 5);
-    tail_reduce<T1>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
+    if constexpr (TAIL) tail_reduce<T1>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
     // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double a = s_bg.accept, tg = st->rp.target;
@@ -902,6 +977,7 @@ __global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows
     const int r = threadIdx.x;
     const Begin2 bg = ctl->bg;
     bool go = bg.stage == n && bg.final && ctl->ps[(n - 1) & 1].stage == n - 1;
+    if (cmrows.mb && !go) { if (r == 0) out[0] = -1; return; }       // (mailbox: no waiting for rows of a stage that does not run)
     reduce_rows<2, 8, 64>(cmrows, s_vt, s_tot);
     double ess;
     if (go) go = decide2(bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) == 1;
@@ -1228,6 +1304,10 @@ __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, 
     if (tid < nf) L.fi[tid] = md->free_inds[tid];
     const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // under the loads' latency
     K2_STAMP(ma.prof, 1);
+    if (ma.cmrows.mb) {                                                // mailbox: see begin2_block
+        __syncthreads();
+        if (S->bg.stage != n || !S->bg.final || S->po.stage != n - 1) return false;
+    }
     reduce_rows<pad2(NPF), 1, T>(ma.cmrows, L.s_vt, L.s_tot);          // (its barriers also publish the LDS copies above)
     K2_STAMP(ma.prof, 2);
     if (S->bg.stage != n || !S->bg.final || S->po.stage != n - 1) return false;
@@ -1280,7 +1360,7 @@ __device__ inline void k2_bookkeeping(DevState *st, Ctl2 *ctl, const Mut2Args &m
 // from LDS by the prologue instead of from DevState; it reads the particle from buffer 0 (buffer 1 on resample stages: the
 // gathered cloud) and always writes buffer 0, applies normalize_weights! (particle.jl:362-366: W̃ N / ΣW̃, two roundings; 1 after a
 // resample) to the weight column and its history, and leaves one row of RMUT sums for the next stage's begin.
-template <int D, bool ALPHA1, int T>
+template <int D, bool ALPHA1, int T, bool TAIL>
 __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
                                                                                Mut2Args ma, int nb, int nf) {
 #pragma clang fp contract(fast)
@@ -1499,7 +1579,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         energy_terms(es, w_part, like, like_prev, e_center, live, rs != 0);
         es[EACC] = acc_val;
         const double tot = block_reduce_es2<T / 64>(es, l_dat);      // likelihood data in LDS is dead by now
-        if (tid < ES) row_store(row + tid, tot, ma.tail.tick != nullptr);
+        if (tid < ES) row_store(row + tid, tot, TAIL && ma.tail.tick != nullptr);
     } else {
         double a1[1] = {acc_val};
         Butterfly<0, 32>::run(a1, tid & 63);
@@ -1508,7 +1588,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         if (tid < ES) {
             double sacc = ((red[0] + red[1]) + red[2]) + red[3];
             if constexpr (T == 512) sacc += ((red[4] + red[5]) + red[6]) + red[7];
-            row_store(row + tid, tid == EACC ? sacc : 0.0, ma.tail.tick != nullptr);
+            row_store(row + tid, tid == EACC ? sacc : 0.0, TAIL && ma.tail.tick != nullptr);
         }
     }
     __syncthreads();
@@ -1516,10 +1596,10 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         double m = emx[0];
 #pragma unroll
         for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
-        row_store(row + RMAX_IDX, m, ma.tail.tick != nullptr);
+        row_store(row + RMAX_IDX, m, TAIL && ma.tail.tick != nullptr);
     }
     K2_STAMP(ma.prof, 10);
-    tail_reduce<T>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, T == 256 ? 1 : 0);
+    if constexpr (TAIL) tail_reduce<T>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, T == 256 ? 1 : 0);
     if (blockIdx.x == 0 && !ma.pre) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);
     K2_STAMP(ma.prof, 11);
 }

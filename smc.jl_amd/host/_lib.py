@@ -107,6 +107,10 @@ SYMBOLS = [
     ("smcmi_comm_unique_id", C.c_int, [C.c_char_p]),
     ("smcmi_comm_init", C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p]),
     ("smcmi_run_sharded", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),
+    ("smcmi_mailbox_export", C.c_int, [_H, C.POINTER(C.c_uint8)]),
+    ("smcmi_mailbox_import", C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    ("smcmi_mailbox_selftest", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    ("smcmi_mailbox_active", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("smcmi_run_group", C.c_int, [C.POINTER(_H), C.c_int32, C.POINTER(RunConfig), C.POINTER(Result)]),
 ]
 

@@ -268,6 +268,30 @@ class Engine:
         """Join the RCCL communicator (unique_id: the 128 bytes of comm_unique_id() from rank 0)."""
         check(self._L.smcmi_comm_init(self._h, rank, world, bytes(unique_id)))
 
+    def mailbox_export(self):
+        """64-byte IPC handle of this handle's peer-mailbox table (include/smcmi.h: smcmi_mailbox_export)."""
+        buf = (C.c_uint8 * 64)()
+        self._checked(self._L.smcmi_mailbox_export(self._h, buf))
+        return bytes(buf)
+
+    def mailbox_import(self, rank, world, handles):
+        """Map every rank's table (handles: rank-ordered list of 64-byte handles)."""
+        raw = b"".join(handles)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        self._checked(self._L.smcmi_mailbox_import(self._h, int(rank), int(world), buf))
+
+    def mailbox_selftest(self, rank, world, rounds=256):
+        """Mismatches + time-outs of `rounds` test exchanges with every peer (all ranks call it together)."""
+        errs = C.c_int32(0)
+        self._checked(self._L.smcmi_mailbox_selftest(self._h, int(rank), int(world), int(rounds), C.byref(errs)))
+        return int(errs.value)
+
+    def mailbox_active(self):
+        """True if the last sharded run handed its per-stage sums over through the peer mailbox (else: all-gathers)."""
+        a = C.c_int32(0)
+        self._checked(self._L.smcmi_mailbox_active(self._h, C.byref(a)))
+        return bool(a.value)
+
     def run_sharded(self, n_blocks=1, n_mh_steps=1, lam=2.1, n_phi=300, resampling_method="systematic", threshold_ratio=0.5,
                     c=0.5, alpha=1.0, target=0.25, use_fixed_schedule=True, tempering_target=0.97, prior_weight=0.0,
                     log_prob_old_data=0.0, solver_passes=0, phi_rtol=0.0, initial_ess=0.0, use_graph=0, stop_after_stage=0,
