@@ -217,6 +217,20 @@ def test_moments_vs_oracle(orc, n, d):
     np.testing.assert_allclose(mean2, mean, rtol=1e-13)
 
 
+def test_moments_pinned_by_the_reference_mutation_fixture(golden):
+    """smcmi_moments on the cloud of test/reference/mutation_inputs.jld2 against the MvNormal(weighted_mean, weighted_cov) the
+    reference stored next to it (a-10 pinned by the reference, not only by the oracle)."""
+    z = golden("mutation")
+    P = np.asfortranarray(z["particles_in"])
+    e = make_engine(dummy_spec(9), P.shape[0])
+    e.upload_cloud(P)
+    e.moments()
+    mean, cov = e.moments()                       # (second call: centred on the first mean)
+    np.testing.assert_allclose(mean, z["mu"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cov, z["Sigma"], rtol=1e-10, atol=1e-12 * np.abs(z["Sigma"]).max())
+    e.close()
+
+
 # ----------------------------------------------------------------------------------------------- mutation
 def _mutation_case(orc, spec, n, n_blocks, n_mh, alpha, c, phi, seed, stage, P=None):
     m = models.oracle_model(spec)

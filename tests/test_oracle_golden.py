@@ -181,6 +181,18 @@ def test_weighted_moments_match_numpy():
 
 
 # ----------------------------------------------------------------------------- end-to-end vs analytic truths
+def test_weighted_moments_pinned_by_the_reference_mutation_fixture(golden):
+    """a-10 (`weighted_mean`, `weighted_cov`, src/particle.jl:481-483, 526-529) against the reference itself: the MvNormal `d` stored in
+    test/reference/mutation_inputs.jld2 is MvNormal(weighted_mean(cloud), weighted_cov(cloud)) of the cloud stored next to it
+    (test/mutation.jl:22-34; the cloud was written right after a resample, all weights 1)."""
+    z = golden("mutation")
+    P = np.asfortranarray(z["particles_in"])
+    assert np.all(P[:, -1] == 1.0)
+    np.testing.assert_allclose(orc.weighted_mean(P), z["mu"], rtol=1e-12, atol=1e-12)
+    C = orc.weighted_cov(P)
+    np.testing.assert_allclose(C, z["Sigma"], rtol=1e-12, atol=1e-12 * np.abs(z["Sigma"]).max())
+
+
 def test_regression_end_to_end_config1():
     """BASELINE config 1: examples/regression_model, N=1000, fixed schedule (defaults smc_main.jl:123-140).
     Exact log-MDD -99.88901084799365 and posterior moments."""
