@@ -415,11 +415,17 @@ __device__ inline double loglik_s(const L &l, Th th) {
         if (singular) return SMCMI_NEG_INF;
         const double term1 = -3.0 / 2.0 * log(2.0 * M_PI) - 1.0 / 2.0 * log(det);
         double S = 0.0, lp = 0.0;
+        // the observations are the same for every lane: read through the constant address space they arrive as scalar operands (the
+        // register kernels hand this family the global pointers, not an LDS copy)
+        using cdp = const double __attribute__((address_space(4))) *;
+        const cdp dat = (cdp)(unsigned long long)l.data, mkt = (cdp)(unsigned long long)l.aux;
+        const long long ar = l.aux_rows;
+#pragma unroll 4
         for (long long t = 0; t < T; ++t) {
-            const double mk = l.aux[l.aux_rows * t];
+            const double mk = mkt[ar * t];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const double e = l.data[i + 3 * t] - a[i] - a[i] * mk;
+                const double e = dat[i + 3 * t] - a[i] - a[i] * mk;
                 S += e * (inv[i] * e);
             }
         }

@@ -1399,7 +1399,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         for (int q = 0; q < 2; ++q) {
             const LikDev &ld = q == 0 ? ld0 : ld1;
             const long long nd = ld.rows * ld.cols, na = ld.aux_rows * ld.aux_cols;
-            const bool fits = ld.family >= 0 && used + nd + na <= LIK_LDS_CAP;
+            const bool fits = ld.family >= 0 && ld.family != SMCMI_LIK_CAPM_LITERAL && used + nd + na <= LIK_LDS_CAP;   // (capm_literal reads its data as scalars)
             if (fits) {
                 for (long long k = tid; k < nd; k += T) l_dat[used + k] = ld.data[k];
                 for (long long k = tid; k < na; k += T) l_dat[used + nd + k] = ld.aux[k];
