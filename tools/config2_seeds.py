@@ -31,4 +31,4 @@ for seed in (1, 2, 3):
                         logmdd_gpu=r["logmdd"], logmdd_cpu=ro["logmdd"], abs_err=abs(r["logmdd"] - ro["logmdd"]),
                         gpu_seconds=r["seconds"], cpu_seconds=ro["seconds"], mean_err=float(np.max(np.abs(mu - spec["lik"][2].ravel() * 25 / 25.0625)))))
         print(json.dumps(out[-1]), flush=True)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "r01z_config2_seeds.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "r02_config2_seeds.json"), "w"), indent=1)
