@@ -148,13 +148,16 @@ struct ShardGroup {
             NCCL_TRY(g_rccl.AllGather(send(h), recv(h), count, SMCMI_NCCL_DOUBLE, h->nccl, h->stream));
             return 0;
         }
+        // (the copies go on the DESTINATION handle's stream, behind which its consumers are enqueued: the handles' streams are
+        // non-blocking, a device-to-device hipMemcpy on the null stream is ordered with none of them and need not have finished when
+        // it returns - consumers could read the table before the copy landed, and once in a few hundred runs did)
         if (int rc = sync_all()) return rc;
         for (auto *dst : hs) {
             HIP_TRY(hipSetDevice(dst->cfg.device));
             for (size_t r = 0; r < hs.size(); ++r)
-                HIP_TRY(hipMemcpy(recv(dst) + r * count, send(hs[r]), sizeof(double) * count, hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpyAsync(recv(dst) + r * count, send(hs[r]), sizeof(double) * count, hipMemcpyDeviceToDevice, dst->stream));
         }
-        return 0;
+        return sync_all();                     // (and no source may go on before every copy out of it is done)
     }
     // Resample redistribution as an all-to-all-v (systematic resampling: the ancestors of a shard's output slots form one
     // contiguous global row range [lo[r], hi[r]]).  Every shard receives exactly the rows of that range, column by column, into
@@ -197,11 +200,11 @@ struct ShardGroup {
                 long long a, b;
                 if (!overlap((int)d, (int)o, a, b)) continue;
                 HIP_TRY(hipSetDevice(hs[d]->cfg.device));
-                HIP_TRY(hipMemcpy2D(hs[d]->d_full_cloud + (long long)o * R * n + (a - (long long)o * n), sizeof(double) * n,
-                                    hs[o]->cl.buf[0] + (a - (long long)o * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
-                                    hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpy2DAsync(hs[d]->d_full_cloud + (long long)o * R * n + (a - (long long)o * n), sizeof(double) * n,
+                                         hs[o]->cl.buf[0] + (a - (long long)o * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
+                                         hipMemcpyDeviceToDevice, hs[d]->stream));
             }
-        return 0;
+        return sync_all();
     }
 };
 

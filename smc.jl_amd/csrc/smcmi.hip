@@ -124,6 +124,18 @@ static int push_model(smcmi_handle *h) {
 template <class T>
 static int dmalloc(T **p, size_t count) {
     HIP_TRY(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    // development (SMCMI_POISON_ALLOC=1): fresh device memory reads as NaN / -1, so a read of something never written shows up
+    // in every test instead of depending on what the allocator hands back
+    static const int poison = getenv("SMCMI_POISON_ALLOC") ? atoi(getenv("SMCMI_POISON_ALLOC")) : 0;
+    static const int plo = getenv("SMCMI_POISON_LO") ? atoi(getenv("SMCMI_POISON_LO")) : 0;               // (bisection: only allocations lo <= # < hi)
+    static const int phi = getenv("SMCMI_POISON_HI") ? atoi(getenv("SMCMI_POISON_HI")) : 1 << 30;
+    static int counter = 0;
+    const int idx = counter++;
+    if (poison && idx >= plo && idx < phi) {
+        HIP_TRY(hipMemset(*p, 0xFF, (count ? count : 1) * sizeof(T)));
+        HIP_TRY(hipDeviceSynchronize());        // (the fill runs on the null stream: it must not land after the handle's first copies)
+        if (poison > 1) fprintf(stderr, "[smcmi] poisoned allocation #%d (%zu bytes)\n", idx, (count ? count : 1) * sizeof(T));
+    }
     return 0;
 }
 static int err_from_state(int code) {
