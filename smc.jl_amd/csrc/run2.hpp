@@ -168,6 +168,7 @@ static int mbox_alloc(smcmi_handle *h) {
     // fine-grained: stores from a peer GPU and this GPU's polling loads meet in memory, not in a die's L2
     HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * MB_WORDS, hipDeviceMallocFinegrained));
     HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_WORDS));
+    HIP_TRY(hipDeviceSynchronize());              // (null-stream fill: not ordered with the handle's non-blocking stream)
     return 0;
 }
 static int mbox_set_peers(smcmi_handle *h, const std::vector<unsigned long long *> &peers) {
@@ -375,6 +376,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (getenv("SMCMI_PROF2") && !h0->e2->d_prof) {
         if (dmalloc(&h0->e2->d_prof, 128)) return SMCMI_ERR_HIP;
         HIP_TRY(hipMemset(h0->e2->d_prof, 0, 128 * sizeof(long long)));
+        HIP_TRY(hipDeviceSynchronize());
         h0->e2->prof_stage = atoi(getenv("SMCMI_PROF2"));
     }
     const Geo2 g0 = h0->e2->g;

@@ -383,6 +383,7 @@ extern "C" int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t fami
     }
     update_lik_prefix(h);
     if (which == 0) h->have_lik = true;
+    HIP_TRY(hipDeviceSynchronize());          // (the data / structure copies above ran on the null stream)
     return push_model(h);
 }
 
@@ -392,6 +393,7 @@ extern "C" int smcmi_upload_cloud(smcmi_handle *h, const double *particles) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (pull_state(h)) return SMCMI_ERR_HIP;
     HIP_TRY(hipMemcpy(h->cl.buf[h->h_st.cur], particles, sizeof(double) * h->n * h->R, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());          // (null-stream copy: not ordered with the handle's non-blocking stream)
     return 0;
 }
 extern "C" int smcmi_upload_cloud_device(smcmi_handle *h, const double *dev_particles) {
@@ -1328,6 +1330,7 @@ extern "C" int smcmi_set_stage_records(smcmi_handle *h, int32_t n_stages, const 
     if (c) HIP_TRY(hipMemcpy(h->rec.c, c, sizeof(double) * n_stages, hipMemcpyHostToDevice));
     if (accept) HIP_TRY(hipMemcpy(h->rec.accept, accept, sizeof(double) * n_stages, hipMemcpyHostToDevice));
     if (resampled) HIP_TRY(hipMemcpy(h->rec.resampled, resampled, sizeof(int) * n_stages, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 
@@ -1338,6 +1341,7 @@ extern "C" int smcmi_set_history(smcmi_handle *h, int32_t n_stages, const double
     const size_t bytes = sizeof(double) * (size_t)h->n * n_stages;
     if (w) HIP_TRY(hipMemcpy(h->d_hist_w, w, bytes, hipMemcpyHostToDevice));
     if (W) HIP_TRY(hipMemcpy(h->d_hist_W, W, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 
