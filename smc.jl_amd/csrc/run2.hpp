@@ -176,6 +176,7 @@ static int mbox_set_peers(smcmi_handle *h, const std::vector<unsigned long long 
     if (h->d_peers) { hipFree(h->d_peers); h->d_peers = nullptr; }
     HIP_TRY(hipMalloc((void **)&h->d_peers, sizeof(unsigned long long *) * peers.size()));
     HIP_TRY(hipMemcpy(h->d_peers, peers.data(), sizeof(unsigned long long *) * peers.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
     h->h_peers = peers;
     return 0;
 }
