@@ -117,7 +117,9 @@ static bool eng2_eligible(const smcmi_handle *h, int world) {
 // 125 000 particles per handle, but 52.7 vs 46.7 ms per run at 10⁶ on one handle); SMCMI_E2_NO_TAIL=1 keeps the launches
 static bool fused_tails(const Eng2 *e) {
     static const int no_tail = getenv("SMCMI_E2_NO_TAIL") ? atoi(getenv("SMCMI_E2_NO_TAIL")) : 0;
-    return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= 1024;
+    // (several handles: up to 2048 blocks - there the tails break even with the launches they replace, 138.5 vs 139.6 µs per stage at
+    // 500 000 particles per handle, and they are what lets the peer mailbox replace the all-gathers)
+    return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= (e->world > 1 ? 2048 : 1024);
 }
 template <int D>
 static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows, const Tail2 &tail) {
