@@ -15,7 +15,7 @@
 module SMCMI
 
 using ModelConstructors, Distributions, Random, Dates
-import JLD2, HDF5
+import JLD2, HDF5, LinearAlgebra
 
 export smc, Cloud, get_vals, get_loglh, get_logprior, get_old_loglh, get_logpost, get_accept, get_weights, weighted_mean, weighted_cov,
        weighted_std, cloud_isempty, GaussIso, LinReg, LinModel3, CapmLiteral, LGSSKalman
@@ -106,12 +106,11 @@ prior_code(d::InverseGamma) = (Int32(4), shape(d), scale(d))
 prior_code(d::ModelConstructors.RootInverseGamma) = (Int32(5), d.ν, d.τ)
 
 const RESAMPLER = Dict(:systematic => Int32(0), :multinomial => Int32(1), :polyalgo => Int32(1))
-const CALLBACK_ERRORS = (ParamBoundsError, LinearAlgebra.LAPACKException, LinearAlgebra.PosDefException,
+const CALLBACK_ERRORS = (ModelConstructors.ParamBoundsError, LinearAlgebra.LAPACKException, LinearAlgebra.PosDefException,
                          LinearAlgebra.SingularException, DomainError)          # the five the reference maps to -Inf (mutation.jl:112-121)
-import LinearAlgebra
 
 # ---- the closure as a batch callback: int (*)(const double *theta, int64_t m, int64_t d, double *out, void *user_data)
-struct CallbackEnv
+mutable struct CallbackEnv      # (mutable: pointer_from_objref needs an object with a stable address)
     f::Function
     parameters::ParameterVector
     data::Matrix{Float64}
