@@ -30,7 +30,7 @@ e = Engine(8192, 6, seed=1, n_local=4096, gid0=rank * 4096, max_stages=50, store
 e.set_model(models.gauss_spec(6))
 open(os.path.join(tmp, "h%%d.bin.tmp" %% rank), "wb").write(e.mailbox_export())
 os.rename(os.path.join(tmp, "h%%d.bin.tmp" %% rank), os.path.join(tmp, "h%%d.bin" %% rank))
-def wait(name, limit=120.0):
+def wait(name, limit=400.0):
     t0 = time.time()
     while not os.path.exists(os.path.join(tmp, name)):
         if time.time() - t0 > limit: raise SystemExit("timed out waiting for " + name)
@@ -57,7 +57,7 @@ def test_two_processes_exchange_rows_through_ipc_mapped_tables():
         outs = []
         for p in procs:
             try:
-                o, e = p.communicate(timeout=600)
+                o, e = p.communicate(timeout=900)
             except subprocess.TimeoutExpired:
                 for q in procs:
                     q.kill()
