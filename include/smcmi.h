@@ -32,7 +32,7 @@ extern "C" {
 
 enum { SMCMI_OK = 0, SMCMI_ERR_ARG = -1, SMCMI_ERR_HIP = -2, SMCMI_ERR_NAN_ESS = -3, SMCMI_ERR_POSDEF = -4,
        SMCMI_ERR_CAPACITY = -5, SMCMI_ERR_BRACKET = -6, SMCMI_ERR_UNSUPPORTED = -7, SMCMI_ERR_STATE = -8,
-       SMCMI_ERR_CALLBACK = -9 };
+       SMCMI_ERR_CALLBACK = -9, SMCMI_ERR_TIMEOUT = -10 };
 
 /* prior families: Distributions.jl / ModelConstructors priors reachable from `prior(parameters)` (src/mutation.jl:95) */
 enum { SMCMI_PRIOR_NORMAL = 0, SMCMI_PRIOR_UNIFORM = 1, SMCMI_PRIOR_GAMMA = 2, SMCMI_PRIOR_BETA = 3,

@@ -1,0 +1,102 @@
+// handle.hpp - the opaque handle of include/smcmi.h (one particle shard on one GPU) and engine 2's per-handle buffers.
+// Shared by the translation units of libsmcmi.so: smcmi.hip (C ABI, drivers, engine 1) and inst2.hip (the per-dimension
+// instantiations of the engine 2 / engine 3 kernels, compiled in parallel - one object per n_para).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smcmi.h"
+#include "devstate.hpp"
+#include "kernels.hpp"
+#include "stage2.hpp"
+
+using namespace smcmi;
+struct CallbackBuffers;            // pinned staging buffers of the host-likelihood path (callback.hpp)
+
+struct Eng2 {
+    Geo2 g{};
+    Ctl2 *d_ctl = nullptr;
+    double *rows_mut = nullptr, *rows_cm = nullptr, *csum = nullptr, *csum_full = nullptr, *rows_gm = nullptr, *rows_pass[2] = {nullptr, nullptr};
+    double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
+    long long *d_ranges = nullptr;
+    Prop2Glob *d_pre = nullptr;      // decision + proposal of the current stage (k2_prepare; large clouds / several handles)
+    int *d_tick = nullptr;           // ticket counters of the fused row totals (Tail2): [0, V) correction rows, [V, 2V) mutation rows
+    long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage
+    int prof_stage = 0;
+    int world = 0;
+    bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
+    int n_steps = 1, n_blocks = 1;
+};
+
+static const int ESUM_RED_ROWS = 128;         // rows left by the first level of the energy-sum reduction when there are very many blocks
+struct smcmi_handle {
+    smcmi_config cfg{};
+    int d = 0, R = 0, npairs = 0;
+    long long n = 0;                 // local particles
+    hipStream_t stream = nullptr;
+    CloudPtrs cl{};
+    DevState *d_st = nullptr;
+    DevState h_st{};
+    ModelDev *d_model = nullptr;
+    ModelDev h_model{};
+    bool have_params = false, have_lik = false;
+    double *d_data[2] = {nullptr, nullptr}, *d_aux[2] = {nullptr, nullptr};
+    Records rec{};
+    double *d_sched = nullptr;
+    int sched_len = 0;
+    // scratch
+    int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
+    size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
+    double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_wt = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
+    long long *d_anc = nullptr;
+    double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_emax_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;
+    long long comm_cap = 0;
+    double *d_hist_w = nullptr, *d_hist_W = nullptr;
+    std::vector<double> lik_host_data[2], lik_host_aux[2];   // host copies (lgss_kalman only): is the old vintage a prefix of the new one?
+    // peer mailbox of sharded engine-2 runs (stage2.hpp Mailbox): this handle's table, the peers' tables as mapped here
+    unsigned long long *d_mbox = nullptr;
+    unsigned long long **d_peers = nullptr;
+    std::vector<unsigned long long *> h_peers;
+    std::vector<void *> ipc_opened;           // peers' tables opened through hipIpcOpenMemHandle (closed with the handle)
+    bool mbox_ok = false;                     // RCCL driver: every rank mapped every table and the self-test passed everywhere
+    bool mbox_tried = false;
+    bool mbox_used = false;                   // the last engine-2 run of this handle handed its sums over through the mailbox
+    unsigned mbox_epoch = 0;
+    double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
+    int *d_mixpos = nullptr;
+    // host-callback split
+    double *d_prop = nullptr, *d_prop_lp = nullptr, *d_prop_q = nullptr, *d_lik_new = nullptr, *d_lik_old = nullptr;
+    int *d_acc_count = nullptr, *d_flag = nullptr;
+    double *d_cum_full = nullptr, *d_part_full = nullptr, *d_off_full = nullptr;
+    int nb_full = 0;
+    // sharded driver (sharded.hpp)
+    void *nccl = nullptr;
+    int rank = 0, world = 1;
+    double *d_tot_ess = nullptr, *d_tot_fin = nullptr, *d_tot_mom = nullptr, *d_tot_acc = nullptr, *d_full_w = nullptr, *d_full_cloud = nullptr;
+    int last_n_stages = 1;
+    int launch_nb = 1;
+    size_t zbuf_cap = 0;         // doubles allocated in d_zbuf (random numbers drawn ahead of the mutation, kernels.hpp RngAhead)
+    bool spec_stage = false;     // the enqueued stage takes the predicted ϕ_n without a certificate pass (W̃ goes to d_wt)
+    bool fused_cm = false;       // the enqueued stage ran k_correct_moments: the mutation kernel normalises the weights
+    bool rng_ahead = false;      // the enqueued stage's k_prepare_mutation fills d_zbuf and the mutation kernel reads it
+    bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
+    int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
+    bool launch_alpha1 = false;
+    long long *d_prof = nullptr;   // development only (smcmi_debug_time_kernel with which = 9 and SMCMI_PROF_MUT=1)
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_sig = 0;
+    Eng2 *e2 = nullptr;            // engine 2 (stage2.hpp / run2.hpp): rows, virtual-shard totals, Ctl2
+    // host likelihoods (callback.hpp)
+    smcmi_lik_callback cb[2] = {nullptr, nullptr};
+    void *cb_ud[2] = {nullptr, nullptr};
+    CallbackBuffers *cbuf = nullptr;
+    long long cb_calls = 0, cb_evals = 0;
+};

@@ -574,7 +574,7 @@ __device__ inline double energy_or_ninf(double like, double like_prev, double w,
 }
 
 // Largest energy of the live cloud per block -> emax_part[blockIdx.x] (run start; afterwards the mutation epilogue keeps it)
-__global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const DevState *st, double *emax_part) {
+static __global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const DevState *st, double *emax_part) {
     __shared__ double smem[TB / 64];
     const int R = cl.R, src = st->cur;
     const double *loglh = col(cl, src, R - 5), *old = col(cl, src, R - 3), *w = col(cl, src, R - 1);
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
 // A spec stage whose prediction could not be used (or failed verification) is resumed by the certificate-pass path: rebuild the
 // plain schedule-walk candidates in solver copy 0 from the loop scalars (ϕ_prop and j are only committed by post_write, so they
 // still are the values the stage started with; ESS_bar / g(ϕ_{n-1}) were stored by k_stage_begin).
-__global__ void k_solver_rearm(DevState *st, const double *sched) {
+static __global__ void k_solver_rearm(DevState *st, const double *sched) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Solver &S = st->sol[0];
     const int j = st->j, n_phi = st->rp.n_phi;
@@ -746,7 +746,7 @@ __global__ void k_solver_rearm(DevState *st, const double *sched) {
 }
 
 // decision of the last solver pass without a correction (stand-alone smcmi_solve_phi)
-__global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double *sched, const double *partials_prev, int nb_prev, int p) {
+static __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double *sched, const double *partials_prev, int nb_prev, int p) {
     __shared__ double scratch[TB];
     __shared__ double tot[2 * KC];
     __shared__ Solver S;
@@ -758,7 +758,7 @@ __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double
 // mutation's acceptance sums into cloud.accept, flip the cloud buffer after a resample, pick ϕ_n from the fixed
 // schedule or arm the adaptive solver with its first candidates (solver copy 0).
 constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
-__global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
+static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
                                                     int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
                                                     int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0) {
     __shared__ double scratch[BT];
@@ -1042,7 +1042,7 @@ __device__ inline int post_write(DevState *st, const Records &rec, const PostIn 
     return rs;
 }
 
-__global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double *partials, int nb, double *chunk_off,
+static __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double *partials, int nb, double *chunk_off,
                                                      Records rec, int sol_slot, CloudPtrs cl = CloudPtrs{}, double *cum = nullptr) {
     __shared__ double scratch[TB];
     __shared__ double s_tot[2];
@@ -1097,7 +1097,7 @@ __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double 
 // ------------------------------------------------------------------------------------------------ resampling
 // Inclusive scan of W̃/ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) in the block chunks of the
 // correction pass; chunk offsets come from k_post_correct.
-__global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevState *st, const double *chunk_off,
+static __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevState *st, const double *chunk_off,
                                                      double *cum, int force, int n_chunks) {
     __shared__ double s_tot[TB];
     if (!force && (st->done || !st->do_resample)) return;
@@ -1111,7 +1111,7 @@ __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevStat
 // round-off, clamps to the last index), then cloud.particles = particles[new_inds, :] and reset_weights!
 // (src/smc_main.jl:440-442): the thread copies its ancestor's R-1 columns into the other cloud buffer and sets W = 1.
 // full != nullptr: rows come from an all-gathered n_cum x R cloud (multi-GPU) and go to the current buffer.
-__global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevState *st, const double *cum, long long n_cum,
+static __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevState *st, const double *cum, long long n_cum,
                                                         long long slot0, long long n_parts_total, int method,
                                                         unsigned long long seed, unsigned stage, const double *offsets,
                                                         long long *anc, const double *full, int force, long long full_shard_n = 0,
@@ -1162,7 +1162,7 @@ __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevS
 // weights (cum = cumsum(weights ./ sum(weights)) over the n_src old particles) and written to rows [0, n_out) of `dst`
 // WITH their old weights (update_cloud! copies whole rows; the weights are only reset after the second resample, :322).
 // Systematic search range is start_ind:n_parts of the *output* length (resample.jl:54, quirk Q5) -> lim = min(n_out, n_src).
-__global__ void __launch_bounds__(TB) k_bridge_gather(CloudPtrs src, int src_buf, const double *cum, long long n_src,
+static __global__ void __launch_bounds__(TB) k_bridge_gather(CloudPtrs src, int src_buf, const double *cum, long long n_src,
                                                       CloudPtrs dst, int dst_buf, long long n_out, int method,
                                                       unsigned long long seed, unsigned stage, const double *offsets,
                                                       long long *anc) {
@@ -1190,14 +1190,14 @@ __global__ void __launch_bounds__(TB) k_bridge_gather(CloudPtrs src, int src_buf
 }
 
 // zero_bad_loglh_weights! (src/particle.jl:392-396): weight 0 where loglh == -Inf
-__global__ void __launch_bounds__(TB) k_zero_bad_weights(CloudPtrs cl, const DevState *st) {
+static __global__ void __launch_bounds__(TB) k_zero_bad_weights(CloudPtrs cl, const DevState *st) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     const int d = cl.R - 5;
     if (col(cl, st->cur, d)[i] == SMCMI_NEG_INF) col(cl, st->cur, cl.R - 1)[i] = 0.0;
 }
 // normalize_weights! (src/particle.jl:362-366): W *= n_parts, W /= sum(W); st->sumw holds the fixed-order sum
-__global__ void __launch_bounds__(TB) k_normalize_weights_n(CloudPtrs cl, const DevState *st, double n_parts) {
+static __global__ void __launch_bounds__(TB) k_normalize_weights_n(CloudPtrs cl, const DevState *st, double n_parts) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     double *w = col(cl, st->cur, cl.R - 1);
@@ -1207,7 +1207,7 @@ __global__ void __launch_bounds__(TB) k_normalize_weights_n(CloudPtrs cl, const 
 // Systematic resampling, sharded: ancestor (global row) of the first and of the last output slot of every shard r - the rows a
 // shard must receive form the contiguous range [out[2r], out[2r+1]] (thresholds ascend with the slot).  Same threshold and
 // upper_bound as k_resample_gather.  out[0] = -1 when this stage does not resample.  One wavefront, lane r = shard r.
-__global__ void k_anc_ranges(const DevState *st, const double *cum, long long N, long long n_local, int world, unsigned long long seed,
+static __global__ void k_anc_ranges(const DevState *st, const double *cum, long long N, long long n_local, int world, unsigned long long seed,
                              long long *out) {
     const int r = threadIdx.x;
     if (st->done || !st->do_resample) { if (r == 0) out[0] = -1; return; }
@@ -1232,7 +1232,7 @@ __global__ void k_anc_ranges(const DevState *st, const double *cum, long long N,
 // Σ w x̃ x̃ᵀ, x̃ = (1, θ - shift), from which weighted_mean / weighted_cov follow (src/particle.jl:481-483, 526-529).
 // Particles are staged through LDS in tiles so every (a,b) pair is accumulated from on-chip data.
 constexpr int MT = 256;                      // particles per LDS tile
-__global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, double *partials, double *hist_W,
+static __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, double *partials, double *hist_W,
                                                 long long hist_ld, int standalone) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (!standalone && st->done) return;
@@ -1430,7 +1430,7 @@ __global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, 
 
 // Fixed-order reduction of the moment partials: totals[p] for the (d+1)(d+2)/2 pairs, 1024 threads per block:
 // thread (s, idx) sums blocks b = s (mod 16) of pair p0 + idx; grid = ceil(npairs / 64).
-__global__ void __launch_bounds__(1024) k_moments_reduce(const DevState *st, const double *partials, int nb, int npairs,
+static __global__ void __launch_bounds__(1024) k_moments_reduce(const DevState *st, const double *partials, int nb, int npairs,
                                                          double *totals, int standalone) {
     __shared__ double scratch[1024];
     if (!standalone && st->done) return;
@@ -1468,7 +1468,7 @@ __device__ inline void moments_from_totals(DevState *st, const double *totals, i
     __syncthreads();
     for (int a = t; a < d; a += nt) st->shift[a] = st->mean[a];
 }
-__global__ void __launch_bounds__(64) k_finalize_moments(DevState *st, const double *totals, int d) {
+static __global__ void __launch_bounds__(64) k_finalize_moments(DevState *st, const double *totals, int d) {
     moments_from_totals(st, totals, d, threadIdx.x, 64);
 }
 
@@ -1481,11 +1481,11 @@ __device__ inline void emax_publish(const double *emax_part, int nb, double *ema
     em = block_max(em, smem, TB / 64);
     if ((int)threadIdx.x < world) emax_slots[threadIdx.x] = ((int)threadIdx.x == rank) ? fmax(em, -1e300) : 0.0;
 }
-__global__ void __launch_bounds__(TB) k_emax_publish(const double *emax_part, int nb, double *emax_slots, int rank, int world) {
+static __global__ void __launch_bounds__(TB) k_emax_publish(const double *emax_part, int nb, double *emax_slots, int rank, int world) {
     __shared__ double smem[TB / 64];
     emax_publish(emax_part, nb, emax_slots, rank, world, smem);
 }
-__global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, int nb, int m, double *out, const double *emax_part = nullptr,
+static __global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, int nb, int m, double *out, const double *emax_part = nullptr,
                                                         int emax_nb = 0, double *emax_slots = nullptr, int rank = 0, int world = 1) {
     __shared__ double scratch[TB];
     __shared__ double smem[TB / 64];
@@ -1501,7 +1501,7 @@ __global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, 
 
 // First level of a two-level row reduction for very many partial rows (N >= ~3e5: one row per 256 particles): block g totals the
 // rows of its contiguous chunk in fixed order -> out[g][m]; the consumer then totals gridDim.x rows instead of nb.
-__global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int nb, int m, double *out, const double *emax_in = nullptr,
+static __global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int nb, int m, double *out, const double *emax_in = nullptr,
                                                     double *emax_out = nullptr) {
     __shared__ double scratch[TB];
     __shared__ double smem[TB / 64];
@@ -1518,7 +1518,7 @@ __global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int 
 }
 
 // normalize_weights! as its own pass (src/particle.jl:362-366) for the stand-alone correction call
-__global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st) {
+static __global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     double *w = col(cl, st->cur, cl.R - 1);
@@ -1526,7 +1526,7 @@ __global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const De
 }
 
 // per-chunk weight sums in the layout k_post_correct / k_scan_weights expect (partials[2 b])
-__global__ void __launch_bounds__(TB) k_weight_chunk_sums(CloudPtrs cl, const DevState *st, double *partials) {
+static __global__ void __launch_bounds__(TB) k_weight_chunk_sums(CloudPtrs cl, const DevState *st, double *partials) {
     __shared__ double red[(TB / 64) * 2];
     const double *w = col(cl, st->cur, cl.R - 1);
     double acc[2] = {0.0, 0.0};
@@ -1536,13 +1536,13 @@ __global__ void __launch_bounds__(TB) k_weight_chunk_sums(CloudPtrs cl, const De
     const double tot = block_reduce_many<2>(acc, red);
     if (threadIdx.x < 2) partials[2 * (long long)blockIdx.x + threadIdx.x] = tot;
 }
-__global__ void k_chunk_offsets(DevState *st, const double *partials, int nb, double *chunk_off, double base,
+static __global__ void k_chunk_offsets(DevState *st, const double *partials, int nb, double *chunk_off, double base,
                                 int set_sum) {
     double run = base;
     for (int b = 0; b < nb; ++b) { chunk_off[b] = run; run += partials[2 * (long long)b]; }
     if (set_sum) st->sumw = run;
 }
-__global__ void k_flip(DevState *st) { st->cur ^= 1; }
+static __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 
 // θ_bar, R from the moment partials; free subset + symmetrisation (src/smc_main.jl:457-465); random blocks
 // (generate_free_blocks/all_blocks, src/helpers.jl:215-260, Fisher-Yates on Philox); then per block the scaled
@@ -1642,7 +1642,7 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
         }
 }
 
-__global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
+static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
                                                          int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}, int sol_slot = 0,
                                                          Records rec = Records{}) {
@@ -2544,7 +2544,7 @@ __global__ void __launch_bounds__(256, 3) k_mutate_reg(CloudPtrs cl, const DevSt
 // ------------------------------------------------------------------------------------------------ initial draw
 // initial_draw! / one_draw (src/initialization.jl:23-119): prior draws with bounds rejection, re-draw until the
 // log-likelihood is finite.  Normal / Uniform priors only (others: host draws + upload).
-__global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState *st, const ModelDev *md,
+static __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState *st, const ModelDev *md,
                                                    unsigned long long seed, long long gid0, int *fail_flag) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
@@ -2583,7 +2583,7 @@ __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState 
 
 // Prior draw of the particles whose attempt[i] >= 0 - the draws k_init_prior makes on outer attempt attempt[i] (same Philox tags, same
 // bounds redraws) - with the log-prior; the likelihood comes from the host (callback.hpp): initial_draw! with a user closure.
-__global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const ModelDev *md, unsigned long long seed, long long gid0, const int *attempt) {
+static __global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const ModelDev *md, unsigned long long seed, long long gid0, const int *attempt) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n || attempt[i] < 0) return;
     const int d = md->d;
@@ -2611,7 +2611,7 @@ __global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const ModelDev 
 
 // initialize_likelihoods! (src/initialization.jl:153-186): retire loglh to old_loglh, then evaluate the (new-data) likelihood
 // and the prior at every particle.  Out-of-bounds parameters give -Inf (the reference would throw ParamBoundsError here).
-__global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, const ModelDev *md) {
+static __global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, const ModelDev *md) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     const int d = md->d;
@@ -2626,9 +2626,9 @@ __global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, con
 }
 
 // empty kernel (event-overhead calibration, smcmi_run profile mode)
-__global__ void k_noop(const DevState *st) { (void)st; }
+static __global__ void k_noop(const DevState *st) { (void)st; }
 
-__global__ void k_fill(double *p, long long n, double v) {
+static __global__ void k_fill(double *p, long long n, double v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }

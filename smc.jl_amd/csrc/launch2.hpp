@@ -1,0 +1,60 @@
+// launch2.hpp - host launchers of the engine 2 kernels that are templates over n_para (stage2.hpp).  Each n_para is compiled in its
+// own translation unit (inst2.hip with -DSMCMI_INST_D=<d>), so the sixty-odd instantiations build in parallel; every other
+// translation unit sees the launchers as extern templates and instantiates none of the kernels.
+#pragma once
+#include "handle.hpp"
+
+template <int D>
+void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows, const Tail2 &tail) {
+    Eng2 *e = h->e2;
+    Rng2 ra{};
+    unsigned grid = (unsigned)(e->g.Vl * e->g.nb1);
+    if (e->rng_ahead) {              // extra blocks, one per mutation block, draw the stage's random numbers on the idle CUs
+        ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
+        grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
+    }
+    if (tail.tick) k2_correct<D, true><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
+    else k2_correct<D, false><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
+}
+template <int D>
+void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full) {
+    Eng2 *e = h->e2;
+    k2_gather<D><<<e->g.Vl * e->g.nbg, TB, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
+                                                          h->n, e->rows_gm);
+}
+template <int D>
+void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {
+    Eng2 *e = h->e2;
+    const size_t lds = k2_lds_bytes(D);
+    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
+    if (e->g.t2 == 512 && !ma.tail.tick) {             // the direct geometry (config 2): no hand-over code in the instantiation
+        if (alpha1) k2_mutate<D, true, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    } else if (e->g.t2 == 512) {
+        if (alpha1) k2_mutate<D, true, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    } else {
+        if (alpha1) k2_mutate<D, true, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        else k2_mutate<D, false, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+    }
+}
+template <int D>
+void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
+    Eng2 *e = h->e2;
+    k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, nb, h->h_model.n_free, e->d_pre);
+}
+
+#define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
+    X template void launch_k2_correct<D>(smcmi_handle *, int, int, int, const Rows2 &, const Tail2 &);                               \
+    X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *);                   \
+    X template void launch_k2_mutate<D>(smcmi_handle *, const Mut2Args &, int, bool);                                                \
+    X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);
+#ifdef SMCMI_INST_D
+SMCMI_LAUNCH2_INSTANCES(, SMCMI_INST_D)
+#else
+SMCMI_LAUNCH2_INSTANCES(extern, 1) SMCMI_LAUNCH2_INSTANCES(extern, 2) SMCMI_LAUNCH2_INSTANCES(extern, 3) SMCMI_LAUNCH2_INSTANCES(extern, 4)
+SMCMI_LAUNCH2_INSTANCES(extern, 5) SMCMI_LAUNCH2_INSTANCES(extern, 6) SMCMI_LAUNCH2_INSTANCES(extern, 7) SMCMI_LAUNCH2_INSTANCES(extern, 8)
+SMCMI_LAUNCH2_INSTANCES(extern, 9) SMCMI_LAUNCH2_INSTANCES(extern, 10)
+#endif

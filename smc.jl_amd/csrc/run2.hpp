@@ -11,20 +11,6 @@
 #pragma once
 #include <map>
 
-struct Eng2 {
-    Geo2 g{};
-    Ctl2 *d_ctl = nullptr;
-    double *rows_mut = nullptr, *rows_cm = nullptr, *csum = nullptr, *csum_full = nullptr, *rows_gm = nullptr, *rows_pass[2] = {nullptr, nullptr};
-    double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
-    long long *d_ranges = nullptr;
-    Prop2Glob *d_pre = nullptr;      // decision + proposal of the current stage (k2_prepare; large clouds / several handles)
-    int *d_tick = nullptr;           // ticket counters of the fused row totals (Tail2): [0, V) correction rows, [V, 2V) mutation rows
-    long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage
-    int prof_stage = 0;
-    int world = 0;
-    bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
-    int n_steps = 1, n_blocks = 1;
-};
 
 static void free_eng2(Eng2 *e) {
     if (!e) return;
@@ -121,42 +107,6 @@ static bool fused_tails(const Eng2 *e) {
     // 500 000 particles per handle, and they are what lets the peer mailbox replace the all-gathers)
     return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= (e->world > 1 ? 2048 : 1024);
 }
-template <int D>
-static void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows, const Tail2 &tail) {
-    Eng2 *e = h->e2;
-    Rng2 ra{};
-    unsigned grid = (unsigned)(e->g.Vl * e->g.nb1);
-    if (e->rng_ahead) {              // extra blocks, one per mutation block, draw the stage's random numbers on the idle CUs
-        ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
-        grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
-    }
-    if (tail.tick) k2_correct<D, true><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
-                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
-    else k2_correct<D, false><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
-                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
-}
-template <int D>
-static void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full) {
-    Eng2 *e = h->e2;
-    k2_gather<D><<<e->g.Vl * e->g.nbg, TB, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
-                                                          h->n, e->rows_gm);
-}
-template <int D>
-static void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {
-    Eng2 *e = h->e2;
-    const size_t lds = k2_lds_bytes(D);
-    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
-    if (e->g.t2 == 512 && !ma.tail.tick) {             // the direct geometry (config 2): no hand-over code in the instantiation
-        if (alpha1) k2_mutate<D, true, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-        else k2_mutate<D, false, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-    } else if (e->g.t2 == 512) {
-        if (alpha1) k2_mutate<D, true, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-        else k2_mutate<D, false, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-    } else {
-        if (alpha1) k2_mutate<D, true, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-        else k2_mutate<D, false, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-    }
-}
 #define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
     switch (d) {                                                                                                                          \
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
@@ -164,12 +114,21 @@ static void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool a
     }
 
 // ---- peer mailbox (stage2.hpp): allocation and the table of peer addresses
+// clear the sticky time-out flag and (re)load the time-out (SMCMI_MAILBOX_TIMEOUT_MS, default 10 s; read at every run)
+static int mbox_reset_flag(smcmi_handle *h, hipStream_t s) {
+    const char *ms = getenv("SMCMI_MAILBOX_TIMEOUT_MS");
+    const unsigned long long fl[MB_FLAG_WORDS] = {0ull, ms && atof(ms) > 0.0 ? (unsigned long long)(atof(ms) * 1e5) : (unsigned long long)MB_TIMEOUT_TICKS_DEFAULT};
+    if (s) { HIP_TRY(hipMemcpyAsync(h->d_mbox + MB_WORDS, fl, sizeof(fl), hipMemcpyHostToDevice, s)); HIP_TRY(hipStreamSynchronize(s)); }
+    else HIP_TRY(hipMemcpy(h->d_mbox + MB_WORDS, fl, sizeof(fl), hipMemcpyHostToDevice));
+    return 0;
+}
 static int mbox_alloc(smcmi_handle *h) {
     if (h->d_mbox) return 0;
     HIP_TRY(hipSetDevice(h->cfg.device));
     // fine-grained: stores from a peer GPU and this GPU's polling loads meet in memory, not in a die's L2
-    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * MB_WORDS, hipDeviceMallocFinegrained));
+    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * (MB_WORDS + MB_FLAG_WORDS), hipDeviceMallocFinegrained));
     HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_WORDS));
+    if (int e = mbox_reset_flag(h, nullptr)) return e;
     HIP_TRY(hipDeviceSynchronize());              // (null-stream fill: not ordered with the handle's non-blocking stream)
     return 0;
 }
@@ -195,7 +154,7 @@ static int mbox_setup_group(ShardGroup &g) {
 }
 // ---- peer mailbox across processes: HIP IPC handles of the tables, exchanged by the caller or through the communicator
 // One block: `rounds` exchanges of a (rank, round)-dependent row with every peer over the real transport; errs += mismatches / time-outs.
-__global__ void k_mbox_selftest(unsigned long long *const *peers, const unsigned long long *mine, int world, int rank, int rounds, int *errs) {
+static __global__ void k_mbox_selftest(unsigned long long *const *peers, const unsigned long long *mine, int world, int rank, int rounds, int *errs) {
     const int t = threadIdx.x;
     int bad = 0;
     for (int q = 0; q < rounds; ++q) {
@@ -205,7 +164,7 @@ __global__ void k_mbox_selftest(unsigned long long *const *peers, const unsigned
             for (int r = 0; r < world; ++r) mb_store(peers[r] + table + ((long long)rank * MB_LD + t) * 2, 1000.0 * rank + q + t / 16.0, tag);
         for (int idx = t; idx < world * 16; idx += blockDim.x) {
             const int r = idx / 16, k = idx % 16;
-            const double x = mb_load(mine + table + ((long long)r * MB_LD + k) * 2, tag);
+            const double x = mb_load(mine + table + ((long long)r * MB_LD + k) * 2, tag, const_cast<unsigned long long *>(mine) + MB_WORDS);
             if (!(x == 1000.0 * r + q + k / 16.0)) ++bad;
         }
         __syncthreads();                     // (a rank re-uses a table two rounds later: only after it has read it)
@@ -405,14 +364,14 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             h->mbox_used = true;
             h->mbox_epoch += 1;
             HIP_TRY(hipMemsetAsync(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_WORDS, h->stream));
-            const int zero = 0;
-            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mb_timed_out), &zero, sizeof(int), 0, hipMemcpyHostToDevice, h->stream));
+            if (int e = mbox_reset_flag(h, h->stream)) return e;
         }
         if (int e = g.barrier()) return e;            // nobody posts before every table is cleared
     }
     auto mb_rows = [&](smcmi_handle *h, int kind, const double *vt, int m) {
         Rows2 r{vt, g0.V, 1, m};
         r.mb = h->d_mbox + mbox_table(kind, mb_cnt[kind]);
+        r.to = h->d_mbox + MB_WORDS;
         r.tag = mbox_tag(h->mbox_epoch, mb_cnt[kind]);
         return r;
     };
@@ -558,7 +517,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             if (!inker) {                // decision + proposal once, by one block
                 Mut2Args mp = ma;
                 mp.pre = nullptr;
-#define SMCMI_CALL(D) k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, rc->n_blocks, h->h_model.n_free, e->d_pre)
+#define SMCMI_CALL(D) launch_k2_prepare<D>(h, mp, rc->n_blocks)
                 SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
             }
@@ -777,6 +736,17 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
     res->paused = (s.done == 5) ? 1 : 0;
+    if (mbox) {
+        // a hand-over that timed out poisoned the sums with NaN: report THAT, not the NaN-ESS message the poisoned sums lead to
+        unsigned long long timed_out = 0;
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        HIP_TRY(hipMemcpy(&timed_out, h0->d_mbox + MB_WORDS, sizeof(timed_out), hipMemcpyDeviceToHost));
+        if (timed_out) {
+            for (auto *h : g.hs) { h->mbox_ok = false; h->mbox_tried = true; }        // later runs of these handles use the all-gathers
+            return set_err(SMCMI_ERR_TIMEOUT, "peer mailbox: a rank's per-stage sums did not arrive within the time-out (SMCMI_MAILBOX_TIMEOUT_MS); "
+                                              "the run is void - repeat it (this handle now uses the all-gathers; SMCMI_MAILBOX=0 does so from the start)");
+        }
+    }
     if (s.err == SMCMI_ERR_NAN_ESS) return nan_ess_error(h0, h0->d_wt);
     if (s.err) return err_from_state(s.err);
     if (!(c.status.code == 1 || c.status.code == 5)) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");

@@ -64,6 +64,7 @@ struct Rows2 {                    // rows[(v * nr + r) * ld + idx], v < nvs, r <
     int nvs, nr, ld;
     const unsigned long long *mb; // non-null: the V x m totals arrive in this handle's mailbox table (Mailbox2 below) under `tag`
     unsigned tag;
+    unsigned long long *to;       // the mailbox's time-out flag words (mb_load)
 };
 
 // ------------------------------------------------------------------------------------------------ peer mailbox (several GPUs)
@@ -79,25 +80,28 @@ constexpr int MB_LD = 72;                                      // row capacity i
 constexpr int MB_TABLE_WORDS = V2_MAXV * MB_LD * 2;            // words of one (kind, parity) table
 constexpr int MB_KINDS = 2;                                    // 0: correction rows, 1: mutation rows
 constexpr int MB_WORDS = MB_KINDS * 2 * MB_TABLE_WORDS;        // a handle's whole mailbox
-constexpr long long MB_TIMEOUT_TICKS = 100000000ll;            // ~1 s of the 100 MHz wall clock: a peer that never posts poisons the totals with NaN
+constexpr long long MB_TIMEOUT_TICKS_DEFAULT = 1000000000ll;    // ~10 s of the 100 MHz wall clock (SMCMI_MAILBOX_TIMEOUT_MS): a peer that never posts
+                                                               // poisons the totals with NaN and raises the handle's time-out flag, which the
+                                                               // driver turns into SMCMI_ERR_TIMEOUT (never into a "no particles" message)
+constexpr int MB_FLAG_WORDS = 2;                               // behind the tables: word MB_WORDS = sticky time-out flag, MB_WORDS + 1 = time-out in ticks
 __device__ inline void mb_store(unsigned long long *w, double v, unsigned tag) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(w + 1, ((unsigned long long)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ int g_mb_timed_out = 0;          // sticky: after the first time-out every wait gives up at once (the run ends with NaN sums)
-__device__ inline double mb_load(const unsigned long long *w, unsigned tag) {
+// to: the handle's flag words (MB_FLAG_WORDS).  to[0] is sticky: after the first time-out every wait gives up at once
+__device__ inline double mb_load(const unsigned long long *w, unsigned tag, unsigned long long *to) {
     unsigned long long a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned long long b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag) {
         const long long t0 = wall_clock64();
         do {
-            if (__hip_atomic_load(&g_mb_timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return __builtin_nan("");
+            if (__hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return __builtin_nan("");
             __builtin_amdgcn_s_sleep(2);
             a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (wall_clock64() - t0 > MB_TIMEOUT_TICKS) {
-                __hip_atomic_store(&g_mb_timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wall_clock64() - t0 > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return __builtin_nan("");
             }
         } while ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag);
@@ -110,7 +114,7 @@ template <int M, int T>
 __device__ inline void mbox_totals(const Rows2 &R, double *vt, double *tot, int max_idx) {
     for (int idx = threadIdx.x; idx < R.nvs * M; idx += T) {
         const int v = idx / M, k = idx % M;
-        vt[idx] = mb_load(R.mb + ((long long)v * MB_LD + k) * 2, R.tag);
+        vt[idx] = mb_load(R.mb + ((long long)v * MB_LD + k) * 2, R.tag, R.to);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < M; k += T) {
@@ -319,7 +323,7 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
     }
     if ((int)threadIdx.x < m) out_v[threadIdx.x] = run;
 }
-__global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
+static __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
     const int v = blockIdx.x;
     reduce_vshard<RT>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
 }
@@ -415,7 +419,7 @@ __device__ inline void vchunk(const Geo2 &g, int vl, int r, long long per, long 
 // ------------------------------------------------------------------------------------------------ state import / export
 // Engine 2 keeps its loop state in Ctl2; the C ABI's stand-alone calls, pause / continue and the result read DevState.  One
 // thread copies one into the other at the start / end of a run.
-__global__ void k2_import(const DevState *st, Ctl2 *ctl) {
+static __global__ void k2_import(const DevState *st, Ctl2 *ctl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl2 c;
     memset(&c, 0, sizeof(c));
@@ -430,7 +434,7 @@ __global__ void k2_import(const DevState *st, Ctl2 *ctl) {
     c.status.solver_passes = st->solver_passes;
     *ctl = c;
 }
-__global__ void k2_export(DevState *st, const Ctl2 *ctl) {
+static __global__ void k2_export(DevState *st, const Ctl2 *ctl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const Post2 &p = ctl->ps[0].stage >= ctl->ps[1].stage ? ctl->ps[0] : ctl->ps[1];
     const Status2 &s = ctl->status;
@@ -446,7 +450,7 @@ __global__ void k2_export(DevState *st, const Ctl2 *ctl) {
 }
 
 // largest energy of the live cloud per mutation block -> rows_mut[b][RMAX_IDX] (run start; afterwards the mutation epilogue)
-__global__ void __launch_bounds__(512) k2_energy_max(CloudPtrs cl, Geo2 g, double *rows_mut) {
+static __global__ void __launch_bounds__(512) k2_energy_max(CloudPtrs cl, Geo2 g, double *rows_mut) {
     __shared__ double smem[8];
     const int vl = blockIdx.x / g.nb2, r = blockIdx.x % g.nb2;
     long long beg, end;
@@ -624,7 +628,7 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
 }
 
 // stage begin as its own launch (certificate path: the solver is armed in DevState::sol[0]); 1 block
-__global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, int n, Rows2 mrows, const double *sched, Records rec, int spec_expected = 0) {
+static __global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, int n, Rows2 mrows, const double *sched, Records rec, int spec_expected = 0) {
     __shared__ Post2 s_po;
     __shared__ Begin2 s_bg;
     __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[RMUT], s_sw[64];
@@ -662,7 +666,7 @@ __device__ inline void solver_prologue2(DevState *st, const double *sched, const
     if (blockIdx.x == 0 && t < NW && *s_flag != 2) reinterpret_cast<double *>(&st->sol[p & 1])[t] = reinterpret_cast<const double *>(S)[t];
 }
 
-__global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int p, Rows2 prev, const double *sched,
+static __global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int p, Rows2 prev, const double *sched,
                                               double *rows_out) {
     constexpr int K = KC;
     __shared__ double red[(T1 / 64) * 2 * K];
@@ -701,7 +705,7 @@ __global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st, Ctl2 *
 
 // decision of the last enqueued pass: ϕ_n certified -> Begin2 becomes final; otherwise the stage stalls (code 2) until the host
 // enqueues more passes (which continue the same search from solver copy (P-1)&1 and its rows).  1 block.
-__global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, int n, int P, Rows2 prev, const double *sched) {
+static __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, int n, int P, Rows2 prev, const double *sched) {
     __shared__ double s_vt[V2_MAXV * 2 * KC * 2], s_tot[2 * KC], s_srt[KC];
     __shared__ Solver S;
     __shared__ int s_flag;
@@ -915,7 +919,7 @@ __device__ inline int decide2(const Begin2 &bg, double threshold, double phi_rto
 // Inclusive scan of W̃ / ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) over the WHOLE cloud (sharded runs hand in the
 // all-gathered W̃ and chunk sums) in the correction's chunks: one block per chunk, chunk offsets = running sum of the chunk sums
 // in chunk order.  Does nothing unless this stage resamples (the decision is re-derived from the correction rows).
-__global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
+static __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
                                               const double *csum_full, double *cum) {
     __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2], scratch[TB], s_off[4 * TB];
     __shared__ Begin2 s_bg;
@@ -971,7 +975,7 @@ __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo
 
 // Systematic resampling, sharded: ancestor (global row) of the first and of the last output slot of every handle r - the rows a
 // handle must receive form the contiguous range [out[2r], out[2r+1]].  out[0] = -1 when this stage does not resample.
-__global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows, const double *cum, long long N, long long n_local, int world,
+static __global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows, const double *cum, long long N, long long n_local, int world,
                               unsigned long long seed, long long *out) {
     __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
     const int r = threadIdx.x;
