@@ -230,6 +230,24 @@ int smcmi_sync(smcmi_handle *h);
 int smcmi_comm_unique_id(uint8_t *id_out /* 128 bytes */);
 int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *id);
 int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
+/* Host-mediated communicator: the collectives of smcmi_run_sharded carried by caller-supplied functions on HOST buffers of doubles -
+   whatever transport the host already has (MPI, torch.distributed / gloo, Julia's Distributed) - instead of RCCL.  Meant for ranks
+   that share one GPU or have no RCCL (multi-process tests on one box, bring-up); the reference's counterpart is the serialisation
+   `@distributed` does per stage (src/smc_main.jl:472-476).  Semantics (all blocking, called on the thread that called smcmi_run_sharded,
+   same sequence on every rank; return 0 on success):
+     allgather : recv[r * count .. (r+1) * count) = rank r's send[0 .. count)
+     alltoallv : send[send_displs[p] .. + send_counts[p]) goes to rank p, recv[recv_displs[p] .. + recv_counts[p]) comes from rank p
+                 (counts in doubles; the own rank's counts are 0).  May be NULL: resample stages then all-gather the shard clouds.
+     barrier   : returns once every rank has called it
+   The peer mailbox (below) works with this communicator as with RCCL: the tables' IPC handles travel through allgather. */
+typedef struct {
+    int (*allgather)(const double *send, double *recv, int64_t count, void *user);
+    int (*alltoallv)(const double *send, const int64_t *send_counts, const int64_t *send_displs, double *recv,
+                     const int64_t *recv_counts, const int64_t *recv_displs, void *user);
+    int (*barrier)(void *user);
+    void *user;
+} smcmi_host_comm;
+int smcmi_comm_init_host(smcmi_handle *h, int32_t rank, int32_t world, const smcmi_host_comm *comm);
 /* Peer mailbox (n_para <= 10, at most 8 handles): the two per-stage hand-overs of a sharded run (correction sums, mutation sums:
    8 x 70 and 8 x 34 doubles) written straight into every peer's fine-grained table over xGMI instead of two all-gathers.
    smcmi_run_sharded sets it up by itself on its first call - it exchanges the tables' IPC handles through the communicator, runs

@@ -5,7 +5,7 @@ Contents: csrc/ (HIP kernels + C ABI -> libsmcmi.so), host/ (ctypes binding and 
 reference's `smc(...)` / `Cloud` interface), julia/ (the ccall shim a Julia user loads).
 """
 from .host import _lib  # noqa: F401
-from .host.engine import Engine, comm_unique_id, run_group  # noqa: F401
+from .host.engine import Engine, comm_unique_id, run_group, torch_dist_host_comm  # noqa: F401
 from .host.api import (Beta, CapmLiteral, LGSSKalman, Cloud, Gamma, GaussIso, InverseGamma, LinModel3, LinReg, Normal, Parameter,  # noqa: F401
                        RootInverseGamma, Uniform, cloud_isempty, get_accept, get_loglh, get_logpost, get_logprior,
                        get_old_loglh, get_vals, get_weights, parameter, smc, weighted_cov, weighted_mean, weighted_std, flatten_regimes, regime_values,

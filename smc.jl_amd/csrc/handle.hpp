@@ -80,6 +80,9 @@ struct smcmi_handle {
     // sharded driver (sharded.hpp)
     void *nccl = nullptr;
     int rank = 0, world = 1;
+    smcmi_host_comm hostc{};         // host-mediated communicator (smcmi_comm_init_host) and its staging buffers
+    bool has_hostc = false;
+    std::vector<double> hc_send, hc_recv;
     double *d_tot_ess = nullptr, *d_tot_fin = nullptr, *d_tot_mom = nullptr, *d_tot_acc = nullptr, *d_full_w = nullptr, *d_full_cloud = nullptr;
     int last_n_stages = 1;
     int launch_nb = 1;

@@ -220,9 +220,11 @@ static int mbox_selftest(smcmi_handle *h, int world, int rank, int rounds, int *
     *errs_out = e;
     return 0;
 }
-// RCCL driver: map every rank's table through the communicator and test the transport; all ranks reach the same verdict
-// (h->mbox_ok) - anything short of a clean self-test on every rank leaves the all-gathers in place.
-static int mbox_setup_rccl(smcmi_handle *h) {
+// One handle per process (RCCL or the host-mediated communicator): map every rank's table through the communicator and test the
+// transport; all ranks reach the same verdict (h->mbox_ok) - anything short of a clean self-test on every rank leaves the all-gathers
+// in place.
+static int mbox_setup_remote(ShardGroup &g) {
+    smcmi_handle *h = g.hs[0];
     if (h->mbox_tried) return 0;
     h->mbox_tried = true; h->mbox_ok = false;
     if (h->world > V2_MAXV) return 0;
@@ -234,7 +236,7 @@ static int mbox_setup_rccl(smcmi_handle *h) {
     HIP_TRY(hipMalloc((void **)&d_send, 64));
     HIP_TRY(hipMalloc((void **)&d_recv, 64 * (size_t)world));
     HIP_TRY(hipMemcpyAsync(d_send, mine, 64, hipMemcpyHostToDevice, h->stream));
-    NCCL_TRY(g_rccl.AllGather(d_send, d_recv, (size_t)8, SMCMI_NCCL_DOUBLE, h->nccl, h->stream));      // 64 bytes = 8 doubles per rank
+    if (int e = g.allgather([=](smcmi_handle *) { return (const double *)d_send; }, [=](smcmi_handle *) { return d_recv; }, (size_t)8)) return e;   // 64 bytes = 8 doubles per rank
     std::vector<uint8_t> all(64 * (size_t)world);
     HIP_TRY(hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -242,7 +244,7 @@ static int mbox_setup_rccl(smcmi_handle *h) {
     if (fail == 0.0 && mbox_import(h, world, rank, all.data())) fail = 1.0;
     auto agree = [&](double mine_bad, double *total) -> int {           // sum of the ranks' failure counts
         HIP_TRY(hipMemcpyAsync(h->d_comm, &mine_bad, sizeof(double), hipMemcpyHostToDevice, h->stream));
-        NCCL_TRY(g_rccl.AllReduce(h->d_comm, h->d_comm, (size_t)1, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
+        if (int e = g.allreduce([](smcmi_handle *hh) { return hh->d_comm; }, 1)) return e;
         HIP_TRY(hipMemcpyAsync(total, h->d_comm, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         return 0;
@@ -351,7 +353,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     const int want = getenv("SMCMI_MAILBOX") ? atoi(getenv("SMCMI_MAILBOX")) : -1;                 // -1: default; 2: also with one rank (tests)
     for (auto *h : g.hs) h->mbox_used = false;
     if ((multi || (g.rccl && want == 2)) && fused_tails(h0->e2)) {
-        if (g.rccl) { if (want != 0) { if (int e = mbox_setup_rccl(h0)) return e; } mbox = h0->mbox_ok && want != 0; }
+        if (g.rccl) { if (want != 0) { if (int e = mbox_setup_remote(g)) return e; } mbox = h0->mbox_ok && want != 0; }
         else if (want == 1) { if (int e = mbox_setup_group(g)) return e; mbox = true; }
     }
     unsigned mb_cnt[MB_KINDS] = {0, 0};               // counter (-> tag, parity) of the post the next consumer of that kind reads
@@ -465,7 +467,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->e2->csum; }, [](smcmi_handle *h) { return h->e2->csum_full; },
                                 (size_t)g0.Vl * g0.nb1)) return e;
         static const char *xchg = getenv("SMCMI_RESAMPLE_EXCHANGE");
-        const bool a2a = !(xchg && !strcmp(xchg, "allgather")) && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC;
+        const bool a2a = !(xchg && !strcmp(xchg, "allgather")) && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC && !(g.hostc && !h0->hostc.alltoallv);
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             Eng2 *e = h->e2;

@@ -96,6 +96,36 @@ extern "C" int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, con
     return 0;
 }
 
+// ---- host-mediated communicator (include/smcmi.h smcmi_host_comm): the same collectives carried by caller-supplied functions on host
+// buffers - for ranks that share a GPU or have no RCCL (the multi-process tests on one GPU, bring-up behind MPI / gloo / Distributed.jl).
+// Every collective is: stream sync -> device-to-host -> callback -> host-to-device on the handle's stream -> sync, so kernels enqueued
+// behind it see its result exactly as they see an in-stream RCCL collective's.
+extern "C" int smcmi_comm_init_host(smcmi_handle *h, int32_t rank, int32_t world, const smcmi_host_comm *comm) {
+    if (!h || !comm || !comm->allgather || !comm->barrier || world < 1 || rank < 0 || rank >= world) return set_err(SMCMI_ERR_ARG, "bad argument");
+    if (h->cfg.n_local * world != h->cfg.n_parts || h->cfg.gid0 != rank * h->cfg.n_local)
+        return set_err(SMCMI_ERR_ARG, "handle shard (n_local, gid0) does not match (rank, world): equal contiguous shards are required");
+    if (h->nccl) smcmi_comm_release(h);
+    h->hostc = *comm; h->has_hostc = true; h->rank = rank; h->world = world;
+    h->mbox_tried = false; h->mbox_ok = false;
+    // self-test, as smcmi_comm_init: every rank contributes (1, rank)
+    const double mine[2] = {1.0, (double)rank};
+    std::vector<double> all(2 * (size_t)world, 0.0);
+    if (comm->allgather(mine, all.data(), 2, comm->user)) return set_err(SMCMI_ERR_CALLBACK, "host communicator: allgather failed");
+    for (int r = 0; r < world; ++r)
+        if (all[2 * r] != 1.0 || all[2 * r + 1] != (double)r) return set_err(SMCMI_ERR_CALLBACK, "host communicator: allgather self-test failed (rank order?)");
+    return 0;
+}
+static int hostc_allgather(smcmi_handle *h, const double *dsend, double *drecv, size_t count) {
+    std::vector<double> &sb = h->hc_send, &rb = h->hc_recv;
+    sb.resize(count); rb.resize(count * (size_t)h->world);
+    HIP_TRY(hipMemcpyAsync(sb.data(), dsend, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->hostc.allgather(sb.data(), rb.data(), (int64_t)count, h->hostc.user)) return set_err(SMCMI_ERR_CALLBACK, "host communicator: allgather failed");
+    HIP_TRY(hipMemcpyAsync(drecv, rb.data(), sizeof(double) * rb.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 constexpr int MAX_SHARDS = 64;     // slots for the per-shard energy maxima behind the all-reduced epilogue row
 static inline int shard_rank(const smcmi_handle *h) { return (int)(h->cfg.gid0 / h->cfg.n_local); }
 
@@ -103,7 +133,8 @@ static inline int shard_rank(const smcmi_handle *h) { return (int)(h->cfg.gid0 /
 struct ShardGroup {
     std::vector<smcmi_handle *> hs;   // local shards (same process); RCCL mode: exactly one
     int world = 1;                    // total number of shards
-    bool rccl = false;
+    bool rccl = false;                // one local handle, the other shards in other processes ("remote")
+    bool hostc = false;               // remote through the handle's host-mediated communicator instead of RCCL
 
     int sync_all() {
         for (auto *h : hs) { HIP_TRY(hipSetDevice(h->cfg.device)); HIP_TRY(hipStreamSynchronize(h->stream)); }
@@ -112,6 +143,20 @@ struct ShardGroup {
     // in-place sum of `count` doubles at buf(h) over all shards, same result everywhere (fixed shard order)
     template <class F>
     int allreduce(F buf, int count) {
+        if (rccl && hostc) {          // all-gather, then the sum in rank order (the same bits on every rank)
+            smcmi_handle *h = hs[0];
+            double *tmp = nullptr;
+            HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * (size_t)count * world));
+            int rc = hostc_allgather(h, buf(h), tmp, (size_t)count);
+            hipFree(tmp);
+            if (rc) return rc;
+            std::vector<double> tot(count, 0.0);
+            for (int r = 0; r < world; ++r)
+                for (int k = 0; k < count; ++k) tot[k] += h->hc_recv[(size_t)r * count + k];
+            HIP_TRY(hipMemcpyAsync(buf(h), tot.data(), sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            return 0;
+        }
         if (rccl) {
             smcmi_handle *h = hs[0];
             NCCL_TRY(g_rccl.AllReduce(buf(h), buf(h), (size_t)count, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
@@ -133,6 +178,12 @@ struct ShardGroup {
     }
     // every handle's stream has reached this point before any goes on (RCCL: an in-stream all-reduce of one double)
     int barrier() {
+        if (rccl && hostc) {
+            smcmi_handle *h = hs[0];
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->hostc.barrier(h->hostc.user)) return set_err(SMCMI_ERR_CALLBACK, "host communicator: barrier failed");
+            return 0;
+        }
         if (rccl) {
             smcmi_handle *h = hs[0];
             NCCL_TRY(g_rccl.AllReduce(h->d_comm, h->d_comm, (size_t)1, SMCMI_NCCL_DOUBLE, SMCMI_NCCL_SUM, h->nccl, h->stream));
@@ -143,6 +194,7 @@ struct ShardGroup {
     // recv(h)[r * count .. (r+1) * count) = send(shard r)
     template <class FS, class FR>
     int allgather(FS send, FR recv, size_t count) {
+        if (rccl && hostc) return hostc_allgather(hs[0], send(hs[0]), recv(hs[0]), count);
         if (rccl) {
             smcmi_handle *h = hs[0];
             NCCL_TRY(g_rccl.AllGather(send(h), recv(h), count, SMCMI_NCCL_DOUBLE, h->nccl, h->stream));
@@ -171,6 +223,45 @@ struct ShardGroup {
             b = std::min(ranges[2 * needer + 1] + 1, (long long)(owner + 1) * n);
             return b > a;
         };
+        if (rccl && hostc) {
+            // all-to-all-v on host buffers: per peer one [R][rows] block, packed from / unpacked into the column-major device layouts
+            smcmi_handle *h = hs[0];
+            const int me = h->rank;
+            if (!h->hostc.alltoallv) return set_err(SMCMI_ERR_UNSUPPORTED, "host communicator lacks alltoallv (SMCMI_RESAMPLE_EXCHANGE=allgather avoids it)");
+            std::vector<int64_t> sc(world, 0), sd(world, 0), rcnt(world, 0), rd(world, 0);
+            std::vector<long long> sa(world, 0), ra(world, 0);
+            int64_t stot = 0, rtot = 0;
+            for (int p = 0; p < world; ++p) {
+                long long a, b;
+                if (p != me && overlap(p, me, a, b)) { sc[p] = (b - a) * R; sa[p] = a - (long long)me * n; }
+                if (p != me && overlap(me, p, a, b)) { rcnt[p] = (b - a) * R; ra[p] = a - (long long)p * n; }
+                sd[p] = stot; stot += sc[p];
+                rd[p] = rtot; rtot += rcnt[p];
+            }
+            std::vector<double> sbuf((size_t)std::max<int64_t>(stot, 1)), rbuf((size_t)std::max<int64_t>(rtot, 1));
+            for (int p = 0; p < world; ++p)
+                if (sc[p]) {
+                    const long long len = sc[p] / R;
+                    HIP_TRY(hipMemcpy2DAsync(sbuf.data() + sd[p], sizeof(double) * len, h->cl.buf[0] + sa[p], sizeof(double) * n, sizeof(double) * (size_t)len, (size_t)R,
+                                             hipMemcpyDeviceToHost, h->stream));
+                }
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->hostc.alltoallv(sbuf.data(), sc.data(), sd.data(), rbuf.data(), rcnt.data(), rd.data(), h->hostc.user))
+                return set_err(SMCMI_ERR_CALLBACK, "host communicator: alltoallv failed");
+            for (int p = 0; p < world; ++p)
+                if (rcnt[p]) {
+                    const long long len = rcnt[p] / R;
+                    HIP_TRY(hipMemcpy2DAsync(h->d_full_cloud + (long long)p * R * n + ra[p], sizeof(double) * n, rbuf.data() + rd[p], sizeof(double) * len, sizeof(double) * (size_t)len,
+                                             (size_t)R, hipMemcpyHostToDevice, h->stream));
+                }
+            long long a, b;
+            if (overlap(me, me, a, b))
+                HIP_TRY(hipMemcpy2DAsync(h->d_full_cloud + (long long)me * R * n + (a - (long long)me * n), sizeof(double) * n,
+                                         h->cl.buf[0] + (a - (long long)me * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
+                                         hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            return 0;
+        }
         if (rccl) {
             smcmi_handle *h = hs[0];
             const int me = h->rank;
@@ -601,9 +692,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
 extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
     if (int e = need_model(h, true)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
-    if (!h->nccl) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init has not been called on this handle");
+    if (!h->nccl && !h->has_hostc) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init / smcmi_comm_init_host has not been called on this handle");
     ShardGroup g;
-    g.hs = {h}; g.world = h->world; g.rccl = true;
+    g.hs = {h}; g.world = h->world; g.rccl = true; g.hostc = h->has_hostc;
     if (eng2_eligible(h, g.world)) return run2_impl(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
     return run_sharded_impl(g, rc, res);
 }

@@ -923,6 +923,13 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     if (int e = need_model(h, 2)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
+    {   // a (host closure, device family) pair in a tempered update: the callback path would score the old likelihood as 0, the device
+        // path would call a device family that does not exist - refuse instead of sampling the wrong posterior
+        const int f1 = h->h_model.lik[1].family;
+        const bool old_dev = f1 != SMCMI_LIK_NONE && f1 != SMCMI_LIK_HOST_CALLBACK, old_cb = h->cb[1] != nullptr;
+        if ((h->cb[0] && old_dev) || (!h->cb[0] && old_cb))
+            return set_err(SMCMI_ERR_UNSUPPORTED, "the new and the old likelihood must both be device families or both host callbacks");
+    }
     if (h->cb[0]) return run_callback(h, rc, res);                    // user likelihood on the host (callback.hpp)
     if (eng2_eligible(h, 1)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
     const int nf = h->h_model.n_free;

@@ -16,7 +16,7 @@ PRIOR = {"normal": 0, "uniform": 1, "gamma": 2, "beta": 3, "invgamma": 4, "rooti
 LIK = {"none": -1, "gauss_iso": 0, "linreg": 1, "linmodel3": 2, "capm_literal": 3, "lgss_kalman": 4, "host_callback": 100}
 RESAMPLE = {"systematic": 0, "multinomial": 1, "polyalgo": 1}
 
-ERRORS = {-1: "ARG", -2: "HIP", -3: "NAN_ESS", -4: "POSDEF", -5: "CAPACITY", -6: "BRACKET", -7: "UNSUPPORTED", -8: "STATE"}
+ERRORS = {-1: "ARG", -2: "HIP", -3: "NAN_ESS", -4: "POSDEF", -5: "CAPACITY", -6: "BRACKET", -7: "UNSUPPORTED", -8: "STATE", -9: "CALLBACK", -10: "TIMEOUT"}
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
@@ -57,6 +57,17 @@ class StageStats(C.Structure):
 
 # int (*smcmi_lik_callback)(const double *theta, int64_t m, int64_t d, double *out, void *user_data)
 LIK_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
+
+# smcmi_host_comm: the collectives of a sharded run as host functions (include/smcmi.h)
+HC_ALLGATHER = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_void_p)
+HC_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
+HC_BARRIER = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class HostComm(C.Structure):
+    _fields_ = [("allgather", HC_ALLGATHER), ("alltoallv", HC_ALLTOALLV), ("barrier", HC_BARRIER), ("user", C.c_void_p)]
+
 
 # every symbol include/smcmi.h declares: (name, restype, argtypes)
 _H = C.c_void_p
@@ -107,6 +118,7 @@ SYMBOLS = [
     ("smcmi_comm_unique_id", C.c_int, [C.c_char_p]),
     ("smcmi_comm_init", C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p]),
     ("smcmi_run_sharded", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),
+    ("smcmi_comm_init_host", C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(HostComm)]),
     ("smcmi_mailbox_export", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("smcmi_mailbox_import", C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     ("smcmi_mailbox_selftest", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),

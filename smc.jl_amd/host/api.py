@@ -314,6 +314,11 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     if tempered:
         ol = old_loglikelihood if old_loglikelihood is not None else loglikelihood
         old_lik = ol.spec(np.asarray(old_data, dtype=np.float64)) if isinstance(ol, DeviceLikelihood) else ("host_callback", [], None, None)
+    if tempered and (lik[0] == "host_callback") != (old_lik[0] == "host_callback"):
+        # one likelihood on the device and the other a host closure: the callback path scores both on the host, the device path both on
+        # the device - a mixed pair would silently lose the old likelihood (csrc/callback.hpp); smcmi_run rejects it as well
+        raise NotImplementedError("tempered update: loglikelihood and old_loglikelihood must both be DeviceLikelihood objects or both "
+                                  "Python callables (wrap the device family in a callable, or pass a DeviceLikelihood for both)")
     if max_stages is None:
         # capacity of the per-stage records and of the two N x max_stages history matrices (16 N max_stages bytes on the device): an
         # adaptive run at the default tempering target takes ~0.9 n_phi stages, so 4 n_phi + 64 is generous; a run that needs

@@ -217,19 +217,30 @@ def host_initial_draw(eng, parameters, seed):
     gen = np.random.Generator(np.random.Philox(key=int(seed)))
     P = np.zeros((n, d + 5), order="F")
     todo = np.arange(n)
+    has_cb = getattr(eng, "_cb", None) is not None and eng._cb[0] is not None
     for attempt in range(1000):
         for k, p in enumerate(parameters):
             P[todo, k] = p.value if p.fixed else _draw_column(p, todo.size, gen)
-        eng.upload_cloud(P)
-        eng.initialize_likelihoods()
+        U = P.copy(order="F")
+        U[:, d:] = 0.0                                   # nothing of an earlier round reaches initialize_likelihoods (it copies loglh -> old_loglh)
+        if has_cb:
+            # a host closure scores only the rows just redrawn: rows whose logprior column is -Inf are skipped by the callback pass
+            U[:, d + 1] = -np.inf
+            U[todo, d + 1] = 0.0
+            eng.upload_cloud(U)
+            eng.eval_cloud_callback(which=0, column=d)
+        else:
+            eng.upload_cloud(U)
+            eng.initialize_likelihoods()
         L = eng.download_cloud()
-        P[:, d], P[:, d + 2] = L[:, d], L[:, d + 2]
-        todo = np.nonzero(~np.isfinite(P[:, d]))[0]
+        P[todo, d] = L[todo, d]
+        todo = todo[~np.isfinite(P[todo, d])]
         if todo.size == 0:
             break
     else:
         raise RuntimeError("initial draw: no finite-likelihood draw found")
     P[:, d + 1] = [logprior(parameters, P[i, :d]) for i in range(n)]
+    P[:, d + 2] = 0.0                                    # old_loglh of a fresh draw (initialization.jl:107-117), whatever the redraw rounds left
     P[:, d + 3] = 0.0
     P[:, d + 4] = 1.0
     eng.upload_cloud(P)

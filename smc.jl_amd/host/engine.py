@@ -268,6 +268,53 @@ class Engine:
         """Join the RCCL communicator (unique_id: the 128 bytes of comm_unique_id() from rank 0)."""
         check(self._L.smcmi_comm_init(self._h, rank, world, bytes(unique_id)))
 
+    def comm_init_host(self, rank, world, allgather, alltoallv=None, barrier=None):
+        """Host-mediated communicator (include/smcmi.h: smcmi_comm_init_host) from Python callables on numpy arrays:
+        allgather(send[count]) -> array[world * count] in rank order; alltoallv(list of per-peer send arrays) -> list of per-peer
+        receive arrays (recv_counts given as second argument); barrier().  `torch_dist_host_comm()` builds the three from
+        torch.distributed (gloo).  Exceptions inside the callables abort the collective (SMCMI_ERR_CALLBACK) and are re-raised."""
+        world = int(world)
+
+        def guard(fn):
+            def g(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except BaseException as ex:      # noqa: BLE001 - must not unwind through the C frames
+                    self._cb_exc = ex
+                    return 1
+            return g
+
+        def c_allgather(send_p, recv_p, count, _ud):
+            send = np.ctypeslib.as_array(send_p, shape=(int(count),))
+            out = np.ctypeslib.as_array(recv_p, shape=(world * int(count),))
+            out[:] = np.asarray(allgather(send.copy()), dtype=np.float64).reshape(-1)
+
+        def c_alltoallv(send_p, sc_p, sd_p, recv_p, rc_p, rd_p, _ud):
+            sc, sd = np.ctypeslib.as_array(sc_p, shape=(world,)), np.ctypeslib.as_array(sd_p, shape=(world,))
+            rcn, rd = np.ctypeslib.as_array(rc_p, shape=(world,)), np.ctypeslib.as_array(rd_p, shape=(world,))
+            stot, rtot = int(sc.sum()), int(rcn.sum())
+            send = np.ctypeslib.as_array(send_p, shape=(max(stot, 1),))
+            recv = np.ctypeslib.as_array(recv_p, shape=(max(rtot, 1),))
+            got = alltoallv([send[int(sd[p]):int(sd[p] + sc[p])].copy() for p in range(world)], [int(x) for x in rcn])
+            for p in range(world):
+                if rcn[p]:
+                    recv[int(rd[p]):int(rd[p] + rcn[p])] = np.asarray(got[p], dtype=np.float64).reshape(-1)
+
+        def c_barrier(_ud):
+            if barrier is not None:
+                barrier()
+
+        if not hasattr(self, "_cb_exc"):
+            self._cb_exc = None
+        hc = _lib.HostComm()
+        hc.allgather = _lib.HC_ALLGATHER(guard(c_allgather))
+        hc.alltoallv = _lib.HC_ALLTOALLV(guard(c_alltoallv)) if alltoallv is not None else C.cast(None, _lib.HC_ALLTOALLV)
+        hc.barrier = _lib.HC_BARRIER(guard(c_barrier))
+        hc.user = None
+        self._hostc = hc                             # keep the trampolines alive as long as the handle
+        self._checked(self._L.smcmi_comm_init_host(self._h, int(rank), world, C.byref(hc)))
+
     def mailbox_export(self):
         """64-byte IPC handle of this handle's peer-mailbox table (include/smcmi.h: smcmi_mailbox_export)."""
         buf = (C.c_uint8 * 64)()
@@ -301,7 +348,7 @@ class Engine:
                               initial_ess)
         rc.stop_after_stage, rc.continue_run = int(stop_after_stage), int(bool(continue_run))
         res = _lib.Result()
-        check(self._L.smcmi_run_sharded(self._h, C.byref(rc), C.byref(res)))
+        self._checked(self._L.smcmi_run_sharded(self._h, C.byref(rc), C.byref(res)))
         out = self._result(res)
         out["paused"] = bool(res.paused)
         return out
@@ -325,7 +372,7 @@ class Engine:
     def sync(self):
         check(self._L.smcmi_sync(self._h))
 
-    # ---- shard-level calls (multi-GPU hosts; see host/distributed.py) ------------------------------------
+    # ---- shard-level calls (multi-GPU hosts; see host/shard_orchestrator.py) ------------------------------------
     tensor_device = "cuda"
 
     def _comm(self, count):
@@ -382,6 +429,41 @@ class Engine:
         check(self._L.smcmi_shard_resample(self._h, C.c_void_p(full_weights.data_ptr()), C.c_void_p(full_cloud.data_ptr()),
                                            _lib.RESAMPLE[method], stage, anc.ctypes.data_as(lp)))
         return anc
+
+
+def torch_dist_host_comm(group=None):
+    """(allgather, alltoallv, barrier) for Engine.comm_init_host on torch.distributed CPU tensors (gloo, or any backend that moves host
+    tensors): what a Julia host would do with Distributed.jl, a C host with MPI."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def allgather(send):
+        t = torch.from_numpy(np.ascontiguousarray(send))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        return np.concatenate([o.numpy() for o in outs])
+
+    def alltoallv(sends, recv_counts):
+        # gloo has no all_to_all for CPU tensors in every build: pairwise isend / irecv in a fixed order
+        recvs = [torch.empty(int(c), dtype=torch.float64) for c in recv_counts]
+        reqs = []
+        for p in range(world):
+            if p == rank:
+                continue
+            if recv_counts[p]:
+                reqs.append(dist.irecv(recvs[p], src=dist.get_global_rank(group, p) if group is not None else p, group=group))
+            if len(sends[p]):
+                reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(sends[p])), dst=dist.get_global_rank(group, p) if group is not None else p, group=group))
+        for r in reqs:
+            r.wait()
+        return [r.numpy() for r in recvs]
+
+    def barrier():
+        dist.barrier(group=group)
+
+    return allgather, alltoallv, barrier
 
 
 def comm_unique_id():

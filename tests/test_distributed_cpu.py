@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: smc_jl_amd.host.distributed.ShardedSMC under torch.distributed/gloo with world_size 2.
+"""N > 1 path on CPU: smc_jl_amd.host.shard_orchestrator.ShardedSMC under torch.distributed/gloo with world_size 2.
 
 The per-shard compute is the oracle-backed engine of tests/dist_helpers.py; what is under test is the orchestration
 (collectives, replicated scalar logic, global-id RNG, resample exchange): a 2-rank sharded run must reproduce the
@@ -89,3 +89,61 @@ def test_host_blocks_match_oracle():
             b = orc.generate_blocks(7, nb, free, 1234, stage)
             for x, y in zip(a, b):
                 np.testing.assert_array_equal(x, y)
+
+
+def _hostcomm_worker(rank, world, port, ret):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smc_jl_amd.host.engine import torch_dist_host_comm
+
+        allgather, alltoallv, barrier = torch_dist_host_comm()
+        got = allgather(np.array([rank + 0.25, 10.0 * rank, -1.0]))
+        # ragged all-to-all-v: rank r sends r + p + 1 doubles to peer p (nothing to itself)
+        sends = [np.full(rank + p + 1, 100.0 * rank + p) if p != rank else np.zeros(0) for p in range(world)]
+        recv_counts = [p + rank + 1 if p != rank else 0 for p in range(world)]
+        recvs = alltoallv(sends, recv_counts)
+        barrier()
+        ret.put(dict(rank=rank, gathered=got.tolist(), recvs=[r.tolist() for r in recvs]))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+
+        ret.put({"error": "rank %d: %s\n%s" % (rank, ex, traceback.format_exc())})
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_communicator_callables_under_gloo(world):
+    """The transport `smcmi_comm_init_host` is given by the multi-process tests and by bench.py's host mode (engine.torch_dist_host_comm):
+    rank order of the all-gather, ragged all-to-all-v, barrier - real processes, gloo, no GPU.  (The driver that calls them is HIP
+    code: tests/test_gpu_multiproc.py runs it as 2 and 4 processes on one GPU.)"""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + world
+    procs = [ctx.Process(target=_hostcomm_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [ret.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()
+    for o in outs:
+        assert "error" not in o, o.get("error")
+        want = []
+        for r in range(world):
+            want += [r + 0.25, 10.0 * r, -1.0]
+        assert o["gathered"] == want
+        me = o["rank"]
+        for p in range(world):
+            if p == me:
+                assert o["recvs"][p] == []
+            else:
+                assert o["recvs"][p] == [100.0 * p + me] * (p + me + 1)

@@ -119,6 +119,65 @@ def test_smc_entry_point_with_a_python_closure_tempered_update():
     assert w.shape == (4000, 50) and W.shape == (4000, 50)
 
 
+def test_closure_with_gamma_prior_and_rejected_draws_starts_from_old_loglh_zero():
+    """a closure that returns -Inf on part of the prior support sends host_initial_draw through redraw rounds; the cloud the
+    recursion starts from must have old_loglh = 0 everywhere (initialization.jl:107-117) - a stale copy of loglh there switches the
+    correction off for the particles that were not redrawn - and each round may only score the rows it redrew."""
+    import smc_jl_amd as S
+    from smc_jl_amd.host import api
+    from smc_jl_amd.host.cloudio import host_initial_draw
+
+    calls = []
+
+    def loglik(theta, dat):
+        calls.append(1)
+        if theta[0] < 0.6:                           # a third of the Gamma(2, 1) draws
+            return -math.inf
+        e = dat[:, 0] - theta[0] - theta[1]
+        return -0.5 * float(e @ e)
+
+    pars = [S.parameter("g", 1.0, (1e-8, 1e5), prior=S.Gamma(2.0, 1.0)), S.parameter("b", 0.0, (-1e5, 1e5), prior=S.Normal(0.0, 2.0))]
+    data = np.full((5, 1), 2.5)
+    n = 1500
+    eng = S.Engine(n, 2, seed=3, max_stages=4, store_history=False)
+    spec = api._spec_from(pars, ("host_callback", [], None, None), None)
+    eng.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
+    eng.set_likelihood_callback(api._batch(loglik, data), which=0)
+    eng.set_likelihood("none", which=1)
+    host_initial_draw(eng, pars, seed=3)
+    P = eng.download_cloud()
+    assert np.all(np.isfinite(P[:, 2])) and np.all(P[:, 0] >= 0.6)
+    np.testing.assert_array_equal(P[:, 4], 0.0)                      # old_loglh
+    np.testing.assert_array_equal(P[:, 6], 1.0)
+    assert n < len(calls) < 2 * n                                   # n + the redrawn rows (geometric: about n / 2 more), not n per round
+    c, _, _ = S.smc(loglik, pars, data, n_parts=n, n_phi=20, verbose="none", seed=3)
+    assert c.stage_index == 20 and np.isfinite(c.logmdd)
+    assert abs(S.weighted_mean(c)[0] + S.weighted_mean(c)[1] - 2.5) < 0.5
+
+
+def test_mixed_device_and_closure_likelihoods_are_refused():
+    """(closure, DeviceLikelihood) pairs in a tempered update ran and silently dropped the old likelihood; both the Python
+    mirror and smcmi_run refuse them now."""
+    import smc_jl_amd as S
+    from smc_jl_amd.host import api
+
+    pars = [S.parameter("a", 0.0, (-1e5, 1e5), prior=S.Normal(0.0, 10.0)), S.parameter("b", 0.0, (-1e5, 1e5), prior=S.Normal(0.0, 10.0))]
+    data = np.random.default_rng(1).normal(size=(40, 2))
+    f = lambda th, dat: -0.5 * float(((dat[:, 0] - th[0] - th[1] * dat[:, 1]) ** 2).sum())
+    for new, old in ((f, S.LinReg(1.0)), (S.LinReg(1.0), f)):
+        with pytest.raises(NotImplementedError, match="both"):
+            S.smc(new, pars, data, old_data=data[:20], old_loglikelihood=old, old_cloud=S.Cloud(2, 10), n_parts=100, verbose="none")
+    # the C ABI itself: a callback for the new likelihood next to a device family for the old one
+    eng = S.Engine(256, 2, seed=1, max_stages=8, store_history=False)
+    spec = api._spec_from(pars, ("host_callback", [], None, None), None)
+    eng.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
+    eng.set_likelihood_callback(api._batch(f, data), which=0)
+    eng.set_likelihood(*S.LinReg(1.0).spec(data[:20]), which=1)
+    eng.init_from_prior()
+    with pytest.raises(RuntimeError, match="both be device families or both host callbacks"):
+        eng.run(n_phi=5)
+
+
 def test_c_callback_example_builds_and_matches():
     """examples/c_abi_callback.c: the callback ABI from plain C (a function pointer computing the 10-dim Gaussian log-likelihood)
     against the fused device family, and the callback path's throughput."""

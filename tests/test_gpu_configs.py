@@ -99,6 +99,18 @@ def test_config3_workload_on_eight_shards_equals_one_handle():
     assert abs(out["1"]["mean0"] - (-1.0) * 25 / 25.0625) < 0.01
 
 
+def test_config3_in_its_own_shape_eight_shards_of_125000():
+    """BASELINE config 3 itself: N = 1 000 000 as 8 x 125 000 (the per-GPU shard of `bench.py --gpus 8`), 8 handles of one process
+    against one handle of 10⁶ particles on the same engine: bit-identical, analytic log-MDD within Monte-Carlo error."""
+    kw = dict(use_fixed_schedule=False, tempering_target=0.97, n_phi=300)
+    out = _invariance(1_000_000, 10, 1, (1, 8), kw)
+    for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+        assert out["8"][key] == out["1"][key], key
+    assert out["1"]["resamples"] >= 8
+    assert abs(float.fromhex(out["1"]["logmdd"]) - models.gauss_logmdd(10)) < 0.05
+    assert abs(out["1"]["mean0"] - (-1.0) * 25 / 25.0625) < 0.005
+
+
 def test_config2_workload_at_one_million_particles():
     """Config 2's workload at 10x its size on one GPU against the CPU oracle on the same Philox streams: identical stage and
     resample counts, ϕ and ESS paths to 1e-9, log-MDD to 1e-9 (the tolerance north_star states is 1e-3)."""

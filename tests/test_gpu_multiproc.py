@@ -1,0 +1,124 @@
+"""The sharded product driver as SEVERAL PROCESSES: what replaces `@distributed` (src/smc_main.jl:472-476,
+src/resample.jl:33-35) is `smcmi_run_sharded` -> csrc/run2.hpp `run2_impl`; with RCCL it needs one GPU per rank, so until now it had
+only ever executed with one rank or as in-process handles.  Here it runs as 2 and 4 processes that share the one GPU of the box, over
+the host-mediated communicator (smcmi_comm_init_host; collectives by torch.distributed / gloo on host buffers), the per-stage sums
+handed over through the peer mailbox mapped between the processes with hipIpcOpenMemHandle - and must reproduce the single handle
+bit for bit: same ϕ schedule, ESS path, acceptance rates, log-MDD, cloud."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import models
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _spawn(world, cfg, tmp_path, env_extra=None, timeout=900):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
+    out = str(tmp_path)
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.mp_shard_worker", str(r), str(world), str(port), out, json.dumps(cfg)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    errs = []
+    for r, p in enumerate(procs):
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        if p.returncode != 0:
+            errs.append("rank %d rc %d:\n%s" % (r, p.returncode, se[-3000:]))
+    assert not errs, "\n".join(errs)
+    runs = [json.load(open(os.path.join(out, "rank%d.json" % r))) for r in range(world)]
+    cloud = np.concatenate([np.load(os.path.join(out, "cloud%d.npy" % r)) for r in range(world)], axis=0)
+    return runs, cloud
+
+
+def _single(cfg, env_engine2=True, env_extra=None):
+    """The same population on ONE handle, in a fresh process (SMCMI_ENGINE=2: the engine every sharded run uses)."""
+    code = r'''
+import json, sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+from smc_jl_amd import Engine
+from tests import models
+cfg = json.loads(%r)
+spec = getattr(models, cfg.get("spec", "gauss_spec"))(*cfg.get("spec_args", []))
+e = Engine(cfg["n"], cfg["d"], seed=cfg["seed"], max_stages=cfg.get("max_stages", 1500), store_history=False)
+e.set_model(spec); e.init_from_prior()
+kw = dict(cfg["kw"]); stop = kw.pop("pause_at", 0)
+if stop:          # (a continuation re-enters the solver without a prediction: pause the single handle at the same stage)
+    r = e.run(stop_after_stage=stop, **kw); assert r["paused"]
+    r = e.run(continue_run=True, **kw)
+else:
+    r = e.run(**kw)
+rec = e.stage_records(r["n_stages"])
+np.save(sys.argv[1], e.download_cloud())
+print("RESULT " + json.dumps(dict(n_stages=r["n_stages"], resamples=r["resamples"], logmdd=float(r["logmdd"]).hex(),
+      schedule=hashlib.sha256(np.ascontiguousarray(rec["schedule"]).tobytes()).hexdigest(),
+      ess=hashlib.sha256(np.ascontiguousarray(rec["ess"]).tobytes()).hexdigest(),
+      accept=hashlib.sha256(np.ascontiguousarray(rec["accept_hist"]).tobytes()).hexdigest())))
+''' % (ROOT, json.dumps(cfg))
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "c.npy")
+        env = dict(os.environ, SMCMI_ENGINE="2") if env_engine2 else dict(os.environ)
+        env.update(env_extra or {})
+        p = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        return res, np.load(path)
+
+
+def _check(runs, cloud, want, want_cloud, expect_mailbox):
+    for rank_runs in runs:
+        for r in rank_runs:
+            for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept"):
+                assert r[key] == want[key], (key, r[key], want[key])
+            if expect_mailbox is not None:
+                assert r["mailbox"] == expect_mailbox
+    assert hashlib.sha256(np.ascontiguousarray(cloud).tobytes()).hexdigest() == hashlib.sha256(np.ascontiguousarray(want_cloud).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_processes_sharing_one_gpu_reproduce_the_single_handle(world, tmp_path):
+    """Adaptive schedule (resample stages among the predicted ones), mailbox mapped across processes for the whole run."""
+    cfg = dict(n=32768, d=10, seed=7, kw=dict(use_fixed_schedule=False, tempering_target=0.95), reps=2)
+    want, want_cloud = _single(cfg)
+    assert want["resamples"] >= 3
+    runs, cloud = _spawn(world, cfg, tmp_path)
+    _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+
+
+def test_stalled_and_resumed_stages_across_processes(tmp_path):
+    """SMCMI_NO_SELECT_PREDICT=2: every resample stage arrives without its selection kernels, stalls on all ranks and is resumed by the
+    hosts (fresh mailbox tags after a barrier); plus a pause at a save point and a continuation.  Same bits as one handle."""
+    cfg = dict(n=16384, d=4, seed=3, spec_args=[4], kw=dict(use_fixed_schedule=False, tempering_target=0.9, n_blocks=2, pause_at=7))
+    # (the switch also makes resample stages take the predicted ϕ_n instead of a certified one: the single handle runs under it too)
+    want, want_cloud = _single(cfg, env_extra={"SMCMI_NO_SELECT_PREDICT": "2"})
+    runs, cloud = _spawn(2, cfg, tmp_path, env_extra={"SMCMI_NO_SELECT_PREDICT": "2"})
+    _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+    assert all(r["stalls"][1] >= 1 for rr in runs for r in rr)
+
+
+@pytest.mark.parametrize("env", [{"SMCMI_MAILBOX": "0"}, {"SMCMI_MAILBOX": "0", "SMCMI_RESAMPLE_EXCHANGE": "allgather"}])
+def test_all_gather_hand_overs_and_multinomial_across_processes(env, tmp_path):
+    """The fall-back transport (every hand-over an all-gather through the host communicator), fixed schedule, multinomial resampling
+    (rows by all-gather) and systematic (all-to-all-v through the communicator's alltoallv)."""
+    method = "multinomial" if "SMCMI_RESAMPLE_EXCHANGE" in env else "systematic"
+    cfg = dict(n=16384, d=10, seed=11, kw=dict(use_fixed_schedule=True, n_phi=40, n_mh_steps=2, resampling_method=method))
+    want, want_cloud = _single(cfg)
+    runs, cloud = _spawn(2, cfg, tmp_path, env_extra=env)
+    _check(runs, cloud, want, want_cloud, expect_mailbox=False)

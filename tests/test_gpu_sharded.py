@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run_sharded_threads(spec, n, seed, world, kw):
     from smc_jl_amd import Engine
-    from smc_jl_amd.host.distributed import ShardedSMC
+    from smc_jl_amd.host.shard_orchestrator import ShardedSMC
 
     import torch
 
