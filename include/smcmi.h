@@ -98,6 +98,10 @@ typedef struct {
     int32_t select_stalls;   /* stages enqueued without selection kernels that had to resample after all (host resumed them) */
     int32_t spec_stalls;     /* stages enqueued without a certificate pass whose predicted ϕ_n was unusable / not verified (resumed) */
     int32_t paused;          /* 1: stopped at stop_after_stage with ϕ_n < 1; continue with continue_run = 1 */
+    int32_t n_segments;      /* persistent stage-segment launches of the run (small clouds on one handle: runs of stages that neither
+                                resample nor need a certificate pass execute as one launch each) */
+    int32_t segment_stages;  /* stages those launches completed (use_graph = 2: the stages behind kernel_ms_segments) */
+    double kernel_ms_segments; /* HIP-event time of the segment launches (use_graph = 2, else 0) */
 } smcmi_result;
 
 typedef struct {             /* the loop scalars an intermediate save holds (smc_main.jl:499-507: cloud fields + j) */

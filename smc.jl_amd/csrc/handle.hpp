@@ -17,6 +17,7 @@
 #include "devstate.hpp"
 #include "kernels.hpp"
 #include "stage2.hpp"
+#include "stage3.hpp"
 
 using namespace smcmi;
 struct CallbackBuffers;            // pinned staging buffers of the host-likelihood path (callback.hpp)
@@ -32,6 +33,12 @@ struct Eng2 {
     long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage
     int prof_stage = 0;
     int world = 0;
+    // engine 3 (stage3.hpp): tickets, records, time-out flag words, per-launch stage counts (profiling)
+    int *d_tick3 = nullptr;
+    unsigned long long *d_rec3 = nullptr, *d_to3 = nullptr;
+    int *d_done3 = nullptr;
+    unsigned seg_seq = 0;
+    int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle
     bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
     int n_steps = 1, n_blocks = 1;
 };

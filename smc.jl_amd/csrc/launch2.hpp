@@ -45,12 +45,28 @@ void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
     Eng2 *e = h->e2;
     k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, nb, h->h_model.n_free, e->d_pre);
 }
+template <int D>
+void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1) {
+    Eng2 *e = h->e2;
+    const size_t lds = k3_lds_bytes(D);
+    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
+    static bool attr_set = false;              // (per instantiation: static + dynamic LDS pass 64 KB)
+    if (!attr_set) {
+        // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
+        hipFuncSetAttribute((const void *)k3_segment<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void *)k3_segment<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    if (alpha1) k3_segment<D, true><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+    else k3_segment<D, false><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+}
 
 #define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
     X template void launch_k2_correct<D>(smcmi_handle *, int, int, int, const Rows2 &, const Tail2 &);                               \
     X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *);                   \
     X template void launch_k2_mutate<D>(smcmi_handle *, const Mut2Args &, int, bool);                                                \
-    X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);
+    X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);                                                     \
+    X template void launch_k3_segment<D>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int, bool);
 #ifdef SMCMI_INST_D
 SMCMI_LAUNCH2_INSTANCES(, SMCMI_INST_D)
 #else

@@ -12,10 +12,11 @@
 #include <map>
 
 
+constexpr int SEG3_MAX_LAUNCHES = 4096;     // segment launches of one run whose stage counts are kept for the profile (more are not timed)
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre, e->d_tick};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete e;
@@ -48,7 +49,9 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     }
     // correction blocks per virtual shard: 1024 particles per block (two passes of its 512 threads), at most 16 rows per virtual shard for
     // K2's prologue to total while the cloud is small
-    g.nb1 = (int)std::max<long long>(1, g.direct ? std::min<long long>((g.nv + 1023) / 1024, 16) : std::min<long long>((g.nv + 1023) / 1024, 128));
+    // (the direct geometry: one correction row per 512 particles, the same particles as a mutation row - the persistent segment kernel
+    // of stage3.hpp holds one particle per thread and writes exactly these rows, so both engines total the same numbers)
+    g.nb1 = (int)std::max<long long>(1, g.direct ? g.nb2 : std::min<long long>((g.nv + 1023) / 1024, 128));
     if (getenv("SMCMI_E2_NB1")) g.nb1 = std::max(1, std::min(atoi(getenv("SMCMI_E2_NB1")), g.direct ? 64 : 128));   // development only
     g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;                        // whole passes of the block
     g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? 32 : 256));
@@ -73,6 +76,15 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
         dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_pre, 1) || dmalloc(&e->d_tick, 2 * V2_MAXV)) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
+    }
+    if (g.direct) {                   // engine 3 (stage3.hpp) can serve this geometry: tickets, records, time-out words, per-launch stage counts
+        if (dmalloc(&e->d_tick3, 2 * SEG3_TICKS) || dmalloc(&e->d_rec3, REC3_WORDS) || dmalloc(&e->d_to3, 2) || dmalloc(&e->d_done3, SEG3_MAX_LAUNCHES)) {
+            free_eng2(e);
+            return SMCMI_ERR_HIP;
+        }
+        HIP_TRY(hipMemsetAsync(e->d_tick3, 0, 2 * SEG3_TICKS * sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
+        HIP_TRY(hipMemsetAsync(e->d_done3, 0, SEG3_MAX_LAUNCHES * sizeof(int), h->stream));
     }
     HIP_TRY(hipMemsetAsync(e->d_pre, 0, sizeof(Prop2Glob), h->stream));
     HIP_TRY(hipMemsetAsync(e->d_tick, 0, 2 * V2_MAXV * sizeof(int), h->stream));
@@ -262,6 +274,46 @@ static int mbox_setup_remote(ShardGroup &g) {
 static long long mbox_table(int kind, unsigned cnt) { return (long long)(kind * 2 + (int)(cnt & 1u)) * MB_TABLE_WORDS; }
 static unsigned mbox_tag(unsigned epoch, unsigned cnt) { return ((epoch & 0x7Fu) << 24) | (cnt & 0xFFFFFFu); }      // (never 0xFFFFFFFF: a cleared word)
 
+// Engine 3 serves a single handle in the direct geometry whose blocks are all resident at one per CU; the first use runs the residency
+// self-test (k3_census) and a failure - or SMCMI_ENGINE3=0 - leaves the handle on engine 2's launches for good.
+static int seg3_time_out_words(smcmi_handle *h, double ms) {
+    const unsigned long long fl[2] = {0ull, (unsigned long long)(ms * 1e5)};         // 100 MHz wall clock
+    HIP_TRY(hipMemcpyAsync(h->e2->d_to3, fl, sizeof(fl), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static int seg3_ready(smcmi_handle *h, bool *ok) {
+    Eng2 *e = h->e2;
+    *ok = false;
+    static const int off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
+    const Geo2 &g = e->g;
+    const int grid = g.Vl * g.nb2;
+    int n_cu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+    if (off || !g.direct || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
+    if (e->e3_state < 0) return 0;
+    if (e->e3_state == 0) {
+        int *d_ok = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_ok, sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_ok, 0, sizeof(int), h->stream));
+        if (int rc = seg3_time_out_words(h, 50.0)) return rc;
+        const size_t lds = 96 * 1024;                       // more than half a CU's LDS: one block per CU, the placement the segment kernel must survive
+        HIP_TRY(hipFuncSetAttribute((const void *)k3_census, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k3_census<<<grid, T3, lds, h->stream>>>(e->d_tick3, e->d_rec3 + REC3_WORDS - 1, 0xC0FFEEu, e->d_to3, d_ok);
+        int okc = 0;
+        unsigned long long fl[2] = {1, 0};
+        HIP_TRY(hipMemcpyAsync(&okc, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(fl, e->d_to3, sizeof(fl), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        hipFree(d_ok);
+        e->e3_state = (okc == grid && fl[0] == 0) ? 1 : -1;
+        HIP_TRY(hipMemsetAsync(e->d_tick3, 0, 2 * SEG3_TICKS * sizeof(int), h->stream));
+        if (getenv("SMCMI_TRACE")) fprintf(stderr, "[smcmi3] residency self-test: %d of %d blocks, time-out flag %llu -> engine 3 %s\n", okc, grid, fl[0], e->e3_state > 0 ? "on" : "off");
+    }
+    *ok = e->e3_state > 0;
+    return 0;
+}
+
 static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res) {
     smcmi_handle *h0 = g.hs[0];
     const int nf = h0->h_model.n_free, d = h0->d;
@@ -427,6 +479,16 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (mutation rows of 256-thread blocks are paired: the canonical row stands for 512 particles, whatever the block size)
     if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256)) return e;
 
+    // ---- engine 3: runs of stages that neither resample nor need a certificate pass become one persistent launch each
+    bool e3 = false;
+    if (!multi && !g.rccl && g.hs.size() == 1) { if (int e = seg3_ready(h0, &e3)) return e; }
+    std::vector<hipEvent_t> evs3;
+    int seg_launches = 0;
+    if (e3) {
+        HIP_TRY(hipMemsetAsync(h0->e2->d_tick3, 0, 2 * SEG3_TICKS * sizeof(int), h0->stream));
+        static const double to_ms = getenv("SMCMI_SEG_TIMEOUT_MS") ? atof(getenv("SMCMI_SEG_TIMEOUT_MS")) : 200.0;
+        if (int e = seg3_time_out_words(h0, to_ms)) return e;
+    }
     const bool profile = rc->use_graph == 2;
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_stage;
@@ -532,6 +594,38 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256, true);
     };
+    auto enq_K3 = [&](int n_first, int n_last) -> int {             // one persistent launch for stages n_first .. n_last (stage3.hpp)
+        smcmi_handle *h = h0;
+        Eng2 *e = h->e2;
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        if (++e->seg_seq >= 0xFFFFu) {                               // tags are (launch << 16 | stage): start over on clean records
+            HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
+            e->seg_seq = 1;
+        }
+        Mut2Args ma{};
+        ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n_first; ma.sel_enqueued = 0; ma.adaptive = adaptive ? 1 : 0;
+        ma.rows_mut = e->rows_mut; ma.zbuf = nullptr; ma.pre = nullptr;
+        ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
+        ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
+        ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
+        ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
+        Seg3Args sa{};
+        sa.n_first = n_first; sa.n_last = n_last; sa.mrows = mut_rows(h); sa.sched = h->d_sched;
+        sa.rows_cm = e->rows_cm; sa.vt_cm = e->vt_cm; sa.vt_mut = e->vt_mut; sa.tick = e->d_tick3; sa.rec = e->d_rec3;
+        sa.tag_base = e->seg_seq << 16; sa.to = e->d_to3; sa.hist_w = h->d_hist_w; sa.hist_ld = h->n;
+        sa.done_out = seg_launches < SEG3_MAX_LAUNCHES ? e->d_done3 + seg_launches : nullptr;
+        sa.prof = (e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
+        sa.prof_stage = e->prof_stage;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile && sa.done_out) { hipEventCreate(&e0); hipEventCreate(&e1); evs3.push_back(e0); evs3.push_back(e1); hipEventRecord(e0, h->stream); }
+        if (sa.done_out) HIP_TRY(hipMemsetAsync(sa.done_out, 0, sizeof(int), h->stream));
+#define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0)
+        SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+        if (e1) hipEventRecord(e1, h->stream);
+        ++seg_launches;
+        return 0;
+    };
     auto enq_passes = [&](int n, int p0, int P) -> int {           // passes p0 .. P-1, then the closing decision
         for (int p = p0; p < P; ++p) {
             for (auto *h : g.hs) {
@@ -612,6 +706,13 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     while (!finished) {
         const int room = max_iter - launched;
         const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), room) : room;
+        int seg_a = -1, seg_b = -1;                      // pending segment of engine 3
+        auto flush_seg = [&]() -> int {
+            if (seg_a < 0) return 0;
+            const int a = seg_a, b2 = seg_b;
+            seg_a = seg_b = -1;
+            return enq_K3(a, b2);
+        };
         for (int b = 0; b < batch; ++b) {
             const int n = base + launched + 2;
             bool sel = true;
@@ -625,11 +726,27 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             // stages that follow a resample or have no mutation rows yet (first stage of a run / a continuation) get certificate
             // passes; so does everything once predictions have stopped verifying
             const bool cert = adaptive && (!spec_on || sel || launched < 2);
+            // engine 3 takes every stage that is expected to need neither (fixed schedules: nobody can tell which stage resamples -
+            // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches)
+            if (e3 && !cert && (!sel || !adaptive)) {
+                if (seg_a < 0) seg_a = n;
+                seg_b = n;
+                ++launched;
+                continue;
+            }
+            if (int e = flush_seg()) return e;
             if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
             ++launched;
         }
+        if (int e = flush_seg()) return e;
         if (int e = read_ctl(&c)) return e;
-        while (c.status.code == 2 || c.status.code == 3 || c.status.code == 4) {
+        static const int trace = getenv("SMCMI_TRACE") ? atoi(getenv("SMCMI_TRACE")) : 0;                       // development only
+        if (trace) {
+            const Post2 &tp = c.ps[0].stage >= c.ps[1].stage ? c.ps[0] : c.ps[1];
+            fprintf(stderr, "[smcmi2] sync: launched %d  status (code %d, stage %d, err %d)  post (stage %d, phi %.6g, ess %.6g, rs %d)  begin (stage %d, phi %.6g, final %d)  segments %d\n",
+                    launched, c.status.code, c.status.stage, c.status.err, tp.stage, tp.phi_n, tp.ess, tp.do_resample, c.bg.stage, c.bg.phi_n, c.bg.final, seg_launches);
+        }
+        while (c.status.code == 2 || c.status.code == 3 || c.status.code == 4 || c.status.code == 6) {
             const int sn = c.status.stage, code = c.status.code;
             // mailbox: a resumed stage posts under fresh tags into tables a slower handle may still be polling for the stalled
             // stage's - every handle must have left the stalled batch first
@@ -643,7 +760,12 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
             for (int &s : ev_stage) if (s >= sn) s = -1;           // the stalled stage's mutation launch and everything behind it were no-ops
             if (int e = clear_status()) return e;
-            if (code == 4) {
+            if (code == 6) {
+                // a segment of engine 3 left at this stage (it must resample): nothing of the stage is committed; the full path runs it
+                if (int e = enq_stage(sn, adaptive, first_passes, true)) return e;
+                if (adaptive) { stall_stage = sn; stall_p = first_passes; }
+                res->select_stalls += 1;
+            } else if (code == 4) {
                 // predicted ϕ_n unusable or not verified: nothing of the stage is committed; run it through the certificate path
                 if (int e = enq_stage(sn, true, first_passes, true)) return e;
                 stall_stage = sn; stall_p = first_passes;
@@ -690,6 +812,20 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (h0->e2->d_prof) {
         long long pr[128];
         HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));
+        if (seg_launches > 0) {
+            // block 0's phases of stage prof_stage, and - where the deciding blocks happened to sit on block 0's XCD (their stamps are
+            // comparable then; 0 otherwise) - the hand-overs seen from inside
+            fprintf(stderr, "[smcmi3] stage %d block 0 ticks:", h0->e2->prof_stage);
+            const char *nm[] = {"", "", "corr+row", "draw", "wait B", "MH", "mut row", "arrive", "wait A"};
+            for (int q = 2; q <= 8; ++q) fprintf(stderr, " %s %lld", nm[q], pr[q] - pr[q - 1]);
+            fprintf(stderr, " | stage %lld\n", pr[8] - pr[1]);
+            if (pr[14]) fprintf(stderr, "[smcmi3]   shard 0 (XCD 0) correction rows: block 0's row stored -> last arrival %lld, shard total %lld\n", pr[14] - pr[2], pr[15] - pr[14]);
+            if (pr[10]) fprintf(stderr, "[smcmi3]   correction decider on XCD 0: block 0's row stored -> all arrived %lld | totals %lld | covariance, shuffle %lld | block matrices %lld | Cholesky %lld | record %lld | publish %lld | -> block 0 has it %lld\n",
+                                pr[10] - pr[2], pr[11] - pr[10], pr[30] - pr[11], pr[31] - pr[30], pr[32] - pr[31], pr[12] - pr[32], pr[13] - pr[12], pr[4] - pr[13]);
+            if (pr[24]) fprintf(stderr, "[smcmi3]   shard 0 (XCD 0) mutation rows: block 0's row stored -> last arrival %lld, shard total %lld\n", pr[24] - pr[6], pr[25] - pr[24]);
+            if (pr[20]) fprintf(stderr, "[smcmi3]   mutation decider on XCD 0: block 0's row stored -> all arrived %lld | totals %lld | begin %lld | publish %lld | -> block 0 has it %lld\n",
+                                pr[20] - pr[6], pr[21] - pr[20], pr[22] - pr[21], pr[23] - pr[22], pr[8] - pr[23]);
+        }
         for (int blk = 0; blk < 2; ++blk) {
             fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");
             for (int q = 1; q <= 5; ++q) fprintf(stderr, " %lld", pr[blk * 32 + q] - pr[blk * 32 + q - 1]);
@@ -734,6 +870,22 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
     }
     for (hipEvent_t e : evs) hipEventDestroy(e);
+    // segments of engine 3: launches, the stages they completed and (profile mode) their HIP-event time
+    res->n_segments = seg_launches; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
+    if (seg_launches > 0) {
+        const int nl = std::min(seg_launches, SEG3_MAX_LAUNCHES);
+        std::vector<int> done(nl);
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        HIP_TRY(hipMemcpy(done.data(), h0->e2->d_done3, sizeof(int) * nl, hipMemcpyDeviceToHost));
+        for (int k = 0; k < nl; ++k) res->segment_stages += done[k];
+        int timed_stages = 0;
+        for (size_t k = 0; k + 1 < evs3.size(); k += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, evs3[k], evs3[k + 1]) == hipSuccess) { res->kernel_ms_segments += (double)ms; timed_stages += done[k / 2]; }
+        }
+        if (!evs3.empty()) res->segment_stages = timed_stages;        // (profile mode: the stages behind kernel_ms_segments)
+    }
+    for (hipEvent_t e : evs3) hipEventDestroy(e);
     res->n_stages = s.stage; res->resamples = s.resamples; res->logmdd = s.logz; res->c = s.c; res->accept = s.accept;
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->solver_passes = s.solver_passes;
@@ -748,6 +900,11 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             return set_err(SMCMI_ERR_TIMEOUT, "peer mailbox: a rank's per-stage sums did not arrive within the time-out (SMCMI_MAILBOX_TIMEOUT_MS); "
                                               "the run is void - repeat it (this handle now uses the all-gathers; SMCMI_MAILBOX=0 does so from the start)");
         }
+    }
+    if (s.err == SMCMI_ERR_TIMEOUT) {
+        h0->e2->e3_state = -1;                           // this handle keeps to engine 2's launches from now on
+        return set_err(SMCMI_ERR_TIMEOUT, "engine 3: a hand-over inside a persistent stage segment timed out (SMCMI_SEG_TIMEOUT_MS); the run is void - "
+                                          "repeat it (this handle now runs every stage as launches; SMCMI_ENGINE3=0 does so from the start)");
     }
     if (s.err == SMCMI_ERR_NAN_ESS) return nan_ess_error(h0, h0->d_wt);
     if (s.err) return err_from_state(s.err);

@@ -692,6 +692,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
 extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
     if (int e = need_model(h, true)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
+    res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
     if (!h->nccl && !h->has_hostc) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init / smcmi_comm_init_host has not been called on this handle");
     ShardGroup g;
     g.hs = {h}; g.world = h->world; g.rccl = true; g.hostc = h->has_hostc;
@@ -701,6 +702,7 @@ extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, sm
 
 extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res) {
     if (!hs || n < 1 || !rc || !res) return set_err(SMCMI_ERR_ARG, "bad argument");
+    res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
     ShardGroup g;
     long long expect = 0;
     for (int k = 0; k < n; ++k) {

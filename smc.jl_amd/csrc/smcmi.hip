@@ -923,6 +923,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     if (int e = need_model(h, 2)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
+    res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
     {   // a (host closure, device family) pair in a tempered update: the callback path would score the old likelihood as 0, the device
         // path would call a device family that does not exist - refuse instead of sampling the wrong posterior
         const int f1 = h->h_model.lik[1].family;

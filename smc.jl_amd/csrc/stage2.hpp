@@ -47,6 +47,15 @@ constexpr int pad2(int m) { return (m + 1) & ~1; }   // row widths are even: row
         }                                                                                                                     \
     } while (0)
 
+#define K3_STAMP_ANY(prof, slot)                                                                                               \
+    do {                                                                                                                      \
+        if ((prof) != nullptr && threadIdx.x == 0) {                                                                           \
+            unsigned long long tt_;                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");       \
+            (prof)[(slot)] = (long long)tt_;                                                                                   \
+        }                                                                                                                     \
+    } while (0)
+
 struct Geo2 {
     long long N, n, nv;           // global / local / per-virtual-shard particles
     int V, Vl, v0;                // virtual shards in total / held by this handle / global index of the first local one
@@ -257,6 +266,10 @@ constexpr int RT = 1024;
 // By a whole block of NT threads (k2_reduce: its own launch; or the last block of a virtual shard to finish, Tail2 below): the
 // result does not depend on NT (groups are totalled in ascending order however many fit a batch).
 // COH: the rows were written by other blocks of the SAME launch (Tail2): read them with agent-scope loads that bypass this die's L2.
+__device__ inline void row_store(double *p, double v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 __device__ inline double2 load_pair(const double2 *p, bool coh) {
     if (!coh) return *p;
     const double *q = reinterpret_cast<const double *>(p);
@@ -264,6 +277,28 @@ __device__ inline double2 load_pair(const double2 *p, bool coh) {
     x.x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     x.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return x;
+}
+// The same 16 bytes with agent-scope cache policy (sc1: served from memory / MALL, not from this die's L2) as a load the compiler
+// counts and pipelines like any other: sixteen of them are in flight at once, where sixteen atomic loads are sixteen round trips
+// (3.6 -> ~1 µs for the totals of a virtual shard).  rsrc: buffer descriptor over the rows (wave-uniform), off: byte offset.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline double2 load_pair_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, /*aux = sc1*/ 16);
+    double2 x;
+    x.x = __hiloint2double((int)v.y, (int)v.x);
+    x.y = __hiloint2double((int)v.w, (int)v.z);
+    return x;
+}
+__device__ inline double load_f64_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, /*aux = sc1*/ 16);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ inline __amdgpu_buffer_rsrc_t rows_rsrc(const double *base, long long bytes) {
+    // (the base is the same in every lane; readfirstlane tells the compiler so)
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 template <int NT, bool COH = false>
 __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int max_idx, double *out_v, int pair) {
@@ -275,6 +310,7 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
     const int ng = (nr + GRP - 1) / GRP;
     const double ninf = -__builtin_inf();
     double run = (int)threadIdx.x == max_idx ? ninf : 0.0;
+    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(base0, (long long)nr_raw * m * 8);
     for (int g0 = 0; g0 < ng; g0 += GB) {
         const int gb = (ng - g0) < GB ? (ng - g0) : GB;
         const int units = gb * mp * 4, u = threadIdx.x;
@@ -286,6 +322,8 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
             const int r_beg = g * GRP, r_end = (r_beg + GRP < nr) ? r_beg + GRP : nr;
             const double2 *base = reinterpret_cast<const double2 *>(base0 + 2 * pr);
             const long long ldp = m / 2;
+            const unsigned boff = (unsigned)(2 * pr) * 8u, brow = (unsigned)m * 8u;      // byte offsets for the sc1 path
+            auto ldrow = [&](int row) { return COH ? load_pair_sc1(rsrc, boff + (unsigned)row * brow) : base[(long long)row * ldp]; };
             double a0[2] = {id0, id0}, a1[2] = {id1, id1};
 #pragma unroll
             for (int j = 0; j < GRP / 8; ++j) {
@@ -296,11 +334,11 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
                     double2 x;
                     if (pair) {                         // (uniform condition; both loads unconditional)
                         const int ra = 2 * rc, rb = 2 * rc + 1 < nr_raw ? 2 * rc + 1 : ra;
-                        const double2 xa = load_pair(base + (long long)ra * ldp, COH), xb = load_pair(base + (long long)rb * ldp, COH);
+                        const double2 xa = ldrow(ra), xb = ldrow(rb);
                         const bool hb = 2 * rc + 1 < nr_raw;
                         x.x = mx0 ? fmax(xa.x, hb ? xb.x : id0) : xa.x + (hb ? xb.x : 0.0);
                         x.y = mx1 ? fmax(xa.y, hb ? xb.y : id1) : xa.y + (hb ? xb.y : 0.0);
-                    } else x = load_pair(base + (long long)rc * ldp, COH);
+                    } else x = ldrow(rc);
                     const double x0 = r < r_end ? x.x : id0, x1 = r < r_end ? x.y : id1;
                     a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
                     a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
@@ -321,7 +359,7 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < m) out_v[threadIdx.x] = run;
+    if ((int)threadIdx.x < m) row_store(out_v + threadIdx.x, run, COH);     // (COH: a block of the same launch may read the totals)
 }
 static __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
     const int v = blockIdx.x;
@@ -343,10 +381,6 @@ struct Tail2 {
     long long table;           // word offset of the (kind, parity) table inside a mailbox
     unsigned tag;
 };
-__device__ inline void row_store(double *p, double v, bool coh) {
-    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 template <int NT>
 __device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, int nr_raw, int m, int max_idx, int pair) {
     if (!t.tick) return;
@@ -586,7 +620,7 @@ __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, c
 template <int T>
 __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &mrows, int spec_expected, const double *sched,
                                    const Records &rec, Post2 *s_po, Begin2 *s_bg, double *s_vt, double *s_tot, double *s_sw, int *s_act,
-                                   long long *prof = nullptr) {
+                                   long long *prof = nullptr, bool coh_bg = false) {
     const int t = threadIdx.x;
     constexpr int NWP = sizeof(Post2) / sizeof(double);
     if (t < NWP) reinterpret_cast<double *>(s_po)[t] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[t];
@@ -623,7 +657,8 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
     K2_STAMP(prof, 3);
     const int act = *s_act;
     constexpr int NWB = sizeof(Begin2) / sizeof(double);
-    if ((act == 0 || act == 6) && blockIdx.x == 0 && t < NWB) reinterpret_cast<double *>(&ctl->bg)[t] = reinterpret_cast<const double *>(s_bg)[t];
+    // (coh_bg: the launch rewrites Ctl2::bg from other blocks later on - stage3.hpp - so no copy of it may stay dirty in this die's L2)
+    if ((act == 0 || act == 6) && blockIdx.x == 0 && t < NWB) row_store(reinterpret_cast<double *>(&ctl->bg) + t, reinterpret_cast<const double *>(s_bg)[t], coh_bg);
     return act;
 }
 
@@ -797,6 +832,62 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
     }
 }
 
+// One correction block's row (ΣW̃, ΣW̃², the (D+1)(D+2)/2 augmented pair sums) from the threads' accumulators; csum (may be null)
+// receives ΣW̃ as well (chunk sums of the selection scan).  red: T1 / 64 * 64 doubles of LDS.  All T1 threads call.
+template <int D>
+__device__ inline void k2_cm_row(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], double *red, double *out, double *csum, bool coh) {
+    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
+    constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
+    constexpr int REM = NPF - 64 * (NCH - 1);
+    constexpr int REMP = REM <= 1 ? 1 : REM <= 2 ? 2 : REM <= 4 ? 4 : REM <= 8 ? 8 : REM <= 16 ? 16 : REM <= 32 ? 32 : 64;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch < NCH - 1 || REMP == 64) {
+            double a64[64];
+#pragma unroll
+            for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
+            const double t64 = block_reduce_nw<64, NW>(a64, red);
+            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, t64, coh);
+            if (ch == 0 && threadIdx.x == 0 && csum) *csum = t64;
+        } else {
+            double ar[REMP];
+#pragma unroll
+            for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
+            const double tr = block_reduce_nw<REMP, NW>(ar, red);
+            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, tr, coh);
+            if (ch == 0 && threadIdx.x == 0 && csum) *csum = tr;
+        }
+    }
+}
+// One particle's contribution to a correction block's accumulators: incremental weight (src/smc_main.jl:401-409), W̃ = W w̃, the
+// sums of weighted_mean / weighted_cov about `sh` (particle.jl:481-483, 526-529).  Returns W̃; *inc_out = w̃.
+template <int D, class XF>
+__device__ inline double k2_cm_particle(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], XF xf, const double *sh, double loglh, double old, double wi,
+                                        double esh, double phi, double phi_prev, double pw, double logp_old, double *inc_out) {
+    constexpr int DA = D + 1;
+    const double l = loglh - esh, o = old;
+    double xx[DA];
+    xx[0] = 1.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) xx[a + 1] = xf(a) - sh[a];
+    double inc;
+    if (pw == 0.0) inc = exp((phi_prev - phi) * o + (phi - phi_prev) * l);
+    else if (pw == 1.0) inc = exp((phi - phi_prev) * l);
+    else inc = exp((phi_prev - phi) * log(exp(o - logp_old + log(1.0 - pw)) + pw) + (phi - phi_prev) * l);
+    const double v = wi * inc;
+    acc[0] += v;
+    acc[1] += v * v;
+    int q = 2;
+#pragma unroll
+    for (int a = 0; a < DA; ++a) {
+        const double wx = v * xx[a];
+#pragma unroll
+        for (int b = a; b < DA; ++b) { acc[q] += wx * xx[b]; ++q; }
+    }
+    *inc_out = inc;
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ K1: correction + moments
 // src/smc_main.jl:401-420 (incremental weights, update_weights!) fused with the sums of weighted_mean / weighted_cov
 // (particle.jl:481-483, 526-529) of the corrected cloud, as k_correct_moments - but the unnormalised weights W̃ always go to the
@@ -845,50 +936,13 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
     // (the geometry gives a thread at most two particles while the cloud is small; requesting the first one ahead of the prologue
     // was tried: the 68 accumulator pairs leave no registers to carry it, the spills inside the loop cost more than the round trip)
     for (long long i = beg + threadIdx.x; i < end; i += T1) {
-        const double l = loglh[i] - esh, o = old[i], wi = w[i];
-        double xx[DA];
-        xx[0] = 1.0;
-#pragma unroll
-        for (int a = 0; a < D; ++a) xx[a + 1] = col(cl, 0, a)[i] - sh[a];
         double inc;
-        if (pw == 0.0) inc = exp((phi_prev - phi) * o + (phi - phi_prev) * l);
-        else if (pw == 1.0) inc = exp((phi - phi_prev) * l);
-        else inc = exp((phi_prev - phi) * log(exp(o - logp_old + log(1.0 - pw)) + pw) + (phi - phi_prev) * l);
-        const double v = wi * inc;
-        acc[0] += v;
-        acc[1] += v * v;
+        const double v = k2_cm_particle<D>(acc, [&](int a) { return col(cl, 0, a)[i]; }, sh, loglh[i], old[i], w[i], esh, phi, phi_prev, pw, logp_old, &inc);
         wt[i] = v;
         if (hist) hist_w[(long long)(n - 1) * hist_ld + i] = inc * unshift;
-        int q = 2;
-#pragma unroll
-        for (int a = 0; a < DA; ++a) {
-            const double wx = v * xx[a];
-#pragma unroll
-            for (int b = a; b < DA; ++b) { acc[q] += wx * xx[b]; ++q; }
-        }
     }
     K2_STAMP(prof, 4);
-    double *out = rows_cm + (long long)blockIdx.x * pad2(NPF);
-    constexpr int REM = NPF - 64 * (NCH - 1);
-    constexpr int REMP = REM <= 1 ? 1 : REM <= 2 ? 2 : REM <= 4 ? 4 : REM <= 8 ? 8 : REM <= 16 ? 16 : REM <= 32 ? 32 : 64;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        if (ch < NCH - 1 || REMP == 64) {
-            double a64[64];
-#pragma unroll
-            for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
-            const double t64 = block_reduce_nw<64, NW>(a64, red);
-            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, t64, TAIL && tail.tick != nullptr);
-            if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = t64;
-        } else {
-            double ar[REMP];
-#pragma unroll
-            for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
-            const double tr = block_reduce_nw<REMP, NW>(ar, red);
-            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, tr, TAIL && tail.tick != nullptr);
-            if (ch == 0 && threadIdx.x == 0) csum[blockIdx.x] = tr;
-        }
-    }
+    k2_cm_row<D>(acc, red, rows_cm + (long long)blockIdx.x * pad2(NPF), csum + blockIdx.x, TAIL && tail.tick != nullptr);
     K2_STAMP(prof, 5);
     if constexpr (TAIL) tail_reduce<T1>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
     // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it
@@ -1172,7 +1226,7 @@ __device__ inline int shuffle_partner(unsigned long long seed, unsigned stage, i
 
 // jx_pre: shuffle_partner() of lane (threadIdx.x & 63), valid in wavefront 1 (threads 64..127)
 __device__ inline bool proposal2(const double *T, const double *shift, int d, int nf, int nb, double c, unsigned long long seed,
-                                 unsigned stage, const Prop2 &P, int *s_fail, int TT, int jx_pre, long long *prof = nullptr) {
+                                 unsigned stage, const Prop2 &P, int *s_fail, int TT, int jx_pre, long long *prof = nullptr, long long *prof_any = nullptr) {
     const int t = threadIdx.x, da = d + 1;
     const double sw = T[0];
     if (t == 0) *s_fail = 0;
@@ -1201,6 +1255,7 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
     }
     __syncthreads();
     K2_STAMP(prof, 4);
+    K3_STAMP_ANY(prof_any, 0);
     // R_fr[f][g] = (R[fi f][fi g] + R[fi g][fi f]) / 2 (smc_main.jl:462-465), formed where it is used
     auto sig = [&](int f, int g2) { const int a = P.fi[f], b = P.fi[g2]; return (P.covl[a * d + b] + P.covl[b * d + a]) / 2.0; };
     for (int i = t; i < nf; i += TT) {
@@ -1222,6 +1277,7 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
     }
     __syncthreads();
     K2_STAMP(prof, 5);
+    K3_STAMP_ANY(prof_any, 1);
     // Right-looking Cholesky of block b inside ONE wavefront (wave b mod 4; lane i owns row i in registers, pivots and multipliers
     // broadcast with v_readlane): same k-ascending subtraction order per entry as the oracle's left-looking loop.
     {
@@ -1251,6 +1307,7 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
     }
     __syncthreads();
     K2_STAMP(prof, 6);
+    K3_STAMP_ANY(prof_any, 2);
     return *s_fail == 0;
 }
 
@@ -1360,117 +1417,45 @@ __device__ inline void k2_bookkeeping(DevState *st, Ctl2 *ctl, const Mut2Args &m
     if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&s_ps)[tid];
 }
 
-// K2.  The mutation body is k_mutate_reg's (src/mutation.jl:56-138, helpers.jl:87-164; same arithmetic in the same order), fed
-// from LDS by the prologue instead of from DevState; it reads the particle from buffer 0 (buffer 1 on resample stages: the
-// gathered cloud) and always writes buffer 0, applies normalize_weights! (particle.jl:362-366: W̃ N / ΣW̃, two roundings; 1 after a
-// resample) to the weight column and its history, and leaves one row of RMUT sums for the next stage's begin.
-template <int D, bool ALPHA1, int T, bool TAIL>
-__global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
-                                                                               Mut2Args ma, int nb, int nf) {
+// The two likelihood descriptors as views for the mutation body; data that fits is staged in LDS (l_dat, LIK_LDS_CAP doubles) by the
+// whole block - the caller's next barrier publishes it.
+template <int T>
+__device__ inline void k2_stage_lik(const LikDev &ld0, const LikDev &ld1, double *l_par, double *l_dat, LikView (&lv)[2]) {
+    const int tid = threadIdx.x;
+    int used = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const LikDev &ld = q == 0 ? ld0 : ld1;
+        const long long nd = ld.rows * ld.cols, na = ld.aux_rows * ld.aux_cols;
+        const bool fits = ld.family >= 0 && ld.family != SMCMI_LIK_CAPM_LITERAL && used + nd + na <= LIK_LDS_CAP;   // (capm_literal reads its data as scalars)
+        if (fits) {
+            for (long long k = tid; k < nd; k += T) l_dat[used + k] = ld.data[k];
+            for (long long k = tid; k < na; k += T) l_dat[used + nd + k] = ld.aux[k];
+        }
+        lv[q] = LikView{ld.family, l_par + q * LIK_PAR_MAX, ld.c0, fits ? l_dat + used : ld.data, ld.rows, ld.cols,
+                        fits ? l_dat + used + nd : ld.aux, ld.aux_rows, ld.aux_cols};
+        if (fits) used += (int)(nd + na);
+    }
+}
+
+// The MH steps of one particle (src/mutation.jl:86-138 over steps x blocks; helpers.jl:87-164 for alpha < 1): the body K2 and the
+// persistent segment kernel (stage3.hpp) share - same arithmetic in the same order.  The proposal's arrays are in LDS (L.Lraw,
+// L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.bptr_s, L.loff_s), published by a barrier before the call; proposal 0's
+// random numbers may arrive in (step_prob, uc, z) (PREDRAW, or ma.zbuf).  ldz: leading dimension of ma.zbuf.  All threads call.
+template <int D, bool ALPHA1, int T, bool PREDRAW>
+__device__ inline void k2_mh_steps(const Mut2Lds<D> &L, double *mixbuf, int *mixpos, double *mixzt, const Mut2Args &ma, long long ldz,
+                                   const LikView (&lv)[2], const ModelView &mv, int nb, int nf, bool live, long long i, unsigned long long pid,
+                                   unsigned stage, double phi_n, double (&x)[D], double &like, double &lprior, double &like_prev, double &accept,
+                                   double &step_prob, double &uc, double (&z)[D]) {
 #pragma clang fp contract(fast)
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ Mut2Stage S;
-    const Mut2Lds<D> L(sm);
-    const int tid = threadIdx.x, n = ma.n;
-    K2_STAMP(ma.prof, 0);
-    const int n_steps = ma.n_steps;
-    const double c_alpha = ma.alpha, nrm_N = ma.n_parts;
-    const int nrm_hist = ma.store_history;
-    const LikDev &ld0 = ma.lik[0], &ld1 = ma.lik[1];
-    const int has_other = ma.has_other;
-    double *Ls = L.Ls, *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
-    double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
+    const int tid = threadIdx.x, n_steps = ma.n_steps, has_other = ma.has_other;
+    const double c_alpha = ma.alpha;
+    double *Ls = L.Ls, *Lraw = L.Lraw, *logdet_s = L.logdet_s, *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
     int *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
-    // ---- the particle (speculatively from buffer 0: only resample stages read the gathered cloud in buffer 1) and the likelihood
-    // data: none of it depends on the stage's decision, so the loads are in flight while the prologue totals rows and factorises
-    long long beg, end;
-    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, T, beg, end);
-    const long long i = beg + tid;
-    const bool live = i < end;
-    const long long il = live ? i : (end > beg ? end - 1 : 0);           // unconditional loads (clamped row)
-    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
-    double like, lprior, like_prev, accept = 0.0, wt_i;
-    double x[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
-    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
-    wt_i = ma.wt[il];
-    ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
-    LikView lv[2];
-    {
-        int used = 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const LikDev &ld = q == 0 ? ld0 : ld1;
-            const long long nd = ld.rows * ld.cols, na = ld.aux_rows * ld.aux_cols;
-            const bool fits = ld.family >= 0 && ld.family != SMCMI_LIK_CAPM_LITERAL && used + nd + na <= LIK_LDS_CAP;   // (capm_literal reads its data as scalars)
-            if (fits) {
-                for (long long k = tid; k < nd; k += T) l_dat[used + k] = ld.data[k];
-                for (long long k = tid; k < na; k += T) l_dat[used + nd + k] = ld.aux[k];
-            }
-            lv[q] = LikView{ld.family, L.l_par + q * LIK_PAR_MAX, ld.c0, fits ? l_dat + used : ld.data, ld.rows, ld.cols,
-                            fits ? l_dat + used + nd : ld.aux, ld.aux_rows, ld.aux_cols};
-            if (fits) used += (int)(nd + na);
-        }
-    }
-    // ---- the first proposal's random numbers depend on (seed, particle, stage) only: drawing them here puts ~40 % of the mutation's
-    // arithmetic under the latency of the loads above and of the prologue's row totals
-    // (512-thread blocks only: with 3 wavefronts per SIMD the 168-register budget has no room to carry them across the prologue)
-    constexpr bool PREDRAW = T == 512;
-    double step_prob, uc, z[D];
-    if (ma.zbuf) {                 // drawn ahead by K1's extra blocks: D + 2 coalesced loads
-        const double *zt = ma.zbuf + il;
-        step_prob = zt[0];
-        uc = zt[g.n];
-#pragma unroll
-        for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * g.n];
-    } else if constexpr (PREDRAW) draw2<D>(ma.seed, pid, (unsigned)n, 0u, nb == 1 ? nf : (nf + nb - 1) / nb, ma.debug, step_prob, uc, z);
-    int rs = 0;
-    double phi_n, e_center, nrm_sumw;
-    if (ma.pre) {
-        // decision and proposal from k2_prepare: model constants + the proposal's arrays into LDS, one barrier
-        const Prop2Glob *G = ma.pre;
-        const int pstage = G->stage, pgo = G->go;
-        rs = G->rs; nrm_sumw = G->s1; phi_n = G->phi_n; e_center = G->e_center;
-        for (int k = tid; k < D; k += T) {
-            L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
-            L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
-        }
-        for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
-        for (int e = tid; e < nf * nf; e += T) Lraw[e] = G->Lraw[e];
-        for (int e = tid; e < nf; e += T) { mub_raw[e] = G->mub[e]; sdd_raw[e] = G->sdd[e]; sdn_raw[e] = G->sdn[e]; ball_raw[e] = G->ball[e]; }
-        for (int b = tid; b < nb; b += T) { loff_s[b] = G->loff[b]; logdet_s[b] = G->logdet[b]; }
-        for (int b = tid; b <= nb; b += T) bptr_s[b] = G->bptr[b];
-        if (pstage != n || !pgo) return;
-        __syncthreads();
-    } else {
-        if (!k2_prologue<D, T>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;
-        phi_n = S.bg.phi_n; e_center = S.bg.e_center; nrm_sumw = L.s_tot[0];
-    }
-    const unsigned stage = (unsigned)n;
-    if (rs) {                       // the resampled cloud is in buffer 1 (k2_gather)
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = col(cl, 1, k)[il];
-        like = col(cl, 1, D)[il]; lprior = col(cl, 1, D + 1)[il]; like_prev = col(cl, 1, D + 2)[il];
-    }
-    double w_part = 0.0;
-    if (live) {
-        w_part = rs ? 1.0 : (wt_i * nrm_N) / nrm_sumw;                      // W·N then /ΣW̃, two roundings like the reference
-        col(cl, 0, D + 4)[i] = w_part;
-        if (ma.hist_W && nrm_hist) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = w_part;
-    } else {
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = 0.0;
-        like = lprior = like_prev = 0.0;
-    }
     auto XN = [&](int k) { return x[k]; };
-    __shared__ double mixbuf[ALPHA1 ? 1 : MixDense<D>::DOUBLES + D * D];
-    __shared__ int mixpos[ALPHA1 ? 1 : D];
-    __shared__ double mixzt[ALPHA1 ? 1 : T * D];               // private z columns of the diagonal component's draw
     const MixDense<D> MX(mixbuf, mixpos);
     double *Wraw = mixbuf + (ALPHA1 ? 0 : MixDense<D>::DOUBLES);
     if constexpr (!ALPHA1) mix_invert_factors<D, T>(Lraw, Wraw, loff_s, bptr_s, nb, tid);     // (prologue / pre-load ended with a barrier)
-    K2_STAMP(ma.prof, 8);
     for (int step = 0; step < n_steps; ++step) {
         for (int b = 0; b < nb; ++b) {
             if ((nb > 1 || step == 0) && (step | b) != 0) __syncthreads();   // previous block's readers (the prologue ends with a barrier)
@@ -1492,11 +1477,11 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
             const unsigned t = (unsigned)(step * nb + b);
             if (ma.zbuf) {
                 if (t != 0) {
-                    const double *zt = ma.zbuf + (long long)t * (D + 2) * g.n + i;
+                    const double *zt = ma.zbuf + (long long)t * (D + 2) * ldz + i;
                     step_prob = zt[0];
-                    uc = zt[g.n];
+                    uc = zt[ldz];
 #pragma unroll
-                    for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * g.n];
+                    for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * ldz];
                 }
             } else if (!PREDRAW || t != 0) draw2<D>(ma.seed, pid, stage, t, db, ma.debug, step_prob, uc, z);   // (proposal 0 may have been drawn ahead of the prologue)
             double prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
@@ -1554,6 +1539,139 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
             }
         }
     }
+}
+
+// One mutation block's row for the next stage's begin (energy power sums on adaptive schedules, Σ accept, energy maximum) from the
+// particles' post-mutation values; scratch: T / 64 * ES doubles of LDS (the likelihood data is dead by now), red: 8 doubles.
+// coh: the row is totalled inside this launch (Tail2 / stage3.hpp).  All threads call; starts and ends with a barrier.
+template <int T>
+__device__ inline void k2_mut_row(double *row, bool adaptive, double like, double like_prev, double w_part, double acc_val, double e_center, bool live,
+                                  bool rs, double *scratch, double *red, bool coh) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    double em = energy_or_ninf(like, like_prev, rs ? 1.0 : w_part, live);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
+    __shared__ double emx[T / 64];
+    if ((tid & 63) == 0) emx[tid >> 6] = em;
+    if (adaptive) {
+        double es[ES];
+        energy_terms(es, w_part, like, like_prev, e_center, live, rs);
+        es[EACC] = acc_val;
+        const double tot = block_reduce_es2<T / 64>(es, scratch);
+        if (tid < ES) row_store(row + tid, tot, coh);
+    } else {
+        double a1[1] = {acc_val};
+        Butterfly<0, 32>::run(a1, tid & 63);
+        if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+        __syncthreads();
+        if (tid < ES) {
+            double sacc = ((red[0] + red[1]) + red[2]) + red[3];
+            if constexpr (T == 512) sacc += ((red[4] + red[5]) + red[6]) + red[7];
+            row_store(row + tid, tid == EACC ? sacc : 0.0, coh);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double m = emx[0];
+#pragma unroll
+        for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
+        row_store(row + RMAX_IDX, m, coh);
+    }
+}
+
+// K2.  The mutation body is k_mutate_reg's (src/mutation.jl:56-138, helpers.jl:87-164; same arithmetic in the same order), fed
+// from LDS by the prologue instead of from DevState; it reads the particle from buffer 0 (buffer 1 on resample stages: the
+// gathered cloud) and always writes buffer 0, applies normalize_weights! (particle.jl:362-366: W̃ N / ΣW̃, two roundings; 1 after a
+// resample) to the weight column and its history, and leaves one row of RMUT sums for the next stage's begin.
+template <int D, bool ALPHA1, int T, bool TAIL>
+__global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
+                                                                               Mut2Args ma, int nb, int nf) {
+#pragma clang fp contract(fast)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ Mut2Stage S;
+    const Mut2Lds<D> L(sm);
+    const int tid = threadIdx.x, n = ma.n;
+    K2_STAMP(ma.prof, 0);
+    const double nrm_N = ma.n_parts;
+    const int nrm_hist = ma.store_history;
+    const LikDev &ld0 = ma.lik[0], &ld1 = ma.lik[1];
+    double *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
+    double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
+    int *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
+    // ---- the particle (speculatively from buffer 0: only resample stages read the gathered cloud in buffer 1) and the likelihood
+    // data: none of it depends on the stage's decision, so the loads are in flight while the prologue totals rows and factorises
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, T, beg, end);
+    const long long i = beg + tid;
+    const bool live = i < end;
+    const long long il = live ? i : (end > beg ? end - 1 : 0);           // unconditional loads (clamped row)
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double like, lprior, like_prev, accept = 0.0, wt_i;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
+    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
+    wt_i = ma.wt[il];
+    ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
+    LikView lv[2];
+    k2_stage_lik<T>(ld0, ld1, L.l_par, l_dat, lv);
+    // ---- the first proposal's random numbers depend on (seed, particle, stage) only: drawing them here puts ~40 % of the mutation's
+    // arithmetic under the latency of the loads above and of the prologue's row totals
+    // (512-thread blocks only: with 3 wavefronts per SIMD the 168-register budget has no room to carry them across the prologue)
+    constexpr bool PREDRAW = T == 512;
+    double step_prob, uc, z[D];
+    if (ma.zbuf) {                 // drawn ahead by K1's extra blocks: D + 2 coalesced loads
+        const double *zt = ma.zbuf + il;
+        step_prob = zt[0];
+        uc = zt[g.n];
+#pragma unroll
+        for (int e = 0; e < D; ++e) z[e] = zt[(long long)(2 + e) * g.n];
+    } else if constexpr (PREDRAW) draw2<D>(ma.seed, pid, (unsigned)n, 0u, nb == 1 ? nf : (nf + nb - 1) / nb, ma.debug, step_prob, uc, z);
+    int rs = 0;
+    double phi_n, e_center, nrm_sumw;
+    if (ma.pre) {
+        // decision and proposal from k2_prepare: model constants + the proposal's arrays into LDS, one barrier
+        const Prop2Glob *G = ma.pre;
+        const int pstage = G->stage, pgo = G->go;
+        rs = G->rs; nrm_sumw = G->s1; phi_n = G->phi_n; e_center = G->e_center;
+        for (int k = tid; k < D; k += T) {
+            L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
+            L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
+        }
+        for (int k = tid; k < 2 * LIK_PAR_MAX; k += T) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
+        for (int e = tid; e < nf * nf; e += T) Lraw[e] = G->Lraw[e];
+        for (int e = tid; e < nf; e += T) { mub_raw[e] = G->mub[e]; sdd_raw[e] = G->sdd[e]; sdn_raw[e] = G->sdn[e]; ball_raw[e] = G->ball[e]; }
+        for (int b = tid; b < nb; b += T) { loff_s[b] = G->loff[b]; logdet_s[b] = G->logdet[b]; }
+        for (int b = tid; b <= nb; b += T) bptr_s[b] = G->bptr[b];
+        if (pstage != n || !pgo) return;
+        __syncthreads();
+    } else {
+        if (!k2_prologue<D, T>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;
+        phi_n = S.bg.phi_n; e_center = S.bg.e_center; nrm_sumw = L.s_tot[0];
+    }
+    const unsigned stage = (unsigned)n;
+    if (rs) {                       // the resampled cloud is in buffer 1 (k2_gather)
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = col(cl, 1, k)[il];
+        like = col(cl, 1, D)[il]; lprior = col(cl, 1, D + 1)[il]; like_prev = col(cl, 1, D + 2)[il];
+    }
+    double w_part = 0.0;
+    if (live) {
+        w_part = rs ? 1.0 : (wt_i * nrm_N) / nrm_sumw;                      // W·N then /ΣW̃, two roundings like the reference
+        col(cl, 0, D + 4)[i] = w_part;
+        if (ma.hist_W && nrm_hist) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = w_part;
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = 0.0;
+        like = lprior = like_prev = 0.0;
+    }
+    __shared__ double mixbuf[ALPHA1 ? 1 : MixDense<D>::DOUBLES + D * D];
+    __shared__ int mixpos[ALPHA1 ? 1 : D];
+    __shared__ double mixzt[ALPHA1 ? 1 : T * D];               // private z columns of the diagonal component's draw
+    K2_STAMP(ma.prof, 8);
+    k2_mh_steps<D, ALPHA1, T, PREDRAW>(L, mixbuf, mixpos, mixzt, ma, g.n, lv, mv, nb, nf, live, i, pid, stage, phi_n, x, like, lprior, like_prev, accept,
+                                       step_prob, uc, z);
     K2_STAMP(ma.prof, 9);
     double acc_val = 0.0;
     if (live) {
@@ -1571,37 +1689,8 @@ __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, D
         col(cl, 0, D + 3)[i] = acc_val;
     }
     // ---- this block's row for the next stage's begin: energy power sums (adaptive schedules), Σ accept, energy maximum
-    __syncthreads();
-    double em = energy_or_ninf(like, like_prev, rs ? 1.0 : w_part, live);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) em = fmax(em, __shfl_xor(em, off, 64));
-    __shared__ double emx[T / 64];
-    if ((tid & 63) == 0) emx[tid >> 6] = em;
-    double *row = ma.rows_mut + (long long)blockIdx.x * RMUT;
-    if (ma.adaptive) {
-        double es[ES];
-        energy_terms(es, w_part, like, like_prev, e_center, live, rs != 0);
-        es[EACC] = acc_val;
-        const double tot = block_reduce_es2<T / 64>(es, l_dat);      // likelihood data in LDS is dead by now
-        if (tid < ES) row_store(row + tid, tot, TAIL && ma.tail.tick != nullptr);
-    } else {
-        double a1[1] = {acc_val};
-        Butterfly<0, 32>::run(a1, tid & 63);
-        if ((tid & 63) == 0) red[tid >> 6] = a1[0];
-        __syncthreads();
-        if (tid < ES) {
-            double sacc = ((red[0] + red[1]) + red[2]) + red[3];
-            if constexpr (T == 512) sacc += ((red[4] + red[5]) + red[6]) + red[7];
-            row_store(row + tid, tid == EACC ? sacc : 0.0, TAIL && ma.tail.tick != nullptr);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double m = emx[0];
-#pragma unroll
-        for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
-        row_store(row + RMAX_IDX, m, TAIL && ma.tail.tick != nullptr);
-    }
+    k2_mut_row<T>(ma.rows_mut + (long long)blockIdx.x * RMUT, ma.adaptive != 0, like, like_prev, w_part, acc_val, e_center, live, rs != 0, l_dat, red,
+                  TAIL && ma.tail.tick != nullptr);
     K2_STAMP(ma.prof, 10);
     if constexpr (TAIL) tail_reduce<T>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, T == 256 ? 1 : 0);
     if (blockIdx.x == 0 && !ma.pre) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);

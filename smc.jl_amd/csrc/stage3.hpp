@@ -1,1 +1,423 @@
-// stage3.hpp - engine 3 (persistent stage segments); see DESIGN.md
+// stage3.hpp - engine 3: persistent stage segments for small clouds on one handle (n_para <= 10, one 512-particle block per CU).
+//
+// Engine 2 (stage2.hpp) pays, per tempering stage (src/smc_main.jl:377-508), two launch boundaries, two kernel starts, the reload of
+// the cloud from HBM / MALL and, in EVERY block, the serial set-up between the hand-overs (row totals, Newton solve of ϕ_n,
+// covariance -> Cholesky): 44 µs per stage at N = 1e5 of which 9 are the bodies.  A run of consecutive stages that neither resample
+// nor need the certificate path (95 % of an adaptive run) is ONE launch here:
+//
+//   * every thread keeps its particle (θ, loglh, logprior, old_loglh, weight) in registers for the whole segment - HBM sees only the
+//     history columns and one row per block and phase;
+//   * the two chip-wide hand-overs of a stage are tickets, not launches: a block stores its row (the same row, bit for bit, K1 / K2
+//     of engine 2 would store for the same 512 particles), takes a ticket of its virtual shard; the last block of a virtual shard
+//     totals the shard's rows (canonical order, reduce_vshard), the last of those totals the V shard totals and does the stage's
+//     scalar work ONCE - decision + proposal (covariance, blocks, Cholesky) after the correction, ϕ_{n+1} (Newton) after the mutation
+//     - and publishes the result as a record of tagged 8-byte granules {32-bit payload | 32-bit tag}: a reader that sees the tag
+//     has the payload, no fence, no flag (the mailbox's wire format, agent scope here);
+//   * the other blocks draw the stage's random numbers while they wait (they depend on (seed, particle, stage) only), so ~40 % of
+//     the mutation's arithmetic hides under the hand-over.
+//
+// Rows, totals, decision logic (begin2_wave, decide2, post2, proposal2) and the MH body (k2_mh_steps) are engine 2's own functions:
+// a segment leaves the bits engine 2's launches would leave, and the two engines alternate freely inside a run - the segment ends
+// (state in memory exactly as between two engine-2 stages: cloud in buffer 0, mutation rows, Post2 / Begin2 in Ctl2) when its last
+// stage is done or as soon as a stage needs what it cannot do (selection, a certificate pass, the end of the run); the host then
+// runs that stage through engine 2's launches and starts the next segment.  Blocks never straddle a virtual shard and every block
+// is resident for the whole launch (grid <= one block per CU), so a waiting block can only wait for blocks that are running;
+// every wait is bounded (time-out -> SMCMI_ERR_TIMEOUT, never a hung GPU).
+#pragma once
+#include "stage2.hpp"
+
+namespace smcmi {
+
+constexpr int T3 = 512;                      // threads = particles of a block
+constexpr int TICK3_STRIDE = 32;             // ints between ticket counters: one 128-byte line each (the arrivals of different shards do not queue behind each other)
+constexpr int SEG3_TICKS = (V2_MAXV + 1) * TICK3_STRIDE;      // per kind: one ticket counter per local virtual shard + the top one
+
+// ---- records: tagged granules in device memory (one writer block, every block reads)
+struct RecA3 {                               // after the mutation of stage n - 1: how stage n begins
+    int act, pad;                            // 0 go on with stage bg.stage; 1 / 5 / 9 / 4: begin2_wave's codes (status written); 7: segment complete
+    Begin2 bg;
+};
+template <int D>
+struct Prop3 {                               // the proposal of a stage (what proposal2 leaves in LDS)
+    double Lraw[D * D], logdet[D], mub[D], sdd[D], sdn[D];
+    int ball[D + (D & 1)], bptr[D + 2 + (D & 1)], loff[D + (D & 1)];
+};
+template <int D>
+struct RecB3 {                               // after the correction of stage n: go (Post2 of n + proposal) or leave the segment
+    int act, pad;                            // 0 go; 6 the stage needs the full path (selection / unverified prediction): nothing of it is committed; 9 error
+    Post2 po;
+    Prop3<D> pr;
+};
+static_assert(sizeof(RecA3) % 4 == 0 && sizeof(RecB3<10>) % 4 == 0, "records are copied as 32-bit words");
+constexpr size_t REC3_WORDS = (sizeof(RecA3) + sizeof(RecB3<10>)) / 4 + 16;       // granules a handle allocates (RecA at 0, RecB behind it)
+constexpr int REC3_B_OFF = (int)(sizeof(RecA3) / 4) + 4;
+
+__device__ inline void rec3_publish(unsigned long long *rec, const void *src_lds, int nwords, unsigned tag) {
+    const unsigned *w = reinterpret_cast<const unsigned *>(src_lds);
+    for (int k = threadIdx.x; k < nwords; k += blockDim.x)
+        __hip_atomic_store(rec + k, ((unsigned long long)tag << 32) | (unsigned long long)w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all threads call; false: a wait timed out (flag words `to` as the mailbox's: to[0] sticky flag, to[1] ticks).
+// ONE lane of the block polls (word 0, with a sleep between probes): seventy thousand threads probing the same two dozen cache lines
+// would queue every other memory access of the chip - the deciding block's included - behind their probes.  When word 0 is there the
+// rest is at most a store queue behind it: every thread then fetches its own words, probing again in the rare case one is not there yet.
+__device__ inline bool rec3_wait(const unsigned long long *rec, void *dst_lds, int nwords, unsigned tag, unsigned long long *to, int *s_to) {
+    unsigned *w = reinterpret_cast<unsigned *>(dst_lds);
+    auto probe = [&](int k, int nap) -> unsigned long long {
+        unsigned long long a = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a >> 32) != tag) {
+            const long long t0 = wall_clock64();
+            const long long lim = (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            do {
+                if (nap) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(1);
+                a = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(a >> 32) == tag) break;
+                if (wall_clock64() - t0 > lim || __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *s_to = 1;
+                    break;
+                }
+            } while (true);
+        }
+        return a;
+    };
+    if (threadIdx.x == 0) w[0] = (unsigned)probe(0, 1);
+    __syncthreads();
+    if (*s_to) return false;
+    for (int k = threadIdx.x; k < nwords; k += blockDim.x)
+        if (k != 0) w[k] = (unsigned)probe(k, 0);
+    __syncthreads();
+    return *s_to == 0;
+}
+
+// Two-level ticket behind a stored row (see Tail2 / tail_reduce in stage2.hpp for the memory-ordering argument): true in the ONE block
+// that arrives last of all; it then holds the V x m totals of all local virtual shards in vt (agent-scope stores by their totalling
+// blocks, read with agent-scope loads below).  tick: SEG3_TICKS counters, zero between uses.
+template <int NT>
+__device__ inline bool seg3_arrive(int *tick, const double *rows, double *vt, int v, int Vl, int nr, int m, int max_idx, long long *prof = nullptr) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&tick[v * TICK3_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr - 1;
+    __syncthreads();
+    if (!s_last) return false;
+    K3_STAMP_ANY(prof, 0);
+    reduce_vshard<NT, true>(rows + (long long)v * nr * m, nr, m, max_idx, vt + (long long)v * m, 0);
+    K3_STAMP_ANY(prof, 1);
+    if (threadIdx.x == 0) __hip_atomic_store(&tick[v * TICK3_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&tick[V2_MAXV * TICK3_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == Vl - 1;
+    __syncthreads();
+    if (!s_last) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(&tick[V2_MAXV * TICK3_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+// totals over the nvs virtual shards in the order of reduce_rows (0 + x_0 + x_1 + ...; maximum for max_idx); ends with a barrier
+__device__ inline void seg3_totals(const double *vt, int nvs, int m, int max_idx, double *tot) {
+    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(vt, (long long)V2_MAXV * m * 8);
+    for (int k = threadIdx.x; k < m; k += blockDim.x) {
+        const bool mx = k == max_idx;
+        double xs[V2_MAXV];
+#pragma unroll
+        for (int v = 0; v < V2_MAXV; ++v)                         // every load in flight before the first use (unconditional, clamped)
+            xs[v] = load_f64_sc1(rsrc, (unsigned)((v < nvs ? v : nvs - 1) * m + k) * 8u);
+        double t = mx ? -__builtin_inf() : 0.0;
+#pragma unroll
+        for (int v = 0; v < V2_MAXV; ++v)
+            if (v < nvs) t = mx ? fmax(t, xs[v]) : t + xs[v];
+        tot[k] = t;
+    }
+    __syncthreads();
+}
+
+// Residency self-test of a handle's segment geometry (first use): `grid` blocks of T3 threads with enough LDS that a CU holds ONE of
+// them - the strictest placement the segment kernel can get - take a ticket; the last publishes a granule every block waits for
+// (bounded).  ok counts the blocks that saw it: anything but `grid` (or a raised time-out flag) keeps the handle on engine 2.
+static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned long long *rec, unsigned tag, unsigned long long *to, int *ok) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_to;
+    __shared__ unsigned s_w[2];
+    if (threadIdx.x == 0) { s_to = 0; sm[0] = 1.0; }
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&tick[V2_MAXV * TICK3_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(&tick[V2_MAXV * TICK3_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec, ((unsigned long long)tag << 32) | 0x5e6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool good = rec3_wait(rec, s_w, 1, tag, to, &s_to);
+    if (threadIdx.x == 0 && good && s_w[0] == 0x5e6u) atomicAdd(ok, 1);
+}
+
+constexpr size_t k3_park_offset(int D) { return (k2_lds_bytes(D) + 15) / 16 * 2; }          // in doubles, 16-byte aligned
+constexpr size_t k3_lds_bytes(int D) { return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double); }
+template <int D>
+__device__ inline void k3_draw_park(double *z_park, unsigned long long seed, unsigned long long pid, unsigned stage, int db, int debug) {
+    double step_prob, uc, z[D];
+    draw2<D>(seed, pid, stage, 0u, db, debug, step_prob, uc, z);
+    double *p = z_park + threadIdx.x;
+    p[0] = step_prob;
+    p[T3] = uc;
+#pragma unroll
+    for (int e = 0; e < D; ++e) p[(2 + e) * T3] = z[e];
+}
+
+struct Seg3Args {
+    int n_first, n_last;           // stages this launch may run
+    Rows2 mrows;                   // mutation rows of stage n_first - 1 (direct view: every block totals them for the first begin)
+    const double *sched;
+    double *rows_cm, *vt_cm, *vt_mut;   // correction rows [blocks][pad2(NPF)]; per-virtual-shard totals [Vl][m] (rows_mut: Mut2Args)
+    int *tick;                     // [2][SEG3_TICKS]: correction / mutation
+    unsigned long long *rec;       // REC3_WORDS granules
+    unsigned tag_base;             // launch sequence << 16 (never reused inside a handle's life without clearing the records)
+    unsigned long long *to;        // time-out flag words
+    double *hist_w;
+    long long hist_ld;
+    int *done_out;                 // non-null: number of stages this launch completed (profiling)
+    long long *prof;               // development only (SMCMI_PROF2=<stage>): stamps of that stage
+    int prof_stage;
+};
+
+#define K3_STAMP(prof, slot)                                                                                                   \
+    do {                                                                                                                      \
+        if ((prof) != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && n == sa.prof_stage) {                                                        \
+            unsigned long long tt_;                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");       \
+            (prof)[(slot)] = (long long)tt_;                                                                                   \
+        }                                                                                                                     \
+    } while (0)
+
+// grid = g.Vl * g.nb2 blocks of T3 threads, every one resident; block b owns block (b / Vl) of local virtual shard (b % Vl): with the
+// hardware's round-robin of consecutive blocks over the 8 XCDs a virtual shard's blocks share an XCD (its rows are totalled out of
+// that die's L2 / MALL path) - placement is speed only, never correctness.
+// (the shader clocks of different XCDs have different origins: the deciding blocks' stamps are comparable with block 0's on XCD 0 only)
+#define K3_STAMP_D(prof, slot)                                                                                                 \
+    do {                                                                                                                      \
+        if ((prof) != nullptr && threadIdx.x == 0 && (blockIdx.x & 7) == 0 && n == sa.prof_stage) {                            \
+            unsigned long long tt_;                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");       \
+            (prof)[(slot)] = (long long)tt_;                                                                                   \
+        }                                                                                                                     \
+    } while (0)
+template <int D, bool ALPHA1>
+__global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
+    constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
+    constexpr int WA = sizeof(RecA3) / 4, WB = sizeof(RecB3<D>) / 4;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ RecA3 s_a;
+    __shared__ RecB3<D> s_b[2];                                 // [n & 1]: Post2 of stage n lives on as "Post2 of n - 1" during stage n + 1
+    __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[pad2(NPF) > RMUT ? pad2(NPF) : RMUT], s_sw[64];
+    __shared__ double red[(T3 / 64) * 64];
+    __shared__ int s_act, s_to, s_fail;
+    __shared__ double s_cfac;
+    __shared__ double mixbuf[ALPHA1 ? 1 : MixDense<D>::DOUBLES + D * D];
+    __shared__ int mixpos[ALPHA1 ? 1 : D];
+    __shared__ double mixzt[ALPHA1 ? 1 : T3 * D];
+    Mut2Lds<D> L(sm);
+    const int tid = threadIdx.x;
+    // the first proposal's random numbers of the NEXT stage, drawn while the block waits for that stage's begin (they depend on (seed,
+    // particle, stage) only) and parked here, slot-major: z_park[slot * T3 + tid], slots = MH uniform, mixture uniform, D normals
+    double *z_park = sm + k3_park_offset(D);
+    const int vl = (int)blockIdx.x % g.Vl, r = (int)blockIdx.x / g.Vl, rowi = vl * g.nb2 + r;       // row index = engine 2's block index
+    // ---- run constants and the particle
+    __shared__ RunParams s_rp;                                  // (by value in registers it costs ~40 SGPRs for the whole launch)
+    if (tid == 0) s_rp = st->rp;
+    __syncthreads();
+    const RunParams &rp = s_rp;
+    const double pw = rp.pw, logp_old = rp.logp_old, nrm_N = ma.n_parts;
+    const bool hist = rp.store_history && sa.hist_w != nullptr;
+    long long beg, end;
+    vchunk(g, vl, r, T3, beg, end);
+    const long long i = beg + tid;
+    const bool live = i < end;
+    const long long il = live ? i : (end > beg ? end - 1 : 0);
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double x[D], like, lprior, like_prev, W, acc_val;
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
+    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
+    acc_val = col(cl, 0, D + 3)[il]; W = col(cl, 0, D + 4)[il];
+    if (!live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = 0.0;
+        like = lprior = like_prev = 0.0;
+    }
+    for (int k = tid; k < D; k += T3) {
+        L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
+        L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
+    }
+    for (int k = tid; k < 2 * LIK_PAR_MAX; k += T3) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
+    if (tid < nf) L.fi[tid] = md->free_inds[tid];
+    if (tid == 0) s_to = 0;
+    ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
+    LikView lv[2];
+    k2_stage_lik<T3>(ma.lik[0], ma.lik[1], L.l_par, L.l_dat, lv);     // once per segment (the mutation rows' scratch is `red`, not this area)
+    int n = sa.n_first;
+    const int db0 = nb == 1 ? nf : (nf + nb - 1) / nb;          // entries of the first random block
+    // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left
+    {
+        const int act = begin2_block<T3>(n, st, ctl, sa.mrows, 1, sa.sched, ma.rec, &s_b[(n - 1) & 1].po, &s_a.bg, s_vt, s_tot, s_sw, &s_act, nullptr, true);
+        if (act != 0) return;                                   // nothing was touched: the cloud in memory is current
+        if (tid == 0) {
+            const double a = s_a.bg.accept, tg = rp.target;
+            s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
+            s_a.bg.cfac = s_cfac;
+        }
+        k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
+        __syncthreads();
+    }
+    int done = 0;
+    bool timed_out = false;
+    for (;; ++n) {
+        K3_STAMP(sa.prof, 1);
+        RecB3<D> &B = s_b[n & 1];
+        const Post2 &po = s_b[(n - 1) & 1].po;                  // stage n - 1 as completed
+        const unsigned tag = sa.tag_base | (unsigned)n;
+        // the proposal arrays of THIS stage (written by proposal2 in the deciding block, by rec3_wait elsewhere)
+        L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
+        L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
+        // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
+        const double phi = s_a.bg.phi_n, phi_prev = s_a.bg.phi_prev, esh = pw == 0.0 ? s_a.bg.e_shift : 0.0, e_center = s_a.bg.e_center;
+        double v = 0.0;
+        {
+            constexpr int NCH = (NPF + 63) / 64;
+            double acc[NCH * 64];
+#pragma unroll
+            for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+            if (live) {
+                double inc;
+                v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, W, esh, phi, phi_prev, pw, logp_old, &inc);
+                if (hist) {
+                    const double unshift = exp((phi - phi_prev) * esh);
+                    sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                }
+            }
+            k2_cm_row<D>(acc, red, sa.rows_cm + (long long)rowi * MCM, nullptr, true);
+        }
+        const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;
+        K3_STAMP(sa.prof, 2);
+        if (seg3_arrive<T3>(sa.tick, sa.rows_cm, sa.vt_cm, vl, g.Vl, g.nb2, MCM, -1, (sa.prof && vl == 0 && n == sa.prof_stage) ? sa.prof + 14 : nullptr)) {
+            // ---- the one deciding block: totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
+            K3_STAMP_D(sa.prof, 10);
+            seg3_totals(sa.vt_cm, g.Vl, MCM, -1, s_tot);
+            K3_STAMP_D(sa.prof, 11);
+            double ess;
+            const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+            if (dec != 0) {
+                if (tid == 0) {
+                    B.act = dec < 0 ? 9 : 6; B.pad = 0;
+                    if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
+                    ctl->status.stage = n;
+                    ctl->status.code = dec < 0 ? 9 : (dec == 4 ? 4 : 6);
+                }
+                __syncthreads();
+                rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);          // (whole record: readers wait for all of it once)
+            } else {
+                if (tid == T3 - 64) {                                    // (the last wavefront: the logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
+                    B.act = 0; B.pad = 0;
+                    post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, 0, &B.po);
+                }
+                Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
+                const bool ok = proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr, (sa.prof && (blockIdx.x & 7) == 0 && n == sa.prof_stage) ? sa.prof + 30 : nullptr);
+                if (!ok) {
+                    if (tid == 0) { B.act = 9; ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
+                    __syncthreads();
+                    rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);
+                } else {
+                    if (tid < D) B.po.shift[tid] = L.mean_s[tid];
+                    __syncthreads();
+                    K3_STAMP_D(sa.prof, 12);
+                    rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);
+                    K3_STAMP_D(sa.prof, 13);
+                    // bookkeeping nobody in this launch waits for: Ctl2 / records / diagnostics (k2_bookkeeping)
+                    if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = 0; ma.rec.c[n - 1] = B.po.c; }
+                    // (write-through: the deciding block changes from stage to stage and with it the die whose L2 would hold these
+                    // words dirty - two dies' copies of one word would reach memory in no particular order at the end of the launch)
+                    if (tid < D) row_store(&st->mean[tid], L.mean_s[tid], true);
+                    for (int e = tid; e < D * D; e += T3) row_store(&st->cov[e], L.covl[e], true);
+                    constexpr int NWP = sizeof(Post2) / sizeof(double);
+                    if (tid < NWP) row_store(reinterpret_cast<double *>(&ctl->ps[n & 1]) + tid, reinterpret_cast<const double *>(&B.po)[tid], true);
+                }
+            }
+        }
+        // ---- everybody: the record
+        K3_STAMP(sa.prof, 3);
+        if (!rec3_wait(sa.rec + REC3_B_OFF, &B, WB, tag, sa.to, &s_to)) { timed_out = true; break; }
+        if (B.act != 0) break;                                  // leave: registers hold the cloud after stage n - 1
+        K3_STAMP(sa.prof, 4);
+        // ================= mutation (src/mutation.jl:56-138): normalize_weights!, the MH steps, one row per block
+        const double phi_n = B.po.phi_n, nrm_sumw = B.po.sumw;
+        double accept = 0.0;
+        double step_prob, uc, z[D];
+        {
+            const double *p = z_park + tid;                     // (written by this thread)
+            step_prob = p[0];
+            uc = p[T3];
+#pragma unroll
+            for (int e = 0; e < D; ++e) z[e] = p[(2 + e) * T3];
+        }
+        if (live) {
+            W = (v * nrm_N) / nrm_sumw;                         // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366)
+            if (ma.hist_W && ma.store_history) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = W;
+        }
+        k2_mh_steps<D, ALPHA1, T3, true>(L, mixbuf, mixpos, mixzt, ma, g.n, lv, mv, nb, nf, live, i, pid, (unsigned)n, phi_n, x, like, lprior, like_prev, accept,
+                                         step_prob, uc, z);
+        if (live) acc_val = accept / (double)nf;                // quirk Q2: normalised by n_free only
+        K3_STAMP(sa.prof, 5);
+        k2_mut_row<T3>(ma.rows_mut + (long long)rowi * RMUT, ma.adaptive != 0, like, like_prev, live ? W : 0.0, live ? acc_val : 0.0, e_center, live, false,
+                       red, L.red, true);
+        ++done;
+        // the window of the proposed schedule the next begin walks (index from Post2 of THIS stage, in LDS since the record arrived)
+        double swv = 2.0;
+        if (tid < 64) {
+            const int jj = B.po.j - 1 + tid;
+            if (!rp.use_fixed_schedule && jj >= 0 && jj < rp.n_phi) swv = sa.sched[jj];
+        }
+        const double inv_pre = INV_FACTORIAL[tid & 31];
+        K3_STAMP(sa.prof, 6);
+        if (seg3_arrive<T3>(sa.tick + SEG3_TICKS, ma.rows_mut, sa.vt_mut, vl, g.Vl, g.nb2, RMUT, RMAX_IDX, (sa.prof && vl == 0 && n == sa.prof_stage) ? sa.prof + 24 : nullptr)) {
+            // ---- the one deciding block: totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
+            K3_STAMP_D(sa.prof, 20);
+            seg3_totals(sa.vt_mut, g.Vl, RMUT, RMAX_IDX, s_tot);
+            K3_STAMP_D(sa.prof, 21);
+            if (tid == 0) { s_act = 7; s_a.pad = 0; }
+            if (tid < 64) s_sw[tid] = swv;
+            if (n < sa.n_last) {
+                if (tid < 64) {
+                    const int act = begin2_wave(n + 1, B.po, rp, s_tot, s_tot[RMAX_IDX], true, 1, sa.sched, s_sw, &s_a.bg, &st->sol[0], true, ma.rec,
+                                                &ctl->status, inv_pre);
+                    if (tid == 0) s_act = act;
+                } else if (tid == 64) {
+                    // the step-size multiplier of stage n + 1 (smc_main.jl:453-455) from the acceptance rate begin2_wave folds
+                    const double a = s_tot[EACC] / (double)rp.n_parts, tg = rp.target;
+                    s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { s_a.act = s_act; if (s_act == 0) s_a.bg.cfac = s_cfac; }
+            __syncthreads();
+            K3_STAMP_D(sa.prof, 22);
+            rec3_publish(sa.rec, &s_a, WA, sa.tag_base | (unsigned)(n + 1));
+            K3_STAMP_D(sa.prof, 23);
+            constexpr int NWB = sizeof(Begin2) / sizeof(double);
+            if (s_a.act == 0 && tid < NWB) row_store(reinterpret_cast<double *>(&ctl->bg) + tid, reinterpret_cast<const double *>(&s_a.bg)[tid], true);
+        }
+        K3_STAMP(sa.prof, 7);
+        if (n < sa.n_last) k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
+        if (!rec3_wait(sa.rec, &s_a, WA, sa.tag_base | (unsigned)(n + 1), sa.to, &s_to)) { timed_out = true; break; }
+        if (s_a.act != 0) break;                                // leave: registers hold the cloud after stage n
+        K3_STAMP(sa.prof, 8);
+    }
+    // ---- the cloud goes back to buffer 0 as the last completed stage left it
+    if (live && !timed_out) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = x[k];
+        col(cl, 0, D)[i] = like; col(cl, 0, D + 1)[i] = lprior; col(cl, 0, D + 2)[i] = like_prev;
+        col(cl, 0, D + 3)[i] = acc_val; col(cl, 0, D + 4)[i] = W;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (sa.done_out) *sa.done_out = done;
+        if (timed_out) { ctl->status.err = SMCMI_ERR_TIMEOUT; ctl->status.stage = n; ctl->status.code = 9; }
+    }
+}
+
+}  // namespace smcmi

@@ -42,7 +42,8 @@ class Result(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("resamples", C.c_int32), ("logmdd", C.c_double), ("c", C.c_double),
                 ("accept", C.c_double), ("seconds", C.c_double), ("kernel_ms_mutate", C.c_double),
                 ("n_mutate_launches", C.c_int32), ("solver_passes", C.c_int64), ("solver_stalls", C.c_int32),
-                ("select_stalls", C.c_int32), ("spec_stalls", C.c_int32), ("paused", C.c_int32)]
+                ("select_stalls", C.c_int32), ("spec_stalls", C.c_int32), ("paused", C.c_int32),
+                ("n_segments", C.c_int32), ("segment_stages", C.c_int32), ("kernel_ms_segments", C.c_double)]
 
 
 class LoopState(C.Structure):

@@ -1,0 +1,94 @@
+"""Engine 3 (csrc/stage3.hpp): runs of stages that neither resample nor need a certificate pass execute as ONE persistent launch -
+particles in registers, the two hand-overs of a stage as tickets + tagged records.  It calls engine 2's own row / decision / proposal /
+MH functions on the same 512-particle blocks, so a run with segments must leave the bits a run of launches leaves (SMCMI_ENGINE3=0):
+ϕ schedule, ESS path, acceptance rates, c, log-MDD, cloud, history.  Oracle parity of the default path is what every other GPU test
+checks (they all run through it when the cloud is small enough)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import models
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import json, sys, hashlib
+import numpy as np
+sys.path.insert(0, %(root)r)
+from smc_jl_amd import Engine
+from tests import models
+cfg = json.loads(%(cfg)r)
+spec = getattr(models, cfg.get("spec", "gauss_spec"))(*cfg.get("spec_args", []))
+e = Engine(cfg["n"], cfg["d"], seed=cfg["seed"], max_stages=cfg.get("max_stages", 1500), store_history=cfg.get("history", True))
+e.set_model(spec)
+out = []
+for rep in range(cfg.get("reps", 1)):
+    e.init_from_prior()
+    kw = dict(cfg["kw"]); stop = kw.pop("pause_at", 0)
+    if stop:
+        r = e.run(stop_after_stage=stop, **kw); assert r["paused"]
+        r = e.run(continue_run=True, **kw)
+    else:
+        r = e.run(**kw)
+    rec = e.stage_records(r["n_stages"])
+    h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    o = dict(n_stages=r["n_stages"], resamples=r["resamples"], logmdd=float(r["logmdd"]).hex(), c=float(r["c"]).hex(), accept=float(r["accept"]).hex(),
+             schedule=h(rec["schedule"]), ess=h(rec["ess"]), c_hist=h(rec["c_hist"]), accept_hist=h(rec["accept_hist"]), resampled=h(rec["resampled"]),
+             cloud=h(e.download_cloud()), n_segments=r["n_segments"], segment_stages=r["segment_stages"],
+             stalls=[r["solver_stalls"], r["select_stalls"], r["spec_stalls"]], logmdd_f=r["logmdd"])
+    if cfg.get("history", True):
+        w, W = e.history(r["n_stages"])
+        o["w"], o["W"] = h(w), h(W)
+    out.append(o)
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _run(cfg, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    code = _WORKER % dict(root=ROOT, cfg=json.dumps(cfg))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+
+
+_KEYS = ("n_stages", "resamples", "logmdd", "c", "accept", "schedule", "ess", "c_hist", "accept_hist", "resampled", "cloud", "w", "W")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=100_000, d=10, seed=1, kw=dict(use_fixed_schedule=False, tempering_target=0.97), reps=2),                       # BASELINE config 2
+    dict(n=20_000, d=10, seed=4, kw=dict(use_fixed_schedule=False, tempering_target=0.95, alpha=0.9, n_blocks=2, n_mh_steps=2)),
+    dict(n=30_000, d=4, seed=2, spec_args=[4], kw=dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial")),
+    dict(n=5_000, d=2, seed=9, spec="regression_spec", kw=dict(use_fixed_schedule=False, tempering_target=0.9, pause_at=6)),
+    dict(n=131_072, d=10, seed=3, kw=dict(use_fixed_schedule=False, tempering_target=0.97), history=False),                # the largest geometry: one block on every CU
+], ids=["config2", "mix2blocks2steps", "fixed_multinomial", "regression_pause", "n131072"])
+def test_segments_leave_the_bits_of_the_launches(cfg):
+    seg = _run(cfg)
+    ref = _run(cfg, {"SMCMI_ENGINE3": "0"})
+    for a, b in zip(seg, ref):
+        assert b["n_segments"] == 0 and a["n_segments"] >= 1, (a["n_segments"], b["n_segments"])
+        if cfg.get("spec") != "regression_spec":                                 # (its predictions rarely verify: heavy-tailed energies, target 0.9)
+            assert a["segment_stages"] >= (a["n_stages"] - 1) // 2               # most stages ran inside segments
+        for k in _KEYS:
+            if k in b:
+                assert a[k] == b[k], (k, a[k], b[k], a["stalls"], b["stalls"])
+    if cfg.get("spec", "gauss_spec") == "gauss_spec" and cfg["d"] == 10 and cfg["kw"].get("alpha", 1.0) == 1.0:
+        assert abs(seg[0]["logmdd_f"] - models.gauss_logmdd(10)) < 0.2
+
+
+def test_a_mispredicted_resample_leaves_the_segment_and_is_redone():
+    """SMCMI_NO_SELECT_PREDICT=2: the host expects no stage to resample, so every resample stage is met INSIDE a segment, which leaves
+    with nothing of the stage committed (status 6); the host runs it through the launches and starts the next segment."""
+    cfg = dict(n=40_000, d=6, seed=13, spec_args=[6], kw=dict(use_fixed_schedule=False, tempering_target=0.95))
+    a = _run(cfg, {"SMCMI_NO_SELECT_PREDICT": "2"})[0]
+    b = _run(cfg, {"SMCMI_NO_SELECT_PREDICT": "2", "SMCMI_ENGINE3": "0"})[0]
+    assert a["resamples"] >= 2 and a["stalls"][1] >= a["resamples"] - 1
+    for k in _KEYS:
+        assert a[k] == b[k], (k, a[k], b[k])
