@@ -35,7 +35,7 @@ struct Eng2 {
     int world = 0;
     // engine 3 (stage3.hpp): tickets, records, time-out flag words, per-launch stage counts (profiling)
     int *d_tick3 = nullptr;
-    unsigned long long *d_rec3 = nullptr, *d_to3 = nullptr;
+    unsigned long long *d_rec3 = nullptr, *d_to3 = nullptr, *d_gran3 = nullptr;    // (d_gran3: rows and shard totals as granules)
     int *d_done3 = nullptr;
     unsigned seg_seq = 0;
     int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle

@@ -16,7 +16,7 @@ constexpr int SEG3_MAX_LAUNCHES = 4096;     // segment launches of one run whose
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete e;
@@ -51,7 +51,9 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     // K2's prologue to total while the cloud is small
     // (the direct geometry: one correction row per 512 particles, the same particles as a mutation row - the persistent segment kernel
     // of stage3.hpp holds one particle per thread and writes exactly these rows, so both engines total the same numbers)
-    g.nb1 = (int)std::max<long long>(1, g.direct ? g.nb2 : std::min<long long>((g.nv + 1023) / 1024, 128));
+    // every geometry cuts a virtual shard the same way, so all of them total the same rows (<= 128 rows per virtual shard: the blocks
+    // grow beyond 512 particles for nv > 65 536, where the direct geometry does not exist)
+    g.nb1 = (int)std::max<long long>(1, g.direct ? g.nb2 : std::min<long long>((g.nv + 511) / 512, 128));
     if (getenv("SMCMI_E2_NB1")) g.nb1 = std::max(1, std::min(atoi(getenv("SMCMI_E2_NB1")), g.direct ? 64 : 128));   // development only
     g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;                        // whole passes of the block
     g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? 32 : 256));
@@ -78,12 +80,15 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
         return SMCMI_ERR_HIP;
     }
     if (g.direct) {                   // engine 3 (stage3.hpp) can serve this geometry: tickets, records, time-out words, per-launch stage counts
-        if (dmalloc(&e->d_tick3, 2 * SEG3_TICKS) || dmalloc(&e->d_rec3, REC3_WORDS) || dmalloc(&e->d_to3, 2) || dmalloc(&e->d_done3, SEG3_MAX_LAUNCHES)) {
+        const size_t gw = k3_table_words(g.Vl * g.nb2);
+        if (dmalloc(&e->d_tick3, 2 * SEG3_TICKS) || dmalloc(&e->d_rec3, REC3_WORDS) || dmalloc(&e->d_to3, 2) || dmalloc(&e->d_done3, SEG3_MAX_LAUNCHES) ||
+            dmalloc(&e->d_gran3, gw)) {
             free_eng2(e);
             return SMCMI_ERR_HIP;
         }
         HIP_TRY(hipMemsetAsync(e->d_tick3, 0, 2 * SEG3_TICKS * sizeof(int), h->stream));
         HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
+        HIP_TRY(hipMemsetAsync(e->d_gran3, 0xFF, gw * sizeof(unsigned long long), h->stream));
         HIP_TRY(hipMemsetAsync(e->d_done3, 0, SEG3_MAX_LAUNCHES * sizeof(int), h->stream));
     }
     HIP_TRY(hipMemsetAsync(e->d_pre, 0, sizeof(Prop2Glob), h->stream));
@@ -287,7 +292,7 @@ static int seg3_ready(smcmi_handle *h, bool *ok) {
     *ok = false;
     static const int off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
     const Geo2 &g = e->g;
-    const int grid = g.Vl * g.nb2;
+    const int grid = g.Vl * g.nb2 + g.Vl + 1;                  // workers + one gatherer per virtual shard + the decider, one CU each
     int n_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
     if (off || !g.direct || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
@@ -485,7 +490,6 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     std::vector<hipEvent_t> evs3;
     int seg_launches = 0;
     if (e3) {
-        HIP_TRY(hipMemsetAsync(h0->e2->d_tick3, 0, 2 * SEG3_TICKS * sizeof(int), h0->stream));
         static const double to_ms = getenv("SMCMI_SEG_TIMEOUT_MS") ? atof(getenv("SMCMI_SEG_TIMEOUT_MS")) : 200.0;
         if (int e = seg3_time_out_words(h0, to_ms)) return e;
     }
@@ -600,6 +604,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         HIP_TRY(hipSetDevice(h->cfg.device));
         if (++e->seg_seq >= 0xFFFFu) {                               // tags are (launch << 16 | stage): start over on clean records
             HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
+            HIP_TRY(hipMemsetAsync(e->d_gran3, 0xFF, k3_table_words(e->g.Vl * e->g.nb2) * sizeof(unsigned long long), h->stream));
             e->seg_seq = 1;
         }
         Mut2Args ma{};
@@ -611,7 +616,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
         Seg3Args sa{};
         sa.n_first = n_first; sa.n_last = n_last; sa.mrows = mut_rows(h); sa.sched = h->d_sched;
-        sa.rows_cm = e->rows_cm; sa.vt_cm = e->vt_cm; sa.vt_mut = e->vt_mut; sa.tick = e->d_tick3; sa.rec = e->d_rec3;
+        const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
+        sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
+        sa.rec = e->d_rec3;
         sa.tag_base = e->seg_seq << 16; sa.to = e->d_to3; sa.hist_w = h->d_hist_w; sa.hist_ld = h->n;
         sa.done_out = seg_launches < SEG3_MAX_LAUNCHES ? e->d_done3 + seg_launches : nullptr;
         sa.prof = (e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
@@ -682,7 +689,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 
     const int base = cont ? h0->h_st.stage - 1 : 0;           // stages completed before this call
     const int max_iter = (adaptive ? h0->cfg.max_stages : rc->n_phi - 1) - base;
-    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 32;     // stages per host sync (a stalled stage wastes the rest of its batch: two idle launches per stage)
+    // stages per host sync (a stalled stage wastes the rest of its batch: two idle launches per stage; with engine 3 a batch end also cuts
+    // a segment in two - a write-back and a reload of the cloud - while an idle segment launch costs next to nothing: longer batches)
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : (e3 ? 96 : 32);
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
@@ -762,8 +771,10 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             if (int e = clear_status()) return e;
             if (code == 6) {
                 // a segment of engine 3 left at this stage (it must resample): nothing of the stage is committed; the full path runs it
-                if (int e = enq_stage(sn, adaptive, first_passes, true)) return e;
-                if (adaptive) { stall_stage = sn; stall_p = first_passes; }
+                // (on the predicted ϕ_n where predictions are in use - what the launches do when a stage resamples unexpectedly: same bits)
+                const bool cert6 = adaptive && !spec_on;
+                if (int e = enq_stage(sn, cert6, first_passes, true)) return e;
+                if (cert6) { stall_stage = sn; stall_p = first_passes; }
                 res->select_stalls += 1;
             } else if (code == 4) {
                 // predicted ϕ_n unusable or not verified: nothing of the stage is committed; run it through the certificate path
@@ -813,18 +824,11 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         long long pr[128];
         HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));
         if (seg_launches > 0) {
-            // block 0's phases of stage prof_stage, and - where the deciding blocks happened to sit on block 0's XCD (their stamps are
-            // comparable then; 0 otherwise) - the hand-overs seen from inside
-            fprintf(stderr, "[smcmi3] stage %d block 0 ticks:", h0->e2->prof_stage);
-            const char *nm[] = {"", "", "corr+row", "draw", "wait B", "MH", "mut row", "arrive", "wait A"};
-            for (int q = 2; q <= 8; ++q) fprintf(stderr, " %s %lld", nm[q], pr[q] - pr[q - 1]);
-            fprintf(stderr, " | stage %lld\n", pr[8] - pr[1]);
-            if (pr[14]) fprintf(stderr, "[smcmi3]   shard 0 (XCD 0) correction rows: block 0's row stored -> last arrival %lld, shard total %lld\n", pr[14] - pr[2], pr[15] - pr[14]);
-            if (pr[10]) fprintf(stderr, "[smcmi3]   correction decider on XCD 0: block 0's row stored -> all arrived %lld | totals %lld | covariance, shuffle %lld | block matrices %lld | Cholesky %lld | record %lld | publish %lld | -> block 0 has it %lld\n",
-                                pr[10] - pr[2], pr[11] - pr[10], pr[30] - pr[11], pr[31] - pr[30], pr[32] - pr[31], pr[12] - pr[32], pr[13] - pr[12], pr[4] - pr[13]);
-            if (pr[24]) fprintf(stderr, "[smcmi3]   shard 0 (XCD 0) mutation rows: block 0's row stored -> last arrival %lld, shard total %lld\n", pr[24] - pr[6], pr[25] - pr[24]);
-            if (pr[20]) fprintf(stderr, "[smcmi3]   mutation decider on XCD 0: block 0's row stored -> all arrived %lld | totals %lld | begin %lld | publish %lld | -> block 0 has it %lld\n",
-                                pr[20] - pr[6], pr[21] - pr[20], pr[22] - pr[21], pr[23] - pr[22], pr[8] - pr[23]);
+            // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
+            fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the begin %lld | stage %lld\n",
+                    h0->e2->prof_stage, pr[2] - pr[1], pr[4] - pr[2], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[8] - pr[1]);
+            fprintf(stderr, "[smcmi3]   decider: covariance, shuffle %lld | block matrices %lld | Cholesky %lld | record %lld | publish %lld || (mutation totals ->) begin %lld | publish %lld\n",
+                    pr[30] - pr[11], pr[31] - pr[30], pr[32] - pr[31], pr[12] - pr[32], pr[13] - pr[12], pr[22] - pr[21], pr[23] - pr[22]);
         }
         for (int blk = 0; blk < 2; ++blk) {
             fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");

@@ -300,8 +300,9 @@ __device__ inline __amdgpu_buffer_rsrc_t rows_rsrc(const double *base, long long
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
-template <int NT, bool COH = false>
-__device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int max_idx, double *out_v, int pair) {
+// LD: double2 ldrow(int row, int pr) - columns 2 pr, 2 pr + 1 of raw row `row` of the virtual shard.  Returns, in thread t < m, total t.
+template <int NT, class LD>
+__device__ inline double reduce_vshard_f(LD ldrow, int nr_raw, int m, int max_idx, int pair) {
     constexpr int GB = NT / (36 * 4) > 0 ? NT / (36 * 4) : 1;      // groups per batch: GB * (m / 2) * 4 <= NT for m <= 72
     static_assert(NT >= 36 * 4, "a group needs (m / 2) * 4 <= 144 threads");
     __shared__ double gs[GB * 72];
@@ -310,7 +311,6 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
     const int ng = (nr + GRP - 1) / GRP;
     const double ninf = -__builtin_inf();
     double run = (int)threadIdx.x == max_idx ? ninf : 0.0;
-    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(base0, (long long)nr_raw * m * 8);
     for (int g0 = 0; g0 < ng; g0 += GB) {
         const int gb = (ng - g0) < GB ? (ng - g0) : GB;
         const int units = gb * mp * 4, u = threadIdx.x;
@@ -320,10 +320,6 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
             const bool mx0 = 2 * pr == max_idx, mx1 = 2 * pr + 1 == max_idx;
             const double id0 = mx0 ? ninf : 0.0, id1 = mx1 ? ninf : 0.0;
             const int r_beg = g * GRP, r_end = (r_beg + GRP < nr) ? r_beg + GRP : nr;
-            const double2 *base = reinterpret_cast<const double2 *>(base0 + 2 * pr);
-            const long long ldp = m / 2;
-            const unsigned boff = (unsigned)(2 * pr) * 8u, brow = (unsigned)m * 8u;      // byte offsets for the sc1 path
-            auto ldrow = [&](int row) { return COH ? load_pair_sc1(rsrc, boff + (unsigned)row * brow) : base[(long long)row * ldp]; };
             double a0[2] = {id0, id0}, a1[2] = {id1, id1};
 #pragma unroll
             for (int j = 0; j < GRP / 8; ++j) {
@@ -334,11 +330,11 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
                     double2 x;
                     if (pair) {                         // (uniform condition; both loads unconditional)
                         const int ra = 2 * rc, rb = 2 * rc + 1 < nr_raw ? 2 * rc + 1 : ra;
-                        const double2 xa = ldrow(ra), xb = ldrow(rb);
+                        const double2 xa = ldrow(ra, pr), xb = ldrow(rb, pr);
                         const bool hb = 2 * rc + 1 < nr_raw;
                         x.x = mx0 ? fmax(xa.x, hb ? xb.x : id0) : xa.x + (hb ? xb.x : 0.0);
                         x.y = mx1 ? fmax(xa.y, hb ? xb.y : id1) : xa.y + (hb ? xb.y : 0.0);
-                    } else x = ldrow(rc);
+                    } else x = ldrow(rc, pr);
                     const double x0 = r < r_end ? x.x : id0, x1 = r < r_end ? x.y : id1;
                     a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
                     a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
@@ -359,6 +355,17 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
         }
         __syncthreads();
     }
+    return run;
+}
+template <int NT, bool COH = false>
+__device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int max_idx, double *out_v, int pair) {
+    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(base0, (long long)nr_raw * m * 8);
+    const unsigned brow = (unsigned)m * 8u;
+    auto ldrow = [&](int row, int pr) {
+        if constexpr (COH) return load_pair_sc1(rsrc, (unsigned)(2 * pr) * 8u + (unsigned)row * brow);
+        else return reinterpret_cast<const double2 *>(base0 + 2 * pr)[(long long)row * (m / 2)];
+    };
+    const double run = reduce_vshard_f<NT>(ldrow, nr_raw, m, max_idx, pair);
     if ((int)threadIdx.x < m) row_store(out_v + threadIdx.x, run, COH);     // (COH: a block of the same launch may read the totals)
 }
 static __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
@@ -834,8 +841,8 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
 
 // One correction block's row (ΣW̃, ΣW̃², the (D+1)(D+2)/2 augmented pair sums) from the threads' accumulators; csum (may be null)
 // receives ΣW̃ as well (chunk sums of the selection scan).  red: T1 / 64 * 64 doubles of LDS.  All T1 threads call.
-template <int D>
-__device__ inline void k2_cm_row(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], double *red, double *out, double *csum, bool coh) {
+template <int D, class ST>
+__device__ inline void k2_cm_row_f(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], double *red, ST store) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
     constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
     constexpr int REM = NPF - 64 * (NCH - 1);
@@ -847,17 +854,22 @@ __device__ inline void k2_cm_row(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) 
 #pragma unroll
             for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
             const double t64 = block_reduce_nw<64, NW>(a64, red);
-            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, t64, coh);
-            if (ch == 0 && threadIdx.x == 0 && csum) *csum = t64;
+            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) store(ch * 64 + (int)threadIdx.x, t64);
         } else {
             double ar[REMP];
 #pragma unroll
             for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
             const double tr = block_reduce_nw<REMP, NW>(ar, red);
-            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) row_store(out + ch * 64 + threadIdx.x, tr, coh);
-            if (ch == 0 && threadIdx.x == 0 && csum) *csum = tr;
+            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) store(ch * 64 + (int)threadIdx.x, tr);
         }
     }
+}
+template <int D>
+__device__ inline void k2_cm_row(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], double *red, double *out, double *csum, bool coh) {
+    k2_cm_row_f<D>(acc, red, [&](int idx, double v) {
+        row_store(out + idx, v, coh);
+        if (idx == 0 && csum) *csum = v;
+    });
 }
 // One particle's contribution to a correction block's accumulators: incremental weight (src/smc_main.jl:401-409), W̃ = W w̃, the
 // sums of weighted_mean / weighted_cov about `sh` (particle.jl:481-483, 526-529).  Returns W̃; *inc_out = w̃.
@@ -1544,9 +1556,9 @@ __device__ inline void k2_mh_steps(const Mut2Lds<D> &L, double *mixbuf, int *mix
 // One mutation block's row for the next stage's begin (energy power sums on adaptive schedules, Σ accept, energy maximum) from the
 // particles' post-mutation values; scratch: T / 64 * ES doubles of LDS (the likelihood data is dead by now), red: 8 doubles.
 // coh: the row is totalled inside this launch (Tail2 / stage3.hpp).  All threads call; starts and ends with a barrier.
-template <int T>
-__device__ inline void k2_mut_row(double *row, bool adaptive, double like, double like_prev, double w_part, double acc_val, double e_center, bool live,
-                                  bool rs, double *scratch, double *red, bool coh) {
+template <int T, class ST>
+__device__ inline void k2_mut_row_f(bool adaptive, double like, double like_prev, double w_part, double acc_val, double e_center, bool live,
+                                    bool rs, double *scratch, double *red, ST store) {
     const int tid = threadIdx.x;
     __syncthreads();
     double em = energy_or_ninf(like, like_prev, rs ? 1.0 : w_part, live);
@@ -1559,7 +1571,7 @@ __device__ inline void k2_mut_row(double *row, bool adaptive, double like, doubl
         energy_terms(es, w_part, like, like_prev, e_center, live, rs);
         es[EACC] = acc_val;
         const double tot = block_reduce_es2<T / 64>(es, scratch);
-        if (tid < ES) row_store(row + tid, tot, coh);
+        if (tid < ES) store(tid, tot);
     } else {
         double a1[1] = {acc_val};
         Butterfly<0, 32>::run(a1, tid & 63);
@@ -1568,7 +1580,7 @@ __device__ inline void k2_mut_row(double *row, bool adaptive, double like, doubl
         if (tid < ES) {
             double sacc = ((red[0] + red[1]) + red[2]) + red[3];
             if constexpr (T == 512) sacc += ((red[4] + red[5]) + red[6]) + red[7];
-            row_store(row + tid, tid == EACC ? sacc : 0.0, coh);
+            store(tid, tid == EACC ? sacc : 0.0);
         }
     }
     __syncthreads();
@@ -1576,8 +1588,13 @@ __device__ inline void k2_mut_row(double *row, bool adaptive, double like, doubl
         double m = emx[0];
 #pragma unroll
         for (int w = 1; w < T / 64; ++w) m = fmax(m, emx[w]);
-        row_store(row + RMAX_IDX, m, coh);
+        store(RMAX_IDX, m);
     }
+}
+template <int T>
+__device__ inline void k2_mut_row(double *row, bool adaptive, double like, double like_prev, double w_part, double acc_val, double e_center, bool live,
+                                  bool rs, double *scratch, double *red, bool coh) {
+    k2_mut_row_f<T>(adaptive, like, like_prev, w_part, acc_val, e_center, live, rs, scratch, red, [&](int idx, double v) { row_store(row + idx, v, coh); });
 }
 
 // K2.  The mutation body is k_mutate_reg's (src/mutation.jl:56-138, helpers.jl:87-164; same arithmetic in the same order), fed

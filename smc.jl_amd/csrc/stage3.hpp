@@ -5,23 +5,24 @@
 // covariance -> Cholesky): 44 µs per stage at N = 1e5 of which 9 are the bodies.  A run of consecutive stages that neither resample
 // nor need the certificate path (95 % of an adaptive run) is ONE launch here:
 //
-//   * every thread keeps its particle (θ, loglh, logprior, old_loglh, weight) in registers for the whole segment - HBM sees only the
-//     history columns and one row per block and phase;
-//   * the two chip-wide hand-overs of a stage are tickets, not launches: a block stores its row (the same row, bit for bit, K1 / K2
-//     of engine 2 would store for the same 512 particles), takes a ticket of its virtual shard; the last block of a virtual shard
-//     totals the shard's rows (canonical order, reduce_vshard), the last of those totals the V shard totals and does the stage's
-//     scalar work ONCE - decision + proposal (covariance, blocks, Cholesky) after the correction, ϕ_{n+1} (Newton) after the mutation
-//     - and publishes the result as a record of tagged 8-byte granules {32-bit payload | 32-bit tag}: a reader that sees the tag
-//     has the payload, no fence, no flag (the mailbox's wire format, agent scope here);
-//   * the other blocks draw the stage's random numbers while they wait (they depend on (seed, particle, stage) only), so ~40 % of
-//     the mutation's arithmetic hides under the hand-over.
+//   * WORKER blocks (one per 512 particles, engine 2's mutation-block geometry): every thread keeps its particle (θ, loglh, logprior,
+//     old_loglh, weight) in registers for the whole segment - HBM sees only the history columns and one row per block and phase;
+//   * the two chip-wide hand-overs of a stage are neither launches nor barriers nor tickets: a worker publishes its row (the same row,
+//     bit for bit, K1 / K2 of engine 2 would store for the same particles) as tagged 8-byte granules {32-bit payload | 32-bit tag} - a
+//     reader that sees the tag has the payload, no fence, no flag, no counter (the mailbox's wire format, agent scope here);
+//     one GATHERER block per virtual shard (on a CU the workers leave idle, on the shard's own XCD) sweeps its shard's rows, totals
+//     them in the canonical order and publishes the shard total the same way; one DECIDER block totals the V shard totals and does
+//     the stage's scalar work ONCE - decision + proposal (covariance, blocks, Cholesky) after the correction, ϕ_{n+1} (Newton) after
+//     the mutation - and publishes the result as a record every block fetches.  Three store -> load hops per hand-over, no atomics;
+//     (a first version with per-shard tickets and "last arriver totals" needed nine dependent memory round trips of ~1.5 µs each);
+//   * the workers draw the NEXT stage's random numbers while they wait for its begin (they depend on (seed, particle, stage) only).
 //
 // Rows, totals, decision logic (begin2_wave, decide2, post2, proposal2) and the MH body (k2_mh_steps) are engine 2's own functions:
 // a segment leaves the bits engine 2's launches would leave, and the two engines alternate freely inside a run - the segment ends
 // (state in memory exactly as between two engine-2 stages: cloud in buffer 0, mutation rows, Post2 / Begin2 in Ctl2) when its last
 // stage is done or as soon as a stage needs what it cannot do (selection, a certificate pass, the end of the run); the host then
-// runs that stage through engine 2's launches and starts the next segment.  Blocks never straddle a virtual shard and every block
-// is resident for the whole launch (grid <= one block per CU), so a waiting block can only wait for blocks that are running;
+// runs that stage through engine 2's launches and starts the next segment.  Every block is resident for the whole launch (grid <=
+// one block per CU, checked by a residency self-test on first use), so a waiting block can only wait for blocks that are running;
 // every wait is bounded (time-out -> SMCMI_ERR_TIMEOUT, never a hung GPU).
 #pragma once
 #include "stage2.hpp"
@@ -90,45 +91,102 @@ __device__ inline bool rec3_wait(const unsigned long long *rec, void *dst_lds, i
     return *s_to == 0;
 }
 
-// Two-level ticket behind a stored row (see Tail2 / tail_reduce in stage2.hpp for the memory-ordering argument): true in the ONE block
-// that arrives last of all; it then holds the V x m totals of all local virtual shards in vt (agent-scope stores by their totalling
-// blocks, read with agent-scope loads below).  tick: SEG3_TICKS counters, zero between uses.
-template <int NT>
-__device__ inline bool seg3_arrive(int *tick, const double *rows, double *vt, int v, int Vl, int nr, int m, int max_idx, long long *prof = nullptr) {
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&tick[v * TICK3_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr - 1;
-    __syncthreads();
-    if (!s_last) return false;
-    K3_STAMP_ANY(prof, 0);
-    reduce_vshard<NT, true>(rows + (long long)v * nr * m, nr, m, max_idx, vt + (long long)v * m, 0);
-    K3_STAMP_ANY(prof, 1);
-    if (threadIdx.x == 0) __hip_atomic_store(&tick[v * TICK3_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&tick[V2_MAXV * TICK3_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == Vl - 1;
-    __syncthreads();
-    if (!s_last) return false;
-    if (threadIdx.x == 0) __hip_atomic_store(&tick[V2_MAXV * TICK3_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
+// ---- rows and shard totals as granules: a double = two tagged words
+__device__ inline void gran_store(unsigned long long *w, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 1, ((unsigned long long)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// totals over the nvs virtual shards in the order of reduce_rows (0 + x_0 + x_1 + ...; maximum for max_idx); ends with a barrier
-__device__ inline void seg3_totals(const double *vt, int nvs, int m, int max_idx, double *tot) {
-    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(vt, (long long)V2_MAXV * m * 8);
-    for (int k = threadIdx.x; k < m; k += blockDim.x) {
-        const bool mx = k == max_idx;
-        double xs[V2_MAXV];
-#pragma unroll
-        for (int v = 0; v < V2_MAXV; ++v)                         // every load in flight before the first use (unconditional, clamped)
-            xs[v] = load_f64_sc1(rsrc, (unsigned)((v < nvs ? v : nvs - 1) * m + k) * 8u);
-        double t = mx ? -__builtin_inf() : 0.0;
-#pragma unroll
-        for (int v = 0; v < V2_MAXV; ++v)
-            if (v < nvs) t = mx ? fmax(t, xs[v]) : t + xs[v];
-        tot[k] = t;
-    }
+// one lane's bounded wait for ONE word to carry `tag` (the sweep proper re-checks every word it uses)
+__device__ inline void gran_poll(const unsigned long long *w, unsigned tag, unsigned long long *to, int *s_to) {
+    unsigned long long a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(a >> 32) == tag) return;
+    const long long t0 = wall_clock64();
+    const long long lim = (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    do {
+        __builtin_amdgcn_s_sleep(2);
+        a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a >> 32) == tag) return;
+        if (wall_clock64() - t0 > lim || __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_to = 1;
+            return;
+        }
+    } while (true);
+}
+// Gatherer: totals of the nr rows (m doubles = 2 m words each, at tbl) of one virtual shard in the canonical order -> thread t < m
+// returns total t.  One lane per row waits for the row's first word, then the sweep loads everything with pipelined sc1 loads and checks
+// EVERY tag; a word that was not there yet repeats the sweep (rows arrive within a fraction of a µs of each other).  false: timed out.
+template <int NT>
+__device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *run_out) {
+    // (one lane per row waits for the row's first word before the sweep: sweeping as the probe - one round trip less on paper - was
+    // measured 4 µs per stage SLOWER: the gatherers' repeated sweeps queue in front of the workers' row stores)
+    if ((int)threadIdx.x < nr) gran_poll(tbl + (long long)threadIdx.x * m * 2, tag, to, s_to);
     __syncthreads();
+    if (*s_to) return false;
+    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)nr * m * 16);
+    const long long t_begin = wall_clock64();
+    for (;;) {
+        int bad = 0;
+        auto ldrow = [&](int row, int pr) {
+            const unsigned off = ((unsigned)row * (unsigned)m + 2u * (unsigned)pr) * 16u;
+            const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 16), b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u), 0, 16);
+            bad |= (a.y != tag) | (a.w != tag) | (b.y != tag) | (b.w != tag);
+            double2 x;
+            x.x = __hiloint2double((int)a.z, (int)a.x);
+            x.y = __hiloint2double((int)b.z, (int)b.x);
+            return x;
+        };
+        const double run = reduce_vshard_f<NT>(ldrow, nr, m, max_idx, 0);
+        if (!__syncthreads_or(bad)) { *run_out = run; return true; }
+        // a word was not there yet: sweep again, bounded like every other wait
+        if (threadIdx.x == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                                 __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_to = 1;
+        }
+        __syncthreads();
+        if (*s_to) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+// Decider: totals over the nvs shard totals (granules at tbl[v * m * 2]) in the order of reduce_rows (0 + x_0 + x_1 + ...; maximum for
+// max_idx) -> tot[0, m).  All threads call; ends with a barrier.  false: timed out.
+__device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *tot) {
+    if ((int)threadIdx.x < nvs) gran_poll(tbl + (long long)threadIdx.x * m * 2, tag, to, s_to);
+    __syncthreads();
+    if (*s_to) return false;
+    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)V2_MAXV * m * 16);
+    const long long t_begin = wall_clock64();
+    for (;;) {
+        int bad = 0;
+        for (int k = threadIdx.x; k < m; k += blockDim.x) {
+            const bool mx = k == max_idx;
+            u32x4_t xs[V2_MAXV];
+#pragma unroll
+            for (int v = 0; v < V2_MAXV; ++v)                     // every load in flight before the first use (unconditional, clamped)
+                xs[v] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)(v < nvs ? v : nvs - 1) * (unsigned)m + (unsigned)k) * 16u), 0, 16);
+            double t = mx ? -__builtin_inf() : 0.0;
+#pragma unroll
+            for (int v = 0; v < V2_MAXV; ++v)
+                if (v < nvs) {
+                    bad |= (xs[v].y != tag) | (xs[v].w != tag);
+                    const double x = __hiloint2double((int)xs[v].z, (int)xs[v].x);
+                    t = mx ? fmax(t, x) : t + x;
+                }
+            tot[k] = t;
+        }
+        if (!__syncthreads_or(bad)) return true;
+        // a word was not there yet: sweep again, bounded like every other wait
+        if (threadIdx.x == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                                 __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_to = 1;
+        }
+        __syncthreads();
+        if (*s_to) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
 }
 
 // Residency self-test of a handle's segment geometry (first use): `grid` blocks of T3 threads with enough LDS that a CU holds ONE of
@@ -165,10 +223,10 @@ struct Seg3Args {
     int n_first, n_last;           // stages this launch may run
     Rows2 mrows;                   // mutation rows of stage n_first - 1 (direct view: every block totals them for the first begin)
     const double *sched;
-    double *rows_cm, *vt_cm, *vt_mut;   // correction rows [blocks][pad2(NPF)]; per-virtual-shard totals [Vl][m] (rows_mut: Mut2Args)
-    int *tick;                     // [2][SEG3_TICKS]: correction / mutation
+    unsigned long long *g_cm, *g_mut;     // the workers' rows as granules: [blocks][MCM * 2] / [blocks][RMUT * 2] words
+    unsigned long long *gt_cm, *gt_mut;   // the shard totals as granules: [V2_MAXV][MCM * 2] / [V2_MAXV][RMUT * 2]
     unsigned long long *rec;       // REC3_WORDS granules
-    unsigned tag_base;             // launch sequence << 16 (never reused inside a handle's life without clearing the records)
+    unsigned tag_base;             // launch sequence << 16 (never reused inside a handle's life without clearing the tables)
     unsigned long long *to;        // time-out flag words
     double *hist_w;
     long long hist_ld;
@@ -176,6 +234,7 @@ struct Seg3Args {
     long long *prof;               // development only (SMCMI_PROF2=<stage>): stamps of that stage
     int prof_stage;
 };
+constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; }
 
 #define K3_STAMP(prof, slot)                                                                                                   \
     do {                                                                                                                      \
@@ -189,15 +248,20 @@ struct Seg3Args {
 // grid = g.Vl * g.nb2 blocks of T3 threads, every one resident; block b owns block (b / Vl) of local virtual shard (b % Vl): with the
 // hardware's round-robin of consecutive blocks over the 8 XCDs a virtual shard's blocks share an XCD (its rows are totalled out of
 // that die's L2 / MALL path) - placement is speed only, never correctness.
-// (the shader clocks of different XCDs have different origins: the deciding blocks' stamps are comparable with block 0's on XCD 0 only)
+// (the shader clocks of different XCDs have different origins: a helper block's stamps compare with block 0's on XCD 0 only)
 #define K3_STAMP_D(prof, slot)                                                                                                 \
     do {                                                                                                                      \
-        if ((prof) != nullptr && threadIdx.x == 0 && (blockIdx.x & 7) == 0 && n == sa.prof_stage) {                            \
+        if ((prof) != nullptr && threadIdx.x == 0 && n == sa.prof_stage) {                                                     \
             unsigned long long tt_;                                                                                           \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");       \
             (prof)[(slot)] = (long long)tt_;                                                                                   \
         }                                                                                                                     \
     } while (0)
+
+// grid = W + g.Vl + 1 blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual
+// shard, then the decider).  Worker b owns block (b / Vl) of local virtual shard (b % Vl): with the hardware's round-robin of
+// consecutive blocks over the 8 XCDs a virtual shard's workers and (W a multiple of 8) its gatherer share an XCD - placement is
+// speed only, never correctness.
 template <int D, bool ALPHA1>
 __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
@@ -209,51 +273,20 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     __shared__ double red[(T3 / 64) * 64];
     __shared__ int s_act, s_to, s_fail;
     __shared__ double s_cfac;
+    __shared__ RunParams s_rp;                                  // (by value in registers it costs ~40 SGPRs for the whole launch)
     __shared__ double mixbuf[ALPHA1 ? 1 : MixDense<D>::DOUBLES + D * D];
     __shared__ int mixpos[ALPHA1 ? 1 : D];
     __shared__ double mixzt[ALPHA1 ? 1 : T3 * D];
     Mut2Lds<D> L(sm);
     const int tid = threadIdx.x;
-    // the first proposal's random numbers of the NEXT stage, drawn while the block waits for that stage's begin (they depend on (seed,
-    // particle, stage) only) and parked here, slot-major: z_park[slot * T3 + tid], slots = MH uniform, mixture uniform, D normals
-    double *z_park = sm + k3_park_offset(D);
-    const int vl = (int)blockIdx.x % g.Vl, r = (int)blockIdx.x / g.Vl, rowi = vl * g.nb2 + r;       // row index = engine 2's block index
-    // ---- run constants and the particle
-    __shared__ RunParams s_rp;                                  // (by value in registers it costs ~40 SGPRs for the whole launch)
-    if (tid == 0) s_rp = st->rp;
+    const int W = g.Vl * g.nb2;
+    const int role = (int)blockIdx.x < W ? 0 : ((int)blockIdx.x < W + g.Vl ? 1 : 2);          // worker / gatherer / decider
+    if (tid == 0) { s_rp = st->rp; s_to = 0; }
+    if (tid < nf) L.fi[tid] = md->free_inds[tid];
     __syncthreads();
     const RunParams &rp = s_rp;
-    const double pw = rp.pw, logp_old = rp.logp_old, nrm_N = ma.n_parts;
-    const bool hist = rp.store_history && sa.hist_w != nullptr;
-    long long beg, end;
-    vchunk(g, vl, r, T3, beg, end);
-    const long long i = beg + tid;
-    const bool live = i < end;
-    const long long il = live ? i : (end > beg ? end - 1 : 0);
-    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
-    double x[D], like, lprior, like_prev, W, acc_val;
-#pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
-    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
-    acc_val = col(cl, 0, D + 3)[il]; W = col(cl, 0, D + 4)[il];
-    if (!live) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = 0.0;
-        like = lprior = like_prev = 0.0;
-    }
-    for (int k = tid; k < D; k += T3) {
-        L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
-        L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
-    }
-    for (int k = tid; k < 2 * LIK_PAR_MAX; k += T3) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
-    if (tid < nf) L.fi[tid] = md->free_inds[tid];
-    if (tid == 0) s_to = 0;
-    ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
-    LikView lv[2];
-    k2_stage_lik<T3>(ma.lik[0], ma.lik[1], L.l_par, L.l_dat, lv);     // once per segment (the mutation rows' scratch is `red`, not this area)
     int n = sa.n_first;
-    const int db0 = nb == 1 ? nf : (nf + nb - 1) / nb;          // entries of the first random block
-    // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left
+    // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left (block 0 records it)
     {
         const int act = begin2_block<T3>(n, st, ctl, sa.mrows, 1, sa.sched, ma.rec, &s_b[(n - 1) & 1].po, &s_a.bg, s_vt, s_tot, s_sw, &s_act, nullptr, true);
         if (act != 0) return;                                   // nothing was touched: the cloud in memory is current
@@ -262,125 +295,76 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
             s_a.bg.cfac = s_cfac;
         }
-        k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
         __syncthreads();
     }
-    int done = 0;
     bool timed_out = false;
-    for (;; ++n) {
-        K3_STAMP(sa.prof, 1);
-        RecB3<D> &B = s_b[n & 1];
-        const Post2 &po = s_b[(n - 1) & 1].po;                  // stage n - 1 as completed
-        const unsigned tag = sa.tag_base | (unsigned)n;
-        // the proposal arrays of THIS stage (written by proposal2 in the deciding block, by rec3_wait elsewhere)
-        L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
-        L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
-        // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
-        const double phi = s_a.bg.phi_n, phi_prev = s_a.bg.phi_prev, esh = pw == 0.0 ? s_a.bg.e_shift : 0.0, e_center = s_a.bg.e_center;
-        double v = 0.0;
-        {
-            constexpr int NCH = (NPF + 63) / 64;
-            double acc[NCH * 64];
-#pragma unroll
-            for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
-            if (live) {
-                double inc;
-                v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, W, esh, phi, phi_prev, pw, logp_old, &inc);
-                if (hist) {
-                    const double unshift = exp((phi - phi_prev) * esh);
-                    sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
-                }
-            }
-            k2_cm_row<D>(acc, red, sa.rows_cm + (long long)rowi * MCM, nullptr, true);
+    if (role == 1) {
+        // ================================================================ GATHERER of local virtual shard vg
+        const int vg = (int)blockIdx.x - W;
+        for (;; ++n) {
+            const unsigned tag = sa.tag_base | (unsigned)n;
+            double run;
+            if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to, &run)) break;
+            if (tid < MCM) gran_store(sa.gt_cm + ((long long)vg * MCM + tid) * 2, run, tag);
+            if (!rec3_wait(sa.rec + REC3_B_OFF, &s_b[n & 1], 2, tag, sa.to, &s_to) || s_b[n & 1].act != 0) break;
+            if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to, &run)) break;
+            if (tid < RMUT) gran_store(sa.gt_mut + ((long long)vg * RMUT + tid) * 2, run, tag);
+            if (!rec3_wait(sa.rec, &s_a, 2, sa.tag_base | (unsigned)(n + 1), sa.to, &s_to) || s_a.act != 0) break;
         }
-        const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;
-        K3_STAMP(sa.prof, 2);
-        if (seg3_arrive<T3>(sa.tick, sa.rows_cm, sa.vt_cm, vl, g.Vl, g.nb2, MCM, -1, (sa.prof && vl == 0 && n == sa.prof_stage) ? sa.prof + 14 : nullptr)) {
-            // ---- the one deciding block: totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-            K3_STAMP_D(sa.prof, 10);
-            seg3_totals(sa.vt_cm, g.Vl, MCM, -1, s_tot);
+        return;
+    }
+    if (role == 2) {
+        // ================================================================ DECIDER
+        const double inv_pre = INV_FACTORIAL[tid & 31];
+        for (;; ++n) {
+            RecB3<D> &B = s_b[n & 1];
+            const Post2 &po = s_b[(n - 1) & 1].po;              // stage n - 1 as completed
+            const unsigned tag = sa.tag_base | (unsigned)n;
+            L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
+            L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
+            const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
+            // ---- totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
+            if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
             K3_STAMP_D(sa.prof, 11);
             double ess;
             const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
-            if (dec != 0) {
-                if (tid == 0) {
-                    B.act = dec < 0 ? 9 : 6; B.pad = 0;
-                    if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
-                    ctl->status.stage = n;
-                    ctl->status.code = dec < 0 ? 9 : (dec == 4 ? 4 : 6);
-                }
-                __syncthreads();
-                rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);          // (whole record: readers wait for all of it once)
-            } else {
-                if (tid == T3 - 64) {                                    // (the last wavefront: the logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
+            bool go = dec == 0;
+            if (go) {
+                if (tid == T3 - 64) {                           // (the last wavefront: the logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
                     B.act = 0; B.pad = 0;
                     post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, 0, &B.po);
                 }
                 Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
-                const bool ok = proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr, (sa.prof && (blockIdx.x & 7) == 0 && n == sa.prof_stage) ? sa.prof + 30 : nullptr);
-                if (!ok) {
-                    if (tid == 0) { B.act = 9; ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
-                    __syncthreads();
-                    rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);
-                } else {
-                    if (tid < D) B.po.shift[tid] = L.mean_s[tid];
-                    __syncthreads();
-                    K3_STAMP_D(sa.prof, 12);
-                    rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);
-                    K3_STAMP_D(sa.prof, 13);
-                    // bookkeeping nobody in this launch waits for: Ctl2 / records / diagnostics (k2_bookkeeping)
-                    if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = 0; ma.rec.c[n - 1] = B.po.c; }
-                    // (write-through: the deciding block changes from stage to stage and with it the die whose L2 would hold these
-                    // words dirty - two dies' copies of one word would reach memory in no particular order at the end of the launch)
-                    if (tid < D) row_store(&st->mean[tid], L.mean_s[tid], true);
-                    for (int e = tid; e < D * D; e += T3) row_store(&st->cov[e], L.covl[e], true);
-                    constexpr int NWP = sizeof(Post2) / sizeof(double);
-                    if (tid < NWP) row_store(reinterpret_cast<double *>(&ctl->ps[n & 1]) + tid, reinterpret_cast<const double *>(&B.po)[tid], true);
-                }
+                go = proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr,
+                               (sa.prof && n == sa.prof_stage) ? sa.prof + 30 : nullptr);
+                if (!go && tid == 0) { B.act = 9; ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }      // PosDefException aborts the run (mutation.jl:81)
+                if (go && tid < D) B.po.shift[tid] = L.mean_s[tid];
+            } else if (tid == 0) {
+                B.act = dec < 0 ? 9 : 6; B.pad = 0;
+                if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
+                ctl->status.stage = n;
+                ctl->status.code = dec < 0 ? 9 : (dec == 4 ? 4 : 6);
             }
-        }
-        // ---- everybody: the record
-        K3_STAMP(sa.prof, 3);
-        if (!rec3_wait(sa.rec + REC3_B_OFF, &B, WB, tag, sa.to, &s_to)) { timed_out = true; break; }
-        if (B.act != 0) break;                                  // leave: registers hold the cloud after stage n - 1
-        K3_STAMP(sa.prof, 4);
-        // ================= mutation (src/mutation.jl:56-138): normalize_weights!, the MH steps, one row per block
-        const double phi_n = B.po.phi_n, nrm_sumw = B.po.sumw;
-        double accept = 0.0;
-        double step_prob, uc, z[D];
-        {
-            const double *p = z_park + tid;                     // (written by this thread)
-            step_prob = p[0];
-            uc = p[T3];
-#pragma unroll
-            for (int e = 0; e < D; ++e) z[e] = p[(2 + e) * T3];
-        }
-        if (live) {
-            W = (v * nrm_N) / nrm_sumw;                         // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366)
-            if (ma.hist_W && ma.store_history) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = W;
-        }
-        k2_mh_steps<D, ALPHA1, T3, true>(L, mixbuf, mixpos, mixzt, ma, g.n, lv, mv, nb, nf, live, i, pid, (unsigned)n, phi_n, x, like, lprior, like_prev, accept,
-                                         step_prob, uc, z);
-        if (live) acc_val = accept / (double)nf;                // quirk Q2: normalised by n_free only
-        K3_STAMP(sa.prof, 5);
-        k2_mut_row<T3>(ma.rows_mut + (long long)rowi * RMUT, ma.adaptive != 0, like, like_prev, live ? W : 0.0, live ? acc_val : 0.0, e_center, live, false,
-                       red, L.red, true);
-        ++done;
-        // the window of the proposed schedule the next begin walks (index from Post2 of THIS stage, in LDS since the record arrived)
-        double swv = 2.0;
-        if (tid < 64) {
-            const int jj = B.po.j - 1 + tid;
-            if (!rp.use_fixed_schedule && jj >= 0 && jj < rp.n_phi) swv = sa.sched[jj];
-        }
-        const double inv_pre = INV_FACTORIAL[tid & 31];
-        K3_STAMP(sa.prof, 6);
-        if (seg3_arrive<T3>(sa.tick + SEG3_TICKS, ma.rows_mut, sa.vt_mut, vl, g.Vl, g.nb2, RMUT, RMAX_IDX, (sa.prof && vl == 0 && n == sa.prof_stage) ? sa.prof + 24 : nullptr)) {
-            // ---- the one deciding block: totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-            K3_STAMP_D(sa.prof, 20);
-            seg3_totals(sa.vt_mut, g.Vl, RMUT, RMAX_IDX, s_tot);
+            __syncthreads();
+            K3_STAMP_D(sa.prof, 12);
+            rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);     // (the whole record either way: readers wait for all of it once)
+            K3_STAMP_D(sa.prof, 13);
+            if (!go) break;
+            // bookkeeping nobody in this launch waits for: Ctl2 / records / diagnostics (k2_bookkeeping)
+            if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = 0; ma.rec.c[n - 1] = B.po.c; }
+            if (tid < D) st->mean[tid] = L.mean_s[tid];
+            for (int e = tid; e < D * D; e += T3) st->cov[e] = L.covl[e];
+            constexpr int NWP = sizeof(Post2) / sizeof(double);
+            if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&B.po)[tid];
+            // the window of the proposed schedule the next begin walks
+            if (tid < 64) {
+                const int jj = B.po.j - 1 + tid;
+                s_sw[tid] = (!rp.use_fixed_schedule && jj >= 0 && jj < rp.n_phi) ? sa.sched[jj] : 2.0;
+            }
+            // ---- totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
+            if (!gather_totals(sa.gt_mut, g.Vl, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
             K3_STAMP_D(sa.prof, 21);
             if (tid == 0) { s_act = 7; s_a.pad = 0; }
-            if (tid < 64) s_sw[tid] = swv;
             if (n < sa.n_last) {
                 if (tid < 64) {
                     const int act = begin2_wave(n + 1, B.po, rp, s_tot, s_tot[RMAX_IDX], true, 1, sa.sched, s_sw, &s_a.bg, &st->sol[0], true, ma.rec,
@@ -398,11 +382,109 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             K3_STAMP_D(sa.prof, 22);
             rec3_publish(sa.rec, &s_a, WA, sa.tag_base | (unsigned)(n + 1));
             K3_STAMP_D(sa.prof, 23);
+            if (s_a.act != 0) break;
             constexpr int NWB = sizeof(Begin2) / sizeof(double);
-            if (s_a.act == 0 && tid < NWB) row_store(reinterpret_cast<double *>(&ctl->bg) + tid, reinterpret_cast<const double *>(&s_a.bg)[tid], true);
+            if (tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
         }
-        K3_STAMP(sa.prof, 7);
+        if (timed_out && tid == 0) { ctl->status.err = SMCMI_ERR_TIMEOUT; ctl->status.stage = n; ctl->status.code = 9; }
+        return;
+    }
+    // ==================================================================== WORKER
+    // the first proposal's random numbers of the NEXT stage, drawn while the block waits for that stage's begin (they depend on (seed,
+    // particle, stage) only) and parked here, slot-major: z_park[slot * T3 + tid], slots = MH uniform, mixture uniform, D normals
+    double *z_park = sm + k3_park_offset(D);
+    const int vl = (int)blockIdx.x % g.Vl, r = (int)blockIdx.x / g.Vl, rowi = vl * g.nb2 + r;       // row index = engine 2's block index
+    const double pw = rp.pw, logp_old = rp.logp_old, nrm_N = ma.n_parts;
+    const bool hist = rp.store_history && sa.hist_w != nullptr;
+    long long beg, end;
+    vchunk(g, vl, r, T3, beg, end);
+    const long long i = beg + tid;
+    const bool live = i < end;
+    const long long il = live ? i : (end > beg ? end - 1 : 0);
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double x[D], like, lprior, like_prev, Wt, acc_val;
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
+    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
+    acc_val = col(cl, 0, D + 3)[il]; Wt = col(cl, 0, D + 4)[il];
+    if (!live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = 0.0;
+        like = lprior = like_prev = 0.0;
+    }
+    for (int k = tid; k < D; k += T3) {
+        L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
+        L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
+    }
+    for (int k = tid; k < 2 * LIK_PAR_MAX; k += T3) L.l_par[k] = md->lik[k / LIK_PAR_MAX].par[k % LIK_PAR_MAX];
+    ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
+    LikView lv[2];
+    k2_stage_lik<T3>(ma.lik[0], ma.lik[1], L.l_par, L.l_dat, lv);     // once per segment (the mutation rows' scratch is `red`, not this area)
+    const int db0 = nb == 1 ? nf : (nf + nb - 1) / nb;          // entries of the first random block
+    k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
+    __syncthreads();
+    int done = 0;
+    unsigned long long *my_cm = sa.g_cm + (long long)rowi * MCM * 2, *my_mut = sa.g_mut + (long long)rowi * RMUT * 2;
+    for (;; ++n) {
+        K3_STAMP(sa.prof, 1);
+        RecB3<D> &B = s_b[n & 1];
+        const Post2 &po = s_b[(n - 1) & 1].po;                  // stage n - 1 as completed
+        const unsigned tag = sa.tag_base | (unsigned)n;
+        // the proposal arrays of THIS stage arrive inside its record
+        L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
+        L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
+        // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
+        const double phi = s_a.bg.phi_n, phi_prev = s_a.bg.phi_prev, esh = pw == 0.0 ? s_a.bg.e_shift : 0.0, e_center = s_a.bg.e_center;
+        double v = 0.0;
+        {
+            constexpr int NCH = (NPF + 63) / 64;
+            double acc[NCH * 64];
+#pragma unroll
+            for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+            if (live) {
+                double inc;
+                v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
+                if (hist) {
+                    const double unshift = exp((phi - phi_prev) * esh);
+                    sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                }
+            }
+            k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+            if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
+        }
+        K3_STAMP(sa.prof, 2);
+        if (!rec3_wait(sa.rec + REC3_B_OFF, &B, WB, tag, sa.to, &s_to)) { timed_out = true; break; }
+        if (B.act != 0) break;                                  // leave: registers hold the cloud after stage n - 1
+        K3_STAMP(sa.prof, 4);
+        // ================= mutation (src/mutation.jl:56-138): normalize_weights!, the MH steps, one row per block
+        const double phi_n = B.po.phi_n, nrm_sumw = B.po.sumw;
+        double accept = 0.0;
+        double step_prob, uc, z[D];
+        {
+            const double *p = z_park + tid;                     // (written by this thread)
+            step_prob = p[0];
+            uc = p[T3];
+#pragma unroll
+            for (int e = 0; e < D; ++e) z[e] = p[(2 + e) * T3];
+        }
+        if (live) {
+            Wt = (v * nrm_N) / nrm_sumw;                        // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366)
+            if (ma.hist_W && ma.store_history) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = Wt;
+        }
+        k2_mh_steps<D, ALPHA1, T3, true>(L, mixbuf, mixpos, mixzt, ma, g.n, lv, mv, nb, nf, live, i, pid, (unsigned)n, phi_n, x, like, lprior, like_prev, accept,
+                                         step_prob, uc, z);
+        if (live) acc_val = accept / (double)nf;                // quirk Q2: normalised by n_free only
+        K3_STAMP(sa.prof, 5);
+        {
+            double *plain = ma.rows_mut + (long long)rowi * RMUT;      // (the launch after this one totals the last stage's rows from here)
+            k2_mut_row_f<T3>(ma.adaptive != 0, like, like_prev, live ? Wt : 0.0, live ? acc_val : 0.0, e_center, live, false, red, L.red,
+                             [&](int idx, double val) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; });
+            if (tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
+        }
+        ++done;
+        K3_STAMP(sa.prof, 6);
         if (n < sa.n_last) k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
+        K3_STAMP(sa.prof, 7);
         if (!rec3_wait(sa.rec, &s_a, WA, sa.tag_base | (unsigned)(n + 1), sa.to, &s_to)) { timed_out = true; break; }
         if (s_a.act != 0) break;                                // leave: registers hold the cloud after stage n
         K3_STAMP(sa.prof, 8);
@@ -412,7 +494,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
 #pragma unroll
         for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = x[k];
         col(cl, 0, D)[i] = like; col(cl, 0, D + 1)[i] = lprior; col(cl, 0, D + 2)[i] = like_prev;
-        col(cl, 0, D + 3)[i] = acc_val; col(cl, 0, D + 4)[i] = W;
+        col(cl, 0, D + 3)[i] = acc_val; col(cl, 0, D + 4)[i] = Wt;
     }
     if (blockIdx.x == 0 && tid == 0) {
         if (sa.done_out) *sa.done_out = done;
