@@ -228,7 +228,7 @@ def main():
     out = {
         "metric": "particle-stages/sec", "value": value, "unit": "particle-stages/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
-        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if world > 1 else None, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (("gauss%d_isotropic_adaptive_phi_n%dk" % (D, n_total // 1000)) +
                                 (" (BASELINE config 3: %d particles in total, strong scaling over %d GPUs, %d per GPU)" % (n_total, world, n_local)
                                  if world > 1 else " (BASELINE config 2)")) if args.workload == "gauss10"
@@ -289,6 +289,30 @@ def main():
                            "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl,
                            "valu_frac": valu.get("frac") if valu else None, "valu": valu,
                            "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None}
+        if prof.get("n_segments", 0) > 0 and prof.get("segment_stages", 0) > 0 and prof.get("kernel_ms_segments", 0.0) > 0.0:
+            # Engine 3 (csrc/stage3.hpp): runs of stages that neither resample nor need a certificate pass execute as ONE persistent
+            # launch each - the dominant kernel is k3_segment and a launch is a whole run of stages, correction + moments + mutation.
+            # Algorithmic bytes of a launch = (24 d + 96) bytes per particle-stage (stage without resampling) x N x the
+            # stages it completed; duration = HIP events around every segment launch on the engine's stream (use_graph = 2).  The
+            # cloud stays in registers inside a segment, so the HBM traffic the counters see is far BELOW the algorithmic figure
+            # (history columns + one row per block and phase); the stage is bound by the latency of its two chip-wide hand-overs.
+            seg_ms, seg_st, seg_n = prof["kernel_ms_segments"], prof["segment_stages"], prof["n_segments"]
+            stage_b = (24 * D + 96) * n_k
+            ach3 = stage_b * seg_st / (seg_ms * 1e-3) / 1e9
+            traffic3, pmc3 = None, None
+            if pmc_file:
+                k3 = [(name, v) for name, v in pm["kernels"].items() if "k3_segment<%d," % D in name]
+                if k3:
+                    traffic3, pmc3 = k3[0][1].get("total_bytes"), k3[0][1].get("valu")
+            out["roofline"] = {"bound": "hbm", "kernel": "k3_segment<%d, %s> (persistent: one launch = a run of stages)" % (D, "true" if RUN_KW["alpha"] == 1.0 else "false"),
+                               "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach3 / HBM_PEAK_GBS, "traffic": traffic3,
+                               "bytes_per_launch": stage_b * seg_st / seg_n, "mean_launch_us": 1e3 * seg_ms / seg_n, "launches": seg_n,
+                               "stages_per_launch": seg_st / seg_n, "bytes_per_stage": stage_b, "mean_stage_us": 1e3 * seg_ms / seg_st,
+                               "note": "latency-bound at this N: two chip-wide hand-overs per stage (3 store->load hops each) + the serial "
+                                       "decision / proposal / Newton work of one block; stages outside segments (resample / certificate "
+                                       "stages: %d of %d) run as engine 2's launches" % (last["n_stages"] - 1 - seg_st, last["n_stages"] - 1),
+                               "valu": pmc3, "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
+                               "mutation_kernel_outside_segments": {"kernel": kname_run, "mean_launch_us": 1e3 * mean_ms, "launches": nl}}
         if args.workload == "kalman" and mean_ms > 0:
             # config 5 is compute bound: ~3300 FP64 flops per filter step (FMA = 2; csrc/model.hpp kalman_lgss), steps = new + old
             # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s

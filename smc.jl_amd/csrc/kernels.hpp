@@ -12,6 +12,16 @@
 #include <hip/hip_runtime.h>
 
 #include "devstate.hpp"
+// The mutation kernels let the compiler contract a*b+c into fused multiply-adds (the product; ~3 % of the MH decisions' operands
+// differ in the last bit from the uncontracted oracle's, about one decision in 10^5 flips).  -DSMCMI_STRICT_FP (libsmcmi_strict.so,
+// `make libsmcmi_strict.so`) builds the same library with every contraction off: the variant the parity tests compare with the
+// oracle decision for decision (tests/test_gpu_strict.py).
+#ifdef SMCMI_STRICT_FP
+#define SMCMI_FP_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define SMCMI_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#endif
+
 #include "model.hpp"
 #include "philox.hpp"
 
@@ -2170,7 +2180,7 @@ __device__ inline void mix_expand(const MixDense<D> &M, const double *Lb, const 
 // rows [E0, E1) of the two solves and their contribution to the three quadratic forms
 template <int D, int E0, int E1, class MX>
 __device__ inline void mix_solve_rows(const MX &M, const double (&x)[D], const double (&xn)[D], double &quad, double &quad_s, double &quad_d) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     constexpr int NE = E1 - E0;
     if constexpr (NE > 0) {
         double v1[NE], v2[NE];
@@ -2199,7 +2209,7 @@ __device__ inline void mix_solve_rows(const MX &M, const double (&x)[D], const d
 template <int D, int T, class MX>
 __device__ inline double mix_propose(const MX &M, const double (&x)[D], const double (&z)[D], double uc, double c_alpha, bool force_diag,
                                      double *zt, double (&xn)[D]) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
     const bool diag_draw = comp == 1 || force_diag;
 #pragma unroll
@@ -2265,7 +2275,7 @@ __global__ void __launch_bounds__(256) k_mix_prepare(const DevState *st, int nb,
 template <int D, bool ALPHA1>
 __global__ void __launch_bounds__(256, 3) k_mutate_reg(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma,
                                                    double *acc_partials, int standalone, int nb, int nf) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int T = blockDim.x, tid = threadIdx.x;
     const bool profme = ma.prof != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);

@@ -153,7 +153,7 @@ __host__ __device__ constexpr int ksym(int i, int j) { return i <= j ? i * 8 - i
 // over the prefix returns) - the tempered update's old_loglikelihood when the old vintage is a prefix of the new one.
 struct KalmanLL { double ll, ll_mid; };
 __device__ __attribute__((noinline)) static KalmanLL kalman_lgss2(const double *thv, const double *ydat, long long nt, long long nt_mid, const double *aux, double kappa) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     // The structure block and the data are the same for every lane, but an out-of-line function receives its pointers in VGPRs and
     // would fetch them with vector loads (105 flat loads and a dozen full waits per filter step): pin the addresses to SGPRs and
     // to the constant address space, so the values arrive through the scalar cache as SGPR operands of the FMAs.

@@ -767,7 +767,7 @@ static __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, 
 template <int D>
 __device__ inline void draw2(unsigned long long seed, unsigned long long pid, unsigned stage, unsigned t, int db, int debug, double &step_prob,
                              double &uc, double (&z)[D]) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     double u_dummy, unext;
     if (t == 0) uniform_pair(seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);       // quirk Q3: drawn before the proposal
     else uniform_pair(seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
@@ -1459,7 +1459,7 @@ __device__ inline void k2_mh_steps(const Mut2Lds<D> &L, double *mixbuf, int *mix
                                    const LikView (&lv)[2], const ModelView &mv, int nb, int nf, bool live, long long i, unsigned long long pid,
                                    unsigned stage, double phi_n, double (&x)[D], double &like, double &lprior, double &like_prev, double &accept,
                                    double &step_prob, double &uc, double (&z)[D]) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     const int tid = threadIdx.x, n_steps = ma.n_steps, has_other = ma.has_other;
     const double c_alpha = ma.alpha;
     double *Ls = L.Ls, *Lraw = L.Lraw, *logdet_s = L.logdet_s, *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
@@ -1604,7 +1604,7 @@ __device__ inline void k2_mut_row(double *row, bool adaptive, double like, doubl
 template <int D, bool ALPHA1, int T, bool TAIL>
 __global__ void __launch_bounds__(T, T == 512 ? 2 : 3) k2_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g,
                                                                                Mut2Args ma, int nb, int nf) {
-#pragma clang fp contract(fast)
+SMCMI_FP_CONTRACT
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ Mut2Stage S;
     const Mut2Lds<D> L(sm);

@@ -70,7 +70,7 @@ __device__ inline bool rec3_wait(const unsigned long long *rec, void *dst_lds, i
             const long long t0 = wall_clock64();
             const long long lim = (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             do {
-                if (nap) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(1);
+                if (nap) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(1);
                 a = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(a >> 32) == tag) break;
                 if (wall_clock64() - t0 > lim || __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -104,7 +104,7 @@ __device__ inline void gran_poll(const unsigned long long *w, unsigned tag, unsi
     const long long t0 = wall_clock64();
     const long long lim = (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     do {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
         a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(a >> 32) == tag) return;
         if (wall_clock64() - t0 > lim || __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsmcmi.so")
+# SMCMI_LIBRARY selects another build of the same library (tests: libsmcmi_strict.so, every floating-point contraction off)
+LIB_PATH = os.environ.get("SMCMI_LIBRARY") or os.path.join(os.path.dirname(_HERE), "csrc", "libsmcmi.so")
 
 MAX_PARA = 64
 MAX_CAND = 16

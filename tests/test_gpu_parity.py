@@ -261,10 +261,11 @@ def test_mutation_vs_oracle(orc, name, n_blocks, n_mh, alpha):
     phi = 0.002 if name.startswith("linmodel") or name == "capm" else 0.05
     P, want, got, acc = _mutation_case(orc, spec, n, n_blocks, n_mh, alpha, 0.4, phi, seed=123, stage=7)
     d = len(spec["priors"])
-    # accept column is discrete (accepted block lengths / n_free): must agree exactly (allow a 1e-4 fraction of
-    # razor-edge u < eta decisions to flip between device and host libm)
+    # accept column is discrete (accepted block lengths / n_free): it must agree exactly - the contracted product build measured 0
+    # differing decisions in 820 000 against the uncontracted oracle (tests/test_gpu_strict.py counts them; the strict build must have
+    # none); one razor-edge u < eta decision is the most this test lets pass
     flips = np.flatnonzero(got[:, d + 3] != want[:, d + 3])
-    assert flips.size <= max(1, n // 10000), flips.size
+    assert flips.size <= 1, flips.size
     keep = np.setdiff1d(np.arange(n), flips)
     np.testing.assert_allclose(got[keep, :d + 3], want[keep, :d + 3], rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(got[:, d + 4], P[:, d + 4])                # weights untouched
@@ -371,11 +372,13 @@ def _compare_runs(orc, spec, n, seed, tol_logmdd, **kw):
     assert g["n_stages"] == r["n_stages"]
     assert g["resamples"] == r["resamples"]
     rec = e.stage_records(g["n_stages"])
-    np.testing.assert_allclose(rec["schedule"], r["schedule"], rtol=1e-8)
-    np.testing.assert_allclose(rec["ess"], r["ess"], rtol=1e-6)
+    # (tolerances: the adaptive root is certified to 1e-12 / verified to 1e-10 relative per stage and carries forward; a flipped MH
+    # decision moves an acceptance rate by at most 1 / n - at most three flips per stage are let through)
+    np.testing.assert_allclose(rec["schedule"], r["schedule"], rtol=1e-9)
+    np.testing.assert_allclose(rec["ess"], r["ess"], rtol=1e-9)
     np.testing.assert_array_equal(rec["resampled"], r["resampled"])
-    np.testing.assert_allclose(rec["c_hist"], r["c_hist"], rtol=1e-6)
-    np.testing.assert_allclose(rec["accept_hist"], r["accept_hist"], atol=2e-3)
+    np.testing.assert_allclose(rec["c_hist"], r["c_hist"], rtol=1e-9)
+    np.testing.assert_allclose(rec["accept_hist"], r["accept_hist"], atol=3.0 / n + 1e-12)
     assert g["logmdd"] == pytest.approx(r["logmdd"], abs=tol_logmdd)
     return e, g, r
 
@@ -678,7 +681,8 @@ def test_bench_line_contract():
               "data", "config", "roofline"):
         assert k in d, k
     assert d["metric"] == "particle-stages/sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    # (one GPU: neither weak nor strong scaling is being measured - null; the N > 1 lines say "strong")
+    assert d["higher_is_better"] is True and d["scaling"] is None and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert "workload" in d["config"] and d["value"] > 0
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):

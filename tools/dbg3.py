@@ -5,7 +5,7 @@ from tests import models
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 e = Engine(n, 10, seed=1, max_stages=400, store_history=True)
 e.set_model(models.gauss_spec(10))
-for rep in range(1):
+for rep in range(3):
     e.init_from_prior()
     try:
         r = e.run(use_fixed_schedule=False, tempering_target=0.97, use_graph=2)
