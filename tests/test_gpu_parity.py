@@ -687,4 +687,5 @@ def test_bench_line_contract():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "valu" and "valu" in r and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # (a cloud this small runs in engine 3's segments: the quoted kernel is k3_segment, per-stage figures beside the per-launch ones)
+    assert r["bound"] in ("hbm", "valu") and "valu" in r and "k3_segment" in r["kernel"] and r["mean_stage_us"] > 0 and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
