@@ -12,6 +12,7 @@
 #include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include <stdatomic.h>
 #endif
 
 #define ORC_MAXD 512
@@ -124,6 +125,148 @@ static double compute_ess_omp(const double *loglh, const double *w, const double
     return s * s / s2;
 }
 
+/* CPU-baseline variant 2 only: the adaptive-ϕ solve on a PERSISTENT team.  ESS(ϕ_k) - ESS_bar for K candidates per pass over the
+   cloud; every thread accumulates the 2 K sums of its chunk, thread 0 combines them in thread order and takes the decision while
+   the others spin on a sequence number - one parallel region per solve.  With a passive wait policy (bench.py sets it: spinning
+   workers slow the serial stretches of the run) every parallel region costs a wake-up of the whole team, and the sixty-odd regions
+   per stage of a bisection to adjacent floats were what made this variant no faster than the serial one. */
+#define ORC_KSEC 4
+typedef struct {
+    const double *loglh, *w, *old;
+    int64_t n;
+    double phi_n1, ess_bar;
+    double phis[ORC_KSEC];
+    int K, nt;
+    double *part;                       /* [nt][2][ORC_KSEC] */
+    _Atomic int seq, done, quit;
+} ess_team;
+static void team_chunk(ess_team *tm, int t) {
+    const int64_t beg = tm->n * t / tm->nt, end = tm->n * (t + 1) / tm->nt;
+    const int K = tm->K;
+    double s[ORC_KSEC], s2[ORC_KSEC];
+    for (int k = 0; k < K; ++k) s[k] = s2[k] = 0.0;
+    for (int64_t i = beg; i < end; ++i) {
+        const double old = tm->old ? tm->old[i] : 0.0, l = tm->loglh[i], wi = tm->w[i];
+        for (int k = 0; k < K; ++k) {
+            const double v = wi * exp((tm->phi_n1 - tm->phis[k]) * old + (tm->phis[k] - tm->phi_n1) * l);
+            s[k] += v;
+            s2[k] += v * v;
+        }
+    }
+    for (int k = 0; k < K; ++k) { tm->part[((size_t)t * 2) * ORC_KSEC + k] = s[k]; tm->part[((size_t)t * 2 + 1) * ORC_KSEC + k] = s2[k]; }
+}
+/* thread 0: g_out[k] = ESS(phis[k]) - ESS_bar */
+static void ess_candidates_team(ess_team *tm, const double *phis, int K, double *g_out) {
+    for (int k = 0; k < K; ++k) tm->phis[k] = phis[k];
+    tm->K = K;
+    atomic_store(&tm->done, 0);
+    atomic_fetch_add(&tm->seq, 1);                          /* release the workers */
+    team_chunk(tm, 0);
+    while (atomic_load(&tm->done) < tm->nt - 1) { }
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0, s2 = 0.0;
+        for (int t = 0; t < tm->nt; ++t) { s += tm->part[((size_t)t * 2) * ORC_KSEC + k]; s2 += tm->part[((size_t)t * 2 + 1) * ORC_KSEC + k]; }
+        g_out[k] = s * s / s2 - tm->ess_bar;
+    }
+}
+static void team_worker(ess_team *tm, int t) {
+    int seen = 0;
+    for (;;) {
+        int sq;
+        while ((sq = atomic_load(&tm->seq)) == seen) { if (atomic_load(&tm->quit)) return; }
+        seen = sq;
+        team_chunk(tm, t);
+        atomic_fetch_add(&tm->done, 1);
+    }
+}
+static double bit_at(double a, double b, int k, int K) {      /* the bit pattern a + (b - a) k / K, a <= b, both >= 0 */
+    uint64_t ia, ib;
+    memcpy(&ia, &a, 8);
+    memcpy(&ib, &b, 8);
+    const uint64_t span = ib - ia;
+    uint64_t im = ia + (uint64_t)(((unsigned __int128)span * (unsigned)k) / (unsigned)K);
+    double m;
+    memcpy(&m, &im, 8);
+    return m;
+}
+/* solve_adaptive_ϕ (helpers.jl:9-56) by K-section instead of bisection: the schedule walk takes K schedule points per pass, the root
+   search K - 1 interior points of the bracket per pass (over the bit pattern, like Roots' bisection) - the same root to adjacent
+   floats in ~11 passes instead of ~60 (for a monotone ESS; the ESS values themselves differ from the serial sums in the last bits). */
+static int ksection_master(ess_team *tm, const double *sched, int32_t n_phi, int32_t *j, double *phi_prop, double phi_n1, double *phi_n, int *evals) {
+    double g[ORC_KSEC], ph[ORC_KSEC];
+    /* the walk: while g(ϕ_prop) >= 0 and j <= n_Φ: ϕ_prop = schedule[j]; j += 1 (helpers.jl:29-32), K schedule points per pass */
+    double g_prop;
+    for (;;) {
+        int K = 0;
+        ph[K++] = *phi_prop;
+        for (int q = 0; K < ORC_KSEC && *j + q <= n_phi; ++q) ph[K++] = sched[*j - 1 + q];
+        ess_candidates_team(tm, ph, K, g);
+        *evals += K;
+        int k = 0;
+        while (k < K - 1 && g[k] >= 0.0) { *phi_prop = ph[k + 1]; *j += 1; ++k; }
+        g_prop = g[k];
+        if (!(g_prop >= 0.0 && *j <= n_phi && k == K - 1 && K > 1)) break;      /* walked off this batch with the condition still true: next batch */
+    }
+    if (*phi_prop != 1.0 || g_prop < 0.0) {
+        double a = phi_n1, b = *phi_prop, fa, fb = g_prop;
+        ph[0] = a;
+        ess_candidates_team(tm, ph, 1, g);
+        *evals += 1;
+        fa = g[0];
+        if (fa == 0.0) { *phi_n = a; return 0; }
+        if (fb == 0.0) { *phi_n = b; return 0; }
+        if ((fa > 0) == (fb > 0) || isnan(fa) || isnan(fb)) return fail("solve_adaptive_phi: bracket does not change sign");
+        for (;;) {
+            int K = 0;
+            for (int k = 1; k <= ORC_KSEC; ++k) {             /* K interior points of the bracket, over the bit pattern like Roots' bisection */
+                const double x = bit_at(a, b, k, ORC_KSEC + 1);
+                if (x != a && x != b && (K == 0 || x != ph[K - 1])) ph[K++] = x;
+            }
+            if (K == 0) break;                                   /* adjacent floats */
+            ess_candidates_team(tm, ph, K, g);
+            *evals += K;
+            int done = 0;
+            for (int k = 0; k < K; ++k) {
+                if (g[k] == 0.0 || isnan(g[k])) { *phi_n = ph[k]; done = 1; break; }
+                if ((g[k] > 0) != (fa > 0)) { b = ph[k]; fb = g[k]; break; }
+                a = ph[k]; fa = g[k];
+            }
+            if (done) return 0;
+        }
+        *phi_n = (fabs(fa) <= fabs(fb)) ? a : b;
+    } else *phi_n = 1.0;
+    return 0;
+}
+/* solve_adaptive_ϕ (helpers.jl:9-56) by K-section on a persistent team: the same root to adjacent floats (for a monotone ESS; the ESS
+   values themselves differ from the serial sums in the last bits). */
+static int solve_adaptive_phi_ksection(const double *loglh, const double *w, const double *old, int64_t n, double ess_bar, const double *sched,
+                                       int32_t n_phi, int32_t *j, double *phi_prop, double phi_n1, double *phi_n, int *evals) {
+    ess_team tm;
+    memset(&tm, 0, sizeof(tm));
+    tm.loglh = loglh; tm.w = w; tm.old = old; tm.n = n; tm.phi_n1 = phi_n1; tm.ess_bar = ess_bar;
+    int nt = g_ess_threads;
+    if ((int64_t)nt * 1024 > n) nt = (int)(n / 1024) > 0 ? (int)(n / 1024) : 1;
+    tm.part = (double *)calloc((size_t)nt * 2 * ORC_KSEC, sizeof(double));
+    int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+    {
+#pragma omp single
+        tm.nt = omp_get_num_threads();                         /* (implicit barrier: every thread sees the team size) */
+        const int t = omp_get_thread_num();
+        if (t == 0) {
+            rc = ksection_master(&tm, sched, n_phi, j, phi_prop, phi_n1, phi_n, evals);
+            atomic_store(&tm.quit, 1);
+        } else team_worker(&tm, t);
+    }
+#else
+    tm.nt = 1;
+    rc = ksection_master(&tm, sched, n_phi, j, phi_prop, phi_n1, phi_n, evals);
+#endif
+    free(tm.part);
+    return rc;
+}
+
 static double bit_middle(double a, double b) { /* Roots.jl exact bisection midpoint over the bit pattern, a,b >= 0 */
     uint64_t ia, ib;
     memcpy(&ia, &a, 8);
@@ -144,6 +287,11 @@ int orc_solve_adaptive_phi(const double *particles, int64_t n, int32_t R, double
     int evals = 0;
     if (*resampled_last) { ess_bar = target * (double)n; *resampled_last = 0; }   /* helpers.jl:14-20 */
     else ess_bar = target * ess_prev;
+    if (g_ess_threads > 1) {                                       /* CPU-baseline variant 2: K candidates per pass */
+        int rc = solve_adaptive_phi_ksection(loglh, w, old, n, ess_bar, sched, n_phi, j, phi_prop, phi_n1, phi_n, &evals);
+        if (n_evals) *n_evals = evals;
+        return rc;
+    }
 #define G(phi) (evals++, (g_ess_threads > 1 ? compute_ess_omp(loglh, w, old, n, (phi), phi_n1) : orc_compute_ess(loglh, w, old, n, (phi), phi_n1)) - ess_bar)
     while (G(*phi_prop) >= 0.0 && *j <= n_phi) { *phi_prop = sched[*j - 1]; *j += 1; } /* helpers.jl:29-32 */
     if (*phi_prop != 1.0 || G(*phi_prop) < 0.0) {                                 /* helpers.jl:48-50 */
