@@ -14,8 +14,8 @@
 #include "devstate.hpp"
 // The mutation kernels let the compiler contract a*b+c into fused multiply-adds (the product; ~3 % of the MH decisions' operands
 // differ in the last bit from the uncontracted oracle's, about one decision in 10^5 flips).  -DSMCMI_STRICT_FP (libsmcmi_strict.so,
-// `make libsmcmi_strict.so`) builds the same library with every contraction off: the variant the parity tests compare with the
-// oracle decision for decision (tests/test_gpu_strict.py).
+// `make libsmcmi_strict.so`) builds the same library with every contraction off: the variant the parity tests compare decision for
+// decision with the CPU restatement (tests/test_gpu_strict.py).
 #ifdef SMCMI_STRICT_FP
 #define SMCMI_FP_CONTRACT _Pragma("clang fp contract(off)")
 #else
