@@ -102,6 +102,9 @@ save("linmodel.npz", data=data, X=X, initial_draw=c1["particles"], init_lik=c2["
      one_draw_theta=od[0], one_draw_loglh=od[1], one_draw_logprior=od[2],
      draw_lik_loglh=dl[0], draw_lik_logprior=dl[1])
 
+# 4b. the regime-switching version of the linear test model (test/regime_switching_smc.jl, test/modelsetup.jl:78-103): data and predictors
+save("rsmodel.npz", rsdata=jl(t["rsdata"][()]), Xrs=jl(t["Xrs"][()]))
+
 # 5. mutation (reject-path identity + stored logprior)
 f = h5py.File(R + "mutation_inputs.jld2", "r")
 mu, Sig = mvn(f, "d")

@@ -220,3 +220,56 @@ def test_regime_switching_columns():
     assert abs(m[0] - y[:T // 2].mean()) < 0.1 and abs(m[2] - y[T // 2:].mean()) < 0.1 and abs(m[1] - 0.3) < 1e-12
     with pytest.raises(ValueError):
         S.smc(S.GaussIso(0.25), pars, data, regime_switching=True, n_parts=100, verbose="none")
+
+
+def test_reference_regime_switching_scenario():
+    """test/regime_switching_smc.jl:25-60 (model: test/modelsetup.jl:9-68, likelihood `rs_loglik_fn` :140-168, data `rsdata` / `Xrs` of
+    test/reference/test_data.h5): three regressions whose constants and slopes switch between three regimes of 100 periods each - 21
+    columns once flattened (α3 fixed at 3 in every regime), fixed schedule n_Φ = 120, α = 0.9, :polyalgo resampling.  The reference's
+    own acceptance test: posterior means within 0.5 of the data-generating values (its golden cloud is one of the missing blobs)."""
+    import smc_jl_amd as S
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "rsmodel.npz"))
+    data, Xrs = z["rsdata"], z["Xrs"]
+    pp = 10.0                                            # prior_para of the regime-switching set-up
+    pars = []
+    for i in (1, 2, 3):
+        a = S.parameter("α%d" % i, 3.0 if i == 3 else -0.1 * i, (-1e5, 1e5), prior=S.Normal(0.0, pp), fixed=(i == 3))
+        a.add_regime(3.0 if i == 3 else 0.1 * i).add_regime(3.0)
+        b = S.parameter("β%d" % i, 0.2 * i, (-1e5, 1e5), prior=S.Normal(0.0, pp))
+        b.add_regime(-0.1 * i, prior=S.Normal(0.0, pp * 1.2)).add_regime(0.1 * i, prior=S.Normal(0.0, pp * 1.5))
+        sg = S.parameter("σ%d" % i, 1.0, (1e-5, 1e5), prior=S.Uniform(0.0, pp))
+        pars += [a, b, sg]
+    flat = S.flatten_regimes(pars)
+    assert len(flat) == 21 and [p.key for p in flat[9:13]] == ["α1_reg2", "α1_reg3", "β1_reg2", "β1_reg3"]
+    # column of (equation i, regime r) for α and β in the flattened vector
+    col = {}
+    pos = 9
+    for k, p in enumerate(pars):
+        col[(p.key, 0)] = k
+        for r in range(len(p.regimes)):
+            col[(p.key, r + 1)] = pos
+            pos += 1
+
+    def loglik(th, d):                                   # rs_loglik_fn, vectorised over the batch of proposals (Σ_ii = σ_i, as written there)
+        m = th.shape[0]
+        out = np.zeros(m)
+        var = np.stack([th[:, col[("σ%d" % i, 0)]] for i in (1, 2, 3)], axis=1)                     # m x 3
+        with np.errstate(invalid="ignore", divide="ignore"):
+            term1 = -1.5 * math.log(2.0 * math.pi) - 0.5 * np.log(var.prod(axis=1))
+            for r in range(3):
+                sl = slice(100 * r, 100 * (r + 1))
+                al = np.stack([th[:, col[("α%d" % i, r)]] for i in (1, 2, 3)], axis=1)[:, :, None]     # m x 3 x 1
+                be = np.stack([th[:, col[("β%d" % i, r)]] for i in (1, 2, 3)], axis=1)[:, :, None]
+                e = d[None, :, sl] - al - be * Xrs[None, :, sl]
+                out += 100 * term1 - 0.5 * (e * e / var[:, :, None]).sum(axis=(1, 2))
+        return out
+    loglik.batched = True
+
+    cloud, w, W = S.smc(loglik, pars, data, verbose="none", use_fixed_schedule=True, n_phi=120, n_mh_steps=1, resampling_method="polyalgo",
+                        target=0.25, alpha=0.9, threshold_ratio=0.5, regime_switching=True, toggle=True, n_parts=5000, seed=42)
+    assert cloud.particles.shape == (5000, 21 + 5) and cloud.stage_index == 120
+    mean_para = S.get_vals(cloud).mean(axis=1)           # mean(SMC.get_vals(test_cloud), dims = 2): unweighted, as the reference's test
+    true_para = np.array([1., 1., 1., 2., 2., 1., 3., 3., 1., 1., 1., 2., 3., 2., 2., 3., 4., 3., 3., 4., 5.])
+    assert np.max(np.abs(mean_para - true_para)) < 0.5, mean_para
+    np.testing.assert_array_equal(cloud.particles[:, [6, 17, 18]], 3.0)        # α3 in its three regimes: fixed

@@ -398,6 +398,21 @@ def test_run_regression_config1(orc):
     np.testing.assert_allclose(orc.weighted_mean(P), [1.00018685, 0.99936133], atol=0.15)
 
 
+def test_run_with_fixed_and_free_regime_columns_vs_oracle(orc):
+    """The shape a regime-switching parameter vector has once flattened (src/smc_main.jl:207-234): extra columns behind the base
+    parameters, some fixed in some regimes - here a device family over 8 columns of which three are fixed (a base parameter and two
+    regime columns), with random blocks and a mixture proposal: free-index bookkeeping, moments and blocks over the free subset only,
+    against the oracle on the same Philox streams."""
+    spec = models.gauss_spec(d=8)
+    spec["fixed"] = [0, 0, 1, 0, 0, 1, 0, 1]
+    spec["priors"] = [("normal", 0.3 * k, 5.0) if not f else ("normal", -1.0 + 2.0 * k / 7.0, 5.0) for k, f in enumerate(spec["fixed"])]
+    e, g, r = _compare_runs(orc, spec, 12000, 31, 1e-6, use_fixed_schedule=False, tempering_target=0.93, n_blocks=2, alpha=0.9)
+    P = e.download_cloud()
+    for k in (2, 5, 7):
+        assert np.all(P[:, k] == P[0, k])                       # fixed columns never move
+    np.testing.assert_allclose(orc.weighted_mean(P), orc.weighted_mean(r["particles"]), atol=1e-6)
+
+
 def test_run_gauss_adaptive_small(orc):
     spec = models.gauss_spec()
     _compare_runs(orc, spec, 20000, 3, 1e-4, use_fixed_schedule=False, tempering_target=0.97)
