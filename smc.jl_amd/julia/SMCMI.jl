@@ -10,6 +10,10 @@
 # bounds check, synchronously on the calling thread (the library never calls back from another thread).  `DeviceLikelihood`
 # structs select a built-in device family instead (no PCIe traffic inside the loop).
 #
+# Bound: smc, Cloud and its accessors, and the other exports of src/SMC.jl:13-17 (mutation, resample, mvnormal_mixture_draw,
+# initial_draw!, get_cloud, isempty).  `run_test` stops at stage 3 like smc_main.jl:495; `verbose` prints the reference's stage lines
+# from the per-stage records after the run; `old_cloud` may be a Cloud of this module or one SMC.jl itself saved.
+#
 # Julia is not part of the build image, so this file has not been executed here; every `ccall` spells out the C signature of
 # include/smcmi.h and the structs mirror its layout field by field (tests/test_abi_cpu.py pins the C side).  See INTEGRATION.md.
 module SMCMI
@@ -18,7 +22,8 @@ using ModelConstructors, Distributions, Random, Dates
 import JLD2, HDF5, LinearAlgebra
 
 export smc, Cloud, get_vals, get_loglh, get_logprior, get_old_loglh, get_logpost, get_accept, get_weights, weighted_mean, weighted_cov,
-       weighted_std, cloud_isempty, GaussIso, LinReg, LinModel3, CapmLiteral, LGSSKalman
+       weighted_std, cloud_isempty, GaussIso, LinReg, LinModel3, CapmLiteral, LGSSKalman,
+       mutation, resample, mvnormal_mixture_draw, initial_draw!, get_cloud                       # src/SMC.jl:13-17
 
 const LIB = get(ENV, "SMCMI_LIB", joinpath(@__DIR__, "..", "csrc", "libsmcmi.so"))
 const Handle = Ptr{Cvoid}
@@ -64,7 +69,14 @@ mutable struct Cloud
 end
 Cloud(n_params::Int, n_parts::Int) = Cloud(Matrix{Float64}(undef, n_parts, n_params + 5), [0.], [0.], 1, 0, 0, 0., 0.25, 0.)
 cloud_isempty(c::Cloud) = isempty(c.particles)
+Base.isempty(c::Cloud) = isempty(c.particles)                                                   # src/particle.jl (the reference's own spelling)
 Base.length(c::Cloud) = size(c.particles, 1)
+# A cloud saved by SMC.jl itself (`load(path, "cloud")::SMC.Cloud`, smc_main.jl:521-525) or by this module: the same nine fields
+as_cloud(c::Cloud) = c
+as_cloud(c) = Cloud(Matrix{Float64}(getfield(c, :particles)), Vector{Float64}(getfield(c, :tempering_schedule)), Vector{Float64}(getfield(c, :ESS)),
+                    Int(getfield(c, :stage_index)), Int(getfield(c, :n_Φ)), Int(getfield(c, :resamples)), Float64(getfield(c, :c)),
+                    Float64(getfield(c, :accept)), Float64(getfield(c, :total_sampling_time)))
+get_cloud(filepath::String) = as_cloud(JLD2.load(filepath, "cloud"))                             # src/util.jl:113-115
 n_para(c::Cloud) = size(c.particles, 2) - 5
 get_vals(c::Cloud; transpose::Bool = true) = transpose ? collect(c.particles[:, 1:n_para(c)]') : c.particles[:, 1:n_para(c)]
 get_loglh(c::Cloud) = c.particles[:, n_para(c) + 1]
@@ -237,7 +249,7 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
              λ::Float64 = 2.1, n_Φ::Int64 = 300, resampling_method::Symbol = :systematic, threshold_ratio::Float64 = 0.5,
              c::Float64 = 0.5, α::Float64 = 1.0, target::Float64 = 0.25,
              use_fixed_schedule::Bool = true, tempering_target::Float64 = 0.97,
-             old_data::Matrix{Float64} = Matrix{Float64}(undef, size(data, 1), 0), old_cloud::Cloud = Cloud(0, 0),
+             old_data::Matrix{Float64} = Matrix{Float64}(undef, size(data, 1), 0), old_cloud = Cloud(0, 0),     # (any Cloud-shaped struct: SMC.Cloud too)
              old_loglikelihood = loglikelihood, old_vintage::String = "", smc_iteration::Int = 1,
              run_test::Bool = false, filestring_addl::Vector{String} = Vector{String}(),
              loadpath::String = "", savepath::String = "smc_cloud.jld2", particle_store_path::String = "smcsave.h5",
@@ -254,7 +266,9 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
     d = length(flat_entries(parameters, regime_switching))                                         # n_para incl. the regime columns, :207-216
     all(e -> e[1], flat_entries(parameters, regime_switching)) && throw(AssertionError("All model parameters are fixed!"))      # :236-239
     tempered_update = !isempty(old_data)
-    max_stages = use_fixed_schedule ? n_Φ : 20 * n_Φ
+    haskey(VERBOSITY, verbose) || throw(ArgumentError("verbose must be one of :none, :low, :high"))
+    old_cloud = as_cloud(old_cloud)
+    max_stages = use_fixed_schedule ? n_Φ : 4 * n_Φ + 64          # (records + two N x max_stages history matrices; as the Python mirror)
     method = RESAMPLER[resampling_method]
     keep = Any[]                                             # callback environments (GC roots)
     h = create(n_parts, d, seed, device, max_stages)
@@ -286,10 +300,12 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
                 i_now = cont ? Int(ls.stage_index) : 1
                 stop = (div(i_now, intermediate_stage_increment) + 1) * intermediate_stage_increment
             end
+            run_test && (stop = stop == 0 ? 3 : min(stop, 3))      # `if run_test && (i == 3) break` (smc_main.jl:495)
             rc = RunConfig(n_blocks, n_mh_steps, λ, n_Φ, method, threshold_ratio, c, α, target, use_fixed_schedule ? 1 : 0,
                            tempering_target, tempered_update_prior_weight, log_prob_old_data, 0, 0, 0, initial_ess, 0.0, stop, cont ? 1 : 0)
             check(ccall((:smcmi_run, LIB), Cint, (Handle, Ref{RunConfig}, Ref{Result}), h, rc, res))
             res.paused == 0 && break
+            run_test && Int(res.n_stages) >= 3 && break
             cl, w, W, j = collect_cloud(h, n_parts, d, n_Φ, res)
             JLD2.jldopen(stage_path(savepath, cl.stage_index), true, true, true, JLD2.IOStream) do file          # :499-507
                 write(file, "cloud", cl); write(file, "w", w); write(file, "W", W); write(file, "j", j)
@@ -298,6 +314,7 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
         end
         cloud, w, W, _ = collect_cloud(h, n_parts, d, n_Φ, res)
         W1 === nothing || (W[:, 1] = sum(W1) <= 1.0 ? W1 .* n_parts : W1)
+        print_stages(h, cloud, parameters, regime_switching; verbose = verbose, use_fixed_schedule = use_fixed_schedule)
         if !testing                                                                                          # :513-526
             HDF5.h5open(particle_store_path, "w") do simfile
                 simfile["smcparams"] = cloud.particles[:, 1:d]
@@ -310,6 +327,53 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
     finally
         destroy(h)
     end
+end
+
+# verbose output (src/util.jl:117-180).  The loop runs on the device without a host round trip per stage, so the stage lines are printed
+# after the run from the per-stage records (the fields end_stage_print shows: iteration, ϕ, c, acceptance rate, ESS, resamples so far);
+# :high adds the final weighted means and standard deviations.  Per-stage wall times do not exist: the total is printed once.
+const VERBOSITY = Dict(:none => 0, :low => 1, :high => 2)
+function print_stages(h::Handle, cloud::Cloud, parameters, regime_switching::Bool; verbose::Symbol = :low, use_fixed_schedule::Bool = true)
+    VERBOSITY[verbose] >= VERBOSITY[:low] || return
+    ns = cloud.stage_index
+    phi = Vector{Float64}(undef, ns); ess = similar(phi); cs = similar(phi); acc = similar(phi); rs = Vector{Int32}(undef, ns)
+    check(ccall((:smcmi_get_stage_records, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                h, phi, ess, cs, acc, rs))
+    total = 0
+    for i in 2:ns
+        total += rs[i]
+        println("--------------------------")
+        println(use_fixed_schedule ? "Iteration = $(i) / $(cloud.n_Φ)" : "Iteration = $(i)")
+        println("--------------------------")
+        println("phi = $(phi[i])")
+        println("--------------------------")
+        println("c = $(cs[i])")
+        println("accept = $(i < ns ? acc[i] : cloud.accept)")
+        println("ESS = $(ess[i])   ($(total) total resamples.)")
+        println("--------------------------")
+    end
+    println("time elapsed: $(round(cloud.total_sampling_time / 60, digits = 4)) minutes")
+    if VERBOSITY[verbose] >= VERBOSITY[:high]
+        μ = weighted_mean(cloud); σ = weighted_std(cloud)
+        syms = para_symbols(parameters, regime_switching)
+        println("Mean and standard deviation of parameter estimates")
+        for n in 1:length(syms)
+            println("$(syms[n]) = $(round(μ[n], digits = 5)), $(round(σ[n], digits = 5))")
+        end
+    end
+end
+# para_symbols (smc_main.jl:207-234): the keys, then key_reg<i> for the regime columns
+function para_symbols(parameters, regime_switching::Bool)
+    syms = Symbol[p.key for p in parameters]
+    if regime_switching
+        for p in parameters
+            isempty(p.regimes) && continue
+            for i in 2:length(p.regimes[:value])
+                push!(syms, Symbol(p.key, "_reg", i))
+            end
+        end
+    end
+    syms
 end
 
 function collect_cloud(h::Handle, n_parts, d, n_Φ, res::Result)
@@ -382,6 +446,167 @@ function tempered_cloud!(h::Handle, old::Cloud, parameters, old_lik, old_data, n
     check(ccall((:smcmi_normalize_weights, LIB), Cint, (Handle, Int32), h, 1))                   # :313-314
     check(ccall((:smcmi_resample, LIB), Cint, (Handle, Int32, UInt32, Ptr{Float64}, Ptr{Int64}), h, method, 1, C_NULL, C_NULL))   # :317-322
     return Float64(n_parts)                                                                      # :325
+end
+
+# ---- the other functions src/SMC.jl:13-17 exports, over the same C entry points (one-off handles; inside smc() these steps are fused
+# kernels of the stage loop).  Random numbers come from the engine's Philox contract (DESIGN.md §2), keyed by `seed` / `stage`, not
+# from Julia's global RNG.
+
+"""
+    resample(weights; n_parts = length(weights), method = :systematic, parallel = false, seed, stage)
+
+src/resample.jl:23-72: the newly assigned (1-based) indices.  `n_parts != length(weights)` (the bridge case, smc_main.jl:266-279) goes
+through `smcmi_bridge_resample`.
+"""
+function resample(weights::Vector{Float64}; n_parts::Int64 = length(weights), method::Symbol = :systematic, parallel::Bool = false,
+                  seed::Integer = rand(UInt64), stage::Integer = 0, device::Integer = 0)
+    haskey(RESAMPLER, method) || throw("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
+    n = length(weights)
+    P = zeros(n, 1 + 5); P[:, 6] = weights
+    h = create(n, 1, seed, device, 2)
+    anc = Vector{Int64}(undef, n_parts)
+    try
+        check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+        if n_parts == n
+            check(ccall((:smcmi_resample, LIB), Cint, (Handle, Int32, UInt32, Ptr{Float64}, Ptr{Int64}), h, RESAMPLER[method], stage, C_NULL, anc))
+        else
+            hd = create(n_parts, 1, seed, device, 2)
+            try
+                check(ccall((:smcmi_bridge_resample, LIB), Cint, (Handle, Handle, Int32, UInt32, Int64, Ptr{Float64}, Ptr{Int64}),
+                            hd, h, RESAMPLER[method], stage, n_parts, C_NULL, anc))
+            finally
+                destroy(hd)
+            end
+        end
+    finally
+        destroy(h)
+    end
+    return anc .+ 1
+end
+
+"""
+    mvnormal_mixture_draw(θ_old, d_prop; c = 1.0, α = 1.0, seed, pid, stage)
+
+src/helpers.jl:87-100: one draw from the three-component mixture around `θ_old` (`d_prop::MvNormal` = the proposal distribution
+MvNormal(θ̄, Σ)).  Computed by `smcmi_propose` on a one-particle cloud, so the draw is the one the mutation kernel makes for particle
+`pid` at `stage`.
+"""
+function mvnormal_mixture_draw(θ_old::Vector{Float64}, d_prop; c::Float64 = 1.0, α::Float64 = 1.0, seed::Integer = rand(UInt64),
+                               pid::Integer = 0, stage::Integer = 0, device::Integer = 0)
+    @assert 0 <= α <= 1
+    d = length(θ_old); n = pid + 1
+    μ = Vector{Float64}(d_prop.μ); Σ = Matrix{Float64}(d_prop.Σ)
+    h = create(n, d, seed, device, 2)                       # (a cloud of pid + 1 rows: row pid + 1 carries the particle's RNG stream)
+    try
+        fixed = zeros(Int32, d); lo = fill(-1e300, d); hi = fill(1e300, d); fam = zeros(Int32, d); pa = zeros(d); pb = ones(d)
+        check(ccall((:smcmi_set_parameters, LIB), Cint, (Handle, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+                    h, fixed, lo, hi, fam, pa, pb))
+        set_model!(h, nothing, GaussIso(1.0), zeros(d, 1), 0, Any[])         # (a model must be set; the draw does not use it)
+        P = zeros(n, d + 5); P[n, 1:d] = θ_old; P[:, d + 5] .= 1.0
+        check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+        prop = Matrix{Float64}(undef, n, d); lp = Vector{Float64}(undef, n); qd = Vector{Float64}(undef, n)
+        bp = Int32[0, d]; bf = Int32.(collect(0:d-1))
+        check(ccall((:smcmi_propose, LIB), Cint,
+                    (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Int32, Int32, Int32, Float64, Float64, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    h, μ, collect(Σ'), bp, bf, 1, 0, 0, c, α, stage, prop, lp, qd))
+        return prop[n, :]
+    finally
+        destroy(h)
+    end
+end
+
+"""
+    initial_draw!(loglikelihood, parameters, data, c::Cloud; parallel = false, regime_switching = false, toggle = true, seed)
+
+src/initialization.jl:88-119: fills `c` with prior draws whose log-likelihood is finite (loglh, logprior; old_loglh = 0, weights = 1).
+"""
+function initial_draw!(loglikelihood, parameters::ParameterVector, data::Matrix{Float64}, c::Cloud; parallel::Bool = false,
+                       regime_switching::Bool = false, toggle::Bool = true, seed::Integer = rand(UInt64), device::Integer = 0)
+    n_parts = length(c); d = length(flat_entries(parameters, regime_switching))
+    keep = Any[]
+    h = create(n_parts, d, seed, device, 2)
+    try
+        set_parameters!(h, parameters; regime_switching = regime_switching)
+        set_model!(h, parameters, loglikelihood, data, 0, keep; toggle = regime_switching && toggle)
+        set_model!(h, parameters, nothing, data, 1, keep)
+        initial_draw!(h, parameters, loglikelihood, n_parts, d)
+        check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, c.particles))
+    finally
+        destroy(h)
+    end
+    return nothing
+end
+
+"""
+    mutation(loglikelihood, parameters, data, p, d_μ, d_Σ, n_free_para, blocks_free, blocks_all, ϕ_n, ϕ_n1; c, α, n_mh_steps,
+             old_data, old_loglikelihood, regime_switching, toggle, seed, pid, stage)
+
+src/mutation.jl:56-138 for ONE particle `p` (a row of `cloud.particles`): the updated particle.  Runs `smcmi_mutate` on a one-particle
+shard with global id `pid`, i.e. exactly what the stage loop does to that particle at `stage` (blocks are 1-based index vectors, as
+the reference passes them).
+"""
+function mutation(loglikelihood, parameters::ParameterVector, data::Matrix{Float64}, p::Vector{Float64}, d_μ::Vector{Float64},
+                  d_Σ::Matrix{Float64}, n_free_para::Int, blocks_free::Vector{Vector{Int}}, blocks_all::Vector{Vector{Int}},
+                  ϕ_n::Float64, ϕ_n1::Float64; c::Float64 = 1., α::Float64 = 1., n_mh_steps::Int = 1,
+                  old_data::Matrix{Float64} = Matrix{Float64}(undef, size(data, 1), 0), old_loglikelihood = loglikelihood,
+                  regime_switching::Bool = false, toggle::Bool = true, seed::Integer = rand(UInt64), pid::Integer = 0, stage::Integer = 0,
+                  device::Integer = 0)
+    d = length(p) - 5; n = pid + 1
+    keep = Any[]
+    h = create(n, d, seed, device, 2)                       # (row pid + 1 of a pid + 1 row cloud: the particle's own RNG stream)
+    try
+        set_parameters!(h, parameters; regime_switching = regime_switching)
+        tempered = !isempty(old_data)
+        P = zeros(n, d + 5); P[n, :] = p; P[1:n-1, d + 2] .= -Inf
+        bp = Int32[0]; bf = Int32[]
+        for b in blocks_free
+            append!(bf, Int32.(b .- 1)); push!(bp, Int32(length(bf)))
+        end
+        nb = length(blocks_free)
+        if loglikelihood isa DeviceLikelihood
+            set_model!(h, parameters, loglikelihood, data, 0, keep)
+            set_model!(h, parameters, tempered ? old_loglikelihood : nothing, old_data, 1, keep)
+            check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+            acc = Ref{Float64}(0.0)
+            check(ccall((:smcmi_mutate, LIB), Cint,
+                        (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Int32, Float64, Float64, Float64, Float64, Int32, UInt32, Ref{Float64}),
+                        h, d_μ, collect(d_Σ'), bp, bf, nb, ϕ_n, ϕ_n1, c, α, n_mh_steps, stage, acc))
+        else
+            # a closure: the propose -> (host evaluates) -> accept split of include/smcmi.h, step by step and block by block
+            set_model!(h, parameters, GaussIso(1.0), zeros(d, 1), 0, keep)                  # (placeholder family: the split never evaluates it)
+            set_model!(h, parameters, nothing, old_data, 1, keep)
+            check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+            prop = Matrix{Float64}(undef, n, d); lp = Vector{Float64}(undef, n); qd = Vector{Float64}(undef, n)
+            pv = deepcopy(parameters)
+            function score(f, θ, dat)
+                try
+                    update!(pv, θ)
+                    v = f(pv, dat)
+                    regime_switching && toggle && ModelConstructors.toggle_regime!(pv, 1)
+                    v
+                catch err
+                    isa(err, Union{CALLBACK_ERRORS...}) ? -Inf : rethrow(err)
+                end
+            end
+            for step in 0:n_mh_steps-1, b in 0:nb-1
+                check(ccall((:smcmi_propose, LIB), Cint,
+                            (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Int32, Int32, Int32, Float64, Float64, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                            h, d_μ, collect(d_Σ'), bp, bf, nb, b, step, c, α, stage, prop, lp, qd))
+                ll = fill(-Inf, n); llo = zeros(n)
+                if isfinite(lp[n])                           # (the bounds check passed: mutation.jl:93)
+                    ll[n] = score(loglikelihood, prop[n, :], data)
+                    tempered && (llo[n] = score(old_loglikelihood, prop[n, :], old_data))
+                end
+                last = (step == n_mh_steps - 1 && b == nb - 1) ? 1 : 0
+                check(ccall((:smcmi_accept, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}, Float64, Int32, Int32, Int32, UInt32, Int32),
+                            h, ll, tempered ? llo : C_NULL, ϕ_n, b, step, nb, stage, last))
+            end
+        end
+        check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
+        return P[n, :]
+    finally
+        destroy(h)
+    end
 end
 
 end # module
