@@ -49,7 +49,7 @@ template <int D>
 void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1) {
     Eng2 *e = h->e2;
     const size_t lds = k3_lds_bytes(D);
-    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl + 1);        // workers, gatherers, decider
+    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl);            // workers, gatherers
     static bool attr_set = false;              // (per instantiation: static + dynamic LDS pass 64 KB)
     if (!attr_set) {
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)

@@ -292,7 +292,7 @@ static int seg3_ready(smcmi_handle *h, bool *ok) {
     *ok = false;
     static const int off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
     const Geo2 &g = e->g;
-    const int grid = g.Vl * g.nb2 + g.Vl + 1;                  // workers + one gatherer per virtual shard + the decider, one CU each
+    const int grid = g.Vl * g.nb2 + g.Vl;                      // workers + one gatherer per virtual shard, one CU each
     int n_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
     if (off || !g.direct || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
@@ -825,10 +825,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));
         if (seg_launches > 0) {
             // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
-            fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the begin %lld | stage %lld\n",
-                    h0->e2->prof_stage, pr[2] - pr[1], pr[4] - pr[2], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[8] - pr[1]);
-            fprintf(stderr, "[smcmi3]   decider: covariance, shuffle %lld | block matrices %lld | Cholesky %lld | record %lld | publish %lld || (mutation totals ->) begin %lld | publish %lld\n",
-                    pr[30] - pr[11], pr[31] - pr[30], pr[32] - pr[31], pr[12] - pr[32], pr[13] - pr[12], pr[22] - pr[21], pr[23] - pr[22]);
+            fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the totals %lld | decision + proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the totals %lld | begin %lld | stage %lld\n",
+                    h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
         }
         for (int blk = 0; blk < 2; ++blk) {
             fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");

@@ -258,14 +258,14 @@ constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT
         }                                                                                                                     \
     } while (0)
 
-// grid = W + g.Vl + 1 blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual
-// shard, then the decider).  Worker b owns block (b / Vl) of local virtual shard (b % Vl): with the hardware's round-robin of
-// consecutive blocks over the 8 XCDs a virtual shard's workers and (W a multiple of 8) its gatherer share an XCD - placement is
-// speed only, never correctness.
+// grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard).
+// Worker b owns block (b / Vl) of local virtual shard (b % Vl): with the hardware's round-robin of consecutive blocks over the 8 XCDs
+// a virtual shard's workers and (W a multiple of 8) its gatherer share an XCD - placement is speed only, never correctness.
+// Every block - gatherers included - derives the stage's decisions itself from the V shard totals (decide2, post2, begin2_wave: same
+// inputs, same code, same result everywhere, as in engine 2's kernels), the workers also the proposal; worker 0 records them.
 template <int D, bool ALPHA1>
 __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
-    constexpr int WA = sizeof(RecA3) / 4, WB = sizeof(RecB3<D>) / 4;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ RecA3 s_a;
     __shared__ RecB3<D> s_b[2];                                 // [n & 1]: Post2 of stage n lives on as "Post2 of n - 1" during stage n + 1
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     Mut2Lds<D> L(sm);
     const int tid = threadIdx.x;
     const int W = g.Vl * g.nb2;
-    const int role = (int)blockIdx.x < W ? 0 : ((int)blockIdx.x < W + g.Vl ? 1 : 2);          // worker / gatherer / decider
+    const bool worker = (int)blockIdx.x < W, writer = blockIdx.x == 0;
     if (tid == 0) { s_rp = st->rp; s_to = 0; }
     if (tid < nf) L.fi[tid] = md->free_inds[tid];
     __syncthreads();
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     int n = sa.n_first;
     // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left (block 0 records it)
     {
-        const int act = begin2_block<T3>(n, st, ctl, sa.mrows, 1, sa.sched, ma.rec, &s_b[(n - 1) & 1].po, &s_a.bg, s_vt, s_tot, s_sw, &s_act, nullptr, true);
+        const int act = begin2_block<T3>(n, st, ctl, sa.mrows, 1, sa.sched, ma.rec, &s_b[(n - 1) & 1].po, &s_a.bg, s_vt, s_tot, s_sw, &s_act);
         if (act != 0) return;                                   // nothing was touched: the cloud in memory is current
         if (tid == 0) {
             const double a = s_a.bg.accept, tg = rp.target;
@@ -297,8 +297,32 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         }
         __syncthreads();
     }
-    bool timed_out = false;
-    if (role == 1) {
+    const double inv_pre = INV_FACTORIAL[tid & 31];
+    // Stage n's begin from the totals of stage n - 1's mutation rows (in s_tot), by every block alike: 0 go on, 7 segment complete,
+    // else begin2_wave's code (finished / paused / error / no usable prediction: the writer has set the status).  Ends with a barrier.
+    auto next_begin = [&](const Post2 &po_n) -> int {
+        if (tid == 0) s_act = 7;
+        if (tid < 64) {
+            const int jj = po_n.j - 1 + tid;                    // the window of the proposed schedule the begin walks
+            s_sw[tid] = (!rp.use_fixed_schedule && jj >= 0 && jj < rp.n_phi) ? sa.sched[jj] : 2.0;
+        }
+        if (n < sa.n_last) {
+            if (tid < 64) {
+                const int act = begin2_wave(n + 1, po_n, rp, s_tot, s_tot[RMAX_IDX], true, 1, sa.sched, s_sw, &s_a.bg, &st->sol[0], writer, ma.rec,
+                                            &ctl->status, inv_pre);
+                if (tid == 0) s_act = act;
+            } else if (tid == 64) {
+                // the step-size multiplier of stage n + 1 (smc_main.jl:453-455) from the acceptance rate begin2_wave folds
+                const double a = s_tot[EACC] / (double)rp.n_parts, tg = rp.target;
+                s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && s_act == 0) s_a.bg.cfac = s_cfac;
+        __syncthreads();
+        return s_act;
+    };
+    if (!worker) {
         // ================================================================ GATHERER of local virtual shard vg
         const int vg = (int)blockIdx.x - W;
         for (;; ++n) {
@@ -306,87 +330,17 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             double run;
             if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to, &run)) break;
             if (tid < MCM) gran_store(sa.gt_cm + ((long long)vg * MCM + tid) * 2, run, tag);
-            if (!rec3_wait(sa.rec + REC3_B_OFF, &s_b[n & 1], 2, tag, sa.to, &s_to) || s_b[n & 1].act != 0) break;
+            // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
+            if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) break;
+            double ess;
+            if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess) != 0) break;
+            if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, 0, &s_b[n & 1].po);
+            __syncthreads();
             if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to, &run)) break;
             if (tid < RMUT) gran_store(sa.gt_mut + ((long long)vg * RMUT + tid) * 2, run, tag);
-            if (!rec3_wait(sa.rec, &s_a, 2, sa.tag_base | (unsigned)(n + 1), sa.to, &s_to) || s_a.act != 0) break;
+            if (!gather_totals(sa.gt_mut, g.Vl, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot)) break;
+            if (next_begin(s_b[n & 1].po) != 0) break;
         }
-        return;
-    }
-    if (role == 2) {
-        // ================================================================ DECIDER
-        const double inv_pre = INV_FACTORIAL[tid & 31];
-        for (;; ++n) {
-            RecB3<D> &B = s_b[n & 1];
-            const Post2 &po = s_b[(n - 1) & 1].po;              // stage n - 1 as completed
-            const unsigned tag = sa.tag_base | (unsigned)n;
-            L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
-            L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
-            const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
-            // ---- totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-            if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
-            K3_STAMP_D(sa.prof, 11);
-            double ess;
-            const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
-            bool go = dec == 0;
-            if (go) {
-                if (tid == T3 - 64) {                           // (the last wavefront: the logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
-                    B.act = 0; B.pad = 0;
-                    post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, 0, &B.po);
-                }
-                Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
-                go = proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr,
-                               (sa.prof && n == sa.prof_stage) ? sa.prof + 30 : nullptr);
-                if (!go && tid == 0) { B.act = 9; ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }      // PosDefException aborts the run (mutation.jl:81)
-                if (go && tid < D) B.po.shift[tid] = L.mean_s[tid];
-            } else if (tid == 0) {
-                B.act = dec < 0 ? 9 : 6; B.pad = 0;
-                if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
-                ctl->status.stage = n;
-                ctl->status.code = dec < 0 ? 9 : (dec == 4 ? 4 : 6);
-            }
-            __syncthreads();
-            K3_STAMP_D(sa.prof, 12);
-            rec3_publish(sa.rec + REC3_B_OFF, &B, WB, tag);     // (the whole record either way: readers wait for all of it once)
-            K3_STAMP_D(sa.prof, 13);
-            if (!go) break;
-            // bookkeeping nobody in this launch waits for: Ctl2 / records / diagnostics (k2_bookkeeping)
-            if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = 0; ma.rec.c[n - 1] = B.po.c; }
-            if (tid < D) st->mean[tid] = L.mean_s[tid];
-            for (int e = tid; e < D * D; e += T3) st->cov[e] = L.covl[e];
-            constexpr int NWP = sizeof(Post2) / sizeof(double);
-            if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&B.po)[tid];
-            // the window of the proposed schedule the next begin walks
-            if (tid < 64) {
-                const int jj = B.po.j - 1 + tid;
-                s_sw[tid] = (!rp.use_fixed_schedule && jj >= 0 && jj < rp.n_phi) ? sa.sched[jj] : 2.0;
-            }
-            // ---- totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-            if (!gather_totals(sa.gt_mut, g.Vl, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
-            K3_STAMP_D(sa.prof, 21);
-            if (tid == 0) { s_act = 7; s_a.pad = 0; }
-            if (n < sa.n_last) {
-                if (tid < 64) {
-                    const int act = begin2_wave(n + 1, B.po, rp, s_tot, s_tot[RMAX_IDX], true, 1, sa.sched, s_sw, &s_a.bg, &st->sol[0], true, ma.rec,
-                                                &ctl->status, inv_pre);
-                    if (tid == 0) s_act = act;
-                } else if (tid == 64) {
-                    // the step-size multiplier of stage n + 1 (smc_main.jl:453-455) from the acceptance rate begin2_wave folds
-                    const double a = s_tot[EACC] / (double)rp.n_parts, tg = rp.target;
-                    s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
-                }
-            }
-            __syncthreads();
-            if (tid == 0) { s_a.act = s_act; if (s_act == 0) s_a.bg.cfac = s_cfac; }
-            __syncthreads();
-            K3_STAMP_D(sa.prof, 22);
-            rec3_publish(sa.rec, &s_a, WA, sa.tag_base | (unsigned)(n + 1));
-            K3_STAMP_D(sa.prof, 23);
-            if (s_a.act != 0) break;
-            constexpr int NWB = sizeof(Begin2) / sizeof(double);
-            if (tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
-        }
-        if (timed_out && tid == 0) { ctl->status.err = SMCMI_ERR_TIMEOUT; ctl->status.stage = n; ctl->status.code = 9; }
         return;
     }
     // ==================================================================== WORKER
@@ -424,13 +378,14 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
     __syncthreads();
     int done = 0;
+    bool timed_out = false;
     unsigned long long *my_cm = sa.g_cm + (long long)rowi * MCM * 2, *my_mut = sa.g_mut + (long long)rowi * RMUT * 2;
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
         RecB3<D> &B = s_b[n & 1];
         const Post2 &po = s_b[(n - 1) & 1].po;                  // stage n - 1 as completed
         const unsigned tag = sa.tag_base | (unsigned)n;
-        // the proposal arrays of THIS stage arrive inside its record
+        // the proposal arrays of THIS stage
         L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
         L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
         // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
@@ -452,9 +407,39 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
             if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
         }
+        const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
         K3_STAMP(sa.prof, 2);
-        if (!rec3_wait(sa.rec + REC3_B_OFF, &B, WB, tag, sa.to, &s_to)) { timed_out = true; break; }
-        if (B.act != 0) break;                                  // leave: registers hold the cloud after stage n - 1
+        // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
+        if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
+        K3_STAMP(sa.prof, 3);
+        double ess;
+        const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+        if (dec != 0) {                                         // leave: nothing of the stage is committed, registers hold the cloud after stage n - 1
+            if (writer && tid == 0) {
+                if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
+                ctl->status.stage = n;
+                ctl->status.code = dec < 0 ? 9 : (dec == 4 ? 4 : 6);
+            }
+            break;
+        }
+        if (tid == T3 - 64) post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, 0, &B.po);       // (the last wavefront: its logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
+        {
+            Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
+            if (!proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre)) {
+                // PosDefException aborts the run (mutation.jl:81); the gatherers, which build no proposal, leave by their time-out
+                if (writer && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
+                break;
+            }
+        }
+        if (tid < D) B.po.shift[tid] = L.mean_s[tid];
+        __syncthreads();
+        if (writer) {                                           // bookkeeping nobody in this launch waits for: Ctl2 / records / diagnostics (k2_bookkeeping)
+            if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = 0; ma.rec.c[n - 1] = B.po.c; }
+            if (tid < D) st->mean[tid] = L.mean_s[tid];
+            for (int e = tid; e < D * D; e += T3) st->cov[e] = L.covl[e];
+            constexpr int NWP = sizeof(Post2) / sizeof(double);
+            if (tid < NWP) reinterpret_cast<double *>(&ctl->ps[n & 1])[tid] = reinterpret_cast<const double *>(&B.po)[tid];
+        }
         K3_STAMP(sa.prof, 4);
         // ================= mutation (src/mutation.jl:56-138): normalize_weights!, the MH steps, one row per block
         const double phi_n = B.po.phi_n, nrm_sumw = B.po.sumw;
@@ -485,9 +470,14 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         K3_STAMP(sa.prof, 6);
         if (n < sa.n_last) k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
-        if (!rec3_wait(sa.rec, &s_a, WA, sa.tag_base | (unsigned)(n + 1), sa.to, &s_to)) { timed_out = true; break; }
-        if (s_a.act != 0) break;                                // leave: registers hold the cloud after stage n
+        // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
+        if (!gather_totals(sa.gt_mut, g.Vl, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 8);
+        const int act = next_begin(B.po);
+        constexpr int NWB = sizeof(Begin2) / sizeof(double);
+        if (act == 0 && writer && tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
+        K3_STAMP(sa.prof, 9);
+        if (act != 0) break;                                    // leave: registers hold the cloud after stage n
     }
     // ---- the cloud goes back to buffer 0 as the last completed stage left it
     if (live && !timed_out) {
@@ -496,7 +486,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         col(cl, 0, D)[i] = like; col(cl, 0, D + 1)[i] = lprior; col(cl, 0, D + 2)[i] = like_prev;
         col(cl, 0, D + 3)[i] = acc_val; col(cl, 0, D + 4)[i] = Wt;
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (writer && tid == 0) {
         if (sa.done_out) *sa.done_out = done;
         if (timed_out) { ctl->status.err = SMCMI_ERR_TIMEOUT; ctl->status.stage = n; ctl->status.code = 9; }
     }
