@@ -302,8 +302,8 @@ def main():
             traffic3, pmc3 = None, None
             if pmc_file:
                 k3 = [(name, v) for name, v in pm["kernels"].items() if "k3_segment<%d," % D in name]
-                if k3:
-                    traffic3, pmc3 = k3[0][1].get("total_bytes"), k3[0][1].get("valu")
+                if k3 and k3[0][1].get("launches"):
+                    traffic3, pmc3 = k3[0][1].get("sum_total_bytes", 0.0) / k3[0][1]["launches"], k3[0][1].get("valu")      # HBM bytes of an average launch
             out["roofline"] = {"bound": "hbm", "kernel": "k3_segment<%d, %s> (persistent: one launch = a run of stages)" % (D, "true" if RUN_KW["alpha"] == 1.0 else "false"),
                                "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach3 / HBM_PEAK_GBS, "traffic": traffic3,
                                "bytes_per_launch": stage_b * seg_st / seg_n, "mean_launch_us": 1e3 * seg_ms / seg_n, "launches": seg_n,

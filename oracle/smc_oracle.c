@@ -501,13 +501,18 @@ void orc_weighted_cov(const double *particles, int64_t n, int32_t R, double *cov
         for (int64_t i = 0; i < n; ++i) s += wn[i] * x[i];
         m[k] = s / swn;
     }
-    for (int a = 0; a < d; ++a)
-        for (int b = a; b < d; ++b) {
-            const double *xa = particles + (int64_t)a * n, *xb = particles + (int64_t)b * n;
-            double s = 0.0;
-            for (int64_t i = 0; i < n; ++i) s += wn[i] * (xa[i] - m[a]) * (xb[i] - m[b]);
-            cov[a * d + b] = cov[b * d + a] = s * (1.0 / swn);
-        }
+    /* (CPU-baseline variant 2: the d (d + 1) / 2 entries over the team, each still summed serially - the same bits as the serial loop) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_ess_threads) if (g_ess_threads > 1)
+#endif
+    for (int ab = 0; ab < d * d; ++ab) {
+        const int a = ab / d, b = ab % d;
+        if (b < a) continue;
+        const double *xa = particles + (int64_t)a * n, *xb = particles + (int64_t)b * n;
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += wn[i] * (xa[i] - m[a]) * (xb[i] - m[b]);
+        cov[a * d + b] = cov[b * d + a] = s * (1.0 / swn);
+    }
     free(wn);
     free(m);
 }
@@ -903,8 +908,18 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
     double *wcol = particles + (int64_t)(R - 1) * n, *acol = particles + (int64_t)(R - 2) * n;
 
     g_refactor_per_particle = cfg->variant == 1;
-    g_ess_threads = (cfg->variant == 2 && cfg->n_threads > 1) ? cfg->n_threads : 1;
-    if (g_ess_threads > 1 && (int64_t)g_ess_threads > n / 4096) g_ess_threads = n / 4096 > 1 ? (int)(n / 4096) : 1;   /* a few thousand exps per thread at least */
+    /* variant 2: ONE team size for every parallel region of the run (libgomp rebuilds its pool when the size changes), capped so
+       that a thread has a few thousand particles: at N = 1e5 waking 255 sleeping threads costs more than their share of the work */
+    int mut_threads = cfg->n_threads;
+    if (cfg->variant == 2) {
+        const char *ot = getenv("ORC_OPT_THREADS");
+        int64_t cap = ot ? atoi(ot) : n / 3072;      /* (32 threads at N = 1e5: measured best on the 256-thread host, 1.9 s vs 2.4 - 2.7 s at 48) */
+        if (cap < 1) cap = 1;
+        if ((int64_t)mut_threads > cap) mut_threads = (int)cap;
+    }
+    g_ess_threads = (cfg->variant == 2 && mut_threads > 1) ? mut_threads : 1;
+    double t_solve = 0.0, t_corr = 0.0, t_sel = 0.0, t_mom = 0.0, t_mut = 0.0;
+    const int profile = getenv("ORC_PROFILE") != NULL;
     int i = 1, j = 2, rc = 0, resampled_last = 0, resamples = 0;
     double phi_n = 0.0, phi_prop = 0.0, c = cfg->c, accept = cfg->target, logmdd = 0.0, secs = 0.0;
     const double threshold = cfg->threshold_ratio * (double)n;
@@ -917,10 +932,12 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
         i += 1;
         if (i > cfg->max_stages) { rc = fail("max_stages exceeded"); break; }
         double phi_n1 = sched_out[i - 2];
+        double tp = now_s();
         if (cfg->use_fixed_schedule) phi_n = sched[i - 1];                                       /* :387 */
         else if ((rc = orc_solve_adaptive_phi(particles, n, R, ess_out[i - 2], sched, n_phi, &j, &phi_prop, phi_n1,
                                               cfg->tempering_target, &resampled_last, &phi_n, NULL)) != 0) break;
         sched_out[i - 1] = phi_n;
+        t_solve += now_s() - tp; tp = now_s();
         double ess, sum_un;
         orc_correct(particles, n, R, phi_n, phi_n1, cfg->prior_weight, cfg->log_prob_old_data, inc_w, norm_w, &ess, &sum_un);
         ess_out[i - 1] = ess;                                                                    /* :427 */
@@ -929,6 +946,7 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
                       memcpy(W_hist + (int64_t)(i - 1) * n, norm_w, sizeof(double) * n); }
         if (isnan(ess)) { rc = fail("No particles have non-zero weight."); break; }              /* :431 */
         resampled_out[i - 1] = 0;
+        t_corr += now_s() - tp; tp = now_s();
         if (ess < threshold) {                                                                   /* :435-446 */
             for (int64_t k = 0; k < n; ++k) rw[k] = norm_w[k] / (double)n;
             orc_resample(rw, n, n, cfg->resampling_method, cfg->seed, (uint32_t)i, idx);
@@ -939,6 +957,7 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
             resamples += 1; resampled_last = 1; resampled_out[i - 1] = 1;
             if (W_hist) for (int64_t k = 0; k < n; ++k) W_hist[(int64_t)(i - 1) * n + k] = 1.0;
         }
+        t_sel += now_s() - tp; tp = now_s();
         c = orc_update_c(c, accept, cfg->target);                                                /* :453-455 */
         c_out[i - 1] = c;
         orc_weighted_mean(particles, n, R, mean);                                                /* :457-458 */
@@ -948,15 +967,19 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
             for (int b = 0; b < n_free; ++b)
                 Sig_f[a * n_free + b] = (cov[free_inds[a] * d + free_inds[b]] + cov[free_inds[b] * d + free_inds[a]]) / 2.0;
         }
+        t_mom += now_s() - tp; tp = now_s();
         orc_generate_blocks(n_free, cfg->n_blocks, free_inds, cfg->seed, (uint32_t)i, bfree, ball, bptr); /* :468-469 */
         if ((rc = orc_mutate_cloud(m, particles, n, 0, mu_f, Sig_f, n_free, bfree, ball, bptr, cfg->n_blocks, phi_n,
-                                   phi_n1, c, cfg->alpha, cfg->n_mh_steps, cfg->seed, (uint32_t)i, cfg->n_threads)) != 0) break;
+                                   phi_n1, c, cfg->alpha, cfg->n_mh_steps, cfg->seed, (uint32_t)i, mut_threads)) != 0) break;
         double sa = 0.0;
         for (int64_t k = 0; k < n; ++k) sa += acol[k];
         accept = sa / (double)n;                                                                 /* :484 */
         accept_out[i - 1] = accept;
+        t_mut += now_s() - tp;
         secs += now_s() - t0;                                                                    /* :489-490 */
     }
+    if (profile) fprintf(stderr, "[orc] variant %d threads %d: solve %.3f correction %.3f selection %.3f moments %.3f mutation %.3f s\n", cfg->variant,
+                         mut_threads, t_solve, t_corr, t_sel, t_mom, t_mut);
     res->n_stages = i; res->resamples = resamples; res->logmdd = logmdd; res->c = c; res->accept = accept;
     res->seconds = secs;
     g_refactor_per_particle = 0; g_ess_threads = 1;

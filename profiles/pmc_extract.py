@@ -45,8 +45,12 @@ for k in sorted(set(fetch) | set(write)):
     f, nf, tf = active_mean(fetch.get(k, [0.0]))
     w, nw, tw = active_mean(write.get(k, [0.0]))
     rd, wr = 2.0 * f * 1024.0, w * 1024.0
+    # (sums over ALL launches as well: a persistent segment launch - k3_segment - covers a varying number of stages, so its typical
+    # launch means little; bench.py divides the sum by the launches for the traffic of an average launch)
+    srd, swr = 2.0 * sum(fetch.get(k, [0.0])) * 1024.0, sum(write.get(k, [0.0])) * 1024.0
     res["kernels"][k.split("(")[0]] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr,
-                                       "bytes_per_particle": (rd + wr) / n, "active_launches": nf, "launches": tf}
+                                       "bytes_per_particle": (rd + wr) / n, "active_launches": nf, "launches": tf,
+                                       "sum_read_bytes": srd, "sum_write_bytes": swr, "sum_total_bytes": srd + swr}
 if sq:
     cnt = {c: per_kernel(sq, c) for c in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES")}
     for k in sorted(cnt["SQ_ACTIVE_INST_VALU"]):

@@ -734,7 +734,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
             // stages that follow a resample or have no mutation rows yet (first stage of a run / a continuation) get certificate
             // passes; so does everything once predictions have stopped verifying
-            const bool cert = adaptive && (!spec_on || sel || launched < 2);
+            static const int cert_sel = getenv("SMCMI_CERT_SELECT") ? atoi(getenv("SMCMI_CERT_SELECT")) : 1;   // development: 0 = resample stages on the predicted ϕ_n too
+            const bool cert = adaptive && (!spec_on || (sel && cert_sel) || launched < 2);
             // engine 3 takes every stage that is expected to need neither (fixed schedules: nobody can tell which stage resamples -
             // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches)
             if (e3 && !cert && (!sel || !adaptive)) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round measurement pipeline (one MI355X): every file profiles/README.md lists, into gpurun_out/final/.
 # usage (GPU box): bash tools/measure_round.sh [rNN]
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -9,8 +9,10 @@ cd $ROOT
 python bench.py --steps 8 --warmup 2 2>/dev/null | tail -1 > $OUT/${R}_bench.json
 python bench.py --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6.json
 python bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e7.json
-python bench.py --workload capm --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_capm.json
-python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
+# configs 4 and 5 with their own cpu_baseline (the CPU leg runs each oracle variant once on the full workload)
+python bench.py --workload capm --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_capm.json
+python bench.py --workload kalman --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
+gcc -O2 -std=c99 -ffp-contract=off -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
 LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
 python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
 python bench.py --alpha 0.9 --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6_alpha09.json
