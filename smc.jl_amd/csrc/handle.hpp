@@ -27,7 +27,7 @@ struct Eng2 {
     Ctl2 *d_ctl = nullptr;
     double *rows_mut = nullptr, *rows_cm = nullptr, *csum = nullptr, *csum_full = nullptr, *rows_gm = nullptr, *rows_pass[2] = {nullptr, nullptr};
     double *vt_mut = nullptr, *vt_cm = nullptr, *vt_gm = nullptr, *vt_pass = nullptr;
-    long long *d_ranges = nullptr;
+    long long *d_ranges = nullptr, *d_ranges_all = nullptr;     // a resample stage: the rows every handle needs of this one; all handles' tables
     Prop2Glob *d_pre = nullptr;      // decision + proposal of the current stage (k2_prepare; large clouds / several handles)
     int *d_tick = nullptr;           // ticket counters of the fused row totals (Tail2): [0, V) correction rows, [V, 2V) mutation rows
     long long *d_prof = nullptr;     // development only (SMCMI_PROF2=<stage>): [0,64) K1 stamps, [64,128) K2 stamps of that stage

@@ -19,10 +19,10 @@ void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected
                                                            e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
 }
 template <int D>
-void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full) {
+void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full, long long s_lo, long long s_hi) {
     Eng2 *e = h->e2;
     k2_gather<D><<<e->g.Vl * e->g.nbg, TB, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
-                                                          h->n, e->rows_gm);
+                                                          h->n, e->rows_gm, s_lo, s_hi);
 }
 template <int D>
 void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {
@@ -63,7 +63,7 @@ void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, 
 
 #define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
     X template void launch_k2_correct<D>(smcmi_handle *, int, int, int, const Rows2 &, const Tail2 &);                               \
-    X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *);                   \
+    X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *, long long, long long); \
     X template void launch_k2_mutate<D>(smcmi_handle *, const Mut2Args &, int, bool);                                                \
     X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);                                                     \
     X template void launch_k3_segment<D>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int, bool);

@@ -16,7 +16,7 @@ constexpr int SEG3_MAX_LAUNCHES = 4096;     // segment launches of one run whose
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_ranges_all, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete e;
@@ -75,7 +75,7 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     if (dmalloc(&e->d_ctl, 1) || dmalloc(&e->rows_mut, n2 * RMUT) || dmalloc(&e->rows_cm, n1 * npf) || dmalloc(&e->csum, n1) ||
         dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * npp) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
         dmalloc(&e->rows_pass[1], n1 * 2 * KC) || dmalloc(&e->vt_mut, (size_t)g.V * RMUT) || dmalloc(&e->vt_cm, (size_t)g.V * npf) ||
-        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_pre, 1) || dmalloc(&e->d_tick, 2 * V2_MAXV)) {
+        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_ranges_all, (size_t)V2_MAXV * (2 * V2_MAXV + 2)) || dmalloc(&e->d_pre, 1) || dmalloc(&e->d_tick, 2 * V2_MAXV)) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
     }
@@ -520,36 +520,61 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 Eng2 *e = h->e2;
                 const Rows2 cr = cm_rows(h);
                 k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cr, h->d_wt, e->csum, h->d_cum);
-#define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum, rc->resampling_method, nullptr)
+#define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum, rc->resampling_method, nullptr, 0, -1)
                 SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
             }
             return publish(&Eng2::rows_gm, &Eng2::vt_gm, g0.nbg, np, -1);
         }
-        // several handles: every handle scans the all-gathered weights itself (same chunks, same chunk sums -> the same cumulative
-        // weights everywhere), then receives the rows its slots descend from
+        // several handles.  Systematic resampling: only the chunk sums are all-gathered; every handle scans ITS weights
+        // into its own cum column (offsets and total from the gathered sums: the values a scan over the whole cloud gives), finds
+        // for every handle r which of its rows r's slots can descend from (k2_owner_ranges), the G x 2G table of those ranges is
+        // all-gathered (the one host read of a resample stage: the exchange below needs its sizes on the host) and only those
+        // rows - with their cum values - travel.  No all-gather of the weight column, no scan of N weights on every handle.
+        // Multinomial resampling (and SMCMI_RESAMPLE_EXCHANGE=allgather): every slot can descend from any row - all-gather of the
+        // weights and of the shard clouds.
         const size_t nloc = (size_t)h0->n;
-        if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->d_wt; }, [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return e;
         if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->e2->csum; }, [](smcmi_handle *h) { return h->e2->csum_full; },
                                 (size_t)g0.Vl * g0.nb1)) return e;
         static const char *xchg = getenv("SMCMI_RESAMPLE_EXCHANGE");
         const bool a2a = !(xchg && !strcmp(xchg, "allgather")) && rc->resampling_method == SMCMI_RESAMPLE_SYSTEMATIC && !(g.hostc && !h0->hostc.alltoallv);
-        for (auto *h : g.hs) {
-            HIP_TRY(hipSetDevice(h->cfg.device));
-            Eng2 *e = h->e2;
-            k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_full_w, e->csum_full, h->d_cum_full);
-            if (a2a) k2_anc_ranges<<<1, 64, 0, h->stream>>>(e->d_ctl, h->d_st, n, cm_rows(h), h->d_cum_full, h->cfg.n_parts, h->n, g.world, h->cfg.seed, e->d_ranges);
-        }
         bool rs = true;
+        std::vector<long long> ranges(2 * (size_t)g.world, -1);            // per needer: the global rows its slots can descend from
         if (a2a) {
-            // all-to-all-v: only the rows inside a handle's ancestor range travel to it (the one host read of a resample stage)
-            std::vector<long long> ranges(2 * (size_t)g.world);
+            const int tw = 2 * g.world + 2;                               // a handle's table: (lo, hi) per needer, the "stage resamples" flag, pad
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                Eng2 *e = h->e2;
+                const int c0 = e->g.v0 * e->g.nb1;
+                k2_scan<<<g0.Vl * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_wt, e->csum_full, h->d_cum, c0, c0 + g0.Vl * g0.nb1, h->cfg.gid0);
+                k2_owner_ranges<<<1, 64, 0, h->stream>>>(e->d_ctl, h->d_st, n, cm_rows(h), h->d_cum, h->cfg.n_parts, h->n, h->cfg.gid0, g.world, h->cfg.seed,
+                                                        e->d_ranges, e->csum_full, c0);
+            }
+            if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->e2->d_ranges; }, [](smcmi_handle *h) { return (double *)h->e2->d_ranges_all; }, (size_t)tw)) return e;
+            std::vector<long long> all((size_t)g.world * tw);
             HIP_TRY(hipSetDevice(h0->cfg.device));
-            HIP_TRY(hipMemcpyAsync(ranges.data(), h0->e2->d_ranges, sizeof(long long) * ranges.size(), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipMemcpyAsync(all.data(), h0->e2->d_ranges_all, sizeof(long long) * all.size(), hipMemcpyDeviceToHost, h0->stream));
             HIP_TRY(hipStreamSynchronize(h0->stream));
-            rs = ranges[0] >= 0;                       // -1: the device decided not to resample after all (or the stage is a no-op)
-            if (rs) { if (int e = g.exchange_rows(ranges)) return e; }
+            rs = all[2 * (size_t)g.world] == 1;            // 0: the device decided not to resample after all (or the stage is a no-op)
+            if (rs) {
+                for (int s = 0; s < g.world; ++s)
+                    for (int r = 0; r < g.world; ++r) {
+                        const long long lo = all[(size_t)s * tw + 2 * r], hi = all[(size_t)s * tw + 2 * r + 1];
+                        if (lo < 0) continue;
+                        if (ranges[2 * r] < 0 || lo < ranges[2 * r]) ranges[2 * r] = lo;
+                        if (hi > ranges[2 * r + 1]) ranges[2 * r + 1] = hi;
+                    }
+                for (int r = 0; r < g.world; ++r)
+                    if (ranges[2 * r] < 0) return set_err(SMCMI_ERR_STATE, "sharded resampling: no handle offers ancestors for a handle's slots");
+                if (int e = g.exchange_rows(ranges, true)) return e;
+            }
         } else {
+            if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->d_wt; }, [](smcmi_handle *h) { return h->d_full_w; }, nloc)) return e;
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                Eng2 *e = h->e2;
+                k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_full_w, e->csum_full, h->d_cum_full);
+            }
             if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->cl.buf[0]; }, [](smcmi_handle *h) { return h->d_full_cloud; },
                                     nloc * h0->R)) return e;
         }
@@ -557,7 +582,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 const Rows2 cr = cm_rows(h);
-#define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum_full, rc->resampling_method, h->d_full_cloud)
+                const int me = g.rccl ? h->rank : shard_rank(h);
+                const long long s_lo = a2a ? ranges[2 * me] : 0, s_hi = a2a ? ranges[2 * me + 1] : -1;
+#define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum_full, rc->resampling_method, h->d_full_cloud, s_lo, s_hi)
                 SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
             }

@@ -215,7 +215,8 @@ struct ShardGroup {
     // contiguous global row range [lo[r], hi[r]]).  Every shard receives exactly the rows of that range, column by column, into
     // the [source shard][column][row] staging layout the all-gather would have produced, so k_resample_gather is unchanged.
     // ranges = (lo, hi) per shard, identical on every shard (all derive it from the same all-gathered cumulative weights).
-    int exchange_rows(const std::vector<long long> &ranges) {
+    // with_cum: the rows' values of the handle's cum column (d_cum, local index) travel as one more column into d_cum_full (global index)
+    int exchange_rows(const std::vector<long long> &ranges, bool with_cum = false) {
         const long long n = hs[0]->n;
         const int R = hs[0]->R;
         auto overlap = [&](int needer, int owner, long long &a, long long &b) {     // rows of `owner` that `needer` needs: [a, b)
@@ -228,37 +229,42 @@ struct ShardGroup {
             smcmi_handle *h = hs[0];
             const int me = h->rank;
             if (!h->hostc.alltoallv) return set_err(SMCMI_ERR_UNSUPPORTED, "host communicator lacks alltoallv (SMCMI_RESAMPLE_EXCHANGE=allgather avoids it)");
+            const int RC = R + (with_cum ? 1 : 0);              // columns per row on the wire
             std::vector<int64_t> sc(world, 0), sd(world, 0), rcnt(world, 0), rd(world, 0);
             std::vector<long long> sa(world, 0), ra(world, 0);
             int64_t stot = 0, rtot = 0;
             for (int p = 0; p < world; ++p) {
                 long long a, b;
-                if (p != me && overlap(p, me, a, b)) { sc[p] = (b - a) * R; sa[p] = a - (long long)me * n; }
-                if (p != me && overlap(me, p, a, b)) { rcnt[p] = (b - a) * R; ra[p] = a - (long long)p * n; }
+                if (p != me && overlap(p, me, a, b)) { sc[p] = (b - a) * RC; sa[p] = a - (long long)me * n; }
+                if (p != me && overlap(me, p, a, b)) { rcnt[p] = (b - a) * RC; ra[p] = a - (long long)p * n; }
                 sd[p] = stot; stot += sc[p];
                 rd[p] = rtot; rtot += rcnt[p];
             }
             std::vector<double> sbuf((size_t)std::max<int64_t>(stot, 1)), rbuf((size_t)std::max<int64_t>(rtot, 1));
             for (int p = 0; p < world; ++p)
                 if (sc[p]) {
-                    const long long len = sc[p] / R;
+                    const long long len = sc[p] / RC;
                     HIP_TRY(hipMemcpy2DAsync(sbuf.data() + sd[p], sizeof(double) * len, h->cl.buf[0] + sa[p], sizeof(double) * n, sizeof(double) * (size_t)len, (size_t)R,
                                              hipMemcpyDeviceToHost, h->stream));
+                    if (with_cum) HIP_TRY(hipMemcpyAsync(sbuf.data() + sd[p] + (size_t)R * len, h->d_cum + sa[p], sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, h->stream));
                 }
             HIP_TRY(hipStreamSynchronize(h->stream));
             if (h->hostc.alltoallv(sbuf.data(), sc.data(), sd.data(), rbuf.data(), rcnt.data(), rd.data(), h->hostc.user))
                 return set_err(SMCMI_ERR_CALLBACK, "host communicator: alltoallv failed");
             for (int p = 0; p < world; ++p)
                 if (rcnt[p]) {
-                    const long long len = rcnt[p] / R;
+                    const long long len = rcnt[p] / RC;
                     HIP_TRY(hipMemcpy2DAsync(h->d_full_cloud + (long long)p * R * n + ra[p], sizeof(double) * n, rbuf.data() + rd[p], sizeof(double) * len, sizeof(double) * (size_t)len,
                                              (size_t)R, hipMemcpyHostToDevice, h->stream));
+                    if (with_cum) HIP_TRY(hipMemcpyAsync(h->d_cum_full + (long long)p * n + ra[p], rbuf.data() + rd[p] + (size_t)R * len, sizeof(double) * (size_t)len, hipMemcpyHostToDevice, h->stream));
                 }
             long long a, b;
-            if (overlap(me, me, a, b))
+            if (overlap(me, me, a, b)) {
                 HIP_TRY(hipMemcpy2DAsync(h->d_full_cloud + (long long)me * R * n + (a - (long long)me * n), sizeof(double) * n,
                                          h->cl.buf[0] + (a - (long long)me * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
                                          hipMemcpyDeviceToDevice, h->stream));
+                if (with_cum) HIP_TRY(hipMemcpyAsync(h->d_cum_full + a, h->d_cum + (a - (long long)me * n), sizeof(double) * (size_t)(b - a), hipMemcpyDeviceToDevice, h->stream));
+            }
             HIP_TRY(hipStreamSynchronize(h->stream));
             return 0;
         }
@@ -270,19 +276,25 @@ struct ShardGroup {
             NCCL_TRY(g_rccl.GroupStart());
             for (int p = 0; p < world; ++p) {
                 long long a, b;
-                if (overlap(p, me, a, b) && p != me)                                   // my rows that p needs
+                if (overlap(p, me, a, b) && p != me) {                                 // my rows that p needs
                     for (int c = 0; c < R; ++c)
                         NCCL_TRY(g_rccl.Send(h->cl.buf[0] + (long long)c * n + (a - (long long)me * n), (size_t)(b - a), SMCMI_NCCL_DOUBLE, p, h->nccl, h->stream));
-                if (overlap(me, p, a, b) && p != me)                                   // p's rows that I need
+                    if (with_cum) NCCL_TRY(g_rccl.Send(h->d_cum + (a - (long long)me * n), (size_t)(b - a), SMCMI_NCCL_DOUBLE, p, h->nccl, h->stream));
+                }
+                if (overlap(me, p, a, b) && p != me) {                                 // p's rows that I need
                     for (int c = 0; c < R; ++c)
                         NCCL_TRY(g_rccl.Recv(h->d_full_cloud + ((long long)p * R + c) * n + (a - (long long)p * n), (size_t)(b - a), SMCMI_NCCL_DOUBLE, p, h->nccl, h->stream));
+                    if (with_cum) NCCL_TRY(g_rccl.Recv(h->d_cum_full + a, (size_t)(b - a), SMCMI_NCCL_DOUBLE, p, h->nccl, h->stream));
+                }
             }
             NCCL_TRY(g_rccl.GroupEnd());
             long long a, b;
-            if (overlap(me, me, a, b))
+            if (overlap(me, me, a, b)) {
                 HIP_TRY(hipMemcpy2DAsync(h->d_full_cloud + (long long)me * R * n + (a - (long long)me * n), sizeof(double) * n,
                                          h->cl.buf[0] + (a - (long long)me * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
                                          hipMemcpyDeviceToDevice, h->stream));
+                if (with_cum) HIP_TRY(hipMemcpyAsync(h->d_cum_full + a, h->d_cum + (a - (long long)me * n), sizeof(double) * (size_t)(b - a), hipMemcpyDeviceToDevice, h->stream));
+            }
             return 0;
         }
         if (int rc = sync_all()) return rc;
@@ -294,6 +306,7 @@ struct ShardGroup {
                 HIP_TRY(hipMemcpy2DAsync(hs[d]->d_full_cloud + (long long)o * R * n + (a - (long long)o * n), sizeof(double) * n,
                                          hs[o]->cl.buf[0] + (a - (long long)o * n), sizeof(double) * n, sizeof(double) * (size_t)(b - a), (size_t)R,
                                          hipMemcpyDeviceToDevice, hs[d]->stream));
+                if (with_cum) HIP_TRY(hipMemcpyAsync(hs[d]->d_cum_full + a, hs[o]->d_cum + (a - (long long)o * n), sizeof(double) * (size_t)(b - a), hipMemcpyDeviceToDevice, hs[d]->stream));
             }
         return sync_all();
     }

@@ -985,8 +985,11 @@ __device__ inline int decide2(const Begin2 &bg, double threshold, double phi_rto
 // Inclusive scan of W̃ / ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) over the WHOLE cloud (sharded runs hand in the
 // all-gathered W̃ and chunk sums) in the correction's chunks: one block per chunk, chunk offsets = running sum of the chunk sums
 // in chunk order.  Does nothing unless this stage resamples (the decision is re-derived from the correction rows).
+// c_begin / c_end / i_off: scan the chunks [c_begin, c_end) only, reading and writing at (global index - i_off) - a handle of a sharded
+// run scans ITS particles' weights into its local cum column from the all-gathered chunk sums (the offsets, the total and therefore
+// the values are those of a scan over the whole cloud).
 static __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
-                                              const double *csum_full, double *cum) {
+                                              const double *csum_full, double *cum, int c_begin = 0, int c_end = -1, long long i_off = 0) {
     __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2], scratch[TB], s_off[4 * TB];
     __shared__ Begin2 s_bg;
     constexpr int NWB = sizeof(Begin2) / sizeof(double);
@@ -1009,7 +1012,8 @@ static __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *
     for (int q = 0; q < 4; ++q) s_off[t * 4 + q] = scratch[t] + loc[q];
     __syncthreads();
     const double total = s_tot[0];
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    wt_full -= i_off; cum -= i_off;
+    for (int c = c_begin + (int)blockIdx.x; c < (c_end < 0 ? nchunks : c_end); c += gridDim.x) {
         const int v = c / g.nb1, r = c % g.nb1;
         const long long v_beg = (long long)v * g.nv, v_end = v_beg + g.nv;
         long long beg = v_beg + (long long)r * g.per1, end = beg + g.per1 < v_end ? beg + g.per1 : v_end;
@@ -1067,6 +1071,47 @@ static __global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2
     }
 }
 
+// Systematic resampling, sharded, owner side: which of THIS handle's rows does handle r need?  The ancestors of r's
+// slots k0 .. k1 (thresholds t = (k + u) / N) are the first j with cum[j] > t; among this handle's rows they lie between its first
+// row with cum > t(k0) and its first row with cum > t(k1) (its last row if there is none) - a superset by at most one row, from this
+// handle's own cum column alone.  out[2 r], out[2 r + 1] = global indices of that range, -1 / -1 if r needs none of the rows;
+// out[2 world] = 1 if the stage resamples, else 0 (nothing else is valid then).
+static __global__ void k2_owner_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows, const double *cum_local, long long N, long long n_local,
+                                       long long gid0, int world, unsigned long long seed, long long *out, const double *csum_full, int c_first) {
+    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
+    const int r = threadIdx.x;
+    const Begin2 bg = ctl->bg;
+    bool go = bg.stage == n && bg.final && ctl->ps[(n - 1) & 1].stage == n - 1;
+    if (cmrows.mb && !go) { if (r == 0) out[2 * world] = 0; return; }       // (mailbox: no waiting for rows of a stage that does not run)
+    reduce_rows<2, 8, 64>(cmrows, s_vt, s_tot);
+    double ess;
+    if (go) go = decide2(bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) == 1;
+    if (r == 0) out[2 * world] = go ? 1 : 0;
+    if (!go || r >= world) return;
+    double ua, ub;
+    uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
+    long long res[2];
+    for (int e = 0; e < 2; ++e) {
+        const long long slot = e == 0 ? (long long)r * n_local : (long long)(r + 1) * n_local - 1;
+        const double thr = ((double)slot + ua) / (double)N;
+        long long lo = 0, hi = n_local;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (cum_local[mid] > thr) hi = mid; else lo = mid + 1;
+        }
+        res[e] = lo;                                        // first own row with cum > thr (n_local: none)
+    }
+    // cumulative weight in front of this handle's first row (to a few ulps: the chunk sums are block reductions, the cum column a
+    // scan): if even that - less a safety margin - exceeds t(k1), r's last ancestor lies before this handle's rows
+    double before = 0.0;
+    for (int c = 0; c < c_first; ++c) before += csum_full[c];
+    const double thr1 = ((double)((long long)(r + 1) * n_local - 1) + ua) / (double)N;
+    const bool behind = (before / s_tot[0]) * (1.0 - 1e-9) > thr1;
+    const bool none = behind || res[0] >= n_local;          // or every own cum <= t(k0): all of r's ancestors lie behind this handle's rows
+    out[2 * r] = none ? -1 : gid0 + res[0];
+    out[2 * r + 1] = none ? -1 : gid0 + (res[1] < n_local ? res[1] : n_local - 1);
+}
+
 // ------------------------------------------------------------------------------------------------ selection: gather + moments
 // Output slot k: ancestor = first j with cum[j] > threshold (src/resample.jl:33-70; fall-through clamps to the last index), its
 // R-1 columns are copied into cloud buffer 1 (K2 reads the resampled cloud from there and writes buffer 0), and the moments of
@@ -1075,7 +1120,7 @@ static __global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2
 template <int D>
 __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *cum,
                                                 int method, unsigned long long seed, long long gid0, long long *anc, const double *full,
-                                                long long full_shard_n, double *rows_gm) {
+                                                long long full_shard_n, double *rows_gm, long long s_lo = 0, long long s_hi = -1) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NCH = (NP + 63) / 64;
     __shared__ double red[(TB / 64) * 64];
     __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
@@ -1105,12 +1150,14 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
         double ua;
         if (method == SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, (unsigned long long)slot, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
         else ua = ((double)slot + u_sys) / (double)N;                       // (i - 1 + offset) / n_parts
-        long long lo = 0, hi = N;
+        // (s_lo .. s_hi: the global rows whose cum this handle holds - a sharded run exchanges only its slots' ancestor range)
+        const long long s_end = s_hi < 0 ? N : s_hi + 1;
+        long long lo = s_lo, hi = s_end;
         while (lo < hi) {
             const long long mid = (lo + hi) >> 1;
             if (cum[mid] > ua) hi = mid; else lo = mid + 1;
         }
-        const long long a = lo < N ? lo : N - 1;
+        const long long a = lo < s_end ? lo : s_end - 1;
         if (anc) anc[k] = a;
         const double *from = cl.buf[0];
         long long ldf = cl.n, a_row = a;
