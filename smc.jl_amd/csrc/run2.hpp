@@ -855,6 +855,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
             fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the totals %lld | decision + proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the totals %lld | begin %lld | stage %lld\n",
                     h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
+            fprintf(stderr, "[smcmi3]   decision + proposal: totals -> covariance, shuffle %lld | block matrices %lld | Cholesky + log det %lld | rest %lld\n",
+                    pr[30] - pr[3], pr[31] - pr[30], pr[32] - pr[31], pr[4] - pr[32]);
         }
         for (int blk = 0; blk < 2; ++blk) {
             fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");

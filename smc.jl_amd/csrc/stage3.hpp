@@ -425,7 +425,8 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         if (tid == T3 - 64) post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, 0, &B.po);       // (the last wavefront: its logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
         {
             Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
-            if (!proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre)) {
+            if (!proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr,
+                           (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 30 : nullptr)) {
                 // PosDefException aborts the run (mutation.jl:81); the gatherers, which build no proposal, leave by their time-out
                 if (writer && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
                 break;
