@@ -625,7 +625,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256, true);
     };
-    auto enq_K3 = [&](int n_first, int n_last) -> int {             // one persistent launch for stages n_first .. n_last (stage3.hpp)
+    // enter_mut: stage n_first's correction (and selection, if sel) were enqueued as launches - the segment enters at its mutation
+    auto enq_K3 = [&](int n_first, int n_last, bool enter_mut = false, bool sel = false) -> int {             // one persistent launch for stages n_first .. n_last (stage3.hpp)
         smcmi_handle *h = h0;
         Eng2 *e = h->e2;
         HIP_TRY(hipSetDevice(h->cfg.device));
@@ -635,14 +636,15 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             e->seg_seq = 1;
         }
         Mut2Args ma{};
-        ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n_first; ma.sel_enqueued = 0; ma.adaptive = adaptive ? 1 : 0;
+        ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n_first; ma.sel_enqueued = sel ? 1 : 0; ma.adaptive = adaptive ? 1 : 0;
         ma.rows_mut = e->rows_mut; ma.zbuf = nullptr; ma.pre = nullptr;
+        ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt;
         ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
         ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
         ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
         ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
         Seg3Args sa{};
-        sa.n_first = n_first; sa.n_last = n_last; sa.mrows = mut_rows(h); sa.sched = h->d_sched;
+        sa.n_first = n_first; sa.n_last = n_last; sa.enter_mut = enter_mut ? 1 : 0; sa.mrows = mut_rows(h); sa.sched = h->d_sched;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
         sa.rec = e->d_rec3;
@@ -683,6 +685,19 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             HIP_TRY(hipSetDevice(h->cfg.device));
             k2_begin<<<1, T1, 0, h->stream>>>(h->d_st, h->e2->d_ctl, n, mut_rows(h), h->d_sched, h->rec, spec_expected);
         }
+        return 0;
+    };
+    // a stage up to (not including) its mutation: what runs as launches in front of a segment that enters at the mutation
+    auto enq_stage_front = [&](int n, bool cert, int P, bool sel) -> int {
+        if (cert) {
+            if (int e = enq_begin(n)) return e;
+            if (int e = enq_passes(n, 0, P)) return e;
+            if (int e = enq_K1(n, 1, 0)) return e;
+        } else if (!inker) {
+            if (int e = enq_begin(n, adaptive ? 1 : 0)) return e;
+            if (int e = enq_K1(n, 1, 0)) return e;
+        } else if (int e = enq_K1(n, 0, adaptive ? 1 : 0)) return e;
+        if (sel) { if (int e = enq_select(n)) return e; }
         return 0;
     };
     // a whole stage; cert: certificate passes instead of a predicted ϕ_n (adaptive schedules only)
@@ -743,12 +758,14 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         const int room = max_iter - launched;
         const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), room) : room;
         int seg_a = -1, seg_b = -1;                      // pending segment of engine 3
+        bool seg_enter = false, seg_sel = false;         // ... which enters at the mutation of its first stage (corrected / resampled by launches)
         auto flush_seg = [&]() -> int {
             if (seg_a < 0) return 0;
             const int a = seg_a, b2 = seg_b;
             seg_a = seg_b = -1;
-            return enq_K3(a, b2);
+            return enq_K3(a, b2, seg_enter, seg_sel);
         };
+        static const int e3_enter = getenv("SMCMI_SEG_ENTER") ? atoi(getenv("SMCMI_SEG_ENTER")) : 1;      // development: 0 = such stages mutate in a K2 launch
         for (int b = 0; b < batch; ++b) {
             const int n = base + launched + 2;
             bool sel = true;
@@ -764,15 +781,20 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             static const int cert_sel = getenv("SMCMI_CERT_SELECT") ? atoi(getenv("SMCMI_CERT_SELECT")) : 1;   // development: 0 = resample stages on the predicted ϕ_n too
             const bool cert = adaptive && (!spec_on || (sel && cert_sel) || launched < 2);
             // engine 3 takes every stage that is expected to need neither (fixed schedules: nobody can tell which stage resamples -
-            // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches)
+            // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches) ...
             if (e3 && !cert && (!sel || !adaptive)) {
-                if (seg_a < 0) seg_a = n;
+                if (seg_a < 0) { seg_a = n; seg_enter = false; seg_sel = false; }
                 seg_b = n;
                 ++launched;
                 continue;
             }
             if (int e = flush_seg()) return e;
-            if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
+            // ... and the MUTATION of the others: their solver passes, correction and selection run as launches, then a new segment
+            // enters at the mutation (what K2 would do) and goes on with the stages behind it
+            if (e3 && e3_enter) {
+                if (int e = enq_stage_front(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
+                seg_a = seg_b = n; seg_enter = true; seg_sel = sel;
+            } else if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
             ++launched;
         }
         if (int e = flush_seg()) return e;

@@ -221,6 +221,10 @@ __device__ inline void k3_draw_park(double *z_park, unsigned long long seed, uns
 
 struct Seg3Args {
     int n_first, n_last;           // stages this launch may run
+    int enter_mut;                 // 1: stage n_first was corrected (and, where needed, resampled) by engine 2's launches - the segment enters at its
+                                   // mutation, doing what K2 would (k2_prologue: totals of the correction rows, decision, proposal; Mut2Args::cmrows,
+                                   // gmrows, wt, sel_enqueued), so resample and certificate stages cost no mutation launch, no write-back and no
+                                   // reload of the cloud
     Rows2 mrows;                   // mutation rows of stage n_first - 1 (direct view: every block totals them for the first begin)
     const double *sched;
     unsigned long long *g_cm, *g_mut;     // the workers' rows as granules: [blocks][MCM * 2] / [blocks][RMUT * 2] words
@@ -286,8 +290,9 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     __syncthreads();
     const RunParams &rp = s_rp;
     int n = sa.n_first;
-    // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left (block 0 records it)
-    {
+    int rs0 = 0;                                                // the entered stage resampled (enter_mut)
+    if (!sa.enter_mut) {
+        // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left (block 0 records it)
         const int act = begin2_block<T3>(n, st, ctl, sa.mrows, 1, sa.sched, ma.rec, &s_b[(n - 1) & 1].po, &s_a.bg, s_vt, s_tot, s_sw, &s_act);
         if (act != 0) return;                                   // nothing was touched: the cloud in memory is current
         if (tid == 0) {
@@ -296,6 +301,25 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             s_a.bg.cfac = s_cfac;
         }
         __syncthreads();
+    } else {
+        // ---- entering at the mutation of stage n: K2's prologue (k2_prologue), by every block
+        constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double), NPm = Mut2Lds<D>::NP;
+        if (tid < NWB) reinterpret_cast<double *>(&s_a.bg)[tid] = reinterpret_cast<const double *>(&ctl->bg)[tid];
+        if (tid < NWP) reinterpret_cast<double *>(&s_b[(n - 1) & 1].po)[tid] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[tid];
+        reduce_rows<MCM, 1, T3>(ma.cmrows, s_vt, s_tot);          // (its barriers also publish the LDS copies above)
+        if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) return;       // the state this launch was enqueued for is not there: no-op
+        double ess;
+        const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+        if (dec == 4 || dec < 0 || (dec == 1 && !ma.sel_enqueued)) {                             // the stalls K2 reports (the host resumes the stage through the launches)
+            if (writer && tid == 0) {
+                if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
+                ctl->status.stage = n;
+                ctl->status.code = dec == 4 ? 4 : (dec < 0 ? 9 : 3);
+            }
+            return;
+        }
+        rs0 = dec == 1 ? 1 : 0;
+        if (rs0) reduce_rows<pad2(NPm), 1, T3>(ma.gmrows, s_vt, s_tot + 2);          // moments of the resampled cloud (k2_gather's rows) replace the correction's
     }
     const double inv_pre = INV_FACTORIAL[tid & 31];
     // Stage n's begin from the totals of stage n - 1's mutation rows (in s_tot), by every block alike: 0 go on, 7 segment complete,
@@ -328,13 +352,16 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
             double run;
-            if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to, &run)) break;
-            if (tid < MCM) gran_store(sa.gt_cm + ((long long)vg * MCM + tid) * 2, run, tag);
-            // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
-            if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) break;
-            double ess;
-            if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess) != 0) break;
-            if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, 0, &s_b[n & 1].po);
+            const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
+            if (!entered) {
+                if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to, &run)) break;
+                if (tid < MCM) gran_store(sa.gt_cm + ((long long)vg * MCM + tid) * 2, run, tag);
+                // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
+                if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) break;
+            }
+            const double ess = s_tot[0] * s_tot[0] / s_tot[1];
+            if (!entered) { double e2; if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &e2) != 0) break; }
+            if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, entered ? rs0 : 0, &s_b[n & 1].po);
             __syncthreads();
             if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to, &run)) break;
             if (tid < RMUT) gran_store(sa.gt_mut + ((long long)vg * RMUT + tid) * 2, run, tag);
@@ -357,10 +384,12 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     const long long il = live ? i : (end > beg ? end - 1 : 0);
     const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
     double x[D], like, lprior, like_prev, Wt, acc_val;
+    // (entered at the mutation of a stage that resampled: the gathered cloud is in buffer 1 - k2_gather - as K2 reads it)
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
-    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
+    for (int k = 0; k < D; ++k) x[k] = col(cl, rs0, k)[il];
+    like = col(cl, rs0, D)[il]; lprior = col(cl, rs0, D + 1)[il]; like_prev = col(cl, rs0, D + 2)[il];
     acc_val = col(cl, 0, D + 3)[il]; Wt = col(cl, 0, D + 4)[il];
+    double v_entered = sa.enter_mut ? ma.wt[il] : 0.0;          // the unnormalised weight K1 left for the entered stage
     if (!live) {
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = 0.0;
@@ -390,8 +419,10 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
         // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
         const double phi = s_a.bg.phi_n, phi_prev = s_a.bg.phi_prev, esh = pw == 0.0 ? s_a.bg.e_shift : 0.0, e_center = s_a.bg.e_center;
-        double v = 0.0;
-        {
+        const bool entered = sa.enter_mut && n == sa.n_first;   // this stage's correction (and selection) ran as launches: totals in s_tot
+        const int rs = entered ? rs0 : 0;
+        double v = entered ? v_entered : 0.0;
+        if (!entered) {
             constexpr int NCH = (NPF + 63) / 64;
             double acc[NCH * 64];
 #pragma unroll
@@ -410,10 +441,10 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
         K3_STAMP(sa.prof, 2);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-        if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
+        if (!entered && !gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
-        double ess;
-        const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+        double ess = s_tot[0] * s_tot[0] / s_tot[1];
+        const int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
         if (dec != 0) {                                         // leave: nothing of the stage is committed, registers hold the cloud after stage n - 1
             if (writer && tid == 0) {
                 if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
@@ -422,7 +453,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             }
             break;
         }
-        if (tid == T3 - 64) post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, 0, &B.po);       // (the last wavefront: its logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
+        if (tid == T3 - 64) post2(n, s_a.bg, po, rp, s_tot[0], s_tot[1], ess, rs, &B.po);       // (the last wavefront: its logarithm runs beside the covariance and the shuffle of wavefronts 0 and 1)
         {
             Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
             if (!proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr,
@@ -435,7 +466,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         if (tid < D) B.po.shift[tid] = L.mean_s[tid];
         __syncthreads();
         if (writer) {                                           // bookkeeping nobody in this launch waits for: Ctl2 / records / diagnostics (k2_bookkeeping)
-            if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = 0; ma.rec.c[n - 1] = B.po.c; }
+            if (tid == 0) { ma.rec.phi[n - 1] = B.po.phi_n; ma.rec.ess[n - 1] = B.po.ess; ma.rec.resampled[n - 1] = rs; ma.rec.c[n - 1] = B.po.c; }
             if (tid < D) st->mean[tid] = L.mean_s[tid];
             for (int e = tid; e < D * D; e += T3) st->cov[e] = L.covl[e];
             constexpr int NWP = sizeof(Post2) / sizeof(double);
@@ -454,7 +485,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             for (int e = 0; e < D; ++e) z[e] = p[(2 + e) * T3];
         }
         if (live) {
-            Wt = (v * nrm_N) / nrm_sumw;                        // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366)
+            Wt = rs ? 1.0 : (v * nrm_N) / nrm_sumw;             // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366); 1 after a resample
             if (ma.hist_W && ma.store_history) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = Wt;
         }
         k2_mh_steps<D, ALPHA1, T3, true>(L, mixbuf, mixpos, mixzt, ma, g.n, lv, mv, nb, nf, live, i, pid, (unsigned)n, phi_n, x, like, lprior, like_prev, accept,
@@ -463,7 +494,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         K3_STAMP(sa.prof, 5);
         {
             double *plain = ma.rows_mut + (long long)rowi * RMUT;      // (the launch after this one totals the last stage's rows from here)
-            k2_mut_row_f<T3>(ma.adaptive != 0, like, like_prev, live ? Wt : 0.0, live ? acc_val : 0.0, e_center, live, false, red, L.red,
+            k2_mut_row_f<T3>(ma.adaptive != 0, like, like_prev, live ? Wt : 0.0, live ? acc_val : 0.0, e_center, live, rs != 0, red, L.red,
                              [&](int idx, double val) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; });
             if (tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
         }

@@ -28,8 +28,17 @@ spec = getattr(models, cfg.get("spec", "gauss_spec"))(*cfg.get("spec_args", []))
 e = Engine(cfg["n"], cfg["d"], seed=cfg["seed"], max_stages=cfg.get("max_stages", 1500), store_history=cfg.get("history", True))
 e.set_model(spec)
 out = []
+P_old = None
+if cfg.get("old_run"):                      # a tempered update: the cloud of an estimation on the old data is the starting point (smc_main.jl:244-260)
+    e0 = Engine(cfg["n"], cfg["d"], seed=cfg["seed"] + 1, max_stages=200, store_history=False)
+    e0.set_model(getattr(models, cfg["spec"])(*cfg["old_run"]["spec_args"])); e0.init_from_prior()
+    e0.run(**cfg["old_run"]["kw"])
+    P_old = e0.download_cloud(); e0.close()
 for rep in range(cfg.get("reps", 1)):
-    e.init_from_prior()
+    if P_old is None:
+        e.init_from_prior()
+    else:
+        e.upload_cloud(P_old); e.initialize_likelihoods()
     kw = dict(cfg["kw"]); stop = kw.pop("pause_at", 0)
     if stop:
         r = e.run(stop_after_stage=stop, **kw); assert r["paused"]
@@ -67,8 +76,13 @@ _KEYS = ("n_stages", "resamples", "logmdd", "c", "accept", "schedule", "ess", "c
     dict(n=20_000, d=10, seed=4, kw=dict(use_fixed_schedule=False, tempering_target=0.95, alpha=0.9, n_blocks=2, n_mh_steps=2)),
     dict(n=30_000, d=4, seed=2, spec_args=[4], kw=dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial")),
     dict(n=5_000, d=2, seed=9, spec="regression_spec", kw=dict(use_fixed_schedule=False, tempering_target=0.9, pause_at=6)),
-    dict(n=122_880, d=10, seed=3, kw=dict(use_fixed_schedule=False, tempering_target=0.97), history=False),                # 240 workers + 9 helpers: nearly every CU
-], ids=["config2", "mix2blocks2steps", "fixed_multinomial", "regression_pause", "n122880"])
+    dict(n=122_880, d=10, seed=3, kw=dict(use_fixed_schedule=False, tempering_target=0.97), history=False),                # 240 workers + 8 gatherers: nearly every CU
+    dict(n=24_000, d=9, seed=6, spec="capm_spec", kw=dict(use_fixed_schedule=True, n_phi=120, n_mh_steps=3)),              # config 4's model: Uniform priors with bounds, 3 MH steps
+    dict(n=16_000, d=9, seed=8, spec="linmodel_spec", spec_args=[100, 60], old_run=dict(spec_args=[60], kw=dict(n_phi=100, lam=2.0, alpha=0.9)),
+         kw=dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=3, alpha=0.9)),                                  # a tempered update: an old-data likelihood beside the new one
+    dict(n=16_000, d=9, seed=8, spec="linmodel_spec", spec_args=[100, 60], old_run=dict(spec_args=[60], kw=dict(n_phi=100, lam=2.0, alpha=0.9)),
+         kw=dict(use_fixed_schedule=True, n_phi=60, lam=2.0, alpha=0.9, prior_weight=0.5, log_prob_old_data=-300.0)),        # mixed prior weight in the correction
+], ids=["config2", "mix2blocks2steps", "fixed_multinomial", "regression_pause", "n122880", "capm3steps", "two_likelihoods", "prior_weight"])
 def test_segments_leave_the_bits_of_the_launches(cfg):
     seg = _run(cfg)
     ref = _run(cfg, {"SMCMI_ENGINE3": "0"})
