@@ -106,8 +106,15 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and torch.cuda.device_count() < world:
+    # SMCMI_BENCH_COMM=host (development / tests): the ranks share ONE GPU and the sharded driver's collectives go through the library's
+    # host-mediated communicator over gloo (include/smcmi.h smcmi_comm_init_host) - the whole multi-rank code path of this script,
+    # pre-flight included, on a one-GPU box.  Never what a scaling number is measured with (config.comm says which it was).
+    host_comm = os.environ.get("SMCMI_BENCH_COMM") == "host"
+    if world > 1 and torch.cuda.device_count() < world and not host_comm:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
+    if host_comm:
+        local_rank = 0
+    red_dev = "cpu" if host_comm else "cuda"            # device of the small tensors torch.distributed reduces
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("SMCMI_FORCE_SHARDED") == "1"
@@ -115,7 +122,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_comm:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     global D, RUN_KW
     if args.workload == "capm":
@@ -172,9 +182,14 @@ def main():
                      n_local=n_local, gid0=rank * n_local)
         eng.set_model(spec)
         eng.init_from_prior()
-        uid = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
+        if host_comm:
+            from smc_jl_amd import torch_dist_host_comm
+
+            eng.comm_init_host(rank, world, *torch_dist_host_comm())
+        else:
+            uid = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init(rank, world, uid[0])
 
         def one_step(profile=False):
             eng.init_from_prior()            # every step is a whole job: each rank draws its shard again (global particle ids)
@@ -202,12 +217,14 @@ def main():
         except Exception as ex:   # noqa: BLE001
             ok = 0
             sys.stderr.write("bench.py: rank %d: run with the default hand-over failed (%s): falling back to all-gathers\n" % (rank, ex))
-        flags = torch.tensor([ok, used], device="cuda", dtype=torch.int32)
+        flags = torch.tensor([ok, used], device=red_dev, dtype=torch.int32)
         if dist is not None:
             dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         if int(flags[0].item()) == 0:
             os.environ["SMCMI_MAILBOX"] = "0"
         hand_over = "peer mailbox (xGMI)" if int(flags[0].item()) == 1 and int(flags[1].item()) == 1 else "RCCL all-gather"
+        if host_comm:
+            hand_over = hand_over.replace("(xGMI)", "(HIP IPC, one GPU)").replace("RCCL all-gather", "host-mediated all-gather") + " [SMCMI_BENCH_COMM=host: ranks share one GPU]"
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -220,7 +237,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = n_total * stages / dt

@@ -122,3 +122,25 @@ def test_all_gather_hand_overs_and_multinomial_across_processes(env, tmp_path):
     want, want_cloud = _single(cfg)
     runs, cloud = _spawn(2, cfg, tmp_path, env_extra=env)
     _check(runs, cloud, want, want_cloud, expect_mailbox=False)
+
+
+def test_bench_py_with_two_ranks_on_one_gpu():
+    """bench.py's whole multi-rank path - rank set-up under torch.distributed.run, the pre-flight that checks the mailbox against the
+    all-gathers bit for bit, the timed steps, the max-over-ranks time, the single-GPU reference, the JSON line - had never executed
+    with more than one rank (one GPU per box).  SMCMI_BENCH_COMM=host lets the ranks share the GPU over the host-mediated communicator."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMCMI_BENCH_COMM="host")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nparts", "65536", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-history"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["steps"] == 2
+    assert d["config"]["n_parts_total"] == 65536 and d["config"]["n_parts_per_gpu"] == 32768
+    assert "one GPU" in d["config"]["hand_over"]
+    assert d["speedup_vs_single_gpu"] > 0 and d["logmdd_abs_diff_vs_single_gpu"] == 0.0      # the same bits as the single handle (engine 3 there, engine 2 here)
+    assert abs(d["logmdd_gpu"] - models.gauss_logmdd(10)) < 0.3
