@@ -60,7 +60,7 @@ struct smcmi_handle {
     double *d_sched = nullptr;
     int sched_len = 0;
     // scratch
-    int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
+    int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, nb_mut_ls4 = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_wt = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;

@@ -1898,19 +1898,38 @@ struct MutArgs {
     const int *mixpos;         //                         and parameter positions ([n_blocks][D])
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma, double *acc_partials,
+// LS = 4 (lgss_kalman family only, MODE 0): FOUR lanes per particle - a 256-thread block carries 64 particles, the four lanes of a
+// quad run the per-particle part (draw, densities, prior, decision) redundantly on the same values (same counters -> same random
+// numbers; nothing to exchange) and share the Kalman filter (model.hpp kalman_lgss_quad).  Per wavefront: θ, θ' [d][16], then
+// {draw, solve scratch [d][16]} overlaid with the filter's 16 transposition slots (dead while the filter runs: the accepted
+// proposal is copied from θ').  Lane 0 of a quad stores the particle and feeds the block sums.
+// what the proposal of the lane-split kernel reads per block and per parameter, staged in LDS once per launch (in DevState / ModelDev
+// they are global loads inside rolled loops: a dependent ~0.3-1 µs round trip per iteration with one wavefront per SIMD)
+struct MutStage {
+    double L[13 * 13], mu_b[13], sd_draw[13], sd_dens[13], logdet[13], lo[13], hi[13], prior_a[13], prior_b[13], prior_k[13];
+    int block_ptr[14], blocks_all[13], l_off[13], fixed[13], prior_family[13];
+};
+constexpr int mutate_wave_bytes_ls4(int d) {
+    return (2 * d * 16 * 8 + ((2 * d * 16 * 8 > 16 * KALMAN4_SLOT_BYTES) ? 2 * d * 16 * 8 : 16 * KALMAN4_SLOT_BYTES) + 15) / 16 * 16;
+}
+template <int MODE, int LS = 1>
+__global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma, double *acc_partials,
                          int standalone) {
+    static_assert(LS == 1 || (LS == 4 && MODE == 0), "lane-split mutation: MODE 0 only");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (!standalone && st->done) return;
-    const int T = blockDim.x, tid = threadIdx.x;
+    const int T = (LS == 4) ? 16 : blockDim.x;                    // stride of the per-particle LDS vectors
+    const int tid = (LS == 4) ? ((threadIdx.x & 63) >> 2) : threadIdx.x;   // column in them
+    const int quad_lane = threadIdx.x & 3;
+    const bool lead = (LS == 1) || quad_lane == 0;
     const int d = md->d, nf = md->n_free;
-    double *th = sm;                       // current θ           [d][T]
+    double *wave_base = (LS == 4) ? sm + (long long)(threadIdx.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : sm;
+    double *th = wave_base;                // current θ           [d][T]
     double *tn = th + (long long)d * T;    // proposed θ          [d][T]
     double *y = tn + (long long)d * T;     // z / draw            [d][T]
     double *v = y + (long long)d * T;      // triangular-solve scratch [d][T]
-    double *red = v + (long long)d * T;    // [T/64]
-    const long long i = (long long)blockIdx.x * T + tid;
+    double *red = (LS == 4) ? sm + (long long)(blockDim.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : v + (long long)d * T;    // [blockDim.x/64]
+    const long long i = (LS == 4) ? (long long)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2) : (long long)blockIdx.x * T + tid;
     const bool live = i < cl.n;
     constexpr int src = 0;
     const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
@@ -1918,26 +1937,47 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
     const int nb = st->n_blocks, n_steps = st->mut_steps;
     double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    MutStage *S = (LS == 4) ? (MutStage *)(red + 8) : nullptr;
+    if (LS == 4) {
+        for (int e = threadIdx.x; e < 13 * 13; e += blockDim.x) S->L[e] = st->L[e];
+        if (threadIdx.x < 13) {
+            const int e = threadIdx.x;
+            S->mu_b[e] = st->mu_b[e]; S->sd_draw[e] = st->sd_draw[e]; S->sd_dens[e] = st->sd_dens[e]; S->logdet[e] = st->logdet[e];
+            S->lo[e] = md->lo[e]; S->hi[e] = md->hi[e]; S->prior_a[e] = md->prior_a[e]; S->prior_b[e] = md->prior_b[e]; S->prior_k[e] = md->prior_k[e];
+            S->blocks_all[e] = st->blocks_all[e]; S->l_off[e] = st->l_off[e]; S->fixed[e] = md->fixed[e]; S->prior_family[e] = md->prior_family[e];
+        }
+        if (threadIdx.x < 14) S->block_ptr[threadIdx.x] = st->block_ptr[threadIdx.x];
+        __syncthreads();
+    }
+    // (LS = 1 reads the same arrays where they are)
+    const double *a_L = (LS == 4) ? S->L : st->L, *a_mu = (LS == 4) ? S->mu_b : st->mu_b, *a_sdd = (LS == 4) ? S->sd_draw : st->sd_draw;
+    const double *a_sdn = (LS == 4) ? S->sd_dens : st->sd_dens, *a_logdet = (LS == 4) ? S->logdet : st->logdet;
+    const int *a_bptr = (LS == 4) ? S->block_ptr : st->block_ptr, *a_ball = (LS == 4) ? S->blocks_all : st->blocks_all, *a_loff = (LS == 4) ? S->l_off : st->l_off;
+    const ModelView mv{d, (LS == 4) ? S->fixed : md->fixed, (LS == 4) ? S->prior_family : md->prior_family, (LS == 4) ? S->lo : md->lo, (LS == 4) ? S->hi : md->hi,
+                       (LS == 4) ? S->prior_a : md->prior_a, (LS == 4) ? S->prior_b : md->prior_b, (LS == 4) ? S->prior_k : md->prior_k};
     if (live) {
         like = col(cl, src, d)[i]; lprior = col(cl, src, d + 1)[i]; like_prev = col(cl, src, d + 2)[i];
         load_columns(cl.buf[src], cl.n, i, d, th + tid, T);
         for (int k = 0; k < d; ++k) tn[k * T + tid] = th[k * T + tid];
     }
     auto TN = [&](int k) { return tn[k * T + tid]; };
-    if (live) {
+    // (the loops are uniform and `live` is tested inside them: the lane-split filter needs every lane of the wavefront)
+    {
         const int s_beg = (MODE == 0) ? 0 : ma.step, s_end = (MODE == 0) ? n_steps : ma.step + 1;
         for (int step = s_beg; step < s_end; ++step) {
             const int b_beg = (MODE == 0) ? 0 : ma.block, b_end = (MODE == 0) ? nb : ma.block + 1;
             for (int b = b_beg; b < b_end; ++b) {
-                const int p0 = st->block_ptr[b], db = st->block_ptr[b + 1] - p0;
-                const double *L = st->L + st->l_off[b];
+                const int p0 = a_bptr[b], db = a_bptr[b + 1] - p0;
+                const double *L = a_L + a_loff[b];
                 const unsigned t = (unsigned)(step * nb + b);
                 // MH uniform for this decision: drawn "before" the proposal (quirk Q3)
-                double step_prob, u_dummy;
-                if (t == 0) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
+                double step_prob = 0.0, u_dummy;
+                bool inb = false;
+                if (!live) {}
+                else if (t == 0) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);
                 else uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t - 1, 0), u_dummy, step_prob);
                 double q0 = 0.0, q1 = 0.0, prior_new = SMCMI_NEG_INF, like_new = SMCMI_NEG_INF, like_old_data = SMCMI_NEG_INF;
-                if (MODE != 2) {
+                if (MODE != 2 && live) {
                     // ---- mvnormal_mixture_draw
                     double uc, unext;
                     uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 0), uc, unext);
@@ -1950,67 +1990,112 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
                     const int comp = (uc < c_alpha) ? 0 : (uc < c_alpha + (1.0 - c_alpha) / 2.0 ? 1 : 2);
                     if (comp == 1) {
                         for (int e = 0; e < db; ++e)
-                            y[e * T + tid] = th[st->blocks_all[p0 + e] * T + tid] + st->sd_draw[p0 + e] * y[e * T + tid];
+                            y[e * T + tid] = th[a_ball[p0 + e] * T + tid] + a_sdd[p0 + e] * y[e * T + tid];
                     } else {
                         for (int e = db - 1; e >= 0; --e) {   // in place: row e only needs z_0..z_e
                             double s = 0.0;
+#pragma unroll 4
                             for (int k = 0; k <= e; ++k) s += L[e * db + k] * y[k * T + tid];
-                            const double center = (comp == 0) ? th[st->blocks_all[p0 + e] * T + tid] : st->mu_b[p0 + e];
+                            const double center = (comp == 0) ? th[a_ball[p0 + e] * T + tid] : a_mu[p0 + e];
                             y[e * T + tid] = center + s;
                         }
                     }
                     // ---- compute_proposal_densities
-                    const double cst = (double)db * LOG2PI + st->logdet[b];
-                    double quad = 0.0;
+                    const double cst = (double)db * LOG2PI + a_logdet[b];
+                    double quad = 0.0, quad_s = 0.0, quad_d = 0.0, ind_pdf = 1.0;
+                    if (LS == 4) {
+                        // the three forward substitutions L⁻¹(θ_b - ϑ_b), L⁻¹(θ_b - θ̄_b), L⁻¹(ϑ_b - θ̄_b) share one sweep over L (each
+                        // sum in the literal order: same bits): a third of the loads, three independent chains
+                        double *v2 = v + (long long)d * T, *v3 = v2 + (long long)d * T;
+                        for (int e = 0; e < db; ++e) {
+                            const double te = th[a_ball[p0 + e] * T + tid], ye = y[e * T + tid], me = a_mu[p0 + e];
+                            double s1 = te - ye, s2 = te - me, s3 = ye - me;
+#pragma unroll 4
+                            for (int k = 0; k < e; ++k) {
+                                const double l = L[e * db + k];
+                                s1 -= l * v[k * T + tid]; s2 -= l * v2[k * T + tid]; s3 -= l * v3[k * T + tid];
+                            }
+                            const double dg = L[e * db + e];
+                            const double e1 = s1 / dg, e2 = s2 / dg, e3 = s3 / dg;
+                            v[e * T + tid] = e1; v2[e * T + tid] = e2; v3[e * T + tid] = e3;
+                            quad += e1 * e1; quad_s += e2 * e2; quad_d += e3 * e3;
+                            const double sii = a_sdn[p0 + e];
+                            const double z = (te - ye) / sii;
+                            ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * z * z);
+                        }
+                    } else {
                     for (int e = 0; e < db; ++e) {            // L⁻¹(θ_b - ϑ_b): forward == reverse density
-                        double s = th[st->blocks_all[p0 + e] * T + tid] - y[e * T + tid];
+                        double s = th[a_ball[p0 + e] * T + tid] - y[e * T + tid];
                         for (int k = 0; k < e; ++k) s -= L[e * db + k] * v[k * T + tid];
                         const double ve = s / L[e * db + e];
                         v[e * T + tid] = ve;
                         quad += ve * ve;
                     }
-                    const double lp_sym = -(cst + quad) / 2.0;
-                    q0 = c_alpha * exp(lp_sym);
-                    q1 = q0;
-                    double ind_pdf = 1.0;
                     for (int e = 0; e < db; ++e) {
-                        const double sii = st->sd_dens[p0 + e];
-                        const double z = (th[st->blocks_all[p0 + e] * T + tid] - y[e * T + tid]) / sii;
+                        const double sii = a_sdn[p0 + e];
+                        const double z = (th[a_ball[p0 + e] * T + tid] - y[e * T + tid]) / sii;
                         ind_pdf = ind_pdf / (sii * sqrt(2.0 * M_PI)) * exp(-0.5 * z * z);
                     }
-                    q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                    q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
-                    double quad_s = 0.0, quad_d = 0.0;
                     for (int e = 0; e < db; ++e) {            // log N(θ_b; θ̄_b, c²Σ)
-                        double s = th[st->blocks_all[p0 + e] * T + tid] - st->mu_b[p0 + e];
+                        double s = th[a_ball[p0 + e] * T + tid] - a_mu[p0 + e];
                         for (int k = 0; k < e; ++k) s -= L[e * db + k] * v[k * T + tid];
                         const double ve = s / L[e * db + e];
                         v[e * T + tid] = ve;
                         quad_s += ve * ve;
                     }
                     for (int e = 0; e < db; ++e) {            // log N(ϑ_b; θ̄_b, c²Σ)
-                        double s = y[e * T + tid] - st->mu_b[p0 + e];
+                        double s = y[e * T + tid] - a_mu[p0 + e];
                         for (int k = 0; k < e; ++k) s -= L[e * db + k] * v[k * T + tid];
                         const double ve = s / L[e * db + e];
                         v[e * T + tid] = ve;
                         quad_d += ve * ve;
                     }
+                    }
+                    const double lp_sym = -(cst + quad) / 2.0;
+                    q0 = c_alpha * exp(lp_sym);
+                    q1 = q0;
+                    q0 += (1.0 - c_alpha) / 2.0 * ind_pdf;
+                    q1 += (1.0 - c_alpha) / 2.0 * ind_pdf;
                     q0 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
                     q1 += (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
                     q0 = log(q0);
                     q1 = log(q1);
                     if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
                     // ---- para_new
-                    for (int e = 0; e < db; ++e) tn[st->blocks_all[p0 + e] * T + tid] = y[e * T + tid];
-                    const bool inb = in_bounds(*md, TN);
-                    if (inb) prior_new = logprior(*md, TN);
+                    for (int e = 0; e < db; ++e) tn[a_ball[p0 + e] * T + tid] = y[e * T + tid];
+                    inb = in_bounds(mv, TN);
+                    if (inb) prior_new = logprior(mv, TN);
                     if (MODE == 1) {
                         for (int k = 0; k < d; ++k) ma.proposals[(long long)k * cl.n + i] = TN(k);
                         ma.prop_logprior[i] = prior_new;
                         ma.prop_qdiff[i] = q0 - q1;
-                        continue;
                     }
-                    if (inb) {
+                }
+                if (MODE == 1) continue;
+                if (MODE == 0 && LS == 4) {
+                    // every lane calls the filter (its structure values travel through DPP operands); quads without a proposal inside
+                    // the bounds run it on the particle's current θ and drop the result
+                    double thv[13];
+                    for (int k = 0; k < 13; ++k) thv[k] = (live && inb) ? TN(k) : (live ? th[k * T + tid] : 0.5);
+                    const lds_bytes slot = (lds_bytes)(y) + tid * KALMAN4_SLOT_BYTES;
+                    // (the draw in y is dead from here on: θ' holds it at the block's positions)
+                    // (inlined - one register allocation with the kernel, nothing saved around a call - hence ONE call site: the second
+                    // trip is the old vintage when it is not a prefix of the data)
+                    const int n_pass = (md->lik_prefix > 0 || md->lik[1].family == SMCMI_LIK_NONE) ? 1 : 2;      // (uniform)
+                    double r_new = 0.0, r_old = 0.0;
+#pragma nounroll
+                    for (int pass = 0; pass < n_pass; ++pass) {
+                        const LikDev &lk = md->lik[pass];
+                        const KalmanLL r = kalman_lgss_quad(thv, lk.data, lk.cols, pass == 0 ? md->lik_prefix : 0, lk.aux, slot, quad_lane);
+                        if (pass == 0) { r_new = r.ll; if (md->lik_prefix > 0) r_old = r.ll_mid; }
+                        else r_old = r.ll;
+                    }
+                    if (live && inb) {
+                        like_new = r_new; like_old_data = r_old;
+                        if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
+                    }
+                } else if (MODE != 2) {
+                    if (live && inb) {
                         if (md->lik_prefix > 0) {
                             // old data = a prefix of the data, same state-space structure: both log-likelihoods from one filter pass
                             double thv[13];
@@ -2023,7 +2108,7 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
                         }
                         if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
                     }
-                } else {
+                } else if (live) {
                     for (int k = 0; k < d; ++k) tn[k * T + tid] = ma.proposals[(long long)k * cl.n + i];
                     prior_new = ma.prop_logprior[i];
                     q0 = ma.prop_qdiff[i];
@@ -2038,20 +2123,22 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
                 }
                 const double eta = exp(phi_n * (like_new - like) + (1.0 - phi_n) * (like_old_data - like_prev) +
                                        (prior_new - lprior) + (q0 - q1));
-                if (step_prob < eta) {
+                if (!live) {}
+                else if (step_prob < eta) {
                     if (MODE == 2) { for (int k = 0; k < d; ++k) th[k * T + tid] = tn[k * T + tid]; }
-                    else for (int e = 0; e < db; ++e) th[st->blocks_all[p0 + e] * T + tid] = y[e * T + tid];
+                    else if (LS == 4) { for (int e = 0; e < db; ++e) { const int k = a_ball[p0 + e]; th[k * T + tid] = tn[k * T + tid]; } }
+                    else for (int e = 0; e < db; ++e) th[a_ball[p0 + e] * T + tid] = y[e * T + tid];
                     like = like_new; lprior = prior_new; like_prev = like_old_data;
                     accept += (double)db;
                 } else if (MODE != 2) {
-                    for (int e = 0; e < db; ++e) tn[st->blocks_all[p0 + e] * T + tid] = th[st->blocks_all[p0 + e] * T + tid];
+                    for (int e = 0; e < db; ++e) tn[a_ball[p0 + e] * T + tid] = th[a_ball[p0 + e] * T + tid];
                 }
             }
         }
     }
     if (MODE == 1) return;
     double acc_val = 0.0;
-    if (live) {
+    if (live && lead) {
         for (int k = 0; k < d; ++k) col(cl, src, k)[i] = th[k * T + tid];
         col(cl, src, d)[i] = like;
         col(cl, src, d + 1)[i] = lprior;
@@ -2067,26 +2154,28 @@ __global__ void __launch_bounds__(256) k_mutate(CloudPtrs cl, const DevState *st
         }
     }
     // Σ accept over the block (update_acceptance_rate!, src/particle.jl:466-468), fixed order
+    const int btid = threadIdx.x, nwv = blockDim.x >> 6;
+    const bool counted = live && lead;               // lanes 1..3 of a quad (LS = 4) carry copies: they add nothing to the block sums
     double a1[1] = {acc_val};
-    Butterfly<0, 32>::run(a1, tid & 63);
-    if ((tid & 63) == 0) red[tid >> 6] = a1[0];
+    Butterfly<0, 32>::run(a1, btid & 63);
+    if ((btid & 63) == 0) red[btid >> 6] = a1[0];
     if (MODE == 0 && ma.emax) {                      // largest energy of the mutated cloud (energy shift of the next stage)
         __shared__ double emx[4];
-        const double wl = (live && !st->do_resample) ? col(cl, src, d + 4)[i] : 1.0;
-        const double em = block_max(energy_or_ninf(like, like_prev, wl, live), emx, T / 64);
-        if (tid == 0) ma.emax[blockIdx.x] = em;
+        const double wl = (counted && !st->do_resample) ? col(cl, src, d + 4)[i] : 1.0;
+        const double em = block_max(energy_or_ninf(like, like_prev, wl, counted), emx, nwv);
+        if (btid == 0) ma.emax[blockIdx.x] = em;
     }
     if (MODE == 0 && ma.esum) {                      // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
-        energy_terms(es, live ? col(cl, src, d + 4)[i] : 0.0, like, like_prev, st->e_center, live, st->do_resample != 0);
+        energy_terms(es, counted ? col(cl, src, d + 4)[i] : 0.0, like, like_prev, st->e_center, counted, st->do_resample != 0);
         es[EACC] = acc_val;
-        const double tot = block_reduce_es(es, th, T / 64);          // θ staging area is dead by now ((T/64) ES <= d T)
-        if (tid < ES) ma.esum[(long long)blockIdx.x * ES + tid] = tot;
+        const double tot = block_reduce_es(es, sm, nwv);             // θ staging area is dead by now (nwv ES <= d T)
+        if (btid < ES) ma.esum[(long long)blockIdx.x * ES + btid] = tot;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (btid == 0) {
         double s = 0.0;
-        for (int w = 0; w < T / 64; ++w) s += red[w];
+        for (int w = 0; w < nwv; ++w) s += red[w];
         acc_partials[blockIdx.x] = s;
     }
 }
@@ -2633,6 +2722,26 @@ static __global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs 
     if (in_bounds(*md, TH)) { ll = loglik(md->lik[0], d, TH); lp = logprior(*md, TH); }
     col(cl, 0, d)[i] = ll;
     col(cl, 0, d + 1)[i] = lp;
+}
+
+// the same for the lgss_kalman family with four lanes per particle (model.hpp kalman_lgss_quad; 64 particles per 256-thread block):
+// the values the lane-split mutation compares its proposals with come from the same filter
+static __global__ void __launch_bounds__(256, 1) k_initialize_likelihoods_ls4(CloudPtrs cl, const ModelDev *md) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int q = threadIdx.x & 3, slot_i = threadIdx.x >> 2;
+    const long long i = (long long)blockIdx.x * 64 + slot_i;
+    const bool live = i < cl.n;
+    double thl[13];
+    for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : 0.5;
+    auto TH = [&](int k) { return thl[k]; };
+    const bool inb = live && in_bounds(*md, TH);
+    // (every lane runs the filter: its structure values travel through DPP operands)
+    const KalmanLL r = kalman_lgss_quad(thl, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux, (lds_bytes)sm + slot_i * KALMAN4_SLOT_BYTES, q);
+    if (live && q == 0) {
+        col(cl, 0, 13 + 2)[i] = col(cl, 0, 13)[i];
+        col(cl, 0, 13)[i] = inb ? r.ll : SMCMI_NEG_INF;
+        col(cl, 0, 13 + 1)[i] = inb ? logprior(*md, TH) : SMCMI_NEG_INF;
+    }
 }
 
 // empty kernel (event-overhead calibration, smcmi_run profile mode)

@@ -274,6 +274,249 @@ __device__ inline double kalman_lgss(const double *thv, const double *ydat, long
     return kalman_lgss2(thv, ydat, nt, 0, aux, kappa).ll;
 }
 
+// ---- the same filter with FOUR lanes per particle (one DPP quad): lane q owns rows 2q, 2q+1 of the covariance.
+// One thread per particle keeps ~460 registers alive and leaves a cloud of 12 500 particles (BASELINE config 5 on 4 GPUs) on a fifth of
+// the SIMDs; here a wavefront carries 16 particles, a lane ~130 registers, and the same cloud fills 782 wavefronts.  How the rows
+// stay local:
+//   W  = P Tm'            row r of W needs row r of P, ρ (replicated) and the wave-uniform κC                 - local
+//   TP = Tm P = W'        (P symmetric)  one 8x8 transpose per step through the particle's 576-byte LDS slot (16-byte accesses,
+//                         conflict-free layout: element (k, c) at (k>>1) 144 + (k&1) 64 + 8 c)
+//   Pn = TP Tm' + R Q R'  local again; R Q R' rows are loop invariants (16 registers instead of 48 multiplies per step)
+//   PZ = Pn Z'            local
+//   F = Z PZ + σ_e² I, Z x_p   two-row partial sums, one quad all-reduce of 9 values (DPP quad_perm: every lane gets the same bits)
+//   3x3 factorisation     replicated in the quad; reciprocal square roots (hardware estimate + two Newton steps) instead of
+//                         sqrt + 9 divisions, and the determinant as a running product with its exponent split off (one log per
+//                         evaluation instead of one per step)
+//   P  = Pn - G G'        G = PZ L^-T: own rows local, the other six rows (and the other six entries of x) by quad broadcasts
+// The 88 wave-uniform structure values (κC, Z) do not fit the scalar registers next to everything else (the compiler parks them in
+// VGPR lanes and pays two v_readlane per use: 380 of 1 250 instructions per step when written with scalar operands).  Here they sit
+// in SIX vector registers - value c in lane c mod 16 of every 16-lane row of register c / 16 - and reach the FMA through its own
+// DPP operand (`v_fmac_f64_dpp ... row_newbcast:n`, the one DPP control gfx90a+ has for 64-bit operations): no instruction, no
+// scalar register per use.  A DPP source lane must be active, so ALL 64 LANES MUST CALL THIS TOGETHER (quads without a valid
+// parameter vector pass any finite numbers and ignore the result).
+// P is not symmetrised (the asymmetric part is rounding noise that Tm contracts).  Values agree with kalman_lgss2 to ~1e-13
+// relative, not bit for bit (different summation orders).  xslot: this particle's LDS slot (KALMAN4_SLOT_BYTES, 16-byte aligned).
+constexpr int KALMAN4_SLOT_BYTES = 576;
+typedef __attribute__((address_space(3))) char *lds_bytes;
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2f64 *lds_v2f64;
+template <int CTRL>
+__device__ inline double quad_perm_f64(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double quad_allsum(double x) {
+    x += quad_perm_f64<0xB1>(x);          // [1,0,3,2]
+    x += quad_perm_f64<0x4E>(x);          // [2,3,0,1]
+    return x;
+}
+__device__ inline double rsqrt_nr(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h0 = 0.5 * a;
+    y = y * (1.5 - h0 * y * y);
+    y = y * (1.5 - h0 * y * y);
+    return y;
+}
+// acc += (structure value C) * x, the value taken from lane C % 16 of this lane's row of cst[C / 16]
+template <int C>
+__device__ inline void fmac_row_const(double &acc, const double (&cst)[6], double x) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cst[C / 16]), "v"(x), "n"(C % 16));
+}
+template <int J, int K = 0>
+struct RowDot8 {                 // acc += Σ_k (structure value BASE + 8 J + k) * x[k]
+    template <int BASE>
+    __device__ static inline void run(double &acc, const double (&cst)[6], const double (&x)[8]) {
+        fmac_row_const<BASE + 8 * J + K>(acc, cst, x[K]);
+        if constexpr (K < 7) RowDot8<J, K + 1>::template run<BASE>(acc, cst, x);
+    }
+};
+template <int BASE, int J = 0>
+struct MatRows8 {                // out[j] = init[j] + Σ_k value(BASE + 8 j + k) x[k], j < NJ
+    template <int NJ>
+    __device__ static inline void run(double *out, const double (&cst)[6], const double (&x)[8]) {
+        double acc = out[J];
+        RowDot8<J>::template run<BASE>(acc, cst, x);
+        out[J] = acc;
+        if constexpr (J + 1 < NJ) MatRows8<BASE, J + 1>::template run<NJ>(out, cst, x);
+    }
+};
+// log-likelihood of the first `steps` observations from the running sums (one expression, never contracted: the value at the old
+// vintage's last period must be bit for bit what a separate pass over that prefix returns)
+__device__ inline double kalman_quad_value(long long steps, double detm, int dete, double quad_acc) {
+#pragma clang fp contract(off)
+    const double ln2 = 0.693147180559945309417232121458;
+    const double a = -1.5 * (double)steps * LOG2PI;
+    const double b = log(detm) + (double)dete * ln2;
+    return (a + b) - 0.5 * quad_acc;
+}
+__device__ __forceinline__ static KalmanLL kalman_lgss_quad(const double *thv, const double *ydat, long long nt, long long nt_mid, const double *aux,
+                                                                     lds_bytes xslot, int q) {
+SMCMI_FP_CONTRACT
+    using cdp = const double __attribute__((address_space(4))) *;
+    auto uniform_ptr = [](const double *p) -> cdp {
+        const unsigned long long a = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (cdp)(((unsigned long long)hi << 32) | lo);
+    };
+    const cdp yd = uniform_ptr(ydat);
+    const double *RRg = aux + KALMAN_AUX_RR, *kCg = aux + KALMAN_AUX_KC, *Zg = aux + 88;
+    nt = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
+                     __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
+    nt_mid = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt_mid >> 32)) << 32) |
+                         __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt_mid));
+    const int r0 = 2 * q, l16 = (int)(threadIdx.x & 15);
+    double cst[6];               // structure values 0..63 = κC (row-major), 64..87 = Z (row-major); lane c % 16 of register c / 16
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cst[g] = kCg[16 * g + l16];
+    cst[4] = Zg[l16];
+    cst[5] = Zg[16 + (l16 & 7)];
+    double rho[8], s2[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rho[i] = thv[i];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) s2[m] = thv[8 + m] * thv[8 + m];
+    const double se2 = thv[11] * thv[11], mu = thv[12];
+    double P[2][8], Qt[2][8], kr[2][8], zc[3][2], rho_own[2], x_own[2], xg[8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int i = r0 + s;
+        rho_own[s] = thv[i];
+        x_own[s] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = ksym(i, j);
+            Qt[s][j] = RRg[p * 3 + 0] * s2[0] + RRg[p * 3 + 1] * s2[1] + RRg[p * 3 + 2] * s2[2];
+            kr[s][j] = kCg[i * 8 + j];
+            P[s][j] = (i == j) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) zc[a][s] = Zg[a * 8 + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xg[j] = 0.0;
+    const lds_v2f64 wrow[2] = {(lds_v2f64)(xslot + q * 144), (lds_v2f64)(xslot + q * 144 + 64)};
+    const lds_bytes rcol = xslot + q * 16;
+    double quad_acc = 0.0, detm = 1.0;
+    int dete = 0;
+    bool bad = false;
+    double ll_mid = SMCMI_NEG_INF;
+    asm volatile("s_nop 4");     // (the loads above and the first DPP read of cst are far apart anyway)
+#pragma nounroll
+    for (long long t = 0; t < nt; ++t) {
+        double xp[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            double v = rho_own[s] * x_own[s];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += kr[s][j] * xg[j];
+            xp[s] = v;
+        }
+        // W = P Tm' (own rows) -> LDS
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            double w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = rho[j] * P[s][j];
+            MatRows8<0>::run<8>(w, cst, P[s]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v2f64 pr; pr.x = w[2 * c]; pr.y = w[2 * c + 1]; wrow[s][c] = pr; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double TP[2][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const v2f64 pr = *(lds_v2f64)(rcol + (k >> 1) * 144 + (k & 1) * 64);
+            TP[0][k] = pr.x; TP[1][k] = pr.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double Pn[2][8], PZ[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Pn[s][j] = Qt[s][j] + TP[s][j] * rho[j];
+            MatRows8<0>::run<8>(Pn[s], cst, TP[s]);
+            PZ[s][0] = PZ[s][1] = PZ[s][2] = 0.0;
+            MatRows8<64>::run<3>(PZ[s], cst, Pn[s]);
+        }
+        // nine two-row partial sums, totalled over the quad together (a DPP move must not follow the write of its source directly:
+        // batching the nine values keeps the hazard's wait states filled with the other eight)
+        double red[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            red[a] = zc[a][0] * xp[0] + zc[a][1] * xp[1];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) red[3 + a * (a + 1) / 2 + b] = zc[a][0] * PZ[0][b] + zc[a][1] * PZ[1][b];
+        }
+        {
+            double m[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m[i] = quad_perm_f64<0xB1>(red[i]);          // [1,0,3,2]
+#pragma unroll
+            for (int i = 0; i < 9; ++i) red[i] += m[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m[i] = quad_perm_f64<0x4E>(red[i]);          // [2,3,0,1]
+#pragma unroll
+            for (int i = 0; i < 9; ++i) red[i] += m[i];
+        }
+        double zx[3], F[6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            zx[a] = red[a];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) F[a * (a + 1) / 2 + b] = red[3 + a * (a + 1) / 2 + b] + ((a == b) ? se2 : 0.0);
+        }
+        const double v0 = yd[0 + 3 * t] - mu - zx[0], v1 = yd[1 + 3 * t] - mu - zx[1], v2 = yd[2 + 3 * t] - mu - zx[2];
+        bad = bad || !(F[0] > 0.0);
+        const double i00 = rsqrt_nr(F[0]), l10 = F[1] * i00, l20 = F[3] * i00;
+        const double p11 = F[2] - l10 * l10;
+        bad = bad || !(p11 > 0.0);
+        const double i11 = rsqrt_nr(p11), l21 = (F[4] - l20 * l10) * i11;
+        const double p22 = F[5] - l20 * l20 - l21 * l21;
+        bad = bad || !(p22 > 0.0);
+        const double i22 = rsqrt_nr(p22);
+        const double w0 = v0 * i00, w1 = (v1 - l10 * w0) * i11, w2 = (v2 - l20 * w0 - l21 * w1) * i22;
+        quad_acc += w0 * w0 + w1 * w1 + w2 * w2;
+        detm *= (i00 * i11) * i22;                                  // 1 / (l00 l11 l22)
+        dete += __builtin_amdgcn_frexp_exp(detm);
+        detm = __builtin_amdgcn_frexp_mant(detm);
+        if (t + 1 == nt_mid)                                         // (wave-uniform)
+            ll_mid = bad ? SMCMI_NEG_INF : kalman_quad_value(t + 1, detm, dete, quad_acc);
+        const double u2 = w2 * i22, u1 = (w1 - l21 * u2) * i11, u0 = (w0 - l10 * u1 - l20 * u2) * i00;
+        double g[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            x_own[s] = xp[s] + (PZ[s][0] * u0 + PZ[s][1] * u1 + PZ[s][2] * u2);
+            g[s][0] = PZ[s][0] * i00;
+            g[s][1] = (PZ[s][1] - l10 * g[s][0]) * i11;
+            g[s][2] = (PZ[s][2] - l20 * g[s][0] - l21 * g[s][1]) * i22;
+        }
+        // rows (G[j][0..2], x[j]) of all eight states: quad broadcasts.  (Through LDS - 4 writes + 16 reads, no VALU slot - was measured:
+        // 231 µs against 210 µs per mutation at one wavefront per SIMD, the extra round trip costs more than the 64 DPP moves.)
+        double G[8][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            xg[0 + s] = quad_perm_f64<0x00>(x_own[s]); xg[2 + s] = quad_perm_f64<0x55>(x_own[s]);
+            xg[4 + s] = quad_perm_f64<0xAA>(x_own[s]); xg[6 + s] = quad_perm_f64<0xFF>(x_own[s]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                G[0 + s][a] = quad_perm_f64<0x00>(g[s][a]); G[2 + s][a] = quad_perm_f64<0x55>(g[s][a]);
+                G[4 + s][a] = quad_perm_f64<0xAA>(g[s][a]); G[6 + s][a] = quad_perm_f64<0xFF>(g[s][a]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) P[s][j] = Pn[s][j] - (g[s][0] * G[j][0] + g[s][1] * G[j][1] + g[s][2] * G[j][2]);
+    }
+    const double ll = bad ? SMCMI_NEG_INF : kalman_quad_value(nt, detm, dete, quad_acc);
+    return KalmanLL{ll, ll_mid};
+}
+
 template <class L, class Th>
 __device__ inline double loglik(const L &l, int d, Th th) {
     switch (l.family) {

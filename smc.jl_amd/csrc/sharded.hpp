@@ -393,7 +393,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     if (g.world > MAX_SHARDS) return set_err(SMCMI_ERR_ARG, "too many shards");
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        const int nb0 = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
+        const int nb0 = mut_blocks(h);
         k_energy_max<<<nb0, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
         k_emax_publish<<<1, TB, 0, h->stream>>>(h->d_emax_part, nb0, h->d_tot_acc + ES, shard_rank(h), g.world);
     }

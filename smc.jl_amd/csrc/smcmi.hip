@@ -140,6 +140,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         if (h->mut_lds <= 64 * 1024) break;
     }
     h->nb_mut = (int)((n + h->mut_T - 1) / h->mut_T);
+    h->nb_mut_ls4 = (int)((n + 63) / 64);              // lane-split mutation (lgss_kalman): 64 particles per 256-thread block
     // register-resident variant: only θ lives in per-thread LDS columns
     h->reg_T = 256;
     h->nb_reg = (int)((n + h->reg_T - 1) / h->reg_T);
@@ -149,7 +150,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) || dmalloc(&h->d_wt, n) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
-        dmalloc(&h->d_acc_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_esum_part, (size_t)std::max(h->nb_mut, h->nb_reg) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * (ES + 1)) || dmalloc(&h->d_emax_part, std::max(h->nb_mut, h->nb_reg)) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
+        dmalloc(&h->d_acc_part, std::max({h->nb_mut, h->nb_reg, h->nb_mut_ls4})) || dmalloc(&h->d_esum_part, (size_t)std::max({h->nb_mut, h->nb_reg, h->nb_mut_ls4}) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * (ES + 1)) || dmalloc(&h->d_emax_part, std::max({h->nb_mut, h->nb_reg, h->nb_mut_ls4})) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4) || dmalloc(&h->d_mix, (size_t)10 * (3 * 100 + 22)) || dmalloc(&h->d_mixpos, 100))
         return SMCMI_ERR_HIP;
     if (h->cfg.store_history) {
@@ -171,6 +172,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     HIP_TRY(hipFuncSetAttribute((const void *)k_moments, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mom_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_prepare_mutation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->prep_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * mutate_wave_bytes_ls4(13) + 64 + sizeof(MutStage))));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
     HIP_TRY(hipFuncSetAttribute((const void *)k_mutate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mut_lds));
     if (set_mutate_attrs(h)) return SMCMI_ERR_HIP;
@@ -375,9 +377,13 @@ extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
 }
 
 static int callback_fill_loglh(smcmi_handle *h, int which, int column);
+static bool use_ls4_mutate(const smcmi_handle *h);
 extern "C" int smcmi_initialize_likelihoods(smcmi_handle *h) {
     if (int rc = need_model(h, 2)) return rc;
-    k_initialize_likelihoods<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model);
+    if (use_ls4_mutate(h) && !h->cb[0])
+        k_initialize_likelihoods_ls4<<<(unsigned)((h->n + 63) / 64), 256, 64 * KALMAN4_SLOT_BYTES, h->stream>>>(h->cl, h->d_model);
+    else
+        k_initialize_likelihoods<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model);
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cb[0]) return callback_fill_loglh(h, 0, h->d);            // host likelihood: the kernel retired loglh and evaluated the prior
     return 0;
@@ -707,6 +713,17 @@ static void launch_reg(smcmi_handle *h, const MutArgs &ma, int standalone) {
 }
 static int set_mutate_attrs(smcmi_handle *) { return 0; }   // the register kernel needs < 64 KiB of dynamic LDS
 static bool use_reg_mutate(const smcmi_handle *h) { return h->d <= 10; }
+// lgss_kalman on both vintages (or no old vintage) and at most 32 768 particles on the handle: four lanes per particle (kernels.hpp
+// k_mutate<0, 4>) - up to two of its wavefronts per SIMD; beyond that one thread per particle (fewer instructions per particle) is
+// faster (measured: §6 of DESIGN.md).  SMCMI_KALMAN_LANES=1 / 4 forces one or the other (development / comparison).
+static bool use_ls4_mutate(const smcmi_handle *h) {
+    static const int lanes = getenv("SMCMI_KALMAN_LANES") ? atoi(getenv("SMCMI_KALMAN_LANES")) : 0;
+    const int f0 = h->h_model.lik[0].family, f1 = h->h_model.lik[1].family;
+    if (!(h->d == 13 && f0 == SMCMI_LIK_LGSS_KALMAN && (f1 == SMCMI_LIK_NONE || f1 == SMCMI_LIK_LGSS_KALMAN))) return false;
+    return lanes == 4 || (lanes != 1 && h->n <= 32768);
+}
+// blocks (= rows of acceptance / energy partials) of the in-run mutation kernel
+static int mut_blocks(const smcmi_handle *h) { return use_reg_mutate(h) ? h->nb_reg : (use_ls4_mutate(h) ? h->nb_mut_ls4 : h->nb_mut); }
 // returns the number of blocks launched (= acceptance partials written)
 static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double alpha) {
     h->launch_nb = n_blocks;
@@ -735,6 +752,11 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     case 9: launch_reg<9>(h, ma, standalone); break;
     case 10: launch_reg<10>(h, ma, standalone); break;
     default:
+        if (use_ls4_mutate(h)) {
+            k_mutate<0, 4><<<h->nb_mut_ls4, 256, 4 * mutate_wave_bytes_ls4(13) + 64 + sizeof(MutStage), h->stream>>>(h->cl, h->d_st, h->d_model, ma,
+                                                                                                             h->d_acc_part, standalone);
+            return h->nb_mut_ls4;
+        }
         k_mutate<0><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, standalone);
         return h->nb_mut;
     }
@@ -994,7 +1016,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
-    const int acc_nb = use_reg_mutate(h) ? h->nb_reg : h->nb_mut;
+    const int acc_nb = mut_blocks(h);
     // largest energy of the initial cloud, in the layout the mutation epilogue uses afterwards (stage 1's energy shift)
     k_energy_max<<<acc_nb, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
     const bool profile = rc->use_graph == 2;    // 2 = direct launches with HIP events around the mutation kernel
@@ -1446,7 +1468,7 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
         case 7: k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->npairs, h->d_totals, 1); break;
         case 8: k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->cfg.seed, 1, 1, 0, h->d_prof); break;
         case 9: launch_mutate(h, 1, 0, 1.0); break;
-        case 10: k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, use_reg_mutate(h) ? h->nb_reg : h->nb_mut, h->rec); break;
+        case 10: k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, mut_blocks(h), h->rec); break;
         default: k_empty<<<1, 64, 0, h->stream>>>(h->d_st); break;
         }
         if (which == 10 || which == 3) { /* keep the stage counter / weights bounded */ }

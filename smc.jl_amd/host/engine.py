@@ -355,10 +355,13 @@ class Engine:
         return out
 
     def stage_records(self, n_stages):
-        phi, ess, c, acc = (np.empty(n_stages) for _ in range(4))
-        rs = np.empty(n_stages, dtype=np.int32)
+        # the library copies as many records as the last run produced (at most max_stages), whatever the caller expects
+        cap = max(int(n_stages), self.max_stages)
+        phi, ess, c, acc = (np.zeros(cap) for _ in range(4))
+        rs = np.zeros(cap, dtype=np.int32)
         check(self._L.smcmi_get_stage_records(self._h, _d(phi), _d(ess), _d(c), _d(acc), _i(rs)))
-        return dict(schedule=phi, ess=ess, c_hist=c, accept_hist=acc, resampled=rs)
+        k = int(n_stages)
+        return dict(schedule=phi[:k].copy(), ess=ess[:k].copy(), c_hist=c[:k].copy(), accept_hist=acc[:k].copy(), resampled=rs[:k].copy())
 
     def history(self, n_stages):
         w, W = np.empty((self.n, n_stages), order="F"), np.empty((self.n, n_stages), order="F")

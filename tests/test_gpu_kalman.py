@@ -145,3 +145,48 @@ def test_old_data_prefix_takes_one_filter_pass_with_identical_bits(shift):
         out.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
     assert out[0] == out[1]
     assert out[0]["n_stages"] > 5
+
+
+_LANES_WORKER = r'''
+import sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+from smc_jl_amd import Engine
+from tests import models
+old = Engine(%(n)d, 13, seed=17, max_stages=400, store_history=False)
+old.set_model(models.kalman_spec(T=40)); old.init_from_prior()
+r0 = old.run(n_phi=60, use_fixed_schedule=False, tempering_target=0.9, n_blocks=%(nb)d, alpha=0.9)
+ess0 = float(old.stage_records(r0["n_stages"])["ess"][-1])
+old.set_model(models.kalman_spec(T=80, old_T=40))          # tempered update from the old posterior (smc_main.jl:249-260)
+old.initialize_likelihoods()
+r = old.run(n_phi=60, use_fixed_schedule=False, tempering_target=0.9, n_blocks=%(nb)d, alpha=0.9, initial_ess=ess0)
+np.save(%(out)r, old.download_cloud())
+print("RESULT " + json.dumps(dict(n_stages=r["n_stages"], resamples=r["resamples"], logmdd=r["logmdd"], old_stages=r0["n_stages"])))
+'''
+
+
+@pytest.mark.parametrize("n,nb", [(4000, 1), (12500, 3)])
+def test_four_lanes_per_particle_match_one_thread_per_particle(n, nb, tmp_path):
+    """The lane-split Kalman mutation (csrc/model.hpp kalman_lgss_quad: four lanes per particle, the default up to 32 768 particles per
+    handle) against one thread per particle (SMCMI_KALMAN_LANES=1) on a whole estimation + tempered update: the filters differ in
+    summation order only (1e-13), so stage counts agree and the clouds to 1e-9 (a flipped MH decision would show as an O(1) row
+    difference; up to 0.1 % of the rows may)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res, clouds = [], []
+    for lanes in ("4", "1"):
+        out = str(tmp_path / ("cloud_%s.npy" % lanes))
+        p = subprocess.run([sys.executable, "-c", _LANES_WORKER % dict(root=root, n=n, nb=nb, out=out)], env=dict(os.environ, SMCMI_KALMAN_LANES=lanes),
+                           capture_output=True, text=True, timeout=900, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
+        clouds.append(np.load(out))
+    assert res[0]["n_stages"] == res[1]["n_stages"] and res[0]["resamples"] == res[1]["resamples"] and res[0]["old_stages"] == res[1]["old_stages"]
+    assert res[0]["n_stages"] > 5
+    assert res[0]["logmdd"] == pytest.approx(res[1]["logmdd"], abs=1e-8)
+    same = np.all(np.abs(clouds[0] - clouds[1]) <= 1e-9 * (1 + np.abs(clouds[1])), axis=1)
+    assert same.mean() > 0.999
