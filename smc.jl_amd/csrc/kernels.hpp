@@ -1960,6 +1960,11 @@ __global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState 
         load_columns(cl.buf[src], cl.n, i, d, th + tid, T);
         for (int k = 0; k < d; ++k) tn[k * T + tid] = th[k * T + tid];
     }
+    // lgss_kalman on both vintages with one thread per particle: the filter whose structure values travel through DPP operands
+    // (model.hpp kalman_lgss_wave) - called by every lane, like the lane-split one.  SMCMI_KALMAN_WAVE=0 (host: ma.debug bit 8) keeps
+    // kalman_lgss2 under the particle's own branch (development / comparison).
+    const bool kalman_wave = LS == 1 && MODE == 0 && d == 13 && !(ma.debug & 256) && md->lik[0].family == SMCMI_LIK_LGSS_KALMAN &&
+                             (md->lik[1].family == SMCMI_LIK_NONE || md->lik[1].family == SMCMI_LIK_LGSS_KALMAN);
     auto TN = [&](int k) { return tn[k * T + tid]; };
     // (the loops are uniform and `live` is tested inside them: the lane-split filter needs every lane of the wavefront)
     {
@@ -2072,21 +2077,27 @@ __global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState 
                     }
                 }
                 if (MODE == 1) continue;
-                if (MODE == 0 && LS == 4) {
-                    // every lane calls the filter (its structure values travel through DPP operands); quads without a proposal inside
-                    // the bounds run it on the particle's current θ and drop the result
+                if (MODE == 0 && (LS == 4 || kalman_wave)) {
+                    // every lane calls the filter (its structure values travel through DPP operands); lanes without a proposal inside
+                    // the bounds run it on the particle's current θ, lanes without a particle on ρ = 0, σ = 0.5, and drop the result
                     double thv[13];
-                    for (int k = 0; k < 13; ++k) thv[k] = (live && inb) ? TN(k) : (live ? th[k * T + tid] : 0.5);
+                    for (int k = 0; k < 13; ++k) thv[k] = (live && inb) ? TN(k) : (live ? th[k * T + tid] : (k < 8 ? 0.0 : (k < 12 ? 0.5 : 0.0)));
                     const lds_bytes slot = (lds_bytes)(y) + tid * KALMAN4_SLOT_BYTES;
-                    // (the draw in y is dead from here on: θ' holds it at the block's positions)
-                    // (inlined - one register allocation with the kernel, nothing saved around a call - hence ONE call site: the second
-                    // trip is the old vintage when it is not a prefix of the data)
+                    // (LS = 4: the draw in y is dead from here on - θ' holds it at the block's positions.  The quad filter is inlined - one
+                    // register allocation with the kernel, nothing saved around a call - hence ONE call site: the second trip is the old
+                    // vintage when it is not a prefix of the data)
                     const int n_pass = (md->lik_prefix > 0 || md->lik[1].family == SMCMI_LIK_NONE) ? 1 : 2;      // (uniform)
                     double r_new = 0.0, r_old = 0.0;
 #pragma nounroll
                     for (int pass = 0; pass < n_pass; ++pass) {
                         const LikDev &lk = md->lik[pass];
-                        const KalmanLL r = kalman_lgss_quad(thv, lk.data, lk.cols, pass == 0 ? md->lik_prefix : 0, lk.aux, slot, quad_lane);
+                        KalmanLL r;
+                        if constexpr (LS == 4) r = kalman_lgss_quad(thv, lk.data, lk.cols, pass == 0 ? md->lik_prefix : 0, lk.aux, slot, quad_lane);
+                        else {
+                            KalmanTheta kt;
+                            for (int k = 0; k < 13; ++k) kt.v[k] = thv[k];
+                            r = kalman_lgss_wave(kt, lk.data, lk.cols, pass == 0 ? md->lik_prefix : 0, lk.aux);
+                        }
                         if (pass == 0) { r_new = r.ll; if (md->lik_prefix > 0) r_old = r.ll_mid; }
                         else r_old = r.ll;
                     }
@@ -2732,12 +2743,31 @@ static __global__ void __launch_bounds__(256, 1) k_initialize_likelihoods_ls4(Cl
     const long long i = (long long)blockIdx.x * 64 + slot_i;
     const bool live = i < cl.n;
     double thl[13];
-    for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : 0.5;
+    for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : (k >= 8 && k < 12 ? 0.5 : 0.0);
     auto TH = [&](int k) { return thl[k]; };
     const bool inb = live && in_bounds(*md, TH);
     // (every lane runs the filter: its structure values travel through DPP operands)
     const KalmanLL r = kalman_lgss_quad(thl, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux, (lds_bytes)sm + slot_i * KALMAN4_SLOT_BYTES, q);
     if (live && q == 0) {
+        col(cl, 0, 13 + 2)[i] = col(cl, 0, 13)[i];
+        col(cl, 0, 13)[i] = inb ? r.ll : SMCMI_NEG_INF;
+        col(cl, 0, 13 + 1)[i] = inb ? logprior(*md, TH) : SMCMI_NEG_INF;
+    }
+}
+
+// ... and with one thread per particle through the filter whose structure values travel through DPP operands (kalman_lgss_wave):
+// whole wavefronts call it, lanes without a particle on ρ = 0, σ = 0.5
+static __global__ void __launch_bounds__(TB) k_initialize_likelihoods_wave(CloudPtrs cl, const ModelDev *md) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    const bool live = i < cl.n;
+    double thl[13];
+    for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : (k >= 8 && k < 12 ? 0.5 : 0.0);
+    auto TH = [&](int k) { return thl[k]; };
+    const bool inb = live && in_bounds(*md, TH);
+    KalmanTheta kt;
+    for (int k = 0; k < 13; ++k) kt.v[k] = thl[k];
+    const KalmanLL r = kalman_lgss_wave(kt, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux);
+    if (live) {
         col(cl, 0, 13 + 2)[i] = col(cl, 0, 13)[i];
         col(cl, 0, 13)[i] = inb ? r.ll : SMCMI_NEG_INF;
         col(cl, 0, 13 + 1)[i] = inb ? logprior(*md, TH) : SMCMI_NEG_INF;

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #include "devstate.hpp"
 
@@ -164,10 +165,10 @@ SMCMI_FP_CONTRACT
         return (cdp)(((unsigned long long)hi << 32) | lo);
     };
     const cdp Zm = uniform_ptr(aux + 88), kC = uniform_ptr(aux + KALMAN_AUX_KC), RR = uniform_ptr(aux + KALMAN_AUX_RR), yd = uniform_ptr(ydat);
-    nt = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
-                     __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
-    nt_mid = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt_mid >> 32)) << 32) |
-                         __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt_mid));
+    nt = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
+                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
+    nt_mid = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt_mid >> 32)) << 32) |
+                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt_mid));
     (void)kappa;
     double rho[8], s2[3];
 #pragma unroll
@@ -319,36 +320,41 @@ __device__ inline double rsqrt_nr(double a) {
     return y;
 }
 // acc += (structure value C) * x, the value taken from lane C % 16 of this lane's row of cst[C / 16]
-template <int C>
-__device__ inline void fmac_row_const(double &acc, const double (&cst)[6], double x) {
+template <int C, int NC>
+__device__ inline void fmac_row_const(double &acc, const double (&cst)[NC], double x) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cst[C / 16]), "v"(x), "n"(C % 16));
 }
 template <int J, int K = 0>
-struct RowDot8 {                 // acc += Σ_k (structure value BASE + 8 J + k) * x[k]
-    template <int BASE>
+struct RowDot8 {                 // acc += Σ_k (structure value BASE + 8 J + k) * x[k]   (SKIPD: without k = J)
+    template <int BASE, bool SKIPD>
     __device__ static inline void run(double &acc, const double (&cst)[6], const double (&x)[8]) {
-        fmac_row_const<BASE + 8 * J + K>(acc, cst, x[K]);
-        if constexpr (K < 7) RowDot8<J, K + 1>::template run<BASE>(acc, cst, x);
+        if constexpr (!(SKIPD && K == J)) fmac_row_const<BASE + 8 * J + K>(acc, cst, x[K]);
+        if constexpr (K < 7) RowDot8<J, K + 1>::template run<BASE, SKIPD>(acc, cst, x);
     }
 };
 template <int BASE, int J = 0>
 struct MatRows8 {                // out[j] = init[j] + Σ_k value(BASE + 8 j + k) x[k], j < NJ
-    template <int NJ>
+    template <int NJ, bool SKIPD = false>
     __device__ static inline void run(double *out, const double (&cst)[6], const double (&x)[8]) {
         double acc = out[J];
-        RowDot8<J>::template run<BASE>(acc, cst, x);
+        RowDot8<J>::template run<BASE, SKIPD>(acc, cst, x);
         out[J] = acc;
-        if constexpr (J + 1 < NJ) MatRows8<BASE, J + 1>::template run<NJ>(out, cst, x);
+        if constexpr (J + 1 < NJ) MatRows8<BASE, J + 1>::template run<NJ, SKIPD>(out, cst, x);
     }
 };
 // log-likelihood of the first `steps` observations from the running sums (one expression, never contracted: the value at the old
 // vintage's last period must be bit for bit what a separate pass over that prefix returns)
-__device__ inline double kalman_quad_value(long long steps, double detm, int dete, double quad_acc) {
+__device__ inline double kalman_quad_value(long long steps, double detm, int dete, double quad_acc, bool bad) {
 #pragma clang fp contract(off)
+    // A filter that lost positive definiteness keeps running on NaN / Inf (its lanes cannot leave the wavefront's lockstep).  None of
+    // that may reach log(): its argument is clamped into the range a live filter's mantissa has (fmax / fmin drop a NaN) - no branch
+    // around the call (a divergent region inside the filter loop next to the DPP operands was measured to end in memory faults).
     const double ln2 = 0.693147180559945309417232121458;
+    const double dm = fmin(fmax(detm, 0.25), 1.0);
     const double a = -1.5 * (double)steps * LOG2PI;
-    const double b = log(detm) + (double)dete * ln2;
-    return (a + b) - 0.5 * quad_acc;
+    const double b = log(dm) + (double)dete * ln2;
+    const double v = (a + b) - 0.5 * quad_acc;
+    return (bad || !(detm >= 0.25) || !(detm <= 1.0)) ? SMCMI_NEG_INF : v;
 }
 __device__ __forceinline__ static KalmanLL kalman_lgss_quad(const double *thv, const double *ydat, long long nt, long long nt_mid, const double *aux,
                                                                      lds_bytes xslot, int q) {
@@ -361,33 +367,32 @@ SMCMI_FP_CONTRACT
     };
     const cdp yd = uniform_ptr(ydat);
     const double *RRg = aux + KALMAN_AUX_RR, *kCg = aux + KALMAN_AUX_KC, *Zg = aux + 88;
-    nt = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
-                     __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
-    nt_mid = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt_mid >> 32)) << 32) |
-                         __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt_mid));
+    nt = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt >> 32)) << 32) |
+                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt));
+    nt_mid = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)nt_mid >> 32)) << 32) |
+                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)nt_mid));
     const int r0 = 2 * q, l16 = (int)(threadIdx.x & 15);
     double cst[6];               // structure values 0..63 = κC (row-major), 64..87 = Z (row-major); lane c % 16 of register c / 16
 #pragma unroll
     for (int g = 0; g < 4; ++g) cst[g] = kCg[16 * g + l16];
     cst[4] = Zg[l16];
     cst[5] = Zg[16 + (l16 & 7)];
-    double rho[8], s2[3];
+    double dT[8], s2[3];          // dT: diagonal of Tm = ρ_j + κC[j][j] (one operand instead of a product and an FMA per use)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rho[i] = thv[i];
+    for (int i = 0; i < 8; ++i) dT[i] = thv[i] + kCg[9 * i];
 #pragma unroll
     for (int m = 0; m < 3; ++m) s2[m] = thv[8 + m] * thv[8 + m];
     const double se2 = thv[11] * thv[11], mu = thv[12];
-    double P[2][8], Qt[2][8], kr[2][8], zc[3][2], rho_own[2], x_own[2], xg[8];
+    double P[2][8], Qt[2][8], kr[2][8], zc[3][2], x_own[2], xg[8];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int i = r0 + s;
-        rho_own[s] = thv[i];
         x_own[s] = 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = ksym(i, j);
             Qt[s][j] = RRg[p * 3 + 0] * s2[0] + RRg[p * 3 + 1] * s2[1] + RRg[p * 3 + 2] * s2[2];
-            kr[s][j] = kCg[i * 8 + j];
+            kr[s][j] = (i == j) ? dT[j] : kCg[i * 8 + j];               // own rows of Tm = κC + diag ρ
             P[s][j] = (i == j) ? 1.0 : 0.0;
         }
 #pragma unroll
@@ -397,9 +402,9 @@ SMCMI_FP_CONTRACT
     for (int j = 0; j < 8; ++j) xg[j] = 0.0;
     const lds_v2f64 wrow[2] = {(lds_v2f64)(xslot + q * 144), (lds_v2f64)(xslot + q * 144 + 64)};
     const lds_bytes rcol = xslot + q * 16;
-    double quad_acc = 0.0, detm = 1.0;
-    int dete = 0;
-    bool bad = false;
+    double quad_acc = 0.0, detm = 1.0, mid_detm = 1.0, mid_quad = 0.0;
+    int dete = 0, mid_dete = 0;
+    bool bad = false, mid_bad = true;
     double ll_mid = SMCMI_NEG_INF;
     asm volatile("s_nop 4");     // (the loads above and the first DPP read of cst are far apart anyway)
 #pragma nounroll
@@ -407,9 +412,9 @@ SMCMI_FP_CONTRACT
         double xp[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            double v = rho_own[s] * x_own[s];
+            double v = kr[s][0] * xg[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v += kr[s][j] * xg[j];
+            for (int j = 1; j < 8; ++j) v += kr[s][j] * xg[j];
             xp[s] = v;
         }
         // W = P Tm' (own rows) -> LDS
@@ -417,8 +422,8 @@ SMCMI_FP_CONTRACT
         for (int s = 0; s < 2; ++s) {
             double w[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = rho[j] * P[s][j];
-            MatRows8<0>::run<8>(w, cst, P[s]);
+            for (int j = 0; j < 8; ++j) w[j] = dT[j] * P[s][j];
+            MatRows8<0>::run<8, true>(w, cst, P[s]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { v2f64 pr; pr.x = w[2 * c]; pr.y = w[2 * c + 1]; wrow[s][c] = pr; }
         }
@@ -438,8 +443,8 @@ SMCMI_FP_CONTRACT
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Pn[s][j] = Qt[s][j] + TP[s][j] * rho[j];
-            MatRows8<0>::run<8>(Pn[s], cst, TP[s]);
+            for (int j = 0; j < 8; ++j) Pn[s][j] = Qt[s][j] + TP[s][j] * dT[j];
+            MatRows8<0>::run<8, true>(Pn[s], cst, TP[s]);
             PZ[s][0] = PZ[s][1] = PZ[s][2] = 0.0;
             MatRows8<64>::run<3>(PZ[s], cst, Pn[s]);
         }
@@ -484,8 +489,7 @@ SMCMI_FP_CONTRACT
         detm *= (i00 * i11) * i22;                                  // 1 / (l00 l11 l22)
         dete += __builtin_amdgcn_frexp_exp(detm);
         detm = __builtin_amdgcn_frexp_mant(detm);
-        if (t + 1 == nt_mid)                                         // (wave-uniform)
-            ll_mid = bad ? SMCMI_NEG_INF : kalman_quad_value(t + 1, detm, dete, quad_acc);
+        if (t + 1 == nt_mid) { mid_detm = detm; mid_dete = dete; mid_quad = quad_acc; mid_bad = bad; }      // (wave-uniform; evaluated after the loop)
         const double u2 = w2 * i22, u1 = (w1 - l21 * u2) * i11, u0 = (w0 - l10 * u1 - l20 * u2) * i00;
         double g[2][3];
 #pragma unroll
@@ -511,9 +515,201 @@ SMCMI_FP_CONTRACT
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) P[s][j] = Pn[s][j] - (g[s][0] * G[j][0] + g[s][1] * G[j][1] + g[s][2] * G[j][2]);
+            for (int j = 0; j < 8; ++j) {
+                double v = Pn[s][j];
+                v -= g[s][0] * G[j][0]; v -= g[s][1] * G[j][1]; v -= g[s][2] * G[j][2];
+                P[s][j] = v;
+            }
     }
-    const double ll = bad ? SMCMI_NEG_INF : kalman_quad_value(nt, detm, dete, quad_acc);
+    const double ll = kalman_quad_value(nt, detm, dete, quad_acc, bad);
+    if (nt_mid > 0 && nt_mid <= nt) ll_mid = kalman_quad_value(nt_mid, mid_detm, mid_dete, mid_quad, mid_bad);      // (wave-uniform)
+    return KalmanLL{ll, ll_mid};
+}
+
+// ---- one thread per particle again, for clouds too large for the lane-split form - but with what the lane-split filter taught:
+// the 196 wave-uniform structure values (Z, κC, Rm Rm') sit in THIRTEEN vector registers (value c in lane c mod 16 of every 16-lane
+// row of register c / 16) and reach the FMAs through their DPP operand - kalman_lgss2 keeps them as scalar operands, which do not fit
+// the SGPR file: the compiler parks them in VGPR lanes and pays ~400 v_readlane per step (17 % of its instructions); the 3x3
+// factorisation uses reciprocal square roots (no sqrt, no division), the determinant a running product (one log per evaluation).
+// ALL 64 LANES MUST CALL THIS TOGETHER (a DPP source lane must be active): the mutation kernel does (lanes without a proposal pass any
+// finite θ and drop the result); callers that cannot (initial draw, stand-alone evaluation) keep kalman_lgss2.  Same algorithm,
+// different summation order in places: values agree to ~1e-13.
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(static_cast<F &&>(f));
+    }
+}
+#define SMCMI_CI(name, T) constexpr int name = decltype(T)::value
+struct KalmanTheta { double v[13]; };
+__device__ __attribute__((noinline)) static KalmanLL kalman_lgss_wave(const KalmanTheta th_in, const double *ydat, long long nt, long long nt_mid, const double *aux) {
+SMCMI_FP_CONTRACT
+    using cdp = const double __attribute__((address_space(4))) *;
+    // (readfirstlane returns int: without the casts the low half would be SIGN-extended over the high half - a fault whenever bit 31 of
+    // an address is set)
+    auto uniform_u64 = [](unsigned long long a) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+    };
+    unsigned long long u_yd = uniform_u64((unsigned long long)ydat), u_aux = uniform_u64((unsigned long long)aux);
+    unsigned long long u_nt = uniform_u64((unsigned long long)nt), u_mid = uniform_u64((unsigned long long)nt_mid);
+    double thv[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) thv[k] = th_in.v[k];
+    // THE WHOLE WAVEFRONT RUNS THE FILTER, whatever lanes the caller arrives with: a DPP operand needs its source lane (lanes 0..15 of each
+    // 16-lane row hold the structure values) active, and the callers' control flow around a particle's proposal is not uniform in
+    // general (measured: the mutation kernel reaches this call with only the lanes that own a particle; their results were garbage
+    // whenever the last block of a cloud was partly empty).  EXEC is widened here and restored before the return; lanes that were not
+    // active run on ρ = 0, σ = 0.5, μ = 0 (finite values: nothing of them survives the restore).  Everything per lane that is read
+    // below comes from uniform values and the lane number, never from a register an inactive lane may hold garbage in.
+    // (one statement: the incoming mask is saved, EXEC widened, and the uniform values pass THROUGH it - they are read from the first
+    // lane that was active, so they must exist before the mask changes and everything below must use the copies that come out)
+    unsigned long long exec_in;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, -1" : "=&s"(exec_in), "+s"(u_yd), "+s"(u_aux), "+s"(u_nt), "+s"(u_mid) : : "memory");
+    const cdp yd = (cdp)u_yd;
+    const double *auxu = (const double *)u_aux;
+    nt = (long long)u_nt;
+    nt_mid = (long long)u_mid;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool was_active = (exec_in >> lane) & 1ull;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) thv[k] = was_active ? thv[k] : ((k >= 8 && k < 12) ? 0.5 : 0.0);
+    // structure values as they lie from aux + 88 on: Z (24) | κC (64) | Rm Rm' (36 x 3)
+    constexpr int CZ = 0, CK = 24, CR = 88, NCST = 13;
+    const int l16 = lane & 15;
+    double cst[NCST];
+#pragma unroll
+    for (int g = 0; g < NCST; ++g) { const int c = 16 * g + l16; cst[g] = auxu[88 + (c < 196 ? c : 195)]; }
+    double rho[8], s2[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rho[i] = thv[i];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) s2[m] = thv[8 + m] * thv[8 + m];
+    const double se2 = thv[11] * thv[11], mu = thv[12];
+    double dT[8];                 // diagonal of Tm = ρ_i + κC[i][i]: one operand instead of a product and an FMA per use
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dT[i] = rho[i] + auxu[88 + CK + 9 * i];
+    double P[36], Pn[36], x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = 0.0;
+#pragma unroll
+        for (int j = i; j < 8; ++j) P[ksym(i, j)] = (i == j) ? 1.0 : 0.0;
+    }
+    double quad_acc = 0.0, detm = 1.0, ll_mid = SMCMI_NEG_INF, mid_detm = 1.0, mid_quad = 0.0;
+    int dete = 0, mid_dete = 0;
+    bool bad = false, mid_bad = true;
+    asm volatile("s_nop 4");
+#pragma nounroll
+    for (long long t = 0; t < nt; ++t) {
+        // (the reduction index runs OUTERMOST everywhere: consecutive instructions then feed different accumulators - the scheduler
+        // knows nothing about the latency of the inline-asm FMAs and leaves them in source order)
+        double xp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xp[i] = dT[i] * x[i];
+        static_for<8>([&](auto J) __attribute__((always_inline)) {
+            SMCMI_CI(j, J);
+            static_for<8>([&](auto I) __attribute__((always_inline)) { SMCMI_CI(i, I); if constexpr (i != j) fmac_row_const<CK + 8 * i + j>(xp[i], cst, x[j]); });
+        });
+        // P_{t|t-1} = Tm P Tm' + R Q R', upper triangle, one row of Tm P at a time
+        static_for<8>([&](auto I) __attribute__((always_inline)) {
+            SMCMI_CI(i, I);
+            double tp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tp[j] = dT[i] * P[ksym(i, j)];
+            static_for<8>([&](auto K) __attribute__((always_inline)) {
+                SMCMI_CI(k, K);
+                if constexpr (k != i)
+                    static_for<8>([&](auto J) __attribute__((always_inline)) { SMCMI_CI(j, J); fmac_row_const<CK + 8 * i + k>(tp[j], cst, P[ksym(k, j)]); });
+            });
+            double pn[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pn[j] = tp[j] * dT[j];
+            static_for<3>([&](auto M) __attribute__((always_inline)) {
+                SMCMI_CI(m, M);
+                static_for<8>([&](auto J) __attribute__((always_inline)) {
+                    SMCMI_CI(j, J);
+                    if constexpr (j >= i) fmac_row_const<CR + 3 * ksym(i, j) + m>(pn[j], cst, s2[m]);
+                });
+            });
+            static_for<8>([&](auto K) __attribute__((always_inline)) {
+                SMCMI_CI(k, K);
+                static_for<8>([&](auto J) __attribute__((always_inline)) {
+                    SMCMI_CI(j, J);
+                    if constexpr (j >= i && k != j) fmac_row_const<CK + 8 * j + k>(pn[j], cst, tp[k]);
+                });
+            });
+#pragma unroll
+            for (int j = i; j < 8; ++j) Pn[ksym(i, j)] = pn[j];
+        });
+        double v[3], PZ[24], F[6];
+        {
+            double zx[3] = {0.0, 0.0, 0.0};
+            static_for<8>([&](auto J) __attribute__((always_inline)) {
+                SMCMI_CI(j, J);
+                static_for<3>([&](auto A) __attribute__((always_inline)) { SMCMI_CI(a, A); fmac_row_const<CZ + 8 * a + j>(zx[a], cst, xp[j]); });
+            });
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = yd[a + 3 * t] - mu - zx[a];
+        }
+#pragma unroll
+        for (int e = 0; e < 24; ++e) PZ[e] = 0.0;
+        static_for<8>([&](auto J) __attribute__((always_inline)) {
+            SMCMI_CI(j, J);
+            static_for<8>([&](auto I) __attribute__((always_inline)) {
+                SMCMI_CI(i, I);
+                static_for<3>([&](auto A) __attribute__((always_inline)) { SMCMI_CI(a, A); fmac_row_const<CZ + 8 * a + j>(PZ[i * 3 + a], cst, Pn[ksym(i, j)]); });
+            });
+        });
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 <= a; ++b2) F[a * (a + 1) / 2 + b2] = (a == b2) ? se2 : 0.0;
+        static_for<8>([&](auto I) __attribute__((always_inline)) {
+            SMCMI_CI(i, I);
+            static_for<3>([&](auto A) __attribute__((always_inline)) {
+                SMCMI_CI(a, A);
+                static_for<3>([&](auto B) __attribute__((always_inline)) {
+                    SMCMI_CI(b2, B);
+                    if constexpr (b2 <= a) fmac_row_const<CZ + 8 * a + i>(F[a * (a + 1) / 2 + b2], cst, PZ[i * 3 + b2]);
+                });
+            });
+        });
+        bad = bad || !(F[0] > 0.0);
+        const double i00 = rsqrt_nr(F[0]), l10 = F[1] * i00, l20 = F[3] * i00;
+        const double p11 = F[2] - l10 * l10;
+        bad = bad || !(p11 > 0.0);
+        const double i11 = rsqrt_nr(p11), l21 = (F[4] - l20 * l10) * i11;
+        const double p22 = F[5] - l20 * l20 - l21 * l21;
+        bad = bad || !(p22 > 0.0);
+        const double i22 = rsqrt_nr(p22);
+        const double w0 = v[0] * i00, w1 = (v[1] - l10 * w0) * i11, w2 = (v[2] - l20 * w0 - l21 * w1) * i22;
+        quad_acc += w0 * w0 + w1 * w1 + w2 * w2;
+        detm *= (i00 * i11) * i22;
+        dete += __builtin_amdgcn_frexp_exp(detm);
+        detm = __builtin_amdgcn_frexp_mant(detm);
+        if (t + 1 == nt_mid) { mid_detm = detm; mid_dete = dete; mid_quad = quad_acc; mid_bad = bad; }      // (wave-uniform; evaluated after the loop)
+        const double u2 = w2 * i22, u1 = (w1 - l21 * u2) * i11, u0 = (w0 - l10 * u1 - l20 * u2) * i00;
+        double G[24];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] = xp[i] + (PZ[i * 3 + 0] * u0 + PZ[i * 3 + 1] * u1 + PZ[i * 3 + 2] * u2);
+            const double g0 = PZ[i * 3 + 0] * i00, g1 = (PZ[i * 3 + 1] - l10 * g0) * i11;
+            G[i * 3 + 0] = g0; G[i * 3 + 1] = g1; G[i * 3 + 2] = (PZ[i * 3 + 2] - l20 * g0 - l21 * g1) * i22;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = i; j < 8; ++j) {
+                double s = Pn[ksym(i, j)];
+                s -= G[i * 3 + 0] * G[j * 3 + 0]; s -= G[i * 3 + 1] * G[j * 3 + 1]; s -= G[i * 3 + 2] * G[j * 3 + 2];
+                P[ksym(i, j)] = s;
+            }
+    }
+    const double ll = kalman_quad_value(nt, detm, dete, quad_acc, bad);
+    if (nt_mid > 0 && nt_mid <= nt) ll_mid = kalman_quad_value(nt_mid, mid_detm, mid_dete, mid_quad, mid_bad);      // (wave-uniform)
+    asm volatile("s_mov_b64 exec, %0" : : "s"(exec_in) : "memory");
     return KalmanLL{ll, ll_mid};
 }
 

@@ -378,10 +378,13 @@ extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
 
 static int callback_fill_loglh(smcmi_handle *h, int which, int column);
 static bool use_ls4_mutate(const smcmi_handle *h);
+static bool use_wave_kalman(const smcmi_handle *h);
 extern "C" int smcmi_initialize_likelihoods(smcmi_handle *h) {
     if (int rc = need_model(h, 2)) return rc;
     if (use_ls4_mutate(h) && !h->cb[0])
         k_initialize_likelihoods_ls4<<<(unsigned)((h->n + 63) / 64), 256, 64 * KALMAN4_SLOT_BYTES, h->stream>>>(h->cl, h->d_model);
+    else if (use_wave_kalman(h) && !h->cb[0])
+        k_initialize_likelihoods_wave<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model);
     else
         k_initialize_likelihoods<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_model);
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -722,6 +725,12 @@ static bool use_ls4_mutate(const smcmi_handle *h) {
     if (!(h->d == 13 && f0 == SMCMI_LIK_LGSS_KALMAN && (f1 == SMCMI_LIK_NONE || f1 == SMCMI_LIK_LGSS_KALMAN))) return false;
     return lanes == 4 || (lanes != 1 && h->n <= 32768);
 }
+// the same models on larger clouds: one thread per particle through kalman_lgss_wave (SMCMI_KALMAN_WAVE=0: kalman_lgss2, development)
+static bool use_wave_kalman(const smcmi_handle *h) {
+    static const int kwave = getenv("SMCMI_KALMAN_WAVE") ? atoi(getenv("SMCMI_KALMAN_WAVE")) : 1;
+    const int f0 = h->h_model.lik[0].family, f1 = h->h_model.lik[1].family;
+    return kwave && !use_ls4_mutate(h) && h->d == 13 && f0 == SMCMI_LIK_LGSS_KALMAN && (f1 == SMCMI_LIK_NONE || f1 == SMCMI_LIK_LGSS_KALMAN);
+}
 // blocks (= rows of acceptance / energy partials) of the in-run mutation kernel
 static int mut_blocks(const smcmi_handle *h) { return use_reg_mutate(h) ? h->nb_reg : (use_ls4_mutate(h) ? h->nb_mut_ls4 : h->nb_mut); }
 // returns the number of blocks launched (= acceptance partials written)
@@ -731,7 +740,8 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     MutArgs ma{};
     ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
     static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
-    ma.debug = dbg;
+    static const int kwave = getenv("SMCMI_KALMAN_WAVE") ? atoi(getenv("SMCMI_KALMAN_WAVE")) : 1;   // development only (kernels.hpp k_mutate)
+    ma.debug = dbg | (kwave ? 0 : 256);
     ma.prof = h->d_prof;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
