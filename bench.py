@@ -359,7 +359,7 @@ def main():
                                "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach3 / HBM_PEAK_GBS, "traffic": traffic3,
                                "bytes_per_launch": stage_b * seg_st / seg_n, "mean_launch_us": 1e3 * seg_ms / seg_n, "launches": seg_n,
                                "stages_per_launch": seg_st / seg_n, "bytes_per_stage": stage_b, "mean_stage_us": 1e3 * seg_ms / seg_st,
-                               "note": "latency-bound at this N: two chip-wide hand-overs per stage (3 store->load hops each) + the serial "
+                               "note": "latency-bound at this N: two chip-wide hand-overs per stage (two store->load hops each) + the serial "
                                        "decision / proposal / Newton work of one block; stages outside segments (resample / certificate "
                                        "stages: %d of %d) run as engine 2's launches" % (last["n_stages"] - 1 - seg_st, last["n_stages"] - 1),
                                "valu": pmc3, "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
@@ -378,7 +378,13 @@ def main():
             steps = t_new if shared else t_new + t_old
             flops = 3300.0 * steps * RUN_KW["n_mh_steps"] * n_k
             tf = flops / (mean_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "k_mutate<0> / kalman_lgss (FP64 vector FMA)", "achieved": tf, "peak": 78.6,
+            lanes = os.environ.get("SMCMI_KALMAN_LANES", "")
+            split = lanes == "4" or (lanes != "1" and n_k <= 32768)
+            kname5 = ("k_mutate<0, 4> / kalman_lgss_quad: four lanes per particle (the default up to 32 768 particles per handle)" if split else
+                      ("k_mutate<0, 1> / kalman_lgss2: one thread per particle, scalar structure operands (round-2 kernel)"
+                       if os.environ.get("SMCMI_KALMAN_WAVE", "1") == "0" else
+                       "k_mutate<0, 1> / kalman_lgss_wave: one thread per particle, structure values through DPP operands"))
+            out["roofline"] = {"bound": "mfma", "kernel": kname5 + " (FP64 vector FMA; FP64 vector = matrix peak on gfx950)", "achieved": tf, "peak": 78.6,
                                "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None, "flops_per_launch": flops,
                                "mean_launch_us": 1e3 * mean_ms, "launches": nl,
                                "filter_steps_per_proposal": steps, "old_data_prefix_shared": shared}

@@ -12,6 +12,11 @@ python bench.py --nparts 10000000 --no-history --no-cpu --steps 1 --warmup 1 2>/
 # configs 4 and 5 with their own cpu_baseline (the CPU leg runs each oracle variant once on the full workload)
 python bench.py --workload capm --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_capm.json
 python bench.py --workload kalman --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
+# config 5 on its stated machine: 50 000 particles on 4 GPUs = 12 500 per GPU (lane-split filter), and the round-2 kernel on the same cloud
+python bench.py --workload kalman --nparts 12500 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500.json
+SMCMI_KALMAN_LANES=1 SMCMI_KALMAN_WAVE=0 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_one_thread_r02_kernel.json
+python bench.py --workload kalman --nparts 25000 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n25000.json
+SMCMI_KALMAN_WAVE=0 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_r02_kernel.json
 gcc -O2 -std=c99 -ffp-contract=off -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
 LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
 python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
@@ -38,6 +43,7 @@ kt() {    # kt <tag> <bench args...>: kernel table only
 }
 kt capm --workload capm --steps 2 --warmup 1
 kt kalman --workload kalman --steps 2 --warmup 1
+kt kalman_n12500 --workload kalman --nparts 12500 --steps 2 --warmup 1
 kt gauss10_n1000000_alpha09 --alpha 0.9 --nparts 1000000 --no-history --steps 1 --warmup 1
 pmc gauss10_n100000 100000 --steps 3 --warmup 1
 pmc gauss10_n1000000 1000000 --nparts 1000000 --no-history --steps 1 --warmup 1
