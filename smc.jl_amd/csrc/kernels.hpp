@@ -1896,6 +1896,7 @@ struct MutArgs {
     double *emax;              // in-run MODE 0: per-block largest loglh - old_loglh of the mutated cloud (next stage's energy shift) or null
     const double *mix;         // register kernel, α < 1: the blocks' dense mixture matrices from k_mix_prepare ([n_blocks][MixDense::DOUBLES])
     const int *mixpos;         //                         and parameter positions ([n_blocks][D])
+    int stage_consts;          // k_mutate<0, 1>: the launch reserved sizeof(MutStage) + 64 bytes behind the per-thread vectors (n_para <= 13)
 };
 
 // LS = 4 (lgss_kalman family only, MODE 0): FOUR lanes per particle - a 256-thread block carries 64 particles, the four lanes of a
@@ -1937,24 +1938,26 @@ __global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState 
     const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
     const int nb = st->n_blocks, n_steps = st->mut_steps;
     double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
-    MutStage *S = (LS == 4) ? (MutStage *)(red + 8) : nullptr;
-    if (LS == 4) {
-        for (int e = threadIdx.x; e < 13 * 13; e += blockDim.x) S->L[e] = st->L[e];
-        if (threadIdx.x < 13) {
+    // LS = 1: the same staging when the host reserved the room (MODE 0, n_para <= 13: ma.stage_consts)
+    const bool staged = (LS == 4) || (MODE == 0 && ma.stage_consts && d <= 13);
+    MutStage *S = staged ? (MutStage *)(red + 8) : nullptr;
+    if (staged) {
+        for (int e = threadIdx.x; e < d * d; e += blockDim.x) S->L[e] = st->L[e];
+        if ((int)threadIdx.x < d) {
             const int e = threadIdx.x;
             S->mu_b[e] = st->mu_b[e]; S->sd_draw[e] = st->sd_draw[e]; S->sd_dens[e] = st->sd_dens[e]; S->logdet[e] = st->logdet[e];
             S->lo[e] = md->lo[e]; S->hi[e] = md->hi[e]; S->prior_a[e] = md->prior_a[e]; S->prior_b[e] = md->prior_b[e]; S->prior_k[e] = md->prior_k[e];
             S->blocks_all[e] = st->blocks_all[e]; S->l_off[e] = st->l_off[e]; S->fixed[e] = md->fixed[e]; S->prior_family[e] = md->prior_family[e];
         }
-        if (threadIdx.x < 14) S->block_ptr[threadIdx.x] = st->block_ptr[threadIdx.x];
+        if ((int)threadIdx.x <= d) S->block_ptr[threadIdx.x] = st->block_ptr[threadIdx.x];
         __syncthreads();
     }
-    // (LS = 1 reads the same arrays where they are)
-    const double *a_L = (LS == 4) ? S->L : st->L, *a_mu = (LS == 4) ? S->mu_b : st->mu_b, *a_sdd = (LS == 4) ? S->sd_draw : st->sd_draw;
-    const double *a_sdn = (LS == 4) ? S->sd_dens : st->sd_dens, *a_logdet = (LS == 4) ? S->logdet : st->logdet;
-    const int *a_bptr = (LS == 4) ? S->block_ptr : st->block_ptr, *a_ball = (LS == 4) ? S->blocks_all : st->blocks_all, *a_loff = (LS == 4) ? S->l_off : st->l_off;
-    const ModelView mv{d, (LS == 4) ? S->fixed : md->fixed, (LS == 4) ? S->prior_family : md->prior_family, (LS == 4) ? S->lo : md->lo, (LS == 4) ? S->hi : md->hi,
-                       (LS == 4) ? S->prior_a : md->prior_a, (LS == 4) ? S->prior_b : md->prior_b, (LS == 4) ? S->prior_k : md->prior_k};
+    // (otherwise the same arrays are read where they are)
+    const double *a_L = staged ? S->L : st->L, *a_mu = staged ? S->mu_b : st->mu_b, *a_sdd = staged ? S->sd_draw : st->sd_draw;
+    const double *a_sdn = staged ? S->sd_dens : st->sd_dens, *a_logdet = staged ? S->logdet : st->logdet;
+    const int *a_bptr = staged ? S->block_ptr : st->block_ptr, *a_ball = staged ? S->blocks_all : st->blocks_all, *a_loff = staged ? S->l_off : st->l_off;
+    const ModelView mv{d, staged ? S->fixed : md->fixed, staged ? S->prior_family : md->prior_family, staged ? S->lo : md->lo, staged ? S->hi : md->hi,
+                       staged ? S->prior_a : md->prior_a, staged ? S->prior_b : md->prior_b, staged ? S->prior_k : md->prior_k};
     if (live) {
         like = col(cl, src, d)[i]; lprior = col(cl, src, d + 1)[i]; like_prev = col(cl, src, d + 2)[i];
         load_columns(cl.buf[src], cl.n, i, d, th + tid, T);

@@ -136,7 +136,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     // mutation block size: largest of 256/128/64 threads whose per-thread LDS vectors fit 64 KiB
     for (int T : {256, 128, 64}) {
         h->mut_T = T;
-        h->mut_lds = (size_t)(4 * h->d * T + T / 64) * sizeof(double);
+        h->mut_lds = (size_t)(4 * h->d * T + T / 64) * sizeof(double) + (h->d <= 13 ? 64 + sizeof(MutStage) : 0);   // (+ staged proposal constants)
         if (h->mut_lds <= 64 * 1024) break;
     }
     h->nb_mut = (int)((n + h->mut_T - 1) / h->mut_T);
@@ -742,6 +742,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
     static const int kwave = getenv("SMCMI_KALMAN_WAVE") ? atoi(getenv("SMCMI_KALMAN_WAVE")) : 1;   // development only (kernels.hpp k_mutate)
     ma.debug = dbg | (kwave ? 0 : 256);
+    ma.stage_consts = (h->d <= 13 && !(dbg & 512)) ? 1 : 0;
     ma.prof = h->d_prof;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
     ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
