@@ -9,7 +9,7 @@ C ABI that `bench.py --gpus N` and the multi-process tests share:
   connect()      the communicator: RCCL over xGMI (`comm="rccl"`, one GPU per rank; unique id broadcast through torch.distributed)
                  or the host-mediated one (`comm="host"`: the library's collectives carried by torch.distributed on CPU tensors -
                  gloo - for ranks that share a GPU or have no RCCL)
-  run()          smcmi_run_sharded
+  run()          smcmi_run_sharded; with host closures the host-orchestrated loop (shard_orchestrator.ShardedSMC)
 
 The peer mailbox (include/smcmi.h) is set up by the library on the first run through whichever communicator is connected.
 (The older host-side orchestration over the shard-level C calls lives in shard_orchestrator.py.)
@@ -44,5 +44,18 @@ def connect(eng, rank, world, comm="rccl", group=None):
     return eng
 
 
-def run(eng, **kw):
-    return eng.run_sharded(**kw)
+def run(eng, spec=None, loglikelihood=None, old_loglikelihood=None, **kw):
+    """The sharded loop on rank's shard `eng`.  Device likelihood families: smcmi_run_sharded (the product driver, communicator from
+    connect()).  Host closures (`loglikelihood(theta (m, d)) -> (m,)`, the reference's user function with `parallel = true`: every
+    worker scores the particles it holds, src/smc_main.jl:472-476): the stage loop is driven from the host over the shard-level C
+    calls with torch.distributed carrying the few all-reduces (shard_orchestrator.ShardedSMC; pass the model `spec` whose
+    likelihood entry is ("host_callback", [], None, None)); the mutation is propose -> closure -> accept on every shard."""
+    if loglikelihood is None:
+        return eng.run_sharded(**kw)
+    from .shard_orchestrator import ShardedSMC
+
+    if spec is None:
+        raise ValueError("run(eng, loglikelihood=...) needs the model spec the shard was opened with")
+    sm = ShardedSMC(spec, eng.n_parts, seed=eng.seed, engine=eng, max_stages=eng.max_stages, loglikelihood=loglikelihood,
+                    old_loglikelihood=old_loglikelihood)
+    return sm.run(**kw)

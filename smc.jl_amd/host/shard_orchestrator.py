@@ -65,7 +65,13 @@ class TorchComm:
 
 
 class ShardedSMC:
-    def __init__(self, spec, n_parts, seed=0, device=0, max_stages=1500, store_history=False, engine=None, comm=None):
+    """`loglikelihood` / `old_loglikelihood`: host closures theta (m, d) -> (m,) log-likelihoods (the reference's
+    `loglikelihood::Function` with `parallel = true`: every worker scores the particles it holds, src/smc_main.jl:472-476) - the
+    spec's likelihood entries are then ("host_callback", [], None, None).  The shard's mutation runs as propose -> closure ->
+    accept through the C ABI's split calls (smcmi_propose / smcmi_accept); nothing else of the loop changes."""
+
+    def __init__(self, spec, n_parts, seed=0, device=0, max_stages=1500, store_history=False, engine=None, comm=None,
+                 loglikelihood=None, old_loglikelihood=None):
         self.comm = comm if comm is not None else TorchComm("cuda" if engine is None else engine.tensor_device)
         world, rank = self.comm.world, self.comm.rank
         if n_parts % world:
@@ -80,6 +86,11 @@ class ShardedSMC:
                             n_local=self.n_local, gid0=self.gid0)
             engine.set_model(spec)
         self.e = engine
+        self.lik_fn, self.old_lik_fn = loglikelihood, old_loglikelihood
+        if loglikelihood is not None:
+            engine.set_likelihood_callback(loglikelihood, which=0)          # (the initial draw scores through it)
+            if old_loglikelihood is not None:
+                engine.set_likelihood_callback(old_loglikelihood, which=1)
         fixed = np.asarray(spec.get("fixed") or [0] * self.d)
         self.free_inds = np.flatnonzero(fixed == 0).astype(np.int32)
         self._snap = None
@@ -156,10 +167,37 @@ class ShardedSMC:
             fi = self.free_inds
             mu_f, S_f = mean[fi], (cov[np.ix_(fi, fi)] + cov[np.ix_(fi, fi)].T) / 2.0           # :462-465
             bf, ba, bp = hm.generate_blocks(nf, n_blocks, fi, self.seed, i)                      # :468-469
-            asum = comm.all_reduce([e.shard_mutate(mu_f, S_f, bp, bf, phi_n, phi_prev, c, alpha, n_mh_steps, i)])
+            if self.lik_fn is None:
+                acc_local = e.shard_mutate(mu_f, S_f, bp, bf, phi_n, phi_prev, c, alpha, n_mh_steps, i)
+            else:
+                acc_local = self._mutate_with_closures(mu_f, S_f, bp, bf, phi_n, c, alpha, n_mh_steps, n_blocks, i)
+            asum = comm.all_reduce([acc_local])
             accept = float(asum[0]) / N                                                          # :484
             ess_hist.append(ess); phi_hist.append(phi_n); c_hist.append(c); acc_hist.append(accept); rs_hist.append(int(resampled))
         secs = time.perf_counter() - t0
         return dict(n_stages=i, resamples=resamples, logmdd=logz, c=c, accept=accept, seconds=secs,
                     schedule=np.array(phi_hist), ess=np.array(ess_hist), c_hist=np.array(c_hist),
                     accept_hist=np.array(acc_hist), resampled=np.array(rs_hist, dtype=np.int32), solver_passes=solver_passes)
+
+    def _mutate_with_closures(self, mu_f, S_f, bp, bf, phi_n, c, alpha, n_mh_steps, n_blocks, stage):
+        """mutation! (src/mutation.jl:56-138) of this shard with the likelihoods on the host: per (MH step, block) the device proposes
+        (mixture draw, proposal densities, bounds, prior), the closures score the proposals inside the bounds, the device decides.
+        Returns the shard's Σ accept (update_acceptance_rate!, src/particle.jl:466-468)."""
+        e = self.e
+        nb = len(bp) - 1
+        for step in range(n_mh_steps):
+            for b in range(nb):
+                prop, lpr, _ = e.propose(mu_f, S_f, bp, bf, b, step, c, alpha, stage)
+                inside = np.isfinite(lpr)                                   # out of bounds => ParamBoundsError => -Inf everywhere
+                ln = np.full(e.n, -np.inf)
+                lo = None
+                if inside.any():
+                    ln[inside] = np.asarray(self.lik_fn(np.ascontiguousarray(prop[inside])), dtype=np.float64)
+                if self.old_lik_fn is not None:
+                    lo = np.full(e.n, -np.inf)
+                    if inside.any():
+                        lo[inside] = np.asarray(self.old_lik_fn(np.ascontiguousarray(prop[inside])), dtype=np.float64)
+                e.accept(ln, lo, phi_n, b, step, nb, stage, last=(step == n_mh_steps - 1 and b == nb - 1))
+        e.sync()                                                            # (the handle's stream is not torch's)
+        return float(e.cloud_tensor()[self.d + 3].sum().item())
+

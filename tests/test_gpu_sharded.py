@@ -291,3 +291,67 @@ def test_two_rank_rccl_run_when_two_gpus_are_visible():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_parts_per_gpu"] == 40000
     assert d["logmdd_abs_diff_vs_single_gpu"] == 0.0
     assert abs(d["logmdd_gpu"] - d["logmdd_exact"]) < 0.3
+
+
+def test_host_closures_on_shards_match_one_handle():
+    """The reference's `parallel = true` with a user closure: every worker scores the particles it holds (smc_main.jl:472-476).  Two
+    shards of one population, the likelihood a host closure on each (ShardedSMC: propose -> closure -> accept per shard), against ONE
+    handle running the same closure through smcmi_run's callback path: same stages and resample decisions, log-MDD to 1e-8, same cloud
+    (particle ids are global: a shard proposes exactly what the single handle proposes for its rows)."""
+    from smc_jl_amd import Engine
+    from smc_jl_amd.host.shard_orchestrator import ShardedSMC
+
+    import torch
+
+    d, n, seed, world = 5, 20000, 21, 2
+    base = models.gauss_spec(d=d)
+    m, sigma = base["lik"][2].ravel(), base["lik"][1][0]
+    const = -0.5 * d * np.log(2.0 * np.pi * sigma * sigma)
+
+    def closure(theta):                                        # (m, d) -> (m,)
+        return const - 0.5 * (((theta - m) / sigma) ** 2).sum(axis=1)
+
+    spec = dict(base, lik=("host_callback", [], None, None))
+    kw = dict(use_fixed_schedule=False, tempering_target=0.9, n_blocks=2, n_mh_steps=2, alpha=0.9)
+    e = Engine(n, d, seed=seed, max_stages=600, store_history=False)
+    e.set_model(spec)
+    e.set_likelihood_callback(closure, which=0)
+    e.init_from_prior()
+    g = e.run(**kw)
+    rec = e.stage_records(g["n_stages"])
+    P = e.download_cloud()
+    e.close()
+
+    torch.zeros(1, device="cuda")
+    shared = dist_helpers.ThreadComm._Shared(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            nl = n // world
+            eng = Engine(n, d, seed=seed, max_stages=600, store_history=False, n_local=nl, gid0=rank * nl)
+            eng.set_model(spec)
+            sm = ShardedSMC(spec, n, seed=seed, engine=eng, comm=dist_helpers.ThreadComm(shared, rank), max_stages=600, loglikelihood=closure)
+            sm.n_local, sm.gid0 = nl, rank * nl
+            sm.init_from_prior()
+            r = sm.run(**kw)
+            r["cloud"] = sm.download_cloud()
+            out[rank] = r
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    for r in out:
+        assert r["n_stages"] == g["n_stages"] and r["resamples"] == g["resamples"]
+        np.testing.assert_allclose(r["schedule"], rec["schedule"], rtol=1e-9)
+        assert r["logmdd"] == pytest.approx(g["logmdd"], abs=1e-8)
+    full = np.concatenate([r["cloud"] for r in out], axis=0)
+    np.testing.assert_allclose(full, P, rtol=1e-7, atol=1e-9)
+    assert g["n_stages"] > 10 and g["resamples"] >= 1
