@@ -190,3 +190,40 @@ def test_four_lanes_per_particle_match_one_thread_per_particle(n, nb, tmp_path):
     assert res[0]["logmdd"] == pytest.approx(res[1]["logmdd"], abs=1e-8)
     same = np.all(np.abs(clouds[0] - clouds[1]) <= 1e-9 * (1 + np.abs(clouds[1])), axis=1)
     assert same.mean() > 0.999
+
+
+@pytest.mark.parametrize("n", [4000, 40000])
+def test_convergent_filters_match_the_one_thread_filter(n):
+    """The two filters whose structure values travel through DPP operands against `kalman_lgss2` on the same parameter vectors:
+    `init_from_prior` scores the draws with kalman_lgss2, `initialize_likelihoods` scores them again with the lane-split filter
+    (n <= 32 768: four lanes per particle) or with kalman_lgss_wave (larger clouds).  Neither n is a multiple of the block size:
+    the last block has lanes without a particle (the case a DPP source lane must not be lost in).  Then parameter vectors whose
+    filter explodes: finite values or -Inf, never NaN (a failed filter's state must not reach log())."""
+    sp = models.kalman_spec(T=80)
+    e = make_engine(sp, n, seed=17)
+    e.init_from_prior()
+    P0 = e.download_cloud()
+    e.initialize_likelihoods()
+    P1 = e.download_cloud()
+    np.testing.assert_allclose(P1[:, 13], P0[:, 13], rtol=1e-10, atol=1e-9)
+    np.testing.assert_array_equal(P1[:, 15], P0[:, 13])                  # old_loglh <- loglh
+    np.testing.assert_allclose(P1[:, 14], P0[:, 14], rtol=1e-12, atol=1e-12)
+    Q = P0.copy()
+    rng = np.random.default_rng(3)
+    Q[:, :8] = rng.uniform(-0.95, 0.95, size=(n, 8))
+    Q[: n // 2, :8] = 0.94                                              # spectral radius of Tm above one
+    e.upload_cloud(Q)
+    e.initialize_likelihoods()
+    P2 = e.download_cloud()
+    assert not np.isnan(P2[:, 13]).any()
+    assert np.isfinite(P2[n // 2:, 13]).mean() > 0.5
+    m = models.oracle_model(sp)
+    from oracle import oracle as orc
+
+    rows = np.r_[0:8, n // 2:n // 2 + 8]
+    ref = np.array([orc.loglik(m.lik, Q[i, :13]) for i in rows])
+    got = P2[rows, 13]
+    both = np.isfinite(ref) & np.isfinite(got)
+    np.testing.assert_allclose(got[both], ref[both], rtol=1e-9, atol=1e-7)
+    assert np.array_equal(np.isfinite(ref), np.isfinite(got))
+    e.close()
