@@ -531,9 +531,10 @@ SMCMI_FP_CONTRACT
 // row of register c / 16) and reach the FMAs through their DPP operand - kalman_lgss2 keeps them as scalar operands, which do not fit
 // the SGPR file: the compiler parks them in VGPR lanes and pays ~400 v_readlane per step (17 % of its instructions); the 3x3
 // factorisation uses reciprocal square roots (no sqrt, no division), the determinant a running product (one log per evaluation).
-// ALL 64 LANES MUST CALL THIS TOGETHER (a DPP source lane must be active): the mutation kernel does (lanes without a proposal pass any
-// finite θ and drop the result); callers that cannot (initial draw, stand-alone evaluation) keep kalman_lgss2.  Same algorithm,
-// different summation order in places: values agree to ~1e-13.
+// A DPP source lane must be active, whatever lanes the caller arrives with: the function widens EXEC itself and restores it before
+// returning (see below) - any WAVE-UNIFORM call site will do, the arguments other than θ must be the same in every lane.  Callers
+// inside per-particle loops that end early (the initial draw's redraw loop) keep kalman_lgss2.  Same algorithm, different summation
+// order in places: values agree to ~1e-12.
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
