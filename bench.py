@@ -384,8 +384,16 @@ def main():
                       ("k_mutate<0, 1> / kalman_lgss2: one thread per particle, scalar structure operands (round-2 kernel)"
                        if os.environ.get("SMCMI_KALMAN_WAVE", "1") == "0" else
                        "k_mutate<0, 1> / kalman_lgss_wave: one thread per particle, structure values through DPP operands"))
+            # counter figures for the filter's kernel at this cloud size, when a PMC file exists (profiles/rNN_pmc_kalman_n<N>.json)
+            traffic5, valu5 = None, None
+            if pmc_file:
+                k5 = [(name, v) for name, v in pm["kernels"].items() if "k_mutate<0," in name]
+                if k5:
+                    k5.sort(key=lambda nv: -nv[1].get("sum_total_bytes", nv[1].get("total_bytes", 0.0)))
+                    traffic5, valu5 = k5[0][1].get("total_bytes"), k5[0][1].get("valu")
             out["roofline"] = {"bound": "mfma", "kernel": kname5 + " (FP64 vector FMA; FP64 vector = matrix peak on gfx950)", "achieved": tf, "peak": 78.6,
-                               "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None, "flops_per_launch": flops,
+                               "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": traffic5, "valu_frac": valu5.get("frac") if valu5 else None, "valu": valu5,
+                               "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None, "flops_per_launch": flops,
                                "mean_launch_us": 1e3 * mean_ms, "launches": nl,
                                "filter_steps_per_proposal": steps, "old_data_prefix_shared": shared}
         # whole-stage algorithmic bytes: 24d+96 per particle-stage, +16d+104 on resample stages

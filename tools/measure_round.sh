@@ -46,6 +46,8 @@ kt kalman --workload kalman --steps 2 --warmup 1
 kt kalman_n12500 --workload kalman --nparts 12500 --steps 2 --warmup 1
 kt gauss10_n1000000_alpha09 --alpha 0.9 --nparts 1000000 --no-history --steps 1 --warmup 1
 pmc gauss10_n100000 100000 --steps 3 --warmup 1
+pmc kalman_n50000 50000 --workload kalman --steps 2 --warmup 1
+pmc kalman_n12500 12500 --workload kalman --nparts 12500 --steps 2 --warmup 1
 pmc gauss10_n1000000 1000000 --nparts 1000000 --no-history --steps 1 --warmup 1
 pmc gauss10_n10000000 10000000 --nparts 10000000 --no-history --steps 1 --warmup 0
 ls -la $OUT
