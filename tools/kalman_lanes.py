@@ -30,7 +30,7 @@ if __name__ == "__main__":
     else:
         import numpy as np
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        for n in [int(a) for a in sys.argv[1:]] or [12500, 50000]:
+        for n in [int(a) for a in sys.argv[1:]] or [12500]:
             for lanes in ("4", "1"):
                 p = subprocess.run([sys.executable, __file__, str(n), "worker"], env=dict(os.environ, SMCMI_KALMAN_LANES=lanes), capture_output=True, text=True, timeout=900)
                 print(p.stdout.strip()[-600:], p.stderr.strip()[-1500:])
