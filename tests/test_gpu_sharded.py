@@ -355,3 +355,79 @@ def test_host_closures_on_shards_match_one_handle():
     full = np.concatenate([r["cloud"] for r in out], axis=0)
     np.testing.assert_allclose(full, P, rtol=1e-7, atol=1e-9)
     assert g["n_stages"] > 10 and g["resamples"] >= 1
+
+
+def test_host_closures_on_shards_tempered_update():
+    """The same with an old vintage: `loglikelihood` and `old_loglikelihood` both host closures (generalized tempering,
+    src/mutation.jl:96-106), every shard scoring its own proposals with both; against one handle with the two callbacks."""
+    from smc_jl_amd import Engine
+    from smc_jl_amd.host.shard_orchestrator import ShardedSMC
+
+    import torch
+
+    d, n, seed, world = 4, 12000, 5, 2
+    base = models.gauss_spec(d=d)
+    m, sigma = base["lik"][2].ravel(), base["lik"][1][0]
+
+    def new_lik(theta):
+        return -0.5 * (((theta - m) / sigma) ** 2).sum(axis=1)
+
+    def old_lik(theta):                                        # a flatter likelihood around a shifted mean: the "old data"
+        return -0.5 * (((theta - (m + 0.3)) / (3.0 * sigma)) ** 2).sum(axis=1)
+
+    spec = dict(base, lik=("host_callback", [], None, None), old_lik=("host_callback", [], None, None))
+    kw = dict(use_fixed_schedule=False, tempering_target=0.9, n_blocks=1, n_mh_steps=1, alpha=1.0)
+    rng = np.random.default_rng(11)
+    P0 = np.zeros((n, d + 5), order="F")
+    P0[:, :d] = m + 0.3 + 3.0 * sigma * rng.standard_normal((n, d))       # a cloud distributed like the old posterior (flat prior)
+    P0[:, d] = old_lik(P0[:, :d])
+    P0[:, d + 4] = 1.0
+
+    def start(eng, rows):
+        eng.upload_cloud(np.asfortranarray(P0[rows]))
+        eng.initialize_likelihoods()                                       # old_loglh <- loglh, loglh / logprior on the new data
+
+    e = Engine(n, d, seed=seed, max_stages=600, store_history=False)
+    e.set_model(spec)
+    e.set_likelihood_callback(new_lik, which=0)
+    e.set_likelihood_callback(old_lik, which=1)
+    start(e, slice(0, n))
+    g = e.run(**kw)
+    rec = e.stage_records(g["n_stages"])
+    P = e.download_cloud()
+    e.close()
+
+    torch.zeros(1, device="cuda")
+    shared = dist_helpers.ThreadComm._Shared(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            nl = n // world
+            eng = Engine(n, d, seed=seed, max_stages=600, store_history=False, n_local=nl, gid0=rank * nl)
+            eng.set_model(spec)
+            sm = ShardedSMC(spec, n, seed=seed, engine=eng, comm=dist_helpers.ThreadComm(shared, rank), max_stages=600, loglikelihood=new_lik,
+                            old_loglikelihood=old_lik)
+            sm.n_local, sm.gid0 = nl, rank * nl
+            start(eng, slice(rank * nl, (rank + 1) * nl))
+            r = sm.run(**kw)
+            r["cloud"] = sm.download_cloud()
+            out[rank] = r
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    for r in out:
+        assert r["n_stages"] == g["n_stages"] and r["resamples"] == g["resamples"]
+        np.testing.assert_allclose(r["schedule"], rec["schedule"], rtol=1e-9)
+        assert r["logmdd"] == pytest.approx(g["logmdd"], abs=1e-8)
+    full = np.concatenate([r["cloud"] for r in out], axis=0)
+    np.testing.assert_allclose(full, P, rtol=1e-7, atol=1e-9)
+    assert g["n_stages"] > 5
