@@ -72,6 +72,50 @@ def test_mutation_kernel_keeps_three_waves_per_simd(libmod):
         assert scratch <= max_scratch, (key, scratch)
 
 
+def test_dpp_operands_of_the_kalman_filters_respect_the_hazard_rule(libmod):
+    """The Kalman filters read their wave-uniform structure values through the DPP operand of `v_fmac_f64_dpp ... row_newbcast` written
+    as inline assembly (csrc/model.hpp): the compiler does not know that operand is a DPP source, so it inserts none of the two wait
+    states gfx9 needs between a VALU write of a VGPR and a DPP read of it.  The registers are loaded once, far in front of the loops -
+    unless a later compiler reloads or copies one right before a use.  The build keeps the device assembly of the main translation
+    unit (csrc/Makefile); this walks it: no VALU instruction within two wait states in front of such an FMA may write its DPP source,
+    and the filters' kernels must not have fallen back to scratch."""
+    asm = os.path.join(ROOT, "smc.jl_amd", "csrc", "build", "smcmi_device.s")
+    if not os.path.exists(asm):
+        pytest.skip("library was built without keeping the device assembly")
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    code = []
+    for ln in open(asm):
+        t = ln.strip()
+        if t and not t.startswith((";", ".")) and not t.endswith(":") and not re.match(r"^[._A-Za-z0-9$]+:", t):
+            code.append(t)
+    total, bad = 0, []
+    for n, t in enumerate(code):
+        if not t.startswith("v_fmac_f64_dpp"):
+            continue
+        total += 1
+        src = regs(t.split()[2].strip(","))
+        ws, k = 0, n - 1
+        while k >= 0 and ws < 2:
+            p = code[k]
+            op = p.split()[0]
+            if op == "s_nop":
+                ws += int(p.split()[1]) + 1
+            else:
+                if op.startswith("v_") and len(p.split()) > 1 and regs(p.split()[1].strip(",")) & src:
+                    bad.append((p, t))
+                ws += 1
+            k -= 1
+    assert total > 1000, total              # the three places the filters are compiled into
+    assert not bad, bad[:3]
+
+
 def test_header_is_plain_c_and_the_c_example_links(libmod, tmp_path):
     """include/smcmi.h is C99 (-pedantic), and examples/c_abi_config2.c - the boundary used from plain C, no Python / torch -
     compiles and links against libsmcmi.so."""
