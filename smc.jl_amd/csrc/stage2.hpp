@@ -841,28 +841,42 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
 
 // One correction block's row (ΣW̃, ΣW̃², the (D+1)(D+2)/2 augmented pair sums) from the threads' accumulators; csum (may be null)
 // receives ΣW̃ as well (chunk sums of the selection scan).  red: T1 / 64 * 64 doubles of LDS.  All T1 threads call.
+// A correction block's row: the NPF = (D+1)(D+2)/2 + 2 sums over the block's particles, in the canonical order - every sum is a 64-lane
+// butterfly per wavefront (16 sums at a time: Butterfly<8, 32>, lane 4k ends with sum k of the chunk), then the wavefronts in order.
+// Sixteen at a time, not sixty-four: the wide butterfly holds 128 registers on top of the accumulators, which a kernel that keeps its
+// particle in registers across stages (stage3.hpp) does not have - 60 scratch reloads inside its stage loop came from there.  All
+// chunks go to LDS before ONE barrier (the 64-wide form took two barriers per chunk).  red: NW * cm_row_ld(NPF) doubles.
+constexpr int CMW = 16;
+constexpr int cm_row_ld(int npf) { return (npf + CMW - 1) / CMW * CMW; }
+template <int NPF, int NW, class GET, class ST>
+__device__ inline void cm_row_chunks(double *red, GET get, ST store) {
+    constexpr int NC = (NPF + CMW - 1) / CMW, LD = NC * CMW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_for<NC>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        double a[CMW];
+        get(C, a);
+        Butterfly<CMW / 2, 32>::run(a, lane);
+        if ((lane & 3) == 0) red[wave * LD + c * CMW + (lane >> 2)] = a[0];
+    });
+    __syncthreads();
+    double tot = 0.0;
+    if ((int)threadIdx.x < NPF) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[w * LD + threadIdx.x];
+    }
+    __syncthreads();
+    // (the stores come AFTER the barrier: a barrier waits for the vector-memory operations in front of it, and these are write-through)
+    if ((int)threadIdx.x < NPF) store((int)threadIdx.x, tot);
+}
 template <int D, class ST>
 __device__ inline void k2_cm_row_f(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], double *red, ST store) {
-    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
-    constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
-    constexpr int REM = NPF - 64 * (NCH - 1);
-    constexpr int REMP = REM <= 1 ? 1 : REM <= 2 ? 2 : REM <= 4 ? 4 : REM <= 8 ? 8 : REM <= 16 ? 16 : REM <= 32 ? 32 : 64;
+    constexpr int NPF = (D + 1) * (D + 2) / 2 + 2;
+    cm_row_chunks<NPF, T1 / 64>(red, [&](auto C, double (&a)[CMW]) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        if (ch < NCH - 1 || REMP == 64) {
-            double a64[64];
-#pragma unroll
-            for (int q = 0; q < 64; ++q) a64[q] = acc[ch * 64 + q];
-            const double t64 = block_reduce_nw<64, NW>(a64, red);
-            if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NPF) store(ch * 64 + (int)threadIdx.x, t64);
-        } else {
-            double ar[REMP];
-#pragma unroll
-            for (int q = 0; q < REMP; ++q) ar[q] = acc[ch * 64 + q];
-            const double tr = block_reduce_nw<REMP, NW>(ar, red);
-            if ((int)threadIdx.x < REMP && ch * 64 + (int)threadIdx.x < NPF) store(ch * 64 + (int)threadIdx.x, tr);
-        }
-    }
+        for (int q = 0; q < CMW; ++q) a[q] = (c * CMW + q < NPF) ? acc[c * CMW + q] : 0.0;
+    }, store);
 }
 template <int D>
 __device__ inline void k2_cm_row(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], double *red, double *out, double *csum, bool coh) {
@@ -871,14 +885,11 @@ __device__ inline void k2_cm_row(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) 
         if (idx == 0 && csum) *csum = v;
     });
 }
-// One particle's contribution to a correction block's accumulators: incremental weight (src/smc_main.jl:401-409), W̃ = W w̃, the
-// sums of weighted_mean / weighted_cov about `sh` (particle.jl:481-483, 526-529).  Returns W̃; *inc_out = w̃.
+// One particle's incremental weight (src/smc_main.jl:401-409), W̃ = W w̃, and x̃ = (1, θ - sh).  Returns W̃; *inc_out = w̃.
 template <int D, class XF>
-__device__ inline double k2_cm_particle(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], XF xf, const double *sh, double loglh, double old, double wi,
-                                        double esh, double phi, double phi_prev, double pw, double logp_old, double *inc_out) {
-    constexpr int DA = D + 1;
+__device__ inline double k2_cm_weight(XF xf, const double *sh, double loglh, double old, double wi, double esh, double phi, double phi_prev, double pw,
+                                      double logp_old, double (&xx)[D + 1], double *inc_out) {
     const double l = loglh - esh, o = old;
-    double xx[DA];
     xx[0] = 1.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) xx[a + 1] = xf(a) - sh[a];
@@ -886,7 +897,17 @@ __device__ inline double k2_cm_particle(double (&acc)[((D + 1) * (D + 2) / 2 + 2
     if (pw == 0.0) inc = exp((phi_prev - phi) * o + (phi - phi_prev) * l);
     else if (pw == 1.0) inc = exp((phi - phi_prev) * l);
     else inc = exp((phi_prev - phi) * log(exp(o - logp_old + log(1.0 - pw)) + pw) + (phi - phi_prev) * l);
-    const double v = wi * inc;
+    *inc_out = inc;
+    return wi * inc;
+}
+// ... and its contribution to a correction block's accumulators: the sums of weighted_mean / weighted_cov about `sh`
+// (particle.jl:481-483, 526-529).
+template <int D, class XF>
+__device__ inline double k2_cm_particle(double (&acc)[((D + 1) * (D + 2) / 2 + 2 + 63) / 64 * 64], XF xf, const double *sh, double loglh, double old, double wi,
+                                        double esh, double phi, double phi_prev, double pw, double logp_old, double *inc_out) {
+    constexpr int DA = D + 1;
+    double xx[DA];
+    const double v = k2_cm_weight<D>(xf, sh, loglh, old, wi, esh, phi, phi_prev, pw, logp_old, xx, inc_out);
     acc[0] += v;
     acc[1] += v * v;
     int q = 2;
@@ -896,8 +917,38 @@ __device__ inline double k2_cm_particle(double (&acc)[((D + 1) * (D + 2) / 2 + 2
 #pragma unroll
         for (int b = a; b < DA; ++b) { acc[q] += wx * xx[b]; ++q; }
     }
-    *inc_out = inc;
     return v;
+}
+// The row of a block whose threads hold ONE particle each (stage3.hpp): the sixteen sums of a chunk are formed where the butterfly
+// needs them - 0 + W̃ x̃_a x̃_b is the accumulator k2_cm_particle would hold, bit for bit - so no accumulator array is alive at all.
+__host__ __device__ constexpr int cm_pair_a(int da, int idx) {      // sum idx >= 2 is the pair (a, b), a <= b, row-major
+    int a = 0, k = idx - 2;
+    while (k >= da - a) { k -= da - a; ++a; }
+    return a;
+}
+__host__ __device__ constexpr int cm_pair_b(int da, int idx) {
+    int a = 0, k = idx - 2;
+    while (k >= da - a) { k -= da - a; ++a; }
+    return a + k;
+}
+template <int D, int NW, class ST>
+__device__ inline void k2_cm_row_one(double v, const double (&xx)[D + 1], bool live, double *red, ST store) {
+    constexpr int DA = D + 1, NPF = DA * (DA + 1) / 2 + 2;
+    cm_row_chunks<NPF, NW>(red, [&](auto C, double (&a)[CMW]) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        static_for<CMW>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int idx = c * CMW + decltype(Q)::value, q = decltype(Q)::value;
+            double val = 0.0;
+            if constexpr (idx == 0) val = v;
+            else if constexpr (idx == 1) val = v * v;
+            else if constexpr (idx < NPF) {
+                constexpr int pa = cm_pair_a(DA, idx), pb = cm_pair_b(DA, idx);      // (constant-evaluated: register indices)
+                const double wx = v * xx[pa];
+                val = wx * xx[pb];
+            }
+            a[q] = live ? val : 0.0;
+        });
+    }, store);
 }
 
 // ------------------------------------------------------------------------------------------------ K1: correction + moments
@@ -917,7 +968,7 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
         if (ra.zbuf && ctl->ps[(n - 1) & 1].stage == n - 1) rng2_block<D>(g, ra, n, (int)blockIdx.x - g.Vl * g.nb1, (int)gridDim.x - g.Vl * g.nb1, 0);
         return;
     }
-    __shared__ double red[NW * 64];
+    __shared__ double red[NW * cm_row_ld(NPF)];
     __shared__ Post2 s_po;
     __shared__ Begin2 s_bg;
     __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[RMUT], s_sw[64];

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     __shared__ RecA3 s_a;
     __shared__ RecB3<D> s_b[2];                                 // [n & 1]: Post2 of stage n lives on as "Post2 of n - 1" during stage n + 1
     __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[pad2(NPF) > RMUT ? pad2(NPF) : RMUT], s_sw[64];
-    __shared__ double red[(T3 / 64) * 64];
+    __shared__ double red[(T3 / 64) * (cm_row_ld(NPF) > 64 ? cm_row_ld(NPF) : 64)];
     __shared__ int s_act, s_to, s_fail;
     __shared__ double s_cfac;
     __shared__ RunParams s_rp;                                  // (by value in registers it costs ~40 SGPRs for the whole launch)
@@ -423,19 +423,37 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         const int rs = entered ? rs0 : 0;
         double v = entered ? v_entered : 0.0;
         if (!entered) {
-            constexpr int NCH = (NPF + 63) / 64;
-            double acc[NCH * 64];
+            if constexpr (ALPHA1) {
+                // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
+                double xx[D + 1];
 #pragma unroll
-            for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
-            if (live) {
-                double inc;
-                v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
-                if (hist) {
-                    const double unshift = exp((phi - phi_prev) * esh);
-                    sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                for (int a = 0; a <= D; ++a) xx[a] = 0.0;
+                if (live) {
+                    double inc;
+                    v = k2_cm_weight<D>([&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, xx, &inc);
+                    if (hist) {
+                        const double unshift = exp((phi - phi_prev) * esh);
+                        sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                    }
                 }
+                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+            } else {
+                // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
+                // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
+                constexpr int NCH = (NPF + 63) / 64;
+                double acc[NCH * 64];
+#pragma unroll
+                for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+                if (live) {
+                    double inc;
+                    v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
+                    if (hist) {
+                        const double unshift = exp((phi - phi_prev) * esh);
+                        sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                    }
+                }
+                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
             }
-            k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
             if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
         }
         const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
