@@ -197,9 +197,13 @@ int smcmi_accept(smcmi_handle *h, const double *loglik_new, const double *loglik
 
 /* ---- whole loop on device (smc_main.jl:377-508) ------------------------------------------------ */
 int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
-/* per-stage records: cloud.tempering_schedule, cloud.ESS, c, accept, resample flags; arrays of n_stages */
+/* Number of stages the handle holds records / history columns for: what the last run (or smcmi_set_stage_records / _set_history /
+   _set_loop_state) left, at most max_stages.  The two getters below copy exactly that many entries / columns - size the buffers by it,
+   not by the n_stages a caller expects. */
+int smcmi_stages_held(smcmi_handle *h, int32_t *n_stages_out);
+/* per-stage records: cloud.tempering_schedule, cloud.ESS, c, accept, resample flags; arrays of smcmi_stages_held() entries */
 int smcmi_get_stage_records(smcmi_handle *h, double *phi, double *ess, double *c, double *accept, int32_t *resampled);
-int smcmi_get_history(smcmi_handle *h, double *w, double *W);           /* n_local x n_stages each, column-major */
+int smcmi_get_history(smcmi_handle *h, double *w, double *W);           /* n_local x smcmi_stages_held() each, column-major */
 /* intermediate save / continue (smc_main.jl:334-361, 499-507): the loop scalars, and - for a continuation in a fresh
  * handle - the records and history columns of the stages already done (the cloud itself goes through smcmi_upload_cloud) */
 int smcmi_get_loop_state(smcmi_handle *h, smcmi_loop_state *out);
@@ -269,6 +273,11 @@ int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, sm
    the current cloud.  which: 0 pass16(p=0) 1 pass16(p=1, with decision prologue) 2 correction 3 post_correct 4 scan 5 resample_gather
    6 moments 7 moments_reduce 8 prepare_mutation 9 mutate 10 stage_begin 11 empty kernel */
 int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t reps, double *usec_per_launch);
+/* parity aid: compute_proposal_densities(para_draw, para_subset, d_subset = MvNormal(mu, Sigma), c, alpha) (src/helpers.jl:128-164;
+   quirk Q1: the diagonal component's density uses the unscaled Σ_ii) evaluated by the dense mixture code of the alpha < 1 mutation
+   kernels on the current device, for one block of d <= 16 entries; Sigma row-major d x d.  q0 / q1 as the reference returns them. */
+int smcmi_debug_proposal_densities(const double *para_draw, const double *para_subset, const double *mu, const double *Sigma,
+                                   int32_t d, double c, double alpha, double *q0, double *q1);
 
 #ifdef __cplusplus
 }

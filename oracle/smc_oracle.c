@@ -10,9 +10,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <stdatomic.h>
 #ifdef _OPENMP
 #include <omp.h>
-#include <stdatomic.h>
 #endif
 
 #define ORC_MAXD 512

@@ -39,6 +39,7 @@ struct Eng2 {
     int *d_done3 = nullptr;
     unsigned seg_seq = 0;
     int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle
+    bool seg_attr_set = false;       // k3_segment's dynamic-LDS opt-in done on this handle's device
     bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
     int n_steps = 1, n_blocks = 1;
 };
@@ -77,6 +78,9 @@ struct smcmi_handle {
     bool mbox_tried = false;
     bool mbox_used = false;                   // the last engine-2 run of this handle handed its sums over through the mailbox
     unsigned mbox_epoch = 0;
+    double *d_snap = nullptr;         // single-handle runs that may use engine 3: the cloud the run started from (repeat after a segment time-out)
+    DevState snap_st;                 // ... and its loop state
+    int seg_timeouts = 0;             // runs repeated as launches after a segment time-out
     double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
     int *d_mixpos = nullptr;
     // host-callback split

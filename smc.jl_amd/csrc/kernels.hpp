@@ -2306,6 +2306,21 @@ SMCMI_FP_CONTRACT
         }
     }
 }
+// compute_proposal_densities (src/helpers.jl:128-164) in the dense form: the two mixture densities (not yet logarithms) of the move
+// x (θ, para_subset) <-> xn (ϑ, para_draw); ssq = Σ_k ((x_k - xn_k) / sd_dens_k)² over the block, the diagonal component's exponent
+// (its standard deviations are the UNSCALED Σ_ii: quirk Q1).  q0 carries N(θ_b; θ̄_b, c²Σ_b), q1 carries N(ϑ_b; θ̄_b, c²Σ_b).
+template <int D, class MX>
+__device__ inline void mix_densities(const MX &M, const double (&x)[D], const double (&xn)[D], double ssq, double c_alpha, double &q0, double &q1) {
+SMCMI_FP_CONTRACT
+    double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
+    constexpr int HALF = (D + 1) / 2;
+    mix_solve_rows<D, 0, HALF, MX>(M, x, xn, quad, quad_s, quad_d);
+    mix_solve_rows<D, HALF, D, MX>(M, x, xn, quad, quad_s, quad_d);
+    const double cst = M.sc[1];
+    const double common = c_alpha * exp(-(cst + quad) / 2.0) + (1.0 - c_alpha) / 2.0 * (M.sc[0] * exp(-0.5 * ssq));
+    q0 = common + (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
+    q1 = common + (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
+}
 // One proposal: x (current θ, parameter order) -> xn, and log q(θ|ϑ) - log q(ϑ|θ) as the MH ratio uses it (NaN when both
 // densities vanish, like the reference's log 0 - log 0).  z: the block's standard normals (block order, zero beyond d_b);
 // zt: this thread's private LDS column (stride T), D entries.
@@ -2337,14 +2352,8 @@ SMCMI_FP_CONTRACT
         const double zz = (x[k] - xn[k]) * M.isd_p[k];
         ssq += zz * zz;
     }
-    double quad = 0.0, quad_s = 0.0, quad_d = 0.0;
-    constexpr int HALF = (D + 1) / 2;
-    mix_solve_rows<D, 0, HALF, MX>(M, x, xn, quad, quad_s, quad_d);
-    mix_solve_rows<D, HALF, D, MX>(M, x, xn, quad, quad_s, quad_d);
-    const double cst = M.sc[1];
-    const double common = c_alpha * exp(-(cst + quad) / 2.0) + (1.0 - c_alpha) / 2.0 * (M.sc[0] * exp(-0.5 * ssq));
-    const double q0 = common + (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_s) / 2.0);
-    const double q1 = common + (1.0 - c_alpha) / 2.0 * exp(-(cst + quad_d) / 2.0);
+    double q0, q1;
+    mix_densities<D, MX>(M, x, xn, ssq, c_alpha, q0, q1);
     return log(q0 / q1);
 }
 
@@ -2366,6 +2375,57 @@ __global__ void __launch_bounds__(256) k_mix_prepare(const DevState *st, int nb,
         const MixDense<D> G(mix + (long long)b * MixDense<D>::DOUBLES, mixpos + b * D);
         const int p0 = bptr[b], db = bptr[b + 1] - p0;
         mix_expand<D, T>(G, Lraw + loff[b], Wraw + loff[b], ball + p0, mub + p0, sdd + p0, sdn + p0, db, logdet[b], tid);
+    }
+}
+
+// Development / parity aid (smcmi_debug_proposal_densities): compute_proposal_densities (src/helpers.jl:128-164) of ONE move through the
+// dense form the register kernels use - factorisation of c²Σ, L⁻¹, mix_expand, mix_densities - for a block that is the whole vector
+// (positions = identity).  out[0] = q0, out[1] = q1 (logarithms; the reference's `q0 == Inf && q1 == Inf -> q0 = 0` included), out[2] = 1
+// if c²Σ is not positive definite.
+template <int D>
+__global__ void __launch_bounds__(256) k_debug_mix_densities(const double *para_draw, const double *para_subset, const double *mu, const double *Sigma, int d,
+                                                             double c, double alpha, double *out) {
+    constexpr int T = 256;
+    __shared__ double Lraw[D * D], Wraw[D * D], mub[D], sdd[D], sdn[D], mixbuf[MixDense<D>::DOUBLES], logdet_s;
+    __shared__ int ball[D], bptr[2], loff[1], mixpos[D], fail;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < d * d; e += T) Lraw[e] = 0.0;
+    for (int e = tid; e < d; e += T) { mub[e] = mu[e]; ball[e] = e; sdd[e] = sqrt(c * c * Sigma[e * d + e]); sdn[e] = sqrt(Sigma[e * d + e]); }
+    if (tid == 0) { bptr[0] = 0; bptr[1] = d; loff[0] = 0; fail = 0; }
+    __syncthreads();
+    if (tid == 0) {                                          // c²Σ = L Lᵀ, row by row (MvNormal(θ̄_b, c²Σ_b), src/mutation.jl:81)
+        double ld = 0.0;
+        for (int i = 0; i < d && !fail; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sacc = c * c * Sigma[i * d + j];
+                for (int k = 0; k < j; ++k) sacc -= Lraw[i * d + k] * Lraw[j * d + k];
+                if (i == j) {
+                    if (!(sacc > 0.0)) { fail = 1; break; }
+                    Lraw[i * d + i] = sqrt(sacc);
+                    ld += 2.0 * log(Lraw[i * d + i]);
+                } else Lraw[i * d + j] = sacc / Lraw[j * d + j];
+            }
+        logdet_s = ld;
+    }
+    __syncthreads();
+    if (fail) { if (tid == 0) { out[0] = out[1] = __builtin_nan(""); out[2] = 1.0; } return; }
+    mix_invert_factors<D, T>(Lraw, Wraw, loff, bptr, 1, tid);
+    const MixDense<D> M(mixbuf, mixpos);
+    mix_expand<D, T>(M, Lraw, Wraw, ball, mub, sdd, sdn, d, logdet_s, tid);
+    if (tid == 0) {
+        double x[D], xn[D], ssq = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            x[k] = k < d ? para_subset[k] : 0.0;
+            xn[k] = k < d ? para_draw[k] : 0.0;
+            const double zz = (x[k] - xn[k]) * M.isd_p[k];
+            ssq += zz * zz;
+        }
+        double q0, q1;
+        mix_densities<D, MixDense<D>>(M, x, xn, ssq, alpha, q0, q1);
+        q0 = log(q0); q1 = log(q1);
+        if (q0 == __builtin_huge_val() && q1 == __builtin_huge_val()) q0 = 0.0;
+        out[0] = q0; out[1] = q1; out[2] = 0.0;
     }
 }
 

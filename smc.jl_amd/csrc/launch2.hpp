@@ -50,12 +50,11 @@ void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, 
     Eng2 *e = h->e2;
     const size_t lds = k3_lds_bytes(D);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl);            // workers, gatherers
-    static bool attr_set = false;              // (per instantiation: static + dynamic LDS pass 64 KB)
-    if (!attr_set) {
+    if (!e->seg_attr_set) {                    // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
         hipFuncSetAttribute((const void *)k3_segment<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         hipFuncSetAttribute((const void *)k3_segment<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
+        e->seg_attr_set = true;
     }
     if (alpha1) k3_segment<D, true><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
     else k3_segment<D, false><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);

@@ -253,7 +253,10 @@ static int mbox_setup_remote(ShardGroup &g) {
     HIP_TRY(hipMalloc((void **)&d_send, 64));
     HIP_TRY(hipMalloc((void **)&d_recv, 64 * (size_t)world));
     HIP_TRY(hipMemcpyAsync(d_send, mine, 64, hipMemcpyHostToDevice, h->stream));
-    if (int e = g.allgather([=](smcmi_handle *) { return (const double *)d_send; }, [=](smcmi_handle *) { return d_recv; }, (size_t)8)) return e;   // 64 bytes = 8 doubles per rank
+    if (int e = g.allgather([=](smcmi_handle *) { return (const double *)d_send; }, [=](smcmi_handle *) { return d_recv; }, (size_t)8)) {   // 64 bytes = 8 doubles per rank
+        hipFree(d_send); hipFree(d_recv);
+        return e;
+    }
     std::vector<uint8_t> all(64 * (size_t)world);
     HIP_TRY(hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -658,6 +661,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 #define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0)
         SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
+        HIP_TRY(hipGetLastError());                  // (a rejected launch would otherwise surface as a bogus capacity / time-out error)
         if (e1) hipEventRecord(e1, h->stream);
         ++seg_launches;
         return 0;
@@ -947,8 +951,12 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (mbox) {
         // a hand-over that timed out poisoned the sums with NaN: report THAT, not the NaN-ESS message the poisoned sums lead to
         unsigned long long timed_out = 0;
-        HIP_TRY(hipSetDevice(h0->cfg.device));
-        HIP_TRY(hipMemcpy(&timed_out, h0->d_mbox + MB_WORDS, sizeof(timed_out), hipMemcpyDeviceToHost));
+        for (auto *h : g.hs) {                           // (any handle of an in-process group may be the one whose wait ran out)
+            unsigned long long t = 0;
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            HIP_TRY(hipMemcpy(&t, h->d_mbox + MB_WORDS, sizeof(t), hipMemcpyDeviceToHost));
+            timed_out |= t;
+        }
         if (timed_out) {
             for (auto *h : g.hs) { h->mbox_ok = false; h->mbox_tried = true; }        // later runs of these handles use the all-gathers
             return set_err(SMCMI_ERR_TIMEOUT, "peer mailbox: a rank's per-stage sums did not arrive within the time-out (SMCMI_MAILBOX_TIMEOUT_MS); "

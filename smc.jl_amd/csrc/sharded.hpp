@@ -82,6 +82,8 @@ extern "C" int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, con
     smcmi_nccl_comm c = nullptr;
     NCCL_TRY(g_rccl.CommInitRank(&c, world, uid, rank));
     h->nccl = c; h->rank = rank; h->world = world;
+    h->has_hostc = false;                             // (a handle connected to a host communicator before: RCCL carries the collectives now)
+    h->mbox_tried = false; h->mbox_ok = false;        // the peer tables of the previous communicator's ranks are not this one's
     // self-test: every rank contributes (1, rank) -> (world, world (world - 1) / 2); a broken transport fails here, loudly,
     // instead of producing a wrong posterior later
     if (!h->d_comm || h->comm_cap < 2) return set_err(SMCMI_ERR_STATE, "communication scratch buffer missing");
@@ -105,14 +107,15 @@ extern "C" int smcmi_comm_init_host(smcmi_handle *h, int32_t rank, int32_t world
     if (h->cfg.n_local * world != h->cfg.n_parts || h->cfg.gid0 != rank * h->cfg.n_local)
         return set_err(SMCMI_ERR_ARG, "handle shard (n_local, gid0) does not match (rank, world): equal contiguous shards are required");
     if (h->nccl) smcmi_comm_release(h);
-    h->hostc = *comm; h->has_hostc = true; h->rank = rank; h->world = world;
+    h->has_hostc = false;
     h->mbox_tried = false; h->mbox_ok = false;
-    // self-test, as smcmi_comm_init: every rank contributes (1, rank)
+    // self-test, as smcmi_comm_init: every rank contributes (1, rank); the handle counts as connected only once it has passed
     const double mine[2] = {1.0, (double)rank};
     std::vector<double> all(2 * (size_t)world, 0.0);
     if (comm->allgather(mine, all.data(), 2, comm->user)) return set_err(SMCMI_ERR_CALLBACK, "host communicator: allgather failed");
     for (int r = 0; r < world; ++r)
         if (all[2 * r] != 1.0 || all[2 * r + 1] != (double)r) return set_err(SMCMI_ERR_CALLBACK, "host communicator: allgather self-test failed (rank order?)");
+    h->hostc = *comm; h->has_hostc = true; h->rank = rank; h->world = world;
     return 0;
 }
 static int hostc_allgather(smcmi_handle *h, const double *dsend, double *drecv, size_t count) {
@@ -121,6 +124,7 @@ static int hostc_allgather(smcmi_handle *h, const double *dsend, double *drecv, 
     HIP_TRY(hipMemcpyAsync(sb.data(), dsend, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->hostc.allgather(sb.data(), rb.data(), (int64_t)count, h->hostc.user)) return set_err(SMCMI_ERR_CALLBACK, "host communicator: allgather failed");
+    if (!drecv) return 0;                  // (the caller reads h->hc_recv on the host)
     HIP_TRY(hipMemcpyAsync(drecv, rb.data(), sizeof(double) * rb.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -145,11 +149,7 @@ struct ShardGroup {
     int allreduce(F buf, int count) {
         if (rccl && hostc) {          // all-gather, then the sum in rank order (the same bits on every rank)
             smcmi_handle *h = hs[0];
-            double *tmp = nullptr;
-            HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * (size_t)count * world));
-            int rc = hostc_allgather(h, buf(h), tmp, (size_t)count);
-            hipFree(tmp);
-            if (rc) return rc;
+            if (int rc = hostc_allgather(h, buf(h), nullptr, (size_t)count)) return rc;      // gathered on the host: h->hc_recv
             std::vector<double> tot(count, 0.0);
             for (int r = 0; r < world; ++r)
                 for (int k = 0; k < count; ++k) tot[k] += h->hc_recv[(size_t)r * count + k];

@@ -197,7 +197,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
                     h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
-                    h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof, h->d_mix, h->d_mixpos};
+                    h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof, h->d_mix, h->d_mixpos, h->d_snap};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1233,6 +1233,12 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     return 0;
 }
 
+extern "C" int smcmi_stages_held(smcmi_handle *h, int32_t *n_stages_out) {
+    if (!h || !n_stages_out) return set_err(SMCMI_ERR_ARG, "null argument");
+    *n_stages_out = h->last_n_stages;
+    return 0;
+}
+
 extern "C" int smcmi_get_stage_records(smcmi_handle *h, double *phi, double *ess, double *c, double *accept, int32_t *resampled) {
     if (!h) return set_err(SMCMI_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -1424,10 +1430,34 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
 #include "sharded.hpp"
 #include "launch2.hpp"
 #include "run2.hpp"
+// Engine 3's persistent segments rely on every block of their grid being resident.  Residency is verified once per handle (k3_census); if
+// the GPU is shared later (another process, CU masking, a second stream) a hand-over inside a segment can time out: the run is void and
+// the cloud already overwritten.  A single-handle run therefore keeps what a repeat needs - the cloud it started from (one
+// device-to-device copy of n x R doubles, ~10 µs at config 2) and the loop state - and repeats itself on engine 2's launches, which the
+// time-out has made the handle's engine from then on.
 static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
     ShardGroup g;
     g.hs = {h}; g.world = 1; g.rccl = false;
-    return run2_impl(g, rc, res);
+    static const int e3_off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
+    const bool may_seg = !e3_off && h->n <= 131072 && (!h->e2 || h->e2->e3_state >= 0);
+    const size_t cloud_bytes = sizeof(double) * (size_t)h->n * h->R;
+    if (may_seg) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        if (!h->d_snap && dmalloc(&h->d_snap, (size_t)h->n * h->R)) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(h->d_snap, h->cl.buf[0], cloud_bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(&h->snap_st, h->d_st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    int e = run2_impl(g, rc, res);
+    if (e == SMCMI_ERR_TIMEOUT && may_seg && h->e2 && h->e2->e3_state < 0) {
+        if (getenv("SMCMI_TRACE")) fprintf(stderr, "[smcmi3] segment time-out: the run is repeated as launches from the cloud it started with\n");
+        HIP_TRY(hipMemcpyAsync(h->cl.buf[0], h->d_snap, cloud_bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_st, &h->snap_st, sizeof(DevState), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        e = run2_impl(g, rc, res);
+        h->seg_timeouts += 1;
+    }
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------ development aid
@@ -1515,6 +1545,34 @@ extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t r
     }
     h->h_st = saved;
     return push_state(h);
+}
+
+// compute_proposal_densities (src/helpers.jl:128-164) of one move through the device's dense mixture form (kernels.hpp mix_densities):
+// the reference's own fixture (test/helpers.jl:101-127) reaches the HIP code the alpha < 1 mutation kernels run
+extern "C" int smcmi_debug_proposal_densities(const double *para_draw, const double *para_subset, const double *mu, const double *Sigma, int32_t d,
+                                              double c, double alpha, double *q0, double *q1) {
+    if (!para_draw || !para_subset || !mu || !Sigma || !q0 || !q1) return set_err(SMCMI_ERR_ARG, "null argument");
+    if (d < 1 || d > 16) return set_err(SMCMI_ERR_ARG, "block length out of range (1..16)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_err(SMCMI_ERR_HIP, "no HIP device available: libsmcmi has no CPU fallback");
+    double *dbuf = nullptr;
+    const size_t nd = (size_t)3 * d + (size_t)d * d + 3;
+    HIP_TRY(hipMalloc((void **)&dbuf, nd * sizeof(double)));
+    std::vector<double> hb(nd);
+    memcpy(&hb[0], para_draw, sizeof(double) * d); memcpy(&hb[d], para_subset, sizeof(double) * d); memcpy(&hb[2 * d], mu, sizeof(double) * d);
+    memcpy(&hb[3 * d], Sigma, sizeof(double) * d * d);
+    hipError_t e = hipMemcpy(dbuf, hb.data(), nd * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_debug_mix_densities<16><<<1, 256>>>(dbuf, dbuf + d, dbuf + 2 * d, dbuf + 3 * d, d, c, alpha, dbuf + 3 * d + (size_t)d * d);
+        e = hipGetLastError();
+    }
+    double o[3] = {0.0, 0.0, 0.0};
+    if (e == hipSuccess) e = hipMemcpy(o, dbuf + 3 * d + (size_t)d * d, sizeof(o), hipMemcpyDeviceToHost);
+    hipFree(dbuf);
+    if (e != hipSuccess) return set_err(SMCMI_ERR_HIP, std::string("smcmi_debug_proposal_densities: ") + hipGetErrorString(e));
+    if (o[2] != 0.0) return err_from_state(SMCMI_ERR_POSDEF);
+    *q0 = o[0]; *q1 = o[1];
+    return 0;
 }
 
 // ---- peer mailbox across processes (include/smcmi.h): the caller may exchange the 64-byte table handles itself

@@ -476,8 +476,12 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
             if (!proposal2(s_tot + 2, po.shift, D, nf, nb, po.c * s_a.bg.cfac, ma.seed, (unsigned)n, P, &s_fail, T3, jx_pre, nullptr,
                            (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 30 : nullptr)) {
-                // PosDefException aborts the run (mutation.jl:81); the gatherers, which build no proposal, leave by their time-out
-                if (writer && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
+                // PosDefException aborts the run (mutation.jl:81).  The gatherers build no proposal and would wait for mutation rows that
+                // never come: the writer raises the waits' abort word (every bounded wait polls it), so they leave at once
+                if (writer && tid == 0) {
+                    ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9;
+                    __hip_atomic_store(sa.to, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 break;
             }
         }

@@ -101,6 +101,7 @@ SYMBOLS = [
     ("smcmi_propose", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint32, dp, dp, dp]),
     ("smcmi_accept", C.c_int, [_H, dp, dp, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32]),
     ("smcmi_run", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),
+    ("smcmi_stages_held", C.c_int, [_H, ip]),
     ("smcmi_get_stage_records", C.c_int, [_H, dp, dp, dp, dp, ip]),
     ("smcmi_get_history", C.c_int, [_H, dp, dp]),
     ("smcmi_get_loop_state", C.c_int, [_H, C.POINTER(LoopState)]),
@@ -117,6 +118,7 @@ SYMBOLS = [
     ("smcmi_shard_mutate_partial", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32]),
     ("smcmi_sync", C.c_int, [_H]),
     ("smcmi_debug_time_kernel", C.c_int, [_H, C.c_int32, C.c_int32, dp]),
+    ("smcmi_debug_proposal_densities", C.c_int, [dp, dp, dp, dp, C.c_int32, C.c_double, C.c_double, dp, dp]),
     ("smcmi_comm_unique_id", C.c_int, [C.c_char_p]),
     ("smcmi_comm_init", C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p]),
     ("smcmi_run_sharded", C.c_int, [_H, C.POINTER(RunConfig), C.POINTER(Result)]),

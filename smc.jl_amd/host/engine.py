@@ -354,9 +354,15 @@ class Engine:
         out["paused"] = bool(res.paused)
         return out
 
+    def stages_held(self):
+        """Stages the handle holds records / history columns for (smcmi_stages_held): what the getters below copy."""
+        k = C.c_int32()
+        check(self._L.smcmi_stages_held(self._h, C.byref(k)))
+        return int(k.value)
+
     def stage_records(self, n_stages):
-        # the library copies as many records as the last run produced (at most max_stages), whatever the caller expects
-        cap = max(int(n_stages), self.max_stages)
+        # the library copies as many records as the handle holds (at most max_stages), whatever the caller expects
+        cap = max(int(n_stages), self.stages_held(), 1)
         phi, ess, c, acc = (np.zeros(cap) for _ in range(4))
         rs = np.zeros(cap, dtype=np.int32)
         check(self._L.smcmi_get_stage_records(self._h, _d(phi), _d(ess), _d(c), _d(acc), _i(rs)))
@@ -364,9 +370,12 @@ class Engine:
         return dict(schedule=phi[:k].copy(), ess=ess[:k].copy(), c_hist=c[:k].copy(), accept_hist=acc[:k].copy(), resampled=rs[:k].copy())
 
     def history(self, n_stages):
-        w, W = np.empty((self.n, n_stages), order="F"), np.empty((self.n, n_stages), order="F")
+        # the library copies as many columns as the handle holds, whatever the caller expects (smcmi_stages_held)
+        cap = max(int(n_stages), self.stages_held(), 1)
+        w, W = np.empty((self.n, cap), order="F"), np.empty((self.n, cap), order="F")
         check(self._L.smcmi_get_history(self._h, _d(w), _d(W)))
-        return w, W
+        k = int(n_stages)
+        return (w, W) if k == cap else (np.asfortranarray(w[:, :k]), np.asfortranarray(W[:, :k]))
 
     def time_kernel(self, which, reps=200):
         us = C.c_double()
@@ -468,6 +477,17 @@ def torch_dist_host_comm(group=None):
         dist.barrier(group=group)
 
     return allgather, alltoallv, barrier
+
+
+def debug_proposal_densities(para_draw, para_subset, mu, Sigma, c, alpha):
+    """compute_proposal_densities (src/helpers.jl:128-164) through the dense mixture code of the alpha < 1 mutation kernels
+    (smcmi_debug_proposal_densities): (q0, q1) as the reference returns them."""
+    pd, ps, m = _f64(para_draw), _f64(para_subset), _f64(mu)
+    S = np.ascontiguousarray(np.asarray(Sigma, dtype=np.float64))
+    assert S.shape == (m.size, m.size) and pd.size == m.size and ps.size == m.size
+    q0, q1 = C.c_double(), C.c_double()
+    check(_lib.lib().smcmi_debug_proposal_densities(_d(pd), _d(ps), _d(m), _d(S), m.size, float(c), float(alpha), C.byref(q0), C.byref(q1)))
+    return q0.value, q1.value
 
 
 def comm_unique_id():

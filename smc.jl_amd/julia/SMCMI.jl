@@ -333,32 +333,29 @@ end
 # after the run from the per-stage records (the fields end_stage_print shows: iteration, ϕ, c, acceptance rate, ESS, resamples so far);
 # :high adds the final weighted means and standard deviations.  Per-stage wall times do not exist: the total is printed once.
 const VERBOSITY = Dict(:none => 0, :low => 1, :high => 2)
-function print_stages(h::Handle, cloud::Cloud, parameters, regime_switching::Bool; verbose::Symbol = :low, use_fixed_schedule::Bool = true)
-    VERBOSITY[verbose] >= VERBOSITY[:low] || return
-    ns = cloud.stage_index
+# the getters copy as many records / history columns as the handle holds (smcmi_stages_held), whatever the caller expects
+stages_held(h::Handle) = (k = Ref{Int32}(0); check(ccall((:smcmi_stages_held, LIB), Cint, (Handle, Ref{Int32}), h, k)); Int(k[]))
+function stage_records(h::Handle)
+    ns = stages_held(h)
     phi = Vector{Float64}(undef, ns); ess = similar(phi); cs = similar(phi); acc = similar(phi); rs = Vector{Int32}(undef, ns)
     check(ccall((:smcmi_get_stage_records, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
                 h, phi, ess, cs, acc, rs))
-    total = 0
+    return phi, ess, cs, acc, rs
+end
+function print_stages(h::Handle, cloud::Cloud, parameters, regime_switching::Bool; verbose::Symbol = :low, use_fixed_schedule::Bool = true)
+    VERBOSITY[verbose] >= VERBOSITY[:low] || return
+    phi, ess, cs, acc, rs = stage_records(h)
+    ns = min(cloud.stage_index, length(phi)); bar = "--------------------------"
     for i in 2:ns
-        total += rs[i]
-        println("--------------------------")
-        println(use_fixed_schedule ? "Iteration = $(i) / $(cloud.n_Φ)" : "Iteration = $(i)")
-        println("--------------------------")
-        println("phi = $(phi[i])")
-        println("--------------------------")
-        println("c = $(cs[i])")
-        println("accept = $(i < ns ? acc[i] : cloud.accept)")
-        println("ESS = $(ess[i])   ($(total) total resamples.)")
-        println("--------------------------")
+        println(bar, "\n", use_fixed_schedule ? "Iteration = $(i) / $(cloud.n_Φ)" : "Iteration = $(i)", "\n", bar, "\nphi = $(phi[i])\n", bar)
+        println("c = $(cs[i])\naccept = $(i < ns ? acc[i] : cloud.accept)\nESS = $(ess[i])   ($(sum(rs[2:i])) total resamples.)\n", bar)
     end
     println("time elapsed: $(round(cloud.total_sampling_time / 60, digits = 4)) minutes")
     if VERBOSITY[verbose] >= VERBOSITY[:high]
         μ = weighted_mean(cloud); σ = weighted_std(cloud)
-        syms = para_symbols(parameters, regime_switching)
         println("Mean and standard deviation of parameter estimates")
-        for n in 1:length(syms)
-            println("$(syms[n]) = $(round(μ[n], digits = 5)), $(round(σ[n], digits = 5))")
+        for (n, sym) in enumerate(para_symbols(parameters, regime_switching))
+            println("$(sym) = $(round(μ[n], digits = 5)), $(round(σ[n], digits = 5))")
         end
     end
 end
@@ -380,13 +377,12 @@ function collect_cloud(h::Handle, n_parts, d, n_Φ, res::Result)
     ns = Int(res.n_stages)
     cloud = Cloud(d, n_parts)
     check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, cloud.particles))
-    phi = Vector{Float64}(undef, ns); ess = similar(phi)
-    check(ccall((:smcmi_get_stage_records, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-                h, phi, ess, C_NULL, C_NULL, C_NULL))
-    cloud.tempering_schedule = phi; cloud.ESS = ess; cloud.stage_index = ns; cloud.n_Φ = n_Φ
+    phi, ess = stage_records(h)
+    cloud.tempering_schedule = phi[1:ns]; cloud.ESS = ess[1:ns]; cloud.stage_index = ns; cloud.n_Φ = n_Φ
     cloud.resamples = res.resamples; cloud.c = res.c; cloud.accept = res.accept; cloud.total_sampling_time = res.seconds
-    w = Matrix{Float64}(undef, n_parts, ns); W = similar(w)
+    w = Matrix{Float64}(undef, n_parts, stages_held(h)); W = similar(w)
     check(ccall((:smcmi_get_history, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Float64}), h, w, W))
+    w = w[:, 1:ns]; W = W[:, 1:ns]
     ls = LoopState()
     check(ccall((:smcmi_get_loop_state, LIB), Cint, (Handle, Ref{LoopState}), h, ls))
     return cloud, w, W, Int(ls.j)

@@ -704,3 +704,30 @@ def test_bench_line_contract():
         assert k in r, k
     # (a cloud this small runs in engine 3's segments: the quoted kernel is k3_segment, per-stage figures beside the per-launch ones)
     assert r["bound"] in ("hbm", "valu") and "valu" in r and "k3_segment" in r["kernel"] and r["mean_stage_us"] > 0 and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+def test_device_proposal_densities_against_the_reference_fixture(orc, golden):
+    """SURVEY §8 a-14 on the HIP side: the reference's own compute_proposal_densities fixture (test/helpers.jl:101-127,
+    α = 0.9, a 13-entry block; pins quirk Q1 - the diagonal component's density uses the UNSCALED Σ_ii) through the dense mixture code
+    the α < 1 mutation kernels run (kernels.hpp mix_expand / mix_densities), which is structurally different from the literal form the
+    oracle restates (one inverse factor and two dense sweeps instead of three forward substitutions)."""
+    from smc_jl_amd.host.engine import debug_proposal_densities
+
+    z = golden("proposal_densities")
+    q0, q1 = debug_proposal_densities(z["para_draw"], z["para_subset"], z["mu"], z["Sigma"], float(z["c"]), float(z["alpha"]))
+    assert q0 == pytest.approx(4.714243032395692, rel=1e-13)
+    assert q1 == pytest.approx(4.714241545508865, rel=1e-13)
+    assert q0 == pytest.approx(float(z["q0"]), rel=1e-13) and q1 == pytest.approx(float(z["q1"]), rel=1e-13)
+    # and against the (fixture-pinned) oracle on random blocks of other sizes / mixture weights, incl. moves far out in the tails
+    rs = np.random.RandomState(5)
+    for d, alpha, c, far in [(1, 0.9, 0.5, 1.0), (3, 0.5, 0.3, 1.0), (10, 0.9, 0.7, 1.0), (16, 0.2, 0.4, 1.0), (7, 1.0, 0.5, 1.0), (5, 0.9, 0.5, 30.0)]:
+        A = rs.standard_normal((d, d))
+        S = A @ A.T + 0.3 * np.eye(d)
+        mu = rs.standard_normal(d)
+        x = mu + far * np.linalg.cholesky(S) @ rs.standard_normal(d)
+        xn = x + c * np.linalg.cholesky(S) @ rs.standard_normal(d)
+        g0, g1 = debug_proposal_densities(xn, x, mu, S, c, alpha)
+        w0, w1 = orc.proposal_densities(xn, x, mu, S, c, alpha)
+        assert g0 == pytest.approx(w0, rel=1e-11, abs=1e-11) and g1 == pytest.approx(w1, rel=1e-11, abs=1e-11), (d, alpha, g0, w0, g1, w1)
+    with pytest.raises(Exception, match="PosDef"):
+        debug_proposal_densities(np.zeros(2), np.zeros(2), np.zeros(2), np.array([[1.0, 2.0], [2.0, 1.0]]), 0.5, 0.9)

@@ -106,3 +106,18 @@ def test_a_mispredicted_resample_leaves_the_segment_and_is_redone():
     assert a["resamples"] >= 2 and a["stalls"][1] >= a["resamples"] - 1
     for k in _KEYS:
         assert a[k] == b[k], (k, a[k], b[k])
+
+
+def test_a_segment_time_out_repeats_the_run_as_launches():
+    """a hand-over inside a persistent segment that times out (the GPU shared after the residency self-test: not every block
+    resident) voids the run with the cloud already overwritten.  A single-handle run keeps the cloud and the loop state it started from
+    and repeats itself on engine 2's launches - here the time-out is forced by a bound no hand-over can meet (0.1 µs), on a fresh run
+    (reps = 2: the second run of the handle starts on engine 2 right away) and on a run that pauses and continues."""
+    for kw in (dict(use_fixed_schedule=False, tempering_target=0.95), dict(use_fixed_schedule=True, n_phi=50, pause_at=12)):
+        cfg = dict(n=30_000, d=6, seed=21, spec_args=[6], kw=kw, reps=2)
+        a = _run(cfg, {"SMCMI_SEG_TIMEOUT_MS": "0.0001"})
+        b = _run(cfg, {"SMCMI_ENGINE3": "0"})
+        for ra, rb in zip(a, b):
+            assert ra["n_segments"] == 0                       # the result comes from the repeat: launches only
+            for k in _KEYS:
+                assert ra[k] == rb[k], (k, ra[k], rb[k])
