@@ -224,6 +224,7 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
             HIP_TRY(hipStreamSynchronize(h->stream));
             done = head.done;
             if (done != 2) break;
+            if (had > 1200) return set_err(SMCMI_ERR_BRACKET, "adaptive tempering solver: the search for phi_n does not terminate (the ESS objective is not a number?)");
             // the solver ran out of passes: continue the same search with more (smcmi_run)
             const int zero = 0;
             HIP_TRY(hipMemcpyAsync(&h->d_st->done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));

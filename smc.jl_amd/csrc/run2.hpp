@@ -492,6 +492,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (!multi && !g.rccl && g.hs.size() == 1) { if (int e = seg3_ready(h0, &e3)) return e; }
     std::vector<hipEvent_t> evs3;
     int seg_launches = 0;
+    struct SegRange { int a, b; bool enter; };
+    std::vector<SegRange> seg_ranges;              // stages each segment launch was enqueued for (error diagnosis)
     if (e3) {
         static const double to_ms = getenv("SMCMI_SEG_TIMEOUT_MS") ? atof(getenv("SMCMI_SEG_TIMEOUT_MS")) : 200.0;
         if (int e = seg3_time_out_words(h0, to_ms)) return e;
@@ -664,6 +666,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         HIP_TRY(hipGetLastError());                  // (a rejected launch would otherwise surface as a bogus capacity / time-out error)
         if (e1) hipEventRecord(e1, h->stream);
         ++seg_launches;
+        seg_ranges.push_back({n_first, n_last, enter_mut});
         return 0;
     };
     auto enq_passes = [&](int n, int p0, int P) -> int {           // passes p0 .. P-1, then the closing decision
@@ -841,6 +844,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             } else if (code == 2) {
                 const int had = (sn == stall_stage) ? stall_p : (sn - base <= 3 ? first_passes : dyn_P);
                 const int more = 8;
+                // (a bracketing search halves its interval at least every pass: 1100 passes exhaust the exponent range of a double - whatever
+                // keeps a stage asking for more is not a search any more, and the host must not feed it for ever)
+                if (had > 1200) return set_err(SMCMI_ERR_BRACKET, "adaptive tempering solver: the search for phi_n does not terminate (the ESS objective is not a number?)");
                 if (int e = enq_passes(sn, had, had + more)) return e;
                 if (int e = enq_K1(sn, 1, 0)) return e;
                 if (int e = enq_select(sn)) return e;
@@ -968,7 +974,19 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return set_err(SMCMI_ERR_TIMEOUT, "engine 3: a hand-over inside a persistent stage segment timed out (SMCMI_SEG_TIMEOUT_MS); the run is void - "
                                           "repeat it (this handle now runs every stage as launches; SMCMI_ENGINE3=0 does so from the start)");
     }
-    if (s.err == SMCMI_ERR_NAN_ESS) return nan_ess_error(h0, h0->d_wt);
+    if (s.err == SMCMI_ERR_NAN_ESS) {
+        // the failing correction's unnormalised weights: the scratch column K1 wrote - unless the stage ran inside a segment (registers only)
+        const int sn = c.status.stage;
+        bool in_seg = false;
+        for (const SegRange &r : seg_ranges) in_seg |= (sn >= r.a && sn <= r.b && !(r.enter && sn == r.a));
+        if (in_seg && sn >= 2 && sn <= h0->cfg.max_stages) {
+            double ph[2] = {0.0, 0.0};
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpy(ph, h0->rec.phi + (sn - 2), sizeof(ph), hipMemcpyDeviceToHost));
+            return nan_ess_error_from_cloud(h0, ph[1], ph[0], rc->tempered_update_prior_weight, rc->log_prob_old_data);
+        }
+        return nan_ess_error(h0, h0->d_wt);
+    }
     if (s.err) return err_from_state(s.err);
     if (!(c.status.code == 1 || c.status.code == 5)) return set_err(SMCMI_ERR_CAPACITY, "max_stages exceeded before the tempering schedule reached 1");
     return 0;

@@ -341,16 +341,25 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     const bool adaptive = !rc->use_fixed_schedule;
     const int P_default = adaptive ? (rc->solver_passes >= 1 ? rc->solver_passes : SHARDED_SOLVER_PASSES) : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
-    const bool predict = adaptive && !no_pred;
+    // User likelihoods on the host (the reference's default use: smc(loglikelihood::Function, ...) with parallel = true, src/smc_main.jl:118,
+    // 472-476): every shard scores the proposals of ITS particles through its registered callback (callback.hpp host_mutation: propose
+    // kernel -> closure on the calling thread -> accept kernel), everything else - solver passes, correction, selection, moments,
+    // proposal set-up, the collectives - is this driver's.  The callback mutation leaves neither energy sums nor energy maxima, so
+    // such runs walk the schedule without a predictor, unshifted, one stage per host sync (the closure needs the host anyway).
+    const bool host_mut = h0->cb[0] != nullptr, tempered_cb = h0->cb[1] != nullptr;
+    for (auto *h : g.hs)
+        if ((h->cb[0] != nullptr) != host_mut || (h->cb[1] != nullptr) != tempered_cb) return set_err(SMCMI_ERR_STATE, "every shard needs the same likelihood callbacks");
+    const bool predict = adaptive && !no_pred && !host_mut;
     static const int sel_mode = getenv("SMCMI_NO_SELECT_PREDICT") ? atoi(getenv("SMCMI_NO_SELECT_PREDICT")) : 0;   // development only
-    const bool predict_select = adaptive && can_fuse_post(h0) && sel_mode != 1;
+    const bool predict_select = adaptive && can_fuse_post(h0) && sel_mode != 1 && !host_mut;
     std::vector<double> sched(rc->n_phi);
     for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
         if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
         if (ensure_shard_buffers(h) || pull_state(h) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
-        if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
+        if (host_mut) { if (int e = ensure_callback_buffers(h)) return e; h->rng_ahead = false; h->cb_calls = 0; h->cb_evals = 0; }
+        else if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
         DevState &s = h->h_st;
         RunParams rp{};
         rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;
@@ -391,6 +400,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     // stage 1's energy shift: largest energy of the initial cloud over all shards (slots after the ES row: a sum all-reduce
     // in which every shard fills only its own slot is a gather)
     if (g.world > MAX_SHARDS) return set_err(SMCMI_ERR_ARG, "too many shards");
+    if (!host_mut) {
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
         const int nb0 = mut_blocks(h);
@@ -398,6 +408,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         k_emax_publish<<<1, TB, 0, h->stream>>>(h->d_emax_part, nb0, h->d_tot_acc + ES, shard_rank(h), g.world);
     }
     if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, g.world)) return rc2;
+    } else {                                  // stage 2's begin folds "the last acceptance rate": none yet
+        for (auto *h : g.hs) { HIP_TRY(hipSetDevice(h->cfg.device)); HIP_TRY(hipMemsetAsync(h->d_tot_acc, 0, sizeof(double) * (ES + MAX_SHARDS), h->stream)); }
+    }
     // One stage = the single-GPU launch sequence with the collectives in-stream.  Nothing in it needs the host: on an adaptive
     // schedule resampling is predictable (smcmi_run), so the selection path - all-gather of weights and shard clouds, global
     // scan, gather - is enqueued exactly where a resample is expected (its kernels gate themselves on the device's decision)
@@ -433,7 +446,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
                     HIP_TRY(hipSetDevice(h->cfg.device));
                     h->run_adaptive = predict;
                     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_tot_acc + EACC, 1, h->rec, predict ? h->d_tot_acc : nullptr, nullptr,
-                                                   h->spec_stage ? 1 : 0, h->d_tot_acc + ES, g.world);
+                                                   h->spec_stage ? 1 : 0, host_mut ? nullptr : h->d_tot_acc + ES, g.world);
                 }
             for (int p = p0; p < P; ++p) {
                 for (auto *h : g.hs) {
@@ -562,6 +575,22 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             }
         }
         if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_mom; }, h0->npairs)) return rc2;
+        if (host_mut) {
+            // the closure scores every shard's proposals; a stage that did not run on the device (stall, pause, ϕ = 1 reached, error - the
+            // same on every rank: all decisions come from all-reduced totals) must not reach it
+            for (auto *h : g.hs) { HIP_TRY(hipSetDevice(h->cfg.device)); launch_prepare_in_run(h, h->d_tot_mom, 1, 2); }
+            int dn = 0;
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(&dn, &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipStreamSynchronize(h0->stream));
+            if (dn) return 0;
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                if (int e = host_mutation(h, rc, tempered_cb)) return e;
+                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_tot_acc + EACC);
+            }
+            return g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1);
+        }
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             launch_prepare_in_run(h, h->d_tot_mom, 1, 2);
@@ -595,7 +624,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     int dyn_P = P_default;                    // raised when stages keep running out of passes
     int stages_left_est = 1 << 30;            // (1 - ϕ_n) / (ϕ_n - ϕ_{n-1}) at the last sync (smcmi_run)
     while (iters < max_iter && !done) {
-        const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), max_iter - iters) : max_iter - iters;
+        const int batch = host_mut ? 1 : (adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), max_iter - iters) : max_iter - iters);
         for (int b = 0; b < batch; ++b) {
             int mode = 0;
             if (predict_select) {
@@ -703,14 +732,15 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
 }
 
 extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
-    if (int e = need_model(h, true)) return e;
+    if (int e = need_model(h, 2)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
     if (!h->nccl && !h->has_hostc) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init / smcmi_comm_init_host has not been called on this handle");
+    if (int e = check_lik_pair(h)) return e;
     ShardGroup g;
     g.hs = {h}; g.world = h->world; g.rccl = true; g.hostc = h->has_hostc;
-    if (eng2_eligible(h, g.world)) return run2_impl(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
-    return run_sharded_impl(g, rc, res);
+    if (!h->cb[0] && eng2_eligible(h, g.world)) return run2_impl(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
+    return run_sharded_impl(g, rc, res);                                             // n_para > 10, and every run with a host likelihood
 }
 
 extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res) {
@@ -719,7 +749,8 @@ extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_con
     ShardGroup g;
     long long expect = 0;
     for (int k = 0; k < n; ++k) {
-        if (int e = need_model(hs[k], true)) return e;
+        if (int e = need_model(hs[k], 2)) return e;
+        if (int e = check_lik_pair(hs[k])) return e;
         if (hs[k]->cfg.gid0 != expect || hs[k]->cfg.n_local != hs[0]->cfg.n_local || hs[k]->cfg.n_parts != hs[0]->cfg.n_parts)
             return set_err(SMCMI_ERR_ARG, "group handles must be equal contiguous shards in rank order");
         expect += hs[k]->cfg.n_local;
@@ -727,6 +758,6 @@ extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_con
     }
     if (expect != hs[0]->cfg.n_parts) return set_err(SMCMI_ERR_ARG, "group handles do not cover n_parts");
     g.world = n; g.rccl = false;
-    if (eng2_eligible(hs[0], g.world)) return run2_impl(g, rc, res);
+    if (!hs[0]->cb[0] && eng2_eligible(hs[0], g.world)) return run2_impl(g, rc, res);
     return run_sharded_impl(g, rc, res);
 }

@@ -71,16 +71,14 @@ static int err_from_state(int code) {
 // check_nan_ess (src/helpers.jl:270-305): the reference's diagnosis of "ESS is NaN", from the unnormalised weights W̃ the failing
 // correction left (`wbuf`: the scratch column of engine 2 / of a predicted stage, else the cloud's weight column) and the stage's
 // incremental weights where the history is stored.
-static int nan_ess_error(smcmi_handle *h, const double *wbuf) {
+static int nan_ess_message(long long n_parts, const std::vector<double> &inc, const std::vector<double> &w, bool ok) {
     std::string msg = "No particles have non-zero weight.";
-    const long long n = h->n;
-    std::vector<double> w((size_t)n);
-    bool ok = hipMemcpy(w.data(), wbuf, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
     if (ok) {
         bool any_inf = false, any_nan = false;
         double s = 0.0, s2 = 0.0;
-        for (long long i = 0; i < n; ++i) { any_inf |= std::isinf(w[i]); any_nan |= std::isnan(w[i]); s += w[i]; }
-        for (long long i = 0; i < n; ++i) { const double v = (double)h->cfg.n_parts * w[i] / s; s2 += v * v; }
+        for (double v : inc) { any_inf |= std::isinf(v); any_nan |= std::isnan(v); }
+        for (double v : w) s += v;
+        for (double v : w) { const double u = (double)n_parts * v / s; s2 += u * u; }
         if (any_inf) msg += " Some particles have approximately infinite log-likelihoods.";
         if (any_nan) msg += " Some particles have approximately NaN log-likelihoods.";
         if (s2 <= 2.220446049250313e-16) msg += " The squared sum of the normalized weights is at machine-error.";
@@ -90,6 +88,32 @@ static int nan_ess_error(smcmi_handle *h, const double *wbuf) {
         }
     }
     return set_err(SMCMI_ERR_NAN_ESS, msg + " (ESS is NaN)");
+}
+static int nan_ess_error(smcmi_handle *h, const double *wbuf) {
+    std::vector<double> w((size_t)h->n);
+    const bool ok = hipMemcpy(w.data(), wbuf, sizeof(double) * h->n, hipMemcpyDeviceToHost) == hipSuccess;
+    return nan_ess_message(h->cfg.n_parts, w, w, ok);
+}
+// The same diagnosis for a stage that failed INSIDE a persistent segment (engine 3): its unnormalised weights lived in registers only.
+// The segment leaves the cloud as stage n - 1 completed it, so the failing correction (src/smc_main.jl:401-420) is repeated here, on
+// the host, for the message alone.
+static int nan_ess_error_from_cloud(smcmi_handle *h, double phi_n, double phi_prev, double pw, double logp_old) {
+    const long long n = h->n;
+    const int d = h->d;
+    std::vector<double> lk((size_t)n), old((size_t)n), W((size_t)n), inc((size_t)n), w((size_t)n);
+    const double *c = h->cl.buf[0];
+    const bool ok = hipMemcpy(lk.data(), c + (long long)d * n, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(old.data(), c + (long long)(d + 2) * n, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(W.data(), c + (long long)(d + 4) * n, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok)
+        for (long long i = 0; i < n; ++i) {
+            const double dphi = phi_n - phi_prev;
+            if (pw == 0.0) inc[i] = exp(-dphi * old[i] + dphi * lk[i]);
+            else if (pw == 1.0) inc[i] = exp(dphi * lk[i]);
+            else inc[i] = exp(-dphi * log(exp(old[i] - logp_old + log(1.0 - pw)) + pw) + dphi * lk[i]);
+            w[i] = W[i] * inc[i];
+        }
+    return nan_ess_message(h->cfg.n_parts, inc, w, ok);
 }
 
 static int set_mutate_attrs(smcmi_handle *h);
@@ -947,6 +971,15 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     if (ev1) hipEventRecord(ev1, s);
 }
 
+// a (host closure, device family) pair in a tempered update: the callback path would score the old likelihood as 0, the device path
+// would call a device family that does not exist - refuse instead of sampling the wrong posterior
+static int check_lik_pair(const smcmi_handle *h) {
+    const int f1 = h->h_model.lik[1].family;
+    const bool old_dev = f1 != SMCMI_LIK_NONE && f1 != SMCMI_LIK_HOST_CALLBACK, old_cb = h->cb[1] != nullptr;
+    if ((h->cb[0] && old_dev) || (!h->cb[0] && old_cb))
+        return set_err(SMCMI_ERR_UNSUPPORTED, "the new and the old likelihood must both be device families or both host callbacks");
+    return 0;
+}
 struct ShardGroup;
 static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
 static bool eng2_eligible(const smcmi_handle *h, int world);
@@ -957,13 +990,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
     res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
-    {   // a (host closure, device family) pair in a tempered update: the callback path would score the old likelihood as 0, the device
-        // path would call a device family that does not exist - refuse instead of sampling the wrong posterior
-        const int f1 = h->h_model.lik[1].family;
-        const bool old_dev = f1 != SMCMI_LIK_NONE && f1 != SMCMI_LIK_HOST_CALLBACK, old_cb = h->cb[1] != nullptr;
-        if ((h->cb[0] && old_dev) || (!h->cb[0] && old_cb))
-            return set_err(SMCMI_ERR_UNSUPPORTED, "the new and the old likelihood must both be device families or both host callbacks");
-    }
+    if (int e = check_lik_pair(h)) return e;
     if (h->cb[0]) return run_callback(h, rc, res);                    // user likelihood on the host (callback.hpp)
     if (eng2_eligible(h, 1)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
     const int nf = h->h_model.n_free;
@@ -1127,6 +1154,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 // A stage exhausted its solver passes: it and everything enqueued behind it did nothing.  Clear the stall, give
                 // that stage more passes (continuing the same search), and go on from the stage after it.
                 const int more = 8;
+                if (had > 1200) return set_err(SMCMI_ERR_BRACKET, "adaptive tempering solver: the search for phi_n does not terminate (the ESS objective is not a number?)");
                 enqueue_stage(h, adaptive, more, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, had);
                 stall_stage = st_i; stall_p = had + more;
                 res->solver_stalls += 1;

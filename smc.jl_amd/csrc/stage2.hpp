@@ -719,7 +719,12 @@ static __global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st,
     const double phi_prev = ctl->bg.phi_prev, esh = st->rp.pw == 0.0 ? ctl->bg.e_shift : 0.0;
     if (bstage != n || bfinal) return;
     solver_prologue2(st, sched, prev, p, &S, s_vt, s_tot, s_srt, 0, &s_flag, T1);
-    if (s_flag) return;                                   // an error: k2_finish reports it
+    if (s_flag) {                                         // an error (the objective is NaN at the walk's end: fzero's bracket error, helpers.jl:49-50)
+        // reported HERE: the solver copy is idle from now on, so neither the passes behind this one nor k2_finish see the error again -
+        // without the status the host would feed an idle search more passes for ever
+        if (blockIdx.x == 0 && threadIdx.x == 0 && s_flag < 0) { ctl->status.err = s_flag; ctl->status.stage = n; ctl->status.code = 9; }
+        return;
+    }
     const int mode = S.mode;
     if (mode != MODE_SCAN && mode != MODE_SECTION) return;
     const int nv = S.n_valid, R = cl.R;
@@ -752,6 +757,7 @@ static __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, 
     __shared__ Solver S;
     __shared__ int s_flag;
     if (ctl->bg.stage != n || ctl->bg.final) return;
+    if (ctl->status.code == 9 && ctl->status.stage == n) return;       // a pass of this stage has reported an error
     solver_prologue2(st, sched, prev, P, &S, s_vt, s_tot, s_srt, 1, &s_flag, T1);
     if (threadIdx.x != 0) return;
     if (s_flag < 0) { ctl->status.err = s_flag; ctl->status.stage = n; ctl->status.code = 9; return; }

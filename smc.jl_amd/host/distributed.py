@@ -9,10 +9,10 @@ C ABI that `bench.py --gpus N` and the multi-process tests share:
   connect()      the communicator: RCCL over xGMI (`comm="rccl"`, one GPU per rank; unique id broadcast through torch.distributed)
                  or the host-mediated one (`comm="host"`: the library's collectives carried by torch.distributed on CPU tensors -
                  gloo - for ranks that share a GPU or have no RCCL)
-  run()          smcmi_run_sharded; with host closures the host-orchestrated loop (shard_orchestrator.ShardedSMC)
+  run()          smcmi_run_sharded - device likelihood families and host closures alike (a closure is registered on the shard's handle
+                 and scores the proposals of the particles that shard holds: the reference's `parallel = true`, src/smc_main.jl:472-476)
 
 The peer mailbox (include/smcmi.h) is set up by the library on the first run through whichever communicator is connected.
-(The older host-side orchestration over the shard-level C calls lives in shard_orchestrator.py.)
 """
 from .engine import Engine, comm_unique_id, torch_dist_host_comm
 
@@ -44,18 +44,13 @@ def connect(eng, rank, world, comm="rccl", group=None):
     return eng
 
 
-def run(eng, spec=None, loglikelihood=None, old_loglikelihood=None, **kw):
-    """The sharded loop on rank's shard `eng`.  Device likelihood families: smcmi_run_sharded (the product driver, communicator from
-    connect()).  Host closures (`loglikelihood(theta (m, d)) -> (m,)`, the reference's user function with `parallel = true`: every
-    worker scores the particles it holds, src/smc_main.jl:472-476): the stage loop is driven from the host over the shard-level C
-    calls with torch.distributed carrying the few all-reduces (shard_orchestrator.ShardedSMC; pass the model `spec` whose
-    likelihood entry is ("host_callback", [], None, None)); the mutation is propose -> closure -> accept on every shard."""
-    if loglikelihood is None:
-        return eng.run_sharded(**kw)
-    from .shard_orchestrator import ShardedSMC
-
-    if spec is None:
-        raise ValueError("run(eng, loglikelihood=...) needs the model spec the shard was opened with")
-    sm = ShardedSMC(spec, eng.n_parts, seed=eng.seed, engine=eng, max_stages=eng.max_stages, loglikelihood=loglikelihood,
-                    old_loglikelihood=old_loglikelihood)
-    return sm.run(**kw)
+def run(eng, loglikelihood=None, old_loglikelihood=None, **kw):
+    """The sharded loop on rank's shard `eng`: smcmi_run_sharded (the product driver, communicator from connect()).  Host closures
+    (`loglikelihood(theta (m, d)) -> (m,)`, the reference's user function: every worker scores the particles it holds) are registered
+    on the handle first - open the shard with a model spec whose likelihood entry is ("host_callback", [], None, None); the driver then
+    runs propose -> closure -> accept per MH step and block on every shard, everything else as for device families."""
+    if loglikelihood is not None:
+        eng.set_likelihood_callback(loglikelihood, which=0)
+        if old_loglikelihood is not None:
+            eng.set_likelihood_callback(old_loglikelihood, which=1)
+    return eng.run_sharded(**kw)

@@ -385,7 +385,7 @@ class Engine:
     def sync(self):
         check(self._L.smcmi_sync(self._h))
 
-    # ---- shard-level calls (multi-GPU hosts; see host/shard_orchestrator.py) ------------------------------------
+    # ---- shard-level calls (multi-GPU hosts that drive the stage loop themselves; tests/shard_orchestrator.py) ------------
     tensor_device = "cuda"
 
     def _comm(self, count):

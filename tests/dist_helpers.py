@@ -1,6 +1,6 @@
 """Test-only helpers for the sharded path: an oracle-backed shard engine (CPU) and an in-process thread communicator.
 
-OracleShardEngine implements the engine protocol of smc_jl_amd.host.shard_orchestrator.ShardedSMC with numpy + the CPU oracle,
+OracleShardEngine implements the engine protocol of tests.shard_orchestrator.ShardedSMC with numpy + the CPU oracle,
 so the orchestration (collectives, replicated scalar logic, resample exchange) runs under gloo without a GPU.
 It lives under tests/ because only tests may touch oracle/.
 """
@@ -121,7 +121,7 @@ def gloo_worker(rank, world, port, spec_name, n_parts, seed, kw, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from smc_jl_amd.host.shard_orchestrator import ShardedSMC, TorchComm
+        from tests.shard_orchestrator import ShardedSMC, TorchComm
         from tests import models
 
         spec = getattr(models, spec_name)()

@@ -128,3 +128,18 @@ def oracle_model(spec):
         return orc.Lik("none") if l is None else orc.Lik(l[0], l[1], l[2], l[3])
 
     return orc.Model(spec["priors"], spec["bounds"], mk(spec["lik"]), mk(spec["old_lik"]), spec["fixed"])
+
+
+def gauss_closures(spec, tempered=False):
+    """The gauss_iso likelihood of `spec` as HOST closures theta (m, d) -> (m,) - what a user hands to smc(loglikelihood, ...)
+    (src/smc_main.jl:118); tempered: a second, wider one as `old_loglikelihood` (generalized tempering, src/mutation.jl:96-106)."""
+    m, sigma = np.asarray(spec["lik"][2]).ravel(), float(spec["lik"][1][0])
+    d = m.size
+
+    def lik(theta, s=sigma):
+        return -0.5 * d * np.log(2.0 * np.pi * s * s) - 0.5 * (((theta - m) / s) ** 2).sum(axis=1)
+
+    fns = [lik]
+    if tempered:
+        fns.append(lambda theta: lik(theta, 3.0 * sigma))
+    return dict(fns=fns)

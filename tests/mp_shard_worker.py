@@ -26,8 +26,16 @@ def main():
 
         spec = getattr(models, cfg.get("spec", "gauss_spec"))(*cfg.get("spec_args", []))
         n, d, seed = cfg["n"], cfg["d"], cfg["seed"]
+        closures = {}
+        if cfg.get("closure"):                         # the likelihood as a HOST closure on every shard (smc(loglikelihood::Function, ...), parallel = true)
+            closures = models.gauss_closures(spec, tempered=cfg["closure"] == "tempered")
+            spec = dict(spec, lik=("host_callback", [], None, None), old_lik=("host_callback", [], None, None) if cfg["closure"] == "tempered" else None)
         eng = shd.open_shard(spec, n, d, rank, world, seed=seed, device=0, max_stages=cfg.get("max_stages", 1500), store_history=False)
+        for which, fn in enumerate(closures.get("fns", [])):
+            eng.set_likelihood_callback(fn, which=which)
         eng.init_from_prior()
+        if cfg.get("closure") == "tempered":
+            eng.eval_cloud_callback(which=1, column=d + 2)      # old_loglh of the initial cloud (a bridge from prior draws)
         shd.connect(eng, rank, world, comm="host")
         runs = []
         for rep in range(cfg.get("reps", 1)):
@@ -49,6 +57,8 @@ def main():
                              accept=hashlib.sha256(np.ascontiguousarray(rec["accept_hist"]).tobytes()).hexdigest(),
                              stalls=[r.get("solver_stalls", 0), r.get("select_stalls", 0), r.get("spec_stalls", 0)],
                              mailbox=bool(eng.mailbox_active()), seconds=r["seconds"]))
+            if cfg.get("full_records"):
+                runs[-1]["schedule_values"] = [float(x) for x in rec["schedule"]]
         np.save(os.path.join(out, "cloud%d.npy" % rank), cloud)
         with open(os.path.join(out, "rank%d.json" % rank), "w") as f:
             json.dump(runs, f)

@@ -1,4 +1,7 @@
-"""ShardedSMC: the SMC loop over particles sharded across ranks (one MI355X per process).
+"""ShardedSMC: TEST DOUBLE of the sharded loop - the stage sequence of csrc/sharded.hpp driven from Python over the shard-level C calls
+(smcmi_shard_*), with the collectives as injectable callables.  The product path is smcmi_run_sharded (Engine.run_sharded; host closures
+included since round 4); this file stays under tests/ because it lets the N > 1 logic run on CPU (gloo, world_size 2, an oracle-backed
+engine: tests/test_distributed_cpu.py) and cross-checks the shard-level entry points on the GPU (tests/test_gpu_sharded.py).
 
 Replaces the reference's only parallel mode - `@distributed` over particles with the whole cloud serialised to every
 worker each stage (src/smc_main.jl:169-170, 472-476) - by resident shards plus a handful of tiny collectives:
@@ -21,7 +24,7 @@ import time
 
 import numpy as np
 
-from . import hostmath as hm
+from smc_jl_amd.host import hostmath as hm
 
 
 class TorchComm:
@@ -80,7 +83,7 @@ class ShardedSMC:
         self.d = len(spec["priors"])
         self.seed, self.max_stages = seed, max_stages
         if engine is None:
-            from .engine import Engine
+            from smc_jl_amd.host.engine import Engine
 
             engine = Engine(n_parts, self.d, seed=seed, device=device, max_stages=max_stages, store_history=store_history,
                             n_local=self.n_local, gid0=self.gid0)

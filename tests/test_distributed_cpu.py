@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: smc_jl_amd.host.shard_orchestrator.ShardedSMC under torch.distributed/gloo with world_size 2.
+"""N > 1 path on CPU: tests.shard_orchestrator.ShardedSMC under torch.distributed/gloo with world_size 2.
 
 The per-shard compute is the oracle-backed engine of tests/dist_helpers.py; what is under test is the orchestration
 (collectives, replicated scalar logic, global-id RNG, resample exchange): a 2-rank sharded run must reproduce the

@@ -14,7 +14,7 @@ So the full-size test asserts what a defect in the engine that serves this size 
   * every bracketed stage - the run paused after stage k - 1 and after stage k, the oracle repeating exactly that stage on the downloaded
     cloud - has the oracle's ancestors, ZERO flipped decisions on the strict-FP build (≤ 3 on the product build), the oracle's weights to
     1e-11 and the oracle's values to rounding, early and late in the run, with and without a resample;
-  * the two whole runs agree to rounding over a long prefix (≥ 40 stages with ESS within 1e-6 relative, the same resample stages, partial
+  * the two whole runs agree to rounding over a long prefix (≥ 40 stages with ESS within 1e-8 relative, the same resample stages, partial
     log-MDD sums within 1e-6) - a systematic error would part them at once;
   * the final log-MDDs are within the estimator's own spread."""
 import json
@@ -49,8 +49,8 @@ del w, Wn
 r = orc.smc_run(m, P0, seed=seed, n_threads=64, history=True, **kw)
 inc_c = np.log(np.sum(r["w"][:, 1:] * r["W"][:, :-1], axis=0) / n)
 rel = np.abs(rec["ess"] - r["ess"]) / r["ess"]
-part = np.nonzero(rel > 1e-6)[0]
-k_part = int(part[0]) + 1 if part.size else 301                      # first stage whose ESS differs beyond rounding drift
+part = np.nonzero(rel > 1e-8)[0]
+k_part = int(part[0]) + 1 if part.size else 301                      # first stage whose ESS differs beyond rounding drift (the first flipped decision shows as ~1e-7)
 out = dict(logmdd_gpu=g["logmdd"], logmdd_cpu=r["logmdd"], n_stages=[g["n_stages"], r["n_stages"]], k_part=k_part,
            prefix_inc_err=float(abs(np.sum(inc_g[:k_part - 2] - inc_c[:k_part - 2]))),
            prefix_resampled_equal=bool(np.array_equal(rec["resampled"][:k_part - 1], r["resampled"][:k_part - 1])),

@@ -144,3 +144,58 @@ def test_bench_py_with_two_ranks_on_one_gpu():
     assert "one GPU" in d["config"]["hand_over"]
     assert d["speedup_vs_single_gpu"] > 0 and d["logmdd_abs_diff_vs_single_gpu"] == 0.0      # the same bits as the single handle (engine 3 there, engine 2 here)
     assert abs(d["logmdd_gpu"] - models.gauss_logmdd(10)) < 0.3
+
+
+@pytest.mark.parametrize("mode", ["closure", "tempered"])
+def test_host_closures_through_the_sharded_product_driver(mode, tmp_path):
+    """VERDICT r3 missing 3: the reference's default use - smc(loglikelihood::Function, ...) with parallel = true, every worker scoring
+    the particles it holds (src/smc_main.jl:118, 472-476) - through smcmi_run_sharded itself: two PROCESSES, each with its shard and its
+    registered closure (propose kernel -> closure -> accept kernel per MH step x block), the collectives over the host communicator;
+    against ONE handle running the same closure through smcmi_run's callback path.  Same stages and resample decisions, log-MDD to 1e-8,
+    the same cloud (particle ids are global: a shard proposes exactly what the single handle proposes for its rows).  "tempered": an
+    old-data closure beside the new one (generalized tempering, src/mutation.jl:96-106)."""
+    cfg = dict(n=20000, d=5, seed=21, spec_args=[5], closure=mode, kw=dict(use_fixed_schedule=False, tempering_target=0.9, n_blocks=2, n_mh_steps=2, alpha=0.9))
+    code = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from smc_jl_amd import Engine
+from tests import models
+cfg = json.loads(%r)
+spec = models.gauss_spec(*cfg["spec_args"])
+cl = models.gauss_closures(spec, tempered=cfg["closure"] == "tempered")
+spec = dict(spec, lik=("host_callback", [], None, None), old_lik=("host_callback", [], None, None) if cfg["closure"] == "tempered" else None)
+e = Engine(cfg["n"], cfg["d"], seed=cfg["seed"], max_stages=1500, store_history=False)
+e.set_model(spec)
+for which, fn in enumerate(cl["fns"]): e.set_likelihood_callback(fn, which=which)
+e.init_from_prior()
+if cfg["closure"] == "tempered": e.eval_cloud_callback(which=1, column=cfg["d"] + 2)
+r = e.run(**cfg["kw"])
+rec = e.stage_records(r["n_stages"])
+np.save(sys.argv[1], e.download_cloud())
+print("RESULT " + json.dumps(dict(n_stages=r["n_stages"], resamples=r["resamples"], logmdd=r["logmdd"], schedule=[float(x) for x in rec["schedule"]], calls=e.callback_stats()["calls"])))
+''' % (ROOT, json.dumps(cfg))
+    path = str(tmp_path / "single.npy")
+    p = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    want = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    want_cloud = np.load(path)
+    assert want["n_stages"] > 10 and want["resamples"] >= 1 and want["calls"] >= (want["n_stages"] - 1) * 4
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = str(tmp_path)
+    wcfg = dict(cfg, full_records=True)
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.mp_shard_worker", str(r), "2", str(port), out, json.dumps(wcfg)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for r, pr in enumerate(procs):
+        so, se = pr.communicate(timeout=900)
+        assert pr.returncode == 0, "rank %d: %s" % (r, se[-3000:])
+    runs = [json.load(open(os.path.join(out, "rank%d.json" % r)))[0] for r in range(2)]
+    cloud = np.concatenate([np.load(os.path.join(out, "cloud%d.npy" % r)) for r in range(2)], axis=0)
+    for r in runs:
+        assert r["n_stages"] == want["n_stages"] and r["resamples"] == want["resamples"]
+        np.testing.assert_allclose(r["schedule_values"], want["schedule"], rtol=1e-9)
+        assert float.fromhex(r["logmdd"]) == pytest.approx(want["logmdd"], abs=1e-8)
+    np.testing.assert_allclose(cloud, want_cloud, rtol=1e-7, atol=1e-9)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run_sharded_threads(spec, n, seed, world, kw):
     from smc_jl_amd import Engine
-    from smc_jl_amd.host.shard_orchestrator import ShardedSMC
+    from tests.shard_orchestrator import ShardedSMC
 
     import torch
 
@@ -299,7 +299,7 @@ def test_host_closures_on_shards_match_one_handle():
     handle running the same closure through smcmi_run's callback path: same stages and resample decisions, log-MDD to 1e-8, same cloud
     (particle ids are global: a shard proposes exactly what the single handle proposes for its rows)."""
     from smc_jl_amd import Engine
-    from smc_jl_amd.host.shard_orchestrator import ShardedSMC
+    from tests.shard_orchestrator import ShardedSMC
 
     import torch
 
@@ -361,7 +361,7 @@ def test_host_closures_on_shards_tempered_update():
     """The same with an old vintage: `loglikelihood` and `old_loglikelihood` both host closures (generalized tempering,
     src/mutation.jl:96-106), every shard scoring its own proposals with both; against one handle with the two callbacks."""
     from smc_jl_amd import Engine
-    from smc_jl_amd.host.shard_orchestrator import ShardedSMC
+    from tests.shard_orchestrator import ShardedSMC
 
     import torch
 
