@@ -1,4 +1,4 @@
-// inst2.hip - one n_para's instantiations of the engine 2 kernels (compile with -DSMCMI_INST_D=<1..10>; see launch2.hpp).
+// inst2.hip - one n_para's instantiations of the engine 2 kernels (compile with -DSMCMI_INST_D=<1..16>; see launch2.hpp).
 #ifndef SMCMI_INST_D
 #error "compile with -DSMCMI_INST_D=<n_para>"
 #endif

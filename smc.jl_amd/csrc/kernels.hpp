@@ -1913,51 +1913,19 @@ struct MutStage {
 constexpr int mutate_wave_bytes_ls4(int d) {
     return (2 * d * 16 * 8 + ((2 * d * 16 * 8 > 16 * KALMAN4_SLOT_BYTES) ? 2 * d * 16 * 8 : 16 * KALMAN4_SLOT_BYTES) + 15) / 16 * 16;
 }
-template <int MODE, int LS = 1>
-__global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma, double *acc_partials,
-                         int standalone) {
-    static_assert(LS == 1 || (LS == 4 && MODE == 0), "lane-split mutation: MODE 0 only");
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (!standalone && st->done) return;
-    const int T = (LS == 4) ? 16 : blockDim.x;                    // stride of the per-particle LDS vectors
-    const int tid = (LS == 4) ? ((threadIdx.x & 63) >> 2) : threadIdx.x;   // column in them
-    const int quad_lane = threadIdx.x & 3;
-    const bool lead = (LS == 1) || quad_lane == 0;
-    const int d = md->d, nf = md->n_free;
-    double *wave_base = (LS == 4) ? sm + (long long)(threadIdx.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : sm;
-    double *th = wave_base;                // current θ           [d][T]
-    double *tn = th + (long long)d * T;    // proposed θ          [d][T]
-    double *y = tn + (long long)d * T;     // z / draw            [d][T]
-    double *v = y + (long long)d * T;      // triangular-solve scratch [d][T]
-    double *red = (LS == 4) ? sm + (long long)(blockDim.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : v + (long long)d * T;    // [blockDim.x/64]
-    const long long i = (LS == 4) ? (long long)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2) : (long long)blockIdx.x * T + tid;
-    const bool live = i < cl.n;
-    constexpr int src = 0;
-    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
-    const unsigned stage = st->mut_stage;
-    const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
-    const int nb = st->n_blocks, n_steps = st->mut_steps;
-    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
-    // LS = 1: the same staging when the host reserved the room (MODE 0, n_para <= 13: ma.stage_consts)
-    const bool staged = (LS == 4) || (MODE == 0 && ma.stage_consts && d <= 13);
-    MutStage *S = staged ? (MutStage *)(red + 8) : nullptr;
-    if (staged) {
-        for (int e = threadIdx.x; e < d * d; e += blockDim.x) S->L[e] = st->L[e];
-        if ((int)threadIdx.x < d) {
-            const int e = threadIdx.x;
-            S->mu_b[e] = st->mu_b[e]; S->sd_draw[e] = st->sd_draw[e]; S->sd_dens[e] = st->sd_dens[e]; S->logdet[e] = st->logdet[e];
-            S->lo[e] = md->lo[e]; S->hi[e] = md->hi[e]; S->prior_a[e] = md->prior_a[e]; S->prior_b[e] = md->prior_b[e]; S->prior_k[e] = md->prior_k[e];
-            S->blocks_all[e] = st->blocks_all[e]; S->l_off[e] = st->l_off[e]; S->fixed[e] = md->fixed[e]; S->prior_family[e] = md->prior_family[e];
-        }
-        if ((int)threadIdx.x <= d) S->block_ptr[threadIdx.x] = st->block_ptr[threadIdx.x];
-        __syncthreads();
-    }
-    // (otherwise the same arrays are read where they are)
-    const double *a_L = staged ? S->L : st->L, *a_mu = staged ? S->mu_b : st->mu_b, *a_sdd = staged ? S->sd_draw : st->sd_draw;
-    const double *a_sdn = staged ? S->sd_dens : st->sd_dens, *a_logdet = staged ? S->logdet : st->logdet;
-    const int *a_bptr = staged ? S->block_ptr : st->block_ptr, *a_ball = staged ? S->blocks_all : st->blocks_all, *a_loff = staged ? S->l_off : st->l_off;
-    const ModelView mv{d, staged ? S->fixed : md->fixed, staged ? S->prior_family : md->prior_family, staged ? S->lo : md->lo, staged ? S->hi : md->hi,
-                       staged ? S->prior_a : md->prior_a, staged ? S->prior_b : md->prior_b, staged ? S->prior_k : md->prior_k};
+// The Metropolis-Hastings moves of ONE particle (src/mutation.jl:56-138; mixture draw helpers.jl:87-100, proposal densities :128-164,
+// bounds, log-prior, device likelihood) for any n_para, with the per-particle vectors in LDS columns th / tn / y / v ([k][T], column tid):
+// the body of the generic mutation kernel k_mutate below (engine 1, host-callback split) and of engine 2's kernel for n_para > 10
+// (stage2.hpp k2w_mutate).  The stage's proposal arrives as plain arrays (a_*: packed block factors, block means, marginal scales,
+// log-determinants, block structure) - DevState, or an LDS staging of it.  MODE / LS as k_mutate.  `src`: cloud buffer to read the
+// particle from.  Every lane of the block calls (the lane-split Kalman filter needs whole wavefronts); results for `live` lanes.
+template <int MODE, int LS>
+__device__ __forceinline__ void mutate_generic(const CloudPtrs &cl, const ModelDev *md, const MutArgs &ma, double *th, double *tn, double *y, double *v, const int T,
+                                               const int tid, const int quad_lane, const long long i, const bool live, const int src, const unsigned long long pid,
+                                               const unsigned stage, const double c_alpha, const double phi_n, const int nb, const int n_steps, const int d,
+                                               const double *a_L, const double *a_mu, const double *a_sdd, const double *a_sdn, const double *a_logdet,
+                                               const int *a_bptr, const int *a_ball, const int *a_loff, const ModelView &mv, double &like, double &lprior,
+                                               double &like_prev, double &accept) {
     if (live) {
         like = col(cl, src, d)[i]; lprior = col(cl, src, d + 1)[i]; like_prev = col(cl, src, d + 2)[i];
         load_columns(cl.buf[src], cl.n, i, d, th + tid, T);
@@ -2150,6 +2118,55 @@ __global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState 
             }
         }
     }
+}
+
+template <int MODE, int LS = 1>
+__global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState *st, const ModelDev *md, MutArgs ma, double *acc_partials,
+                         int standalone) {
+    static_assert(LS == 1 || (LS == 4 && MODE == 0), "lane-split mutation: MODE 0 only");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (!standalone && st->done) return;
+    const int T = (LS == 4) ? 16 : blockDim.x;                    // stride of the per-particle LDS vectors
+    const int tid = (LS == 4) ? ((threadIdx.x & 63) >> 2) : threadIdx.x;   // column in them
+    const int quad_lane = threadIdx.x & 3;
+    const bool lead = (LS == 1) || quad_lane == 0;
+    const int d = md->d, nf = md->n_free;
+    double *wave_base = (LS == 4) ? sm + (long long)(threadIdx.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : sm;
+    double *th = wave_base;                // current θ           [d][T]
+    double *tn = th + (long long)d * T;    // proposed θ          [d][T]
+    double *y = tn + (long long)d * T;     // z / draw            [d][T]
+    double *v = y + (long long)d * T;      // triangular-solve scratch [d][T]
+    double *red = (LS == 4) ? sm + (long long)(blockDim.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : v + (long long)d * T;    // [blockDim.x/64]
+    const long long i = (LS == 4) ? (long long)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2) : (long long)blockIdx.x * T + tid;
+    const bool live = i < cl.n;
+    constexpr int src = 0;
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    const unsigned stage = st->mut_stage;
+    const double c_alpha = st->mut_alpha, phi_n = st->mut_phi;
+    const int nb = st->n_blocks, n_steps = st->mut_steps;
+    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    // LS = 1: the same staging when the host reserved the room (MODE 0, n_para <= 13: ma.stage_consts)
+    const bool staged = (LS == 4) || (MODE == 0 && ma.stage_consts && d <= 13);
+    MutStage *S = staged ? (MutStage *)(red + 8) : nullptr;
+    if (staged) {
+        for (int e = threadIdx.x; e < d * d; e += blockDim.x) S->L[e] = st->L[e];
+        if ((int)threadIdx.x < d) {
+            const int e = threadIdx.x;
+            S->mu_b[e] = st->mu_b[e]; S->sd_draw[e] = st->sd_draw[e]; S->sd_dens[e] = st->sd_dens[e]; S->logdet[e] = st->logdet[e];
+            S->lo[e] = md->lo[e]; S->hi[e] = md->hi[e]; S->prior_a[e] = md->prior_a[e]; S->prior_b[e] = md->prior_b[e]; S->prior_k[e] = md->prior_k[e];
+            S->blocks_all[e] = st->blocks_all[e]; S->l_off[e] = st->l_off[e]; S->fixed[e] = md->fixed[e]; S->prior_family[e] = md->prior_family[e];
+        }
+        if ((int)threadIdx.x <= d) S->block_ptr[threadIdx.x] = st->block_ptr[threadIdx.x];
+        __syncthreads();
+    }
+    // (otherwise the same arrays are read where they are)
+    const double *a_L = staged ? S->L : st->L, *a_mu = staged ? S->mu_b : st->mu_b, *a_sdd = staged ? S->sd_draw : st->sd_draw;
+    const double *a_sdn = staged ? S->sd_dens : st->sd_dens, *a_logdet = staged ? S->logdet : st->logdet;
+    const int *a_bptr = staged ? S->block_ptr : st->block_ptr, *a_ball = staged ? S->blocks_all : st->blocks_all, *a_loff = staged ? S->l_off : st->l_off;
+    const ModelView mv{d, staged ? S->fixed : md->fixed, staged ? S->prior_family : md->prior_family, staged ? S->lo : md->lo, staged ? S->hi : md->hi,
+                       staged ? S->prior_a : md->prior_a, staged ? S->prior_b : md->prior_b, staged ? S->prior_k : md->prior_k};
+    mutate_generic<MODE, LS>(cl, md, ma, th, tn, y, v, T, tid, quad_lane, i, live, src, pid, stage, c_alpha, phi_n, nb, n_steps, d, a_L, a_mu, a_sdd, a_sdn, a_logdet,
+                             a_bptr, a_ball, a_loff, mv, like, lprior, like_prev, accept);
     if (MODE == 1) return;
     double acc_val = 0.0;
     if (live && lead) {

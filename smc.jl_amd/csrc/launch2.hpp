@@ -27,6 +27,19 @@ void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double 
 template <int D>
 void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {
     Eng2 *e = h->e2;
+    if constexpr (D > 10) {          // the generic mutation body behind K2's prologue (stage2.hpp k2w_mutate); e->g.wide = lanes per particle
+        const unsigned gw = (unsigned)(e->g.Vl * e->g.nb2);
+        if (!e->wide_attr_set) {     // (more than the default 64 KB of dynamic LDS per block: the per-particle vectors of 256 particles)
+            hipFuncSetAttribute((const void *)k2w_mutate<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2w_lds_bytes(D, 1));
+            if constexpr (D == 13) hipFuncSetAttribute((const void *)k2w_mutate<13, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2w_lds_bytes(13, 4));
+            e->wide_attr_set = true;
+        }
+        if constexpr (D == 13) {
+            if (e->g.wide == 4) { k2w_mutate<13, 4><<<gw, 256, k2w_lds_bytes(13, 4), h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free); return; }
+        }
+        k2w_mutate<D, 1><<<gw, 256, k2w_lds_bytes(D, 1), h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
+        return;
+    } else {
     const size_t lds = k2_lds_bytes(D);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
     if (e->g.t2 == 512 && !ma.tail.tick) {             // the direct geometry (config 2): no hand-over code in the instantiation
@@ -39,15 +52,17 @@ void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) 
         if (alpha1) k2_mutate<D, true, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
         else k2_mutate<D, false, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
     }
+    }
 }
 template <int D>
 void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
     Eng2 *e = h->e2;
-    k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, nb, h->h_model.n_free, e->d_pre);
+    if constexpr (D <= 10) k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, nb, h->h_model.n_free, e->d_pre);
 }
 template <int D>
 void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1) {
     Eng2 *e = h->e2;
+    if constexpr (D <= 10) {
     const size_t lds = k3_lds_bytes(D);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl);            // workers, gatherers
     if (!e->seg_attr_set) {                    // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
@@ -58,6 +73,7 @@ void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, 
     }
     if (alpha1) k3_segment<D, true><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
     else k3_segment<D, false><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+    }
 }
 
 #define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
@@ -71,5 +87,6 @@ SMCMI_LAUNCH2_INSTANCES(, SMCMI_INST_D)
 #else
 SMCMI_LAUNCH2_INSTANCES(extern, 1) SMCMI_LAUNCH2_INSTANCES(extern, 2) SMCMI_LAUNCH2_INSTANCES(extern, 3) SMCMI_LAUNCH2_INSTANCES(extern, 4)
 SMCMI_LAUNCH2_INSTANCES(extern, 5) SMCMI_LAUNCH2_INSTANCES(extern, 6) SMCMI_LAUNCH2_INSTANCES(extern, 7) SMCMI_LAUNCH2_INSTANCES(extern, 8)
-SMCMI_LAUNCH2_INSTANCES(extern, 9) SMCMI_LAUNCH2_INSTANCES(extern, 10)
+SMCMI_LAUNCH2_INSTANCES(extern, 9) SMCMI_LAUNCH2_INSTANCES(extern, 10) SMCMI_LAUNCH2_INSTANCES(extern, 11) SMCMI_LAUNCH2_INSTANCES(extern, 12)
+SMCMI_LAUNCH2_INSTANCES(extern, 13) SMCMI_LAUNCH2_INSTANCES(extern, 14) SMCMI_LAUNCH2_INSTANCES(extern, 15) SMCMI_LAUNCH2_INSTANCES(extern, 16)
 #endif

@@ -33,6 +33,21 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     if (!V) { if (world <= V2_MAXV) V = world; else return false; }
     g.V = V; g.Vl = V / world; g.v0 = rank * g.Vl; g.nv = g.n / g.Vl;
     if (g.nv < 1) return false;
+    // n_para > 10: the generic mutation body behind engine 2's prologues (stage2.hpp k2w_mutate) - 256 particles per block with one
+    // thread per particle, 64 with four lanes per particle (lgss_kalman on small clouds); rows always totalled per virtual shard (Tail2)
+    g.wide = h->d > 10 ? (use_ls4_mutate(h) ? 4 : 1) : 0;
+    if (g.wide) {
+        g.t2 = g.wide == 4 ? 64 : 256;
+        g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
+        if (g.nv > 65536 || (long long)g.nb2 * g.Vl > 1024) return false;      // (a correction row is 512 particles, one per thread: nb1 <= 128)
+        g.direct = 0; g.inker = 1;
+        g.nb1 = (int)std::max<long long>(1, (g.nv + 511) / 512);
+        g.per1 = T1;
+        g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, 256));
+        g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
+        *out = g;
+        return true;
+    }
     g.t2 = 512;
     g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
     // direct: every block totals the per-block rows itself - one handle, <= GRP rows per virtual shard, and the 512-thread mutation
@@ -66,7 +81,7 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
 static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     Geo2 g;
     if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
-    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1) return 0;
+    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1 && h->e2->g.wide == g.wide) return 0;
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     Eng2 *e = new Eng2();
     e->g = g; e->world = world;
@@ -109,9 +124,13 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
 // SMCMI_ENGINE=1 / =2 force one engine wherever it can run (development, tests).
 static bool eng2_eligible(const smcmi_handle *h, int world) {
     static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 0;
-    if (eng == 1 || h->d > 10) return false;
+    if (eng == 1 || h->d > 16) return false;
     Geo2 g;
     if (!make_geo2(h, world, 0, world == 1, &g)) return false;
+    if (g.wide) {                     // n_para 11 .. 16: the same two-launch stage around the generic mutation body (SMCMI_ENGINE_WIDE=0: engine 1's stage)
+        static const int wide_on = getenv("SMCMI_ENGINE_WIDE") ? atoi(getenv("SMCMI_ENGINE_WIDE")) : 1;
+        return wide_on != 0;
+    }
     return eng == 2 || world > 1 || g.direct;
 }
 
@@ -122,12 +141,15 @@ static bool fused_tails(const Eng2 *e) {
     static const int no_tail = getenv("SMCMI_E2_NO_TAIL") ? atoi(getenv("SMCMI_E2_NO_TAIL")) : 0;
     // (several handles: up to 2048 blocks - there the tails break even with the launches they replace, 138.5 vs 139.6 µs per stage at
     // 500 000 particles per handle, and they are what lets the peer mailbox replace the all-gathers)
+    if (e->g.wide) return true;                  // (the wide kernels' rows are always totalled by the last block of a virtual shard)
     return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= (e->world > 1 ? 2048 : 1024);
 }
 #define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
     switch (d) {                                                                                                                          \
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
-    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break; default: CALL(10); break;              \
+    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break; case 10: CALL(10); break;              \
+    case 11: CALL(11); break; case 12: CALL(12); break; case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break;      \
+    default: CALL(16); break;                                                                                                             \
     }
 
 // ---- peer mailbox (stage2.hpp): allocation and the table of peer addresses
@@ -412,7 +434,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (read at every run: a caller that has validated - or lost confidence in - the transport can switch it between runs)
     const int want = getenv("SMCMI_MAILBOX") ? atoi(getenv("SMCMI_MAILBOX")) : -1;                 // -1: default; 2: also with one rank (tests)
     for (auto *h : g.hs) h->mbox_used = false;
-    if ((multi || (g.rccl && want == 2)) && fused_tails(h0->e2)) {
+    if ((multi || (g.rccl && want == 2)) && fused_tails(h0->e2) && npf <= MB_LD) {       // (a mailbox row carries at most MB_LD sums: n_para <= 10)
         if (g.rccl) { if (want != 0) { if (int e = mbox_setup_remote(g)) return e; } mbox = h0->mbox_ok && want != 0; }
         else if (want == 1) { if (int e = mbox_setup_group(g)) return e; mbox = true; }
     }
@@ -485,7 +507,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         k2_energy_max<<<g0.Vl * g0.nb2, g0.t2, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
     }
     // (mutation rows of 256-thread blocks are paired: the canonical row stands for 512 particles, whatever the block size)
-    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256)) return e;
+    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256 && !g0.wide)) return e;
 
     // ---- engine 3: runs of stages that neither resample nor need a certificate pass become one persistent launch each
     bool e3 = false;
@@ -628,7 +650,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 #undef SMCMI_CALL
             if (e1) hipEventRecord(e1, h->stream);
         }
-        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256, true);
+        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256 && !g0.wide, true);
     };
     // enter_mut: stage n_first's correction (and selection, if sel) were enqueued as launches - the segment enters at its mutation
     auto enq_K3 = [&](int n_first, int n_last, bool enter_mut = false, bool sel = false) -> int {             // one persistent launch for stages n_first .. n_last (stage3.hpp)

@@ -66,6 +66,8 @@ struct Geo2 {
     int direct;                   // consumers total the per-block rows themselves (one handle, <= GRP rows per virtual shard)
     int inker;                    // every block runs the begin / decision / proposal logic in its prologue (<= one 512-thread block per CU):
                                   // direct, or several handles with small shards (the rows then are the all-gathered V x m totals)
+    int wide;                     // n_para > 10 (k2w_mutate): lanes per particle of the mutation kernel (1 or 4), t2 = particles of a mutation
+                                  // block (256 or 64); a mutation row is one block's, never paired; 0: the register kernels (n_para <= 10)
 };
 
 struct Rows2 {                    // rows[(v * nr + r) * ld + idx], v < nvs, r < nr
@@ -301,11 +303,12 @@ __device__ inline __amdgpu_buffer_rsrc_t rows_rsrc(const double *base, long long
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 // LD: double2 ldrow(int row, int pr) - columns 2 pr, 2 pr + 1 of raw row `row` of the virtual shard.  Returns, in thread t < m, total t.
-template <int NT, class LD>
+// MMAX: capacity in columns (72: every row of the register kernels; 160: the correction rows of n_para up to 16)
+template <int NT, class LD, int MMAX = 72>
 __device__ inline double reduce_vshard_f(LD ldrow, int nr_raw, int m, int max_idx, int pair) {
-    constexpr int GB = NT / (36 * 4) > 0 ? NT / (36 * 4) : 1;      // groups per batch: GB * (m / 2) * 4 <= NT for m <= 72
-    static_assert(NT >= 36 * 4, "a group needs (m / 2) * 4 <= 144 threads");
-    __shared__ double gs[GB * 72];
+    constexpr int GB = NT / (MMAX / 2 * 4) > 0 ? NT / (MMAX / 2 * 4) : 1;      // groups per batch: GB * (m / 2) * 4 <= NT for m <= MMAX
+    static_assert(NT >= MMAX / 2 * 4, "a group needs (m / 2) * 4 threads");
+    __shared__ double gs[GB * MMAX];
     const int mp = m / 2;
     const int nr = pair ? (nr_raw + 1) / 2 : nr_raw;
     const int ng = (nr + GRP - 1) / GRP;
@@ -346,18 +349,18 @@ __device__ inline double reduce_vshard_f(LD ldrow, int nr_raw, int m, int max_id
             p0 = mx0 ? fmax(p0, q0) : p0 + q0; p1 = mx1 ? fmax(p1, q1) : p1 + q1;
             const double r0 = fetch_xor<2>(p0), r1 = fetch_xor<2>(p1);
             p0 = mx0 ? fmax(p0, r0) : p0 + r0; p1 = mx1 ? fmax(p1, r1) : p1 + r1;
-            if (u < units && h == 0) { gs[gl * 72 + 2 * pr] = p0; gs[gl * 72 + 2 * pr + 1] = p1; }
+            if (u < units && h == 0) { gs[gl * MMAX + 2 * pr] = p0; gs[gl * MMAX + 2 * pr + 1] = p1; }
         }
         __syncthreads();
         if ((int)threadIdx.x < m) {
             const bool mx = (int)threadIdx.x == max_idx;
-            for (int g = 0; g < gb; ++g) run = mx ? fmax(run, gs[g * 72 + threadIdx.x]) : run + gs[g * 72 + threadIdx.x];
+            for (int g = 0; g < gb; ++g) run = mx ? fmax(run, gs[g * MMAX + threadIdx.x]) : run + gs[g * MMAX + threadIdx.x];
         }
         __syncthreads();
     }
     return run;
 }
-template <int NT, bool COH = false>
+template <int NT, bool COH = false, int MMAX = 72>
 __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int max_idx, double *out_v, int pair) {
     const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(base0, (long long)nr_raw * m * 8);
     const unsigned brow = (unsigned)m * 8u;
@@ -365,12 +368,13 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
         if constexpr (COH) return load_pair_sc1(rsrc, (unsigned)(2 * pr) * 8u + (unsigned)row * brow);
         else return reinterpret_cast<const double2 *>(base0 + 2 * pr)[(long long)row * (m / 2)];
     };
-    const double run = reduce_vshard_f<NT>(ldrow, nr_raw, m, max_idx, pair);
+    const double run = reduce_vshard_f<NT, decltype(ldrow), MMAX>(ldrow, nr_raw, m, max_idx, pair);
     if ((int)threadIdx.x < m) row_store(out_v + threadIdx.x, run, COH);     // (COH: a block of the same launch may read the totals)
 }
 static __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
     const int v = blockIdx.x;
-    reduce_vshard<RT>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
+    if (m <= 72) reduce_vshard<RT>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
+    else reduce_vshard<RT, false, 160>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
 }
 
 // The same totals without a launch of their own (sharded runs, large clouds): every block of a row-producing kernel takes a
@@ -388,7 +392,7 @@ struct Tail2 {
     long long table;           // word offset of the (kind, parity) table inside a mailbox
     unsigned tag;
 };
-template <int NT>
+template <int NT, int MMAX = 72>
 __device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, int nr_raw, int m, int max_idx, int pair) {
     if (!t.tick) return;
     __shared__ int s_last;
@@ -399,7 +403,7 @@ __device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, in
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&t.tick[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr_raw - 1;
     __syncthreads();
     if (!s_last) return;
-    reduce_vshard<NT, true>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, t.vt + (long long)v * m, pair);
+    reduce_vshard<NT, true, MMAX>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, t.vt + (long long)v * m, pair);
     if (t.peers && (int)threadIdx.x < m) {             // (thread k < m stored total k just above)
         const double x = t.vt[(long long)v * m + threadIdx.x];
         const long long w = t.table + ((long long)(t.gv0 + v) * MB_LD + threadIdx.x) * 2;
@@ -998,10 +1002,11 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
     }
     const double phi = s_bg.phi_n, phi_prev = s_bg.phi_prev, esh = pw == 0.0 ? s_bg.e_shift : 0.0;
     const double *sh = s_po.shift;           // read from LDS where used (uniform address): twenty registers the accumulators need
+    const double unshift = hist ? exp((phi - phi_prev) * esh) : 1.0;                      // history keeps the true exp(δ e)
+    if constexpr (D <= 10) {
     double acc[NCH * 64];
 #pragma unroll
     for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
-    const double unshift = hist ? exp((phi - phi_prev) * esh) : 1.0;                      // history keeps the true exp(δ e)
     // (the geometry gives a thread at most two particles while the cloud is small; requesting the first one ahead of the prologue
     // was tried: the 68 accumulator pairs leave no registers to carry it, the spills inside the loop cost more than the round trip)
     for (long long i = beg + threadIdx.x; i < end; i += T1) {
@@ -1012,8 +1017,29 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
     }
     K2_STAMP(prof, 4);
     k2_cm_row<D>(acc, red, rows_cm + (long long)blockIdx.x * pad2(NPF), csum + blockIdx.x, TAIL && tail.tick != nullptr);
+    } else {
+        // n_para > 10: 100 - 155 sums do not fit a thread's registers as accumulators.  The geometry gives every thread ONE particle of the
+        // row (per1 = 512: make_geo2), and the row's sums are formed sixteen at a time where the butterflies need them (k2_cm_row_one, the
+        // form the persistent segment kernel uses): nothing is accumulated, 0 + W̃ x̃_a x̃_b is what an accumulator would hold.
+        const long long i = beg + threadIdx.x;
+        const bool live = i < end;
+        const long long il = live ? i : (end > beg ? end - 1 : 0);
+        double xx[D + 1], inc;
+        double v = k2_cm_weight<D>([&](int a) { return col(cl, 0, a)[il]; }, sh, loglh[il], old[il], w[il], esh, phi, phi_prev, pw, logp_old, xx, &inc);
+        if (live) {
+            wt[i] = v;
+            if (hist) hist_w[(long long)(n - 1) * hist_ld + i] = inc * unshift;
+        } else v = 0.0;
+        K2_STAMP(prof, 4);
+        double *out = rows_cm + (long long)blockIdx.x * pad2(NPF);
+        const bool coh = TAIL && tail.tick != nullptr;
+        k2_cm_row_one<D, NW>(v, xx, live, red, [&](int idx, double val) {
+            row_store(out + idx, val, coh);
+            if (idx == 0) csum[blockIdx.x] = val;
+        });
+    }
     K2_STAMP(prof, 5);
-    if constexpr (TAIL) tail_reduce<T1>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
+    if constexpr (TAIL) tail_reduce<T1, (pad2(NPF) > 72 ? 160 : 72)>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
     // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double a = s_bg.accept, tg = st->rp.target;
@@ -1341,6 +1367,8 @@ __device__ inline int shuffle_partner(unsigned long long seed, unsigned stage, i
 }
 
 // jx_pre: shuffle_partner() of lane (threadIdx.x & 63), valid in wavefront 1 (threads 64..127)
+// CHM: rows of the in-register Cholesky (12 serves n_para <= 12; 16 the wide kernels)
+template <int CHM = 12>
 __device__ inline bool proposal2(const double *T, const double *shift, int d, int nf, int nb, double c, unsigned long long seed,
                                  unsigned stage, const Prop2 &P, int *s_fail, int TT, int jx_pre, long long *prof = nullptr, long long *prof_any = nullptr) {
     const int t = threadIdx.x, da = d + 1;
@@ -1400,25 +1428,27 @@ __device__ inline bool proposal2(const double *T, const double *shift, int d, in
         const int sub = (nf + nb - 1) / nb, wave = t >> 6, lane = t & 63, nwv = TT >> 6;
         for (int b = wave; b < nb; b += nwv) {
             const int p0 = P.bptr[b], db = P.bptr[b + 1] - p0, off = b * sub * sub;
-            double r[12];
+            double r[CHM];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) r[k] = (lane < db && k < db) ? P.A[off + lane * db + k] : 0.0;
+            for (int k = 0; k < CHM; ++k) r[k] = (lane < db && k < db) ? P.A[off + lane * db + k] : 0.0;
             bool ok;
             // (the whole triangle in every lane's registers - no lane exchange, ~220 dependent FP64 operations - was measured: the same
             // 3.2 µs; a dependent FP64 operation costs ~16 cycles with one wavefront per SIMD, whichever way the ten columns are cut)
-            if (db == d && d <= 10 && d >= 2) ok = chol_full_dispatch(r, d, lane);      // one block over all parameters: no per-column branches
-            else ok = chol_rows_in_regs<12, true>(r, db, lane);
+            if constexpr (CHM == 12) {
+                if (db == d && d <= 10 && d >= 2) ok = chol_full_dispatch(r, d, lane);      // one block over all parameters: no per-column branches
+                else ok = chol_rows_in_regs<12, true>(r, db, lane);
+            } else ok = chol_rows_in_regs<CHM, true>(r, db, lane);
             if (!ok && lane == 0) *s_fail = 1;
 #pragma unroll
-            for (int k = 0; k < 12; ++k)
+            for (int k = 0; k < CHM; ++k)
                 if (lane < db && k < db) P.Lraw[off + lane * db + k] = k <= lane ? r[k] : 0.0;
             double dg = 1.0;                        // own diagonal entry L[lane][lane]
 #pragma unroll
-            for (int k = 0; k < 12; ++k) dg = (k == lane) ? r[k] : dg;
+            for (int k = 0; k < CHM; ++k) dg = (k == lane) ? r[k] : dg;
             const double lg = (lane < db) ? log(dg) : 0.0;
             double ld = 0.0;
 #pragma unroll
-            for (int i = 0; i < 12; ++i)
+            for (int i = 0; i < CHM; ++i)
                 if (i < db) ld += bcast_lane(lg, i);
             if (lane == 0) { P.logdet[b] = 2.0 * ld; P.loff[b] = off; }
         }
@@ -1437,10 +1467,11 @@ struct Mut2Lds {
     int *ball_s, *m_fix, *m_fam, *bptr_s, *loff_s, *ball_raw;
     double *s_vt, *s_tot, *covl, *sig_f, *Aw, *Lw, *mean_s, *mu_f;
     int *bfree, *fi, *fi_j;
-    __device__ explicit Mut2Lds(double *sm) {
+    // lik_cap: doubles reserved for staged likelihood data (the generic mutation body of n_para > 10 reads its data where it is: 0)
+    __device__ explicit Mut2Lds(double *sm, int lik_cap = LIK_LDS_CAP) {
         Ls = sm; mu_s = Ls + D * D; sdd_s = mu_s + D; sdn_s = sdd_s + D; red = sdn_s + D;
         m_lo = red + 8; m_hi = m_lo + D; m_a = m_hi + D; m_b = m_a + D; m_k = m_b + D;
-        l_par = m_k + D; l_dat = l_par + 2 * LIK_PAR_MAX; Lraw = l_dat + LIK_LDS_CAP; logdet_s = Lraw + D * D;
+        l_par = m_k + D; l_dat = l_par + 2 * LIK_PAR_MAX; Lraw = l_dat + lik_cap; logdet_s = Lraw + D * D;
         mub_raw = logdet_s + D; sdd_raw = mub_raw + D; sdn_raw = sdd_raw + D;
         ball_s = (int *)(sdn_raw + D); m_fix = ball_s + D + (D & 1); m_fam = m_fix + D;
         bptr_s = m_fam + D; loff_s = bptr_s + D + 1; ball_raw = loff_s + D;
@@ -1451,9 +1482,9 @@ struct Mut2Lds {
         bfree = (int *)(mu_f + D); fi = bfree + D; fi_j = fi + D;
     }
 };
-constexpr size_t k2_lds_bytes(int D) {
+constexpr size_t k2_lds_bytes(int D, int lik_cap = LIK_LDS_CAP) {
     const size_t np = (size_t)(D + 1) * (D + 2) / 2, npf = np + 2;
-    return (size_t)(2 * D * D + 12 * D + 8 + 2 * LIK_PAR_MAX + LIK_LDS_CAP) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32 +
+    return (size_t)(2 * D * D + 12 * D + 8 + 2 * LIK_PAR_MAX + lik_cap) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32 +
            (V2_MAXV * (npf + 1) + npf + 5 + 4 * D * D + 2 * D) * sizeof(double) + (size_t)(3 * D + 4) * sizeof(int) + 32;
 }
 
@@ -1507,7 +1538,7 @@ __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, 
     // moments of the resampled cloud (k2_gather's rows) replace the correction's on resample stages
     if (rs) reduce_rows<pad2(NP), 1, T>(ma.gmrows, L.s_vt, L.s_tot + 2);
     Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
-    if (!proposal2(L.s_tot + 2, S->po.shift, D, nf, nb, S->po.c * S->bg.cfac, ma.seed, (unsigned)n, P, &S->fail, T, jx_pre, ma.prof)) {
+    if (!proposal2<(D > 12 ? 16 : 12)>(L.s_tot + 2, S->po.shift, D, nf, nb, S->po.c * S->bg.cfac, ma.seed, (unsigned)n, P, &S->fail, T, jx_pre, ma.prof)) {
         // PosDefException aborts the run (mutation.jl:81)
         if (blockIdx.x == 0 && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
         return false;
@@ -1818,6 +1849,75 @@ SMCMI_FP_CONTRACT
     if constexpr (TAIL) tail_reduce<T>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, T == 256 ? 1 : 0);
     if (blockIdx.x == 0 && !ma.pre) k2_bookkeeping<D, T>(st, ctl, ma, L, &S, rs);
     K2_STAMP(ma.prof, 11);
+}
+
+// K2 for n_para > 10 (the Kalman-filter family of BASELINE config 5, and any device family with 11 - 16 parameters): the same prologue
+// as k2_mutate - every block totals the V x m correction table, decides, builds the proposal in LDS (k2_prologue) - in front of the
+// GENERIC mutation body (kernels.hpp mutate_generic: per-particle vectors in LDS columns; the lgss_kalman filters with their structure
+// values in DPP operands), which engine 1 reaches through k_prepare_mutation + k_mutate.  LS = 1: one thread per particle, 256 particles
+// per block; LS = 4 (lgss_kalman, small clouds): four lanes per particle, 64 particles per block, the quad runs the proposal redundantly
+// and shares the filter (model.hpp kalman_lgss_quad).  One mutation row per block (never paired), totalled per virtual shard by the last
+// block to finish (Tail2): with global particle ids in the RNG the results do not depend on the number of handles, bit for bit.
+// Replaces, for these models, engine 1's eight-launch stage (src/smc_main.jl:427-484 as k_post_correct ... k_mutate) by K1 -> K2.
+constexpr size_t k2w_lds_bytes(int D, int LS) {
+    const size_t pro = (k2_lds_bytes(D, 0) + 15) / 16 * 16;
+    return pro + (LS == 4 ? (size_t)4 * mutate_wave_bytes_ls4(13) : (size_t)4 * D * 256 * sizeof(double)) + 64;
+}
+template <int D, int LS>
+__global__ void __launch_bounds__(256, 1) k2w_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, int nb, int nf) {
+    static_assert(LS == 1 || (LS == 4 && D == 13), "four lanes per particle: the lgss_kalman family (13 parameters)");
+    constexpr int TB2 = 256, P = LS == 4 ? 64 : 256;           // threads / particles of a block
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ Mut2Stage S;
+    const Mut2Lds<D> L(sm, 0);
+    const int n = ma.n;
+    int rs = 0;
+    if (!k2_prologue<D, TB2>(st, ctl, md, ma, L, &S, nb, nf, &rs)) return;
+    const double phi_n = S.bg.phi_n, e_center = S.bg.e_center, nrm_sumw = L.s_tot[0], nrm_N = ma.n_parts;
+    // ---- the per-particle LDS vectors behind the prologue's area
+    double *gen = sm + (k2_lds_bytes(D, 0) + 15) / 16 * 2;
+    const int T = LS == 4 ? 16 : TB2;                                                // stride of the per-particle vectors
+    const int tid = LS == 4 ? (((int)threadIdx.x & 63) >> 2) : (int)threadIdx.x;     // column in them
+    const int quad_lane = threadIdx.x & 3;
+    const bool lead = LS == 1 || quad_lane == 0;
+    double *wave_base = LS == 4 ? gen + (long long)(threadIdx.x >> 6) * (mutate_wave_bytes_ls4(13) / 8) : gen;
+    double *th = wave_base, *tn = th + (long long)D * T, *y = tn + (long long)D * T, *v = y + (long long)D * T;
+    const int vl = (int)blockIdx.x / g.nb2, r = (int)blockIdx.x % g.nb2;
+    long long beg, end;
+    vchunk(g, vl, r, P, beg, end);
+    const long long i = beg + (LS == 4 ? (long long)(threadIdx.x >> 2) : (long long)threadIdx.x);
+    const bool live = i < end;
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double w_part = 0.0;
+    if (live) {
+        w_part = rs ? 1.0 : (ma.wt[i] * nrm_N) / nrm_sumw;                  // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366)
+        if (lead) {
+            col(cl, 0, D + 4)[i] = w_part;
+            if (ma.hist_W && ma.store_history) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = w_part;
+        }
+    }
+    MutArgs ga{};
+    ga.seed = ma.seed; ga.gid0 = ma.gid0; ga.debug = ma.debug;
+    const ModelView mv{D, L.m_fix, L.m_fam, L.m_lo, L.m_hi, L.m_a, L.m_b, L.m_k};
+    double like = 0.0, lprior = 0.0, like_prev = 0.0, accept = 0.0;
+    // (the resampled cloud is in buffer 1: k2_gather)
+    mutate_generic<0, LS>(cl, md, ga, th, tn, y, v, T, tid, quad_lane, i, live, rs, pid, (unsigned)n, ma.alpha, phi_n, nb, ma.n_steps, D, L.Lraw, L.mub_raw, L.sdd_raw,
+                          L.sdn_raw, L.logdet_s, L.bptr_s, L.ball_raw, L.loff_s, mv, like, lprior, like_prev, accept);
+    double acc_val = 0.0;
+    const bool counted = live && lead;                          // lanes 1..3 of a quad carry copies: they store nothing and add nothing to the row
+    if (counted) {
+        for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = th[k * T + tid];
+        col(cl, 0, D)[i] = like;
+        col(cl, 0, D + 1)[i] = lprior;
+        col(cl, 0, D + 2)[i] = like_prev;
+        acc_val = accept / (double)nf;                          // quirk Q2: normalised by n_free only
+        col(cl, 0, D + 3)[i] = acc_val;
+    }
+    // ---- this block's row for the next stage's begin (the per-particle vectors are dead: their area is the reduction's scratch)
+    k2_mut_row<TB2>(ma.rows_mut + (long long)blockIdx.x * RMUT, ma.adaptive != 0, like, like_prev, counted ? w_part : 0.0, counted ? acc_val : 0.0, e_center, counted,
+                    rs != 0, gen, L.red, ma.tail.tick != nullptr);
+    tail_reduce<TB2>(ma.tail, ma.rows_mut, vl, g.nb2, RMUT, RMAX_IDX, 0);
+    if (blockIdx.x == 0) k2_bookkeeping<D, TB2>(st, ctl, ma, L, &S, rs);
 }
 
 // Decision, bookkeeping and proposal of stage n by one block (large clouds, sharded runs): K2's prologue as its own launch.
