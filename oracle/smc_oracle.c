@@ -841,11 +841,53 @@ void orc_initialize_likelihoods(const orc_model *m, double *particles, int64_t n
 
 /* ref: src/initialization.jl:23-63 one_draw + :88-119 initial_draw!.  Philox: counter stage field = outer
    attempt, tag(P_INIT, redraw, k) per parameter.  Only Normal / Uniform priors can be sampled here. */
+/* rand(::ParameterVector) for one parameter on the RNG contract: Normal / Uniform from one Philox call; Gamma, Beta,
+   InverseGamma, RootInverseGamma through unit gammas by Marsaglia & Tsang (2000): iteration mm < 32 of unit gamma g reads its normal from
+   tag(P_INIT, r | (32 g + mm) << 14, k) and its acceptance uniform u1 (u2: the shape < 1 boost) from tag(P_INIT, same, k | 64).
+   Distributions.jl's own samplers differ (parity unpinned: the reference's streams are MersenneTwister's); the DISTRIBUTIONS are what
+   ModelConstructors' prior(...) evaluates (prior_logpdf above). */
+static double gamma_unit_draw(uint64_t seed, uint64_t pid, uint32_t attempt, uint32_t r, uint32_t k, uint32_t g, double shape) {
+    int boost = shape < 1.0;
+    double a = boost ? shape + 1.0 : shape;
+    double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+    for (uint32_t mm = 0; mm < 32u; ++mm) {
+        uint32_t t = (r & 0x3FFFu) | ((32u * g + mm) << 14);
+        double ua, ub, u1, u2;
+        orc_uniform_pair(seed, pid, attempt, TAG(P_INIT, t, k), &ua, &ub);
+        double x = sqrt(-2.0 * log(ua)) * cos(TWO_PI * ub);
+        double v = 1.0 + c * x;
+        if (!(v > 0.0)) continue;
+        v = v * v * v;
+        orc_uniform_pair(seed, pid, attempt, TAG(P_INIT, t, k | 64u), &u1, &u2);
+        double x2 = x * x;
+        if (u1 < 1.0 - 0.0331 * x2 * x2 || log(u1) < 0.5 * x2 + dd * (1.0 - v + log(v))) {
+            double G = dd * v;
+            if (boost) G *= exp(log(u2) / shape);
+            return G;
+        }
+    }
+    return NAN;
+}
+static double prior_draw(uint64_t seed, uint64_t pid, uint32_t attempt, uint32_t r, uint32_t k, int fam, double a, double b) {
+    if (fam == ORC_PRIOR_NORMAL || fam == ORC_PRIOR_UNIFORM) {
+        double ua, ub;
+        orc_uniform_pair(seed, pid, attempt, TAG(P_INIT, r, k), &ua, &ub);
+        return fam == ORC_PRIOR_NORMAL ? a + b * (sqrt(-2.0 * log(ua)) * cos(TWO_PI * ub)) : a + (b - a) * ua;
+    }
+    switch (fam) {
+    case ORC_PRIOR_GAMMA: return b * gamma_unit_draw(seed, pid, attempt, r, k, 0u, a);
+    case ORC_PRIOR_BETA: {
+        double g1 = gamma_unit_draw(seed, pid, attempt, r, k, 0u, a), g2 = gamma_unit_draw(seed, pid, attempt, r, k, 1u, b);
+        return g1 / (g1 + g2);
+    }
+    case ORC_PRIOR_INVGAMMA: return b / gamma_unit_draw(seed, pid, attempt, r, k, 0u, a);
+    case ORC_PRIOR_ROOTINVGAMMA: return sqrt(a * b * b / (2.0 * gamma_unit_draw(seed, pid, attempt, r, k, 0u, 0.5 * a)));
+    default: return NAN;
+    }
+}
 int orc_initial_draw(const orc_model *m, double *particles, int64_t n, int64_t pid0, uint64_t seed) {
     int d = m->n_para, R = d + 5;
-    for (int k = 0; k < d; ++k)
-        if (!m->fixed[k] && m->prior_family[k] != ORC_PRIOR_NORMAL && m->prior_family[k] != ORC_PRIOR_UNIFORM)
-            return fail("initial_draw: only Normal/Uniform priors can be sampled by the oracle");
+    if (d > 64) return fail("initial_draw: the RNG tags carry the parameter index in 6 bits");
     for (int64_t i = 0; i < n; ++i) {
         double th[ORC_MAXD], ll = 0, lp = 0;
         uint64_t pid = (uint64_t)(pid0 + i);
@@ -853,14 +895,12 @@ int orc_initial_draw(const orc_model *m, double *particles, int64_t n, int64_t p
             if (attempt > 100000) return fail("initial_draw: no finite-likelihood draw after 100000 attempts");
             for (int k = 0; k < d; ++k) {
                 if (m->fixed[k]) { th[k] = m->prior_a[k]; continue; }   /* fixed: value carried in prior_a */
+                int fam = m->prior_family[k];
+                uint32_t r_max = (fam == ORC_PRIOR_NORMAL || fam == ORC_PRIOR_UNIFORM) ? 100000u : 16383u;
                 for (uint32_t r = 0;; ++r) {
-                    double ua, ub, x;
-                    orc_uniform_pair(seed, pid, attempt, TAG(P_INIT, r, k), &ua, &ub);
-                    if (m->prior_family[k] == ORC_PRIOR_NORMAL)
-                        x = m->prior_a[k] + m->prior_b[k] * (sqrt(-2.0 * log(ua)) * cos(TWO_PI * ub));
-                    else x = m->prior_a[k] + (m->prior_b[k] - m->prior_a[k]) * ua;
+                    double x = prior_draw(seed, pid, attempt, r, (uint32_t)k, fam, m->prior_a[k], m->prior_b[k]);
                     if (m->lo[k] < x && x < m->hi[k]) { th[k] = x; break; }  /* rand(::ParameterVector) redraw */
-                    if (r > 100000) return fail("initial_draw: prior draw never inside bounds");
+                    if (r >= r_max) return fail("initial_draw: prior draw never inside bounds");
                 }
             }
             if (orc_in_bounds(m, th)) {

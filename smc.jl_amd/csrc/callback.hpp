@@ -113,9 +113,6 @@ static int callback_fill_loglh(smcmi_handle *h, int which, int column) {
 // (attempt a of particle i = the draws k_init_prior makes on its a-th outer attempt), the callback scores them, particles without
 // a finite log-likelihood are redrawn (one_draw's loop, :23-63) - the cloud a device family with the same values would start from.
 static int callback_init_from_prior(smcmi_handle *h) {
-    for (int k = 0; k < h->d; ++k)
-        if (!h->h_model.fixed[k] && h->h_model.prior_family[k] != SMCMI_PRIOR_NORMAL && h->h_model.prior_family[k] != SMCMI_PRIOR_UNIFORM)
-            return set_err(SMCMI_ERR_UNSUPPORTED, "device prior sampling supports Normal/Uniform priors; draw on the host and upload");
     if (int e = ensure_callback_buffers(h)) return e;
     if (ensure_split_buffers(h)) return SMCMI_ERR_HIP;
     CallbackBuffers *b = h->cbuf;

@@ -2732,8 +2732,62 @@ SMCMI_FP_CONTRACT
 }
 
 // ------------------------------------------------------------------------------------------------ initial draw
+// One prior draw of parameter k (rand(::ParameterVector), src/initialization.jl:27) on the RNG contract: outer attempt in the counter's
+// stage field, bounds redraw r and parameter k in the tag.  Normal / Uniform: one Philox call, tag(P_INIT, r, k).  The Gamma family
+// (Gamma, Beta, InverseGamma, RootInverseGamma - the priors DSGE parameter vectors carry) by Marsaglia & Tsang's method: iteration m
+// (< 32) of unit gamma g (< 2: Beta needs two) reads its normal from tag(P_INIT, r | (32 g + m) << 14, k) (Box-Muller, cosine branch)
+// and its acceptance uniform u1 - with u2 for the shape < 1 boost G(a) = G(a + 1) u2^(1/a) - from tag(P_INIT, same, k | 64); r < 16384.
+// (the CPU restatement used by the tests follows the same rules); NaN = no acceptance in 32 iterations (probability < 1e-40).
+__device__ inline double gamma_unit_draw(unsigned long long seed, unsigned long long pid, unsigned attempt, unsigned r, unsigned k, unsigned g, double shape) {
+    const bool boost = shape < 1.0;
+    const double a = boost ? shape + 1.0 : shape;
+    const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+    for (unsigned m = 0; m < 32u; ++m) {
+        const unsigned t = (r & 0x3FFFu) | ((32u * g + m) << 14);
+        double ua, ub, u1, u2;
+        uniform_pair(seed, pid, attempt, rng_tag(P_INIT, t, k), ua, ub);
+        const double x = sqrt(-2.0 * log(ua)) * cos(6.283185307179586476925286766559 * ub);
+        double v = 1.0 + c * x;
+        if (!(v > 0.0)) continue;
+        v = v * v * v;
+        uniform_pair(seed, pid, attempt, rng_tag(P_INIT, t, k | 64u), u1, u2);
+        const double x2 = x * x;
+        if (u1 < 1.0 - 0.0331 * x2 * x2 || log(u1) < 0.5 * x2 + dd * (1.0 - v + log(v))) {
+            double G = dd * v;
+            if (boost) G *= exp(log(u2) / shape);
+            return G;
+        }
+    }
+    return __builtin_nan("");
+}
+__device__ inline double prior_draw(unsigned long long seed, unsigned long long pid, unsigned attempt, unsigned r, unsigned k, int fam, double a, double b) {
+    if (fam == SMCMI_PRIOR_NORMAL || fam == SMCMI_PRIOR_UNIFORM) {
+        double ua, ub;
+        uniform_pair(seed, pid, attempt, rng_tag(P_INIT, r, k), ua, ub);
+        return fam == SMCMI_PRIOR_NORMAL ? a + b * (sqrt(-2.0 * log(ua)) * cos(6.283185307179586476925286766559 * ub)) : a + (b - a) * ua;
+    }
+    switch (fam) {
+    case SMCMI_PRIOR_GAMMA: return b * gamma_unit_draw(seed, pid, attempt, r, k, 0u, a);                       // Gamma(shape a, scale b)
+    case SMCMI_PRIOR_BETA: {
+        const double g1 = gamma_unit_draw(seed, pid, attempt, r, k, 0u, a), g2 = gamma_unit_draw(seed, pid, attempt, r, k, 1u, b);
+        return g1 / (g1 + g2);
+    }
+    case SMCMI_PRIOR_INVGAMMA: return b / gamma_unit_draw(seed, pid, attempt, r, k, 0u, a);                   // InverseGamma(shape a, scale b)
+    case SMCMI_PRIOR_ROOTINVGAMMA: return sqrt(a * b * b / (2.0 * gamma_unit_draw(seed, pid, attempt, r, k, 0u, 0.5 * a)));   // sqrt(ν τ² / χ²_ν)
+    default: return __builtin_nan("");
+    }
+}
+// the redraw loop of one parameter (rand(::ParameterVector) redraws until the value is inside the bounds)
+__device__ inline double prior_draw_in_bounds(unsigned long long seed, unsigned long long pid, unsigned attempt, unsigned k, int fam, double a, double b, double lo,
+                                              double hi) {
+    const unsigned r_max = (fam == SMCMI_PRIOR_NORMAL || fam == SMCMI_PRIOR_UNIFORM) ? 100000u : 16383u;
+    for (unsigned r = 0;; ++r) {
+        const double x = prior_draw(seed, pid, attempt, r, k, fam, a, b);
+        if ((lo < x && x < hi) || r >= r_max) return x;
+    }
+}
 // initial_draw! / one_draw (src/initialization.jl:23-119): prior draws with bounds rejection, re-draw until the
-// log-likelihood is finite.  Normal / Uniform priors only (others: host draws + upload).
+// log-likelihood is finite.
 static __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState *st, const ModelDev *md,
                                                    unsigned long long seed, long long gid0, int *fail_flag) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
@@ -2747,14 +2801,7 @@ static __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const De
         if (attempt > 100000u) { *fail_flag = 1; break; }
         for (int k = 0; k < d; ++k) {
             if (md->fixed[k]) { thl[k] = md->prior_a[k]; continue; }
-            for (unsigned r = 0;; ++r) {
-                double ua, ub, x;
-                uniform_pair(seed, pid, attempt, rng_tag(P_INIT, r, (unsigned)k), ua, ub);
-                if (md->prior_family[k] == SMCMI_PRIOR_NORMAL)
-                    x = md->prior_a[k] + md->prior_b[k] * (sqrt(-2.0 * log(ua)) * cos(6.283185307179586476925286766559 * ub));
-                else x = md->prior_a[k] + (md->prior_b[k] - md->prior_a[k]) * ua;
-                if ((md->lo[k] < x && x < md->hi[k]) || r > 100000u) { thl[k] = x; break; }
-            }
+            thl[k] = prior_draw_in_bounds(seed, pid, attempt, (unsigned)k, md->prior_family[k], md->prior_a[k], md->prior_b[k], md->lo[k], md->hi[k]);
         }
         if (in_bounds(*md, TH)) {
             ll = loglik(md->lik[0], d, TH);
@@ -2782,14 +2829,7 @@ static __global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const Mo
     auto TH = [&](int k) { return thl[k]; };
     for (int k = 0; k < d; ++k) {
         if (md->fixed[k]) { thl[k] = md->prior_a[k]; continue; }
-        for (unsigned r = 0;; ++r) {
-            double ua, ub, x;
-            uniform_pair(seed, pid, (unsigned)attempt[i], rng_tag(P_INIT, r, (unsigned)k), ua, ub);
-            if (md->prior_family[k] == SMCMI_PRIOR_NORMAL)
-                x = md->prior_a[k] + md->prior_b[k] * (sqrt(-2.0 * log(ua)) * cos(6.283185307179586476925286766559 * ub));
-            else x = md->prior_a[k] + (md->prior_b[k] - md->prior_a[k]) * ua;
-            if ((md->lo[k] < x && x < md->hi[k]) || r > 100000u) { thl[k] = x; break; }
-        }
+        thl[k] = prior_draw_in_bounds(seed, pid, (unsigned)attempt[i], (unsigned)k, md->prior_family[k], md->prior_a[k], md->prior_b[k], md->lo[k], md->hi[k]);
     }
     for (int k = 0; k < d; ++k) col(cl, 0, k)[i] = thl[k];
     col(cl, 0, d)[i] = 0.0;

@@ -388,9 +388,7 @@ static int callback_init_from_prior(smcmi_handle *h);
 extern "C" int smcmi_init_from_prior(smcmi_handle *h) {
     if (int rc = need_model(h, 2)) return rc;
     if (h->cb[0]) return callback_init_from_prior(h);                 // user likelihood: device draws, host scores
-    for (int k = 0; k < h->d; ++k)
-        if (!h->h_model.fixed[k] && h->h_model.prior_family[k] != SMCMI_PRIOR_NORMAL && h->h_model.prior_family[k] != SMCMI_PRIOR_UNIFORM)
-            return set_err(SMCMI_ERR_UNSUPPORTED, "device prior sampling supports Normal/Uniform priors; draw on the host and upload");
+    if (h->d > 64) return set_err(SMCMI_ERR_UNSUPPORTED, "device prior sampling: the RNG tags carry the parameter index in 6 bits");
     HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
     k_init_prior<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_model, h->cfg.seed, h->cfg.gid0, h->d_flag);
     int flag = 0;

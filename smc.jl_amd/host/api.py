@@ -364,20 +364,13 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
             else:
                 pri.set_likelihood(*old_lik, which=0)
             pri.set_likelihood("none", which=1)
-            if all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
-                pri.init_from_prior()
-            else:
-                from .cloudio import host_initial_draw
-                host_initial_draw(pri, parameters, seed)
+            pri.init_from_prior()
             return pri
         kw["initial_ess"] = _tempered_update_cloud(eng, old_cloud, n_parts, tempered_update_prior_weight, resampling_method, seed,
                                                    device, prior_engine)
         w0 = eng.download_cloud()[:, d + 4].copy()
-    elif all(p.fixed or p.prior.family in ("normal", "uniform") for p in parameters):
-        eng.init_from_prior()                             # device prior draws; log-likelihoods by the device family or the callback
     else:
-        from .cloudio import host_initial_draw
-        host_initial_draw(eng, parameters, seed)          # host draws; likelihoods by the device family or the callback
+        eng.init_from_prior()                             # device prior draws (every prior family); log-likelihoods by the device family or the callback
     cont, elapsed = False, 0.0
     if continue_intermediate:
         cont = _load_intermediate(eng, loadpath, n_phi, lam, d)
@@ -620,11 +613,7 @@ def initial_draw(loglikelihood, parameters, data, cloud, parallel=False, regime_
     eng = Engine(n, d, seed=seed, device=device, max_stages=2, store_history=False)
     try:
         eng.set_model(_spec_from(parameters, loglikelihood.spec(np.asarray(data, dtype=np.float64)), None))
-        if all(q.fixed or q.prior.family in ("normal", "uniform") for q in parameters):
-            eng.init_from_prior()
-        else:
-            from .cloudio import host_initial_draw
-            host_initial_draw(eng, parameters, seed)
+        eng.init_from_prior()
         cloud.particles = eng.download_cloud()
     finally:
         eng.close()

@@ -178,75 +178,6 @@ def _prior_draw(p, seed, pid, k, gen):
     raise RuntimeError("no prior draw of %s inside its bounds" % p.key)
 
 
-def _draw_column(p, n, gen):
-    """n draws of one parameter's prior, each redrawn until strictly inside valuebounds (vectorised; numpy Philox stream)."""
-    fam, a, b = p.prior.triple()
-    lo, hi = p.valuebounds
-    x = np.empty(n)
-    todo = np.arange(n)
-    for _ in range(100000):
-        m = todo.size
-        if fam == "normal":
-            v = a + b * gen.standard_normal(m)
-        elif fam == "uniform":
-            v = a + (b - a) * gen.random(m)
-        elif fam == "gamma":
-            v = gen.gamma(a, b, m)
-        elif fam == "beta":
-            v = gen.beta(a, b, m)
-        elif fam == "invgamma":
-            v = b / gen.gamma(a, 1.0, m)
-        elif fam == "rootinvgamma":
-            v = np.sqrt(a * b * b / gen.chisquare(a, m))
-        else:
-            raise ValueError("unknown prior family %r" % (fam,))
-        x[todo] = v
-        todo = todo[~((v > lo) & (v < hi))]
-        if todo.size == 0:
-            return x
-    raise RuntimeError("no prior draw of %s inside its bounds" % p.key)
-
-
-def host_initial_draw(eng, parameters, seed):
-    """initial_draw! (src/initialization.jl:88-119) for prior families the device sampler does not draw (Gamma, Beta, InverseGamma,
-    RootInverseGamma next to Normal / Uniform): parameters are drawn on the host (numpy Philox keyed by the seed), the likelihoods
-    are evaluated on the device (`initialize_likelihoods`), and particles whose log-likelihood is not finite are redrawn as a
-    whole, like `one_draw` does (:23-63).  Leaves the cloud on the device: loglh, logprior, old_loglh, weight 1."""
-    parameters = list(parameters)
-    n, d = eng.n, len(parameters)
-    gen = np.random.Generator(np.random.Philox(key=int(seed)))
-    P = np.zeros((n, d + 5), order="F")
-    todo = np.arange(n)
-    has_cb = getattr(eng, "_cb", None) is not None and eng._cb[0] is not None
-    for attempt in range(1000):
-        for k, p in enumerate(parameters):
-            P[todo, k] = p.value if p.fixed else _draw_column(p, todo.size, gen)
-        U = P.copy(order="F")
-        U[:, d:] = 0.0                                   # nothing of an earlier round reaches initialize_likelihoods (it copies loglh -> old_loglh)
-        if has_cb:
-            # a host closure scores only the rows just redrawn: rows whose logprior column is -Inf are skipped by the callback pass
-            U[:, d + 1] = -np.inf
-            U[todo, d + 1] = 0.0
-            eng.upload_cloud(U)
-            eng.eval_cloud_callback(which=0, column=d)
-        else:
-            eng.upload_cloud(U)
-            eng.initialize_likelihoods()
-        L = eng.download_cloud()
-        P[todo, d] = L[todo, d]
-        todo = todo[~np.isfinite(P[todo, d])]
-        if todo.size == 0:
-            break
-    else:
-        raise RuntimeError("initial draw: no finite-likelihood draw found")
-    P[:, d + 1] = [logprior(parameters, P[i, :d]) for i in range(n)]
-    P[:, d + 2] = 0.0                                    # old_loglh of a fresh draw (initialization.jl:107-117), whatever the redraw rounds left
-    P[:, d + 3] = 0.0
-    P[:, d + 4] = 1.0
-    eng.upload_cloud(P)
-    return P
-
-
 def add_parameters_to_cloud(old_cloud, parameters, old_para_inds, seed=0):
     """src/particle.jl:705-760 (regime_switching = false): the cloud of an old estimation extended by prior draws of the new
     parameters.  `parameters` is the new model's vector, `old_para_inds` the boolean mask of those the old model had (in the

@@ -207,28 +207,10 @@ function set_parameters!(h::Handle, parameters; regime_switching::Bool = false)
                 h, fixed, lo, hi, fam, pa, pb))
 end
 
-# initial_draw! (src/initialization.jl:88-119): device sampler for Normal / Uniform priors (log-likelihoods by the device family or,
-# for a closure, by the callback: smcmi_init_from_prior); otherwise prior draws on the host (rand(parameters, n), re-drawn until
-# the log-likelihood is finite, :23-63) scored through the handle
-function initial_draw!(h::Handle, parameters, lik, n_parts::Int, d::Int)
-    simple = all(p -> p.fixed || p.prior.value isa Union{Normal, Uniform}, parameters)
-    if simple
-        return check(ccall((:smcmi_init_from_prior, LIB), Cint, (Handle,), h))
-    end
-    P = zeros(n_parts, d + 5)
-    todo = collect(1:n_parts)
-    while !isempty(todo)
-        draws = rand(parameters, length(todo))               # d x length(todo), inside the bounds (ModelConstructors)
-        P[todo, 1:d] = draws'
-        P[:, d + 5] .= 1.0
-        check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
-        check(ccall((:smcmi_initialize_likelihoods, LIB), Cint, (Handle,), h))      # logprior on the device, loglh by family / callback
-        check(ccall((:smcmi_download_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
-        todo = findall(!isfinite, P[:, d + 1])
-    end
-    P[:, d + 3] .= 0.0; P[:, d + 4] .= 0.0; P[:, d + 5] .= 1.0
-    check(ccall((:smcmi_upload_cloud, LIB), Cint, (Handle, Ptr{Float64}), h, P))
-end
+# initial_draw! (src/initialization.jl:88-119): the device samples every prior family (Normal, Uniform, Gamma, Beta, InverseGamma,
+# RootInverseGamma) with the bounds redraw of rand(parameters), scores the draws (device family, or the closure through the callback)
+# and redraws particles without a finite log-likelihood (:23-63)
+initial_draw!(h::Handle, parameters, lik, n_parts::Int, d::Int) = check(ccall((:smcmi_init_from_prior, LIB), Cint, (Handle,), h))
 
 stage_path(savepath, i) = replace(savepath, ".jld2" => "_stage=$(i).jld2")         # smc_main.jl:500
 

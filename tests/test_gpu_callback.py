@@ -120,12 +120,12 @@ def test_smc_entry_point_with_a_python_closure_tempered_update():
 
 
 def test_closure_with_gamma_prior_and_rejected_draws_starts_from_old_loglh_zero():
-    """a closure that returns -Inf on part of the prior support sends host_initial_draw through redraw rounds; the cloud the
-    recursion starts from must have old_loglh = 0 everywhere (initialization.jl:107-117) - a stale copy of loglh there switches the
-    correction off for the particles that were not redrawn - and each round may only score the rows it redrew."""
+    """a closure that returns -Inf on part of the prior support sends the initial draw (device draws - a Gamma prior among
+    them -, the closure scores) through redraw rounds; the cloud the recursion starts from must have old_loglh = 0 everywhere
+    (initialization.jl:107-117) - a stale copy of loglh there switches the correction off for the particles that were not redrawn - and
+    each round may only score the rows it redrew."""
     import smc_jl_amd as S
     from smc_jl_amd.host import api
-    from smc_jl_amd.host.cloudio import host_initial_draw
 
     calls = []
 
@@ -144,7 +144,7 @@ def test_closure_with_gamma_prior_and_rejected_draws_starts_from_old_loglh_zero(
     eng.set_parameters(spec["priors"], spec["bounds"], spec["fixed"])
     eng.set_likelihood_callback(api._batch(loglik, data), which=0)
     eng.set_likelihood("none", which=1)
-    host_initial_draw(eng, pars, seed=3)
+    eng.init_from_prior()
     P = eng.download_cloud()
     assert np.all(np.isfinite(P[:, 2])) and np.all(P[:, 0] >= 0.6)
     np.testing.assert_array_equal(P[:, 4], 0.0)                      # old_loglh
