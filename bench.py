@@ -318,9 +318,10 @@ def main():
         import glob
         import re
 
-        kname = ("k_mutate_reg<%d," % D) if D <= 10 else "k_mutate<0>"
-        # (small clouds and sharded runs use engine 2's k2_mutate, a single handle with a larger cloud engine 1's k_mutate_reg)
-        kname_run = ("k2_mutate<%d,...> / k_mutate_reg<%d,...>" % (D, D)) if D <= 10 else "k_mutate<0>"
+        kname = ("k_mutate_reg<%d," % D) if D <= 10 else ("k2w_mutate<%d," % D)
+        # (small clouds and sharded runs use engine 2's k2_mutate, a single handle with a larger cloud engine 1's k_mutate_reg;
+        # n_para 11..16: k2w_mutate - engine 2's prologue in front of the generic mutation body - or, SMCMI_ENGINE_WIDE=0, engine 1's k_mutate)
+        kname_run = ("k2_mutate<%d,...> / k_mutate_reg<%d,...>" % (D, D)) if D <= 10 else ("k2w_mutate<%d,...>" % D)
         traffic, valu = None, None
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_n%d.json" % (args.workload, n_k))),
                            key=lambda f: int(re.search(r"r(\d+)", os.path.basename(f)).group(1)))
@@ -380,14 +381,16 @@ def main():
             tf = flops / (mean_ms * 1e-3) / 1e12
             lanes = os.environ.get("SMCMI_KALMAN_LANES", "")
             split = lanes == "4" or (lanes != "1" and n_k <= 32768)
-            kname5 = ("k_mutate<0, 4> / kalman_lgss_quad: four lanes per particle (the default up to 32 768 particles per handle)" if split else
-                      ("k_mutate<0, 1> / kalman_lgss2: one thread per particle, scalar structure operands (round-2 kernel)"
+            wide = os.environ.get("SMCMI_ENGINE_WIDE", "1") != "0" and os.environ.get("SMCMI_ENGINE", "0") != "1"
+            kk = (lambda ls: ("k2w_mutate<13, %d> (decision + proposal prologue, then the filter)" % ls) if wide else ("k_mutate<0, %d>" % ls))
+            kname5 = (kk(4) + " / kalman_lgss_quad: four lanes per particle (the default up to 32 768 particles per handle)" if split else
+                      (kk(1) + " / kalman_lgss2: one thread per particle, scalar structure operands (round-2 kernel)"
                        if os.environ.get("SMCMI_KALMAN_WAVE", "1") == "0" else
-                       "k_mutate<0, 1> / kalman_lgss_wave: one thread per particle, structure values through DPP operands"))
+                       kk(1) + " / kalman_lgss_wave: one thread per particle, structure values through DPP operands"))
             # counter figures for the filter's kernel at this cloud size, when a PMC file exists (profiles/rNN_pmc_kalman_n<N>.json)
             traffic5, valu5 = None, None
             if pmc_file:
-                k5 = [(name, v) for name, v in pm["kernels"].items() if "k_mutate<0," in name]
+                k5 = [(name, v) for name, v in pm["kernels"].items() if "k_mutate<0," in name or "k2w_mutate<13," in name]
                 if k5:
                     k5.sort(key=lambda nv: -nv[1].get("sum_total_bytes", nv[1].get("total_bytes", 0.0)))
                     traffic5, valu5 = k5[0][1].get("total_bytes"), k5[0][1].get("valu")

@@ -954,6 +954,9 @@ int orc_smc_run(const orc_model *m, const orc_run_config *cfg, double *particles
     if (cfg->variant == 2) {
         const char *ot = getenv("ORC_OPT_THREADS");
         int64_t cap = ot ? atoi(ot) : n / 3072;      /* (32 threads at N = 1e5: measured best on the 256-thread host, 1.9 s vs 2.4 - 2.7 s at 48) */
+        /* a Kalman-filter likelihood costs ~0.5 MFLOP per proposal: the mutation loop, not the wake-ups, is the run - a thread per 48
+           particles (round 3 capped it at 4 threads for 12 500 particles and the "optimised" variant came out slower than the faithful one) */
+        if (!ot && m->lik.family == ORC_LIK_LGSS_KALMAN && cap < n / 48) cap = n / 48;
         if (cap < 1) cap = 1;
         if ((int64_t)mut_threads > cap) mut_threads = (int)cap;
     }

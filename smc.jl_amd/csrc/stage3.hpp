@@ -11,10 +11,11 @@
 //     bit for bit, K1 / K2 of engine 2 would store for the same particles) as tagged 8-byte granules {32-bit payload | 32-bit tag} - a
 //     reader that sees the tag has the payload, no fence, no flag, no counter (the mailbox's wire format, agent scope here);
 //     one GATHERER block per virtual shard (on a CU the workers leave idle, on the shard's own XCD) sweeps its shard's rows, totals
-//     them in the canonical order and publishes the shard total the same way; one DECIDER block totals the V shard totals and does
-//     the stage's scalar work ONCE - decision + proposal (covariance, blocks, Cholesky) after the correction, ϕ_{n+1} (Newton) after
-//     the mutation - and publishes the result as a record every block fetches.  Three store -> load hops per hand-over, no atomics;
-//     (a first version with per-shard tickets and "last arriver totals" needed nine dependent memory round trips of ~1.5 µs each);
+//     them in the canonical order and publishes the shard total the same way; EVERY block - gatherers included - then fetches the V
+//     shard totals and derives the stage's decisions itself (decide2, post2, begin2_wave; the workers also proposal2): same inputs,
+//     same code, same result everywhere, as in engine 2's kernels; worker 0 records them.  Two store -> load hops per hand-over, no
+//     atomics (a first version with per-shard tickets and "last arriver totals" needed nine dependent memory round trips of ~1.5 µs
+//     each; one decider block that published the decision as a record cost a third hop: 37.8 against 37.1 µs per stage);
 //   * the workers draw the NEXT stage's random numbers while they wait for its begin (they depend on (seed, particle, stage) only).
 //
 // Rows, totals, decision logic (begin2_wave, decide2, post2, proposal2) and the MH body (k2_mh_steps) are engine 2's own functions:
@@ -53,11 +54,6 @@ static_assert(sizeof(RecA3) % 4 == 0 && sizeof(RecB3<10>) % 4 == 0, "records are
 constexpr size_t REC3_WORDS = (sizeof(RecA3) + sizeof(RecB3<10>)) / 4 + 16;       // granules a handle allocates (RecA at 0, RecB behind it)
 constexpr int REC3_B_OFF = (int)(sizeof(RecA3) / 4) + 4;
 
-__device__ inline void rec3_publish(unsigned long long *rec, const void *src_lds, int nwords, unsigned tag) {
-    const unsigned *w = reinterpret_cast<const unsigned *>(src_lds);
-    for (int k = threadIdx.x; k < nwords; k += blockDim.x)
-        __hip_atomic_store(rec + k, ((unsigned long long)tag << 32) | (unsigned long long)w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // all threads call; false: a wait timed out (flag words `to` as the mailbox's: to[0] sticky flag, to[1] ticks).
 // ONE lane of the block polls (word 0, with a sleep between probes): seventy thousand threads probing the same two dozen cache lines
 // would queue every other memory access of the chip - the deciding block's included - behind their probes.  When word 0 is there the

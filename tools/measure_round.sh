@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round measurement pipeline (one MI355X): every file profiles/README.md lists, into gpurun_out/final/.
 # usage (GPU box): bash tools/measure_round.sh [rNN]
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -14,9 +14,9 @@ python bench.py --workload capm --steps 3 --warmup 1 2>/dev/null | tail -1 > $OU
 python bench.py --workload kalman --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
 # config 5 on its stated machine: 50 000 particles on 4 GPUs = 12 500 per GPU (lane-split filter), and the round-2 kernel on the same cloud
 python bench.py --workload kalman --nparts 12500 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500.json
-SMCMI_KALMAN_LANES=1 SMCMI_KALMAN_WAVE=0 SMCMI_DEBUG_MUT=512 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_one_thread_r02_kernel.json
+SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_engine1_stage.json
 python bench.py --workload kalman --nparts 25000 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n25000.json
-SMCMI_KALMAN_WAVE=0 SMCMI_DEBUG_MUT=512 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_r02_kernel.json
+SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_engine1_stage.json
 gcc -O2 -std=c99 -ffp-contract=off -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
 LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
 python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
