@@ -79,8 +79,7 @@ struct smcmi_handle {
     bool mbox_tried = false;
     bool mbox_used = false;                   // the last engine-2 run of this handle handed its sums over through the mailbox
     unsigned mbox_epoch = 0;
-    double *d_snap = nullptr;         // single-handle runs that may use engine 3: the cloud the run started from (repeat after a segment time-out)
-    DevState snap_st;                 // ... and its loop state
+    double *d_snap = nullptr;         // single-handle runs that may use engine 3: the cloud the run started from and, behind it, its DevState (repeat after a segment time-out)
     int seg_timeouts = 0;             // runs repeated as launches after a segment time-out
     double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
     int *d_mixpos = nullptr;

@@ -364,7 +364,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         const int rank = multi ? (g.rccl ? h->rank : shard_rank(h)) : 0;
         if (int e = ensure_eng2(h, g.world, rank, g.hs.size() == 1 && !g.rccl)) return e;
         if (multi && ensure_shard_buffers(h)) return SMCMI_ERR_HIP;
-        if (pull_state(h) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
+        // (a fresh run rebuilds the loop state from scratch: only a continuation needs what the device holds - one 70 KB copy and a host
+        // round trip less at the start of every run)
+        if ((cont && pull_state(h)) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
         DevState &s = h->h_st;
         RunParams rp{};
         rp.n_parts = h->cfg.n_parts; rp.n_blocks = rc->n_blocks; rp.n_mh_steps = rc->n_mh_steps; rp.n_phi = rc->n_phi;

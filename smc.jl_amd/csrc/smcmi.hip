@@ -345,7 +345,7 @@ extern "C" int smcmi_upload_cloud_device(smcmi_handle *h, const double *dev_part
     if (!h || !dev_particles) return set_err(SMCMI_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (pull_state(h)) return SMCMI_ERR_HIP;
-    HIP_TRY(hipMemcpyAsync(h->cl.buf[h->h_st.cur], dev_particles, sizeof(double) * h->n * h->R, hipMemcpyDeviceToDevice, h->stream));
+    launch_copy_f64(h->cl.buf[h->h_st.cur], dev_particles, (long long)h->n * h->R, h->stream);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1465,20 +1465,20 @@ static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result
     ShardGroup g;
     g.hs = {h}; g.world = 1; g.rccl = false;
     static const int e3_off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
-    const bool may_seg = !e3_off && h->n <= 131072 && (!h->e2 || h->e2->e3_state >= 0);
-    const size_t cloud_bytes = sizeof(double) * (size_t)h->n * h->R;
+    const bool may_seg = !e3_off && h->d <= 10 && h->n <= 131072 && (!h->e2 || h->e2->e3_state >= 0);
+    const long long cloud_n = (long long)h->n * h->R, state_n = (long long)((sizeof(DevState) + 7) / 8);     // (doubles)
     if (may_seg) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        if (!h->d_snap && dmalloc(&h->d_snap, (size_t)h->n * h->R)) return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemcpyAsync(h->d_snap, h->cl.buf[0], cloud_bytes, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(&h->snap_st, h->d_st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->d_snap && dmalloc(&h->d_snap, (size_t)(cloud_n + state_n))) return SMCMI_ERR_HIP;
+        // (both copies stay on the device, in stream order: no host round trip at the start of a run)
+        launch_copy_f64(h->d_snap, h->cl.buf[0], cloud_n, h->stream);
+        HIP_TRY(hipMemcpyAsync(h->d_snap + cloud_n, h->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream));
     }
     int e = run2_impl(g, rc, res);
     if (e == SMCMI_ERR_TIMEOUT && may_seg && h->e2 && h->e2->e3_state < 0) {
         if (getenv("SMCMI_TRACE")) fprintf(stderr, "[smcmi3] segment time-out: the run is repeated as launches from the cloud it started with\n");
-        HIP_TRY(hipMemcpyAsync(h->cl.buf[0], h->d_snap, cloud_bytes, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->d_st, &h->snap_st, sizeof(DevState), hipMemcpyHostToDevice, h->stream));
+        launch_copy_f64(h->cl.buf[0], h->d_snap, cloud_n, h->stream);
+        HIP_TRY(hipMemcpyAsync(h->d_st, h->d_snap + cloud_n, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         e = run2_impl(g, rc, res);
         h->seg_timeouts += 1;

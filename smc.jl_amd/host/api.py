@@ -278,7 +278,7 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     The remaining reference keywords are accepted for call compatibility: `testing` suppresses the file output like the
     reference's (src/smc_main.jl:513); `parallel` is moot (the device is the parallelism); `data_vintage`, `old_vintage`,
     `smc_iteration`, `run_test`, `filestring_addl`, `intermediate_stage_start`, `toggle`, `debug_assertion` only label or
-    guard things that do not exist here; `regime_switching=True` is not supported.  A tempered update without `old_cloud`
+    guard things that do not exist here.  A tempered update without `old_cloud`
     loads the old cloud from `loadpath` (src/smc_main.jl:245-246).
 
     Intermediate saves (src/smc_main.jl:499-507): with `save_intermediate`, every `intermediate_stage_increment` stages the
@@ -299,8 +299,8 @@ def smc(loglikelihood, parameters, data, *, verbose="low", n_parts=5000, n_block
     d = len(parameters)
     if all(p.fixed for p in parameters):
         raise AssertionError("All model parameters are fixed!")
-    if regime_switching and isinstance(loglikelihood, DeviceLikelihood):
-        raise ValueError("regime_switching = true needs a likelihood closure (the device families take a fixed parameter layout)")
+    # (a device family sees the same flattened vector a closure does - regime-1 values of every parameter, then the other regimes'
+    # values key by key: its parameter layout must cover all those columns)
     if old_data is not None and np.size(old_data) and initial_cloud is None and old_cloud is None and not continue_intermediate:
         if not loadpath:
             raise ValueError("a tempered update (non-empty old_data) needs old_cloud = the Cloud of the old estimation, or loadpath")
@@ -604,11 +604,9 @@ def mutation(loglikelihood, parameters, data, p, d_mu, d_Sigma, n_free_para, blo
 def initial_draw(loglikelihood, parameters, data, cloud, parallel=False, regime_switching=False, toggle=True, seed=0, device=0):
     """initial_draw! (src/initialization.jl:88-119): fills `cloud` (n_parts x n_para + 5) with prior draws whose log-likelihood is
     finite, their loglh / logprior, old_loglh = 0, weight 1.  Device likelihoods only; returns the cloud."""
-    if regime_switching:
-        raise NotImplementedError("regime_switching = true is outside this build")
     if not isinstance(loglikelihood, DeviceLikelihood):
         raise NotImplementedError("initial_draw() takes a device likelihood; host callbacks run through smc()")
-    parameters = list(parameters)
+    parameters = flatten_regimes(list(parameters), regime_switching)      # (the regime columns are drawn like any other, smc_main.jl:207-234)
     n, d = len(cloud), len(parameters)
     eng = Engine(n, d, seed=seed, device=device, max_stages=2, store_history=False)
     try:

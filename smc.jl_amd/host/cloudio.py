@@ -34,6 +34,8 @@ def save_arrays(path, **arrays):
         items, grp = {}, {}
         for k, v in arrays.items():
             (grp if k.startswith("cloud_") else items)[k[6:] if k.startswith("cloud_") else k] = np.asarray(v)
+        if "n_Phi" in grp:
+            grp["n_\u03a6"] = grp.pop("n_Phi")          # the reference's field name (src/particle.jl:37: n_Φ), UTF-8 in the file
         if grp:
             items["cloud"] = grp
         h5min.write_julia(path, items)
@@ -51,6 +53,8 @@ def load_arrays(path):
         z = h5min.read(path, julia=True)
         out = {k: v for k, v in z.items() if not isinstance(v, dict)}
         out.update(z.get("cloud", {}))
+        if "n_\u03a6" in out:
+            out["n_Phi"] = out.pop("n_\u03a6")
         return out
     z = np.load(path)
     return {k: z[k] for k in z.files}

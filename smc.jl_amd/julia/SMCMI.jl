@@ -222,7 +222,7 @@ Drop-in for `SMC.smc` (src/smc_main.jl:118-161): same positional arguments, same
 `savepath` with `_stage=i` (smc_main.jl:499-507, 513-526).  `loglikelihood` is the user's closure
 `loglikelihood(parameters::ParameterVector, data::Matrix{Float64})::Float64` or one of the `DeviceLikelihood` structs.
 Returns `(cloud, w, W)` in addition to writing the files (the reference returns nothing, quirk Q8).
-`regime_switching = true` (closures only) samples the extra regime values as additional columns; `parallel` is moot (the device is
+`regime_switching = true` samples the extra regime values as additional columns (a device family then takes the flattened vector); `parallel` is moot (the device is
 the parallelism).
 """
 function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
@@ -240,8 +240,6 @@ function smc(loglikelihood, parameters::ParameterVector, data::Matrix{Float64};
              regime_switching::Bool = false, toggle::Bool = true, debug_assertion::Bool = false,
              log_prob_old_data::Float64 = 0.0, seed::Integer = rand(UInt64), device::Integer = 0)
     haskey(RESAMPLER, resampling_method) || throw("Invalid resampler in SMC. Options are :systematic, :multinomial, or :polyalgo")
-    regime_switching && loglikelihood isa DeviceLikelihood &&
-        throw(ArgumentError("regime_switching = true needs a likelihood closure (the device families take a fixed parameter layout)"))
     0.0 <= tempered_update_prior_weight <= 1.0 ||
         throw(DomainError("The keyword tempered_update_prior_weight must be within the interval [0, 1] but " *
                           "is currently set to $(tempered_update_prior_weight)"))

@@ -218,8 +218,19 @@ def test_regime_switching_columns():
     assert cloud.particles.shape == (3000, 3 + 5)
     m = S.weighted_mean(cloud)
     assert abs(m[0] - y[:T // 2].mean()) < 0.1 and abs(m[2] - y[T // 2:].mean()) < 0.1 and abs(m[1] - 0.3) < 1e-12
-    with pytest.raises(ValueError):
-        S.smc(S.GaussIso(0.25), pars, data, regime_switching=True, n_parts=100, verbose="none")
+    # a DEVICE family with regime switching (VERDICT r3 missing 5): it sees the same flattened vector (mu, sig, mu_reg2) a closure sees -
+    # here a Gaussian centred on (0.5, 0.3, 2.0) - and must sample what the closure form of the same density samples
+    m3 = np.array([0.5, 0.3, 2.0])
+    kw = dict(regime_switching=True, n_parts=3000, n_phi=40, verbose="none", seed=2)
+    c_dev, _, _ = S.smc(S.GaussIso(0.25), pars, m3, **kw)
+
+    def lik3(theta, dat):
+        return -1.5 * math.log(2.0 * math.pi * 0.0625) - 0.5 * float(((theta - dat.ravel()) ** 2).sum()) / 0.0625
+
+    c_cl, _, _ = S.smc(lik3, pars, m3.reshape(3, 1), **kw)
+    assert c_dev.particles.shape == (3000, 8) and np.all(c_dev.particles[:, 1] == 0.3)
+    np.testing.assert_allclose(S.weighted_mean(c_dev), S.weighted_mean(c_cl), atol=1e-6)
+    assert abs(S.weighted_mean(c_dev)[2] - 2.0 * 9.0 / 9.0625) < 0.02
 
 
 def test_reference_regime_switching_scenario():
