@@ -2460,9 +2460,16 @@ SMCMI_FP_CONTRACT
     const int T = blockDim.x, tid = threadIdx.x;
     const bool profme = ma.prof != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);
     long long *profp = ma.prof + (blockIdx.x == 0 ? 0 : 16);
+    // (-DSMCMI_ISA_MARKS, profiles/isa_phases.py: the phase boundaries as comments in the ISA - the per-phase instruction census)
+#ifdef SMCMI_ISA_MARKS
+#define SMCMI_MARK(slot) asm volatile("; SMCMI_MARK " #slot ::: "memory")
+#else
+#define SMCMI_MARK(slot) (void)0
+#endif
 #define SMCMI_PROF(slot)                                                                                    \
     do {                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
+        SMCMI_MARK(slot);                                                                                   \
         if (profme) { unsigned long long tt_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory"); profp[slot] = (long long)tt_; } \
     } while (0)
     SMCMI_PROF(0);
@@ -2602,6 +2609,10 @@ SMCMI_FP_CONTRACT
                     ua[q] = 0.5; ub[q] = 0.0;
                     if (2 * q < db) uniform_pair(ma.seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua[q], ub[q]);
                 }
+#ifdef SMCMI_ISA_MARKS
+                __builtin_amdgcn_sched_barrier(0);
+                SMCMI_MARK(31);
+#endif
 #pragma unroll
                 for (int g0 = 0; g0 < NP2; g0 += GRP) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -2729,6 +2740,8 @@ SMCMI_FP_CONTRACT
     }
     SMCMI_PROF(9);
 #undef SMCMI_PROF
+#undef SMCMI_MARK
+#undef SMCMI_MARK
 }
 
 // ------------------------------------------------------------------------------------------------ initial draw

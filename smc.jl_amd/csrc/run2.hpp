@@ -94,7 +94,7 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
     }
-    if (g.direct) {                   // engine 3 (stage3.hpp) can serve this geometry: tickets, records, time-out words, per-launch stage counts
+    if (g.direct || (g.inker && !g.wide && g.t2 == T3 && g.nb1 == g.nb2)) {       // engine 3 (stage3.hpp) can serve this geometry: tickets, records, time-out words, per-launch stage counts
         const size_t gw = k3_table_words(g.Vl * g.nb2);
         if (dmalloc(&e->d_tick3, 2 * SEG3_TICKS) || dmalloc(&e->d_rec3, REC3_WORDS) || dmalloc(&e->d_to3, 2) || dmalloc(&e->d_done3, SEG3_MAX_LAUNCHES) ||
             dmalloc(&e->d_gran3, gw)) {
@@ -165,8 +165,8 @@ static int mbox_alloc(smcmi_handle *h) {
     if (h->d_mbox) return 0;
     HIP_TRY(hipSetDevice(h->cfg.device));
     // fine-grained: stores from a peer GPU and this GPU's polling loads meet in memory, not in a die's L2
-    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * (MB_WORDS + MB_FLAG_WORDS), hipDeviceMallocFinegrained));
-    HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_WORDS));
+    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * MB_ALLOC_WORDS, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_ALLOC_WORDS));
     if (int e = mbox_reset_flag(h, nullptr)) return e;
     HIP_TRY(hipDeviceSynchronize());              // (null-stream fill: not ordered with the handle's non-blocking stream)
     return 0;
@@ -320,7 +320,7 @@ static int seg3_ready(smcmi_handle *h, bool *ok) {
     const int grid = g.Vl * g.nb2 + g.Vl;                      // workers + one gatherer per virtual shard, one CU each
     int n_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
-    if (off || !g.direct || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
+    if (off || !(g.direct || g.inker) || g.wide || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
     if (e->e3_state < 0) return 0;
     if (e->e3_state == 0) {
         int *d_ok = nullptr;
@@ -514,13 +514,47 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // ---- engine 3: runs of stages that neither resample nor need a certificate pass become one persistent launch each
     bool e3 = false;
     if (!multi && !g.rccl && g.hs.size() == 1) { if (int e = seg3_ready(h0, &e3)) return e; }
+    // several handles: the segments span them when the peer mailbox is up (the gatherers post their shard totals into every handle's
+    // tables, stage3.hpp Seg3Args::peers) and every handle's grid passed its residency self-test - all ranks must take the same decision
+    static const int e3_multi = getenv("SMCMI_ENGINE3_SHARDED") ? atoi(getenv("SMCMI_ENGINE3_SHARDED")) : 1;
+    // (handles of ONE process share the device's few hardware queues: beyond two of them a handle's persistent launch can sit in a queue
+    // in front of the launch it waits for - the in-process group driver, a test vehicle, keeps to launches there; =2 forces segments)
+    const bool seg_sys = (multi || g.rccl) && mbox;      // (a one-rank communicator with SMCMI_MAILBOX=2: the measurement vehicle for one rank's share)
+    if (seg_sys && e3_multi && (g.hs.size() <= 2 || e3_multi == 2)) {
+        double bad = 0.0;
+        for (auto *h : g.hs) {
+            bool ok = false;
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            if (int e = seg3_ready(h, &ok)) return e;
+            if (!ok) bad += 1.0;
+        }
+        for (auto *h : g.hs) { HIP_TRY(hipSetDevice(h->cfg.device)); HIP_TRY(hipMemcpyAsync(h->d_comm, &bad, sizeof(double), hipMemcpyHostToDevice, h->stream)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+        if (int e = g.allreduce([](smcmi_handle *h) { return h->d_comm; }, 1)) return e;
+        HIP_TRY(hipSetDevice(h0->cfg.device));
+        HIP_TRY(hipMemcpyAsync(&bad, h0->d_comm, sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+        HIP_TRY(hipStreamSynchronize(h0->stream));
+        e3 = bad == 0.0;
+    }
     std::vector<hipEvent_t> evs3;
     int seg_launches = 0;
     struct SegRange { int a, b; bool enter; };
     std::vector<SegRange> seg_ranges;              // stages each segment launch was enqueued for (error diagnosis)
     if (e3) {
         static const double to_ms = getenv("SMCMI_SEG_TIMEOUT_MS") ? atof(getenv("SMCMI_SEG_TIMEOUT_MS")) : 200.0;
-        if (int e = seg3_time_out_words(h0, to_ms)) return e;
+        for (auto *h : g.hs) { HIP_TRY(hipSetDevice(h->cfg.device)); if (int e = seg3_time_out_words(h, to_ms)) return e; }
+        if (seg_sys) {
+            // one launch sequence for all handles - the tags (sequence << 16 | stage) must agree - restarted for every run on cleared tables:
+            // this handle's rows, and the totals tables every handle posts into
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                Eng2 *e = h->e2;
+                e->seg_seq = 0;
+                HIP_TRY(hipMemsetAsync(e->d_gran3, 0xFF, k3_table_words(e->g.Vl * e->g.nb2) * sizeof(unsigned long long), h->stream));
+                HIP_TRY(hipMemsetAsync(h->d_mbox + MB_SEG_OFF, 0xFF, sizeof(unsigned long long) * 2 * MB_SEG_KIND_WORDS, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            }
+            if (int e = g.barrier()) return e;           // nobody posts before every table is cleared
+        }
     }
     const bool profile = rc->use_graph == 2;
     std::vector<hipEvent_t> evs;
@@ -656,10 +690,19 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     };
     // enter_mut: stage n_first's correction (and selection, if sel) were enqueued as launches - the segment enters at its mutation
     auto enq_K3 = [&](int n_first, int n_last, bool enter_mut = false, bool sel = false) -> int {             // one persistent launch for stages n_first .. n_last (stage3.hpp)
-        smcmi_handle *h = h0;
+        std::vector<Rows2> mrs, crs;
+        for (auto *h : g.hs) { mrs.push_back(mut_rows(h)); crs.push_back(cm_rows(h)); }      // (what the segment's first stage consumes)
+        if (seg_sys) {
+            // the rows these stages leave reach the launches behind the segment as the plain V x m table (Seg3Args::vt_mut_out), not through the mailbox
+            mb_live[1] = false;
+            for (int q = n_first; q <= n_last; ++q) { mb_mut_at.erase(q); if (!(enter_mut && q == n_first)) mb_cm_at.erase(q); }
+        }
+        for (size_t hk = 0; hk < g.hs.size(); ++hk) {
+        smcmi_handle *h = g.hs[hk];
         Eng2 *e = h->e2;
         HIP_TRY(hipSetDevice(h->cfg.device));
         if (++e->seg_seq >= 0xFFFFu) {                               // tags are (launch << 16 | stage): start over on clean records
+            if (seg_sys) return set_err(SMCMI_ERR_CAPACITY, "sharded segments: launch sequence exhausted (65 535 segment launches on one set of handles)");
             HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
             HIP_TRY(hipMemsetAsync(e->d_gran3, 0xFF, k3_table_words(e->g.Vl * e->g.nb2) * sizeof(unsigned long long), h->stream));
             e->seg_seq = 1;
@@ -667,19 +710,25 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         Mut2Args ma{};
         ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n_first; ma.sel_enqueued = sel ? 1 : 0; ma.adaptive = adaptive ? 1 : 0;
         ma.rows_mut = e->rows_mut; ma.zbuf = nullptr; ma.pre = nullptr;
-        ma.cmrows = cm_rows(h); ma.gmrows = gm_rows(h); ma.wt = h->d_wt;
+        ma.cmrows = crs[hk]; ma.gmrows = gm_rows(h); ma.wt = h->d_wt;
         ma.lik[0] = h->h_model.lik[0]; ma.lik[1] = h->h_model.lik[1];
         ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
         ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
         ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
         Seg3Args sa{};
-        sa.n_first = n_first; sa.n_last = n_last; sa.enter_mut = enter_mut ? 1 : 0; sa.mrows = mut_rows(h); sa.sched = h->d_sched;
+        sa.n_first = n_first; sa.n_last = n_last; sa.enter_mut = enter_mut ? 1 : 0; sa.mrows = mrs[hk]; sa.sched = h->d_sched;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
+        if (seg_sys) {                                               // the totals tables every handle posts into: inside the mailbox allocation
+            sa.peers = h->d_peers; sa.world = g.world;
+            sa.off_cm = MB_SEG_OFF; sa.off_mut = MB_SEG_OFF + MB_SEG_KIND_WORDS;
+            sa.gt_cm = h->d_mbox + sa.off_cm; sa.gt_mut = h->d_mbox + sa.off_mut;
+            sa.vt_mut_out = e->vt_mut;
+        }
         sa.rec = e->d_rec3;
         sa.tag_base = e->seg_seq << 16; sa.to = e->d_to3; sa.hist_w = h->d_hist_w; sa.hist_ld = h->n;
-        sa.done_out = seg_launches < SEG3_MAX_LAUNCHES ? e->d_done3 + seg_launches : nullptr;
-        sa.prof = (e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
+        sa.done_out = (h == h0 && seg_launches < SEG3_MAX_LAUNCHES) ? e->d_done3 + seg_launches : nullptr;
+        sa.prof = (h == h0 && e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
         sa.prof_stage = e->prof_stage;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && sa.done_out) { hipEventCreate(&e0); hipEventCreate(&e1); evs3.push_back(e0); evs3.push_back(e1); hipEventRecord(e0, h->stream); }
@@ -689,6 +738,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 #undef SMCMI_CALL
         HIP_TRY(hipGetLastError());                  // (a rejected launch would otherwise surface as a bogus capacity / time-out error)
         if (e1) hipEventRecord(e1, h->stream);
+        }
         ++seg_launches;
         seg_ranges.push_back({n_first, n_last, enter_mut});
         return 0;
@@ -989,7 +1039,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         if (timed_out) {
             for (auto *h : g.hs) { h->mbox_ok = false; h->mbox_tried = true; }        // later runs of these handles use the all-gathers
-            return set_err(SMCMI_ERR_TIMEOUT, "peer mailbox: a rank's per-stage sums did not arrive within the time-out (SMCMI_MAILBOX_TIMEOUT_MS); "
+            return set_err(SMCMI_ERR_TIMEOUT, "peer mailbox (flag " + std::to_string(timed_out) + "): a rank's per-stage sums did not arrive within the time-out (SMCMI_MAILBOX_TIMEOUT_MS); "
                                               "the run is void - repeat it (this handle now uses the all-gathers; SMCMI_MAILBOX=0 does so from the start)");
         }
     }

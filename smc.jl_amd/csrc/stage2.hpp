@@ -95,6 +95,11 @@ constexpr long long MB_TIMEOUT_TICKS_DEFAULT = 1000000000ll;    // ~10 s of the 
                                                                // poisons the totals with NaN and raises the handle's time-out flag, which the
                                                                // driver turns into SMCMI_ERR_TIMEOUT (never into a "no particles" message)
 constexpr int MB_FLAG_WORDS = 2;                               // behind the tables: word MB_WORDS = sticky time-out flag, MB_WORDS + 1 = time-out in ticks
+// behind the flag words: the shard-total tables of persistent stage segments that span several handles (stage3.hpp: a gatherer posts its
+// virtual shard's totals into every handle's copy, every block reads its own handle's) - [V2_MAXV][MB_LD] granule pairs per kind
+constexpr int MB_SEG_OFF = MB_WORDS + MB_FLAG_WORDS;
+constexpr int MB_SEG_KIND_WORDS = V2_MAXV * MB_LD * 2;
+constexpr int MB_ALLOC_WORDS = MB_SEG_OFF + 2 * MB_SEG_KIND_WORDS;
 __device__ inline void mb_store(unsigned long long *w, double v, unsigned tag) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

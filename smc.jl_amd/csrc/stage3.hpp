@@ -93,15 +93,22 @@ __device__ inline void gran_store(unsigned long long *w, double v, unsigned tag)
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(w + 1, ((unsigned long long)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one lane's bounded wait for ONE word to carry `tag` (the sweep proper re-checks every word it uses)
-__device__ inline void gran_poll(const unsigned long long *w, unsigned tag, unsigned long long *to, int *s_to) {
-    unsigned long long a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// the same into another handle's table (fine-grained memory, possibly another GPU's over xGMI): system scope, as the mailbox's mb_store
+__device__ inline void gran_store_sys(unsigned long long *w, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, ((unsigned long long)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one lane's bounded wait for ONE word to carry `tag` (the sweep proper re-checks every word it uses); sys: the word is written by peers
+__device__ inline void gran_poll(const unsigned long long *w, unsigned tag, unsigned long long *to, int *s_to, bool sys = false) {
+    auto ld = [&]() { return sys ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    unsigned long long a = ld();
     if ((unsigned)(a >> 32) == tag) return;
     const long long t0 = wall_clock64();
     const long long lim = (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     do {
         __builtin_amdgcn_s_sleep(1);
-        a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = ld();
         if ((unsigned)(a >> 32) == tag) return;
         if (wall_clock64() - t0 > lim || __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -148,8 +155,11 @@ __device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int 
 }
 // Decider: totals over the nvs shard totals (granules at tbl[v * m * 2]) in the order of reduce_rows (0 + x_0 + x_1 + ...; maximum for
 // max_idx) -> tot[0, m).  All threads call; ends with a barrier.  false: timed out.
-__device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *tot) {
-    if ((int)threadIdx.x < nvs) gran_poll(tbl + (long long)threadIdx.x * m * 2, tag, to, s_to);
+// sys: the table is this handle's copy in fine-grained memory, posted into by the gatherers of every handle (system-scope loads);
+// vt_out (one block): the per-shard values as plain doubles [nvs][m] for the launch behind the segment
+__device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *tot,
+                                     bool sys = false, double *vt_out = nullptr) {
+    if ((int)threadIdx.x < nvs) gran_poll(tbl + (long long)threadIdx.x * m * 2, tag, to, s_to, sys);
     __syncthreads();
     if (*s_to) return false;
     const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)V2_MAXV * m * 16);
@@ -160,8 +170,10 @@ __device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int
             const bool mx = k == max_idx;
             u32x4_t xs[V2_MAXV];
 #pragma unroll
-            for (int v = 0; v < V2_MAXV; ++v)                     // every load in flight before the first use (unconditional, clamped)
-                xs[v] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)(v < nvs ? v : nvs - 1) * (unsigned)m + (unsigned)k) * 16u), 0, 16);
+            for (int v = 0; v < V2_MAXV; ++v) {                   // every load in flight before the first use (unconditional, clamped)
+                const int off = (int)(((unsigned)(v < nvs ? v : nvs - 1) * (unsigned)m + (unsigned)k) * 16u);
+                xs[v] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, /*sc0 sc1: system scope*/ 17) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+            }
             double t = mx ? -__builtin_inf() : 0.0;
 #pragma unroll
             for (int v = 0; v < V2_MAXV; ++v)
@@ -169,6 +181,7 @@ __device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int
                     bad |= (xs[v].y != tag) | (xs[v].w != tag);
                     const double x = __hiloint2double((int)xs[v].z, (int)xs[v].x);
                     t = mx ? fmax(t, x) : t + x;
+                    if (vt_out) vt_out[v * m + k] = x;
                 }
             tot[k] = t;
         }
@@ -224,7 +237,16 @@ struct Seg3Args {
     Rows2 mrows;                   // mutation rows of stage n_first - 1 (direct view: every block totals them for the first begin)
     const double *sched;
     unsigned long long *g_cm, *g_mut;     // the workers' rows as granules: [blocks][MCM * 2] / [blocks][RMUT * 2] words
-    unsigned long long *gt_cm, *gt_mut;   // the shard totals as granules: [V2_MAXV][MCM * 2] / [V2_MAXV][RMUT * 2]
+    unsigned long long *gt_cm, *gt_mut;   // the shard totals as granules: [V2_MAXV][MCM * 2] / [V2_MAXV][RMUT * 2], indexed by GLOBAL virtual shard
+    // several handles (one per GPU; stage2.hpp peer mailbox): a gatherer posts its shard's totals into EVERY handle's tables - gt_cm / gt_mut
+    // are this handle's copies inside its fine-grained mailbox allocation, peers[r] + off_cm / off_mut the same tables of handle r - and
+    // every block reads its own handle's copy: the segment spans the GPUs with the hand-overs it has on one (two store -> load hops, the
+    // second one over xGMI), no collective call, no launch.  Worker 0 leaves the V x RMUT mutation totals of the last completed stage as
+    // plain doubles (vt_mut_out) for the launches behind the segment.
+    unsigned long long *const *peers;     // null: one handle
+    int world;
+    long long off_cm, off_mut;
+    double *vt_mut_out;
     unsigned long long *rec;       // REC3_WORDS granules
     unsigned tag_base;             // launch sequence << 16 (never reused inside a handle's life without clearing the tables)
     unsigned long long *to;        // time-out flag words
@@ -302,6 +324,10 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double), NPm = Mut2Lds<D>::NP;
         if (tid < NWB) reinterpret_cast<double *>(&s_a.bg)[tid] = reinterpret_cast<const double *>(&ctl->bg)[tid];
         if (tid < NWP) reinterpret_cast<double *>(&s_b[(n - 1) & 1].po)[tid] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[tid];
+        if (ma.cmrows.mb) {                                       // mailbox: a launch that will not run must not wait for rows nobody posts (begin2_block)
+            __syncthreads();
+            if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) return;
+        }
         reduce_rows<MCM, 1, T3>(ma.cmrows, s_vt, s_tot);          // (its barriers also publish the LDS copies above)
         if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) return;       // the state this launch was enqueued for is not there: no-op
         double ess;
@@ -342,6 +368,11 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         __syncthreads();
         return s_act;
     };
+    const bool sys = sa.peers != nullptr;
+    auto post_total = [&](unsigned long long *mine, long long off, long long w, double val, unsigned tg) {
+        if (sys) { for (int pr = 0; pr < sa.world; ++pr) gran_store_sys(sa.peers[pr] + off + w, val, tg); }
+        else gran_store(mine + w, val, tg);
+    };
     if (!worker) {
         // ================================================================ GATHERER of local virtual shard vg
         const int vg = (int)blockIdx.x - W;
@@ -351,17 +382,17 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
             if (!entered) {
                 if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to, &run)) break;
-                if (tid < MCM) gran_store(sa.gt_cm + ((long long)vg * MCM + tid) * 2, run, tag);
+                if (tid < MCM) post_total(sa.gt_cm, sa.off_cm, ((long long)(g.v0 + vg) * MCM + tid) * 2, run, tag);
                 // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
-                if (!gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) break;
+                if (!gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, sys)) break;
             }
             const double ess = s_tot[0] * s_tot[0] / s_tot[1];
             if (!entered) { double e2; if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &e2) != 0) break; }
             if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, entered ? rs0 : 0, &s_b[n & 1].po);
             __syncthreads();
             if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to, &run)) break;
-            if (tid < RMUT) gran_store(sa.gt_mut + ((long long)vg * RMUT + tid) * 2, run, tag);
-            if (!gather_totals(sa.gt_mut, g.Vl, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot)) break;
+            if (tid < RMUT) post_total(sa.gt_mut, sa.off_mut, ((long long)(g.v0 + vg) * RMUT + tid) * 2, run, tag);
+            if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys)) break;
             if (next_begin(s_b[n & 1].po) != 0) break;
         }
         return;
@@ -455,7 +486,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
         K3_STAMP(sa.prof, 2);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-        if (!entered && !gather_totals(sa.gt_cm, g.Vl, MCM, -1, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
+        if (!entered && !gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, sys)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
         const int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
@@ -521,7 +552,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         if (n < sa.n_last) k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
         // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-        if (!gather_totals(sa.gt_mut, g.Vl, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot)) { timed_out = true; break; }
+        if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 8);
         const int act = next_begin(B.po);
         constexpr int NWB = sizeof(Begin2) / sizeof(double);

@@ -83,7 +83,8 @@ res = run_group(engs, **kw) if world > 1 else engs[0].run(**kw)
 cloud = np.concatenate([e.download_cloud() for e in engs], axis=0)
 print("RESULT " + json.dumps(dict(n_stages=res["n_stages"], resamples=res["resamples"], logmdd=float(res["logmdd"]).hex(),
                                   cloud=hashlib.sha256(np.ascontiguousarray(cloud).tobytes()).hexdigest(),
-                                  stalls=[res.get("solver_stalls", 0), res.get("select_stalls", 0), res.get("spec_stalls", 0)])))
+                                  stalls=[res.get("solver_stalls", 0), res.get("select_stalls", 0), res.get("spec_stalls", 0)],
+                                  segments=res["n_segments"], segment_stages=res["segment_stages"])))
 '''
 
 
@@ -106,6 +107,18 @@ def test_mailbox_hand_overs_reproduce_the_single_handle_bits(kw, extra):
         got = _group(world, kw, dict(SMCMI_MAILBOX="1", **extra))
         for key in ("n_stages", "resamples", "logmdd", "cloud"):
             assert got[key] == ref[key], (world, key, got, ref)
+        # with the mailbox up the persistent segments span the handles (stage3.hpp Seg3Args::peers): most stages ran inside them
+        # (eight handles of ONE process share the device's four hardware queues - a persistent launch could sit in front of the launch it
+        # waits for -, so the in-process driver keeps to launches beyond two handles; one handle per process has no such limit:
+        # tests/test_gpu_multiproc.py)
+        if world == 2:
+            assert got["segments"] >= 1 and got["segment_stages"] >= (got["n_stages"] - 1) // 2, got
+            off = _group(world, kw, dict(SMCMI_MAILBOX="1", SMCMI_ENGINE3_SHARDED="0", **extra))       # ... and as launches: the same bits
+            assert off["segments"] == 0
+            for key in ("n_stages", "resamples", "logmdd", "cloud"):
+                assert off[key] == ref[key], (world, key, off, ref)
+        else:
+            assert got["segments"] == 0
     if extra:
         assert got["stalls"][1] >= 2          # the stall path really ran
 
