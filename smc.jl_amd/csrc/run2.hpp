@@ -540,7 +540,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     struct SegRange { int a, b; bool enter; };
     std::vector<SegRange> seg_ranges;              // stages each segment launch was enqueued for (error diagnosis)
     if (e3) {
-        static const double to_ms = getenv("SMCMI_SEG_TIMEOUT_MS") ? atof(getenv("SMCMI_SEG_TIMEOUT_MS")) : 200.0;
+        // (across ranks the first hand-over of a segment also absorbs the skew between the ranks' hosts: a longer bound)
+        static const double to_env = getenv("SMCMI_SEG_TIMEOUT_MS") ? atof(getenv("SMCMI_SEG_TIMEOUT_MS")) : 0.0;
+        const double to_ms = to_env > 0.0 ? to_env : (seg_sys ? 1000.0 : 200.0);
         for (auto *h : g.hs) { HIP_TRY(hipSetDevice(h->cfg.device)); if (int e = seg3_time_out_words(h, to_ms)) return e; }
         if (seg_sys) {
             // one launch sequence for all handles - the tags (sequence << 16 | stage) must agree - restarted for every run on cleared tables:
@@ -1044,7 +1046,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
     }
     if (s.err == SMCMI_ERR_TIMEOUT) {
-        h0->e2->e3_state = -1;                           // this handle keeps to engine 2's launches from now on
+        for (auto *h : g.hs) h->e2->e3_state = -1;       // these handles keep to engine 2's launches from now on
         return set_err(SMCMI_ERR_TIMEOUT, "engine 3: a hand-over inside a persistent stage segment timed out (SMCMI_SEG_TIMEOUT_MS); the run is void - "
                                           "repeat it (this handle now runs every stage as launches; SMCMI_ENGINE3=0 does so from the start)");
     }

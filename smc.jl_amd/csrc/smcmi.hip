@@ -1461,29 +1461,45 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
 // the cloud already overwritten.  A single-handle run therefore keeps what a repeat needs - the cloud it started from (one
 // device-to-device copy of n x R doubles, ~10 µs at config 2) and the loop state - and repeats itself on engine 2's launches, which the
 // time-out has made the handle's engine from then on.
+// A group of handles (sharded segments, run2.hpp) does the same: a hand-over that ran out anywhere stops that rank's posts, so every rank's
+// run ends in the time-out and every rank repeats - the same decision everywhere without an exchange.
+static int run2_guarded(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res) {
+    static const int e3_off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
+    static const int e3_sharded = getenv("SMCMI_ENGINE3_SHARDED") ? atoi(getenv("SMCMI_ENGINE3_SHARDED")) : 1;
+    smcmi_handle *h0 = g.hs[0];
+    const bool single = g.world == 1 && !g.rccl && g.hs.size() == 1;
+    bool may_seg = !e3_off && h0->d <= 10 && (single || e3_sharded);
+    for (auto *h : g.hs) may_seg = may_seg && h->n <= 131072 && (!h->e2 || h->e2->e3_state >= 0);
+    const long long state_n = (long long)((sizeof(DevState) + 7) / 8);     // (doubles)
+    if (may_seg) {
+        for (auto *h : g.hs) {
+            const long long cloud_n = (long long)h->n * h->R;
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            if (!h->d_snap && dmalloc(&h->d_snap, (size_t)(cloud_n + state_n))) return SMCMI_ERR_HIP;
+            // (both copies stay on the device, in stream order: no host round trip at the start of a run)
+            launch_copy_f64(h->d_snap, h->cl.buf[0], cloud_n, h->stream);
+            HIP_TRY(hipMemcpyAsync(h->d_snap + cloud_n, h->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    int e = run2_impl(g, rc, res);
+    if (e == SMCMI_ERR_TIMEOUT && may_seg && h0->e2 && h0->e2->e3_state < 0) {
+        if (getenv("SMCMI_TRACE")) fprintf(stderr, "[smcmi3] segment time-out: the run is repeated as launches from the cloud it started with\n");
+        for (auto *h : g.hs) {
+            const long long cloud_n = (long long)h->n * h->R;
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            launch_copy_f64(h->cl.buf[0], h->d_snap, cloud_n, h->stream);
+            HIP_TRY(hipMemcpyAsync(h->d_st, h->d_snap + cloud_n, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            h->seg_timeouts += 1;
+        }
+        e = run2_impl(g, rc, res);
+    }
+    return e;
+}
 static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
     ShardGroup g;
     g.hs = {h}; g.world = 1; g.rccl = false;
-    static const int e3_off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
-    const bool may_seg = !e3_off && h->d <= 10 && h->n <= 131072 && (!h->e2 || h->e2->e3_state >= 0);
-    const long long cloud_n = (long long)h->n * h->R, state_n = (long long)((sizeof(DevState) + 7) / 8);     // (doubles)
-    if (may_seg) {
-        HIP_TRY(hipSetDevice(h->cfg.device));
-        if (!h->d_snap && dmalloc(&h->d_snap, (size_t)(cloud_n + state_n))) return SMCMI_ERR_HIP;
-        // (both copies stay on the device, in stream order: no host round trip at the start of a run)
-        launch_copy_f64(h->d_snap, h->cl.buf[0], cloud_n, h->stream);
-        HIP_TRY(hipMemcpyAsync(h->d_snap + cloud_n, h->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream));
-    }
-    int e = run2_impl(g, rc, res);
-    if (e == SMCMI_ERR_TIMEOUT && may_seg && h->e2 && h->e2->e3_state < 0) {
-        if (getenv("SMCMI_TRACE")) fprintf(stderr, "[smcmi3] segment time-out: the run is repeated as launches from the cloud it started with\n");
-        launch_copy_f64(h->cl.buf[0], h->d_snap, cloud_n, h->stream);
-        HIP_TRY(hipMemcpyAsync(h->d_st, h->d_snap + cloud_n, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        e = run2_impl(g, rc, res);
-        h->seg_timeouts += 1;
-    }
-    return e;
+    return run2_guarded(g, rc, res);
 }
 
 // ------------------------------------------------------------------------------------------------ development aid

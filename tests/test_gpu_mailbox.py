@@ -123,6 +123,18 @@ def test_mailbox_hand_overs_reproduce_the_single_handle_bits(kw, extra):
         assert got["stalls"][1] >= 2          # the stall path really ran
 
 
+def test_a_segment_time_out_in_a_group_repeats_the_run_as_launches():
+    """A hand-over inside a sharded segment that runs out (forced: a bound nothing meets) stops that handle's posts, so every handle's run
+    ends in the time-out; the group driver keeps every handle's starting cloud and loop state and repeats the run on the launches - the
+    caller sees the single-handle result, from launches only."""
+    kw = dict(use_fixed_schedule=False, tempering_target=0.95)
+    ref = _group(1, kw, dict(SMCMI_ENGINE="2"))
+    got = _group(2, kw, dict(SMCMI_MAILBOX="1", SMCMI_SEG_TIMEOUT_MS="0.0001"))
+    assert got["segments"] == 0
+    for key in ("n_stages", "resamples", "logmdd", "cloud"):
+        assert got[key] == ref[key], (key, got, ref)
+
+
 def test_rccl_driver_sets_the_mailbox_up_through_the_communicator():
     """bench.py under torch.distributed.run with one rank: smcmi_run_sharded exchanges the table handle through ncclAllGather, runs
     the 256-round self-test, agrees on the verdict through ncclAllReduce and then hands every stage's sums over through the table
