@@ -64,6 +64,8 @@ struct smcmi_handle {
     // scratch
     int nb_e = 0, nb_m = 0, nb_mr = 0, nb_mut = 0, nb_mut_ls4 = 0, mut_T = 0, nb_reg = 0, reg_T = 0;
     size_t mut_lds = 0, mom_lds = 0, reg_lds_base = 0, prep_lds = 0;
+    double *d_prep_rows = nullptr;    // PREP_G group rows of the prepare launch's two-level totals, the ticket behind them (d_prep_tick)
+    int *d_prep_tick = nullptr;
     double *d_part_ess[2] = {nullptr, nullptr}, *d_part_fin = nullptr, *d_part_cm = nullptr, *d_wt = nullptr, *d_chunk_off = nullptr, *d_cum = nullptr;
     long long *d_anc = nullptr;
     double *d_part_mom = nullptr, *d_totals = nullptr, *d_acc_part = nullptr, *d_esum_part = nullptr, *d_esum_red = nullptr, *d_emax_part = nullptr, *d_zbuf = nullptr, *d_comm = nullptr, *d_offsets = nullptr;

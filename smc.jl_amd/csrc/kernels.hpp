@@ -232,6 +232,67 @@ __device__ inline double final_sum1(const double *partials, int nb, double *scra
     return tot;
 }
 
+// Two-level row totals INSIDE the prepare launch.  One block totalling the 1024 x 68 rows the correction left (config 3 on one GPU)
+// is bound by what a single CU can pull from memory - 557 KB at ~43 GB/s = 13 µs of a 20 µs launch, whatever the number of loads in
+// flight (32 instead of 8: no change) - with 255 CUs idle.  Blocks 1..PREP_G of the same launch therefore total a contiguous chunk of
+// rows each (final_sum: the order is fixed by PREP_G, not by timing) into PREP_G group rows and take a ticket; block 0 waits for the
+// PREP_G tickets and adds the group rows in order.  The group rows travel as agent-scope stores / loads (no fence: see Tail2 in
+// stage2.hpp); all blocks of the launch are resident (it is the only kernel running), the wait is bounded like every other one.
+constexpr int PREP_G = 15;
+constexpr int PREP_MIN_ROWS = 128;   // fewer rows: the hand-over (~2 µs) costs more than one CU's total
+struct PrepRed {
+    double *rows;            // [PREP_G][m] group rows; null: block 0 totals the rows itself
+    int *tick;               // arrivals, zero between launches
+};
+__device__ inline void prep_reduce_block(const PrepRed &pr, const double *partials, int nb, int m, double *scratch) {
+    const int g = (int)blockIdx.x - 1;
+    const int per = (nb + PREP_G - 1) / PREP_G;
+    const int r0 = g * per, rows = (r0 + per <= nb) ? per : (nb > r0 ? nb - r0 : 0);
+    const double v = final_sum(partials + (long long)r0 * m, rows, m, scratch);
+    if ((int)threadIdx.x < m)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(pr.rows) + (long long)g * m + threadIdx.x, (unsigned long long)__double_as_longlong(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the row is acknowledged before the ticket (tail_reduce, stage2.hpp)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(pr.tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// block 0: total idx = threadIdx.x < m of the group rows (0 for the other threads); false: the tickets did not arrive (50 ms)
+__device__ inline bool tickets_wait(int *tick, int need) {       // all threads call; ends with a barrier; re-arms the counter
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 5000000ll) { ok = 0; break; }
+        }
+        __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+__device__ inline double agent_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline void agent_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline bool prep_group_total(const PrepRed &pr, int m, double *out) {
+    const bool ok = tickets_wait(pr.tick, PREP_G);
+    double v = 0.0;
+    if ((int)threadIdx.x < m) {
+        unsigned long long x[PREP_G];
+#pragma unroll
+        for (int g = 0; g < PREP_G; ++g)
+            x[g] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(pr.rows) + (long long)g * m + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int g = 0; g < PREP_G; ++g) v += __longlong_as_double((long long)x[g]);
+    }
+    *out = v;
+    return ok;
+}
+
 // chunk of particles owned by block b out of nb (contiguous, multiple of TB except the last)
 __device__ inline void block_chunk(long long n, int nb, int b, long long &beg, long long &end) {
     long long per = (n + nb - 1) / nb;
@@ -770,9 +831,36 @@ static __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const
 constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
 static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
                                                     int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
-                                                    int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0) {
+                                                    int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0, PrepRed rr = PrepRed{}) {
     __shared__ double scratch[BT];
     __shared__ double s_em[BT], s_em2[64], s_em3[8];     // energy maxima: reduced through LDS behind the barriers the sums need anyway
+    // very many rows (N >= ~5e5: one row per 256 particles): blocks 1.. of THIS launch total a contiguous chunk of rows each into
+    // gridDim.x - 1 group rows (the group's energy maximum behind them) and take a ticket - as the prepare launch's (PrepRed above);
+    // block 0 then reads group rows instead of rows.  This used to be a launch of its own (k_reduce_rows: 4.6 µs + a launch boundary).
+    const int G = (int)gridDim.x - 1;
+    if (blockIdx.x > 0) {
+        if (!rr.rows || st->done) return;
+        const int g = (int)blockIdx.x - 1, per = (acc_nb + G - 1) / G;
+        const int r0 = g * per, rows = (r0 + per <= acc_nb) ? per : (acc_nb > r0 ? acc_nb - r0 : 0);
+        const double tot = final_sum(esum_partials + (long long)r0 * ES, rows, ES, scratch);
+        if (threadIdx.x < ES) agent_store(rr.rows + (long long)g * ES + threadIdx.x, tot);
+        double em = -__builtin_inf();
+        if (emax_part) for (int b = threadIdx.x; b < rows; b += BT) em = fmax(em, emax_part[r0 + b]);
+        em = block_max(em, s_em2, BT / 64);
+        if (threadIdx.x == 0) agent_store(rr.rows + (long long)G * ES + g, em);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(rr.tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const bool two = rr.rows != nullptr && G > 0;
+    if (two) {
+        if (st->done) return;
+        if (!tickets_wait(rr.tick, G)) { if (threadIdx.x == 0) { st->err = SMCMI_ERR_TIMEOUT; st->done = 1; } return; }
+        esum_partials = rr.rows; emax_part = emax_part ? rr.rows + (long long)G * ES : nullptr; emax_n = G;
+    }
+    const int es_nb = two ? G : acc_nb;                   // rows of the energy sums this block reads
+    auto ld = [&](const double *p) { return two ? agent_load(p) : *p; };
     SMCMI_STAMP(prof, 0);
     __shared__ double s_es[ES];
     __shared__ double s_sw[64];          // window of the proposed schedule: s_sw[q] = walk step q + 1 = schedule[j + q] (1-based)
@@ -792,13 +880,13 @@ static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const d
 #pragma unroll
         for (int q = 0; q < 16; ++q) a[q] = 0.0;
         int b = rg;
-        for (; b + 15 * 32 < acc_nb; b += 16 * 32) {
+        for (; b + 15 * 32 < es_nb; b += 16 * 32) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) a[q] += esum_partials[(long long)(b + q * 32) * ES + colx];
+            for (int q = 0; q < 16; ++q) a[q] += ld(esum_partials + (long long)(b + q * 32) * ES + colx);
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            if (b + q * 32 < acc_nb) a[q] += esum_partials[(long long)(b + q * 32) * ES + colx];
+            if (b + q * 32 < es_nb) a[q] += ld(esum_partials + (long long)(b + q * 32) * ES + colx);
         double v = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
                    (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
         v += __shfl_xor(v, 32, 64);                      // the wave's two row-groups
@@ -807,7 +895,7 @@ static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const d
     // largest energy the previous mutation (or k_energy_max) left: per-block / per-shard maxima -> this stage's energy shift
     double em = -__builtin_inf();
     if (emax_part)
-        for (int b = threadIdx.x; b < emax_n; b += BT) em = fmax(em, emax_part[b]);
+        for (int b = threadIdx.x; b < emax_n; b += BT) em = fmax(em, ld(emax_part + b));
     if (done) return;
     SMCMI_STAMP(prof, 1);
     s_em[threadIdx.x] = em;
@@ -1606,7 +1694,8 @@ constexpr int PT = 1024;  // threads of the single prepare block
 // then just loads.  Layout: zbuf[(t ZS + slot) n + i], t = mh_step n_blocks + block, ZS = D + 2 slots: MH uniform, mixture
 // uniform, D normals (zero beyond the block length).  Same tags and the same expressions as the in-kernel path -> same bits.
 constexpr int RA_T = 256;
-constexpr int RA_SKIP = 8;      // blocks 1..7 of k_prepare_mutation idle (block 0 prepares): see rng_ahead_block
+constexpr int RA_SKIP = 16;     // blocks 1..15 of k_prepare_mutation draw nothing (block 0 prepares, the others may total rows): see rng_ahead_block
+
 struct RngAhead {
     double *zbuf;            // null: disabled
     long long n, gid0;
@@ -1655,14 +1744,22 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
 static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
                                                          int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}, int sol_slot = 0,
-                                                         Records rec = Records{}) {
+                                                         Records rec = Records{}, PrepRed pr = PrepRed{}) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
-    if (blockIdx.x > 0) {                    // the idle CUs draw the mutation's random numbers (see RngAhead)
+    __shared__ double scratch[PT];
+    if (blockIdx.x > 0) {
+        if (blockIdx.x <= PREP_G) {          // blocks 1..PREP_G total a chunk of the rows each (see PrepRed)
+            if (pr.rows && (standalone || !st->done)) {
+                const int dd = md->d + 1, np = dd * (dd + 1) / 2;
+                prep_reduce_block(pr, partials, nb_part, from_totals == 3 ? np + 2 : np, scratch);
+            }
+            return;
+        }
+        // the idle CUs draw the mutation's random numbers (see RngAhead)
         if (ra.zbuf && !st->done) rng_ahead_block(st, md, seed, ra);
         return;
     }
     SMCMI_STAMP(prof, 0);
-    __shared__ double scratch[PT];
     __shared__ double mu_f[MAXD];
     __shared__ int bfree[MAXD], bptr[MAXD + 1], fi[MAXD], fi_j[MAXD];
     __shared__ int s_fail;
@@ -1686,7 +1783,10 @@ static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, co
         __shared__ int s_go;
         const PostIn pin = post_load(st, sol_slot);
         const int npf = npairs + 2;
-        const double v = final_sum(partials, nb_part, npf, scratch);
+        double v;
+        if (pr.rows) {
+            if (!prep_group_total(pr, npf, &v)) { if (t == 0) { st->err = SMCMI_ERR_TIMEOUT; st->done = 1; } return; }
+        } else v = final_sum(partials, nb_part, npf, scratch);
         if (t < 2) s_cm[t] = v;
         else if (t < npf) tot[t - 2] = v;
         if (t == 0) s_go = 0;
@@ -1718,7 +1818,10 @@ static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, co
             // all (d+1)(d+2)/2 pair sums in one round of loads: thread (slice, pair) adds the blocks of its slice, eight
             // loads in flight, slices combined in a fixed tree (final_sum); npairs <= PT for d <= 43, else 64-wide chunks
             if (npairs <= PT) {
-                const double v = final_sum(partials, nb_part, npairs, scratch);
+                double v;
+                if (pr.rows) {
+                    if (!prep_group_total(pr, npairs, &v)) { if (t == 0) { st->err = SMCMI_ERR_TIMEOUT; st->done = 1; } return; }
+                } else v = final_sum(partials, nb_part, npairs, scratch);
                 if (t < npairs) tot[t] = v;
                 __syncthreads();
             } else {

@@ -151,7 +151,7 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     if (dmalloc(&h->rec.phi, ms) || dmalloc(&h->rec.ess, ms) || dmalloc(&h->rec.c, ms) || dmalloc(&h->rec.accept, ms) ||
         dmalloc(&h->rec.resampled, ms))
         return SMCMI_ERR_HIP;
-    h->nb_e = (int)std::min<long long>(1024, std::max<long long>(1, (n + 511) / 512));
+    h->nb_e = (int)std::min<long long>(512, std::max<long long>(1, (n + 511) / 512));      // (512 rows, not 1024: less for the prepare launch to total - measured 2-4 % per run from 4e5 to 1e7 particles)
     if (getenv("SMCMI_NB_E")) h->nb_e = std::max(1, std::min(1024, atoi(getenv("SMCMI_NB_E"))));   // development only
     h->nb_m = (int)std::min<long long>(256, std::max<long long>(1, (n + MT - 1) / MT));
     h->nb_mr = (int)std::min<long long>(512, std::max<long long>(std::min<long long>(64, (n + TB - 1) / TB), n / 1024));
@@ -171,12 +171,14 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;
     h->comm_cap = std::max<long long>(2 * KC, h->npairs) + 8;
     h->prep_lds = (size_t)(((h->npairs + 63) / 64) * 64 + 4 * h->d * h->d + 8) * sizeof(double);
-    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) || dmalloc(&h->d_wt, n) ||
+    if (dmalloc(&h->d_part_ess[0], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_ess[1], (size_t)h->nb_e * 2 * KC) || dmalloc(&h->d_part_fin, (size_t)h->nb_e * 2) || dmalloc(&h->d_part_cm, (size_t)h->nb_e * (h->npairs + 2)) || dmalloc(&h->d_prep_rows, (size_t)PREP_G * PT + 8) || dmalloc(&h->d_wt, n) ||
         dmalloc(&h->d_chunk_off, h->nb_e) || dmalloc(&h->d_cum, n) || dmalloc(&h->d_anc, n) ||
         dmalloc(&h->d_part_mom, (size_t)std::max(h->nb_m, h->nb_mr) * h->npairs) || dmalloc(&h->d_totals, h->npairs) ||
         dmalloc(&h->d_acc_part, std::max({h->nb_mut, h->nb_reg, h->nb_mut_ls4})) || dmalloc(&h->d_esum_part, (size_t)std::max({h->nb_mut, h->nb_reg, h->nb_mut_ls4}) * ES) || dmalloc(&h->d_esum_red, (size_t)ESUM_RED_ROWS * (ES + 1)) || dmalloc(&h->d_emax_part, std::max({h->nb_mut, h->nb_reg, h->nb_mut_ls4})) || dmalloc(&h->d_comm, h->comm_cap) || dmalloc(&h->d_offsets, n) ||
         dmalloc(&h->d_flag, 4) || dmalloc(&h->d_mix, (size_t)10 * (3 * 100 + 22)) || dmalloc(&h->d_mixpos, 100))
         return SMCMI_ERR_HIP;
+    h->d_prep_tick = reinterpret_cast<int *>(h->d_prep_rows + (size_t)PREP_G * PT);
+    HIP_TRY(hipMemset(h->d_prep_tick, 0, 8 * sizeof(double)));
     if (h->cfg.store_history) {
         if (dmalloc(&h->d_hist_w, (size_t)n * ms) || dmalloc(&h->d_hist_W, (size_t)n * ms)) return SMCMI_ERR_HIP;
     }
@@ -218,7 +220,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->cbuf) { free_callback_buffers(h->cbuf); h->cbuf = nullptr; }
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
-                    h->d_part_fin, h->d_part_cm, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
+                    h->d_part_fin, h->d_part_cm, h->d_prep_rows, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
                     h->d_comm, h->d_offsets, h->d_hist_w, h->d_hist_W, h->d_prop, h->d_prop_lp, h->d_prop_q,
                     h->d_lik_new, h->d_lik_old, h->d_acc_count, h->d_flag, h->d_cum_full, h->d_part_full, h->d_off_full,
                     h->d_tot_ess, h->d_tot_fin, h->d_tot_mom, h->d_tot_acc, h->d_full_w, h->d_full_cloud, h->d_prof, h->d_mix, h->d_mixpos, h->d_snap};
@@ -901,8 +903,16 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
         ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d;
         grid = RA_SKIP + (unsigned)((h->n + RA_T - 1) / RA_T);
     }
+    // many rows: blocks 1..PREP_G of the launch total a chunk each (PrepRed, kernels.hpp) - one CU alone is bandwidth-bound on them
+    PrepRed pr{};
+    static const int prep_two_level = getenv("SMCMI_PREP_TWO_LEVEL") ? atoi(getenv("SMCMI_PREP_TWO_LEVEL")) : 1;   // development only
+    const int m_rows = from_totals == 3 ? h->npairs + 2 : h->npairs;
+    if (prep_two_level && (from_totals == 3 || from_totals == 1) && nb_part >= PREP_MIN_ROWS && m_rows <= PT && h->d_prep_rows) {
+        pr.rows = h->d_prep_rows; pr.tick = h->d_prep_tick;
+        if (grid < 1u + PREP_G) grid = 1u + PREP_G;
+    }
     k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, h->d_prof ? h->d_prof + 25 : nullptr, ra,
-                                                             sol_slot, h->rec);
+                                                             sol_slot, h->rec, pr);
 }
 
 // ------------------------------------------------------------------------------------------------ whole loop
@@ -935,13 +945,16 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
         const double *es = (adaptive && !no_pred && !host_mut) ? h->d_esum_part : nullptr;
         int es_nb = acc_nb, em_nb = acc_nb;
         const double *em = host_mut ? nullptr : h->d_emax_part;
-        if (es && acc_nb > 2048) {       // one wave per column in k_stage_begin does not scale to tens of thousands of rows
-            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red, h->d_emax_part, h->d_esum_red + (size_t)ESUM_RED_ROWS * ES);
+        // tens of thousands of rows are not for one block: blocks 1..ESUM_RED_ROWS of the same launch total a chunk each (k_stage_begin)
+        PrepRed rr{};
+        unsigned grid = 1;
+        if (es && acc_nb > 2048 && em) { rr.rows = h->d_esum_red; rr.tick = h->d_prep_tick + 1; grid = 1u + ESUM_RED_ROWS; }
+        else if (es && acc_nb > 2048) {
+            k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red, nullptr, nullptr);
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
-            em = h->d_esum_red + (size_t)ESUM_RED_ROWS * ES; em_nb = ESUM_RED_ROWS;
         }
-        k_stage_begin<<<1, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
-                                       h->spec_stage ? 1 : 0, no_eshift ? nullptr : em, em_nb);
+        k_stage_begin<<<grid, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
+                                          h->spec_stage ? 1 : 0, no_eshift ? nullptr : em, em_nb, rr);
     }
     if (adaptive && !h->spec_stage) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);
