@@ -1730,8 +1730,8 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
                 if (2 * q < db) {
                     double ua, ub, sn, cs;
                     uniform_pair(seed, pid, stage, rng_tag(P_MUT, t, 1 + q), ua, ub);
-                    const double rr = sqrt(-2.0 * log(ua));
-                    sincospi(2.0 * ub, &sn, &cs);
+                    const double rr = bx_sqrt(bx_neg2log(ua));
+                    bx_sincos2pi(ub, &sn, &cs);
                     z0 = rr * cs;
                     z1 = (2 * q + 1 < db) ? rr * sn : 0.0;
                 }
@@ -2720,16 +2720,15 @@ SMCMI_FP_CONTRACT
                 for (int g0 = 0; g0 < NP2; g0 += GRP) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) rr[q] = log(ua[q]);
+                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) rr[q] = bx_neg2log(ua[q]);
 #pragma unroll
-                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) rr[q] = sqrt(-2.0 * rr[q]);
+                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) rr[q] = bx_sqrt(rr[q]);
 #pragma unroll
-                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) sincospi(2.0 * ub[q], &sn[q], &cs[q]);
+                    for (int q = g0; q < g0 + GRP && q < NP2; ++q) bx_sincos2pi(ub[q], &sn[q], &cs[q]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < NP2; ++q) {
-                    if (ma.debug & 1) { rr[q] = 1.0; cs[q] = uc - 0.5; sn[q] = unext - 0.5; }
                     z[2 * q] = (2 * q < db) ? rr[q] * cs[q] : 0.0;
                     if (2 * q + 1 < D) z[2 * q + 1] = (2 * q + 1 < db) ? rr[q] * sn[q] : 0.0;
                 }

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "bmmath.hpp"
 
 namespace smcmi {
 
@@ -58,12 +59,24 @@ __host__ __device__ inline void uniform_pair(uint64_t seed, uint64_t pid, uint32
     ub = u53(o.z, o.w);
 }
 
+// The Box-Muller pieces every kernel uses (one definition: all engines draw the same bits): bmmath.hpp's cut-down functions, or - with
+// -DSMCMI_LIBM_BOX_MULLER, the A/B build - the device library's general-purpose ones.
+#ifdef SMCMI_LIBM_BOX_MULLER
+__device__ inline double bx_neg2log(double u) { return -2.0 * log(u); }
+__device__ inline double bx_sqrt(double x) { return sqrt(x); }
+__device__ inline void bx_sincos2pi(double ub, double *s, double *c) { sincospi(2.0 * ub, s, c); }
+#else
+__device__ inline double bx_neg2log(double u) { return bm_neg2log(u); }
+__device__ inline double bx_sqrt(double x) { return bm_sqrt(x); }
+__device__ inline void bx_sincos2pi(double ub, double *s, double *c) { bm_sincos2pi(ub, s, c); }
+#endif
+
 __device__ inline void normal_pair(uint64_t seed, uint64_t pid, uint32_t stage, uint32_t tag, double &z0, double &z1) {
     double ua, ub;
     uniform_pair(seed, pid, stage, tag, ua, ub);
-    const double r = sqrt(-2.0 * log(ua));
+    const double r = bx_sqrt(bx_neg2log(ua));
     double s, c;
-    sincospi(2.0 * ub, &s, &c);      // sin/cos(2π ub) with the cheap exact range reduction
+    bx_sincos2pi(ub, &s, &c);
     z0 = r * c;
     z1 = r * s;
 }

@@ -799,16 +799,15 @@ SMCMI_FP_CONTRACT
     for (int g0 = 0; g0 < NP2; g0 += GRPB) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = log(ua[q]);
+        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = bx_neg2log(ua[q]);
 #pragma unroll
-        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = sqrt(-2.0 * rr[q]);
+        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) rr[q] = bx_sqrt(rr[q]);
 #pragma unroll
-        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) sincospi(2.0 * ub[q], &sn[q], &cs[q]);
+        for (int q = g0; q < g0 + GRPB && q < NP2; ++q) bx_sincos2pi(ub[q], &sn[q], &cs[q]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < NP2; ++q) {
-        if (debug & 1) { rr[q] = 1.0; cs[q] = uc - 0.5; sn[q] = unext - 0.5; }
         z[2 * q] = (2 * q < db) ? rr[q] * cs[q] : 0.0;
         if (2 * q + 1 < D) z[2 * q + 1] = (2 * q + 1 < db) ? rr[q] * sn[q] : 0.0;
     }

@@ -217,13 +217,14 @@ static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned lo
 
 constexpr size_t k3_park_offset(int D) { return (k2_lds_bytes(D) + 15) / 16 * 2; }          // in doubles, 16-byte aligned
 constexpr size_t k3_lds_bytes(int D) { return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double); }
-template <int D>
+// (MIX = false, α = 1: the mixture-component uniform is never read, so its Philox call is not made at all)
+template <int D, bool MIX = true>
 __device__ inline void k3_draw_park(double *z_park, unsigned long long seed, unsigned long long pid, unsigned stage, int db, int debug) {
     double step_prob, uc, z[D];
     draw2<D>(seed, pid, stage, 0u, db, debug, step_prob, uc, z);
     double *p = z_park + threadIdx.x;
     p[0] = step_prob;
-    p[T3] = uc;
+    if constexpr (MIX) p[T3] = uc;
 #pragma unroll
     for (int e = 0; e < D; ++e) p[(2 + e) * T3] = z[e];
 }
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
     LikView lv[2];
     k2_stage_lik<T3>(ma.lik[0], ma.lik[1], L.l_par, L.l_dat, lv);     // once per segment (the mutation rows' scratch is `red`, not this area)
     const int db0 = nb == 1 ? nf : (nf + nb - 1) / nb;          // entries of the first random block
-    k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
+    k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
     __syncthreads();
     int done = 0;
     bool timed_out = false;
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, 
         }
         ++done;
         K3_STAMP(sa.prof, 6);
-        if (n < sa.n_last) k3_draw_park<D>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
+        if (n < sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
         // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
         if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
