@@ -24,6 +24,9 @@ python bench.py --alpha 0.9 --nparts 1000000 --no-history --no-cpu --steps 2 --w
 # one rank's share of config 3 on 8 GPUs (125 000 particles, every hand-over through the all-gather path of a 1-rank RCCL communicator)
 HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu --no-history --nparts 125000 2>/dev/null | grep '^{' | tail -1 > $OUT/${R}_shard_rank_125k.json
+# the same rank with the peer mailbox forced on (system-scope hand-overs): its stages run inside sharded segments
+HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_FORCE_SHARDED=1 SMCMI_MAILBOX=2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 \
+    bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu --no-history --nparts 125000 2>/dev/null | grep '^{' | tail -1 > $OUT/${R}_shard_rank_125k_segments.json
 cd /tmp && export TMPDIR=/tmp
 pmc() {   # pmc <tag> <n> <bench args...>: kernel table + the three counter passes of one configuration
     local tag=$1 n=$2; shift 2
