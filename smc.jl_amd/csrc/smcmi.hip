@@ -948,7 +948,8 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
         // tens of thousands of rows are not for one block: blocks 1..ESUM_RED_ROWS of the same launch total a chunk each (k_stage_begin)
         PrepRed rr{};
         unsigned grid = 1;
-        if (es && acc_nb > 2048 && em) { rr.rows = h->d_esum_red; rr.tick = h->d_prep_tick + 1; grid = 1u + ESUM_RED_ROWS; }
+        // (reducer blocks: ~96 rows each - 40 blocks at N = 1e6, the full 128 from 3e6 on; block 0 adds one group row per reducer)
+        if (es && acc_nb > 2048 && em) { rr.rows = h->d_esum_red; rr.tick = h->d_prep_tick + 1; grid = 1u + (unsigned)std::min(ESUM_RED_ROWS, std::max(16, acc_nb / 96)); }
         else if (es && acc_nb > 2048) {
             k_reduce_rows<<<ESUM_RED_ROWS, TB, 0, s>>>(h->d_esum_part, acc_nb, ES, h->d_esum_red, nullptr, nullptr);
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
@@ -1064,7 +1065,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
-    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 16;
+    const int sync_every = rc->sync_every > 0 ? rc->sync_every : 32;     // (16 until round 4: 36.75 vs 36.45 ms per run at N = 1e6)
     const int acc_nb = mut_blocks(h);
     // largest energy of the initial cloud, in the layout the mutation epilogue uses afterwards (stage 1's energy shift)
     k_energy_max<<<acc_nb, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
