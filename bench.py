@@ -291,6 +291,8 @@ def main():
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world,
                    "hand_over": hand_over},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
+        # stages that ran inside persistent segments (engine 3; with several ranks: sharded segments through the peer mailbox)
+        "segments": last.get("n_segments", 0), "segment_stages": last.get("segment_stages", 0),
         "logmdd_exact": models.gauss_logmdd(D) if args.workload == "gauss10" else None, "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
     }
 
