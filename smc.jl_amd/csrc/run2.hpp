@@ -393,19 +393,14 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         if (push_state(h)) return SMCMI_ERR_HIP;
         if (!cont) {
-            const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};
-            HIP_TRY(hipMemcpyAsync(h->rec.phi, &v0[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->rec.ess, &v0[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->rec.c, &v0[2], sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->rec.accept, &v0[3], sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemsetAsync(h->rec.resampled, 0, sizeof(int) * h->cfg.max_stages, h->stream));
             if (h->cfg.store_history) {
                 HIP_TRY(hipMemsetAsync(h->d_hist_w, 0, sizeof(double) * h->n, h->stream));
-                HIP_TRY(hipMemcpyAsync(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+                launch_copy_f64(h->d_hist_W, h->cl.buf[0] + (long long)(h->R - 1) * h->n, h->n, h->stream);
             }
-            HIP_TRY(hipStreamSynchronize(h->stream));
         }
-        k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
+        // (the run's first records ride on the import kernel: four 8-byte host copies and a stream sync less per run)
+        k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl, h->rec, cont ? 0 : 1, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target);
         HIP_TRY(hipMemsetAsync(h->e2->d_tick, 0, 2 * V2_MAXV * sizeof(int), h->stream));
         // random numbers drawn ahead: while K1 leaves most CUs idle (small clouds = the direct geometry with 512-thread mutation blocks)
         static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
@@ -734,7 +729,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         sa.prof_stage = e->prof_stage;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && sa.done_out) { hipEventCreate(&e0); hipEventCreate(&e1); evs3.push_back(e0); evs3.push_back(e1); hipEventRecord(e0, h->stream); }
-        if (sa.done_out) HIP_TRY(hipMemsetAsync(sa.done_out, 0, sizeof(int), h->stream));
+        // (the stage counters of all launches of a run are cleared once, in front of its first segment: a fill per launch was 5 µs each)
+        if (sa.done_out && seg_launches == 0) HIP_TRY(hipMemsetAsync(e->d_done3, 0, SEG3_MAX_LAUNCHES * sizeof(int), h->stream));
 #define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0)
         SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL

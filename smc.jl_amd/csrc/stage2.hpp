@@ -469,8 +469,10 @@ __device__ inline void vchunk(const Geo2 &g, int vl, int r, long long per, long 
 // ------------------------------------------------------------------------------------------------ state import / export
 // Engine 2 keeps its loop state in Ctl2; the C ABI's stand-alone calls, pause / continue and the result read DevState.  One
 // thread copies one into the other at the start / end of a run.
-static __global__ void k2_import(const DevState *st, Ctl2 *ctl) {
+// fresh: a new run's first records (ϕ_1 = 0, ESS, c, target acceptance: smc_main.jl:337-352) are written here, not by four host copies
+static __global__ void k2_import(const DevState *st, Ctl2 *ctl, Records rec = Records{}, int fresh = 0, double ess0 = 0.0, double c0 = 0.0, double acc0 = 0.0) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (fresh) { rec.phi[0] = 0.0; rec.ess[0] = ess0; rec.c[0] = c0; rec.accept[0] = acc0; }
     Ctl2 c;
     memset(&c, 0, sizeof(c));
     Post2 &p = c.ps[st->stage & 1];
