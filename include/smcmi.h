@@ -234,7 +234,13 @@ int smcmi_sync(smcmi_handle *h);
    One handle per GPU/process, equal contiguous shards.  smcmi_comm_unique_id on rank 0 -> broadcast the 128 bytes by any means
    -> smcmi_comm_init on every rank (RCCL communicator over xGMI) -> smcmi_run_sharded: the loop of smcmi_run with in-stream
    all-reduces of the stage sums and an all-gather on resample stages.  smcmi_run_group drives several handles of ONE process
-   in lock step (single-process multi-shard / multi-GPU; host-mediated sums). */
+   in lock step (single-process multi-shard / multi-GPU; host-mediated sums).
+   n_para <= 16 with device likelihood families runs on the two-launch stage (per-stage sums through the peer mailbox when every
+   rank could map and test it, runs of stages without resampling as one persistent launch per rank); a handle with a registered
+   likelihood callback (smcmi_set_likelihood_callback on EVERY rank, src/smc_main.jl:472-476 `parallel = true`) scores the
+   proposals it holds through that callback inside the same call.  A hand-over that runs out (SMCMI_ERR_TIMEOUT: a GPU shared
+   after the residency test, a stalled peer) voids a run; persistent-segment time-outs are repeated as launches from a
+   device-side snapshot before the call returns. */
 int smcmi_comm_unique_id(uint8_t *id_out /* 128 bytes */);
 int smcmi_comm_init(smcmi_handle *h, int32_t rank, int32_t world, const uint8_t *id);
 int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
