@@ -39,7 +39,7 @@ struct Eng2 {
     int *d_done3 = nullptr;
     unsigned seg_seq = 0;
     int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle
-    bool seg_attr_set = false;       // k3_segment's dynamic-LDS opt-in done on this handle's device
+    int seg_attr_set = 0;         /* bit 0: α = 1 variant, bit 1: mixture variant */       // k3_segment's dynamic-LDS opt-in done on this handle's device
     bool wide_attr_set = false;      // k2w_mutate's dynamic-LDS opt-in done on this handle's device
     bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
     int n_steps = 1, n_blocks = 1;

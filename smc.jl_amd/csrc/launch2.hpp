@@ -59,21 +59,25 @@ void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10) k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, nb, h->h_model.n_free, e->d_pre);
 }
-template <int D>
-void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1) {
+// one instantiation per (n_para, α = 1?): the two variants are compiled with different flags (Makefile SEGFLAGS / SEGFLAGS_MIX)
+template <int D, bool A1>
+void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10) {
     const size_t lds = k3_lds_bytes(D);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl);            // workers, gatherers
-    if (!e->seg_attr_set) {                    // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
+    if (!(e->seg_attr_set & (A1 ? 1 : 2))) {   // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
-        hipFuncSetAttribute((const void *)k3_segment<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void *)k3_segment<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        e->seg_attr_set = true;
+        hipFuncSetAttribute((const void *)k3_segment<D, A1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        e->seg_attr_set |= (A1 ? 1 : 2);
     }
-    if (alpha1) k3_segment<D, true><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
-    else k3_segment<D, false><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+    k3_segment<D, A1><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
     }
+}
+template <int D>
+inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1) {
+    if (alpha1) launch_k3_seg<D, true>(h, ma, sa, nb);
+    else launch_k3_seg<D, false>(h, ma, sa, nb);
 }
 
 #define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
@@ -81,18 +85,22 @@ void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, 
     X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *, long long, long long); \
     X template void launch_k2_mutate<D>(smcmi_handle *, const Mut2Args &, int, bool);                                                \
     X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);
-// the persistent segment kernel lives in translation units of its own (inst3.hip): it is the one kernel that gains from the compiler
-// sinking hoisted address / mask computations back into its stage loop (-mllvm -sink-insts-to-avoid-spills: 216 -> 72 B of scratch per
-// lane, 36.4 -> 35.6 µs per stage), where K1 / K2 and the generic mutation kernels lose 1-2 % to the same flag
-#define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_segment<D>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int, bool);
+// the persistent segment kernel lives in translation units of its own (inst3.hip, one per n_para and proposal kind): it is the one kernel
+// that gains from the compiler sinking hoisted address / mask computations back into its stage loop (-mllvm -sink-insts-to-avoid-spills:
+// 216 -> 72 B of scratch per lane, 36.4 -> 35.6 µs per stage), where K1 / K2 and the generic mutation kernels lose 1-2 % to the same flag;
+// the mixture variant (α < 1) additionally without machine LICM (264 -> 40 B of scratch, 70 -> 0 spilled VGPRs: 44.3 -> 42.6 µs per stage;
+// the α = 1 variant is 0.3 % slower that way)
+#define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_seg<D, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+#define SMCMI_LAUNCH3_ONE(D, A) template void launch_k3_seg<D, A>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
 #define SMCMI_LAUNCH_ALL_D(M, X)                                                                                                          \
     M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10) M(X, 11) M(X, 12) M(X, 13) M(X, 14) M(X, 15) M(X, 16)
 #if defined(SMCMI_INST_D)
 SMCMI_LAUNCH2_INSTANCES(, SMCMI_INST_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
 #elif defined(SMCMI_INST3_D)
-SMCMI_LAUNCH3_INSTANCES(, SMCMI_INST3_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
+SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0))
 #else
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
