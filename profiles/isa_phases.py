@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "smc.jl_amd", "csrc", "smcmi.hip")
 OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_isa_k_mutate_reg.json")
 asm = "/tmp/smcmi_isa_marks.s"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DSMCMI_ISA_MARKS", "-S",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-DSMCMI_ISA_MARKS", "-S",
                        "--cuda-device-only", "-o", asm, SRC], stderr=subprocess.DEVNULL)
 lines = open(asm).read().split("\n")
 PHASES = {0: "prologue: staging of the proposal / model constants (once per launch)", 1: "prologue: particle loads", 2: "prologue: rest",
