@@ -85,11 +85,11 @@ inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Arg
     X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *, long long, long long); \
     X template void launch_k2_mutate<D>(smcmi_handle *, const Mut2Args &, int, bool);                                                \
     X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);
-// the persistent segment kernel lives in translation units of its own (inst3.hip, one per n_para and proposal kind): it is the one kernel
-// that gains from the compiler sinking hoisted address / mask computations back into its stage loop (-mllvm -sink-insts-to-avoid-spills:
-// 216 -> 72 B of scratch per lane, 36.4 -> 35.6 µs per stage), where K1 / K2 and the generic mutation kernels lose 1-2 % to the same flag;
-// the mixture variant (α < 1) additionally without machine LICM (264 -> 40 B of scratch, 70 -> 0 spilled VGPRs: 44.3 -> 42.6 µs per stage;
-// the α = 1 variant is 0.3 % slower that way)
+// the persistent segment kernel lives in translation units of its own (inst3.hip, one per n_para and proposal kind) with their own flags
+// (Makefile SEGFLAGS / SEGFLAGS_MIX).  History of the α = 1 variant at n_para 10: default flags 256 VGPRs / 216 B of scratch per lane, 36.4 µs per
+// stage; hoisted computations sunk back into the stage loop (-sink-insts-to-avoid-spills) 72 B, 35.6 µs; no machine LICM instead 229 VGPRs,
+// no spill, 35.2 µs (both together: 36.6).  The mixture variant needs both (251 VGPRs, no spill, 42.5 µs; LICM off alone: 77 spilled
+// registers, 45.3 µs).  K1 / K2 and the generic mutation kernels lose 1-2 % to the sinking and are indifferent to the LICM switch.
 #define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_seg<D, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
                                       X template void launch_k3_seg<D, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
 #define SMCMI_LAUNCH3_ONE(D, A) template void launch_k3_seg<D, A>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
