@@ -1234,19 +1234,9 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
     vchunk(g, blockIdx.x / g.nbg, blockIdx.x % g.nbg, g.perg, beg, end);
     double u_sys = 0.0, ub;
     if (method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub);
-    for (long long k = beg + threadIdx.x; k < end; k += TB) {
-        const long long slot = gid0 + k;
-        double ua;
-        if (method == SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, (unsigned long long)slot, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
-        else ua = ((double)slot + u_sys) / (double)N;                       // (i - 1 + offset) / n_parts
-        // (s_lo .. s_hi: the global rows whose cum this handle holds - a sharded run exchanges only its slots' ancestor range)
-        const long long s_end = s_hi < 0 ? N : s_hi + 1;
-        long long lo = s_lo, hi = s_end;
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if (cum[mid] > ua) hi = mid; else lo = mid + 1;
-        }
-        const long long a = lo < s_end ? lo : s_end - 1;
+    // (s_lo .. s_hi: the global rows whose cum this handle holds - a sharded run exchanges only its slots' ancestor range)
+    const long long s_end = s_hi < 0 ? N : s_hi + 1;
+    auto gather_row = [&](long long a, long long k) {
         if (anc) anc[k] = a;
         const double *from = cl.buf[0];
         long long ldf = cl.n, a_row = a;
@@ -1271,6 +1261,64 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
 #pragma unroll
             for (int b = a2; b < DA; ++b) { acc[p] += xx[a2] * xx[b]; ++p; }
         }
+    };
+    // Systematic resampling: the thresholds of consecutive slots ascend, so a tile of TB slots descends from one contiguous range of rows.
+    // A binary search over cum in global memory is 17 dependent loads per slot (~10 of this kernel's 16 µs at N = 1e5); instead the block
+    // keeps cum at the ends of 512-row chunks in LDS (one round of loads), finds the chunks of the tile's first and last threshold there,
+    // stages the rows in between (one more round) and searches in LDS: the same comparisons on the same values, hence the same
+    // ancestors.  Ranges that do not fit (a cloud about to collapse can spread a tile over many rows of tiny weight) and multinomial
+    // resampling keep the search in global memory.
+    constexpr int GCH = 512, G_NC = 2048, G_CAP = 2048;
+    __shared__ double s_ce[G_NC], s_cw[G_CAP];
+    __shared__ long long s_r0, s_r1;
+    const long long span = s_end - s_lo;
+    const int nc = (int)((span + GCH - 1) / GCH);
+    const bool staged = method != SMCMI_RESAMPLE_MULTINOMIAL && span > 0 && nc <= G_NC;       // (block-uniform)
+    if (staged) {
+        for (int c = threadIdx.x; c < nc; c += TB) {
+            const long long last = s_lo + (long long)(c + 1) * GCH - 1;
+            s_ce[c] = cum[last < s_end ? last : s_end - 1];
+        }
+        __syncthreads();
+    }
+    const long long n_tiles = (end - beg + TB - 1) / TB;
+    for (long long tile = 0; tile < n_tiles; ++tile) {
+        const long long k = beg + tile * TB + threadIdx.x;
+        const bool live = k < end;
+        const long long slot = gid0 + (live ? k : end - 1);                  // (a dead thread stands for the tile's last live slot)
+        double ua;
+        if (method == SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, (unsigned long long)slot, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
+        else ua = ((double)slot + u_sys) / (double)N;                       // (i - 1 + offset) / n_parts
+        if (staged) {
+            if (threadIdx.x == 0 || threadIdx.x == TB - 1) {               // the tile's first / last threshold -> first chunk whose end exceeds it
+                int lo = 0, hi = nc;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_ce[mid] > ua) hi = mid; else lo = mid + 1; }
+                // rows below chunk `lo` end at or below the threshold; chunk `lo` (if any) holds a row above it
+                if (threadIdx.x == 0) s_r0 = s_lo + (long long)lo * GCH;
+                else s_r1 = lo < nc ? s_lo + (long long)(lo + 1) * GCH : s_end;
+            }
+            __syncthreads();
+            const long long r0 = s_r0 < s_end ? s_r0 : s_end, r1 = s_r1 < s_end ? s_r1 : s_end;
+            const bool in_lds = r1 - r0 <= G_CAP;                            // (block-uniform)
+            if (in_lds)
+                for (long long j = r0 + threadIdx.x; j < r1; j += TB) s_cw[j - r0] = cum[j];
+            __syncthreads();
+            if (in_lds) {
+                // every slot of the tile has its answer in [r0, r1] (r1 itself = "none": clamped below like the full search)
+                int lo = 0, hi = (int)(r1 - r0);
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cw[mid] > ua) hi = mid; else lo = mid + 1; }
+                const long long lg = r0 + lo;
+                if (live) gather_row(lg < s_end ? lg : s_end - 1, k);
+                continue;
+            }
+        }
+        if (!live) continue;
+        long long lo = s_lo, hi = s_end;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (cum[mid] > ua) hi = mid; else lo = mid + 1;
+        }
+        gather_row(lo < s_end ? lo : s_end - 1, k);
     }
     double *out = rows_gm + (long long)blockIdx.x * pad2(NP);
 #pragma unroll
