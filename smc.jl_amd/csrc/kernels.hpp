@@ -831,7 +831,8 @@ static __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const
 constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
 static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
                                                     int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
-                                                    int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0, PrepRed rr = PrepRed{}) {
+                                                    int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0, PrepRed rr = PrepRed{},
+                                                    int *host_note = nullptr) {
     __shared__ double scratch[BT];
     __shared__ double s_em[BT], s_em2[64], s_em3[8];     // energy maxima: reduced through LDS behind the barriers the sums need anyway
     // very many rows (N >= ~5e5: one row per 256 particles): blocks 1.. of THIS launch total a contiguous chunk of rows each into
@@ -955,6 +956,9 @@ static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const d
     if (i > max_stages) { if (lane == 0) { st->err = SMCMI_ERR_CAPACITY; st->done = 1; } return; }
     Solver &S = st->sol[0];
     if (lane == 0) { st->stage = i; st->phi_prev = phi_n; S.unconverged = 0; }
+    // host-mapped progress word (fixed schedules enqueued without selection kernels, smcmi_run): the host stays a bounded number of
+    // stages ahead of this stage index, so a stage that resamples after all leaves few idle launches behind it
+    if (host_note && lane == 0) __hip_atomic_store(host_note, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (emax_part && lane == 0) {
         double m = s_em3[0];
 #pragma unroll
@@ -1744,7 +1748,7 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
 static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
                                                          int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}, int sol_slot = 0,
-                                                         Records rec = Records{}, PrepRed pr = PrepRed{}) {
+                                                         Records rec = Records{}, PrepRed pr = PrepRed{}, int *host_note = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
     __shared__ double scratch[PT];
     if (blockIdx.x > 0) {
@@ -1804,7 +1808,11 @@ static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, co
                     else verified = ess >= Sv.ess_bar * (1.0 - 1e-13);
                 }
                 if (!verified) st->done = 4;
-                else if (!isnan(ess) && ess < pin.thr) st->done = Sv.spec ? 4 : 3;   // (a spec stage keeps W̃ in scratch: redo it in full)
+                else if (!isnan(ess) && ess < pin.thr) {
+                    st->done = Sv.spec ? 4 : 3;   // (a spec stage keeps W̃ in scratch: redo it in full)
+                    // a host that runs ahead unsynchronised (fixed schedules) learns of the stall without waiting for the stream
+                    if (host_note) __hip_atomic_store(host_note + 1, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 else if (post_write(st, rec, pin, s_cm[0], s_cm[1]) == 0) { s_go = 1; s_c = st->c; }
             }
         }

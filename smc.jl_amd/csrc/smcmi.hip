@@ -218,6 +218,7 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (h->d_mbox) { hipFree(h->d_mbox); h->d_mbox = nullptr; }
     if (h->d_peers) { hipFree(h->d_peers); h->d_peers = nullptr; }
     if (h->cbuf) { free_callback_buffers(h->cbuf); h->cbuf = nullptr; }
+    if (h->h_note) { hipHostFree((void *)h->h_note); h->h_note = nullptr; h->d_note = nullptr; }
     void *ptrs[] = {h->cl.buf[0], h->cl.buf[1], h->d_st, h->d_model, h->d_data[0], h->d_data[1], h->d_aux[0], h->d_aux[1],
                     h->rec.phi, h->rec.ess, h->rec.c, h->rec.accept, h->rec.resampled, h->d_sched, h->d_part_ess[0], h->d_part_ess[1],
                     h->d_part_fin, h->d_part_cm, h->d_prep_rows, h->d_wt, h->d_chunk_off, h->d_cum, h->d_anc, h->d_part_mom, h->d_totals, h->d_acc_part, h->d_esum_part, h->d_esum_red, h->d_emax_part, h->d_zbuf,
@@ -912,7 +913,7 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
         if (grid < 1u + PREP_G) grid = 1u + PREP_G;
     }
     k_prepare_mutation<<<grid, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, partials, nb_part, h->cfg.seed, from_totals, 1, 0, h->d_prof ? h->d_prof + 25 : nullptr, ra,
-                                                             sol_slot, h->rec, pr);
+                                                             sol_slot, h->rec, pr, h->note_on ? h->d_note : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ whole loop
@@ -955,7 +956,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
         }
         k_stage_begin<<<grid, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
-                                          h->spec_stage ? 1 : 0, no_eshift ? nullptr : em, em_nb, rr);
+                                          h->spec_stage ? 1 : 0, no_eshift ? nullptr : em, em_nb, rr, h->note_on ? h->d_note : nullptr);
     }
     if (adaptive && !h->spec_stage) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);
@@ -1080,6 +1081,29 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     // (Fixed schedules: extrapolating the ESS decay was tried and dropped - CAPM-like posteriors collapse within two or three
     // stages, 19 of 20 resamples stalled, and the per-batch sync it needs makes short stages host-bound.)
     const bool predict_select = adaptive && can_fuse_post(h) && sel_mode != 1;
+    // Fixed schedules: the host cannot foresee which stages resample, so EVERY stage is enqueued without the selection kernels
+    // (begin, correction + moments, prepare, mutation: four launches instead of seven) and a stage that resamples after all stalls
+    // (done = 3) and is resumed through the full path, exactly as a mispredicted stage of an adaptive run.  What made this a loss
+    // before was the drain - the whole schedule is enqueued at once, a stall left hundreds of idle launches behind it - and a sync
+    // per batch makes short stages host-bound.  Instead the host stays `run_ahead` stages in front of the device WITHOUT a sync:
+    // k_stage_begin posts its stage index and the stalling k_prepare_mutation a flag into host-mapped words (handle.hpp h_note)
+    // which the enqueue loop polls; a drained stream (an error, a pause, phi = 1) also ends the wait.
+    static const int fixed_sel = getenv("SMCMI_FIXED_NO_SELECT") ? atoi(getenv("SMCMI_FIXED_NO_SELECT")) : 1;        // development: 0 = the seven-launch stage
+    static const int run_ahead = getenv("SMCMI_FIXED_RUN_AHEAD") ? std::max(1, atoi(getenv("SMCMI_FIXED_RUN_AHEAD"))) : 1;   // (config 4: 30.6 ms at 1, 30.8 at 2, 31.1 at 4 - fewer idle launches behind a stall)
+    bool fixed_ns = !adaptive && can_fuse_cm(h) && sel_mode != 1 && fixed_sel != 0 && rc->use_graph != 1;
+    if (fixed_ns && !h->h_note) {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            h->h_note = (volatile int *)hp; h->d_note = (int *)dp;
+        } else {
+            if (hp) hipHostFree(hp);
+            (void)hipGetLastError();
+            fixed_ns = false;
+        }
+    }
+    struct NoteGuard { smcmi_handle *h; ~NoteGuard() { h->note_on = false; } } note_guard{h};
+    h->note_on = fixed_ns;
+    if (fixed_ns) { h->h_note[0] = s.stage; h->h_note[1] = 0; }
     static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
     // (with a prior weight the correction's incremental weight differs from the solver's objective - quirk Q4 - so the ESS it
     // produces cannot verify a predicted root: those runs keep the certificate pass)
@@ -1112,9 +1136,37 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     int stages_left_est = 1 << 30;             // from the last sync: (1 - ϕ_n) / (ϕ_n - ϕ_{n-1}), an over-estimate while the steps grow
     while (launched < max_iter && !done) {
         // near the end of the run the batch shrinks to what is left, so that few no-op stages trail the one that reaches ϕ = 1
-        const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), max_iter - launched) : max_iter - launched;
+        int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), max_iter - launched) : max_iter - launched;
         for (int b = 0; b < batch; ++b) {
             bool no_select = false;
+            if (fixed_ns) {
+                // iteration `launched` begins stage base + launched + 2: wait until the device has begun the stage run_ahead before it
+                const int need = base + launched + 2 - run_ahead;
+                bool leave = false;
+                while (h->h_note[0] < need) {
+                    if (h->h_note[1] != 0) break;
+                    if (hipStreamQuery(h->stream) != hipErrorNotReady) { leave = h->h_note[0] < need; break; }   // nothing left in flight: look at the state
+                }
+                if (h->h_note[1] != 0) {
+                    // Stage h_note[0] resamples after all (the begins behind it returned at once and posted nothing).  No sync: clear
+                    // the stall behind the idle launches already in the stream, run the rest of that stage through the full path
+                    // (tail_only: the correction is done) and go on enqueuing from the stage after it.
+                    const int st_i = h->h_note[0];
+                    h->h_note[1] = 0;
+                    HIP_TRY(hipMemsetAsync(&h->d_st->done, 0, sizeof(int), h->stream));
+                    for (int &it : ev_iter)
+                        if (it >= st_i - 2 - base) it = -1;           // the stalled stage and everything behind it were no-ops
+                    hipEvent_t r0 = nullptr, r1 = nullptr;
+                    if (profile) { hipEventCreate(&r0); hipEventCreate(&r1); evs.push_back(r0); evs.push_back(r1); ev_iter.push_back(st_i - 2 - base); }
+                    enqueue_stage(h, adaptive, 0, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, r0, r1, 0, false, true);
+                    res->select_stalls += 1;
+                    launched = st_i - 1 - base;
+                    batch = max_iter - launched; b = -1;
+                    continue;
+                }
+                if (leave) break;
+                no_select = true;
+            }
             if (predict_select) {
                 // ESS this stage will end at (helpers.jl:14-20), with a margin: a wrong "resample" guess only costs two idle launches
                 const double ess_bar = rc->tempering_target * (pred_rl ? (double)h->cfg.n_parts : pred_ess);
@@ -1143,6 +1195,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         while (done == 2 || done == 3 || done == 4) {
             resumed = true;
             if (pull_state(h)) return SMCMI_ERR_HIP;
+            if (fixed_ns) h->h_note[1] = 0;               // (the stream is drained: no post is in flight)
             const int st_i = s.stage;
             const int had = (st_i == stall_stage) ? stall_p : (st_i - base <= 3 ? first_passes : dyn_P);
             const int zero = 0;
