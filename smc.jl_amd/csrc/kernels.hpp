@@ -1706,21 +1706,24 @@ struct RngAhead {
     int D;
 };
 __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, unsigned long long seed, const RngAhead &ra) {
-    // RA_T particles per block although the launch has PT threads per block (block 0 needs them): 4 wavefronts per CU spread the
-    // draws over the whole chip instead of 16 per CU on a quarter of it
-    if (threadIdx.x >= RA_T) return;
+    // RA_T particles per block although the launch has PT threads per block (block 0 needs them): with one proposal per particle
+    // 4 wavefronts per CU spread the draws over the whole chip instead of 16 per CU on a quarter of it
     // chunk c of RA_T particles is drawn by block c + RA_SKIP: workgroups go round-robin over the 8 XCDs, so the block that draws a
     // chunk sits on the XCD whose L2 the mutation block c (same chunking, blockIdx = c) will read the numbers from
     if (blockIdx.x < RA_SKIP) return;
-    const long long i = (long long)(blockIdx.x - RA_SKIP) * RA_T + threadIdx.x;
+    // the block's other wavefronts take the other (MH step, parameter block) proposals of the same particles: with 3 MH steps
+    // (config 4) 12 wavefronts per block draw 870 instructions each instead of 4 drawing 2 610 - the draws are independent
+    // functions of (seed, particle, stage, proposal), so who draws them changes no bit
+    const int tq = (int)(threadIdx.x / RA_T), tn = (int)(blockDim.x / RA_T);
+    const long long i = (long long)(blockIdx.x - RA_SKIP) * RA_T + (threadIdx.x % RA_T);
     if (i >= ra.n) return;
     const int nf = md->n_free, nb = st->rp.n_blocks, n_steps = st->rp.n_mh_steps, D = ra.D, ZS = D + 2;
     const unsigned stage = (unsigned)st->stage;
     const unsigned long long pid = (unsigned long long)(ra.gid0 + i);
     const int sub = (nf + nb - 1) / nb;
-    for (int step = 0; step < n_steps; ++step)
-        for (int b = 0; b < nb; ++b) {
-            const unsigned t = (unsigned)(step * nb + b);
+    for (int tt = tq; tt < n_steps * nb; tt += tn) {
+            const unsigned t = (unsigned)tt;
+            const int b = tt % nb;
             const int db = (b < nb - 1) ? sub : nf - sub * (nb - 1);
             double step_prob, u_dummy, uc, unext;
             if (t == 0) uniform_pair(seed, pid, stage, rng_tag(P_MUT, 0xFFFFFu, 0), step_prob, u_dummy);

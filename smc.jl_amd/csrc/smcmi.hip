@@ -888,7 +888,8 @@ static int ensure_zbuf(smcmi_handle *h, int n_mh_steps, int n_blocks) {
     const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)n_mh_steps * (size_t)n_blocks;
     // Worth it only while the chip is under-occupied during the set-up launch: measured +4 % at n = 1e5, +1.5 % at 3e5, -5 % at 1e6
     // (config 2); beyond that the draws are cheaper inside the mutation kernel than a round trip through HBM.
-    if ((size_t)h->n * (size_t)n_mh_steps * (size_t)n_blocks > 500000) return 0;
+    static const long long ahead_max = getenv("SMCMI_RNG_AHEAD_MAX") ? atoll(getenv("SMCMI_RNG_AHEAD_MAX")) : 500000;   // development only
+    if ((long long)h->n * n_mh_steps * n_blocks > ahead_max) return 0;
     if (need > h->zbuf_cap) {
         if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
         if (dmalloc(&h->d_zbuf, need)) return SMCMI_ERR_HIP;
