@@ -95,7 +95,8 @@ typedef struct {
     int32_t n_mutate_launches;
     int64_t solver_passes;   /* particle passes spent in the adaptive-ϕ solver over the run */
     int32_t solver_stalls;   /* stages that ran out of enqueued solver passes and were resumed by the host */
-    int32_t select_stalls;   /* stages enqueued without selection kernels that had to resample after all (host resumed them) */
+    int32_t select_stalls;   /* stages enqueued without selection kernels that had to resample after all (host resumed them); on a fixed
+                                schedule with a large cloud every stage is enqueued that way, so this equals the number of resample stages */
     int32_t spec_stalls;     /* stages enqueued without a certificate pass whose predicted ϕ_n was unusable / not verified (resumed) */
     int32_t paused;          /* 1: stopped at stop_after_stage with ϕ_n < 1; continue with continue_run = 1 */
     int32_t n_segments;      /* persistent stage-segment launches of the run (small clouds on one handle: runs of stages that neither
