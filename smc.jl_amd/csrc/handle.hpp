@@ -103,6 +103,7 @@ struct smcmi_handle {
     bool spec_stage = false;     // the enqueued stage takes the predicted ϕ_n without a certificate pass (W̃ goes to d_wt)
     bool fused_cm = false;       // the enqueued stage ran k_correct_moments: the mutation kernel normalises the weights
     bool rng_ahead = false;      // the enqueued stage's k_prepare_mutation fills d_zbuf and the mutation kernel reads it
+    int z_ahead = 0;             //   ... for the first z_ahead proposals (MH step x block) of every particle
     bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
     int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
     bool launch_alpha1 = false;

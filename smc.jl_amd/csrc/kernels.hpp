@@ -1704,6 +1704,7 @@ struct RngAhead {
     double *zbuf;            // null: disabled
     long long n, gid0;
     int D;
+    int t_ahead;             // proposals t < t_ahead are drawn here, the others inside the mutation kernel (see ensure_zbuf)
 };
 __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, unsigned long long seed, const RngAhead &ra) {
     // RA_T particles per block although the launch has PT threads per block (block 0 needs them): with one proposal per particle
@@ -1721,7 +1722,8 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
     const unsigned stage = (unsigned)st->stage;
     const unsigned long long pid = (unsigned long long)(ra.gid0 + i);
     const int sub = (nf + nb - 1) / nb;
-    for (int tt = tq; tt < n_steps * nb; tt += tn) {
+    const int t_end = n_steps * nb < ra.t_ahead ? n_steps * nb : ra.t_ahead;
+    for (int tt = tq; tt < t_end; tt += tn) {
             const unsigned t = (unsigned)tt;
             const int b = tt % nb;
             const int db = (b < nb - 1) ? sub : nf - sub * (nb - 1);
@@ -2002,6 +2004,7 @@ struct MutArgs {
     int debug;                 // development only (tools/kbench.py): bit0 skip normals, bit1 skip prior/likelihood, bit2 skip matvec
     double *esum;              // in-run MODE 0: per-block energy power sums for the next stage's ϕ predictor ([blocks][ES]) or null
     const double *zbuf;        // in-run register kernel: random numbers drawn ahead by k_prepare_mutation (RngAhead layout) or null
+    int z_ahead;               //   ... for the proposals t < z_ahead (the later ones are drawn in the kernel)
     int normalize;             // in-run register kernel after k_correct_moments: the weight column still holds W̃ - apply
                                // normalize_weights! (src/particle.jl:362-366) here and write the W history column
     double *hist_W;
@@ -2700,7 +2703,7 @@ SMCMI_FP_CONTRACT
 #else
             constexpr bool z_only = false;
 #endif
-            if (z_only || ma.zbuf) {
+            if (z_only || (ma.zbuf && (int)t < ma.z_ahead)) {
                 // drawn ahead by the idle CUs during k_prepare_mutation (RngAhead): D + 2 coalesced loads
                 const double *zt = ma.zbuf + (long long)t * (D + 2) * cl.n + i;
                 step_prob = zt[0];

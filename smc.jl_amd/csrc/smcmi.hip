@@ -773,6 +773,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     ma.esum = (!standalone && h->run_adaptive && !no_pred) ? h->d_esum_part : nullptr;
     ma.emax = !standalone ? h->d_emax_part : nullptr;
     ma.zbuf = (!standalone && h->rng_ahead && use_reg_mutate(h)) ? h->d_zbuf : nullptr;
+    ma.z_ahead = h->z_ahead;
     ma.normalize = (!standalone && h->fused_cm) ? 1 : 0;
     ma.hist_W = h->d_hist_W; ma.hist_ld = h->n;
     ma.wt = (!standalone && h->fused_cm && h->spec_stage) ? h->d_wt : nullptr;
@@ -885,11 +886,19 @@ static int ensure_zbuf(smcmi_handle *h, int n_mh_steps, int n_blocks) {
     static const int off = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
     h->rng_ahead = false;
     if (off || !use_reg_mutate(h)) return 0;
-    const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)n_mh_steps * (size_t)n_blocks;
     // Worth it only while the chip is under-occupied during the set-up launch: measured +4 % at n = 1e5, +1.5 % at 3e5, -5 % at 1e6
-    // (config 2); beyond that the draws are cheaper inside the mutation kernel than a round trip through HBM.
+    // (config 2); beyond that the draws are cheaper inside the mutation kernel than a round trip through HBM.  With several
+    // proposals per particle (MH steps x blocks) the first few are drawn ahead - as many as fit the window - and the rest in the
+    // mutation kernel: up to 250 000 particle-proposals - about what the set-up launch's idle window (~10 µs on 255 CUs) absorbs.
+    // Config 4 (3 proposals for each of 200 000 particles) per run: none ahead 30.5 ms, one 29.6-29.8, two 30.2-30.3, all three 30.7.
     static const long long ahead_max = getenv("SMCMI_RNG_AHEAD_MAX") ? atoll(getenv("SMCMI_RNG_AHEAD_MAX")) : 500000;   // development only
-    if ((long long)h->n * n_mh_steps * n_blocks > ahead_max) return 0;
+    static const long long part_max = getenv("SMCMI_RNG_AHEAD_PART") ? atoll(getenv("SMCMI_RNG_AHEAD_PART")) : 250000;  // development only
+    const int props = n_mh_steps * n_blocks;
+    int k_ahead = props;
+    if ((long long)h->n * props > ahead_max) k_ahead = (int)std::min<long long>(props, part_max / (long long)h->n);
+    h->z_ahead = k_ahead;
+    if (k_ahead < 1) return 0;
+    const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)k_ahead;
     if (need > h->zbuf_cap) {
         if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
         if (dmalloc(&h->d_zbuf, need)) return SMCMI_ERR_HIP;
@@ -902,7 +911,7 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
     RngAhead ra{};
     unsigned grid = 1;
     if (h->rng_ahead) {
-        ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d;
+        ra.zbuf = h->d_zbuf; ra.n = h->n; ra.gid0 = h->cfg.gid0; ra.D = h->d; ra.t_ahead = h->z_ahead;
         grid = RA_SKIP + (unsigned)((h->n + RA_T - 1) / RA_T);
     }
     // many rows: blocks 1..PREP_G of the launch total a chunk each (PrepRed, kernels.hpp) - one CU alone is bandwidth-bound on them

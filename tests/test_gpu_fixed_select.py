@@ -104,3 +104,15 @@ def test_fixed_schedule_without_selection_kernels_follows_the_oracle():
     assert abs(r["logmdd"] - got["logmdd"]) < 1e-3          # north_star's log-MDD tolerance
     np.testing.assert_allclose(got["ess"], r["ess"], rtol=1e-6)
     assert [int(x) for x in r["resampled"]] == got["resampled"]
+
+
+def test_random_numbers_partly_drawn_ahead_are_the_same_numbers():
+    """4 proposals for each of 150 000 particles do not fit the set-up launch's window: the first k are drawn ahead by its idle CUs
+    (csrc/smcmi.hip ensure_zbuf, kernels.hpp rng_ahead_block), the others inside the mutation kernel - pure functions of (seed,
+    particle, stage, proposal), so k = 0, 1, 3 and all 4 must leave the same bits (reference: the draws of src/mutation.jl:81-101)."""
+    cfg = dict(CASES[1])
+    runs = [_run(cfg, {"SMCMI_RNG_AHEAD_PART": part, **extra}) for part, extra in
+            (("0", {}), ("250000", {}), ("450000", {}), ("0", {"SMCMI_RNG_AHEAD_MAX": "100000000"}))]
+    for r in runs[1:]:
+        assert r["n"] == runs[0]["n"] and r["resampled"] == runs[0]["resampled"]
+        assert r["logmdd"] == runs[0]["logmdd"] and r["ess"] == runs[0]["ess"] and r["accept"] == runs[0]["accept"] and r["chk"] == runs[0]["chk"]
