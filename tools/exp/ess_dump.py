@@ -1,3 +1,5 @@
+"""development: the ESS trajectory of config 4 around its resample stages (stage, ESS, resampled, ratio to the stage before) - the decay is
+smooth (ratios 0.74 - 0.99), what a host forecast of resample stages could use.  usage (GPU box): python tools/exp/ess_dump.py"""
 import sys, json, numpy as np
 sys.path.insert(0, '/root/repo')
 from tests import models
