@@ -84,7 +84,8 @@ def test_fixed_schedule_without_selection_kernels_pause_and_continue():
     assert parts["logmdd"] == whole["logmdd"] and parts["ess"] == whole["ess"] and parts["chk"] == whole["chk"]
 
 
-def test_fixed_schedule_without_selection_kernels_follows_the_oracle():
+@pytest.mark.parametrize("case", [0, 1], ids=["gauss6", "gauss10_2blocks_multinomial_n150000"])
+def test_fixed_schedule_without_selection_kernels_follows_the_oracle(case):
     """The same run against the CPU restatement (same Philox seed, same initial cloud; the engine under test runs in a child process
     because the library reads its switches once per process)."""
     from oracle import oracle as orc
@@ -92,14 +93,14 @@ def test_fixed_schedule_without_selection_kernels_follows_the_oracle():
     from tests.test_gpu_parity import make_engine
 
     orc.build()
-    cfg = dict(CASES[0])
+    cfg = dict(CASES[case])
     spec = models.gauss_spec(d=cfg["d"])
     got = _run(cfg, {})
     eng = make_engine(spec, cfg["n"], seed=cfg["seed"], max_stages=400)
     eng.init_from_prior()
     P0 = eng.download_cloud()
-    r = orc.smc_run(models.oracle_model(spec), P0, seed=cfg["seed"], use_fixed_schedule=True, n_phi=cfg["n_phi"], n_mh_steps=1, n_blocks=1,
-                    n_threads=8, history=False)
+    r = orc.smc_run(models.oracle_model(spec), P0, seed=cfg["seed"], use_fixed_schedule=True, n_phi=cfg["n_phi"], n_mh_steps=cfg["mh"],
+                    n_blocks=cfg["blocks"], resampling_method=cfg["resampler"], n_threads=32, history=False)
     assert r["n_stages"] == got["n"]
     assert abs(r["logmdd"] - got["logmdd"]) < 1e-3          # north_star's log-MDD tolerance
     np.testing.assert_allclose(got["ess"], r["ess"], rtol=1e-6)
