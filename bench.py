@@ -59,6 +59,23 @@ def spawn_ranks(n_gpus, argv, environ=None, run=None):
     return (run or subprocess.call)(cmd, env=env)
 
 
+def probe_julia(run=None):
+    """is the reference's own runtime on this box?  `julia --version` (the C port stands in for the Distributed.jl path while
+    it is not: `cpu_baseline.kind` = "port").  Returns the version line, or "unavailable"."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("julia")
+    if not exe:
+        return "unavailable"
+    try:
+        p = (run or subprocess.run)([exe, "--version"], capture_output=True, text=True, timeout=30)
+        line = (p.stdout or "").strip().splitlines()
+        return (line[0] if line else "unavailable") + " (present, but SMC.jl and its dependencies are not installed offline: not timed)"
+    except Exception:
+        return "unavailable"
+
+
 def resolve_world(n_gpus, environ):
     """(world, must_spawn): the world size this process runs in and whether bench.py has to launch the ranks itself.
     Raises SystemExit when the environment's world size contradicts --gpus (a silent 1-GPU run must never be reported as N)."""
@@ -102,7 +119,7 @@ def main():
     import numpy as np
     import torch
 
-    from tests import models
+    from smc_jl_amd.host import workloads as models
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -416,7 +433,7 @@ def main():
             from oracle import oracle as orc
 
             orc.build()
-            m = models.oracle_model(spec)
+            m = orc.model_from_spec(spec)
             cores = os.cpu_count() or 1
             variants = {}
             cpu_extra, P_cpu = {}, P0
@@ -434,7 +451,8 @@ def main():
                                              "re-factorisation mutation.jl:81, serial bisection helpers.jl:49, mutation over all cores "
                                              "like @distributed smc_main.jl:472-476)" % (n_total, rf["n_stages"] - 1,
                                                                                          os.environ.get("OMP_WAIT_POLICY", "default")),
-                                   "seconds": rf["seconds"], "logmdd": rf["logmdd"], "variants": variants}
+                                   "seconds": rf["seconds"], "logmdd": rf["logmdd"], "variants": variants,
+                                   "reference_julia": probe_julia()}
             out["logmdd_cpu"] = rf["logmdd"]
             out["logmdd_abs_err"] = abs(last["logmdd"] - rf["logmdd"])
             out["gpu_over_cpu"] = value / rf["value"]

@@ -148,6 +148,14 @@ class Model:
 
 
 # ----------------------------------------------------------------------------- function wrappers
+def model_from_spec(spec):
+    """The oracle's Model for a workload spec (smc.jl_amd/host/workloads.py: priors, bounds, fixed, lik, old_lik)."""
+    def mk(l):
+        return Lik("none") if l is None else Lik(l[0], l[1], l[2], l[3])
+
+    return Model(spec["priors"], spec["bounds"], mk(spec["lik"]), mk(spec["old_lik"]), spec["fixed"])
+
+
 def compute_ess(loglh, weights, phi_n, phi_n1, old_loglh=None):
     loglh, weights = _f64(loglh), _f64(weights)
     old = None if old_loglh is None else _f64(old_loglh)

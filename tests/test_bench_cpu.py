@@ -52,3 +52,14 @@ def test_spawn_command_is_the_drivers_launch_line():
 
 def test_config3_is_one_million_in_total():
     assert bench.N_TOTAL_SHARDED == 1_000_000 and bench.N_PER_GPU == 100_000
+
+
+def test_julia_probe_reports_unavailable_or_a_version():
+    """the bench line says by itself whether the reference's runtime is on the box (cpu_baseline.reference_julia)."""
+    import shutil
+
+    got = bench.probe_julia()
+    if shutil.which("julia") is None:
+        assert got == "unavailable"
+    else:
+        assert "julia" in got.lower()
