@@ -113,6 +113,8 @@ static int callback_fill_loglh(smcmi_handle *h, int which, int column) {
 // (attempt a of particle i = the draws k_init_prior makes on its a-th outer attempt), the callback scores them, particles without
 // a finite log-likelihood are redrawn (one_draw's loop, :23-63) - the cloud a device family with the same values would start from.
 static int callback_init_from_prior(smcmi_handle *h) {
+    // (the Gamma-family draws keep their acceptance uniforms in tag k | 64: beyond 64 parameters that collides with parameter k's normal)
+    if (h->d > 64) return set_err(SMCMI_ERR_UNSUPPORTED, "device prior draws serve n_para <= 64");
     if (int e = ensure_callback_buffers(h)) return e;
     if (ensure_split_buffers(h)) return SMCMI_ERR_HIP;
     CallbackBuffers *b = h->cbuf;

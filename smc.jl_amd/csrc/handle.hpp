@@ -17,6 +17,7 @@
 #include "devstate.hpp"
 #include "kernels.hpp"
 #include "stage2.hpp"
+#include "stage2b.hpp"
 #include "stage3.hpp"
 
 using namespace smcmi;
@@ -43,6 +44,7 @@ struct Eng2 {
     bool wide_attr_set = false;      // k2w_mutate's dynamic-LDS opt-in done on this handle's device
     bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
     int n_steps = 1, n_blocks = 1;
+    int z_ahead = 0;                 // large shards: proposals per particle the drawing blocks of K1 leave in zbuf (0 with rng_ahead: all of them)
 };
 
 static const int ESUM_RED_ROWS = 128;         // rows left by the first level of the energy-sum reduction when there are very many blocks

@@ -3034,7 +3034,10 @@ static __global__ void __launch_bounds__(256) k_copy_f64(double *dst, const doub
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) d2[i] = s2[i];
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
 }
+// (a column that starts at an odd multiple of 8 bytes - the weight column of a cloud with n (R-1) odd, a caller's view with an odd offset -
+// goes through the runtime's copy: the kernel's 16-byte accesses assume 16-byte alignment)
 static inline void launch_copy_f64(double *dst, const double *src, long long n, hipStream_t s) {
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) != 0) { (void)hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s); return; }
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(2048, (n / 2 + 255) / 256));
     k_copy_f64<<<grid, 256, 0, s>>>(dst, src, n);
 }

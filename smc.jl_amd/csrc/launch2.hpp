@@ -4,19 +4,28 @@
 #pragma once
 #include "handle.hpp"
 
+// pb.enable: the launch carries the helper block of stage2b.hpp (decision + proposal from this launch's own totals; large shards with the mailbox)
 template <int D>
-void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows, const Tail2 &tail) {
+void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected, const Rows2 &mrows, const Tail2 &tail, const Prep2Args &pb) {
     Eng2 *e = h->e2;
     Rng2 ra{};
     unsigned grid = (unsigned)(e->g.Vl * e->g.nb1);
+    const bool helper = pb.enable && tail.tick && D <= 10;
     if (e->rng_ahead) {              // extra blocks, one per mutation block, draw the stage's random numbers on the idle CUs
         ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
-        grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
+        ra.t_lim = e->z_ahead;
+        // (large shards: the drawing blocks follow the correction blocks onto the CUs - one 512-thread block each - and run under the helper's serial work)
+        if (e->g.t2 == 512) grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
+        else grid += (unsigned)std::max<long long>(1, std::min<long long>((e->g.n + T1 - 1) / T1, 256));
     }
-    if (tail.tick) k2_correct<D, true><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
-                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
+    if (helper) grid += 1;
+    const size_t lds = helper ? k2_lds_bytes(D) : 0;
+    Prep2Args pa = pb;
+    pa.enable = helper ? 1 : 0;
+    if (tail.tick) k2_correct<D, true><<<grid, T1, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, pa, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
     else k2_correct<D, false><<<grid, T1, 0, h->stream>>>(h->cl, h->d_st, e->d_ctl, e->g, n, begin_done, spec_expected, mrows, h->d_sched, h->rec,
-                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
+                                                           e->rows_cm, e->csum, h->d_wt, h->d_hist_w, h->n, ra, tail, pa, (e->d_prof && n == e->prof_stage) ? e->d_prof : nullptr);
 }
 template <int D>
 void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full, long long s_lo, long long s_hi) {
@@ -48,10 +57,19 @@ void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) 
     } else if (e->g.t2 == 512) {
         if (alpha1) k2_mutate<D, true, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
         else k2_mutate<D, false, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-    } else {
-        if (alpha1) k2_mutate<D, true, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-        else k2_mutate<D, false, 256, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
     }
+    // (256-thread mutation blocks - large shards, the reduced geometry - are k2b_mutate's: launch_k2b_mutate)
+    }
+}
+// the mutation launch of large shards (stage2b.hpp), compiled in translation units of its own (inst2b.hip, Makefile BIGFLAGS)
+template <int D>
+void launch_k2b_mutate(smcmi_handle *h, const Mut2Args &ma, const Beg2Args &bb, int nb, bool alpha1) {
+    Eng2 *e = h->e2;
+    if constexpr (D <= 10) {
+        const size_t lds = k2_lds_bytes(D);
+        const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2) + (bb.enable ? 1u : 0u);
+        if (alpha1) k2b_mutate<D, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
+        else k2b_mutate<D, false><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
     }
 }
 template <int D>
@@ -81,7 +99,7 @@ inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Arg
 }
 
 #define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
-    X template void launch_k2_correct<D>(smcmi_handle *, int, int, int, const Rows2 &, const Tail2 &);                               \
+    X template void launch_k2_correct<D>(smcmi_handle *, int, int, int, const Rows2 &, const Tail2 &, const Prep2Args &);            \
     X template void launch_k2_gather<D>(smcmi_handle *, int, const Rows2 &, const double *, int, const double *, long long, long long); \
     X template void launch_k2_mutate<D>(smcmi_handle *, const Mut2Args &, int, bool);                                                \
     X template void launch_k2_prepare<D>(smcmi_handle *, const Mut2Args &, int);
@@ -93,15 +111,25 @@ inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Arg
 #define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_seg<D, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
                                       X template void launch_k3_seg<D, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
 #define SMCMI_LAUNCH3_ONE(D, A) template void launch_k3_seg<D, A>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+#define SMCMI_LAUNCH2B_INSTANCES(X, D) X template void launch_k2b_mutate<D>(smcmi_handle *, const Mut2Args &, const Beg2Args &, int, bool);
 #define SMCMI_LAUNCH_ALL_D(M, X)                                                                                                          \
     M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10) M(X, 11) M(X, 12) M(X, 13) M(X, 14) M(X, 15) M(X, 16)
+// (the large-shard mutation kernel exists for n_para <= 10: beyond that the launcher is empty and instantiated where it is called)
+#define SMCMI_LAUNCH_B_D(M, X) M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10)
 #if defined(SMCMI_INST_D)
 SMCMI_LAUNCH2_INSTANCES(, SMCMI_INST_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
+SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST3_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
 SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0))
+SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
+#elif defined(SMCMI_INST2B_D)
+SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
+SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
+SMCMI_LAUNCH2B_INSTANCES(, SMCMI_INST2B_D)
 #else
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
+SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #endif

@@ -90,7 +90,7 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     if (dmalloc(&e->d_ctl, 1) || dmalloc(&e->rows_mut, n2 * RMUT) || dmalloc(&e->rows_cm, n1 * npf) || dmalloc(&e->csum, n1) ||
         dmalloc(&e->csum_full, (size_t)g.V * g.nb1) || dmalloc(&e->rows_gm, ng * npp) || dmalloc(&e->rows_pass[0], n1 * 2 * KC) ||
         dmalloc(&e->rows_pass[1], n1 * 2 * KC) || dmalloc(&e->vt_mut, (size_t)g.V * RMUT) || dmalloc(&e->vt_cm, (size_t)g.V * npf) ||
-        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_ranges_all, (size_t)V2_MAXV * (2 * V2_MAXV + 2)) || dmalloc(&e->d_pre, 1) || dmalloc(&e->d_tick, 2 * V2_MAXV)) {
+        dmalloc(&e->vt_gm, (size_t)g.V * npp) || dmalloc(&e->vt_pass, (size_t)g.V * 2 * KC) || dmalloc(&e->d_ranges, 2 * V2_MAXV + 2) || dmalloc(&e->d_ranges_all, (size_t)V2_MAXV * (2 * V2_MAXV + 2)) || dmalloc(&e->d_pre, 1) || dmalloc(&e->d_tick, 2 * V2_MAXV * TICK2_STRIDE)) {
         free_eng2(e);
         return SMCMI_ERR_HIP;
     }
@@ -107,7 +107,7 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
         HIP_TRY(hipMemsetAsync(e->d_done3, 0, SEG3_MAX_LAUNCHES * sizeof(int), h->stream));
     }
     HIP_TRY(hipMemsetAsync(e->d_pre, 0, sizeof(Prop2Glob), h->stream));
-    HIP_TRY(hipMemsetAsync(e->d_tick, 0, 2 * V2_MAXV * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(e->d_tick, 0, 2 * V2_MAXV * TICK2_STRIDE * sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(e->rows_mut, 0, n2 * RMUT * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(e->rows_cm, 0, n1 * npf * sizeof(double), h->stream));        // (the pad columns stay zero)
     HIP_TRY(hipMemsetAsync(e->rows_gm, 0, ng * npp * sizeof(double), h->stream));
@@ -142,7 +142,7 @@ static bool fused_tails(const Eng2 *e) {
     // (several handles: up to 2048 blocks - there the tails break even with the launches they replace, 138.5 vs 139.6 µs per stage at
     // 500 000 particles per handle, and they are what lets the peer mailbox replace the all-gathers)
     if (e->g.wide) return true;                  // (the wide kernels' rows are always totalled by the last block of a virtual shard)
-    return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= (e->world > 1 ? 2048 : 1024);
+    return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= 2048;
 }
 #define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
     switch (d) {                                                                                                                          \
@@ -401,11 +401,11 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         // (the run's first records ride on the import kernel: four 8-byte host copies and a stream sync less per run)
         k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl, h->rec, cont ? 0 : 1, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target);
-        HIP_TRY(hipMemsetAsync(h->e2->d_tick, 0, 2 * V2_MAXV * sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(h->e2->d_tick, 0, 2 * V2_MAXV * TICK2_STRIDE * sizeof(int), h->stream));
         // random numbers drawn ahead: while K1 leaves most CUs idle (small clouds = the direct geometry with 512-thread mutation blocks)
         static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
         Eng2 *e = h->e2;
-        e->rng_ahead = false; e->n_steps = rc->n_mh_steps; e->n_blocks = rc->n_blocks;
+        e->rng_ahead = false; e->z_ahead = 0; e->n_steps = rc->n_mh_steps; e->n_blocks = rc->n_blocks;
         if (!no_ra && e->g.inker && e->g.t2 == 512 && e->g.Vl * e->g.nb1 <= 160) {
             const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)rc->n_mh_steps * (size_t)rc->n_blocks;
             if (need > h->zbuf_cap) {
@@ -431,9 +431,35 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (read at every run: a caller that has validated - or lost confidence in - the transport can switch it between runs)
     const int want = getenv("SMCMI_MAILBOX") ? atoi(getenv("SMCMI_MAILBOX")) : -1;                 // -1: default; 2: also with one rank (tests)
     for (auto *h : g.hs) h->mbox_used = false;
-    if ((multi || (g.rccl && want == 2)) && fused_tails(h0->e2) && npf <= MB_LD) {       // (a mailbox row carries at most MB_LD sums: n_para <= 10)
+    // large shards (stage2b.hpp): 256-particle mutation blocks, the stage's serial work in helper blocks that take their hand-over from the mailbox
+    const bool big = !inker && !g0.wide && d <= 10;
+    // (a single handle on that geometry - SMCMI_ENGINE=2, the 1-rank measurement vehicle - posts to itself: the same two-launch stage a rank runs)
+    const bool self_mb = big && !multi && want != 0;
+    if ((multi || (g.rccl && want == 2) || self_mb) && fused_tails(h0->e2) && npf <= MB_LD) {       // (a mailbox row carries at most MB_LD sums: n_para <= 10)
         if (g.rccl) { if (want != 0) { if (int e = mbox_setup_remote(g)) return e; } mbox = h0->mbox_ok && want != 0; }
-        else if (want == 1) { if (int e = mbox_setup_group(g)) return e; mbox = true; }
+        else if (want == 1 || self_mb) { if (int e = mbox_setup_group(g)) return e; mbox = true; }
+    }
+    static const int big_helpers = getenv("SMCMI_E2_HELPERS") ? atoi(getenv("SMCMI_E2_HELPERS")) : 1;      // development: 0 = k2_begin / k2_prepare as launches
+    const bool bighelp = big && mbox && big_helpers != 0;
+    if (bighelp) {
+        // the first proposals' random numbers are drawn by blocks of K1 that follow the correction blocks onto the CUs and run under the helper
+        // block's serial work: as many proposals per particle as fit that window (SMCMI_RNG_AHEAD_PART draws, default 250 000: engine 1's measure)
+        static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
+        static const long long part = getenv("SMCMI_RNG_AHEAD_PART") ? atoll(getenv("SMCMI_RNG_AHEAD_PART")) : 250000;
+        for (auto *h : g.hs) {
+            Eng2 *e = h->e2;
+            const int za = (int)std::min<long long>((long long)rc->n_mh_steps * rc->n_blocks, part / std::max<long long>(1, h->n));
+            e->z_ahead = 0;
+            if (no_ra || za < 1) continue;
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)za;
+            if (need > h->zbuf_cap) {
+                if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
+                if (dmalloc(&h->d_zbuf, need)) return SMCMI_ERR_HIP;
+                h->zbuf_cap = need;
+            }
+            e->rng_ahead = true; e->z_ahead = za;
+        }
     }
     unsigned mb_cnt[MB_KINDS] = {0, 0};               // counter (-> tag, parity) of the post the next consumer of that kind reads
     unsigned mb_next[MB_KINDS] = {0, 0};              // counters are never reused: a resumed stage posts under fresh tags
@@ -460,7 +486,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         Eng2 *e = h->e2;
         Tail2 t{};
         if (!fused_tails(e)) return t;
-        t.tick = e->d_tick + kind * V2_MAXV; t.vt = vt_slice;
+        t.tick = e->d_tick + kind * V2_MAXV * TICK2_STRIDE; t.vt = vt_slice;
         if (mbox) {
             t.peers = h->d_peers; t.world = g.world; t.gv0 = e->g.v0;
             t.table = mbox_table(kind, mb_cnt[kind]); t.tag = mbox_tag(h->mbox_epoch, mb_cnt[kind]);
@@ -557,8 +583,13 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_stage;
     static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
+    // large shards with helper blocks: the stage whose decision + proposal K1's helper leaves in Prop2Glob (no k2_prepare launch for it), and
+    // the stage whose begin the mutation launch in front of it ran (no k2_begin launch for it) with that spec_expected
+    int prepared_stage = -1, begun_stage = -1, begun_spec = 0;
+    int drawn_stage = -1;        // the stage whose first proposals' random numbers the latest K1 launch drew into zbuf
     // ---- pieces of a stage
-    auto enq_K1 = [&](int n, int begin_done, int spec_expected) -> int {
+    // helper: the launch's extra block takes the hand-over of its own rows and leaves decision + proposal in Prop2Glob (large shards, no selection)
+    auto enq_K1 = [&](int n, int begin_done, int spec_expected, bool helper = false) -> int {
         std::vector<Rows2> mrs;
         for (auto *h : g.hs) mrs.push_back(mut_rows(h));                 // (the mutation rows this launch consumes)
         if (mbox) { mb_cnt[0] = ++mb_next[0]; mb_live[0] = true; mb_cm_at[n] = mb_cnt[0]; }   // its own rows go out under a fresh correction tag
@@ -567,10 +598,17 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             HIP_TRY(hipSetDevice(h->cfg.device));
             const Rows2 mr = mrs[k];
             const Tail2 tail = mb_tail(h, 0, h->e2->vt_cm + (size_t)h->e2->g.v0 * npf);
-#define SMCMI_CALL(D) launch_k2_correct<D>(h, n, begin_done, spec_expected, mr, tail)
+            Prep2Args pb{};
+            if (helper && bighelp) {
+                pb.enable = 1; pb.nb = rc->n_blocks; pb.nf = nf; pb.seed = h->cfg.seed; pb.cmrows = cm_rows(h); pb.rec = h->rec;
+                pb.md = h->d_model; pb.out = h->e2->d_pre;
+            }
+#define SMCMI_CALL(D) launch_k2_correct<D>(h, n, begin_done, spec_expected, mr, tail, pb)
             SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
         }
+        if (helper && bighelp) prepared_stage = n;
+        if (h0->e2->rng_ahead) drawn_stage = n;
         return publish(&Eng2::rows_cm, &Eng2::vt_cm, g0.nb1, npf, -1, 0, true);
     };
     auto enq_select = [&](int n) -> int {
@@ -650,7 +688,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
         return publish(&Eng2::rows_gm, &Eng2::vt_gm, g0.nbg, np, -1);
     };
-    auto enq_K2 = [&](int n, int sel_enqueued) -> int {
+    // next_begin: -1 none; 0 / 1: the launch's helper block runs stage n + 1's begin with that spec_expected (large shards with the mailbox)
+    auto enq_K2 = [&](int n, int sel_enqueued, int next_begin = -1) -> int {
         std::vector<Rows2> crs;
         for (auto *h : g.hs) crs.push_back(cm_rows(h));                  // (the correction rows this launch consumes)
         if (mbox) { mb_cnt[1] = ++mb_next[1]; mb_live[1] = true; mb_mut_at[n] = mb_cnt[1]; }
@@ -669,7 +708,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
             ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
             ma.prof = (e->d_prof && n == e->prof_stage) ? e->d_prof + 64 : nullptr;
-            if (!inker) {                // decision + proposal once, by one block
+            if (!inker && prepared_stage != n) {                // decision + proposal once, by one block (unless K1's helper block left them)
                 Mut2Args mp = ma;
                 mp.pre = nullptr;
 #define SMCMI_CALL(D) launch_k2_prepare<D>(h, mp, rc->n_blocks)
@@ -678,11 +717,23 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profile && h == h0) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_stage.push_back(n); hipEventRecord(e0, h->stream); }
+            if (!inker && !g0.wide) {
+                // 256-particle blocks (stage2b.hpp); the drawn-ahead numbers only where this stage's K1 carried the drawing blocks
+                Beg2Args bb{};
+                if (bighelp && next_begin >= 0) { bb.enable = 1; bb.spec_expected = next_begin; bb.mrows = mb_rows(h, 1, e->vt_mut, RMUT); bb.sched = h->d_sched; bb.rec = h->rec; }
+                ma.zbuf = (e->rng_ahead && e->z_ahead > 0 && drawn_stage == n) ? h->d_zbuf : nullptr;
+                ma.z_ahead = ma.zbuf ? e->z_ahead : 0;
+#define SMCMI_CALL(D) launch_k2b_mutate<D>(h, ma, bb, rc->n_blocks, rc->alpha == 1.0)
+                SMCMI_D_SWITCH(d, SMCMI_CALL)
+#undef SMCMI_CALL
+            } else {
 #define SMCMI_CALL(D) launch_k2_mutate<D>(h, ma, rc->n_blocks, rc->alpha == 1.0)
             SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
+            }
             if (e1) hipEventRecord(e1, h->stream);
         }
+        if (bighelp && next_begin >= 0) { begun_stage = n + 1; begun_spec = next_begin; }
         return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256 && !g0.wide, true);
     };
     // enter_mut: stage n_first's correction (and selection, if sel) were enqueued as launches - the segment enters at its mutation
@@ -760,6 +811,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return 0;
     };
     auto enq_begin = [&](int n, int spec_expected = 0) -> int {
+        if (begun_stage == n && begun_spec == spec_expected) return 0;      // (the helper block of the mutation launch in front ran it)
+        begun_stage = -1;
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));
             k2_begin<<<1, T1, 0, h->stream>>>(h->d_st, h->e2->d_ctl, n, mut_rows(h), h->d_sched, h->rec, spec_expected);
@@ -780,17 +833,18 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return 0;
     };
     // a whole stage; cert: certificate passes instead of a predicted ϕ_n (adaptive schedules only)
-    auto enq_stage = [&](int n, bool cert, int P, bool sel) -> int {
+    // next_begin: what the mutation launch's helper block runs for stage n + 1 (-1: nothing - the batch ends here, or its mode is not known)
+    auto enq_stage = [&](int n, bool cert, int P, bool sel, int next_begin = -1) -> int {
         if (cert) {
             if (int e = enq_begin(n)) return e;
             if (int e = enq_passes(n, 0, P)) return e;
-            if (int e = enq_K1(n, 1, 0)) return e;
+            if (int e = enq_K1(n, 1, 0, !sel)) return e;
         } else if (!inker) {               // many blocks per CU: the stage-begin logic once, by one block
             if (int e = enq_begin(n, adaptive ? 1 : 0)) return e;
-            if (int e = enq_K1(n, 1, 0)) return e;
+            if (int e = enq_K1(n, 1, 0, !sel)) return e;
         } else if (int e = enq_K1(n, 0, adaptive ? 1 : 0)) return e;
         if (sel) { if (int e = enq_select(n)) return e; }
-        return enq_K2(n, sel ? 1 : 0);
+        return enq_K2(n, sel ? 1 : 0, next_begin);
     };
     auto read_ctl = [&](Ctl2 *c) -> int {
         HIP_TRY(hipSetDevice(h0->cfg.device));
@@ -875,7 +929,18 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             if (e3 && e3_enter) {
                 if (int e = enq_stage_front(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
                 seg_a = seg_b = n; seg_enter = true; seg_sel = sel;
-            } else if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
+            } else {
+                // large shards: the mutation launch's helper block runs the NEXT stage's begin - in the mode that stage will be enqueued in
+                // (the same rules one stage ahead; the last stage of a batch leaves it to a launch: the sync in between may change the mode)
+                int next_begin = -1;
+                if (bighelp && b + 1 < batch) {
+                    bool sel2 = true;
+                    if (predict_select) sel2 = (rc->tempering_target * (pred_rl ? N_tot : pred_ess) < thr * (1.0 + 1e-6)) && sel_mode != 2;
+                    const bool cert2 = adaptive && (!spec_on || (sel2 && cert_sel) || launched + 1 < 2);
+                    next_begin = cert2 ? 0 : (adaptive ? 1 : 0);
+                }
+                if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel, next_begin)) return e;
+            }
             ++launched;
         }
         if (int e = flush_seg()) return e;
@@ -899,6 +964,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 if (code == 3) { mb_cnt[0] = mb_cm_at[sn]; mb_live[0] = true; }
             }
             for (int &s : ev_stage) if (s >= sn) s = -1;           // the stalled stage's mutation launch and everything behind it were no-ops
+            prepared_stage = begun_stage = -1;                     // (nothing a helper block was enqueued for stands: the resumed stage runs on launches)
             if (int e = clear_status()) return e;
             if (code == 6) {
                 // a segment of engine 3 left at this stage (it must resample): nothing of the stage is committed; the full path runs it

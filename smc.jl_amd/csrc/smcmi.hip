@@ -348,7 +348,8 @@ extern "C" int smcmi_upload_cloud_device(smcmi_handle *h, const double *dev_part
     if (!h || !dev_particles) return set_err(SMCMI_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (pull_state(h)) return SMCMI_ERR_HIP;
-    launch_copy_f64(h->cl.buf[h->h_st.cur], dev_particles, (long long)h->n * h->R, h->stream);
+    // (the caller's pointer may be peer-device memory without peer access, or a misaligned view: the runtime's copy handles both)
+    HIP_TRY(hipMemcpyAsync(h->cl.buf[h->h_st.cur], dev_particles, sizeof(double) * (size_t)h->n * h->R, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1057,6 +1058,9 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     }
     const int base = cont ? s.stage - 1 : 0;                // stages completed before this call
     if (push_state(h)) return SMCMI_ERR_HIP;
+    // the arrival counters of the two-level totals (PrepRed) start every run at zero: a launch whose wait timed out (SMCMI_ERR_TIMEOUT,
+    // the run is void) may have left late arrivals behind - in stream order they precede this fill
+    HIP_TRY(hipMemsetAsync(h->d_prep_tick, 0, 8 * sizeof(double), h->stream));
     // stage-1 records and history columns (w[:,1] = 0, W[:,1] = weights; smc_main.jl:363-366)
     if (!cont) {
         const double v0[4] = {0.0, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target};

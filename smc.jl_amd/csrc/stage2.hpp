@@ -389,8 +389,10 @@ static __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int n
 // the mutation kernel; instead the rows themselves are stored and read with agent-scope accesses (write-through / L2 bypass,
 // `row_store`, `load_pair`), ordered by the wait for their completion, the block barrier and the relaxed ticket.  Blocks that
 // leave early (a stage that does not run) take no ticket.  All threads of the block call, after the row is stored.
+constexpr int TICK2_STRIDE = 32;   // ints between a handle's ticket counters: one 128-byte line each.  Agent-scope atomics execute at the memory side; eight
+                                   // counters on ONE line serialised all 984 arrivals of a 250 000-particle mutation launch (~15 of its 37 µs)
 struct Tail2 {
-    int *tick;                 // [Vl] counters, zero between launches; null: no tail (direct geometry: consumers read the rows)
+    int *tick;                 // [Vl * TICK2_STRIDE] counters (counter v at tick[v * TICK2_STRIDE]), zero between launches; null: no tail (direct geometry: consumers read the rows)
     double *vt;                // this handle's slice of the V x m table: vt[v * m]
     unsigned long long *const *peers;   // non-null: post the totals into every handle's mailbox (peers[r], r < world) instead of an all-gather
     int world, gv0;            // handles; global index of this handle's first virtual shard
@@ -405,7 +407,7 @@ __device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, in
     // release fence does not: outside tgsplit mode the compiler omits the vmcnt wait there, and the ticket could overtake a row)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&t.tick[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr_raw - 1;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&t.tick[v * TICK2_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr_raw - 1;
     __syncthreads();
     if (!s_last) return;
     reduce_vshard<NT, true, MMAX>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, t.vt + (long long)v * m, pair);
@@ -414,7 +416,7 @@ __device__ inline void tail_reduce(const Tail2 &t, const double *rows, int v, in
         const long long w = t.table + ((long long)(t.gv0 + v) * MB_LD + threadIdx.x) * 2;
         for (int r = 0; r < t.world; ++r) mb_store(t.peers[r] + w, x, t.tag);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&t.tick[v], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(&t.tick[v * TICK2_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // block-wide fixed-order reduction of M accumulators per thread for a block of NW wavefronts; thread t < M gets total t.
@@ -635,11 +637,15 @@ __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, c
 // Shared front of K1 and k2_begin: load Post2[(n-1)&1], total the mutation rows, run begin2_wave.  Returns the action code to all
 // threads; s_bg holds stage n's Begin2 when the action is 0 or 6.  LDS: s_po, s_bg, s_vt (V2_MAXV * RMUT * 4 doubles), s_tot (RMUT),
 // s_sw (64), s_act.
-template <int T>
+// writer_ov: -1 = block 0 stores the stage's state (every block of a launch runs this); 0 / 1 = this block does not / does (a helper block
+// behind the blocks of another kernel, stage2b.hpp).  MBONLY: the rows arrive through the mailbox - nothing of reduce_rows_ct is instantiated
+// (a kernel whose other blocks live on a small register budget)
+template <int T, bool MBONLY = false>
 __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &mrows, int spec_expected, const double *sched,
                                    const Records &rec, Post2 *s_po, Begin2 *s_bg, double *s_vt, double *s_tot, double *s_sw, int *s_act,
-                                   long long *prof = nullptr, bool coh_bg = false) {
+                                   long long *prof = nullptr, bool coh_bg = false, int writer_ov = -1) {
     const int t = threadIdx.x;
+    const bool writer = writer_ov >= 0 ? writer_ov != 0 : blockIdx.x == 0;
     constexpr int NWP = sizeof(Post2) / sizeof(double);
     if (t < NWP) reinterpret_cast<double *>(s_po)[t] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[t];
     if (t == 0) *s_act = -1;
@@ -658,8 +664,10 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
         __syncthreads();
         if (s_po->stage != n - 1) return -1;
     }
-    if (rows_valid) reduce_rows<RMUT, 2, T>(mrows, s_vt, s_tot, RMAX_IDX);
-    else {
+    if (rows_valid) {
+        if constexpr (MBONLY) mbox_totals<RMUT, T>(mrows, s_vt, s_tot, RMAX_IDX);
+        else reduce_rows<RMUT, 2, T>(mrows, s_vt, s_tot, RMAX_IDX);
+    } else {
         if (t < RMUT) s_tot[t] = t == RMAX_IDX ? -__builtin_inf() : 0.0;
         __syncthreads();
     }
@@ -668,7 +676,7 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
     K2_STAMP(prof, 2);
     if (t < 64) {
         const int act = begin2_wave(n, *s_po, st->rp, s_tot, s_tot[RMAX_IDX], rows_valid && s_po->fold_valid, spec_expected, sched, s_sw, s_bg,
-                                    &st->sol[0], blockIdx.x == 0, rec, &ctl->status, inv_pre);
+                                    &st->sol[0], writer, rec, &ctl->status, inv_pre);
         if (t == 0) *s_act = act;
     }
     __syncthreads();
@@ -676,7 +684,7 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
     const int act = *s_act;
     constexpr int NWB = sizeof(Begin2) / sizeof(double);
     // (coh_bg: the launch rewrites Ctl2::bg from other blocks later on - stage3.hpp - so no copy of it may stay dirty in this die's L2)
-    if ((act == 0 || act == 6) && blockIdx.x == 0 && t < NWB) row_store(reinterpret_cast<double *>(&ctl->bg) + t, reinterpret_cast<const double *>(s_bg)[t], coh_bg);
+    if ((act == 0 || act == 6) && writer && t < NWB) row_store(reinterpret_cast<double *>(&ctl->bg) + t, reinterpret_cast<const double *>(s_bg)[t], coh_bg);
     return act;
 }
 
@@ -825,6 +833,7 @@ SMCMI_FP_CONTRACT
 // MH uniform, mixture uniform, D normals.  Same expressions as draw2 -> same bits.
 struct Rng2 {
     double *zbuf;            // null: disabled
+    int t_lim;               // > 0: only the first t_lim proposals (mh_step * n_blocks + block) of every particle are drawn
     int n_steps, nb, nf;
     unsigned long long seed;
     long long gid0;
@@ -834,14 +843,12 @@ struct Rng2 {
 template <int D>
 __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int block, int nblocks, int debug) {
     const int sub = (ra.nf + ra.nb - 1) / ra.nb;
-    for (int cb = block; cb < g.Vl * g.nb2; cb += nblocks) {
-    long long beg, end;
-    vchunk(g, cb / g.nb2, cb % g.nb2, g.t2, beg, end);
-    for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    auto particle = [&](long long i) {
         const unsigned long long pid = (unsigned long long)(ra.gid0 + i);
         for (int step = 0; step < ra.n_steps; ++step)
             for (int b = 0; b < ra.nb; ++b) {
                 const unsigned t = (unsigned)(step * ra.nb + b);
+                if (ra.t_lim > 0 && (int)t >= ra.t_lim) continue;
                 const int db = (b < ra.nb - 1) ? sub : ra.nf - sub * (ra.nb - 1);
                 double step_prob, uc, z[D];
                 draw2<D>(ra.seed, pid, (unsigned)n, t, db, debug, step_prob, uc, z);
@@ -851,7 +858,15 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
 #pragma unroll
                 for (int e = 0; e < D; ++e) zt[(long long)(2 + e) * g.n] = z[e];
             }
+    };
+    if (g.t2 != 512) {        // large shards (256-particle mutation blocks): the local particles dealt out block-width by block-width
+        for (long long i = (long long)block * blockDim.x + threadIdx.x; i < g.n; i += (long long)nblocks * blockDim.x) particle(i);
+        return;
     }
+    for (int cb = block; cb < g.Vl * g.nb2; cb += nblocks) {
+        long long beg, end;
+        vchunk(g, cb / g.nb2, cb % g.nb2, g.t2, beg, end);
+        for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) particle(i);
     }
 }
 
@@ -973,15 +988,39 @@ __device__ inline void k2_cm_row_one(double v, const double (&xx)[D + 1], bool l
 // scratch column `wt` (the cloud's weight column is rewritten by K2 / the gather once the stage is decided), the block's ΣW̃
 // also goes to csum[b] (chunk sums of the selection scan), and the stage-begin logic runs in the prologue (begin_done = 0).
 // TAIL: the geometry hands its rows over through Tail2 (sharded runs, large clouds); the direct geometry's instantiation carries none of it
+// Large shards (stage2b.hpp): ONE extra block behind the correction blocks - the only block of the launch that waits for anything - takes the
+// hand-over of this launch's own rows (the V x m totals arrive in the handle's mailbox), decides, builds the proposal and leaves it in
+// Prop2Glob for the mutation launch: k2_prepare without its launch, its kernel start and its launch boundary.
+struct Prop2Glob;
+struct Prep2Args {
+    int enable;                   // the launch carries the helper block (block Vl * nb1; dynamic LDS = k2_lds_bytes)
+    int nb, nf;                   // random blocks / free parameters
+    unsigned long long seed;
+    Rows2 cmrows;                 // this launch's correction totals as the mailbox delivers them
+    Records rec;
+    const ModelDev *md;
+    Prop2Glob *out;
+};
+template <int D>
+__device__ void k2_prepare_block(DevState *st, Ctl2 *ctl, const Prep2Args &pb, int n);
+
 template <int D, bool TAIL>
 __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int begin_done, int spec_expected,
                                                  Rows2 mrows, const double *sched, Records rec, double *rows_cm, double *csum, double *wt,
-                                                 double *hist_w, long long hist_ld, Rng2 ra, Tail2 tail, long long *prof = nullptr) {
+                                                 double *hist_w, long long hist_ld, Rng2 ra, Tail2 tail, Prep2Args pb, long long *prof = nullptr) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NPF = NP + 2;
     constexpr int NCH = (NPF + 63) / 64, NW = T1 / 64;
-    if ((int)blockIdx.x >= g.Vl * g.nb1) {               // the idle CUs draw the mutation's random numbers (Rng2)
+    if ((int)blockIdx.x >= g.Vl * g.nb1) {
+        int xb = (int)blockIdx.x - g.Vl * g.nb1, nx = (int)gridDim.x - g.Vl * g.nb1;
+        if constexpr (TAIL && D <= 10) {
+            if (pb.enable) {
+                if (xb == 0) { k2_prepare_block<D>(st, ctl, pb, n); return; }
+                --xb; --nx;
+            }
+        }
+        // the idle CUs draw the mutation's random numbers (Rng2)
         // (drawn whether or not the stage goes ahead: a stalled stage is redone with the same numbers)
-        if (ra.zbuf && ctl->ps[(n - 1) & 1].stage == n - 1) rng2_block<D>(g, ra, n, (int)blockIdx.x - g.Vl * g.nb1, (int)gridDim.x - g.Vl * g.nb1, 0);
+        if (ra.zbuf && ctl->ps[(n - 1) & 1].stage == n - 1) rng2_block<D>(g, ra, n, xb, nx, 0);
         return;
     }
     __shared__ double red[NW * cm_row_ld(NPF)];
@@ -1046,8 +1085,9 @@ __global__ void __launch_bounds__(T1) k2_correct(CloudPtrs cl, DevState *st, Ctl
     }
     K2_STAMP(prof, 5);
     if constexpr (TAIL) tail_reduce<T1, (pad2(NPF) > 72 ? 160 : 72)>(tail, rows_cm, (int)blockIdx.x / g.nb1, g.nb1, pad2(NPF), -1, 0);
-    // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // off the critical path: the step-size multiplier K2 applies (two exponentials) - nobody in this launch reads it (a helper block
+    // computes its own: the mutation launch behind it takes everything from Prop2Glob)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !(TAIL && pb.enable)) {
         const double a = s_bg.accept, tg = st->rp.target;
         ctl->bg.cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
     }
@@ -1354,6 +1394,7 @@ struct Mut2Args {
     int n_steps, store_history, has_other;
     double alpha, n_parts;
     const double *zbuf;        // random numbers drawn ahead by K1's extra blocks (Rng2 layout) or null
+    int z_ahead;               // k2b_mutate only (stage2b.hpp): the first z_ahead proposals of every particle come from zbuf, the rest are drawn
     const double *wt;          // unnormalised weights W̃ of the correction
     double *rows_mut;          // [blocks][RMUT]
     Tail2 tail;                // the last block of a virtual shard totals its mutation rows (sharded runs, large clouds)
@@ -1551,11 +1592,14 @@ struct Mut2Stage {             // what the prologue hands to the mutation body (
 // Prologue of K2, every block: state + model constants into LDS, totals of the correction rows, decision, proposal.  Nothing in
 // it goes through a single thread: every thread derives the (identical) decision from the totals itself.  Returns false when
 // the block must not mutate (stale launch, stall, error); *rs_out = this stage resamples.
+// writer_ov: as in begin2_block.  own_cfac: the step-size multiplier K1's block 0 leaves in Begin2 is computed here instead (a helper block of
+// the K1 launch itself - stage2b.hpp - must not read a word another block of its launch writes; same expression, same bits).
 template <int D, int T>
 __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, const Mut2Args &ma, const Mut2Lds<D> &L, Mut2Stage *S, int nb, int nf,
-                                   int *rs_out) {
+                                   int *rs_out, int writer_ov = -1, bool own_cfac = false) {
     constexpr int NP = Mut2Lds<D>::NP, NPF = Mut2Lds<D>::NPF;
     const int tid = threadIdx.x, n = ma.n;
+    const bool writer = writer_ov >= 0 ? writer_ov != 0 : blockIdx.x == 0;
     constexpr int NWB = sizeof(Begin2) / sizeof(double), NWP = sizeof(Post2) / sizeof(double);
     if (tid < NWB) reinterpret_cast<double *>(&S->bg)[tid] = reinterpret_cast<const double *>(&ctl->bg)[tid];
     if (tid < NWP) reinterpret_cast<double *>(&S->po)[tid] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[tid];
@@ -1575,11 +1619,15 @@ __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, 
     reduce_rows<pad2(NPF), 1, T>(ma.cmrows, L.s_vt, L.s_tot);          // (its barriers also publish the LDS copies above)
     K2_STAMP(ma.prof, 2);
     if (S->bg.stage != n || !S->bg.final || S->po.stage != n - 1) return false;
+    if (own_cfac) {
+        if (tid == 0) { const double a = S->bg.accept, tg = st->rp.target; S->bg.cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg))); }
+        __syncthreads();
+    }
     double ess;
     const int dec = decide2(S->bg, thr, rtol, L.s_tot[0], L.s_tot[1], &ess);
     const bool stall = dec == 4 || dec < 0 || (dec == 1 && !ma.sel_enqueued);
     if (stall) {
-        if (blockIdx.x == 0 && tid == 0) {
+        if (writer && tid == 0) {
             if (dec < 0) { ma.rec.phi[n - 1] = S->bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }
             ctl->status.stage = n;
             ctl->status.code = dec == 4 ? 4 : (dec < 0 ? 9 : 3);
@@ -1594,7 +1642,7 @@ __device__ inline bool k2_prologue(DevState *st, Ctl2 *ctl, const ModelDev *md, 
     Prop2 P{L.covl, L.Aw, L.mean_s, L.bfree, L.bptr_s, L.fi, L.Lraw, L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.loff_s};
     if (!proposal2<(D > 12 ? 16 : 12)>(L.s_tot + 2, S->po.shift, D, nf, nb, S->po.c * S->bg.cfac, ma.seed, (unsigned)n, P, &S->fail, T, jx_pre, ma.prof)) {
         // PosDefException aborts the run (mutation.jl:81)
-        if (blockIdx.x == 0 && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
+        if (writer && tid == 0) { ctl->status.err = SMCMI_ERR_POSDEF; ctl->status.stage = n; ctl->status.code = 9; }
         return false;
     }
     K2_STAMP(ma.prof, 7);
@@ -1645,7 +1693,7 @@ __device__ inline void k2_stage_lik(const LikDev &ld0, const LikDev &ld1, double
 // persistent segment kernel (stage3.hpp) share - same arithmetic in the same order.  The proposal's arrays are in LDS (L.Lraw,
 // L.logdet_s, L.mub_raw, L.sdd_raw, L.sdn_raw, L.ball_raw, L.bptr_s, L.loff_s), published by a barrier before the call; proposal 0's
 // random numbers may arrive in (step_prob, uc, z) (PREDRAW, or ma.zbuf).  ldz: leading dimension of ma.zbuf.  All threads call.
-template <int D, bool ALPHA1, int T, bool PREDRAW>
+template <int D, bool ALPHA1, int T, bool PREDRAW, bool ZPART = false>
 __device__ inline void k2_mh_steps(const Mut2Lds<D> &L, double *mixbuf, int *mixpos, double *mixzt, const Mut2Args &ma, long long ldz,
                                    const LikView (&lv)[2], const ModelView &mv, int nb, int nf, bool live, long long i, unsigned long long pid,
                                    unsigned stage, double phi_n, double (&x)[D], double &like, double &lprior, double &like_prev, double &accept,
@@ -1678,8 +1726,8 @@ SMCMI_FP_CONTRACT
             }
             if (!live) continue;
             const unsigned t = (unsigned)(step * nb + b);
-            if (ma.zbuf) {
-                if (t != 0) {
+            if (ma.zbuf && (!ZPART || (int)t < ma.z_ahead)) {
+                if (ZPART || t != 0) {            // (ZPART: proposal 0 is loaded here as well, nothing is carried into the loop)
                     const double *zt = ma.zbuf + (long long)t * (D + 2) * ldz + i;
                     step_prob = zt[0];
                     uc = zt[ldz];
@@ -1990,6 +2038,28 @@ __global__ void __launch_bounds__(256) k2_prepare(DevState *st, Ctl2 *ctl, const
     for (int b = tid; b <= nb; b += 256) out->bptr[b] = L.bptr_s[b];
     if (tid == 0) { out->rs = rs; out->s1 = L.s_tot[0]; out->phi_n = S.bg.phi_n; out->e_center = S.bg.e_center; out->go = 1; out->stage = n; }
     k2_bookkeeping<D, 256>(st, ctl, ma, L, &S, rs);
+}
+
+// ... and as the helper block of K1 (Prep2Args above): T1 threads, the launch's dynamic LDS.  A decision to resample stalls the stage
+// (status 3) like any launch enqueued without its selection kernels: nothing is left in Prop2Glob, the mutation launch does nothing.
+template <int D>
+__device__ void k2_prepare_block(DevState *st, Ctl2 *ctl, const Prep2Args &pb, int n) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ Mut2Stage S;
+    const Mut2Lds<D> L(sm);
+    const int tid = threadIdx.x;
+    Mut2Args ma{};
+    ma.n = n; ma.seed = pb.seed; ma.cmrows = pb.cmrows; ma.sel_enqueued = 0; ma.rec = pb.rec;
+    int rs = 0;
+    if (!k2_prologue<D, T1>(st, ctl, pb.md, ma, L, &S, pb.nb, pb.nf, &rs, 1, true)) return;
+    Prop2Glob *out = pb.out;
+    const int nb = pb.nb, nf = pb.nf;
+    for (int e = tid; e < nf * nf; e += T1) out->Lraw[e] = L.Lraw[e];
+    for (int e = tid; e < nf; e += T1) { out->mub[e] = L.mub_raw[e]; out->sdd[e] = L.sdd_raw[e]; out->sdn[e] = L.sdn_raw[e]; out->ball[e] = L.ball_raw[e]; }
+    for (int b = tid; b < nb; b += T1) { out->loff[b] = L.loff_s[b]; out->logdet[b] = L.logdet_s[b]; }
+    for (int b = tid; b <= nb; b += T1) out->bptr[b] = L.bptr_s[b];
+    if (tid == 0) { out->rs = rs; out->s1 = L.s_tot[0]; out->phi_n = S.bg.phi_n; out->e_center = S.bg.e_center; out->go = 1; out->stage = n; }
+    k2_bookkeeping<D, T1>(st, ctl, ma, L, &S, rs);
 }
 
 }  // namespace smcmi
