@@ -139,8 +139,10 @@ int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const d
    inside mutation() after update!/prior (src/mutation.jl:93-121).  Batch form: theta is m x d column-major (proposal k =
    theta[k + m*j], j < d) holding only proposals that passed the bounds check; write out[k] = log-likelihood (-Inf allowed, NaN is
    taken as -Inf like the reference's try/catch); return 0, anything else aborts smcmi_run with SMCMI_ERR_CALLBACK.  Invoked
-   synchronously on the thread that called smcmi_run / smcmi_initialize_likelihoods / smcmi_eval_cloud_callback, once per MH step x
-   block (twice with an old-data callback), never from another thread.  which = SMCMI_WHICH_NEW: loglikelihood(parameters, data);
+   synchronously on the thread that called smcmi_run / smcmi_initialize_likelihoods / smcmi_eval_cloud_callback, never from another
+   thread.  Inside smcmi_run / smcmi_run_sharded the batch of one MH step x block arrives in up to 8 CHUNKS of consecutive particles
+   (none smaller than 12 288 proposals): one invocation per chunk (two with an old-data callback), each on its own m x d block, while
+   the next chunk is still crossing PCIe; the results do not depend on the chunking.  which = SMCMI_WHICH_NEW: loglikelihood(parameters, data);
    SMCMI_WHICH_OLD: old_loglikelihood(parameters, old_data) (tempered updates; leave unset when old_data is empty).  fn = NULL
    unregisters.  With a callback registered smcmi_run keeps ϕ solver, correction, selection, moments, proposal and the MH decision
    on the device and ships only the n x d proposals and the n log-likelihoods across PCIe per step. */
@@ -150,6 +152,10 @@ int smcmi_set_likelihood_callback(smcmi_handle *h, int32_t which, smcmi_lik_call
    rows whose logprior column is -Inf are skipped (-Inf).  For initial clouds drawn by the caller (initial_draw!). */
 int smcmi_eval_cloud_callback(smcmi_handle *h, int32_t which, int32_t column);
 int smcmi_callback_stats(smcmi_handle *h, int64_t *calls, int64_t *evaluations);   /* of the last smcmi_run */
+/* where the last run with a host callback spent its wall time on the calling thread, in ms (the first n <= 8 of: waiting for the propose
+   kernel and the first chunk; waiting for later chunks; packing chunks that hold out-of-bounds proposals; inside the callback; NaN -> -Inf /
+   scatter; enqueueing copies and kernels; the stage's device part up to the proposal incl. its sync; reserved) */
+int smcmi_callback_phases(smcmi_handle *h, double *ms_out, int32_t n);
 
 /* ---- cloud transfer (cloud.particles; get_vals/get_loglh/... read columns of the download) ---- */
 int smcmi_upload_cloud(smcmi_handle *h, const double *particles);       /* n_local x R, column-major */

@@ -10,85 +10,190 @@
 // (mutation.jl:102-104); a non-zero return aborts the run with SMCMI_ERR_CALLBACK.
 #pragma once
 
+// Phases of the host-likelihood mutation, accumulated over a run (smcmi_callback_phases; wall clock of the calling thread, ms)
+enum { CBP_FIRST = 0,      // propose kernel + the first chunk's way across PCIe (nothing to overlap it with)
+       CBP_WAIT = 1,       // waiting for later chunks (0 when the callback is the slower side)
+       CBP_PACK = 2,       // gathering the in-bounds proposals of a chunk that has out-of-bounds ones (0 when every proposal passed)
+       CBP_CALL = 3,       // inside the user's callback
+       CBP_SCATTER = 4,    // NaN -> -Inf pass / scatter of the packed results
+       CBP_ENQUEUE = 5,    // enqueueing copies and kernels
+       CBP_STAGE = 6,      // the stage's device part up to the proposal set-up, incl. the per-stage sync (run_callback)
+       CBP_N = 8 };
+
 struct CallbackBuffers {
     double *h_prop = nullptr, *h_lp = nullptr, *h_pack = nullptr, *h_lik[2] = {nullptr, nullptr}, *h_out = nullptr;
     long long *h_idx = nullptr;
     long long n = 0;
     int d = 0;
+    // the chunk pipeline of host_mutation: proposals cross PCIe chunk by chunk on their own stream while the callback scores the chunk before
+    hipStream_t s_down = nullptr, s_up = nullptr;
+    hipEvent_t ev_prop = nullptr, ev_up = nullptr, ev_head = nullptr;
+    std::vector<hipEvent_t> ev_chunk;
+    double phase_ms[CBP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 static void free_callback_buffers(CallbackBuffers *b) {
     if (!b) return;
     void *ptrs[] = {b->h_prop, b->h_lp, b->h_pack, b->h_lik[0], b->h_lik[1], b->h_out, b->h_idx};
     for (void *p : ptrs)
         if (p) hipHostFree(p);
+    for (hipEvent_t e : b->ev_chunk) hipEventDestroy(e);
+    if (b->ev_prop) hipEventDestroy(b->ev_prop);
+    if (b->ev_up) hipEventDestroy(b->ev_up);
+    if (b->ev_head) hipEventDestroy(b->ev_head);
+    if (b->s_down) hipStreamDestroy(b->s_down);
+    if (b->s_up) hipStreamDestroy(b->s_up);
     delete b;
 }
+constexpr int CB_MAX_CHUNKS = 16;
 static int ensure_callback_buffers(smcmi_handle *h) {
     if (h->cbuf && h->cbuf->n == h->n && h->cbuf->d == h->d) return 0;
     if (h->cbuf) { free_callback_buffers(h->cbuf); h->cbuf = nullptr; }
     CallbackBuffers *b = new CallbackBuffers();
     b->n = h->n; b->d = h->d;
     const size_t n = (size_t)h->n, d = (size_t)h->d;
-    if (hipHostMalloc((void **)&b->h_prop, n * d * 8) != hipSuccess || hipHostMalloc((void **)&b->h_lp, n * 8) != hipSuccess ||
-        hipHostMalloc((void **)&b->h_pack, n * d * 8) != hipSuccess || hipHostMalloc((void **)&b->h_lik[0], n * 8) != hipSuccess ||
-        hipHostMalloc((void **)&b->h_lik[1], n * 8) != hipSuccess || hipHostMalloc((void **)&b->h_out, n * 8) != hipSuccess ||
-        hipHostMalloc((void **)&b->h_idx, n * 8) != hipSuccess) {
+    bool ok = hipHostMalloc((void **)&b->h_prop, n * (d + 1) * 8) == hipSuccess && hipHostMalloc((void **)&b->h_lp, n * 8) == hipSuccess &&
+              hipHostMalloc((void **)&b->h_pack, n * d * 8) == hipSuccess && hipHostMalloc((void **)&b->h_lik[0], n * 8) == hipSuccess &&
+              hipHostMalloc((void **)&b->h_lik[1], n * 8) == hipSuccess && hipHostMalloc((void **)&b->h_out, n * 8) == hipSuccess &&
+              hipHostMalloc((void **)&b->h_idx, n * 8) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&b->s_down, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&b->ev_prop, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&b->ev_head, hipEventDisableTiming) == hipSuccess;
+    for (int c = 0; ok && c < CB_MAX_CHUNKS; ++c) {
+        hipEvent_t e = nullptr;
+        ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) b->ev_chunk.push_back(e);
+    }
+    if (!ok) {
         free_callback_buffers(b);
-        return set_err(SMCMI_ERR_HIP, "hipHostMalloc failed (callback staging buffers)");
+        return set_err(SMCMI_ERR_HIP, "hipHostMalloc / stream creation failed (callback staging buffers)");
     }
     h->cbuf = b;
     return 0;
 }
+// chunks a batch of n proposals crosses PCIe in: <= 8, none smaller than 12 288 particles (a chunk costs an event wait and an invocation of the
+// user's function: ~20 µs); SMCMI_CB_CHUNKS=<k> (development: 1 = the whole batch at once, the phase profile's serial reference)
+static int callback_chunks(long long n) {
+    static const int forced = getenv("SMCMI_CB_CHUNKS") ? atoi(getenv("SMCMI_CB_CHUNKS")) : 0;
+    if (forced > 0) return std::min(forced, CB_MAX_CHUNKS);
+    return (int)std::max<long long>(1, std::min<long long>(8, n / 12288));
+}
+static inline double cb_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// evaluate callback `which` on the rows of theta (n x d, column-major, leading dimension n) whose `gate` is finite; others get -Inf
-static int eval_callback(smcmi_handle *h, int which, const double *theta, const double *gate, double *lik_out) {
+// Evaluate callback `which` on the m_rows x d column-major block `theta` (leading dimension m_rows) for the rows whose `gate` is finite
+// (gate = the proposals' log-priors: -Inf = the bounds check failed, the reference never calls the likelihood there, mutation.jl:93);
+// the others get -Inf.  When every row passes - the common case - the block goes to the user's function as it is and the results land in
+// lik_out directly; otherwise the passing rows are packed first.  Synchronously on the calling thread.
+static int eval_callback(smcmi_handle *h, int which, const double *theta, const double *gate, double *lik_out, long long m_rows = -1) {
     CallbackBuffers *b = h->cbuf;
-    const long long n = h->n;
+    const long long n = m_rows >= 0 ? m_rows : h->n;
     const int d = h->d;
+    double t0 = cb_now_ms();
     long long m = 0;
+    if (gate) { for (long long i = 0; i < n; ++i) m += gate[i] != -HUGE_VAL; } else m = n;
+    if (m == n) {
+        const int rc = n > 0 ? h->cb[which](theta, (int64_t)n, (int64_t)d, lik_out, h->cb_ud[which]) : 0;
+        const double t1 = cb_now_ms();
+        b->phase_ms[CBP_CALL] += t1 - t0;
+        if (rc != 0) return set_err(SMCMI_ERR_CALLBACK, "the likelihood callback returned " + std::to_string(rc));
+        for (long long i = 0; i < n; ++i) { const double v = lik_out[i]; if (v != v) lik_out[i] = -HUGE_VAL; }      // NaN: the reference's `try ... catch` turns a failed evaluation into -Inf
+        b->phase_ms[CBP_SCATTER] += cb_now_ms() - t1;
+        h->cb_calls += 1; h->cb_evals += n;
+        return 0;
+    }
+    m = 0;
     for (long long i = 0; i < n; ++i)
-        if (!gate || gate[i] != -HUGE_VAL) b->h_idx[m++] = i;
+        if (gate[i] != -HUGE_VAL) b->h_idx[m++] = i;
     for (int j = 0; j < d; ++j) {
         const double *col = theta + (long long)j * n;
         double *dst = b->h_pack + (long long)j * m;
         for (long long k = 0; k < m; ++k) dst[k] = col[b->h_idx[k]];
     }
+    double t1 = cb_now_ms();
+    b->phase_ms[CBP_PACK] += t1 - t0;
     if (m > 0) {
         const int rc = h->cb[which](b->h_pack, (int64_t)m, (int64_t)d, b->h_out, h->cb_ud[which]);
         if (rc != 0) return set_err(SMCMI_ERR_CALLBACK, "the likelihood callback returned " + std::to_string(rc));
     }
+    double t2 = cb_now_ms();
+    b->phase_ms[CBP_CALL] += t2 - t1;
     for (long long i = 0; i < n; ++i) lik_out[i] = -HUGE_VAL;
     for (long long k = 0; k < m; ++k) {
         const double v = b->h_out[k];
-        lik_out[b->h_idx[k]] = (v != v) ? -HUGE_VAL : v;          // NaN: the reference's `try ... catch` turns a failed evaluation into -Inf
+        lik_out[b->h_idx[k]] = (v != v) ? -HUGE_VAL : v;
     }
+    b->phase_ms[CBP_SCATTER] += cb_now_ms() - t2;
     h->cb_calls += 1; h->cb_evals += m;
     return 0;
 }
 
-// all MH steps x blocks of one stage's mutation with the host callback (src/mutation.jl:56-138); the proposal was set up by
-// k_prepare_mutation of this stage
-static int host_mutation(smcmi_handle *h, const smcmi_run_config *rc, bool tempered) {
+// All MH steps x blocks of one stage's mutation with the host callback (src/mutation.jl:56-138); the proposal was set up by
+// k_prepare_mutation of this stage.  Per step x block: propose (k_mutate<1>, proposals chunk-major: a chunk's block = its d proposal
+// columns + their log-priors) -> the chunks cross PCIe back to back on a copy stream, each ONE linear copy -> the callback scores chunk c on
+// the calling thread while chunk c + 1 is on its way -> the chunk's log-likelihoods go back on a third stream -> accept (k_mutate<2>)
+// behind the last of them.  One invocation of the user's function per chunk (two with an old-data callback); the values, and so every
+// bit of the run, do not depend on the chunking.
+// host_propose_enqueue: the first half for (step, blk) - run_callback enqueues it for the first proposal BEFORE it has read the stage's
+// verdict (a stage that did not go ahead leaves the propose kernel a no-op and the copies meaningless: they are dropped), so the
+// stage's only host wait is the first chunk's arrival.
+static int host_propose_enqueue(smcmi_handle *h, int step, int blk) {
     CallbackBuffers *b = h->cbuf;
     const long long n = h->n;
     const int d = h->d;
+    const int K = callback_chunks(n);
+    const long long mc = (n + K - 1) / K;
+    const double t0 = cb_now_ms();
+    MutArgs ma{};
+    ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.proposals = h->d_prop; ma.prop_logprior = h->d_prop_lp;
+    ma.prop_qdiff = h->d_prop_q; ma.acc_count = h->d_acc_count; ma.block = blk; ma.step = step;
+    ma.prop_chunk = mc;
+    k_mutate<1><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
+    HIP_TRY(hipEventRecord(b->ev_prop, h->stream));
+    HIP_TRY(hipStreamWaitEvent(b->s_down, b->ev_prop, 0));
+    int c = 0;
+    for (long long a = 0; a < n; a += mc, ++c) {
+        const long long len = std::min(mc, n - a);
+        HIP_TRY(hipMemcpyAsync(b->h_prop + a * (d + 1), h->d_prop + a * (d + 1), sizeof(double) * len * (d + 1), hipMemcpyDeviceToHost, b->s_down));
+        HIP_TRY(hipEventRecord(b->ev_chunk[c], b->s_down));
+    }
+    b->phase_ms[CBP_ENQUEUE] += cb_now_ms() - t0;
+    return 0;
+}
+static int host_mutation(smcmi_handle *h, const smcmi_run_config *rc, bool tempered, bool first_enqueued = false) {
+    CallbackBuffers *b = h->cbuf;
+    const long long n = h->n;
+    const int d = h->d;
+    const int K = callback_chunks(n);
+    const long long mc = (n + K - 1) / K;
     if (ensure_split_buffers(h)) return SMCMI_ERR_HIP;
     for (int step = 0; step < rc->n_mh_steps; ++step)
         for (int blk = 0; blk < rc->n_blocks; ++blk) {
+            if (!(first_enqueued && step == 0 && blk == 0)) { if (int e = host_propose_enqueue(h, step, blk)) return e; }
+            int c = 0;
+            for (long long a = 0; a < n; a += mc, ++c) {
+                const long long len = std::min(mc, n - a);
+                double t0 = cb_now_ms();
+                HIP_TRY(hipEventSynchronize(b->ev_chunk[c]));
+                b->phase_ms[c == 0 ? CBP_FIRST : CBP_WAIT] += cb_now_ms() - t0;
+                const double *blk_theta = b->h_prop + a * (d + 1), *blk_lp = blk_theta + len * d;
+                if (int e = eval_callback(h, 0, blk_theta, blk_lp, b->h_lik[0] + a, len)) return e;
+                if (tempered) { if (int e = eval_callback(h, 1, blk_theta, blk_lp, b->h_lik[1] + a, len)) return e; }
+                t0 = cb_now_ms();
+                HIP_TRY(hipMemcpyAsync(h->d_lik_new + a, b->h_lik[0] + a, sizeof(double) * len, hipMemcpyHostToDevice, b->s_up));
+                if (tempered) HIP_TRY(hipMemcpyAsync(h->d_lik_old + a, b->h_lik[1] + a, sizeof(double) * len, hipMemcpyHostToDevice, b->s_up));
+                b->phase_ms[CBP_ENQUEUE] += cb_now_ms() - t0;
+            }
+            const double t0 = cb_now_ms();
+            HIP_TRY(hipEventRecord(b->ev_up, b->s_up));
+            HIP_TRY(hipStreamWaitEvent(h->stream, b->ev_up, 0));
             MutArgs ma{};
             ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.proposals = h->d_prop; ma.prop_logprior = h->d_prop_lp;
             ma.prop_qdiff = h->d_prop_q; ma.acc_count = h->d_acc_count; ma.block = blk; ma.step = step;
-            k_mutate<1><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
-            HIP_TRY(hipMemcpyAsync(b->h_prop, h->d_prop, sizeof(double) * n * d, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipMemcpyAsync(b->h_lp, h->d_prop_lp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (int e = eval_callback(h, 0, b->h_prop, b->h_lp, b->h_lik[0])) return e;
-            if (tempered) { if (int e = eval_callback(h, 1, b->h_prop, b->h_lp, b->h_lik[1])) return e; }
-            HIP_TRY(hipMemcpyAsync(h->d_lik_new, b->h_lik[0], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-            if (tempered) HIP_TRY(hipMemcpyAsync(h->d_lik_old, b->h_lik[1], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+            ma.prop_chunk = mc;
             ma.lik_new = h->d_lik_new; ma.lik_old_new = tempered ? h->d_lik_old : nullptr;
             ma.last = (step == rc->n_mh_steps - 1 && blk == rc->n_blocks - 1) ? 1 : 0;
             k_mutate<2><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
+            // (the next propose overwrites d_prop / the pinned buffers: in stream order behind this accept; the copy streams are drained)
+            b->phase_ms[CBP_ENQUEUE] += cb_now_ms() - t0;
         }
     return 0;
 }
@@ -210,19 +315,29 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
     const auto t0 = std::chrono::steady_clock::now();
     const int max_iter = (adaptive ? h->cfg.max_stages : rc->n_phi - 1) - base;
     h->cb_calls = 0; h->cb_evals = 0;
+    for (double &p : h->cbuf->phase_ms) p = 0.0;
     res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0;
     int launched = 0, done = 0, had = first_passes;
     DevState head;
     constexpr size_t head_off = offsetof(DevState, stage), head_len = offsetof(DevState, ess) - offsetof(DevState, stage);
     while (launched < max_iter && !done) {
         // the stage up to the proposal set-up (no mutation kernel: host_mutation below); no energy sums exist for a predictor
+        const double ts0 = cb_now_ms();
         enqueue_stage(h, adaptive, first_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, false, false, false, false, true);
         had = first_passes;
+        bool first_enqueued = false;
         for (;;) {
             HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipEventRecord(h->cbuf->ev_head, h->stream));
+            // the first proposal goes out before the verdict is read (a stage that stalled or ended leaves it a no-op)
+            if (ensure_split_buffers(h)) return SMCMI_ERR_HIP;
+            if (int e = host_propose_enqueue(h, 0, 0)) return e;
+            first_enqueued = true;
+            HIP_TRY(hipEventSynchronize(h->cbuf->ev_head));
             done = head.done;
             if (done != 2) break;
+            first_enqueued = false;
+            HIP_TRY(hipStreamSynchronize(h->cbuf->s_down));          // (the dropped proposal's copies: the pinned buffers are reused below)
             if (had > 1200) return set_err(SMCMI_ERR_BRACKET, "adaptive tempering solver: the search for phi_n does not terminate (the ESS objective is not a number?)");
             // the solver ran out of passes: continue the same search with more (smcmi_run)
             const int zero = 0;
@@ -231,11 +346,13 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
             had += 8;
             res->solver_stalls += 1;
         }
+        h->cbuf->phase_ms[CBP_STAGE] += cb_now_ms() - ts0;
         if (done) break;                                 // ϕ = 1 was reached by the previous stage (its begin raised the flag), a pause, or an error
-        if (int e = host_mutation(h, rc, tempered)) return e;
+        if (int e = host_mutation(h, rc, tempered, first_enqueued)) return e;
         ++launched;
     }
     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
+    HIP_TRY(hipStreamSynchronize(h->cbuf->s_down));                  // (a proposal enqueued for a stage that turned out to be the end of the run)
     if (pull_state(h)) return SMCMI_ERR_HIP;
     const auto t1 = std::chrono::steady_clock::now();
     res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;

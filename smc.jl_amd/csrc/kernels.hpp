@@ -1997,6 +1997,10 @@ struct MutArgs {
     long long gid0;            // global id of local particle 0
     double *proposals;         // MODE 1/2: n x d proposals (column-major), logprior', q0-q1
     double *prop_logprior, *prop_qdiff;
+    long long prop_chunk;      // MODE 1/2, > 0: `proposals` is chunk-major - particles [c m, (c + 1) m) form one contiguous column-major block of
+                               // len x d (len = m, the last chunk's is shorter), so a chunk crosses PCIe as ONE linear copy and reaches the host
+                               // callback as the m x d matrix its contract names, without a pack (callback.hpp host_mutation); column d of a
+                               // chunk's block holds the proposals' log-priors (prop_logprior is not used), so a chunk is ONE copy; 0: n x d
     const double *lik_new, *lik_old_new;   // MODE 2
     int *acc_count;            // MODE 1/2: accepted block lengths so far
     int block, step, last;     // MODE 1/2
@@ -2054,6 +2058,13 @@ __device__ __forceinline__ void mutate_generic(const CloudPtrs &cl, const ModelD
     const bool kalman_wave = LS == 1 && MODE == 0 && d == 13 && !(ma.debug & 256) && md->lik[0].family == SMCMI_LIK_LGSS_KALMAN &&
                              (md->lik[1].family == SMCMI_LIK_NONE || md->lik[1].family == SMCMI_LIK_LGSS_KALMAN);
     auto TN = [&](int k) { return tn[k * T + tid]; };
+    // proposal k of this particle in the MODE 1/2 buffer: proposals[k * p_ld + p_off]
+    long long p_ld = cl.n, p_off = i;
+    if (MODE != 0 && ma.prop_chunk > 0 && live) {
+        const long long c0 = (i / ma.prop_chunk) * ma.prop_chunk;
+        p_ld = (cl.n - c0 < ma.prop_chunk) ? cl.n - c0 : ma.prop_chunk;
+        p_off = c0 * (d + 1) + (i - c0);                // (a chunk's block: d proposal columns + the log-prior column)
+    }
     // (the loops are uniform and `live` is tested inside them: the lane-split filter needs every lane of the wavefront)
     {
         const int s_beg = (MODE == 0) ? 0 : ma.step, s_end = (MODE == 0) ? n_steps : ma.step + 1;
@@ -2159,8 +2170,9 @@ __device__ __forceinline__ void mutate_generic(const CloudPtrs &cl, const ModelD
                     inb = in_bounds(mv, TN);
                     if (inb) prior_new = logprior(mv, TN);
                     if (MODE == 1) {
-                        for (int k = 0; k < d; ++k) ma.proposals[(long long)k * cl.n + i] = TN(k);
-                        ma.prop_logprior[i] = prior_new;
+                        for (int k = 0; k < d; ++k) ma.proposals[(long long)k * p_ld + p_off] = TN(k);
+                        if (ma.prop_chunk > 0) ma.proposals[(long long)d * p_ld + p_off] = prior_new;
+                        else ma.prop_logprior[i] = prior_new;
                         ma.prop_qdiff[i] = q0 - q1;
                     }
                 }
@@ -2208,8 +2220,8 @@ __device__ __forceinline__ void mutate_generic(const CloudPtrs &cl, const ModelD
                         if (like_new == SMCMI_NEG_INF) prior_new = SMCMI_NEG_INF;
                     }
                 } else if (live) {
-                    for (int k = 0; k < d; ++k) tn[k * T + tid] = ma.proposals[(long long)k * cl.n + i];
-                    prior_new = ma.prop_logprior[i];
+                    for (int k = 0; k < d; ++k) tn[k * T + tid] = ma.proposals[(long long)k * p_ld + p_off];
+                    prior_new = ma.prop_chunk > 0 ? ma.proposals[(long long)d * p_ld + p_off] : ma.prop_logprior[i];
                     q0 = ma.prop_qdiff[i];
                     q1 = 0.0;
                     if (prior_new == SMCMI_NEG_INF) {            // out of bounds: ParamBoundsError => everything -Inf

@@ -66,7 +66,7 @@ template <int D>
 void launch_k2b_mutate(smcmi_handle *h, const Mut2Args &ma, const Beg2Args &bb, int nb, bool alpha1) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10) {
-        const size_t lds = k2_lds_bytes(D);
+        const size_t lds = k2_lds_bytes_body(D);          // (the prologue's scratch behind it is never touched: 13 instead of 22 KB per block)
         const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2) + (bb.enable ? 1u : 0u);
         if (alpha1) k2b_mutate<D, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
         else k2b_mutate<D, false><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);

@@ -13,6 +13,7 @@
 
 
 constexpr int SEG3_MAX_LAUNCHES = 4096;     // segment launches of one run whose stage counts are kept for the profile (more are not timed)
+constexpr int PROF2_BLOCKS = 4096;
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
@@ -417,8 +418,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
     }
     if (getenv("SMCMI_PROF2") && !h0->e2->d_prof) {
-        if (dmalloc(&h0->e2->d_prof, 128)) return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemset(h0->e2->d_prof, 0, 128 * sizeof(long long)));
+        // ([128, 128 + 3 * PROF2_BLOCKS): wall-clock start / end and CU of every block of that stage's large-shard mutation launch - the census below)
+        if (dmalloc(&h0->e2->d_prof, 128 + 3 * PROF2_BLOCKS)) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemset(h0->e2->d_prof, 0, (128 + 3 * PROF2_BLOCKS) * sizeof(long long)));
         HIP_TRY(hipDeviceSynchronize());
         h0->e2->prof_stage = atoi(getenv("SMCMI_PROF2"));
     }
@@ -1029,6 +1031,38 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                     h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
             fprintf(stderr, "[smcmi3]   decision + proposal: totals -> covariance, shuffle %lld | block matrices %lld | Cholesky + log det %lld | rest %lld\n",
                     pr[30] - pr[3], pr[31] - pr[30], pr[32] - pr[31], pr[4] - pr[32]);
+        }
+        if (!g0.direct && !g0.inker && !g0.wide) {
+            // census of the large-shard mutation launch of the profiled stage (100 MHz wall clock, the CU every block sat on): how many blocks
+            // a CU held at once
+            std::vector<long long> cs(3 * PROF2_BLOCKS);
+            HIP_TRY(hipMemcpy(cs.data(), h0->e2->d_prof + 128, sizeof(long long) * cs.size(), hipMemcpyDeviceToHost));
+            long long t_min = 0, t_max = 0, sum = 0;
+            int nbk = 0;
+            std::map<long long, std::vector<std::pair<long long, int>>> per_cu;
+            for (int b = 0; b < PROF2_BLOCKS; ++b) {
+                const long long t_a = cs[3 * b], t_b = cs[3 * b + 1];
+                if (!t_a || !t_b) continue;
+                if (!nbk || t_a < t_min) t_min = t_a;
+                if (!nbk || t_b > t_max) t_max = t_b;
+                sum += t_b - t_a;
+                ++nbk;
+                per_cu[cs[3 * b + 2]].push_back({t_a, +1});
+                per_cu[cs[3 * b + 2]].push_back({t_b, -1});
+            }
+            int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (auto &kv : per_cu) {
+                std::sort(kv.second.begin(), kv.second.end());
+                int cur = 0, mx = 0;
+                for (auto &ev : kv.second) { cur += ev.second; mx = std::max(mx, cur); }
+                hist[std::min(mx, 8)] += 1;
+            }
+            if (nbk) {
+                fprintf(stderr, "[smcmi2] K2b census: %d blocks on %d CUs, first start -> last end %.2f us, mean block %.2f us, mean residency %.1f blocks; CUs by the most blocks they held at once:", nbk,
+                        (int)per_cu.size(), (t_max - t_min) * 0.01, sum * 0.01 / nbk, (double)sum / (double)std::max<long long>(1, t_max - t_min));
+                for (int k = 1; k <= 8; ++k) if (hist[k]) fprintf(stderr, " %d x %d", hist[k], k);
+                fprintf(stderr, "\n");
+            }
         }
         for (int blk = 0; blk < 2; ++blk) {
             fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");

@@ -584,12 +584,27 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             HIP_TRY(hipMemcpyAsync(&dn, &h0->d_st->done, sizeof(int), hipMemcpyDeviceToHost, h0->stream));
             HIP_TRY(hipStreamSynchronize(h0->stream));
             if (dn) return 0;
+            // (a closure that fails on ONE rank must end the stage on every rank: the failure rides the acceptance all-reduce as a second
+            // number - a rank that returned alone would leave the others waiting in the collective)
+            int my_err = 0;
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
-                if (int e = host_mutation(h, rc, tempered_cb)) return e;
-                k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_tot_acc + EACC);
+                const int e = my_err ? my_err : host_mutation(h, rc, tempered_cb);
+                if (e) my_err = e;
+                else k_reduce_partials<<<1, TB, 0, h->stream>>>(h->d_acc_part, h->nb_mut, 1, h->d_tot_acc + EACC);
+                const double flag = e ? 1.0 : 0.0;
+                HIP_TRY(hipMemcpyAsync(h->d_tot_acc + EACC + 1, &flag, sizeof(double), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));           // (`flag` is a stack variable)
             }
-            return g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 1);
+            const std::string my_msg = my_err ? g_err : std::string();
+            if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + EACC; }, 2)) return rc2;
+            double failed = 0.0;
+            HIP_TRY(hipSetDevice(h0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(&failed, h0->d_tot_acc + EACC + 1, sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+            HIP_TRY(hipStreamSynchronize(h0->stream));
+            if (my_err) return set_err(my_err, my_msg);
+            if (failed != 0.0) return set_err(SMCMI_ERR_CALLBACK, "the likelihood callback failed on another rank of the sharded run");
+            return 0;
         }
         for (auto *h : g.hs) {
             HIP_TRY(hipSetDevice(h->cfg.device));

@@ -831,7 +831,7 @@ extern "C" int smcmi_mutate(smcmi_handle *h, const double *mu_free, const double
 static int ensure_split_buffers(smcmi_handle *h) {
     if (h->d_prop) return 0;
     const long long n = h->n;
-    if (dmalloc(&h->d_prop, (size_t)n * h->d) || dmalloc(&h->d_prop_lp, n) || dmalloc(&h->d_prop_q, n) ||
+    if (dmalloc(&h->d_prop, (size_t)n * (h->d + 1)) || dmalloc(&h->d_prop_lp, n) || dmalloc(&h->d_prop_q, n) ||       // (+ 1: the chunk-major layout's log-prior column)
         dmalloc(&h->d_lik_new, n) || dmalloc(&h->d_lik_old, n) || dmalloc(&h->d_acc_count, n))
         return SMCMI_ERR_HIP;
     return 0;
@@ -1534,6 +1534,11 @@ extern "C" int smcmi_shard_mutate_partial(smcmi_handle *h, const double *mu_free
 }
 
 #include "callback.hpp"
+extern "C" int smcmi_callback_phases(smcmi_handle *h, double *ms_out, int32_t n) {
+    if (!h || !ms_out || n < 1) return set_err(SMCMI_ERR_ARG, "bad argument");
+    for (int k = 0; k < n; ++k) ms_out[k] = (h->cbuf && k < CBP_N) ? h->cbuf->phase_ms[k] : 0.0;
+    return 0;
+}
 #include "sharded.hpp"
 #include "launch2.hpp"
 #include "run2.hpp"

@@ -1577,6 +1577,10 @@ struct Mut2Lds {
         bfree = (int *)(mu_f + D); fi = bfree + D; fi_j = fi + D;
     }
 };
+// ... of the mutation body alone (Ls .. ball_raw: what a kernel that loads a finished proposal needs - k2b_mutate, stage2b.hpp)
+constexpr size_t k2_lds_bytes_body(int D, int lik_cap = LIK_LDS_CAP) {
+    return (size_t)(2 * D * D + 12 * D + 8 + 2 * LIK_PAR_MAX + lik_cap) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32;
+}
 constexpr size_t k2_lds_bytes(int D, int lik_cap = LIK_LDS_CAP) {
     const size_t np = (size_t)(D + 1) * (D + 2) / 2, npf = np + 2;
     return (size_t)(2 * D * D + 12 * D + 8 + 2 * LIK_PAR_MAX + lik_cap) * sizeof(double) + (size_t)(6 * D + 8) * sizeof(int) + 32 +

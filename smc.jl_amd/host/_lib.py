@@ -83,6 +83,7 @@ SYMBOLS = [
     ("smcmi_set_likelihood_callback", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p]),
     ("smcmi_eval_cloud_callback", C.c_int, [_H, C.c_int32, C.c_int32]),
     ("smcmi_callback_stats", C.c_int, [_H, lp, lp]),
+    ("smcmi_callback_phases", C.c_int, [_H, dp, C.c_int32]),
     ("smcmi_upload_cloud", C.c_int, [_H, dp]),
     ("smcmi_download_cloud", C.c_int, [_H, dp]),
     ("smcmi_upload_cloud_device", C.c_int, [_H, C.c_void_p]),

@@ -100,6 +100,13 @@ class Engine:
         check(self._L.smcmi_callback_stats(self._h, C.byref(a), C.byref(b)))
         return dict(calls=a.value, evaluations=b.value)
 
+    def callback_phases(self):
+        """ms the last run with a host callback spent per phase on the calling thread (include/smcmi.h smcmi_callback_phases)"""
+        out = (C.c_double * 8)()
+        check(self._L.smcmi_callback_phases(self._h, out, 8))
+        names = ("first_chunk_wait", "later_chunk_wait", "pack", "callback", "scatter", "enqueue", "stage_device_part")
+        return {k: out[i] for i, k in enumerate(names)}
+
     def set_model(self, spec):
         """spec: dict(priors, bounds, fixed, lik=(family, par, data, aux), old_lik=None|(...))."""
         self.set_parameters(spec["priors"], spec["bounds"], spec.get("fixed"))

@@ -61,6 +61,50 @@ def test_callback_run_matches_the_device_likelihood(kw):
     assert st["calls"] == steps * (r1["n_stages"] - 1) and 0 < st["evaluations"] <= st["calls"] * n
 
 
+def test_chunked_callback_batches_give_the_device_likelihoods_run():
+    """A batch of 50 000 proposals crosses PCIe in 4 chunks (include/smcmi.h: one invocation per chunk, each on its own m x d block, the next
+    chunk in flight meanwhile); with bounds that some proposals leave, chunks are packed before the call.  The run must be the one the
+    device family gives - the values do not depend on the chunking."""
+    from smc_jl_amd import Engine
+
+    d, n, seed = 5, 50000, 11
+    spec = models.gauss_spec(d)
+    spec = dict(spec, bounds=[(-1.6, 1.6)] * d, priors=[("uniform", -1.6, 1.6)] * d)
+    m, sig = np.asarray(spec["lik"][2]).ravel(), float(spec["lik"][1][0])
+    base = _gauss_batch(m, sig)
+    sizes = []
+
+    def f(th):
+        sizes.append(th.shape[0])
+        assert th.min() >= -1.6 and th.max() <= 1.6
+        return base(th)
+
+    kw = dict(use_fixed_schedule=True, n_phi=30, n_blocks=1, n_mh_steps=2, c=1.5)
+    out = []
+    for mode in ("device", "callback"):
+        e = Engine(n, d, seed=seed, max_stages=100, store_history=False)
+        e.set_model(spec)
+        e.init_from_prior()
+        P0 = e.download_cloud()
+        if mode == "callback":
+            e.set_likelihood_callback(f, which=0)
+            e.upload_cloud(P0)
+        r = e.run(**kw)
+        out.append((r, e.stage_records(r["n_stages"]), e.download_cloud(), e.callback_stats(), e.callback_phases() if mode == "callback" else None))
+        e.close()
+    (r0, rec0, P_dev, _, _), (r1, rec1, P_cb, st, ph) = out
+    assert r0["n_stages"] == r1["n_stages"] == 30 and r0["resamples"] == r1["resamples"]
+    np.testing.assert_allclose(rec1["ess"], rec0["ess"], rtol=1e-7)
+    np.testing.assert_allclose(rec1["accept_hist"], rec0["accept_hist"], atol=3.0 / n)
+    assert abs(r1["logmdd"] - r0["logmdd"]) < 1e-7
+    same = np.all(np.abs(P_cb - P_dev) <= 1e-9 * (1 + np.abs(P_dev)), axis=1)
+    assert same.mean() > 0.999
+    chunks = 4                                                   # min(8, 50000 // 12288)
+    assert st["calls"] == len(sizes) == chunks * 2 * (r1["n_stages"] - 1)
+    assert max(sizes) <= 12500 and st["evaluations"] == sum(sizes) < st["calls"] * 12500      # out-of-bounds proposals were packed away
+    assert ph["callback"] > 0.0 and ph["pack"] > 0.0
+
+
 def test_callback_sees_only_in_bounds_proposals_and_errors_abort():
     from smc_jl_amd import Engine
 

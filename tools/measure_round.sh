@@ -17,7 +17,7 @@ python bench.py --workload kalman --nparts 12500 --steps 3 --warmup 1 2>/dev/nul
 SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_engine1_stage.json
 python bench.py --workload kalman --nparts 25000 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n25000.json
 SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_engine1_stage.json
-gcc -O2 -std=c99 -ffp-contract=off -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
+gcc -O2 -std=c99 -ffp-contract=off -fopenmp -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
 LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
 python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
 python bench.py --alpha 0.9 --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6_alpha09.json
