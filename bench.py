@@ -403,9 +403,7 @@ def main():
             wide = os.environ.get("SMCMI_ENGINE_WIDE", "1") != "0" and os.environ.get("SMCMI_ENGINE", "0") != "1"
             kk = (lambda ls: ("k2w_mutate<13, %d> (decision + proposal prologue, then the filter)" % ls) if wide else ("k_mutate<0, %d>" % ls))
             kname5 = (kk(4) + " / kalman_lgss_quad: four lanes per particle (the default up to 32 768 particles per handle)" if split else
-                      (kk(1) + " / kalman_lgss2: one thread per particle, scalar structure operands (round-2 kernel)"
-                       if os.environ.get("SMCMI_KALMAN_WAVE", "1") == "0" else
-                       kk(1) + " / kalman_lgss_wave: one thread per particle, structure values through DPP operands"))
+                      kk(1) + " / kalman_lgss_wave: one thread per particle, structure values through DPP operands")
             # counter figures for the filter's kernel at this cloud size, when a PMC file exists (profiles/rNN_pmc_kalman_n<N>.json)
             traffic5, valu5 = None, None
             if pmc_file:

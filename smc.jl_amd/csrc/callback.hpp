@@ -191,6 +191,7 @@ static int host_mutation(smcmi_handle *h, const smcmi_run_config *rc, bool tempe
             ma.prop_chunk = mc;
             ma.lik_new = h->d_lik_new; ma.lik_old_new = tempered ? h->d_lik_old : nullptr;
             ma.last = (step == rc->n_mh_steps - 1 && blk == rc->n_blocks - 1) ? 1 : 0;
+            if (h->cb_energy && ma.last) { ma.esum = h->d_esum_part; ma.emax = h->d_emax_part; }
             k_mutate<2><<<h->nb_mut, h->mut_T, h->mut_lds, h->stream>>>(h->cl, h->d_st, h->d_model, ma, h->d_acc_part, 0);
             // (the next propose overwrites d_prop / the pinned buffers: in stream order behind this accept; the copy streams are drained)
             b->phase_ms[CBP_ENQUEUE] += cb_now_ms() - t0;
@@ -309,6 +310,9 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->rng_ahead = false;
+    // adaptive schedules: the accept launches leave the energy power sums the phi predictor reads, so a stage's certificate search starts
+    // from rings around the predicted root - one pass instead of six - and the energy maxima the shifted weights need
+    h->cb_energy = adaptive && !getenv("SMCMI_NO_PREDICTOR");
     const int acc_nb = h->nb_mut;                       // the split kernels are the generic (LDS) mutation kernels
     k_energy_max<<<acc_nb, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
     const int first_passes = std::max(rc->solver_passes, FIRST_SOLVER_PASSES);
@@ -323,8 +327,9 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
     while (launched < max_iter && !done) {
         // the stage up to the proposal set-up (no mutation kernel: host_mutation below); no energy sums exist for a predictor
         const double ts0 = cb_now_ms();
-        enqueue_stage(h, adaptive, first_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, false, false, false, false, true);
-        had = first_passes;
+        const int passes = (h->cb_energy && launched >= 2) ? std::max(1, rc->solver_passes) : first_passes;
+        enqueue_stage(h, adaptive, passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, false, false, false, false, true);
+        had = passes;
         bool first_enqueued = false;
         for (;;) {
             HIP_TRY(hipMemcpyAsync((char *)&head + head_off, (const char *)h->d_st + head_off, head_len, hipMemcpyDeviceToHost, h->stream));

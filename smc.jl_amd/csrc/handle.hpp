@@ -123,4 +123,5 @@ struct smcmi_handle {
     void *cb_ud[2] = {nullptr, nullptr};
     CallbackBuffers *cbuf = nullptr;
     long long cb_calls = 0, cb_evals = 0;
+    bool cb_energy = false;        // the run's accept launches leave energy power sums / maxima (adaptive single-handle closure runs: predictor rings, shifted weights)
 };

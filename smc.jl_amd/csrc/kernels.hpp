@@ -2053,9 +2053,8 @@ __device__ __forceinline__ void mutate_generic(const CloudPtrs &cl, const ModelD
         for (int k = 0; k < d; ++k) tn[k * T + tid] = th[k * T + tid];
     }
     // lgss_kalman on both vintages with one thread per particle: the filter whose structure values travel through DPP operands
-    // (model.hpp kalman_lgss_wave) - called by every lane, like the lane-split one.  SMCMI_KALMAN_WAVE=0 (host: ma.debug bit 8) keeps
-    // kalman_lgss2 under the particle's own branch (development / comparison).
-    const bool kalman_wave = LS == 1 && MODE == 0 && d == 13 && !(ma.debug & 256) && md->lik[0].family == SMCMI_LIK_LGSS_KALMAN &&
+    // (model.hpp kalman_lgss_wave) - called by every lane, like the lane-split one.
+    const bool kalman_wave = LS == 1 && MODE == 0 && d == 13 && md->lik[0].family == SMCMI_LIK_LGSS_KALMAN &&
                              (md->lik[1].family == SMCMI_LIK_NONE || md->lik[1].family == SMCMI_LIK_LGSS_KALMAN);
     auto TN = [&](int k) { return tn[k * T + tid]; };
     // proposal k of this particle in the MODE 1/2 buffer: proposals[k * p_ld + p_off]
@@ -2319,13 +2318,16 @@ __global__ void __launch_bounds__(256, 1) k_mutate(CloudPtrs cl, const DevState 
     double a1[1] = {acc_val};
     Butterfly<0, 32>::run(a1, btid & 63);
     if ((btid & 63) == 0) red[btid >> 6] = a1[0];
-    if (MODE == 0 && ma.emax) {                      // largest energy of the mutated cloud (energy shift of the next stage)
+    // (MODE 2: the accept launch of a stage's LAST proposal leaves them as well - the host-closure path then has the predictor's rings
+    // around its certificate pass and the shifted weights, like every other path)
+    const bool leaves_sums = MODE == 0 || (MODE == 2 && ma.last);
+    if (leaves_sums && ma.emax) {                    // largest energy of the mutated cloud (energy shift of the next stage)
         __shared__ double emx[4];
         const double wl = (counted && !st->do_resample) ? col(cl, src, d + 4)[i] : 1.0;
         const double em = block_max(energy_or_ninf(like, like_prev, wl, counted), emx, nwv);
         if (btid == 0) ma.emax[blockIdx.x] = em;
     }
-    if (MODE == 0 && ma.esum) {                      // energy power sums of the mutated cloud (ϕ predictor of the next stage)
+    if (leaves_sums && ma.esum) {                    // energy power sums of the mutated cloud (ϕ predictor of the next stage)
         double es[ES];
         energy_terms(es, counted ? col(cl, src, d + 4)[i] : 0.0, like, like_prev, st->e_center, counted, st->do_resample != 0);
         es[EACC] = acc_val;

@@ -15,7 +15,7 @@ void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected
         ra.zbuf = h->d_zbuf; ra.n_steps = e->n_steps; ra.nb = e->n_blocks; ra.nf = h->h_model.n_free; ra.seed = h->cfg.seed; ra.gid0 = h->cfg.gid0;
         ra.t_lim = e->z_ahead;
         // (large shards: the drawing blocks follow the correction blocks onto the CUs - one 512-thread block each - and run under the helper's serial work)
-        if (e->g.t2 == 512) grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
+        if (e->g.inker) grid += (unsigned)std::max(1, std::min(e->g.Vl * e->g.nb2, 256 - (int)grid));
         else grid += (unsigned)std::max<long long>(1, std::min<long long>((e->g.n + T1 - 1) / T1, 256));
     }
     if (helper) grid += 1;
@@ -51,14 +51,14 @@ void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) 
     } else {
     const size_t lds = k2_lds_bytes(D);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2);
-    if (e->g.t2 == 512 && !ma.tail.tick) {             // the direct geometry (config 2): no hand-over code in the instantiation
+    // (every block runs the prologue: the direct geometry and small shards of several handles; large shards are k2b_mutate's - launch_k2b_mutate)
+    if (!ma.tail.tick) {             // the direct geometry (config 2): no hand-over code in the instantiation
         if (alpha1) k2_mutate<D, true, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
         else k2_mutate<D, false, 512, false><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
-    } else if (e->g.t2 == 512) {
+    } else {
         if (alpha1) k2_mutate<D, true, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
         else k2_mutate<D, false, 512, true><<<grid, 512, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, nb, h->h_model.n_free);
     }
-    // (256-thread mutation blocks - large shards, the reduced geometry - are k2b_mutate's: launch_k2b_mutate)
     }
 }
 // the mutation launch of large shards (stage2b.hpp), compiled in translation units of its own (inst2b.hip, Makefile BIGFLAGS)
@@ -68,8 +68,8 @@ void launch_k2b_mutate(smcmi_handle *h, const Mut2Args &ma, const Beg2Args &bb, 
     if constexpr (D <= 10) {
         const size_t lds = k2_lds_bytes_body(D);          // (the prologue's scratch behind it is never touched: 13 instead of 22 KB per block)
         const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2) + (bb.enable ? 1u : 0u);
-        if (alpha1) k2b_mutate<D, true><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
-        else k2b_mutate<D, false><<<grid, 256, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
+        if (alpha1) k2b_mutate<D, true><<<grid, T2B, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
+        else k2b_mutate<D, false><<<grid, T2B, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, bb, nb, h->h_model.n_free);
     }
 }
 template <int D>

@@ -53,16 +53,13 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
     // direct: every block totals the per-block rows itself - one handle, <= GRP rows per virtual shard, and the 512-thread mutation
     // blocks (one per CU) resident at once
-    static const int direct_max = getenv("SMCMI_E2_DIRECT_MAX") ? atoi(getenv("SMCMI_E2_DIRECT_MAX")) : 256;   // development only
-    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= direct_max) ? 1 : 0;
+    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= 256) ? 1 : 0;
     if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
     // several handles with small shards: one 512-thread mutation block per CU as well, prologues in the kernels, fed by the gathered totals
-    static const int no_inker = getenv("SMCMI_E2_NO_INKER") ? atoi(getenv("SMCMI_E2_NO_INKER")) : 0;              // development only
-    g.inker = (g.direct || (!single && !no_inker && (long long)g.nb2 * g.Vl <= 256)) ? 1 : 0;
-    if (!g.inker) {                                       // large clouds: 256-thread mutation blocks (3 wavefronts per SIMD)
-        g.t2 = 256;
-        g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
-    }
+    g.inker = (g.direct || (!single && (long long)g.nb2 * g.Vl <= 256)) ? 1 : 0;
+    // large shards (stage2b.hpp k2b_mutate): the same 512-particle mutation blocks at half the registers - two per CU, 4 wavefronts per SIMD
+    // (256-thread blocks - 489 raw rows per virtual shard at 125 000 particles, paired into canonical rows by whoever totals them - cost
+    // the block that totals a shard's rows ~10 µs at the END of every mutation launch: twice the loads, a quarter of them in flight)
     // correction blocks per virtual shard: 1024 particles per block (two passes of its 512 threads), at most 16 rows per virtual shard for
     // K2's prologue to total while the cloud is small
     // (the direct geometry: one correction row per 512 particles, the same particles as a mutation row - the persistent segment kernel
@@ -82,7 +79,7 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
 static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     Geo2 g;
     if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
-    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1 && h->e2->g.wide == g.wide) return 0;
+    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.nb2 == g.nb2 && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1 && h->e2->g.wide == g.wide) return 0;
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     Eng2 *e = new Eng2();
     e->g = g; e->world = world;
@@ -137,13 +134,12 @@ static bool eng2_eligible(const smcmi_handle *h, int world) {
 
 // the row totals of K1 / K2 are taken by the last block of each virtual shard instead of a k2_reduce launch, while the mutation
 // kernel has at most ~4 blocks per CU (the ticket costs every block two barriers and an atomic: 48.1 vs 50.8 µs per stage at
-// 125 000 particles per handle, but 52.7 vs 46.7 ms per run at 10⁶ on one handle); SMCMI_E2_NO_TAIL=1 keeps the launches
+// 125 000 particles per handle, but 52.7 vs 46.7 ms per run at 10⁶ on one handle: beyond 2048 blocks k2_reduce launches total the rows)
 static bool fused_tails(const Eng2 *e) {
-    static const int no_tail = getenv("SMCMI_E2_NO_TAIL") ? atoi(getenv("SMCMI_E2_NO_TAIL")) : 0;
     // (several handles: up to 2048 blocks - there the tails break even with the launches they replace, 138.5 vs 139.6 µs per stage at
     // 500 000 particles per handle, and they are what lets the peer mailbox replace the all-gathers)
     if (e->g.wide) return true;                  // (the wide kernels' rows are always totalled by the last block of a virtual shard)
-    return !e->g.direct && !no_tail && (long long)e->g.Vl * e->g.nb2 <= 2048;
+    return !e->g.direct && (long long)e->g.Vl * e->g.nb2 <= 2048;
 }
 #define SMCMI_D_SWITCH(d, CALL)                                                                                                              \
     switch (d) {                                                                                                                          \
@@ -532,7 +528,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         k2_energy_max<<<g0.Vl * g0.nb2, g0.t2, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
     }
     // (mutation rows of 256-thread blocks are paired: the canonical row stands for 512 particles, whatever the block size)
-    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256 && !g0.wide)) return e;
+    if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, 0)) return e;
 
     // ---- engine 3: runs of stages that neither resample nor need a certificate pass become one persistent launch each
     bool e3 = false;
@@ -736,7 +732,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             if (e1) hipEventRecord(e1, h->stream);
         }
         if (bighelp && next_begin >= 0) { begun_stage = n + 1; begun_spec = next_begin; }
-        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, g0.t2 == 256 && !g0.wide, true);
+        return publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, 0, true);
     };
     // enter_mut: stage n_first's correction (and selection, if sel) were enqueued as launches - the segment enters at its mutation
     auto enq_K3 = [&](int n_first, int n_last, bool enter_mut = false, bool sel = false) -> int {             // one persistent launch for stages n_first .. n_last (stage3.hpp)
@@ -873,10 +869,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
     static const int sel_mode = getenv("SMCMI_NO_SELECT_PREDICT") ? atoi(getenv("SMCMI_NO_SELECT_PREDICT")) : 0;   // development only
-    static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;                       // development only
     const bool predict_select = adaptive && sel_mode != 1;
     // predicted ϕ_n needs the solver's objective to be the correction's ESS (no prior weight, quirk Q4) and a tolerance to verify against
-    const bool spec_ok = adaptive && !no_spec && !getenv("SMCMI_NO_PREDICTOR") && rc->tempered_update_prior_weight == 0.0 && !(rc->phi_rtol < 0.0);
+    const bool spec_ok = adaptive && !getenv("SMCMI_NO_PREDICTOR") && rc->tempered_update_prior_weight == 0.0 && !(rc->phi_rtol < 0.0);
     bool spec_on = spec_ok;
     int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;
     int dyn_P = solver_passes;
@@ -900,7 +895,6 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             seg_a = seg_b = -1;
             return enq_K3(a, b2, seg_enter, seg_sel);
         };
-        static const int e3_enter = getenv("SMCMI_SEG_ENTER") ? atoi(getenv("SMCMI_SEG_ENTER")) : 1;      // development: 0 = such stages mutate in a K2 launch
         for (int b = 0; b < batch; ++b) {
             const int n = base + launched + 2;
             bool sel = true;
@@ -913,10 +907,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
             // stages that follow a resample or have no mutation rows yet (first stage of a run / a continuation) get certificate
             // passes; so does everything once predictions have stopped verifying
-            // (resample stages run on the predicted, verified ϕ_n like every other stage since round 4: 10.16 -> 10.00 ms on config 2;
-            // SMCMI_CERT_SELECT=1 gives them their certificate passes back)
-            static const int cert_sel = getenv("SMCMI_CERT_SELECT") ? atoi(getenv("SMCMI_CERT_SELECT")) : 0;
-            const bool cert = adaptive && (!spec_on || (sel && cert_sel) || launched < 2);
+            // (resample stages run on the predicted, verified ϕ_n like every other stage since round 4: 10.16 -> 10.00 ms on config 2)
+            const bool cert = adaptive && (!spec_on || launched < 2);
             // engine 3 takes every stage that is expected to need neither (fixed schedules: nobody can tell which stage resamples -
             // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches) ...
             if (e3 && !cert && (!sel || !adaptive)) {
@@ -928,7 +920,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             if (int e = flush_seg()) return e;
             // ... and the MUTATION of the others: their solver passes, correction and selection run as launches, then a new segment
             // enters at the mutation (what K2 would do) and goes on with the stages behind it
-            if (e3 && e3_enter) {
+            if (e3) {
                 if (int e = enq_stage_front(n, cert, launched < 2 ? first_passes : dyn_P, sel)) return e;
                 seg_a = seg_b = n; seg_enter = true; seg_sel = sel;
             } else {
@@ -938,7 +930,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 if (bighelp && b + 1 < batch) {
                     bool sel2 = true;
                     if (predict_select) sel2 = (rc->tempering_target * (pred_rl ? N_tot : pred_ess) < thr * (1.0 + 1e-6)) && sel_mode != 2;
-                    const bool cert2 = adaptive && (!spec_on || (sel2 && cert_sel) || launched + 1 < 2);
+                    const bool cert2 = adaptive && (!spec_on || launched + 1 < 2);
                     next_begin = cert2 ? 0 : (adaptive ? 1 : 0);
                 }
                 if (int e = enq_stage(n, cert, launched < 2 ? first_passes : dyn_P, sel, next_begin)) return e;
@@ -1061,6 +1053,19 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 fprintf(stderr, "[smcmi2] K2b census: %d blocks on %d CUs, first start -> last end %.2f us, mean block %.2f us, mean residency %.1f blocks; CUs by the most blocks they held at once:", nbk,
                         (int)per_cu.size(), (t_max - t_min) * 0.01, sum * 0.01 / nbk, (double)sum / (double)std::max<long long>(1, t_max - t_min));
                 for (int k = 1; k <= 8; ++k) if (hist[k]) fprintf(stderr, " %d x %d", hist[k], k);
+                // when the blocks started (µs behind the first) and how long they ran
+                int st_h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, du_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const double st_e[7] = {1, 2, 5, 10, 15, 20, 25}, du_e[7] = {8, 12, 16, 20, 24, 28, 32};
+                for (int b = 0; b < PROF2_BLOCKS; ++b) {
+                    if (!cs[3 * b] || !cs[3 * b + 1]) continue;
+                    const double st = (cs[3 * b] - t_min) * 0.01, du = (cs[3 * b + 1] - cs[3 * b]) * 0.01;
+                    int k = 0; while (k < 7 && st >= st_e[k]) ++k; st_h[k] += 1;
+                    k = 0; while (k < 7 && du >= du_e[k]) ++k; du_h[k] += 1;
+                }
+                fprintf(stderr, "\n[smcmi2]   started at <1 <2 <5 <10 <15 <20 <25 >=25 us:");
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", st_h[k]);
+                fprintf(stderr, "; ran <8 <12 <16 <20 <24 <28 <32 >=32 us:");
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", du_h[k]);
                 fprintf(stderr, "\n");
             }
         }

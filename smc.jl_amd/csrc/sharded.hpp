@@ -358,7 +358,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         HIP_TRY(hipSetDevice(h->cfg.device));
         if (!adaptive && rc->n_phi > h->cfg.max_stages) return set_err(SMCMI_ERR_CAPACITY, "max_stages < n_phi");
         if (ensure_shard_buffers(h) || pull_state(h) || upload_sched(h, sched.data(), rc->n_phi)) return SMCMI_ERR_HIP;
-        if (host_mut) { if (int e = ensure_callback_buffers(h)) return e; h->rng_ahead = false; h->cb_calls = 0; h->cb_evals = 0; }
+        if (host_mut) { if (int e = ensure_callback_buffers(h)) return e; h->rng_ahead = false; h->cb_energy = false; h->cb_calls = 0; h->cb_evals = 0; }
         else if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
         DevState &s = h->h_st;
         RunParams rp{};
@@ -426,10 +426,9 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     auto enqueue = [&](int p0, int P, int mode, bool spec = false, bool skip_begin = false) -> int {
         if (spec) P = 0;
         const int fin_slot = P == 0 ? 0 : (P & 1);
-        static const int no_cm = getenv("SMCMI_NO_CORRECT_MOMENTS") ? atoi(getenv("SMCMI_NO_CORRECT_MOMENTS")) : 0;   // development only
         // no selection expected + register kernels: the correction pass gathers the moments too, so (ΣW̃, ΣW̃², pair sums) travel
         // in ONE all-reduce (3 collectives per stage instead of 4); k_prepare_mutation decides, the mutation kernel normalises
-        const bool cm = mode == 1 && can_fuse_cm(h0) && !no_cm;
+        const bool cm = mode == 1 && can_fuse_cm(h0);
         const int npf = h0->npairs + 2;
         for (auto *h : g.hs) { h->fused_cm = cm; h->spec_stage = spec && cm; }
         if (mode == 2) {
@@ -631,8 +630,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
     double pred_ess = cont ? h0->h_st.ess_prev : (rc->initial_ess > 0.0 ? rc->initial_ess : N_tot);
     int pred_rl = cont ? h0->h_st.resampled_last : 0, stall_stage = -1, stall_p = 0;
     int done = 0, iters = 0, stalls = 0, sel_stalls = 0, spec_stalls = 0;
-    static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
-    const bool spec_ok = predict_select && predict && can_fuse_cm(h0) && !no_spec && !getenv("SMCMI_NO_CORRECT_MOMENTS") &&
+    const bool spec_ok = predict_select && predict && can_fuse_cm(h0) &&
                          rc->tempered_update_prior_weight == 0.0 && !(rc->phi_rtol < 0.0);
     bool spec_on = spec_ok;                   // switched off after repeated verification failures (see smcmi_run)
     int last_spec_stall = -100, spec_strikes = 0, last_solver_stall = -100;

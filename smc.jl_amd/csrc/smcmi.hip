@@ -46,11 +46,9 @@ static int dmalloc(T **p, size_t count) {
     // development (SMCMI_POISON_ALLOC=1): fresh device memory reads as NaN / -1, so a read of something never written shows up
     // in every test instead of depending on what the allocator hands back
     static const int poison = getenv("SMCMI_POISON_ALLOC") ? atoi(getenv("SMCMI_POISON_ALLOC")) : 0;
-    static const int plo = getenv("SMCMI_POISON_LO") ? atoi(getenv("SMCMI_POISON_LO")) : 0;               // (bisection: only allocations lo <= # < hi)
-    static const int phi = getenv("SMCMI_POISON_HI") ? atoi(getenv("SMCMI_POISON_HI")) : 1 << 30;
     static int counter = 0;
     const int idx = counter++;
-    if (poison && idx >= plo && idx < phi) {
+    if (poison) {
         HIP_TRY(hipMemset(*p, 0xFF, (count ? count : 1) * sizeof(T)));
         HIP_TRY(hipDeviceSynchronize());        // (the fill runs on the null stream: it must not land after the handle's first copies)
         if (poison > 1) fprintf(stderr, "[smcmi] poisoned allocation #%d (%zu bytes)\n", idx, (count ? count : 1) * sizeof(T));
@@ -152,11 +150,8 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
         dmalloc(&h->rec.resampled, ms))
         return SMCMI_ERR_HIP;
     h->nb_e = (int)std::min<long long>(512, std::max<long long>(1, (n + 511) / 512));      // (512 rows, not 1024: less for the prepare launch to total - measured 2-4 % per run from 4e5 to 1e7 particles)
-    if (getenv("SMCMI_NB_E")) h->nb_e = std::max(1, std::min(1024, atoi(getenv("SMCMI_NB_E"))));   // development only
     h->nb_m = (int)std::min<long long>(256, std::max<long long>(1, (n + MT - 1) / MT));
     h->nb_mr = (int)std::min<long long>(512, std::max<long long>(std::min<long long>(64, (n + TB - 1) / TB), n / 1024));
-    if (getenv("SMCMI_NOOP_GRID")) h->noop_grid = std::max(1, atoi(getenv("SMCMI_NOOP_GRID")));   // development only
-    if (getenv("SMCMI_NB_MR")) h->nb_mr = std::max(1, atoi(getenv("SMCMI_NB_MR")));   // development only
     // mutation block size: largest of 256/128/64 threads whose per-thread LDS vectors fit 64 KiB
     for (int T : {256, 128, 64}) {
         h->mut_T = T;
@@ -751,11 +746,10 @@ static bool use_ls4_mutate(const smcmi_handle *h) {
     if (!(h->d == 13 && f0 == SMCMI_LIK_LGSS_KALMAN && (f1 == SMCMI_LIK_NONE || f1 == SMCMI_LIK_LGSS_KALMAN))) return false;
     return lanes == 4 || (lanes != 1 && h->n <= 32768);
 }
-// the same models on larger clouds: one thread per particle through kalman_lgss_wave (SMCMI_KALMAN_WAVE=0: kalman_lgss2, development)
+// the same models on larger clouds: one thread per particle through kalman_lgss_wave
 static bool use_wave_kalman(const smcmi_handle *h) {
-    static const int kwave = getenv("SMCMI_KALMAN_WAVE") ? atoi(getenv("SMCMI_KALMAN_WAVE")) : 1;
     const int f0 = h->h_model.lik[0].family, f1 = h->h_model.lik[1].family;
-    return kwave && !use_ls4_mutate(h) && h->d == 13 && f0 == SMCMI_LIK_LGSS_KALMAN && (f1 == SMCMI_LIK_NONE || f1 == SMCMI_LIK_LGSS_KALMAN);
+    return !use_ls4_mutate(h) && h->d == 13 && f0 == SMCMI_LIK_LGSS_KALMAN && (f1 == SMCMI_LIK_NONE || f1 == SMCMI_LIK_LGSS_KALMAN);
 }
 // blocks (= rows of acceptance / energy partials) of the in-run mutation kernel
 static int mut_blocks(const smcmi_handle *h) { return use_reg_mutate(h) ? h->nb_reg : (use_ls4_mutate(h) ? h->nb_mut_ls4 : h->nb_mut); }
@@ -766,8 +760,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     MutArgs ma{};
     ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
     static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
-    static const int kwave = getenv("SMCMI_KALMAN_WAVE") ? atoi(getenv("SMCMI_KALMAN_WAVE")) : 1;   // development only (kernels.hpp k_mutate)
-    ma.debug = dbg | (kwave ? 0 : 256);
+    ma.debug = dbg;
     ma.stage_consts = (h->d <= 13 && !(dbg & 512)) ? 1 : 0;
     ma.prof = h->d_prof;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
@@ -942,21 +935,21 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
     // spec: predict -> correct -> verify (kernels.hpp k_stage_begin): no certificate pass is enqueued at all - 4 launches
     const int P = (adaptive && !spec) ? p0 + solver_passes : 0;
     static const int no_pred = getenv("SMCMI_NO_PREDICTOR") ? atoi(getenv("SMCMI_NO_PREDICTOR")) : 0;   // development only
-    static const int no_eshift = getenv("SMCMI_NO_ESHIFT") ? atoi(getenv("SMCMI_NO_ESHIFT")) : 0;       // development only
     h->run_adaptive = adaptive;
     const int fin_slot = P == 0 ? 0 : (P & 1);
-    static const int no_cm = getenv("SMCMI_NO_CORRECT_MOMENTS") ? atoi(getenv("SMCMI_NO_CORRECT_MOMENTS")) : 0;   // development only
     // no selection expected and the register kernels apply: the correction pass gathers the moments too, k_prepare_mutation
     // takes the post-correction decision, the mutation kernel normalises the weights (5 launches per stage)
-    const bool cm = no_select && !tail_only && can_fuse_cm(h) && !no_cm;
+    const bool cm = no_select && !tail_only && can_fuse_cm(h);
     h->fused_cm = cm;
     h->spec_stage = spec && cm;
     if (!tail_only) {
     if (p0 == 0 && !skip_begin) {
-        // (host-callback mutation leaves neither energy sums nor energy maxima: plain schedule walk, unshifted weights)
-        const double *es = (adaptive && !no_pred && !host_mut) ? h->d_esum_part : nullptr;
+        // (a host-callback mutation without cb_energy - sharded closure runs, fixed schedules - leaves neither energy sums nor energy maxima:
+        // plain schedule walk, unshifted weights)
+        const bool hm_plain = host_mut && !h->cb_energy;
+        const double *es = (adaptive && !no_pred && !hm_plain) ? h->d_esum_part : nullptr;
         int es_nb = acc_nb, em_nb = acc_nb;
-        const double *em = host_mut ? nullptr : h->d_emax_part;
+        const double *em = hm_plain ? nullptr : h->d_emax_part;
         // tens of thousands of rows are not for one block: blocks 1..ESUM_RED_ROWS of the same launch total a chunk each (k_stage_begin)
         PrepRed rr{};
         unsigned grid = 1;
@@ -967,7 +960,7 @@ static void enqueue_stage(smcmi_handle *h, bool adaptive, int solver_passes, int
             es = h->d_esum_red; es_nb = ESUM_RED_ROWS;
         }
         k_stage_begin<<<grid, BT, 0, s>>>(h->d_st, h->d_sched, h->d_acc_part, es ? es_nb : acc_nb, h->rec, es, h->d_prof ? h->d_prof + 9 : nullptr,
-                                          h->spec_stage ? 1 : 0, no_eshift ? nullptr : em, em_nb, rr, h->note_on ? h->d_note : nullptr);
+                                          h->spec_stage ? 1 : 0, em, em_nb, rr, h->note_on ? h->d_note : nullptr);
     }
     if (adaptive && !h->spec_stage) enqueue_solver(h, P, p0);
     if (cm) launch_correct_moments(h, P);
@@ -1118,11 +1111,10 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     struct NoteGuard { smcmi_handle *h; ~NoteGuard() { h->note_on = false; } } note_guard{h};
     h->note_on = fixed_ns;
     if (fixed_ns) { h->h_note[0] = s.stage; h->h_note[1] = 0; }
-    static const int no_spec = getenv("SMCMI_NO_SPEC") ? atoi(getenv("SMCMI_NO_SPEC")) : 0;   // development only
     // (with a prior weight the correction's incremental weight differs from the solver's objective - quirk Q4 - so the ESS it
     // produces cannot verify a predicted root: those runs keep the certificate pass)
-    const bool spec_ok = predict_select && can_fuse_cm(h) && !no_spec && !getenv("SMCMI_NO_PREDICTOR") &&
-                         !getenv("SMCMI_NO_CORRECT_MOMENTS") && rc->tempered_update_prior_weight == 0.0 && rp.phi_rtol > 0.0;
+    const bool spec_ok = predict_select && can_fuse_cm(h) && !getenv("SMCMI_NO_PREDICTOR") &&
+                         rc->tempered_update_prior_weight == 0.0 && rp.phi_rtol > 0.0;
     hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // [0] full stage, [1] without selection kernels, [2] predict-correct-verify
     if (rc->use_graph == 1) {

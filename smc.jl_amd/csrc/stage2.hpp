@@ -61,8 +61,8 @@ struct Geo2 {
     int V, Vl, v0;                // virtual shards in total / held by this handle / global index of the first local one
     int nb1, nb2, nbg;            // blocks per virtual shard: correction (and scan chunks) / mutation / gather
     long long per1, perg;         // particles per correction / gather block
-    int t2;                       // threads (= particles) of a mutation block: 512 while the cloud is small (half as many rows for the
-                                  // next stage's begin to total, one block per CU), 256 beyond (3 wavefronts per SIMD)
+    int t2;                       // threads (= particles) of a mutation block: 512 (the register kernels: one block per CU with the prologue
+                                  // in every block, two per CU on large shards - stage2b.hpp); 256 / 64 the wide kernels
     int direct;                   // consumers total the per-block rows themselves (one handle, <= GRP rows per virtual shard)
     int inker;                    // every block runs the begin / decision / proposal logic in its prologue (<= one 512-thread block per CU):
                                   // direct, or several handles with small shards (the rows then are the all-gathered V x m totals)
@@ -859,7 +859,7 @@ __device__ inline void rng2_block(const Geo2 &g, const Rng2 &ra, int n, int bloc
                 for (int e = 0; e < D; ++e) zt[(long long)(2 + e) * g.n] = z[e];
             }
     };
-    if (g.t2 != 512) {        // large shards (256-particle mutation blocks): the local particles dealt out block-width by block-width
+    if (!g.inker) {           // large shards: the local particles dealt out block-width by block-width
         for (long long i = (long long)block * blockDim.x + threadIdx.x; i < g.n; i += (long long)nblocks * blockDim.x) particle(i);
         return;
     }

@@ -2,7 +2,8 @@
 //
 // What a rank of a 2- or 4-GPU run of config 3 holds (500 000 / 250 000 particles) ran through four launches per stage - k2_begin (one
 // block), K1, k2_prepare (one block), K2 = k2_mutate<D, a, 256, true> at 168 VGPRs, three wavefronts per SIMD: 977 blocks on 768 slots,
-// two rounds where engine 1's k_mutate_reg (127 VGPRs, 1 024 slots) needs one - 88 / 116 µs per stage against 131 µs for the WHOLE 10^6
+// two rounds where engine 1's k_mutate_reg (127 VGPRs, 1 024 slots) needs one, and the block that totalled a shard's 489 paired rows
+// took ~10 µs doing so at the end of every launch - 88 / 116 µs per stage against 131 µs for the WHOLE 10^6
 // cloud on one GPU.  Here the stage is two launches whose blocks never wait, with one helper block each that does:
 //
 //   K1  = k2_correct<D, true>: correction blocks (rows totalled per virtual shard by Tail2, posted into every handle's mailbox)
@@ -40,15 +41,14 @@ __device__ inline void k2b_begin_block(int n_next, DevState *st, Ctl2 *ctl, cons
     begin2_block<T, true>(n_next, st, ctl, bb.mrows, bb.spec_expected, bb.sched, bb.rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act, nullptr, false, 1);
 }
 
-#ifndef SMCMI_K2B_WAVES
-#define SMCMI_K2B_WAVES(A1) ((A1) ? 4 : 3)
-#endif
-// One 256-particle block of the mutation (src/mutation.jl:56-138, helpers.jl:87-164): the `ma.pre` path of k2_mutate and nothing else.
+constexpr int T2B = 512;          // threads = particles of a block: one canonical mutation row (block_reduce_es2<8>), two blocks per CU
+// One 512-particle block of the mutation (src/mutation.jl:56-138, helpers.jl:87-164): the `ma.pre` path of k2_mutate and nothing else -
+// 128 VGPRs (alpha = 1), i.e. 4 wavefronts per SIMD.
 template <int D, bool ALPHA1>
-__global__ void __launch_bounds__(256, SMCMI_K2B_WAVES(ALPHA1)) k2b_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma,
+__global__ void __launch_bounds__(T2B, ALPHA1 ? 2 : 1) k2b_mutate(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma,
                                                                    Beg2Args bb, int nb, int nf) {
 SMCMI_FP_CONTRACT
-    constexpr int T = 256;
+    constexpr int T = T2B;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, n = ma.n;
     if ((int)blockIdx.x >= g.Vl * g.nb2) {
@@ -72,6 +72,20 @@ SMCMI_FP_CONTRACT
     double *red = L.red, *l_dat = L.l_dat, *Lraw = L.Lraw, *logdet_s = L.logdet_s;
     double *mub_raw = L.mub_raw, *sdd_raw = L.sdd_raw, *sdn_raw = L.sdn_raw;
     int *bptr_s = L.bptr_s, *loff_s = L.loff_s, *ball_raw = L.ball_raw;
+    // ---- the particle (speculatively from buffer 0: only resample stages read the gathered cloud in buffer 1) is requested before anything
+    // is waited for: its columns and the stage's decision arrive under one round trip
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, T, beg, end);
+    const long long i = beg + tid;
+    const bool live = i < end;
+    const long long il = live ? i : (end > beg ? end - 1 : 0);           // unconditional loads (clamped row)
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    double like, lprior, like_prev, accept = 0.0;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = col(cl, 0, k)[il];
+    like = col(cl, 0, D)[il]; lprior = col(cl, 0, D + 1)[il]; like_prev = col(cl, 0, D + 2)[il];
+    const double wt_i = ma.wt[il];
     // ---- decision and proposal (k2_prepare / K1's helper block): model constants + the proposal's arrays into LDS, one barrier
     const Prop2Glob *G = ma.pre;
     const int pstage = G->stage, pgo = G->go;
@@ -88,20 +102,11 @@ SMCMI_FP_CONTRACT
     for (int b = tid; b <= nb; b += T) bptr_s[b] = G->bptr[b];
     if (pstage != n || !pgo) return;
     K2_STAMP(ma.prof, 1);
-    // ---- the particle (buffer 1 on resample stages: the gathered cloud), the likelihood data, the first proposal's drawn-ahead numbers
-    long long beg, end;
-    vchunk(g, blockIdx.x / g.nb2, blockIdx.x % g.nb2, T, beg, end);
-    const long long i = beg + tid;
-    const bool live = i < end;
-    const long long il = live ? i : (end > beg ? end - 1 : 0);           // unconditional loads (clamped row)
-    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
-    const int src = rs ? 1 : 0;
-    double like, lprior, like_prev, accept = 0.0;
-    double x[D];
+    if (rs) {                       // the resampled cloud is in buffer 1 (k2_gather)
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = col(cl, src, k)[il];
-    like = col(cl, src, D)[il]; lprior = col(cl, src, D + 1)[il]; like_prev = col(cl, src, D + 2)[il];
-    const double wt_i = ma.wt[il];
+        for (int k = 0; k < D; ++k) x[k] = col(cl, 1, k)[il];
+        like = col(cl, 1, D)[il]; lprior = col(cl, 1, D + 1)[il]; like_prev = col(cl, 1, D + 2)[il];
+    }
     double step_prob = 0.0, uc = 0.0, z[D];        // (every proposal's numbers are loaded or drawn inside the MH loop: nothing is carried into it)
 #pragma unroll
     for (int e = 0; e < D; ++e) z[e] = 0.0;
@@ -140,12 +145,12 @@ SMCMI_FP_CONTRACT
         acc_val = accept / (double)nf;                      // quirk Q2: normalised by n_free only
         col(cl, 0, D + 3)[i] = acc_val;
     }
-    // ---- this block's row for the next stage's begin; the last block of a virtual shard totals the shard's rows (pairs of raw rows:
-    // the canonical row stands for 512 particles) and posts them
+    // ---- this block's row for the next stage's begin; the last block of a virtual shard totals the shard's rows - all groups of 64 rows
+    // in ONE batch of loads (RMUT columns: seven groups fit the block) - and posts them
     k2_mut_row<T>(ma.rows_mut + (long long)blockIdx.x * RMUT, ma.adaptive != 0, like, like_prev, w_part, acc_val, e_center, live, rs != 0, l_dat, red,
                   ma.tail.tick != nullptr);
     K2_STAMP(ma.prof, 10);
-    tail_reduce<T>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, 1);
+    tail_reduce<T, RMUT>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, 0);
     K2_STAMP(ma.prof, 11);
     if (ma.prof != nullptr && tid == 0 && blockIdx.x < 4096) ma.prof[64 + 3 * blockIdx.x + 1] = wall_clock64();
 }

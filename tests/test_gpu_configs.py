@@ -78,6 +78,35 @@ def test_results_do_not_depend_on_the_shard_count(kw):
             assert out[w][key] == ref[key], (w, key, out[w], ref)
 
 
+@pytest.mark.parametrize("n,worlds,kw", [
+    (1_000_000, (1, 2, 4), dict(use_fixed_schedule=False, tempering_target=0.97)),
+    (400_000, (1, 2), dict(use_fixed_schedule=True, n_phi=40, n_mh_steps=2, n_blocks=2, alpha=0.9)),
+    (400_000, (1, 2), dict(use_fixed_schedule=False, tempering_target=0.9, resampling_method="multinomial")),
+])
+def test_large_shards_do_not_depend_on_the_shard_count(n, worlds, kw):
+    """Shards of more than 131 072 particles (what a rank of a 2- or 4-GPU run of config 3 holds: 500 000 / 250 000) run engine 2's
+    large-shard stage (csrc/stage2b.hpp: k2b_mutate at two 512-particle blocks per CU, rows totalled per virtual shard in the canonical
+    order).  One handle takes it with the self-addressed mailbox and the helper blocks (decision + proposal inside K1's launch, the next
+    stage's begin inside the mutation launch); the in-process groups hand their totals over with device copies and run k2_begin /
+    k2_prepare as launches - the bits must be the same on 1, 2 and 4 shards either way (src/smc_main.jl:472-476: the reference's
+    particle loop does not depend on the number of workers either)."""
+    d = 10
+    out = _invariance(n, d, 3, worlds, kw)
+    ref = out["1"]
+    assert ref["n_stages"] > 10 and ref["resamples"] >= 1
+    for w in worlds[1:]:
+        for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+            assert out[str(w)][key] == ref[key], (w, key, out[str(w)], ref)
+    # two in-process handles with the peer mailbox: helper blocks on both, each polling for the other's totals
+    out_mb = _invariance(n, d, 3, (2,), kw, extra_env={"SMCMI_MAILBOX": "1"})
+    for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+        assert out_mb["2"][key] == ref[key], ("mailbox", key, out_mb["2"], ref)
+    # ... and one handle with k2_begin / k2_prepare as launches (SMCMI_E2_HELPERS=0)
+    out_nh = _invariance(n, d, 3, (1,), kw, extra_env={"SMCMI_E2_HELPERS": "0"})
+    for key in ("n_stages", "resamples", "logmdd", "schedule", "ess", "accept", "cloud"):
+        assert out_nh["1"][key] == ref[key], ("no helpers", key, out_nh["1"], ref)
+
+
 @pytest.mark.parametrize("case", [
     dict(spec=("gauss_spec", [12]), n=24000, d=12, kw=dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=3, alpha=0.9), env={}),
     dict(spec=("gauss_spec", [16]), n=16384, d=16, kw=dict(use_fixed_schedule=True, n_phi=40, n_mh_steps=2, resampling_method="multinomial"), env={}),

@@ -42,6 +42,35 @@ def test_random_configurations_match_oracle():
     assert len(seen_d) >= 8
 
 
+@pytest.mark.parametrize("name,env,d_max", [
+    ("engine 1 (the stage of large single-handle clouds, n_para > 16 and host closures) on small clouds", {"SMCMI_ENGINE": "1"}, 13),
+    ("engine 2's large-shard stage (k2b_mutate, helper blocks, self-mailbox) on small clouds", {"SMCMI_ENGINE": "2", "SMCMI_E2_REDUCED": "1"}, 10),
+    ("engine 2's launches without segments", {"SMCMI_ENGINE3": "0"}, 10),
+])
+def test_random_configurations_match_oracle_on_every_stage_engine(name, env, d_max):
+    """The sweep above through the stage engines the defaults do not pick at these sizes (the switches are read once per process: a worker
+    process per engine) - every (engine x schedule x alpha x resampler) cell is checked against the ORACLE inside the suite, not only
+    against another engine (path x evidence matrix)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "sweep_worker.py"), "20260930", "16", str(d_max)], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=1200, cwd=root)
+    assert p.returncode == 0 and "DONE 16" in p.stdout, (name, p.stdout[-1500:], p.stderr[-1500:])
+    rows = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 16
+    seen = set()
+    for r in rows:
+        tag = "%s: %r" % (name, r)
+        assert r["stages"][0] == r["stages"][1] and r["resamples"][0] == r["resamples"][1], tag
+        assert r["logmdd_err"] <= 1e-8 and r["ess_relerr"] <= 1e-8 and r["phi_relerr"] <= 1e-9, tag
+        seen.add((r["kw"]["use_fixed_schedule"], r["kw"]["alpha"] == 1.0, r["kw"]["resampling_method"]))
+    assert len(seen) >= 6, seen                                 # the sweep visited most (schedule, alpha = 1?, resampler) cells
+
+
 @pytest.mark.parametrize("n", [33, 65, 1023, 100003])
 def test_ragged_cloud_sizes_match_oracle(n):
     """Cloud sizes that are no multiple of a wavefront, a block or a chunk (and one below a single wavefront): both schedules,
