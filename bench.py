@@ -340,7 +340,7 @@ def main():
         kname = ("k_mutate_reg<%d," % D) if D <= 10 else ("k2w_mutate<%d," % D)
         # (small clouds and sharded runs use engine 2's k2_mutate, a single handle with a larger cloud engine 1's k_mutate_reg;
         # n_para 11..16: k2w_mutate - engine 2's prologue in front of the generic mutation body - or, SMCMI_ENGINE_WIDE=0, engine 1's k_mutate)
-        kname_run = ("k2_mutate<%d,...> / k_mutate_reg<%d,...>" % (D, D)) if D <= 10 else ("k2w_mutate<%d,...>" % D)
+        kname_run = ("k2_mutate<%d,...> / k2b_mutate<%d,...> / k_mutate_reg<%d,...>" % (D, D, D)) if D <= 10 else ("k2w_mutate<%d,...>" % D)
         traffic, valu = None, None
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_n%d.json" % (args.workload, n_k))),
                            key=lambda f: int(re.search(r"r(\d+)", os.path.basename(f)).group(1)))
@@ -348,7 +348,7 @@ def main():
         if pmc_file:
             with open(pmc_file) as f:
                 pm = json.load(f)
-            k = [(name, v) for name, v in pm["kernels"].items() if kname in name or ("k2_mutate<%d," % D) in name]
+            k = [(name, v) for name, v in pm["kernels"].items() if kname in name or ("k2_mutate<%d," % D) in name or ("k2b_mutate<%d," % D) in name]
             if k:
                 k.sort(key=lambda nv: -nv[1].get("total_bytes", 0.0))
                 kname_run, traffic, valu = k[0][0].split("::")[-1], k[0][1].get("total_bytes"), k[0][1].get("valu")

@@ -30,6 +30,9 @@
 
 namespace smcmi {
 
+#ifndef SMCMI_K3_WAVES
+#define SMCMI_K3_WAVES 2          // (launch bound: wavefronts per SIMD the segment kernel is compiled for; 2 = one 512-thread block per CU)
+#endif
 constexpr int T3 = 512;                      // threads = particles of a block
 constexpr int TICK3_STRIDE = 32;             // ints between ticket counters: one 128-byte line each (the arrivals of different shards do not queue behind each other)
 constexpr int SEG3_TICKS = (V2_MAXV + 1) * TICK3_STRIDE;      // per kind: one ticket counter per local virtual shard + the top one
@@ -287,7 +290,7 @@ constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT
 // Every block - gatherers included - derives the stage's decisions itself from the V shard totals (decide2, post2, begin2_wave: same
 // inputs, same code, same result everywhere, as in engine 2's kernels), the workers also the proposal; worker 0 records them.
 template <int D, bool ALPHA1>
-__global__ void __launch_bounds__(T3, 2) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
+__global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ RecA3 s_a;

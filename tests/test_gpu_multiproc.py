@@ -102,6 +102,18 @@ def test_processes_sharing_one_gpu_reproduce_the_single_handle(world, tmp_path):
     _check(runs, cloud, want, want_cloud, expect_mailbox=True)
 
 
+def test_large_shards_across_processes(tmp_path):
+    """Two processes of 200 000 particles each - shards beyond one 512-particle block per CU run engine 2's large-shard stage
+    (csrc/stage2b.hpp): the helper block of every rank's K1 launch polls the IPC-mapped mailbox for BOTH ranks' correction totals, the helper
+    block of the mutation launch for both ranks' mutation totals; only those two blocks ever wait, so ranks that share the one GPU cannot
+    starve each other.  Same bits as one handle of 400 000."""
+    cfg = dict(n=400000, d=10, seed=5, kw=dict(use_fixed_schedule=False, tempering_target=0.95), reps=1)
+    want, want_cloud = _single(cfg)
+    assert want["resamples"] >= 2
+    runs, cloud = _spawn(2, cfg, tmp_path)
+    _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+
+
 def test_stalled_and_resumed_stages_across_processes(tmp_path):
     """SMCMI_NO_SELECT_PREDICT=2: every resample stage arrives without its selection kernels, stalls on all ranks and is resumed by the
     hosts (fresh mailbox tags after a barrier); plus a pause at a save point and a continuation.  Same bits as one handle."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round measurement pipeline (one MI355X): every file profiles/README.md lists, into gpurun_out/final/.
 # usage (GPU box): bash tools/measure_round.sh [rNN]
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -17,8 +17,12 @@ python bench.py --workload kalman --nparts 12500 --steps 3 --warmup 1 2>/dev/nul
 SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_engine1_stage.json
 python bench.py --workload kalman --nparts 25000 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n25000.json
 SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_engine1_stage.json
-gcc -O2 -std=c99 -ffp-contract=off -fopenmp -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
-LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
+gcc -O2 -std=c99 -ffp-contract=off -fopenmp -DCB_THREADS=8 -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
+OMP_WAIT_POLICY=ACTIVE OMP_PROC_BIND=close LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
+# where a stage of the closure path spends its time: the batch at once / in chunks, the example's callback on 1 / 8 threads
+bash tools/callback_phases.sh > $OUT/${R}_callback_phases.json 2>/dev/null
+# FP64 matrix pipe beside the vector pipe (config 5's question: tools/ubench/mfma_f64.hip)
+(cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -w -o mfma_f64 mfma_f64.hip > /dev/null 2>&1 && ./mfma_f64 > $OUT/${R}_mfma_f64.json 2>/dev/null)
 python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
 python bench.py --alpha 0.9 --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6_alpha09.json
 # one rank's share of config 3 on 8 GPUs (125 000 particles, every hand-over through the all-gather path of a 1-rank RCCL communicator)
@@ -27,6 +31,12 @@ HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_FORCE_SHARDED=1 python -m torch.distributed.r
 # the same rank with the peer mailbox forced on (system-scope hand-overs): its stages run inside sharded segments
 HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_FORCE_SHARDED=1 SMCMI_MAILBOX=2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 \
     bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu --no-history --nparts 125000 2>/dev/null | grep '^{' | tail -1 > $OUT/${R}_shard_rank_125k_segments.json
+# one rank's share of config 3 on 4 / 2 GPUs (250 000 / 500 000 particles: engine 2's large-shard stage, csrc/stage2b.hpp) with its kernel table
+bash tools/shard_rank_prof.sh final_shard 250000 500000 > $OUT/${R}_shard_rank_large.log 2>&1
+for n in 250000 500000; do
+    cp gpurun_out/final_shard/bench_n${n}_mb2.json $OUT/${R}_shard_rank_${n}.json
+    cp gpurun_out/final_shard/kernel_stats_n${n}.txt $OUT/${R}_kernel_stats_shard_rank_${n}.txt
+done
 cd /tmp && export TMPDIR=/tmp
 pmc() {   # pmc <tag> <n> <bench args...>: kernel table + the three counter passes of one configuration
     local tag=$1 n=$2; shift 2
@@ -44,7 +54,7 @@ kt() {    # kt <tag> <bench args...>: kernel table only
     python $ROOT/profiles/summarize_rocpd.py $(find $OUT/kt_$tag -name "*.db" | head -1) > $OUT/${R}_kernel_stats_${tag}.txt
     rm -rf $OUT/kt_$tag
 }
-kt capm --workload capm --steps 2 --warmup 1
+pmc capm_n200000 200000 --workload capm --steps 2 --warmup 1
 kt kalman --workload kalman --steps 2 --warmup 1
 kt kalman_n12500 --workload kalman --nparts 12500 --steps 2 --warmup 1
 kt gauss10_n1000000_alpha09 --alpha 0.9 --nparts 1000000 --no-history --steps 1 --warmup 1
