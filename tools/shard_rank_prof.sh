@@ -24,6 +24,8 @@ for N in ${@:-250000 500000}; do
   done
   (cd /tmp && export TMPDIR=/tmp && SMCMI_MAILBOX=2 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt_$N -o kt -- python $ROOT/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-history --nparts $N > /dev/null 2>&1)
   python profiles/summarize_rocpd.py $(find $OUT/kt_$N -name "*.db" | head -1) > $OUT/kernel_stats_n$N.txt
+  python profiles/gaps_rocpd.py $(find $OUT/kt_$N -name "*.db" | head -1) 200 > $OUT/kernel_gaps_n$N.txt
   rm -rf $OUT/kt_$N
   head -14 $OUT/kernel_stats_n$N.txt | cut -c1-60,75-140
+  cat $OUT/kernel_gaps_n$N.txt
 done
