@@ -52,9 +52,7 @@ SMCMI_FP_CONTRACT
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, n = ma.n;
     if ((int)blockIdx.x >= g.Vl * g.nb2) {
-#ifndef SMCMI_X_NOBEGIN
         if (bb.enable) k2b_begin_block<T>(n + 1, st, ctl, bb);
-#endif
         return;
     }
     const Mut2Lds<D> L(sm);

@@ -44,11 +44,17 @@ def connect(eng, rank, world, comm="rccl", group=None):
     return eng
 
 
-def run(eng, loglikelihood=None, old_loglikelihood=None, **kw):
+def run(eng, loglikelihood=None, old_loglikelihood=None, spec=None, **kw):
     """The sharded loop on rank's shard `eng`: smcmi_run_sharded (the product driver, communicator from connect()).  Host closures
     (`loglikelihood(theta (m, d)) -> (m,)`, the reference's user function: every worker scores the particles it holds) are registered
     on the handle first - open the shard with a model spec whose likelihood entry is ("host_callback", [], None, None); the driver then
-    runs propose -> closure -> accept per MH step and block on every shard, everything else as for device families."""
+    runs propose -> closure -> accept per MH step and block on every shard, everything else as for device families.  Closures passed here
+    are registered AFTER the shard was opened: a run whose initial draw (`init_from_prior`) must score the closure registers it on the handle
+    before that draw (`eng.set_likelihood_callback`) and calls run() without it.  `spec` (rounds 2-4 took the model here) is accepted and
+    ignored: the model is the one open_shard() was given."""
+    if spec is not None:
+        import warnings
+        warnings.warn("distributed.run(spec=...) is ignored: the model is set by open_shard()", DeprecationWarning, stacklevel=2)
     if loglikelihood is not None:
         eng.set_likelihood_callback(loglikelihood, which=0)
         if old_loglikelihood is not None:
