@@ -776,6 +776,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         sa.done_out = (h == h0 && seg_launches < SEG3_MAX_LAUNCHES) ? e->d_done3 + seg_launches : nullptr;
         sa.prof = (h == h0 && e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
         sa.prof_stage = e->prof_stage;
+        sa.gprof = sa.prof;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && sa.done_out) { hipEventCreate(&e0); hipEventCreate(&e1); evs3.push_back(e0); evs3.push_back(e1); hipEventRecord(e0, h->stream); }
         // (the stage counters of all launches of a run are cleared once, in front of its first segment: a fill per launch was 5 µs each)
@@ -865,6 +866,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // stages per host sync (a stalled stage wastes the rest of its batch: two idle launches per stage; with engine 3 a batch end also cuts
     // a segment in two - a write-back and a reload of the cloud - while an idle segment launch costs next to nothing: longer batches)
     const int sync_every = rc->sync_every > 0 ? rc->sync_every : (e3 ? 96 : 32);
+    // (default batches double while nothing stalls - a sync in the middle of a run idles the GPU for ~50 µs and cuts a segment in two - and
+    // fall back after a stall; the first batch stays short: only its sync tells how many stages are left)
+    int cur_sync = sync_every;
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
@@ -886,7 +890,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     bool finished = false;
     while (!finished) {
         const int room = max_iter - launched;
-        const int batch = adaptive ? std::min(std::min(sync_every, std::max(stages_left_est, 4)), room) : room;
+        const int batch = adaptive ? std::min(std::min(cur_sync, std::max(stages_left_est, 4)), room) : room;
+        bool stalled = false;
         int seg_a = -1, seg_b = -1;                      // pending segment of engine 3
         bool seg_enter = false, seg_sel = false;         // ... which enters at the mutation of its first stage (corrected / resampled by launches)
         auto flush_seg = [&]() -> int {
@@ -947,6 +952,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         while (c.status.code == 2 || c.status.code == 3 || c.status.code == 4 || c.status.code == 6) {
             const int sn = c.status.stage, code = c.status.code;
+            stalled = true;
             // mailbox: a resumed stage posts under fresh tags into tables a slower handle may still be polling for the stalled
             // stage's - every handle must have left the stalled batch first
             if (mbox) {
@@ -1013,6 +1019,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             stages_left_est = left < 1e6 ? (int)left + 1 : 1 << 30;
         }
         if (predict_select) { pred_ess = p.ess; pred_rl = p.do_resample; }
+        if (rc->sync_every <= 0) cur_sync = stalled ? sync_every : std::min(2 * cur_sync, 4 * sync_every);
     }
     if (h0->e2->d_prof) {
         long long pr[128];
@@ -1023,6 +1030,32 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                     h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
             fprintf(stderr, "[smcmi3]   decision + proposal: totals -> covariance, shuffle %lld | block matrices %lld | Cholesky + log det %lld | rest %lld\n",
                     pr[30] - pr[3], pr[31] - pr[30], pr[32] - pr[31], pr[4] - pr[32]);
+        }
+        if (seg_launches > 0) {
+            // the two hand-overs of that stage on the wall clock (10 ns ticks): when the workers' rows went out, what the gatherers did, when
+            // the workers had the totals
+            const int Wk = g0.Vl * g0.nb2;
+            std::vector<long long> ws(4 * (size_t)Wk);
+            HIP_TRY(hipMemcpy(ws.data(), h0->e2->d_prof + 128, sizeof(long long) * ws.size(), hipMemcpyDeviceToHost));
+            for (int kind = 0; kind < 2; ++kind) {
+                long long p_min = 0, p_max = 0, s_min = 0, s_max = 0;
+                for (int b = 0; b < Wk; ++b) {
+                    const long long pb = ws[4 * b + 2 * kind], sb = ws[4 * b + 2 * kind + 1];
+                    if (!b || pb < p_min) p_min = pb;
+                    if (!b || pb > p_max) p_max = pb;
+                    if (!b || sb < s_min) s_min = sb;
+                    if (!b || sb > s_max) s_max = sb;
+                }
+                fprintf(stderr, "[smcmi3] hand-over %d (%s rows): rows published over %.2f us (worker 0 at +%.2f); totals seen by the first worker +%.2f, the last +%.2f, worker 0 +%.2f after the first row\n",
+                        kind, kind ? "mutation" : "correction", (p_max - p_min) * 0.01, (ws[2 * kind] - p_min) * 0.01, (s_min - p_min) * 0.01, (s_max - p_min) * 0.01, (ws[2 * kind + 1] - p_min) * 0.01);
+                for (int v = 0; v < g0.Vl; ++v) {
+                    long long lastrow = 0;
+                    for (int b = v; b < Wk; b += g0.Vl) lastrow = std::max(lastrow, ws[4 * b + 2 * kind]);
+                    fprintf(stderr, "[smcmi3]   gatherer %d: its last row +%.2f | first words seen +%.2f | %lld sweep(s) done +%.2f | totals posted +%.2f (started waiting at +%.2f)\n", v, (lastrow - p_min) * 0.01,
+                            (pr[90 + 4 * v + 2 * kind] - p_min) * 0.01, pr[90 + 4 * v + 2 * kind + 1],
+                            (pr[40 + 6 * v + 3 * kind + 1] - p_min) * 0.01, (pr[40 + 6 * v + 3 * kind + 2] - p_min) * 0.01, (pr[40 + 6 * v + 3 * kind] - p_min) * 0.01);
+                }
+            }
         }
         if (!g0.direct && !g0.inker && !g0.wide) {
             // census of the large-shard mutation launch of the profiled stage (100 MHz wall clock, the CU every block sat on): how many blocks

@@ -373,6 +373,9 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
         if constexpr (COH) return load_pair_sc1(rsrc, (unsigned)(2 * pr) * 8u + (unsigned)row * brow);
         else return reinterpret_cast<const double2 *>(base0 + 2 * pr)[(long long)row * (m / 2)];
     };
+    // (round 5: staging the rows through LDS with the whole block's loads - what made engine 3's gatherers 2.5x faster, stage3.hpp
+    // gather_vshard - was measured here too: K2b's tail indifferent, K1's 1.5 / 4 µs SLOWER at 250 000 / 500 000 particles per handle: one
+    // 16-byte load per unit and row is already one round trip, and 35 KB more LDS per block are not free)
     const double run = reduce_vshard_f<NT, decltype(ldrow), MMAX>(ldrow, nr_raw, m, max_idx, pair);
     if ((int)threadIdx.x < m) row_store(out_v + threadIdx.x, run, COH);     // (COH: a block of the same launch may read the totals)
 }

@@ -121,30 +121,45 @@ __device__ inline void gran_poll(const unsigned long long *w, unsigned tag, unsi
     } while (true);
 }
 // Gatherer: totals of the nr rows (m doubles = 2 m words each, at tbl) of one virtual shard in the canonical order -> thread t < m
-// returns total t.  One lane per row waits for the row's first word, then the sweep loads everything with pipelined sc1 loads and checks
-// EVERY tag; a word that was not there yet repeats the sweep (rows arrive within a fraction of a µs of each other).  false: timed out.
-template <int NT>
-__device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *run_out) {
+// returns total t.  One lane per row waits for the row's first word; then the WHOLE block fetches the table - consecutive threads
+// consecutive granules, every load of a thread in flight at once - checks EVERY tag and leaves the doubles in LDS (`stage`, nr * m
+// doubles), where reduce_vshard_f does its additions in the canonical order.  (Until round 5 the reduction's own units loaded the rows:
+// 144 threads with 32 loads each, two thirds of them the clamped last row - 4.9 µs per sweep against ~1 here.)  A word that was not
+// there yet repeats the sweep (rows arrive within a fraction of a µs of each other).  false: timed out.
+// post(idx, total): called by the thread that ends up with total idx (two columns per thread).  nr <= GRP: ONE canonical group, i.e.
+// reduce_vshard_f's arithmetic (slices 2h, 2h+1 in ascending row order, the tree across the quad, 0 + group) without its hand-over of the
+// group totals through LDS and the two barriers around it.
+template <int NT, class POST>
+__device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, POST post,
+                                     double *stage, long long *pw = nullptr) {
     // (one lane per row waits for the row's first word before the sweep: sweeping as the probe - one round trip less on paper - was
     // measured 4 µs per stage SLOWER: the gatherers' repeated sweeps queue in front of the workers' row stores)
     if ((int)threadIdx.x < nr) gran_poll(tbl + (long long)threadIdx.x * m * 2, tag, to, s_to);
     __syncthreads();
     if (*s_to) return false;
-    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)nr * m * 16);
+    if (pw && threadIdx.x == 0) { pw[0] = wall_clock64(); pw[1] = 0; }
+    const int cnt = nr * m;                                     // granules (16 bytes: {low word | tag}, {high word | tag})
+    constexpr int U = 5;                                        // loads per thread: 31 rows x 72 columns fit NT = 512
+    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)cnt * 16);
     const long long t_begin = wall_clock64();
     for (;;) {
-        int bad = 0;
-        auto ldrow = [&](int row, int pr) {
-            const unsigned off = ((unsigned)row * (unsigned)m + 2u * (unsigned)pr) * 16u;
-            const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 16), b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u), 0, 16);
-            bad |= (a.y != tag) | (a.w != tag) | (b.y != tag) | (b.w != tag);
-            double2 x;
-            x.x = __hiloint2double((int)a.z, (int)a.x);
-            x.y = __hiloint2double((int)b.z, (int)b.x);
-            return x;
-        };
-        const double run = reduce_vshard_f<NT>(ldrow, nr, m, max_idx, 0);
-        if (!__syncthreads_or(bad)) { *run_out = run; return true; }
+        int bad = cnt > U * NT;                                 // (cannot happen: one block per CU bounds nr at 31)
+        if (pw && threadIdx.x == 0) pw[1] += 1;
+        u32x4_t gq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = u * NT + (int)threadIdx.x;
+            gq[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (e < cnt ? e : cnt - 1) * 16, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = u * NT + (int)threadIdx.x;
+            if (e < cnt) {
+                bad |= (gq[u].y != tag) | (gq[u].w != tag);
+                stage[e] = __hiloint2double((int)gq[u].z, (int)gq[u].x);
+            }
+        }
+        if (!__syncthreads_or(bad)) break;
         // a word was not there yet: sweep again, bounded like every other wait
         if (threadIdx.x == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
                                  __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -155,6 +170,34 @@ __device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int 
         if (*s_to) return false;
         __builtin_amdgcn_s_sleep(4);
     }
+    const int u = threadIdx.x;
+    if (u < (m / 2) * 4) {                                      // (whole quads)
+        const int h = u & 3, pr = u >> 2;
+        const bool mx0 = 2 * pr == max_idx, mx1 = 2 * pr + 1 == max_idx;
+        const double ninf = -__builtin_inf(), id0 = mx0 ? ninf : 0.0, id1 = mx1 ? ninf : 0.0;
+        double a0[2] = {id0, id0}, a1[2] = {id1, id1};
+#pragma unroll
+        for (int j = 0; j < GRP / 8; ++j) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * h + q + 8 * j;
+                const double2 x = reinterpret_cast<const double2 *>(stage + (r < nr ? r : nr - 1) * m)[pr];
+                const double x0 = r < nr ? x.x : id0, x1 = r < nr ? x.y : id1;
+                a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
+                a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
+            }
+        }
+        double p0 = mx0 ? fmax(a0[0], a0[1]) : a0[0] + a0[1], p1 = mx1 ? fmax(a1[0], a1[1]) : a1[0] + a1[1];
+        const double q0 = fetch_xor<1>(p0), q1 = fetch_xor<1>(p1);
+        p0 = mx0 ? fmax(p0, q0) : p0 + q0; p1 = mx1 ? fmax(p1, q1) : p1 + q1;
+        const double r0 = fetch_xor<2>(p0), r1 = fetch_xor<2>(p1);
+        p0 = mx0 ? fmax(p0, r0) : p0 + r0; p1 = mx1 ? fmax(p1, r1) : p1 + r1;
+        if (h == 0) {
+            post(2 * pr, mx0 ? fmax(ninf, p0) : 0.0 + p0);
+            post(2 * pr + 1, mx1 ? fmax(ninf, p1) : 0.0 + p1);
+        }
+    }
+    return true;
 }
 // Decider: totals over the nvs shard totals (granules at tbl[v * m * 2]) in the order of reduce_rows (0 + x_0 + x_1 + ...; maximum for
 // max_idx) -> tot[0, m).  All threads call; ends with a barrier.  false: timed out.
@@ -258,6 +301,7 @@ struct Seg3Args {
     long long hist_ld;
     int *done_out;                 // non-null: number of stages this launch completed (profiling)
     long long *prof;               // development only (SMCMI_PROF2=<stage>): stamps of that stage
+    long long *gprof;              // ... and every block's hand-over stamps (K3_WALL)
     int prof_stage;
 };
 constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; }
@@ -282,6 +326,13 @@ constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");       \
             (prof)[(slot)] = (long long)tt_;                                                                                   \
         }                                                                                                                     \
+    } while (0)
+
+// (development, SMCMI_PROF2: the hand-overs of the profiled stage on the 100 MHz wall clock, which all dies share - worker b's slots at
+// prof[128 + 4 b ..], gatherer v's at prof[40 + 6 v ..]; run2_impl prints the spread)
+#define K3_WALL(prof, idx)                                                                                                    \
+    do {                                                                                                                      \
+        if ((prof) != nullptr && threadIdx.x == 0 && n == sa.prof_stage) (prof)[(idx)] = wall_clock64();                       \
     } while (0)
 
 // grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard).
@@ -380,13 +431,18 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     if (!worker) {
         // ================================================================ GATHERER of local virtual shard vg
         const int vg = (int)blockIdx.x - W;
+        static_assert((D + 2) * T3 >= 31 * (MCM > RMUT ? MCM : RMUT), "the gatherer stages a shard's rows in the workers' parking area");
+        double *g_stage = sm + k3_park_offset(D);                // (the workers' parking area for drawn-ahead numbers: (D + 2) * T3 doubles >= 31 rows x 72)
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
-            double run;
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
             if (!entered) {
-                if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to, &run)) break;
-                if (tid < MCM) post_total(sa.gt_cm, sa.off_cm, ((long long)(g.v0 + vg) * MCM + tid) * 2, run, tag);
+                K3_WALL(sa.gprof, 40 + 6 * vg + 0);
+                if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to,
+                                       [&](int idx, double val) { post_total(sa.gt_cm, sa.off_cm, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tag); }, g_stage,
+                                       (sa.gprof && n == sa.prof_stage) ? sa.gprof + 90 + 4 * vg : nullptr)) break;
+                K3_WALL(sa.gprof, 40 + 6 * vg + 1);
+                K3_WALL(sa.gprof, 40 + 6 * vg + 2);
                 // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
                 if (!gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, sys)) break;
             }
@@ -394,8 +450,12 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             if (!entered) { double e2; if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &e2) != 0) break; }
             if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, entered ? rs0 : 0, &s_b[n & 1].po);
             __syncthreads();
-            if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to, &run)) break;
-            if (tid < RMUT) post_total(sa.gt_mut, sa.off_mut, ((long long)(g.v0 + vg) * RMUT + tid) * 2, run, tag);
+            K3_WALL(sa.gprof, 40 + 6 * vg + 3);
+            if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to,
+                                   [&](int idx, double val) { post_total(sa.gt_mut, sa.off_mut, ((long long)(g.v0 + vg) * RMUT + idx) * 2, val, tag); }, g_stage,
+                                   (sa.gprof && n == sa.prof_stage) ? sa.gprof + 90 + 4 * vg + 2 : nullptr)) break;
+            K3_WALL(sa.gprof, 40 + 6 * vg + 4);
+            K3_WALL(sa.gprof, 40 + 6 * vg + 5);
             if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys)) break;
             if (next_begin(s_b[n & 1].po) != 0) break;
         }
@@ -489,9 +549,11 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         }
         const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
         K3_STAMP(sa.prof, 2);
+        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
         if (!entered && !gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, sys)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
+        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
         const int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
         if (dec != 0) {                                         // leave: nothing of the stage is committed, registers hold the cloud after stage n - 1
@@ -553,11 +615,13 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         }
         ++done;
         K3_STAMP(sa.prof, 6);
+        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 2);
         if (n < sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
         // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
         if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 8);
+        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
         const int act = next_begin(B.po);
         constexpr int NWB = sizeof(Begin2) / sizeof(double);
         if (act == 0 && writer && tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
