@@ -200,48 +200,62 @@ __device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int 
     return true;
 }
 // Decider: totals over the nvs shard totals (granules at tbl[v * m * 2]) in the order of reduce_rows (0 + x_0 + x_1 + ...; maximum for
-// max_idx) -> tot[0, m).  All threads call; ends with a barrier.  false: timed out.
+// max_idx) -> tot[0, m).  All threads call (a block of at least nvs wavefronts); ends with a barrier.  false: timed out.
+// Wavefront v takes shard v: its first lane waits for the shard's first word, the wavefront then fetches the shard's m granules (checking
+// EVERY tag; a word not there yet repeats the fetch) into vt[v * m ..] - a shard that is early is in LDS before the last one arrives, and
+// no block barrier stands between the wait and the fetch; after the one barrier thread k adds column k over the shards in ascending order.
 // sys: the table is this handle's copy in fine-grained memory, posted into by the gatherers of every handle (system-scope loads);
-// vt_out (one block): the per-shard values as plain doubles [nvs][m] for the launch behind the segment
+// vt: LDS, V2_MAXV * m doubles; vt_out (one block): the per-shard values as plain doubles [nvs][m] for the launch behind the segment
 __device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *tot,
-                                     bool sys = false, double *vt_out = nullptr) {
-    if ((int)threadIdx.x < nvs) gran_poll(tbl + (long long)threadIdx.x * m * 2, tag, to, s_to, sys);
+                                     double *vt, bool sys = false, double *vt_out = nullptr) {
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    if (w < nvs) {                                                          // (wave-uniform)
+        const unsigned long long *row = tbl + (long long)w * m * 2;
+        if (lane == 0) gran_poll(row, tag, to, s_to, sys);
+        const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(row), (long long)m * 16);
+        const long long t_begin = wall_clock64();
+        for (;;) {
+            int bad = 0;
+            u32x4_t xs[2];                                                  // m <= 128
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = lane + 64 * q, off = (k < m ? k : m - 1) * 16;
+                xs[q] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, /*sc0 sc1: system scope*/ 17) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = lane + 64 * q;
+                if (k < m) {
+                    bad |= (xs[q].y != tag) | (xs[q].w != tag);
+                    vt[w * m + k] = __hiloint2double((int)xs[q].z, (int)xs[q].x);
+                }
+            }
+            if (!__any(bad)) break;
+            // a word was not there yet: fetch again, bounded like every other wait (another wavefront's time-out ends this one too)
+            if (*(volatile int *)s_to) break;
+            if (lane == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                              __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_to = 1;
+            }
+            if (*(volatile int *)s_to) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
     __syncthreads();
     if (*s_to) return false;
-    const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)V2_MAXV * m * 16);
-    const long long t_begin = wall_clock64();
-    for (;;) {
-        int bad = 0;
-        for (int k = threadIdx.x; k < m; k += blockDim.x) {
-            const bool mx = k == max_idx;
-            u32x4_t xs[V2_MAXV];
-#pragma unroll
-            for (int v = 0; v < V2_MAXV; ++v) {                   // every load in flight before the first use (unconditional, clamped)
-                const int off = (int)(((unsigned)(v < nvs ? v : nvs - 1) * (unsigned)m + (unsigned)k) * 16u);
-                xs[v] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, /*sc0 sc1: system scope*/ 17) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-            }
-            double t = mx ? -__builtin_inf() : 0.0;
-#pragma unroll
-            for (int v = 0; v < V2_MAXV; ++v)
-                if (v < nvs) {
-                    bad |= (xs[v].y != tag) | (xs[v].w != tag);
-                    const double x = __hiloint2double((int)xs[v].z, (int)xs[v].x);
-                    t = mx ? fmax(t, x) : t + x;
-                    if (vt_out) vt_out[v * m + k] = x;
-                }
-            tot[k] = t;
+    for (int k = threadIdx.x; k < m; k += blockDim.x) {
+        const bool mx = k == max_idx;
+        double t = mx ? -__builtin_inf() : 0.0;
+        for (int v = 0; v < nvs; ++v) {
+            const double x = vt[v * m + k];
+            t = mx ? fmax(t, x) : t + x;
+            if (vt_out) vt_out[v * m + k] = x;
         }
-        if (!__syncthreads_or(bad)) return true;
-        // a word was not there yet: sweep again, bounded like every other wait
-        if (threadIdx.x == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                                 __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_to = 1;
-        }
-        __syncthreads();
-        if (*s_to) return false;
-        __builtin_amdgcn_s_sleep(4);
+        tot[k] = t;
     }
+    __syncthreads();
+    return true;
 }
 
 // Residency self-test of a handle's segment geometry (first use): `grid` blocks of T3 threads with enough LDS that a CU holds ONE of
@@ -444,7 +458,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                 K3_WALL(sa.gprof, 40 + 6 * vg + 1);
                 K3_WALL(sa.gprof, 40 + 6 * vg + 2);
                 // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
-                if (!gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, sys)) break;
+                if (!gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
             }
             const double ess = s_tot[0] * s_tot[0] / s_tot[1];
             if (!entered) { double e2; if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &e2) != 0) break; }
@@ -456,7 +470,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                                    (sa.gprof && n == sa.prof_stage) ? sa.gprof + 90 + 4 * vg + 2 : nullptr)) break;
             K3_WALL(sa.gprof, 40 + 6 * vg + 4);
             K3_WALL(sa.gprof, 40 + 6 * vg + 5);
-            if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys)) break;
+            if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
             if (next_begin(s_b[n & 1].po) != 0) break;
         }
         return;
@@ -551,7 +565,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 2);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-        if (!entered && !gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, sys)) { timed_out = true; break; }
+        if (!entered && !gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
@@ -619,7 +633,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (n < sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
         // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-        if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
+        if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 8);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
         const int act = next_begin(B.po);
