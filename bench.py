@@ -380,8 +380,9 @@ def main():
                                "bytes_per_launch": stage_b * seg_st / seg_n, "mean_launch_us": 1e3 * seg_ms / seg_n, "launches": seg_n,
                                "stages_per_launch": seg_st / seg_n, "bytes_per_stage": stage_b, "mean_stage_us": 1e3 * seg_ms / seg_st,
                                "note": "latency-bound at this N: two chip-wide hand-overs per stage (two store->load hops each) + the serial "
-                                       "decision / proposal / Newton work of one block; stages outside segments (resample / certificate "
-                                       "stages: %d of %d) run as engine 2's launches" % (last["n_stages"] - 1 - seg_st, last["n_stages"] - 1),
+                                       "decision / proposal / Newton work of one block; the correction and selection of resample / certificate "
+                                       "stages run as engine 2's launches in front of the segment that enters at their mutation "
+                                       "(%d segment launches for %d stages)" % (seg_n, last["n_stages"] - 1),
                                "valu": pmc3, "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
                                "mutation_kernel_outside_segments": {"kernel": kname_run, "mean_launch_us": 1e3 * mean_ms, "launches": nl}}
         if args.workload == "kalman" and mean_ms > 0:

@@ -75,11 +75,37 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     *out = g;
     return true;
 }
+// One handle whose particle count has no divisor among 8 / 4 / 2 that leaves it the direct geometry (100 001 particles: one virtual
+// shard of 196 rows - engine 1's stage at twice the time): virtual shards of ceil(n / V) particles, the last one shorter (vchunk and
+// k2_scan clamp at n; a block beyond the end holds no particle and publishes zero rows).  Only where no sharded run of the same
+// cloud shares the canonical order anyway (such a cloud runs on engine 1 today, which has another order).
+static bool make_geo2_uneven(const smcmi_handle *h, Geo2 *out) {
+    if (h->d > 10 || getenv("SMCMI_E2_REDUCED")) return false;
+    for (int V : {8, 4, 2}) {
+        Geo2 g{};
+        g.N = h->cfg.n_parts; g.n = h->n;
+        if (g.n != g.N) return false;
+        g.V = V; g.Vl = V; g.v0 = 0; g.nv = (g.n + V - 1) / V;
+        if ((long long)(V - 1) * g.nv >= g.n) continue;                              // (no empty virtual shard)
+        g.wide = 0; g.t2 = 512;
+        g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
+        if (!(g.nb2 <= GRP && (long long)g.nb2 * V <= 256)) continue;
+        g.direct = 1; g.inker = 1;
+        g.nb1 = g.nb2;
+        g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;
+        g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, 32));
+        g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
+        *out = g;
+        return true;
+    }
+    return false;
+}
 
 static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     Geo2 g;
     if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
-    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.nb2 == g.nb2 && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1 && h->e2->g.wide == g.wide) return 0;
+    if (single && world == 1 && !g.wide && !g.direct) { Geo2 gu; if (make_geo2_uneven(h, &gu)) g = gu; }
+    if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.nb2 == g.nb2 && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1 && h->e2->g.wide == g.wide && h->e2->g.V == g.V && h->e2->g.nv == g.nv) return 0;
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     Eng2 *e = new Eng2();
     e->g = g; e->world = world;
@@ -125,6 +151,7 @@ static bool eng2_eligible(const smcmi_handle *h, int world) {
     if (eng == 1 || h->d > 16) return false;
     Geo2 g;
     if (!make_geo2(h, world, 0, world == 1, &g)) return false;
+    if (world == 1 && !g.wide && !g.direct) { Geo2 gu; if (make_geo2_uneven(h, &gu)) g = gu; }
     if (g.wide) {                     // n_para 11 .. 16: the same two-launch stage around the generic mutation body (SMCMI_ENGINE_WIDE=0: engine 1's stage)
         static const int wide_on = getenv("SMCMI_ENGINE_WIDE") ? atoi(getenv("SMCMI_ENGINE_WIDE")) : 1;
         return wide_on != 0;

@@ -465,7 +465,8 @@ __device__ inline double block_reduce_es2(double (&a)[ES], double *red) {
 
 // particle range of block r of local virtual shard vl (per = particles per block)
 __device__ inline void vchunk(const Geo2 &g, int vl, int r, long long per, long long &beg, long long &end) {
-    const long long v_beg = (long long)vl * g.nv, v_end = v_beg + g.nv;
+    // (one handle with virtual shards of ceil(n / V) particles - run2.hpp make_geo2_uneven: the last shard ends at n)
+    const long long v_beg0 = (long long)vl * g.nv, v_beg = v_beg0 < g.n ? v_beg0 : g.n, v_end = v_beg + g.nv < g.n ? v_beg + g.nv : g.n;
     beg = v_beg + (long long)r * per;
     end = beg + per < v_end ? beg + per : v_end;
     if (beg > v_end) beg = v_end;
@@ -1147,7 +1148,7 @@ static __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *
     wt_full -= i_off; cum -= i_off;
     for (int c = c_begin + (int)blockIdx.x; c < (c_end < 0 ? nchunks : c_end); c += gridDim.x) {
         const int v = c / g.nb1, r = c % g.nb1;
-        const long long v_beg = (long long)v * g.nv, v_end = v_beg + g.nv;
+        const long long v_beg0 = (long long)v * g.nv, v_beg = v_beg0 < g.N ? v_beg0 : g.N, v_end = v_beg + g.nv < g.N ? v_beg + g.nv : g.N;
         long long beg = v_beg + (long long)r * g.per1, end = beg + g.per1 < v_end ? beg + g.per1 : v_end;
         if (beg > v_end) beg = v_end;
         constexpr int IPT = 4;

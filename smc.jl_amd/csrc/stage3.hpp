@@ -139,24 +139,26 @@ __device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int 
     if (*s_to) return false;
     if (pw && threadIdx.x == 0) { pw[0] = wall_clock64(); pw[1] = 0; }
     const int cnt = nr * m;                                     // granules (16 bytes: {low word | tag}, {high word | tag})
-    constexpr int U = 5;                                        // loads per thread: 31 rows x 72 columns fit NT = 512
+    constexpr int U = 5;                                        // loads per thread and batch: the 31 rows x 72 columns of an 8-shard cloud are ONE batch
     const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(tbl), (long long)cnt * 16);
     const long long t_begin = wall_clock64();
     for (;;) {
-        int bad = cnt > U * NT;                                 // (cannot happen: one block per CU bounds nr at 31)
+        int bad = 0;
         if (pw && threadIdx.x == 0) pw[1] += 1;
-        u32x4_t gq[U];
+        for (int b0 = 0; b0 < cnt; b0 += U * NT) {              // (block-uniform; a second batch only with fewer, longer virtual shards: <= 64 rows)
+            u32x4_t gq[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = u * NT + (int)threadIdx.x;
-            gq[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (e < cnt ? e : cnt - 1) * 16, 0, 16);
-        }
+            for (int u = 0; u < U; ++u) {
+                const int e = b0 + u * NT + (int)threadIdx.x;
+                gq[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (e < cnt ? e : cnt - 1) * 16, 0, 16);
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = u * NT + (int)threadIdx.x;
-            if (e < cnt) {
-                bad |= (gq[u].y != tag) | (gq[u].w != tag);
-                stage[e] = __hiloint2double((int)gq[u].z, (int)gq[u].x);
+            for (int u = 0; u < U; ++u) {
+                const int e = b0 + u * NT + (int)threadIdx.x;
+                if (e < cnt) {
+                    bad |= (gq[u].y != tag) | (gq[u].w != tag);
+                    stage[e] = __hiloint2double((int)gq[u].z, (int)gq[u].x);
+                }
             }
         }
         if (!__syncthreads_or(bad)) break;
@@ -445,8 +447,8 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     if (!worker) {
         // ================================================================ GATHERER of local virtual shard vg
         const int vg = (int)blockIdx.x - W;
-        static_assert((D + 2) * T3 >= 31 * (MCM > RMUT ? MCM : RMUT), "the gatherer stages a shard's rows in the workers' parking area");
-        double *g_stage = sm + k3_park_offset(D);                // (the workers' parking area for drawn-ahead numbers: (D + 2) * T3 doubles >= 31 rows x 72)
+        static_assert(k3_lds_bytes(D) / sizeof(double) >= (size_t)GRP * (MCM > RMUT ? MCM : RMUT), "the gatherer stages a shard's rows (<= GRP of them) in the dynamic LDS");
+        double *g_stage = sm;                                    // (a gatherer uses none of the workers' dynamic LDS: model constants, proposal, parked draws)
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)

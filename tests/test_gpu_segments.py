@@ -82,7 +82,10 @@ _KEYS = ("n_stages", "resamples", "logmdd", "c", "accept", "schedule", "ess", "c
          kw=dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=3, alpha=0.9)),                                  # a tempered update: an old-data likelihood beside the new one
     dict(n=16_000, d=9, seed=8, spec="linmodel_spec", spec_args=[100, 60], old_run=dict(spec_args=[60], kw=dict(n_phi=100, lam=2.0, alpha=0.9)),
          kw=dict(use_fixed_schedule=True, n_phi=60, lam=2.0, alpha=0.9, prior_weight=0.5, log_prob_old_data=-300.0)),        # mixed prior weight in the correction
-], ids=["config2", "mix2blocks2steps", "fixed_multinomial", "regression_pause", "n122880", "capm3steps", "two_likelihoods", "prior_weight"])
+    dict(n=50_002, d=10, seed=5, kw=dict(use_fixed_schedule=False, tempering_target=0.95), history=False),                 # two virtual shards of 49 rows: a gatherer's sweep in two batches
+    dict(n=100_001, d=10, seed=7, kw=dict(use_fixed_schedule=False, tempering_target=0.95), history=False),                # no divisor among 8 / 4 / 2: virtual shards of ceil(n / 8), the last one shorter
+], ids=["config2", "mix2blocks2steps", "fixed_multinomial", "regression_pause", "n122880", "capm3steps", "two_likelihoods", "prior_weight", "two_long_shards",
+        "uneven_shards"])
 def test_segments_leave_the_bits_of_the_launches(cfg):
     seg = _run(cfg)
     ref = _run(cfg, {"SMCMI_ENGINE3": "0"})
