@@ -39,6 +39,9 @@ struct Eng2 {
     unsigned long long *d_rec3 = nullptr, *d_to3 = nullptr, *d_gran3 = nullptr;    // (d_gran3: rows and shard totals as granules)
     int *d_done3 = nullptr;
     unsigned seg_seq = 0;
+    // a segment's exit note in host-mapped memory (one handle): [0] = the launch sequence number of the segment that has left, behind it a copy of
+    // Ctl2 - the host learns of a batch's end (or of a stage that must resample) without a device-to-host copy and a stream sync
+    void *h_note3 = nullptr, *d_note3 = nullptr;
     int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle
     int seg_attr_set = 0;         /* bit 0: α = 1 variant, bit 1: mixture variant */       // k3_segment's dynamic-LDS opt-in done on this handle's device
     bool wide_attr_set = false;      // k2w_mutate's dynamic-LDS opt-in done on this handle's device

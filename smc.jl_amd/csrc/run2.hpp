@@ -9,6 +9,8 @@
 // device copies inside a process); every handle then totals the same V rows in the same order, so all take the same decisions
 // and the results do not depend on the number of handles.
 #pragma once
+#include <atomic>
+#include <cstring>
 #include <map>
 
 
@@ -20,6 +22,7 @@ static void free_eng2(Eng2 *e) {
                     e->vt_gm, e->vt_pass, e->d_ranges, e->d_ranges_all, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (e->h_note3) hipHostFree(e->h_note3);
     delete e;
 }
 
@@ -124,6 +127,14 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
             dmalloc(&e->d_gran3, gw)) {
             free_eng2(e);
             return SMCMI_ERR_HIP;
+        }
+        // (the exit note of a segment: host-mapped; without it the host copies Ctl2 and syncs as for every other launch)
+        if (hipHostMalloc(&e->h_note3, 64 + sizeof(Ctl2), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&e->d_note3, e->h_note3, 0) == hipSuccess) {
+            memset(e->h_note3, 0, 64 + sizeof(Ctl2));
+        } else {
+            if (e->h_note3) hipHostFree(e->h_note3);
+            e->h_note3 = e->d_note3 = nullptr;
+            (void)hipGetLastError();
         }
         HIP_TRY(hipMemsetAsync(e->d_tick3, 0, 2 * SEG3_TICKS * sizeof(int), h->stream));
         HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
@@ -583,6 +594,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     }
     std::vector<hipEvent_t> evs3;
     int seg_launches = 0;
+    static const int note3_on = getenv("SMCMI_SEG_NOTE") ? atoi(getenv("SMCMI_SEG_NOTE")) : 1;      // development: 0 = every batch ends with a copy and a sync
+    int last_note_seq = -1;      // sequence number of the latest segment launch that leaves a note; -1: the stream's last launch is not such a segment
     struct SegRange { int a, b; bool enter; };
     std::vector<SegRange> seg_ranges;              // stages each segment launch was enqueued for (error diagnosis)
     if (e3) {
@@ -615,6 +628,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // ---- pieces of a stage
     // helper: the launch's extra block takes the hand-over of its own rows and leaves decision + proposal in Prop2Glob (large shards, no selection)
     auto enq_K1 = [&](int n, int begin_done, int spec_expected, bool helper = false) -> int {
+        last_note_seq = -1;
         std::vector<Rows2> mrs;
         for (auto *h : g.hs) mrs.push_back(mut_rows(h));                 // (the mutation rows this launch consumes)
         if (mbox) { mb_cnt[0] = ++mb_next[0]; mb_live[0] = true; mb_cm_at[n] = mb_cnt[0]; }   // its own rows go out under a fresh correction tag
@@ -637,6 +651,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return publish(&Eng2::rows_cm, &Eng2::vt_cm, g0.nb1, npf, -1, 0, true);
     };
     auto enq_select = [&](int n) -> int {
+        last_note_seq = -1;
         if (!multi) {
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
@@ -715,6 +730,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     };
     // next_begin: -1 none; 0 / 1: the launch's helper block runs stage n + 1's begin with that spec_expected (large shards with the mailbox)
     auto enq_K2 = [&](int n, int sel_enqueued, int next_begin = -1) -> int {
+        last_note_seq = -1;
         std::vector<Rows2> crs;
         for (auto *h : g.hs) crs.push_back(cm_rows(h));                  // (the correction rows this launch consumes)
         if (mbox) { mb_cnt[1] = ++mb_next[1]; mb_live[1] = true; mb_mut_at[n] = mb_cnt[1]; }
@@ -799,6 +815,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             sa.vt_mut_out = e->vt_mut;
         }
         sa.rec = e->d_rec3;
+        sa.note = (!seg_sys && g.hs.size() == 1 && note3_on) ? (int *)e->d_note3 : nullptr; sa.note_seq = (int)e->seg_seq;
+        if (sa.note) { last_note_seq = (int)e->seg_seq; }
         sa.tag_base = e->seg_seq << 16; sa.to = e->d_to3; sa.hist_w = h->d_hist_w; sa.hist_ld = h->n;
         sa.done_out = (h == h0 && seg_launches < SEG3_MAX_LAUNCHES) ? e->d_done3 + seg_launches : nullptr;
         sa.prof = (h == h0 && e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
@@ -820,6 +838,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     };
     auto enq_passes = [&](int n, int p0, int P) -> int {           // passes p0 .. P-1, then the closing decision
         for (int p = p0; p < P; ++p) {
+        last_note_seq = -1;
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 Eng2 *e = h->e2;
@@ -837,6 +856,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         return 0;
     };
     auto enq_begin = [&](int n, int spec_expected = 0) -> int {
+        last_note_seq = -1;
         if (begun_stage == n && begun_spec == spec_expected) return 0;      // (the helper block of the mutation launch in front ran it)
         begun_stage = -1;
         for (auto *h : g.hs) {
@@ -874,6 +894,23 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     };
     auto read_ctl = [&](Ctl2 *c) -> int {
         HIP_TRY(hipSetDevice(h0->cfg.device));
+        if (last_note_seq >= 0 && h0->e2->h_note3) {
+            // the batch ends with a segment: its block 0 leaves Ctl2 and its sequence number in host-mapped memory when it is done with them
+            // (stage3.hpp k3_leave_note) - no copy, no wait for the stream to drain; a stream that drains without the note (a launch that
+            // was rejected) falls through to the copy
+            volatile int *note = (volatile int *)h0->e2->h_note3;
+            const int want = last_note_seq;
+            last_note_seq = -1;
+            for (;;) {
+                if (note[0] == want) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    memcpy(c, (const char *)h0->e2->h_note3 + 64, sizeof(Ctl2));
+                    return 0;
+                }
+                if (hipStreamQuery(h0->stream) != hipErrorNotReady) break;
+            }
+            (void)hipGetLastError();
+        }
         HIP_TRY(hipMemcpyAsync(c, h0->e2->d_ctl, sizeof(Ctl2), hipMemcpyDeviceToHost, h0->stream));
         HIP_TRY(hipStreamSynchronize(h0->stream));
         if (g.hs.size() > 1)                                          // in-process groups: the other streams are done when the collectives' syncs are
@@ -896,6 +933,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (default batches double while nothing stalls - a sync in the middle of a run idles the GPU for ~50 µs and cuts a segment in two - and
     // fall back after a stall; the first batch stays short: only its sync tells how many stages are left)
     int cur_sync = sync_every;
+    int force_sel = -1;          // the stage a segment left because it must resample: enqueued with its selection in front of the next segment
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
@@ -943,7 +981,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             const bool cert = adaptive && (!spec_on || launched < 2);
             // engine 3 takes every stage that is expected to need neither (fixed schedules: nobody can tell which stage resamples -
             // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches) ...
-            if (e3 && !cert && (!sel || !adaptive)) {
+            if (n == force_sel) { sel = true; if (predict_select) pred_rl = 1; }        // (a segment left at this stage: it must resample)
+            if (e3 && !cert && (!sel || !adaptive) && n != force_sel) {
                 if (seg_a < 0) { seg_a = n; seg_enter = false; seg_sel = false; }
                 seg_b = n;
                 ++launched;
@@ -993,9 +1032,18 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             for (int &s : ev_stage) if (s >= sn) s = -1;           // the stalled stage's mutation launch and everything behind it were no-ops
             prepared_stage = begun_stage = -1;                     // (nothing a helper block was enqueued for stands: the resumed stage runs on launches)
             if (int e = clear_status()) return e;
-            if (code == 6) {
-                // a segment of engine 3 left at this stage (it must resample): nothing of the stage is committed; the full path runs it
-                // (on the predicted ϕ_n where predictions are in use - what the launches do when a stage resamples unexpectedly: same bits)
+            if (code == 6 && e3 && !(adaptive && !spec_on)) {
+                // a segment of engine 3 left at this stage (it must resample): nothing of the stage is committed.  The next batch starts
+                // with it - correction and selection as launches, then a segment that enters at its mutation and goes on - instead of the
+                // whole stage as launches behind a second host sync (fixed schedules, whose resample stages nobody can foresee, pay this at
+                // every one of them: 9.2 -> 8.6 ms for 300 fixed stages at N = 1e5)
+                force_sel = sn;
+                res->select_stalls += 1;
+                launched = sn - 2 - base;                          // (stage sn itself is the next one to enqueue)
+                c.status.code = 0;
+                break;
+            } else if (code == 6) {
+                // ... with certificate passes (predictions switched off): the full path runs it
                 const bool cert6 = adaptive && !spec_on;
                 if (int e = enq_stage(sn, cert6, first_passes, true)) return e;
                 if (cert6) { stall_stage = sn; stall_p = first_passes; }
@@ -1048,6 +1096,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (predict_select) { pred_ess = p.ess; pred_rl = p.do_resample; }
         if (rc->sync_every <= 0) cur_sync = stalled ? sync_every : std::min(2 * cur_sync, 4 * sync_every);
     }
+    // (a batch that ended with a segment's exit note was read before the launch had finished: everything behind this line reads what it left)
+    HIP_TRY(hipSetDevice(h0->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h0->stream));
     if (h0->e2->d_prof) {
         long long pr[128];
         HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));

@@ -316,11 +316,27 @@ struct Seg3Args {
     double *hist_w;
     long long hist_ld;
     int *done_out;                 // non-null: number of stages this launch completed (profiling)
+    int *note;                     // non-null (one handle): host-mapped words - block 0 leaves a copy of Ctl2 at note + 16 and then this launch's
+    int note_seq;                  // sequence number at note[0] when it is done with Ctl2 (k3_leave_note)
     long long *prof;               // development only (SMCMI_PROF2=<stage>): stamps of that stage
     long long *gprof;              // ... and every block's hand-over stamps (K3_WALL)
     int prof_stage;
 };
 constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; }
+
+// Block 0 of a segment launch, when it has written everything it writes into Ctl2 (all its threads call, at a block-uniform point): Ctl2 as
+// the launch leaves it goes into host-mapped memory, then the launch's sequence number - the host that finds the number there has the state
+// the copy-and-sync at the end of a batch would hand it, tens of microseconds earlier (run2.hpp read_ctl).
+__device__ inline void k3_leave_note(const Seg3Args &sa, const Ctl2 *ctl) {
+    if (blockIdx.x != 0 || sa.note == nullptr) return;
+    __syncthreads();                                            // (the block's own stores into Ctl2 are in the L2 behind this barrier)
+    constexpr int NW = sizeof(Ctl2) / sizeof(double);
+    volatile double *dst = reinterpret_cast<volatile double *>(sa.note + 16);
+    for (int k = threadIdx.x; k < NW; k += blockDim.x) dst[k] = __hip_atomic_load(reinterpret_cast<const double *>(ctl) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(sa.note, sa.note_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #define K3_STAMP(prof, slot)                                                                                                   \
     do {                                                                                                                      \
@@ -383,7 +399,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     if (!sa.enter_mut) {
         // ---- the first stage's begin: as K1's prologue, by every block from the rows the previous launch left (block 0 records it)
         const int act = begin2_block<T3>(n, st, ctl, sa.mrows, 1, sa.sched, ma.rec, &s_b[(n - 1) & 1].po, &s_a.bg, s_vt, s_tot, s_sw, &s_act);
-        if (act != 0) return;                                   // nothing was touched: the cloud in memory is current
+        if (act != 0) { k3_leave_note(sa, ctl); return; }       // nothing was touched: the cloud in memory is current
         if (tid == 0) {
             const double a = s_a.bg.accept, tg = rp.target;
             s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
@@ -397,10 +413,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (tid < NWP) reinterpret_cast<double *>(&s_b[(n - 1) & 1].po)[tid] = reinterpret_cast<const double *>(&ctl->ps[(n - 1) & 1])[tid];
         if (ma.cmrows.mb) {                                       // mailbox: a launch that will not run must not wait for rows nobody posts (begin2_block)
             __syncthreads();
-            if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) return;
+            if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) { k3_leave_note(sa, ctl); return; }
         }
         reduce_rows<MCM, 1, T3>(ma.cmrows, s_vt, s_tot);          // (its barriers also publish the LDS copies above)
-        if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) return;       // the state this launch was enqueued for is not there: no-op
+        if (s_a.bg.stage != n || !s_a.bg.final || s_b[(n - 1) & 1].po.stage != n - 1) { k3_leave_note(sa, ctl); return; }       // the state this launch was enqueued for is not there: no-op
         double ess;
         const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
         if (dec == 4 || dec < 0 || (dec == 1 && !ma.sel_enqueued)) {                             // the stalls K2 reports (the host resumes the stage through the launches)
@@ -409,6 +425,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                 ctl->status.stage = n;
                 ctl->status.code = dec == 4 ? 4 : (dec < 0 ? 9 : 3);
             }
+            k3_leave_note(sa, ctl);
             return;
         }
         rs0 = dec == 1 ? 1 : 0;
@@ -655,6 +672,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (sa.done_out) *sa.done_out = done;
         if (timed_out) { ctl->status.err = SMCMI_ERR_TIMEOUT; ctl->status.stage = n; ctl->status.code = 9; }
     }
+    k3_leave_note(sa, ctl);
 }
 
 }  // namespace smcmi
