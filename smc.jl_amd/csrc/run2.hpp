@@ -595,6 +595,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     std::vector<hipEvent_t> evs3;
     int seg_launches = 0;
     static const int note3_on = getenv("SMCMI_SEG_NOTE") ? atoi(getenv("SMCMI_SEG_NOTE")) : 1;      // development: 0 = every batch ends with a copy and a sync
+    int force_sel = -1;          // the stage a segment left because it must resample: enqueued with its selection in front of the next segment
+    bool status_pending = false; // ... and its status (code 6) is still set: the segment that enters at that stage's mutation clears it
     int last_note_seq = -1;      // sequence number of the latest segment launch that leaves a note; -1: the stream's last launch is not such a segment
     struct SegRange { int a, b; bool enter; };
     std::vector<SegRange> seg_ranges;              // stages each segment launch was enqueued for (error diagnosis)
@@ -806,6 +808,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
         Seg3Args sa{};
         sa.n_first = n_first; sa.n_last = n_last; sa.enter_mut = enter_mut ? 1 : 0; sa.mrows = mrs[hk]; sa.sched = h->d_sched;
+        sa.clear_status = (enter_mut && n_first == force_sel && status_pending) ? 1 : 0;
+        if (sa.clear_status && hk + 1 == g.hs.size()) status_pending = false;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
         if (seg_sys) {                                               // the totals tables every handle posts into: inside the mailbox allocation
@@ -933,7 +937,6 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (default batches double while nothing stalls - a sync in the middle of a run idles the GPU for ~50 µs and cuts a segment in two - and
     // fall back after a stall; the first batch stays short: only its sync tells how many stages are left)
     int cur_sync = sync_every;
-    int force_sel = -1;          // the stage a segment left because it must resample: enqueued with its selection in front of the next segment
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
     const double N_tot = (double)h0->cfg.n_parts, thr = rc->threshold_ratio * N_tot;
@@ -1031,13 +1034,15 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
             for (int &s : ev_stage) if (s >= sn) s = -1;           // the stalled stage's mutation launch and everything behind it were no-ops
             prepared_stage = begun_stage = -1;                     // (nothing a helper block was enqueued for stands: the resumed stage runs on launches)
-            if (int e = clear_status()) return e;
-            if (code == 6 && e3 && !(adaptive && !spec_on)) {
+            const bool resume_in_segment = code == 6 && e3 && !(adaptive && !spec_on);
+            if (!resume_in_segment) { if (int e = clear_status()) return e; }
+            if (resume_in_segment) {
                 // a segment of engine 3 left at this stage (it must resample): nothing of the stage is committed.  The next batch starts
                 // with it - correction and selection as launches, then a segment that enters at its mutation and goes on - instead of the
                 // whole stage as launches behind a second host sync (fixed schedules, whose resample stages nobody can foresee, pay this at
                 // every one of them: 9.2 -> 8.6 ms for 300 fixed stages at N = 1e5)
                 force_sel = sn;
+                status_pending = true;                             // (the entering segment clears the status: no fill launch in front of the stage)
                 res->select_stalls += 1;
                 launched = sn - 2 - base;                          // (stage sn itself is the next one to enqueue)
                 c.status.code = 0;

@@ -316,6 +316,7 @@ struct Seg3Args {
     double *hist_w;
     long long hist_ld;
     int *done_out;                 // non-null: number of stages this launch completed (profiling)
+    int clear_status;              // enter_mut: this launch resumes the stage a segment left (status code 6) - block 0 clears the status once it is in
     int *note;                     // non-null (one handle): host-mapped words - block 0 leaves a copy of Ctl2 at note + 16 and then this launch's
     int note_seq;                  // sequence number at note[0] when it is done with Ctl2 (k3_leave_note)
     long long *prof;               // development only (SMCMI_PROF2=<stage>): stamps of that stage
@@ -429,6 +430,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             return;
         }
         rs0 = dec == 1 ? 1 : 0;
+        if (sa.clear_status && writer && tid == 0) { ctl->status.code = 0; ctl->status.stage = 0; }        // (instead of a fill launch by the host)
         if (rs0) reduce_rows<pad2(NPm), 1, T3>(ma.gmrows, s_vt, s_tot + 2);          // moments of the resampled cloud (k2_gather's rows) replace the correction's
     }
     const double inv_pre = INV_FACTORIAL[tid & 31];
