@@ -30,8 +30,12 @@ void launch_k2_correct(smcmi_handle *h, int n, int begin_done, int spec_expected
 template <int D>
 void launch_k2_gather(smcmi_handle *h, int n, const Rows2 &cmrows, const double *cum, int method, const double *full, long long s_lo, long long s_hi) {
     Eng2 *e = h->e2;
-    k2_gather<D><<<e->g.Vl * e->g.nbg, TB, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
-                                                          h->n, e->rows_gm, s_lo, s_hi);
+    if constexpr (D <= 10)
+        k2_gather<D><<<e->g.Vl * e->g.nbg, TS, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
+                                                              h->n, e->rows_gm, s_lo, s_hi);
+    else
+        k2_gather_wide<D><<<e->g.Vl * e->g.nbg, TB, 0, h->stream>>>(h->cl, e->d_ctl, h->d_st, e->g, n, cmrows, cum, method, h->cfg.seed, h->cfg.gid0, h->d_anc, full,
+                                                                   h->n, e->rows_gm, s_lo, s_hi);
 }
 template <int D>
 void launch_k2_mutate(smcmi_handle *h, const Mut2Args &ma, int nb, bool alpha1) {

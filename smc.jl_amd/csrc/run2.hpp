@@ -659,7 +659,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 Eng2 *e = h->e2;
                 const Rows2 cr = cm_rows(h);
-                k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cr, h->d_wt, e->csum, h->d_cum);
+                k2_scan<<<g0.V * g0.nb1, TS, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cr, h->d_wt, e->csum, h->d_cum);
 #define SMCMI_CALL(D) launch_k2_gather<D>(h, n, cr, h->d_cum, rc->resampling_method, nullptr, 0, -1)
                 SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
@@ -686,7 +686,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 Eng2 *e = h->e2;
                 const int c0 = e->g.v0 * e->g.nb1;
-                k2_scan<<<g0.Vl * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_wt, e->csum_full, h->d_cum, c0, c0 + g0.Vl * g0.nb1, h->cfg.gid0);
+                k2_scan<<<g0.Vl * g0.nb1, TS, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_wt, e->csum_full, h->d_cum, c0, c0 + g0.Vl * g0.nb1, h->cfg.gid0);
                 k2_owner_ranges<<<1, 64, 0, h->stream>>>(e->d_ctl, h->d_st, n, cm_rows(h), h->d_cum, h->cfg.n_parts, h->n, h->cfg.gid0, g.world, h->cfg.seed,
                                                         e->d_ranges, e->csum_full, c0);
             }
@@ -713,7 +713,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             for (auto *h : g.hs) {
                 HIP_TRY(hipSetDevice(h->cfg.device));
                 Eng2 *e = h->e2;
-                k2_scan<<<g0.V * g0.nb1, TB, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_full_w, e->csum_full, h->d_cum_full);
+                k2_scan<<<g0.V * g0.nb1, TS, 0, h->stream>>>(e->d_ctl, h->d_st, e->g, n, cm_rows(h), h->d_full_w, e->csum_full, h->d_cum_full);
             }
             if (int e = g.allgather([](smcmi_handle *h) { return (const double *)h->cl.buf[0]; }, [](smcmi_handle *h) { return h->d_full_cloud; },
                                     nloc * h0->R)) return e;

@@ -1118,32 +1118,65 @@ __device__ inline int decide2(const Begin2 &bg, double threshold, double phi_rto
 // Inclusive scan of W̃ / ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) over the WHOLE cloud (sharded runs hand in the
 // all-gathered W̃ and chunk sums) in the correction's chunks: one block per chunk, chunk offsets = running sum of the chunk sums
 // in chunk order.  Does nothing unless this stage resamples (the decision is re-derived from the correction rows).
+// The pieces are functions of a block of TS = 512 threads with one value per thread - what a worker of a persistent segment (stage3.hpp)
+// holds - so that a segment that resamples without leaving writes the cum column this kernel writes, bit for bit.
+constexpr int TS = 512;
+// exclusive prefix of the chunk sums cs(b), b < nchunks <= 1024, in chunk order -> s_off[b]: 256 threads x 4 chunks each, then a sequential
+// carry.  All threads of the block call; scratch: 256 doubles, s_off: 1024 doubles of LDS; ends with a barrier.
+template <class CS>
+__device__ inline void sel_chunk_offsets(CS cs, int nchunks, double *scratch, double *s_off) {
+    const int t = threadIdx.x;
+    double loc[4], run = 0.0;
+    if (t < 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; loc[q] = run; run += (b < nchunks) ? cs(b) : 0.0; }
+        scratch[t] = run;
+    }
+    __syncthreads();
+    if (t == 0) { double carry = 0.0; for (int q = 0; q < 256; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
+    __syncthreads();
+    if (t < 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_off[t * 4 + q] = scratch[t] + loc[q];
+    }
+    __syncthreads();
+}
+// inclusive scan of one tile of TS values (thread t holds value t; 0 beyond the end of the data): inside a wavefront by shuffles
+// (x_t += x_{t - off}, off = 1 .. 32), the wavefronts' totals added up in ascending order.  Returns the inclusive sum at this thread,
+// *tile_total the tile's total.  s_w: TS / 64 doubles of LDS; all TS threads call; two barriers.
+__device__ inline double sel_tile_scan(double w, double *s_w, double *tile_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double x = w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double y = __shfl_up(x, off, 64);
+        x = lane >= off ? x + y : x;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    double ex = 0.0, tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < TS / 64; ++k) { const double v = s_w[k]; ex = k < wave ? ex + v : ex; tot += v; }
+    __syncthreads();
+    *tile_total = tot;
+    return ex + x;
+}
 // c_begin / c_end / i_off: scan the chunks [c_begin, c_end) only, reading and writing at (global index - i_off) - a handle of a sharded
 // run scans ITS particles' weights into its local cum column from the all-gathered chunk sums (the offsets, the total and therefore
 // the values are those of a scan over the whole cloud).
-static __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
+static __global__ void __launch_bounds__(TS) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
                                               const double *csum_full, double *cum, int c_begin = 0, int c_end = -1, long long i_off = 0) {
-    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2], scratch[TB], s_off[4 * TB];
+    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2], scratch[256], s_off[1024], s_w[TS / 64];
     __shared__ Begin2 s_bg;
     constexpr int NWB = sizeof(Begin2) / sizeof(double);
     if (threadIdx.x < NWB) reinterpret_cast<double *>(&s_bg)[threadIdx.x] = reinterpret_cast<const double *>(&ctl->bg)[threadIdx.x];
     __syncthreads();
     if (s_bg.stage != n || !s_bg.final || ctl->ps[(n - 1) & 1].stage != n - 1) return;
-    reduce_rows<2, 8, TB>(cmrows, s_vt, s_tot);
+    reduce_rows<2, 8, TS>(cmrows, s_vt, s_tot);
     double ess;
     if (decide2(s_bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) != 1) return;
     const int nchunks = g.V * g.nb1, t = threadIdx.x;
-    // exclusive prefix of the chunk sums in chunk order: 256 threads x 4 chunks each, then a sequential carry (<= 1024 chunks)
-    double loc[4], run = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const int b = t * 4 + q; loc[q] = run; run += (b < nchunks) ? csum_full[b] : 0.0; }
-    scratch[t] = run;
-    __syncthreads();
-    if (t == 0) { double carry = 0.0; for (int q = 0; q < TB; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s_off[t * 4 + q] = scratch[t] + loc[q];
-    __syncthreads();
+    sel_chunk_offsets([&](int b) { return csum_full[b]; }, nchunks, scratch, s_off);
     const double total = s_tot[0];
     wt_full -= i_off; cum -= i_off;
     for (int c = c_begin + (int)blockIdx.x; c < (c_end < 0 ? nchunks : c_end); c += gridDim.x) {
@@ -1151,27 +1184,13 @@ static __global__ void __launch_bounds__(TB) k2_scan(Ctl2 *ctl, const DevState *
         const long long v_beg0 = (long long)v * g.nv, v_beg = v_beg0 < g.N ? v_beg0 : g.N, v_end = v_beg + g.nv < g.N ? v_beg + g.nv : g.N;
         long long beg = v_beg + (long long)r * g.per1, end = beg + g.per1 < v_end ? beg + g.per1 : v_end;
         if (beg > v_end) beg = v_end;
-        constexpr int IPT = 4;
         double carry = s_off[c];
-        for (long long base = beg; base < end; base += (long long)TB * IPT) {
-            const long long i0 = base + (long long)t * IPT;
-            double vv[IPT], rr = 0.0;
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) { vv[k] = (i0 + k < end) ? wt_full[i0 + k] : 0.0; rr += vv[k]; vv[k] = rr; }
-            scratch[t] = rr;
-            __syncthreads();
-            for (int off = 1; off < TB; off <<= 1) {
-                const double add = (t >= off) ? scratch[t - off] : 0.0;
-                __syncthreads();
-                scratch[t] += add;
-                __syncthreads();
-            }
-            const double excl = (t > 0 ? scratch[t - 1] : 0.0) + carry;
-#pragma unroll
-            for (int k = 0; k < IPT; ++k)
-                if (i0 + k < end) cum[i0 + k] = (excl + vv[k]) / total;
-            carry += scratch[TB - 1];
-            __syncthreads();
+        for (long long base = beg; base < end; base += TS) {
+            const long long i = base + t;
+            double tt;
+            const double incl = sel_tile_scan(i < end ? wt_full[i] : 0.0, s_w, &tt);
+            if (i < end) cum[i] = (carry + incl) / total;
+            carry += tt;
         }
     }
 }
@@ -1251,7 +1270,7 @@ static __global__ void k2_owner_ranges(Ctl2 *ctl, const DevState *st, int n, Row
 // the resampled cloud (all weights 1; smc_main.jl:440-446, 457-465) are accumulated on the way -> one row of pair sums per block.
 // full: rows come from the per-handle [R][full_shard_n] shard buffers of an exchange (sharded runs), else from buffer 0.
 template <int D>
-__global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *cum,
+__global__ void __launch_bounds__(TB) k2_gather_wide(CloudPtrs cl, Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *cum,
                                                 int method, unsigned long long seed, long long gid0, long long *anc, const double *full,
                                                 long long full_shard_n, double *rows_gm, long long s_lo = 0, long long s_hi = -1) {
     constexpr int DA = D + 1, NP = DA * (DA + 1) / 2, NCH = (NP + 63) / 64;
@@ -1373,6 +1392,148 @@ __global__ void __launch_bounds__(TB) k2_gather(CloudPtrs cl, Ctl2 *ctl, const D
         const double tot = block_reduce_many<64>(a64, red);
         if (threadIdx.x < 64 && ch * 64 + (int)threadIdx.x < NP) out[ch * 64 + threadIdx.x] = tot;
     }
+}
+
+// The same for n_para <= 10 by blocks of TS = 512 threads, one output slot per thread and tile - built from functions a worker of a
+// persistent segment (stage3.hpp: 512 particles, one per thread) calls on its own slots, so that a segment that resamples without
+// leaving selects the ancestors and leaves the moment row this kernel leaves, bit for bit.
+constexpr int SEL_GCH = 512, SEL_NC = 2048, SEL_CAP = 4096;
+// threshold of global output slot `slot` (src/resample.jl:33-70)
+__device__ inline double sel_threshold(int method, unsigned long long seed, long long slot, int n, double u_sys, long long N) {
+    if (method == SMCMI_RESAMPLE_MULTINOMIAL) {
+        double ua, ub;
+        uniform_pair(seed, (unsigned long long)slot, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
+        return ua;
+    }
+    return ((double)slot + u_sys) / (double)N;                       // (i - 1 + offset) / n_parts
+}
+// cum at the ends of the SEL_GCH-row chunks of [s_lo, s_end) -> s_ce[0, nc) (all threads call; ends with a barrier)
+template <class LDC>
+__device__ inline void sel_chunk_ends(LDC ldcum, long long s_lo, long long s_end, int nc, double *s_ce) {
+    for (int c = threadIdx.x; c < nc; c += TS) {
+        const long long last = s_lo + (long long)(c + 1) * SEL_GCH - 1;
+        s_ce[c] = ldcum(last < s_end ? last : s_end - 1);
+    }
+    __syncthreads();
+}
+// Ancestor of this thread's threshold ua = first row j of [s_lo, s_end) with cum[j] > ua, clamped to the last row.  Systematic resampling:
+// the thresholds of a tile of TS consecutive slots ascend (a dead thread carries the tile's last live threshold), so the tile descends from
+// one contiguous range of rows: threads 0 and TS - 1 find its chunks in s_ce, the rows in between are staged in s_cw (SEL_CAP doubles) and
+// searched there - the same comparisons on the same values as a search over the whole column, which is what ranges that do not fit and
+// multinomial resampling (staged = false) get.  All TS threads call; s_r: two long longs of LDS.
+template <class LDC>
+__device__ inline long long sel_search_tile(double ua, bool staged, int nc, const double *s_ce, double *s_cw, long long *s_r, LDC ldcum, long long s_lo, long long s_end) {
+    if (staged) {
+        if (threadIdx.x == 0 || threadIdx.x == TS - 1) {
+            int lo = 0, hi = nc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_ce[mid] > ua) hi = mid; else lo = mid + 1; }
+            // rows below chunk `lo` end at or below the threshold; chunk `lo` (if any) holds a row above it
+            if (threadIdx.x == 0) s_r[0] = s_lo + (long long)lo * SEL_GCH;
+            else s_r[1] = lo < nc ? s_lo + (long long)(lo + 1) * SEL_GCH : s_end;
+        }
+        __syncthreads();
+        const long long r0 = s_r[0] < s_end ? s_r[0] : s_end, r1 = s_r[1] < s_end ? s_r[1] : s_end;
+        const bool in_lds = r1 - r0 <= SEL_CAP;                        // (block-uniform)
+        if (in_lds)
+            for (long long j = r0 + threadIdx.x; j < r1; j += TS) s_cw[j - r0] = ldcum(j);
+        __syncthreads();
+        if (in_lds) {
+            int lo = 0, hi = (int)(r1 - r0);
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cw[mid] > ua) hi = mid; else lo = mid + 1; }
+            const long long lg = r0 + lo;
+            return lg < s_end ? lg : s_end - 1;
+        }
+    }
+    long long lo = s_lo, hi = s_end;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (ldcum(mid) > ua) hi = mid; else lo = mid + 1;
+    }
+    return lo < s_end ? lo : s_end - 1;
+}
+// the moment row of a block of TS threads from per-thread pair sums acc[p] = Σ x̃_a x̃_b over the thread's slots, p < NP, as the correction
+// rows are formed (cm_row_chunks: sixteen sums at a time through the butterflies) -> store(p, total)
+template <int D, class ST>
+__device__ inline void sel_moment_row(const double (&acc)[(D + 1) * (D + 2) / 2], double *red, ST store) {
+    constexpr int NP = (D + 1) * (D + 2) / 2;
+    cm_row_chunks<NP, TS / 64>(red, [&](auto C, double (&a)[CMW]) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+#pragma unroll
+        for (int q = 0; q < CMW; ++q) a[q] = (c * CMW + q < NP) ? acc[(c * CMW + q < NP) ? c * CMW + q : 0] : 0.0;
+    }, store);
+}
+template <int D>
+__global__ void __launch_bounds__(TS) k2_gather(CloudPtrs cl, Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *cum,
+                                                int method, unsigned long long seed, long long gid0, long long *anc, const double *full,
+                                                long long full_shard_n, double *rows_gm, long long s_lo = 0, long long s_hi = -1) {
+    constexpr int DA = D + 1, NP = DA * (DA + 1) / 2;
+    __shared__ double red[(TS / 64) * cm_row_ld(NP)];
+    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
+    __shared__ Begin2 s_bg;
+    __shared__ double s_sh[D];
+    __shared__ double s_ce[SEL_NC], s_cw[SEL_CAP];
+    __shared__ long long s_r[2];
+    constexpr int NWB = sizeof(Begin2) / sizeof(double);
+    if (threadIdx.x < NWB) reinterpret_cast<double *>(&s_bg)[threadIdx.x] = reinterpret_cast<const double *>(&ctl->bg)[threadIdx.x];
+    const Post2 &po = ctl->ps[(n - 1) & 1];
+    const int pstage = po.stage;
+    if (threadIdx.x < D) s_sh[threadIdx.x] = po.shift[threadIdx.x];
+    __syncthreads();
+    if (s_bg.stage != n || !s_bg.final || pstage != n - 1) return;
+    reduce_rows<2, 8, TS>(cmrows, s_vt, s_tot);
+    double ess;
+    if (decide2(s_bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) != 1) return;
+    const int R = cl.R;
+    const long long N = g.N;
+    double acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+    long long beg, end;
+    vchunk(g, blockIdx.x / g.nbg, blockIdx.x % g.nbg, g.perg, beg, end);
+    double u_sys = 0.0, ub;
+    if (method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub);
+    // (s_lo .. s_hi: the global rows whose cum this handle holds - a sharded run exchanges only its slots' ancestor range)
+    const long long s_end = s_hi < 0 ? N : s_hi + 1;
+    const long long span = s_end - s_lo;
+    const int nc = (int)((span + SEL_GCH - 1) / SEL_GCH);
+    const bool staged = method != SMCMI_RESAMPLE_MULTINOMIAL && span > 0 && nc <= SEL_NC;       // (block-uniform)
+    auto ldcum = [&](long long j) { return cum[j]; };
+    if (staged) sel_chunk_ends(ldcum, s_lo, s_end, nc, s_ce);
+    const long long n_tiles = (end - beg + TS - 1) / TS;
+    for (long long tile = 0; tile < n_tiles; ++tile) {
+        const long long k = beg + tile * TS + threadIdx.x;
+        const bool live = k < end;
+        const long long slot = gid0 + (live ? k : end - 1);                  // (a dead thread stands for the tile's last live slot)
+        const double ua = sel_threshold(method, seed, slot, n, u_sys, N);
+        const long long a = sel_search_tile(ua, staged, nc, s_ce, s_cw, s_r, ldcum, s_lo, s_end);
+        if (!live) continue;
+        if (anc) anc[k] = a;
+        const double *from = cl.buf[0];
+        long long ldf = cl.n, a_row = a;
+        if (full) {
+            from = full + (a / full_shard_n) * (long long)R * full_shard_n;
+            ldf = full_shard_n;
+            a_row = a % full_shard_n;
+        }
+        double row[D + 3];
+#pragma unroll
+        for (int q = 0; q < D + 3; ++q) row[q] = from[(long long)q * ldf + a_row];
+#pragma unroll
+        for (int q = 0; q < D + 3; ++q) col(cl, 1, q)[k] = row[q];
+        col(cl, 1, D + 3)[k] = from[(long long)(D + 3) * ldf + a_row];
+        double xx[DA];
+        xx[0] = 1.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - s_sh[q];
+        int p = 0;
+#pragma unroll
+        for (int a2 = 0; a2 < DA; ++a2) {
+#pragma unroll
+            for (int b2 = a2; b2 < DA; ++b2) { acc[p] += xx[a2] * xx[b2]; ++p; }
+        }
+    }
+    double *out = rows_gm + (long long)blockIdx.x * pad2(NP);
+    sel_moment_row<D>(acc, red, [&](int idx, double v) { out[idx] = v; });
 }
 
 // ------------------------------------------------------------------------------------------------ K2: decision + proposal + mutation
