@@ -19,7 +19,7 @@ constexpr int PROF2_BLOCKS = 4096;
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_ranges_all, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_ranges_all, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3, e->d_sel3};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_note3) hipHostFree(e->h_note3);
@@ -124,7 +124,7 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     if (g.direct || (g.inker && !g.wide && g.t2 == T3 && g.nb1 == g.nb2)) {       // engine 3 (stage3.hpp) can serve this geometry: tickets, records, time-out words, per-launch stage counts
         const size_t gw = k3_table_words(g.Vl * g.nb2);
         if (dmalloc(&e->d_tick3, 2 * SEG3_TICKS) || dmalloc(&e->d_rec3, REC3_WORDS) || dmalloc(&e->d_to3, 2) || dmalloc(&e->d_done3, SEG3_MAX_LAUNCHES) ||
-            dmalloc(&e->d_gran3, gw)) {
+            dmalloc(&e->d_gran3, gw) || dmalloc(&e->d_sel3, 1)) {
             free_eng2(e);
             return SMCMI_ERR_HIP;
         }
@@ -594,6 +594,22 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     }
     std::vector<hipEvent_t> evs3;
     int seg_launches = 0;
+    // a stage that must resample does so inside the segment (stage3.hpp SELECTION): one handle, its own tables
+    static const int sel_in_env = getenv("SMCMI_SEG_SELECT") ? atoi(getenv("SMCMI_SEG_SELECT")) : 1;      // development: 0 = the segment leaves, selection as launches
+    // (the workers' blocks must be the selection kernels' blocks: one 512-slot tile per moment row - not so when a cloud is cut into 2 or 4
+    // long virtual shards of more than 32 rows, whose gather blocks take two tiles each)
+    const bool sel_inside = e3 && !seg_sys && g.hs.size() == 1 && d <= 10 && sel_in_env != 0 && h0->d_cum != nullptr && g0.nbg == g0.nb2 && g0.perg == T3 &&
+                            g0.V * g0.nb1 <= 256 && rc->alpha == 1.0;
+    if (sel_inside) {
+        Eng2 *e = h0->e2;
+        const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
+        Sel3Args sl{};
+        sl.method = rc->resampling_method; sl.cum = h0->d_cum; sl.anc = h0->d_anc;
+        sl.g_sel = e->d_gran3 + nblk * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; sl.gt_sel = sl.g_sel + nblk * 2 * 2;
+        sl.g_gm = sl.gt_sel + (size_t)V2_MAXV * 2 * 2; sl.gt_gm = sl.g_gm + nblk * 72 * 2;
+        HIP_TRY(hipMemcpyAsync(e->d_sel3, &sl, sizeof(sl), hipMemcpyHostToDevice, h0->stream));
+        HIP_TRY(hipStreamSynchronize(h0->stream));               // (sl is a local)
+    }
     static const int note3_on = getenv("SMCMI_SEG_NOTE") ? atoi(getenv("SMCMI_SEG_NOTE")) : 1;      // development: 0 = every batch ends with a copy and a sync
     int force_sel = -1;          // the stage a segment left because it must resample: enqueued with its selection in front of the next segment
     bool status_pending = false; // ... and its status (code 6) is still set: the segment that enters at that stage's mutation clears it
@@ -812,6 +828,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (sa.clear_status && hk + 1 == g.hs.size()) status_pending = false;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
+        sa.sel = sel_inside ? e->d_sel3 : nullptr;
         if (seg_sys) {                                               // the totals tables every handle posts into: inside the mailbox allocation
             sa.peers = h->d_peers; sa.world = g.world;
             sa.off_cm = MB_SEG_OFF; sa.off_mut = MB_SEG_OFF + MB_SEG_KIND_WORDS;
@@ -985,7 +1002,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             // engine 3 takes every stage that is expected to need neither (fixed schedules: nobody can tell which stage resamples -
             // the segment leaves at the first one that must, code 6, and the host runs that stage through the launches) ...
             if (n == force_sel) { sel = true; if (predict_select) pred_rl = 1; }        // (a segment left at this stage: it must resample)
-            if (e3 && !cert && (!sel || !adaptive) && n != force_sel) {
+            if (e3 && !cert && (!sel || !adaptive || sel_inside) && n != force_sel) {
                 if (seg_a < 0) { seg_a = n; seg_enter = false; seg_sel = false; }
                 seg_b = n;
                 ++launched;

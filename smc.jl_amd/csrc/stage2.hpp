@@ -1122,7 +1122,7 @@ __device__ inline int decide2(const Begin2 &bg, double threshold, double phi_rto
 // holds - so that a segment that resamples without leaving writes the cum column this kernel writes, bit for bit.
 constexpr int TS = 512;
 // exclusive prefix of the chunk sums cs(b), b < nchunks <= 1024, in chunk order -> s_off[b]: 256 threads x 4 chunks each, then a sequential
-// carry.  All threads of the block call; scratch: 256 doubles, s_off: 1024 doubles of LDS; ends with a barrier.
+// carry.  All threads of the block call; scratch: 256 doubles, s_off: nchunks doubles of LDS; ends with a barrier.
 template <class CS>
 __device__ inline void sel_chunk_offsets(CS cs, int nchunks, double *scratch, double *s_off) {
     const int t = threadIdx.x;
@@ -1137,7 +1137,8 @@ __device__ inline void sel_chunk_offsets(CS cs, int nchunks, double *scratch, do
     __syncthreads();
     if (t < 256) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s_off[t * 4 + q] = scratch[t] + loc[q];
+        for (int q = 0; q < 4; ++q)
+            if (t * 4 + q < nchunks) s_off[t * 4 + q] = scratch[t] + loc[q];
     }
     __syncthreads();
 }
@@ -1418,11 +1419,12 @@ __device__ inline void sel_chunk_ends(LDC ldcum, long long s_lo, long long s_end
 }
 // Ancestor of this thread's threshold ua = first row j of [s_lo, s_end) with cum[j] > ua, clamped to the last row.  Systematic resampling:
 // the thresholds of a tile of TS consecutive slots ascend (a dead thread carries the tile's last live threshold), so the tile descends from
-// one contiguous range of rows: threads 0 and TS - 1 find its chunks in s_ce, the rows in between are staged in s_cw (SEL_CAP doubles) and
+// one contiguous range of rows: threads 0 and TS - 1 find its chunks in s_ce, the rows in between are staged in s_cw (cap doubles) and
 // searched there - the same comparisons on the same values as a search over the whole column, which is what ranges that do not fit and
 // multinomial resampling (staged = false) get.  All TS threads call; s_r: two long longs of LDS.
 template <class LDC>
-__device__ inline long long sel_search_tile(double ua, bool staged, int nc, const double *s_ce, double *s_cw, long long *s_r, LDC ldcum, long long s_lo, long long s_end) {
+__device__ inline long long sel_search_tile(double ua, bool staged, int nc, const double *s_ce, double *s_cw, long long *s_r, LDC ldcum, long long s_lo, long long s_end,
+                                            int cap = SEL_CAP) {
     if (staged) {
         if (threadIdx.x == 0 || threadIdx.x == TS - 1) {
             int lo = 0, hi = nc;
@@ -1433,7 +1435,7 @@ __device__ inline long long sel_search_tile(double ua, bool staged, int nc, cons
         }
         __syncthreads();
         const long long r0 = s_r[0] < s_end ? s_r[0] : s_end, r1 = s_r[1] < s_end ? s_r[1] : s_end;
-        const bool in_lds = r1 - r0 <= SEL_CAP;                        // (block-uniform)
+        const bool in_lds = r1 - r0 <= cap;                            // (block-uniform; whether a range is staged changes no result)
         if (in_lds)
             for (long long j = r0 + threadIdx.x; j < r1; j += TS) s_cw[j - r0] = ldcum(j);
         __syncthreads();

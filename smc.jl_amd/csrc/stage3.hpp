@@ -278,7 +278,11 @@ static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned lo
 }
 
 constexpr size_t k3_park_offset(int D) { return (k2_lds_bytes(D) + 15) / 16 * 2; }          // in doubles, 16-byte aligned
-constexpr size_t k3_lds_bytes(int D) { return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double); }
+// (k2's arrays | the parking area (D + 2) T3 | α = 1 only: the particle in transit through an in-place selection (D + 5) T3 - the mixture
+// variant's static arrays leave no room for it: its segments leave at a stage that must resample)
+constexpr size_t k3_lds_bytes(int D, bool sel_state = false) {
+    return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double) + (sel_state ? (size_t)(D + 5) * T3 * sizeof(double) : 0);
+}
 // (MIX = false, α = 1: the mixture-component uniform is never read, so its Philox call is not made at all)
 template <int D, bool MIX = true>
 __device__ inline void k3_draw_park(double *z_park, unsigned long long seed, unsigned long long pid, unsigned stage, int db, int debug) {
@@ -291,6 +295,13 @@ __device__ inline void k3_draw_park(double *z_park, unsigned long long seed, uns
     for (int e = 0; e < D; ++e) p[(2 + e) * T3] = z[e];
 }
 
+struct Sel3Args {
+    int method, pad;               // resampling method (SMCMI_RESAMPLE_*)
+    double *cum;                   // the cum column k2_scan writes ([n])
+    long long *anc;                // ancestors (or null)
+    unsigned long long *g_sel, *gt_sel;   // "my particle and cum values are written": [blocks][2 * 2] / [V2_MAXV][2 * 2] granules (a hand-over with no payload)
+    unsigned long long *g_gm, *gt_gm;     // moment rows of the resampled cloud: [blocks][72 * 2] / [V2_MAXV][72 * 2]
+};
 struct Seg3Args {
     int n_first, n_last;           // stages this launch may run
     int enter_mut;                 // 1: stage n_first was corrected (and, where needed, resampled) by engine 2's launches - the segment enters at its
@@ -316,6 +327,9 @@ struct Seg3Args {
     double *hist_w;
     long long hist_ld;
     int *done_out;                 // non-null: number of stages this launch completed (profiling)
+    // selection inside the segment (one handle, stage3.hpp "SELECTION"): a stage that must resample does so without leaving.  What only that
+    // path needs lives in device memory (kernel arguments sit in scalar registers for the whole launch: the segment kernel has none to spare)
+    const struct Sel3Args *sel;    // null: the segment leaves at a stage that must resample (status code 6)
     int clear_status;              // enter_mut: this launch resumes the stage a segment left (status code 6) - block 0 clears the status once it is in
     int *note;                     // non-null (one handle): host-mapped words - block 0 leaves a copy of Ctl2 at note + 16 and then this launch's
     int note_seq;                  // sequence number at note[0] when it is done with Ctl2 (k3_leave_note)
@@ -323,7 +337,7 @@ struct Seg3Args {
     long long *gprof;              // ... and every block's hand-over stamps (K3_WALL)
     int prof_stage;
 };
-constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; }
+constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT + 2 + 72) * 2 + (size_t)V2_MAXV * (72 + RMUT + 2 + 72) * 2; }
 
 // Block 0 of a segment launch, when it has written everything it writes into Ctl2 (all its threads call, at a block-uniform point): Ctl2 as
 // the launch leaves it goes into host-mapped memory, then the launch's sequence number - the host that finds the number there has the state
@@ -367,6 +381,98 @@ __device__ inline void k3_leave_note(const Seg3Args &sa, const Ctl2 *ctl) {
     do {                                                                                                                      \
         if ((prof) != nullptr && threadIdx.x == 0 && n == sa.prof_stage) (prof)[(idx)] = wall_clock64();                       \
     } while (0)
+
+// SELECTION inside the segment (src/smc_main.jl:435-446, src/resample.jl:23-72): what k2_scan + k2_gather do between two launches, by the
+// workers on the particles they hold - the same functions on the same 512-particle blocks, hence the same cum column, ancestors and moment
+// rows.  Two more hand-overs: "every particle and cum value is written" (no payload), and the moment rows of the resampled cloud.
+// Not inlined, and the particle comes and goes through LDS (stt: [W̃ | θ_1..θ_D | loglh | logprior | old_loglh | accept][T3]): the stage loop
+// keeps its registers.  sc: the workers' parking area as scratch.  Returns 1 when a wait timed out.
+template <int D>
+__device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, double *buf0, long long cl_n, int cl_R, long long Ng, int nchunks, int V, int rowi, long long i,
+                                                          long long beg, long long end, unsigned tag, int n, unsigned long long seed, long long gid0,
+                                                          const unsigned long long *g_cm, unsigned long long *to, int *s_to, double *s_tot, double *s_vt, double *s_sw,
+                                                          double *red, double *sc, double *stt, const double *shift) {
+    constexpr int NPm = Mut2Lds<D>::NP, MGM = pad2(NPm), DAm = D + 1, NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
+    const Sel3Args sl = *selp;
+    const int tid = threadIdx.x;
+    const bool live = i < end;
+    double *s_cs = sc, *s_scr = sc + 256, *s_off = sc + 512, *s_w = sc + 768, *s_ce = sc + 776, *s_cw = sc + 1034;
+    long long *s_r = reinterpret_cast<long long *>(sc + 1032);
+    const int cap_w = (D + 2) * T3 - 1034;
+    const __amdgpu_buffer_rsrc_t cl_rsrc = rows_rsrc(buf0, (long long)cl_R * cl_n * 8);
+    const __amdgpu_buffer_rsrc_t cum_rsrc = rows_rsrc(sl.cum, Ng * 8);
+    __syncthreads();
+    // (1) my particle as stage n - 1 left it -> buffer 0, agent scope (other dies read it below)
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < D + 4; ++k) row_store(buf0 + (long long)k * cl_n + i, stt[(1 + k) * T3 + tid], true);
+    }
+    // (2) the chunk sums = entry 0 of every block's correction row (published under this stage's tag) -> chunk offsets
+    if (tid < nchunks) {
+        const unsigned long long *wd = g_cm + (long long)tid * MCM * 2;
+        gran_poll(wd, tag, to, s_to);
+        gran_poll(wd + 1, tag, to, s_to);
+        const unsigned long long w0 = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w1 = __hip_atomic_load(wd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cs[tid] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+    }
+    __syncthreads();
+    if (*s_to) return 1;
+    sel_chunk_offsets([&](int b) { return s_cs[b]; }, nchunks, s_scr, s_off);
+    // (3) the cum values of my chunk (k2_scan's arithmetic on W̃)
+    {
+        double tt;
+        const double incl = sel_tile_scan(live ? stt[tid] : 0.0, s_w, &tt);
+        if (live) row_store(sl.cum + i, (s_off[rowi] + incl) / s_tot[0], true);
+    }
+    // (4) hand-over: every store above is acknowledged before this block says so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 2) gran_store(sl.g_sel + ((long long)rowi * 2 + tid) * 2, 0.0, tag);
+    if (!gather_totals(sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false)) return 1;
+    // (5) ancestors of my output slots
+    double u_sys = 0.0, ub_;
+    if (sl.method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub_);
+    auto ldcum = [&](long long j) { return load_f64_sc1(cum_rsrc, (unsigned)j * 8u); };
+    const int ncg = (int)((Ng + SEL_GCH - 1) / SEL_GCH);
+    const bool staged = sl.method != SMCMI_RESAMPLE_MULTINOMIAL && ncg <= 256;
+    if (staged) sel_chunk_ends(ldcum, 0, Ng, ncg, s_ce);
+    const long long slot = gid0 + (live ? i : (end > beg ? end - 1 : 0));
+    const double ua = sel_threshold(sl.method, seed, slot, n, u_sys, Ng);
+    const long long anc_i = (end > beg) ? sel_search_tile(ua, staged, ncg, s_ce, s_cw, s_r, ldcum, 0, Ng, cap_w) : 0;
+    // (6) the ancestor's row becomes my particle
+    double xx[DAm];
+    xx[0] = 1.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) xx[q + 1] = 0.0;
+    if (live) {
+        if (sl.anc) sl.anc[i] = anc_i;
+        double row[D + 4];
+#pragma unroll
+        for (int q = 0; q < D + 4; ++q) row[q] = load_f64_sc1(cl_rsrc, (unsigned)(((long long)q * cl_n + anc_i) * 8));
+#pragma unroll
+        for (int q = 0; q < D + 4; ++q) stt[(1 + q) * T3 + tid] = row[q];
+#pragma unroll
+        for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - shift[q];
+    }
+    // (7) the moment row of my block (pair sums x̃_a x̃_b about the shift, all weights 1: 0 + x̃_a x̃_b is the accumulator k2_gather holds for a
+    // block's only tile), published; (8) the totals of the resampled cloud's moments replace the correction's
+    unsigned long long *my_gm = sl.g_gm + (long long)rowi * MGM * 2;
+    cm_row_chunks<NPm, T3 / 64>(red, [&](auto C, double (&a)[CMW]) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        static_for<CMW>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int idx = c * CMW + decltype(Q)::value, q = decltype(Q)::value;
+            double val = 0.0;
+            if constexpr (idx < NPm) {
+                constexpr int pa = cm_pair_a(DAm, idx + 2), pb = cm_pair_b(DAm, idx + 2);
+                val = 0.0 + xx[pa] * xx[pb];
+            }
+            a[q] = live ? val : 0.0;
+        });
+    }, [&](int idx, double val) { gran_store(my_gm + idx * 2, val, tag); });
+    if (tid >= NPm && tid < MGM) gran_store(my_gm + tid * 2, 0.0, tag);
+    if (!gather_totals(sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false)) return 1;
+    return 0;
+}
 
 // grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard).
 // Worker b owns block (b / Vl) of local virtual shard (b % Vl): with the hardware's round-robin of consecutive blocks over the 8 XCDs
@@ -482,8 +588,24 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                 if (!gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
             }
             const double ess = s_tot[0] * s_tot[0] / s_tot[1];
-            if (!entered) { double e2; if (decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &e2) != 0) break; }
-            if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, entered ? rs0 : 0, &s_b[n & 1].po);
+            int rs_g = entered ? rs0 : 0;
+            if (!entered) {
+                double e2;
+                const int dec = decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &e2);
+                if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
+                    // SELECTION inside the segment (the workers' side is below): "everything is written", then the moment rows of the resampled cloud
+                    constexpr int MGM = pad2(Mut2Lds<D>::NP);
+                    const Sel3Args sl = *sa.sel;
+                    if (!gather_vshard<T3>(sl.g_sel + (long long)vg * g.nb2 * 2 * 2, g.nb2, 2, -1, tag, sa.to, &s_to,
+                                           [&](int idx, double val) { gran_store(sl.gt_sel + ((long long)(g.v0 + vg) * 2 + idx) * 2, val, tag); }, g_stage)) break;
+                    if (!gather_totals(sl.gt_sel, g.V, 2, -1, tag, sa.to, &s_to, s_sw, s_vt, false)) break;
+                    if (!gather_vshard<T3>(sl.g_gm + (long long)vg * g.nb2 * MGM * 2, g.nb2, MGM, -1, tag, sa.to, &s_to,
+                                           [&](int idx, double val) { gran_store(sl.gt_gm + ((long long)(g.v0 + vg) * MGM + idx) * 2, val, tag); }, g_stage)) break;
+                    if (!gather_totals(sl.gt_gm, g.V, MGM, -1, tag, sa.to, &s_to, s_tot + 2, s_vt, false)) break;
+                    rs_g = 1;
+                } else if (dec != 0) break;
+            }
+            if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, rs_g, &s_b[n & 1].po);
             __syncthreads();
             K3_WALL(sa.gprof, 40 + 6 * vg + 3);
             if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to,
@@ -546,7 +668,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
         const double phi = s_a.bg.phi_n, phi_prev = s_a.bg.phi_prev, esh = pw == 0.0 ? s_a.bg.e_shift : 0.0, e_center = s_a.bg.e_center;
         const bool entered = sa.enter_mut && n == sa.n_first;   // this stage's correction (and selection) ran as launches: totals in s_tot
-        const int rs = entered ? rs0 : 0;
+        int rs = entered ? rs0 : 0;
         double v = entered ? v_entered : 0.0;
         if (!entered) {
             if constexpr (ALPHA1) {
@@ -590,7 +712,27 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 3);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
-        const int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+        int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+        if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
+            // ================= SELECTION inside the segment (k3_select_inside above): the particle goes through LDS - a call that took it in registers
+            // would cost the stage loop 26 registers and 38 spills for a path one stage in twenty takes
+            double *stt = z_park + (D + 2) * T3;
+            __syncthreads();
+            stt[tid] = v;
+#pragma unroll
+            for (int k = 0; k < D; ++k) stt[(1 + k) * T3 + tid] = x[k];
+            stt[(D + 1) * T3 + tid] = like; stt[(D + 2) * T3 + tid] = lprior; stt[(D + 3) * T3 + tid] = like_prev; stt[(D + 4) * T3 + tid] = acc_val;
+            const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm, sa.to, &s_to, s_tot, s_vt, s_sw,
+                                                red, z_park, stt, po.shift);
+            if (bad) { timed_out = true; break; }
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = stt[(1 + k) * T3 + tid];
+            like = stt[(D + 1) * T3 + tid]; lprior = stt[(D + 2) * T3 + tid]; like_prev = stt[(D + 3) * T3 + tid]; acc_val = stt[(D + 4) * T3 + tid];
+            // this stage's draws again (the parking area was the selection's scratch; they are functions of (seed, particle, stage))
+            k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);
+            __syncthreads();
+            rs = 1; dec = 0;
+        }
         if (dec != 0) {                                         // leave: nothing of the stage is committed, registers hold the cloud after stage n - 1
             if (writer && tid == 0) {
                 if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }

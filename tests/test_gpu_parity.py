@@ -554,7 +554,8 @@ print(json.dumps(dict(n=r["n_stages"], logmdd=r["logmdd"], resamples=r["resample
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
     for mode in ("0", "1", "2"):          # predicted / always the full list / deliberately wrong prediction
-        env = dict(os.environ, SMCMI_NO_SELECT_PREDICT=mode)
+        # (SMCMI_SEG_SELECT=0: a persistent segment leaves at a stage that must resample instead of resampling in place - the stall path this test is about)
+        env = dict(os.environ, SMCMI_NO_SELECT_PREDICT=mode, SMCMI_SEG_SELECT="0")
         res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         out[mode] = json.loads(res.stdout.strip().splitlines()[-1])

@@ -101,14 +101,31 @@ def test_segments_leave_the_bits_of_the_launches(cfg):
 
 
 def test_a_mispredicted_resample_leaves_the_segment_and_is_redone():
-    """SMCMI_NO_SELECT_PREDICT=2: the host expects no stage to resample, so every resample stage is met INSIDE a segment, which leaves
-    with nothing of the stage committed (status 6); the host runs it through the launches and starts the next segment."""
+    """SMCMI_NO_SELECT_PREDICT=2: the host expects no stage to resample, so every resample stage is met INSIDE a segment.  Where the segment
+    cannot resample in place (mixture proposals, several handles; here: SMCMI_SEG_SELECT=0) it leaves with nothing of the stage committed
+    (status 6); the host resumes the stage - correction and selection as launches, a segment entering at its mutation."""
     cfg = dict(n=40_000, d=6, seed=13, spec_args=[6], kw=dict(use_fixed_schedule=False, tempering_target=0.95))
-    a = _run(cfg, {"SMCMI_NO_SELECT_PREDICT": "2"})[0]
+    a = _run(cfg, {"SMCMI_NO_SELECT_PREDICT": "2", "SMCMI_SEG_SELECT": "0"})[0]
     b = _run(cfg, {"SMCMI_NO_SELECT_PREDICT": "2", "SMCMI_ENGINE3": "0"})[0]
     assert a["resamples"] >= 2 and a["stalls"][1] >= a["resamples"] - 1
     for k in _KEYS:
         assert a[k] == b[k], (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("kw", [dict(use_fixed_schedule=True, n_phi=120), dict(use_fixed_schedule=False, tempering_target=0.95),
+                                dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial", n_blocks=2, n_mh_steps=2)],
+                         ids=["fixed", "adaptive", "fixed_multinomial_2blocks"])
+def test_selection_inside_the_segment_leaves_the_bits_of_the_selection_launches(kw):
+    """One handle, α = 1: a stage that must resample does so inside the segment (stage3.hpp k3_select_inside: the workers scan their
+    weights, find their ancestors and total the resampled cloud's moments with k2_scan's / k2_gather's own functions) - no stall, a run of
+    one or two launches, and the bits of a run whose segments leave for the selection launches (SMCMI_SEG_SELECT=0) and of a run of launches."""
+    cfg = dict(n=60_000, d=7, seed=17, spec_args=[7], kw=kw)
+    a = _run(cfg)[0]
+    b = _run(cfg, {"SMCMI_SEG_SELECT": "0"})[0]
+    c = _run(cfg, {"SMCMI_ENGINE3": "0"})[0]
+    assert a["resamples"] >= 3 and a["stalls"][1] == 0 and a["n_segments"] <= 4 and b["n_segments"] > a["resamples"]
+    for k in _KEYS:
+        assert a[k] == b[k] == c[k], (k, a[k], b[k], c[k])
 
 
 def test_a_segment_time_out_repeats_the_run_as_launches():
