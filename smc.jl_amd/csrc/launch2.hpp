@@ -86,11 +86,11 @@ template <int D, bool A1>
 void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10) {
-    const size_t lds = k3_lds_bytes(D, A1);
+    const size_t lds = k3_lds_bytes(D, k3_sel_cols(D, A1));
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl);            // workers, gatherers
     if (!(e->seg_attr_set & (A1 ? 1 : 2))) {   // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
-        hipFuncSetAttribute((const void *)k3_segment<D, A1>, hipFuncAttributeMaxDynamicSharedMemorySize, (A1 ? 136 : 96) * 1024);
+        hipFuncSetAttribute((const void *)k3_segment<D, A1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((k3_lds_bytes(D, k3_sel_cols(D, A1)) + 1023) / 1024 * 1024));
         e->seg_attr_set |= (A1 ? 1 : 2);
     }
     k3_segment<D, A1><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);

@@ -599,7 +599,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (the workers' blocks must be the selection kernels' blocks: one 512-slot tile per moment row - not so when a cloud is cut into 2 or 4
     // long virtual shards of more than 32 rows, whose gather blocks take two tiles each)
     const bool sel_inside = e3 && !seg_sys && g.hs.size() == 1 && d <= 10 && sel_in_env != 0 && h0->d_cum != nullptr && g0.nbg == g0.nb2 && g0.perg == T3 &&
-                            g0.V * g0.nb1 <= 256 && rc->alpha == 1.0;
+                            g0.V * g0.nb1 <= 256 && k3_sel_cols(d, rc->alpha == 1.0) > 0;
     if (sel_inside) {
         Eng2 *e = h0->e2;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;

@@ -278,10 +278,15 @@ static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned lo
 }
 
 constexpr size_t k3_park_offset(int D) { return (k2_lds_bytes(D) + 15) / 16 * 2; }          // in doubles, 16-byte aligned
-// (k2's arrays | the parking area (D + 2) T3 | α = 1 only: the particle in transit through an in-place selection (D + 5) T3 - the mixture
-// variant's static arrays leave no room for it: its segments leave at a stage that must resample)
-constexpr size_t k3_lds_bytes(int D, bool sel_state = false) {
-    return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double) + (sel_state ? (size_t)(D + 5) * T3 * sizeof(double) : 0);
+// (k2's arrays | the parking area (D + 2) T3 | the particle in transit through an in-place selection: (D + 5) T3, see k3_sel_cols)
+constexpr size_t k3_lds_bytes(int D, int sel_cols = 0) {
+    return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double) + (size_t)sel_cols * T3 * sizeof(double);
+}
+// columns of LDS a segment kernel gets for the particle in transit (0: its selection stays outside).  The mixture variant carries
+// T3 x D doubles of static z columns and the dense mixture block: with them and the D + 5 columns a block outgrows a CU's 160 KB beyond n_para 7
+// (24 KB: a bound on the rest of the kernel's static arrays)
+constexpr int k3_sel_cols(int D, bool alpha1) {
+    return (alpha1 || 24 * 1024 + ((size_t)T3 * D + 3 * D * D + 3 * D + 2) * sizeof(double) + k3_lds_bytes(D, D + 5) <= 160 * 1024) ? D + 5 : 0;
 }
 // (MIX = false, α = 1: the mixture-component uniform is never read, so its Philox call is not made at all)
 template <int D, bool MIX = true>
@@ -385,13 +390,13 @@ __device__ inline void k3_leave_note(const Seg3Args &sa, const Ctl2 *ctl) {
 // SELECTION inside the segment (src/smc_main.jl:435-446, src/resample.jl:23-72): what k2_scan + k2_gather do between two launches, by the
 // workers on the particles they hold - the same functions on the same 512-particle blocks, hence the same cum column, ancestors and moment
 // rows.  Two more hand-overs: "every particle and cum value is written" (no payload), and the moment rows of the resampled cloud.
-// Not inlined, and the particle comes and goes through LDS (stt: [W̃ | θ_1..θ_D | loglh | logprior | old_loglh | accept][T3]): the stage loop
-// keeps its registers.  sc: the workers' parking area as scratch.  Returns 1 when a wait timed out.
+// Not inlined, and the particle comes and goes through LDS (stx: [θ_1..θ_D][T3], sto: [W̃ | loglh | logprior | old_loglh | accept][T3]): the
+// stage loop keeps its registers.  sc: the workers' parking area as scratch.  Returns 1 when a wait timed out.
 template <int D>
 __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, double *buf0, long long cl_n, int cl_R, long long Ng, int nchunks, int V, int rowi, long long i,
                                                           long long beg, long long end, unsigned tag, int n, unsigned long long seed, long long gid0,
                                                           const unsigned long long *g_cm, unsigned long long *to, int *s_to, double *s_tot, double *s_vt, double *s_sw,
-                                                          double *red, double *sc, double *stt, const double *shift) {
+                                                          double *red, double *sc, double *stx, double *sto, const double *shift) {
     constexpr int NPm = Mut2Lds<D>::NP, MGM = pad2(NPm), DAm = D + 1, NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     const Sel3Args sl = *selp;
     const int tid = threadIdx.x;
@@ -405,7 +410,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     // (1) my particle as stage n - 1 left it -> buffer 0, agent scope (other dies read it below)
     if (live) {
 #pragma unroll
-        for (int k = 0; k < D + 4; ++k) row_store(buf0 + (long long)k * cl_n + i, stt[(1 + k) * T3 + tid], true);
+        for (int k = 0; k < D + 4; ++k) row_store(buf0 + (long long)k * cl_n + i, k < D ? stx[k * T3 + tid] : sto[(1 + k - D) * T3 + tid], true);
     }
     // (2) the chunk sums = entry 0 of every block's correction row (published under this stage's tag) -> chunk offsets
     if (tid < nchunks) {
@@ -421,7 +426,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     // (3) the cum values of my chunk (k2_scan's arithmetic on W̃)
     {
         double tt;
-        const double incl = sel_tile_scan(live ? stt[tid] : 0.0, s_w, &tt);
+        const double incl = sel_tile_scan(live ? sto[tid] : 0.0, s_w, &tt);
         if (live) row_store(sl.cum + i, (s_off[rowi] + incl) / s_tot[0], true);
     }
     // (4) hand-over: every store above is acknowledged before this block says so
@@ -450,7 +455,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
 #pragma unroll
         for (int q = 0; q < D + 4; ++q) row[q] = load_f64_sc1(cl_rsrc, (unsigned)(((long long)q * cl_n + anc_i) * 8));
 #pragma unroll
-        for (int q = 0; q < D + 4; ++q) stt[(1 + q) * T3 + tid] = row[q];
+        for (int q = 0; q < D + 4; ++q) { if (q < D) stx[q * T3 + tid] = row[q]; else sto[(1 + q - D) * T3 + tid] = row[q]; }
 #pragma unroll
         for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - shift[q];
     }
@@ -716,18 +721,18 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
             // ================= SELECTION inside the segment (k3_select_inside above): the particle goes through LDS - a call that took it in registers
             // would cost the stage loop 26 registers and 38 spills for a path one stage in twenty takes
-            double *stt = z_park + (D + 2) * T3;
+            double *sto = z_park + (D + 2) * T3, *stx = sto + 5 * T3;
             __syncthreads();
-            stt[tid] = v;
+            sto[tid] = v;
 #pragma unroll
-            for (int k = 0; k < D; ++k) stt[(1 + k) * T3 + tid] = x[k];
-            stt[(D + 1) * T3 + tid] = like; stt[(D + 2) * T3 + tid] = lprior; stt[(D + 3) * T3 + tid] = like_prev; stt[(D + 4) * T3 + tid] = acc_val;
+            for (int k = 0; k < D; ++k) stx[k * T3 + tid] = x[k];
+            sto[T3 + tid] = like; sto[2 * T3 + tid] = lprior; sto[3 * T3 + tid] = like_prev; sto[4 * T3 + tid] = acc_val;
             const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm, sa.to, &s_to, s_tot, s_vt, s_sw,
-                                                red, z_park, stt, po.shift);
+                                                red, z_park, stx, sto, po.shift);
             if (bad) { timed_out = true; break; }
 #pragma unroll
-            for (int k = 0; k < D; ++k) x[k] = stt[(1 + k) * T3 + tid];
-            like = stt[(D + 1) * T3 + tid]; lprior = stt[(D + 2) * T3 + tid]; like_prev = stt[(D + 3) * T3 + tid]; acc_val = stt[(D + 4) * T3 + tid];
+            for (int k = 0; k < D; ++k) x[k] = stx[k * T3 + tid];
+            like = sto[T3 + tid]; lprior = sto[2 * T3 + tid]; like_prev = sto[3 * T3 + tid]; acc_val = sto[4 * T3 + tid];
             // this stage's draws again (the parking area was the selection's scratch; they are functions of (seed, particle, stage))
             k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);
             __syncthreads();

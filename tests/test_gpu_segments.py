@@ -113,10 +113,11 @@ def test_a_mispredicted_resample_leaves_the_segment_and_is_redone():
 
 
 @pytest.mark.parametrize("kw", [dict(use_fixed_schedule=True, n_phi=120), dict(use_fixed_schedule=False, tempering_target=0.95),
-                                dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial", n_blocks=2, n_mh_steps=2)],
-                         ids=["fixed", "adaptive", "fixed_multinomial_2blocks"])
+                                dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial", n_blocks=2, n_mh_steps=2),
+                                dict(use_fixed_schedule=False, tempering_target=0.95, alpha=0.9, n_blocks=2)],
+                         ids=["fixed", "adaptive", "fixed_multinomial_2blocks", "adaptive_mixture_2blocks"])
 def test_selection_inside_the_segment_leaves_the_bits_of_the_selection_launches(kw):
-    """One handle, α = 1: a stage that must resample does so inside the segment (stage3.hpp k3_select_inside: the workers scan their
+    """One handle (mixture proposals: n_para <= 7, where the particle in transit still fits a CU's LDS): a stage that must resample does so inside the segment (stage3.hpp k3_select_inside: the workers scan their
     weights, find their ancestors and total the resampled cloud's moments with k2_scan's / k2_gather's own functions) - no stall, a run of
     one or two launches, and the bits of a run whose segments leave for the selection launches (SMCMI_SEG_SELECT=0) and of a run of launches."""
     cfg = dict(n=60_000, d=7, seed=17, spec_args=[7], kw=kw)
