@@ -39,6 +39,9 @@ struct Eng2 {
     unsigned long long *d_rec3 = nullptr, *d_to3 = nullptr, *d_gran3 = nullptr;    // (d_gran3: rows and shard totals as granules)
     int *d_done3 = nullptr;
     smcmi::Sel3Args *d_sel3 = nullptr;    // what a segment's in-place selection needs (stage3.hpp)
+    // host copies of small per-run uploads (members, not locals: the asynchronous copy may read them after the call that issued it has returned)
+    smcmi::Sel3Args h_sel3{};
+    unsigned long long h_to3[2] = {0ull, 0ull};
     unsigned seg_seq = 0;
     // a segment's exit note in host-mapped memory (one handle): [0] = the launch sequence number of the segment that has left, behind it a copy of
     // Ctl2 - the host learns of a batch's end (or of a stage that must resample) without a device-to-host copy and a stream sync

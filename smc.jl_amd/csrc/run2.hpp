@@ -342,9 +342,9 @@ static unsigned mbox_tag(unsigned epoch, unsigned cnt) { return ((epoch & 0x7Fu)
 // Engine 3 serves a single handle in the direct geometry whose blocks are all resident at one per CU; the first use runs the residency
 // self-test (k3_census) and a failure - or SMCMI_ENGINE3=0 - leaves the handle on engine 2's launches for good.
 static int seg3_time_out_words(smcmi_handle *h, double ms) {
-    const unsigned long long fl[2] = {0ull, (unsigned long long)(ms * 1e5)};         // 100 MHz wall clock
-    HIP_TRY(hipMemcpyAsync(h->e2->d_to3, fl, sizeof(fl), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // (in stream order in front of the launches that read the words; the source is a member of the handle: no sync)
+    h->e2->h_to3[0] = 0ull; h->e2->h_to3[1] = (unsigned long long)(ms * 1e5);          // 100 MHz wall clock
+    HIP_TRY(hipMemcpyAsync(h->e2->d_to3, h->e2->h_to3, sizeof(h->e2->h_to3), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 static int seg3_ready(smcmi_handle *h, bool *ok) {
@@ -603,12 +603,12 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (sel_inside) {
         Eng2 *e = h0->e2;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
-        Sel3Args sl{};
+        Sel3Args &sl = e->h_sel3;                                  // (a member: the copy needs no sync)
+        sl = Sel3Args{};
         sl.method = rc->resampling_method; sl.cum = h0->d_cum; sl.anc = h0->d_anc;
         sl.g_sel = e->d_gran3 + nblk * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; sl.gt_sel = sl.g_sel + nblk * 2 * 2;
         sl.g_gm = sl.gt_sel + (size_t)V2_MAXV * 2 * 2; sl.gt_gm = sl.g_gm + nblk * 72 * 2;
         HIP_TRY(hipMemcpyAsync(e->d_sel3, &sl, sizeof(sl), hipMemcpyHostToDevice, h0->stream));
-        HIP_TRY(hipStreamSynchronize(h0->stream));               // (sl is a local)
     }
     static const int note3_on = getenv("SMCMI_SEG_NOTE") ? atoi(getenv("SMCMI_SEG_NOTE")) : 1;      // development: 0 = every batch ends with a copy and a sync
     int force_sel = -1;          // the stage a segment left because it must resample: enqueued with its selection in front of the next segment
