@@ -1128,6 +1128,12 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
             fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the totals %lld | decision + proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the totals %lld | begin %lld | stage %lld\n",
                     h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
+            {
+                long long sp[10];
+                HIP_TRY(hipMemcpy(sp, h0->e2->d_prof + 1300, sizeof(sp), hipMemcpyDeviceToHost));
+                if (sp[9]) fprintf(stderr, "[smcmi3]   selection inside the segment (wall clock, us): particle stored %.2f | chunk offsets %.2f | scan + cum %.2f | stores acknowledged %.2f | hand-over %.2f | chunk ends %.2f | search %.2f | rows gathered %.2f | moment row %.2f | hand-over %.2f\n",
+                                   0.0, (sp[1] - sp[0]) * 0.01, (sp[2] - sp[1]) * 0.01, (sp[3] - sp[2]) * 0.01, (sp[4] - sp[3]) * 0.01, (sp[5] - sp[4]) * 0.01, (sp[6] - sp[5]) * 0.01, (sp[7] - sp[6]) * 0.01, (sp[8] - sp[7]) * 0.01, (sp[9] - sp[8]) * 0.01);
+            }
             fprintf(stderr, "[smcmi3]   decision + proposal: totals -> covariance, shuffle %lld | block matrices %lld | Cholesky + log det %lld | rest %lld\n",
                     pr[30] - pr[3], pr[31] - pr[30], pr[32] - pr[31], pr[4] - pr[32]);
         }

@@ -1133,7 +1133,8 @@ __device__ inline void sel_chunk_offsets(CS cs, int nchunks, double *scratch, do
         scratch[t] = run;
     }
     __syncthreads();
-    if (t == 0) { double carry = 0.0; for (int q = 0; q < 256; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
+    // (threads beyond the last chunk hold 0: the carry past them is never read)
+    if (t == 0) { double carry = 0.0; const int nq = (nchunks + 3) / 4; for (int q = 0; q < nq; ++q) { const double x = scratch[q]; scratch[q] = carry; carry += x; } }
     __syncthreads();
     if (t < 256) {
 #pragma unroll

@@ -396,7 +396,8 @@ template <int D>
 __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, double *buf0, long long cl_n, int cl_R, long long Ng, int nchunks, int V, int rowi, long long i,
                                                           long long beg, long long end, unsigned tag, int n, unsigned long long seed, long long gid0,
                                                           const unsigned long long *g_cm, unsigned long long *to, int *s_to, double *s_tot, double *s_vt, double *s_sw,
-                                                          double *red, double *sc, double *stx, double *sto, const double *shift) {
+                                                          double *red, double *sc, double *stx, double *sto, const double *shift, long long *pf) {
+#define K3S(k) do { if (pf && threadIdx.x == 0) pf[k] = wall_clock64(); } while (0)
     constexpr int NPm = Mut2Lds<D>::NP, MGM = pad2(NPm), DAm = D + 1, NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     const Sel3Args sl = *selp;
     const int tid = threadIdx.x;
@@ -412,6 +413,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
 #pragma unroll
         for (int k = 0; k < D + 4; ++k) row_store(buf0 + (long long)k * cl_n + i, k < D ? stx[k * T3 + tid] : sto[(1 + k - D) * T3 + tid], true);
     }
+    K3S(0);
     // (2) the chunk sums = entry 0 of every block's correction row (published under this stage's tag) -> chunk offsets
     if (tid < nchunks) {
         const unsigned long long *wd = g_cm + (long long)tid * MCM * 2;
@@ -423,17 +425,21 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     __syncthreads();
     if (*s_to) return 1;
     sel_chunk_offsets([&](int b) { return s_cs[b]; }, nchunks, s_scr, s_off);
+    K3S(1);
     // (3) the cum values of my chunk (k2_scan's arithmetic on W̃)
     {
         double tt;
         const double incl = sel_tile_scan(live ? sto[tid] : 0.0, s_w, &tt);
         if (live) row_store(sl.cum + i, (s_off[rowi] + incl) / s_tot[0], true);
     }
+    K3S(2);
     // (4) hand-over: every store above is acknowledged before this block says so
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    K3S(3);
     if (tid < 2) gran_store(sl.g_sel + ((long long)rowi * 2 + tid) * 2, 0.0, tag);
     if (!gather_totals(sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false)) return 1;
+    K3S(4);
     // (5) ancestors of my output slots
     double u_sys = 0.0, ub_;
     if (sl.method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub_);
@@ -441,9 +447,11 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     const int ncg = (int)((Ng + SEL_GCH - 1) / SEL_GCH);
     const bool staged = sl.method != SMCMI_RESAMPLE_MULTINOMIAL && ncg <= 256;
     if (staged) sel_chunk_ends(ldcum, 0, Ng, ncg, s_ce);
+    K3S(5);
     const long long slot = gid0 + (live ? i : (end > beg ? end - 1 : 0));
     const double ua = sel_threshold(sl.method, seed, slot, n, u_sys, Ng);
     const long long anc_i = (end > beg) ? sel_search_tile(ua, staged, ncg, s_ce, s_cw, s_r, ldcum, 0, Ng, cap_w) : 0;
+    K3S(6);
     // (6) the ancestor's row becomes my particle
     double xx[DAm];
     xx[0] = 1.0;
@@ -459,6 +467,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
 #pragma unroll
         for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - shift[q];
     }
+    K3S(7);
     // (7) the moment row of my block (pair sums x̃_a x̃_b about the shift, all weights 1: 0 + x̃_a x̃_b is the accumulator k2_gather holds for a
     // block's only tile), published; (8) the totals of the resampled cloud's moments replace the correction's
     unsigned long long *my_gm = sl.g_gm + (long long)rowi * MGM * 2;
@@ -475,8 +484,11 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
         });
     }, [&](int idx, double val) { gran_store(my_gm + idx * 2, val, tag); });
     if (tid >= NPm && tid < MGM) gran_store(my_gm + tid * 2, 0.0, tag);
+    K3S(8);
     if (!gather_totals(sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false)) return 1;
+    K3S(9);
     return 0;
+#undef K3S
 }
 
 // grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard).
@@ -728,7 +740,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             for (int k = 0; k < D; ++k) stx[k * T3 + tid] = x[k];
             sto[T3 + tid] = like; sto[2 * T3 + tid] = lprior; sto[3 * T3 + tid] = like_prev; sto[4 * T3 + tid] = acc_val;
             const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm, sa.to, &s_to, s_tot, s_vt, s_sw,
-                                                red, z_park, stx, sto, po.shift);
+                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr);
             if (bad) { timed_out = true; break; }
 #pragma unroll
             for (int k = 0; k < D; ++k) x[k] = stx[k * T3 + tid];
