@@ -74,6 +74,9 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;                        // whole passes of the block
     g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? 32 : 256));
     g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
+    // (a virtual shard of at most 256 particles: one gather block of ONE 512-slot tile all the same - the block a segment worker is, so that
+    // clouds of a few thousand particles resample inside their segments too)
+    if (g.direct && g.perg < 512) g.perg = 512;
     if ((long long)g.V * g.nb1 > 1024) return false;
     *out = g;
     return true;
@@ -98,6 +101,7 @@ static bool make_geo2_uneven(const smcmi_handle *h, Geo2 *out) {
         g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;
         g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, 32));
         g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
+        if (g.perg < 512) g.perg = 512;
         *out = g;
         return true;
     }
