@@ -396,7 +396,7 @@ template <int D>
 __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, double *buf0, long long cl_n, int cl_R, long long Ng, int nchunks, int V, int rowi, long long i,
                                                           long long beg, long long end, unsigned tag, int n, unsigned long long seed, long long gid0,
                                                           const unsigned long long *g_cm, unsigned long long *to, int *s_to, double *s_tot, double *s_vt, double *s_sw,
-                                                          double *red, double *sc, double *stx, double *sto, const double *shift, long long *pf) {
+                                                          double *red, double *sc, double *stx, double *sto, const double *shift, long long *pf, bool rows_direct) {
 #define K3S(k) do { if (pf && threadIdx.x == 0) pf[k] = wall_clock64(); } while (0)
     constexpr int NPm = Mut2Lds<D>::NP, MGM = pad2(NPm), DAm = D + 1, NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     const Sel3Args sl = *selp;
@@ -438,7 +438,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     __syncthreads();
     K3S(3);
     if (tid < 2) gran_store(sl.g_sel + ((long long)rowi * 2 + tid) * 2, 0.0, tag);
-    if (!gather_totals(sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false)) return 1;
+    if (!gather_totals(rows_direct ? sl.g_sel : sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false)) return 1;
     K3S(4);
     // (5) ancestors of my output slots
     double u_sys = 0.0, ub_;
@@ -485,7 +485,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     }, [&](int idx, double val) { gran_store(my_gm + idx * 2, val, tag); });
     if (tid >= NPm && tid < MGM) gran_store(my_gm + tid * 2, 0.0, tag);
     K3S(8);
-    if (!gather_totals(sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false)) return 1;
+    if (!gather_totals(rows_direct ? sl.g_gm : sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false)) return 1;
     K3S(9);
     return 0;
 #undef K3S
@@ -674,6 +674,11 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     int done = 0;
     bool timed_out = false;
     unsigned long long *my_cm = sa.g_cm + (long long)rowi * MCM * 2, *my_mut = sa.g_mut + (long long)rowi * RMUT * 2;
+    // one handle whose virtual shards are ONE block each (clouds of up to 4 096 particles): a shard's total is its only row (the canonical
+    // sum of one row adds zeros to it), so every worker takes the V rows themselves - one hop per hand-over instead of two; the gatherers
+    // still run and post totals (they follow the decisions with them), nobody waits for them
+    const bool rows_direct = g.nb2 == 1 && !sys;
+    const unsigned long long *t_cm = rows_direct ? sa.g_cm : sa.gt_cm, *t_mut = rows_direct ? sa.g_mut : sa.gt_mut;
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
         RecB3<D> &B = s_b[n & 1];
@@ -725,7 +730,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 2);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-        if (!entered && !gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) { timed_out = true; break; }
+        if (!entered && !gather_totals(t_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
@@ -740,7 +745,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             for (int k = 0; k < D; ++k) stx[k * T3 + tid] = x[k];
             sto[T3 + tid] = like; sto[2 * T3 + tid] = lprior; sto[3 * T3 + tid] = like_prev; sto[4 * T3 + tid] = acc_val;
             const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm, sa.to, &s_to, s_tot, s_vt, s_sw,
-                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr);
+                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr, rows_direct);
             if (bad) { timed_out = true; break; }
 #pragma unroll
             for (int k = 0; k < D; ++k) x[k] = stx[k * T3 + tid];
@@ -813,7 +818,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (n < sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
         // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-        if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
+        if (!gather_totals(t_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
         K3_STAMP(sa.prof, 8);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
         const int act = next_begin(B.po);
