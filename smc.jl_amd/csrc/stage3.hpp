@@ -208,28 +208,48 @@ __device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int 
 // no block barrier stands between the wait and the fetch; after the one barrier thread k adds column k over the shards in ascending order.
 // sys: the table is this handle's copy in fine-grained memory, posted into by the gatherers of every handle (system-scope loads);
 // vt: LDS, V2_MAXV * m doubles; vt_out (one block): the per-shard values as plain doubles [nvs][m] for the launch behind the segment
+// RPS = 2: tbl is the workers' ROW table of a cloud whose virtual shards are two blocks each (the reference's default 5 000 particles: up to
+// 8 192) - wavefront v fetches shard v's two rows and totals them as gather_vshard would (a row per slice: 0 + x; their sum; the identity for
+// the six missing slices; 0 + that), so no worker waits for a gatherer.  (Four rows per shard the same way, inline, cost the stage loop 14
+// spilled registers - config 2 8.18 -> 8.41 ms - and a non-inlined fetch of up to eight rows was no faster than the gatherers: measured, dropped.)
+template <int RPS = 1>
 __device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int m, int max_idx, unsigned tag, unsigned long long *to, int *s_to, double *tot,
                                      double *vt, bool sys = false, double *vt_out = nullptr) {
     const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     if (w < nvs) {                                                          // (wave-uniform)
-        const unsigned long long *row = tbl + (long long)w * m * 2;
-        if (lane == 0) gran_poll(row, tag, to, s_to, sys);
-        const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(row), (long long)m * 16);
+        const unsigned long long *row = tbl + (long long)w * RPS * m * 2;
+        if (lane < RPS) gran_poll(row + (long long)lane * m * 2, tag, to, s_to, sys);
+        const __amdgpu_buffer_rsrc_t rsrc = rows_rsrc(reinterpret_cast<const double *>(row), (long long)RPS * m * 16);
         const long long t_begin = wall_clock64();
         for (;;) {
             int bad = 0;
-            u32x4_t xs[2];                                                  // m <= 128
+            u32x4_t xs[2][RPS];                                             // m <= 128
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int k = lane + 64 * q, off = (k < m ? k : m - 1) * 16;
-                xs[q] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, /*sc0 sc1: system scope*/ 17) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+                const int k = lane + 64 * q;
+#pragma unroll
+                for (int r = 0; r < RPS; ++r) {
+                    const int off = (r * m + (k < m ? k : m - 1)) * 16;
+                    xs[q][r] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, /*sc0 sc1: system scope*/ 17) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int k = lane + 64 * q;
                 if (k < m) {
-                    bad |= (xs[q].y != tag) | (xs[q].w != tag);
-                    vt[w * m + k] = __hiloint2double((int)xs[q].z, (int)xs[q].x);
+                    if constexpr (RPS == 1) {
+                        bad |= (xs[q][0].y != tag) | (xs[q][0].w != tag);
+                        vt[w * m + k] = __hiloint2double((int)xs[q][0].z, (int)xs[q][0].x);
+                    } else {
+                        bad |= (xs[q][0].y != tag) | (xs[q][0].w != tag) | (xs[q][1].y != tag) | (xs[q][1].w != tag);
+                        const double x0 = __hiloint2double((int)xs[q][0].z, (int)xs[q][0].x), x1 = __hiloint2double((int)xs[q][1].z, (int)xs[q][1].x);
+                        const bool mx = k == max_idx;
+                        const double ninf = -__builtin_inf();
+                        double p;
+                        if (mx) { p = fmax(fmax(ninf, x0), fmax(ninf, x1)); p = fmax(p, ninf); p = fmax(p, ninf); p = fmax(ninf, p); }
+                        else { p = (0.0 + x0) + (0.0 + x1); p = p + 0.0; p = p + 0.0; p = 0.0 + p; }
+                        vt[w * m + k] = p;
+                    }
                 }
             }
             if (!__any(bad)) break;
@@ -396,7 +416,7 @@ template <int D>
 __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, double *buf0, long long cl_n, int cl_R, long long Ng, int nchunks, int V, int rowi, long long i,
                                                           long long beg, long long end, unsigned tag, int n, unsigned long long seed, long long gid0,
                                                           const unsigned long long *g_cm, unsigned long long *to, int *s_to, double *s_tot, double *s_vt, double *s_sw,
-                                                          double *red, double *sc, double *stx, double *sto, const double *shift, long long *pf, bool rows_direct) {
+                                                          double *red, double *sc, double *stx, double *sto, const double *shift, long long *pf, bool rows_direct, bool rows_two) {
 #define K3S(k) do { if (pf && threadIdx.x == 0) pf[k] = wall_clock64(); } while (0)
     constexpr int NPm = Mut2Lds<D>::NP, MGM = pad2(NPm), DAm = D + 1, NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     const Sel3Args sl = *selp;
@@ -438,7 +458,8 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     __syncthreads();
     K3S(3);
     if (tid < 2) gran_store(sl.g_sel + ((long long)rowi * 2 + tid) * 2, 0.0, tag);
-    if (!gather_totals(rows_direct ? sl.g_sel : sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false)) return 1;
+    if (!(rows_two ? gather_totals<2>(sl.g_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt)
+                   : gather_totals(rows_direct ? sl.g_sel : sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false))) return 1;
     K3S(4);
     // (5) ancestors of my output slots
     double u_sys = 0.0, ub_;
@@ -485,7 +506,8 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     }, [&](int idx, double val) { gran_store(my_gm + idx * 2, val, tag); });
     if (tid >= NPm && tid < MGM) gran_store(my_gm + tid * 2, 0.0, tag);
     K3S(8);
-    if (!gather_totals(rows_direct ? sl.g_gm : sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false)) return 1;
+    if (!(rows_two ? gather_totals<2>(sl.g_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt)
+                   : gather_totals(rows_direct ? sl.g_gm : sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false))) return 1;
     K3S(9);
     return 0;
 #undef K3S
@@ -678,6 +700,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     // sum of one row adds zeros to it), so every worker takes the V rows themselves - one hop per hand-over instead of two; the gatherers
     // still run and post totals (they follow the decisions with them), nobody waits for them
     const bool rows_direct = g.nb2 == 1 && !sys;
+    const bool rows_two = g.nb2 == 2 && !sys;                    // ... two blocks each (up to 8 192 particles: the reference's default 5 000): gather_totals<2>
     const unsigned long long *t_cm = rows_direct ? sa.g_cm : sa.gt_cm, *t_mut = rows_direct ? sa.g_mut : sa.gt_mut;
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
@@ -730,7 +753,8 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 2);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-        if (!entered && !gather_totals(t_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) { timed_out = true; break; }
+        if (!entered && !(rows_two ? gather_totals<2>(sa.g_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt)
+                                   : gather_totals(t_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys))) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
@@ -745,7 +769,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             for (int k = 0; k < D; ++k) stx[k * T3 + tid] = x[k];
             sto[T3 + tid] = like; sto[2 * T3 + tid] = lprior; sto[3 * T3 + tid] = like_prev; sto[4 * T3 + tid] = acc_val;
             const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm, sa.to, &s_to, s_tot, s_vt, s_sw,
-                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr, rows_direct);
+                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr, rows_direct, rows_two);
             if (bad) { timed_out = true; break; }
 #pragma unroll
             for (int k = 0; k < D; ++k) x[k] = stx[k * T3 + tid];
@@ -818,7 +842,8 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (n < sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
         K3_STAMP(sa.prof, 7);
         // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-        if (!gather_totals(t_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys, (writer && sys) ? sa.vt_mut_out : nullptr)) { timed_out = true; break; }
+        if (!(rows_two ? gather_totals<2>(sa.g_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt)
+                       : gather_totals(t_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys, (writer && sys) ? sa.vt_mut_out : nullptr))) { timed_out = true; break; }
         K3_STAMP(sa.prof, 8);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
         const int act = next_begin(B.po);
