@@ -103,6 +103,14 @@ typedef struct {
                                 resample nor need a certificate pass execute as one launch each) */
     int32_t segment_stages;  /* stages those launches completed (use_graph = 2: the stages behind kernel_ms_segments) */
     double kernel_ms_segments; /* HIP-event time of the segment launches (use_graph = 2, else 0) */
+    int32_t segment_blocks;  /* blocks (one per CU, all resident) of a segment launch of this run: workers + gatherers; 0: the run had no segment */
+    int32_t segment_state;   /* the handle's persistent-segment state after the run: 1 the residency self-test passed; 0 segments do not apply to this
+                                cloud / were not tried; -1 the self-test failed or a hand-over timed out (e.g. a partitioned or shared GPU where
+                                not every block is resident): every later run of the handle uses launches only */
+    int32_t segment_timeouts;/* runs of this handle so far that met a hand-over time-out inside a segment and were repeated as launches from the
+                                cloud they started with (each cost its time-out, SMCMI_SEG_TIMEOUT_MS, before the repeat) */
+    int32_t shift_fallback_stage; /* fixed schedules: the stage from which the run shifted the incremental weights by the cloud's CURRENT largest
+                                energy because a stage's sums overflowed under the lagged shift of the one-hand-over stage; 0: never (the rule) */
 } smcmi_result;
 
 typedef struct {             /* the loop scalars an intermediate save holds (smc_main.jl:499-507: cloud fields + j) */
@@ -140,9 +148,12 @@ int smcmi_set_likelihood(smcmi_handle *h, int32_t which, int32_t family, const d
    theta[k + m*j], j < d) holding only proposals that passed the bounds check; write out[k] = log-likelihood (-Inf allowed, NaN is
    taken as -Inf like the reference's try/catch); return 0, anything else aborts smcmi_run with SMCMI_ERR_CALLBACK.  Invoked
    synchronously on the thread that called smcmi_run / smcmi_initialize_likelihoods / smcmi_eval_cloud_callback, never from another
-   thread.  Inside smcmi_run / smcmi_run_sharded the batch of one MH step x block arrives in up to 8 CHUNKS of consecutive particles
-   (none smaller than 12 288 proposals): one invocation per chunk (two with an old-data callback), each on its own m x d block, while
-   the next chunk is still crossing PCIe; the results do not depend on the chunking.  which = SMCMI_WHICH_NEW: loglikelihood(parameters, data);
+   thread.  Inside smcmi_run / smcmi_run_sharded the batch of one MH step x block arrives in K = min(8, max(1, n / 12288)) CHUNKS of
+   ceil(n / K) consecutive particles, the last one possibly shorter (n = 98 305: 7 x 12 289 + 12 282; a shard below 24 576 particles: one
+   chunk = the batch): one invocation per chunk (two with an old-data callback), each on its own m x d block, while the next chunk is
+   still crossing PCIe; the results do not depend on the chunking, smcmi_callback_stats counts invocations = chunks.  A callback that
+   keeps per-batch state or counts its invocations sets SMCMI_CB_CHUNKS=1 in the environment (whole batches, one invocation per MH step x
+   block as in rounds 1-4).  which = SMCMI_WHICH_NEW: loglikelihood(parameters, data);
    SMCMI_WHICH_OLD: old_loglikelihood(parameters, old_data) (tempered updates; leave unset when old_data is empty).  fn = NULL
    unregisters.  With a callback registered smcmi_run keeps ϕ solver, correction, selection, moments, proposal and the MH decision
    on the device and ships only the n x d proposals and the n log-likelihoods across PCIe per step. */

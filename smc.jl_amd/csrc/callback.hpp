@@ -70,8 +70,9 @@ static int ensure_callback_buffers(smcmi_handle *h) {
     h->cbuf = b;
     return 0;
 }
-// chunks a batch of n proposals crosses PCIe in: <= 8, none smaller than 12 288 particles (a chunk costs an event wait and an invocation of the
-// user's function: ~20 µs); SMCMI_CB_CHUNKS=<k> (development: 1 = the whole batch at once, the phase profile's serial reference)
+// chunks a batch of n proposals crosses PCIe in: K = min(8, n / 12288) chunks of ceil(n / K) particles, the last one possibly shorter (a chunk
+// costs an event wait and an invocation of the user's function: ~20 µs); SMCMI_CB_CHUNKS=<k> (1 = the whole batch at once: the documented
+// opt-out for callbacks with per-batch state, include/smcmi.h, and the phase profile's serial reference)
 static int callback_chunks(long long n) {
     static const int forced = getenv("SMCMI_CB_CHUNKS") ? atoi(getenv("SMCMI_CB_CHUNKS")) : 0;
     if (forced > 0) return std::min(forced, CB_MAX_CHUNKS);
@@ -289,6 +290,7 @@ static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resul
     } else {
         const int cur = s.cur;
         memset(&s, 0, sizeof(DevState));
+        s.e_seen = __builtin_nan("");
         s.rp = rp; s.cur = cur;
         s.stage = 1; s.j = 2;
         s.c = rc->c; s.accept = rc->target;

@@ -65,7 +65,8 @@ struct RunParams {             // smc() kwargs, uploaded once per run
     int store_history;
     int stall_on_exhaust;      // out of solver passes: 1 = stall the run (done = 2) for the host to resume, 0 = accept the bracket
     int stop_stage;            // > 0: pause (done = 5) once stage_index has reached it (intermediate saves, smc_main.jl:499-507)
-    int pad_;
+    int shift_lag;             // engines 2 / 3, fixed schedules: the energy shift of a stage's incremental weights is the cloud's largest energy
+                               // one mutation earlier than the latest (stage2.hpp Begin2::e_seen) - a stage then needs ONE chip-wide hand-over
     double threshold;          // threshold_ratio * n_parts (:203)
     double alpha, target;
     double tempering_target;
@@ -114,6 +115,7 @@ struct DevState {
     double e_shift;            // energy shift of this stage's incremental weights (largest loglh - old_loglh of the cloud; 0 = none)
     int skip_fold;             // continued run: the acceptance / energy sums of the last mutation are already folded (or were never here)
     int pad2_;
+    double e_seen;             // engines 2 / 3: Post2::e_seen across a pause (NaN: none)
     Solver sol[2];
     // ---- moments / proposal (smc_main.jl:457-469, mutation.jl:81)
     double shift[MAXD];        // centering used by the one-pass moment kernel (previous mean)

@@ -39,6 +39,7 @@ struct Eng2 {
     unsigned long long *d_rec3 = nullptr, *d_to3 = nullptr, *d_gran3 = nullptr;    // (d_gran3: rows and shard totals as granules)
     int *d_done3 = nullptr;
     smcmi::Sel3Args *d_sel3 = nullptr;    // what a segment's in-place selection needs (stage3.hpp)
+    double *d_transit3 = nullptr;         // ... where its workers park their particles when the kernel's LDS has no room (Sel3Args::transit)
     // host copies of small per-run uploads (members, not locals: the asynchronous copy may read them after the call that issued it has returned)
     smcmi::Sel3Args h_sel3{};
     unsigned long long h_to3[2] = {0ull, 0ull};
@@ -47,7 +48,7 @@ struct Eng2 {
     // Ctl2 - the host learns of a batch's end (or of a stage that must resample) without a device-to-host copy and a stream sync
     void *h_note3 = nullptr, *d_note3 = nullptr;
     int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle
-    int seg_attr_set = 0;         /* bit 0: α = 1 variant, bit 1: mixture variant */       // k3_segment's dynamic-LDS opt-in done on this handle's device
+    int seg_attr_set = 0;         /* bits 0 / 1: α = 1 / mixture variant, bits 2 / 3: their riding instantiations */       // k3_segment's dynamic-LDS opt-in done on this handle's device
     bool wide_attr_set = false;      // k2w_mutate's dynamic-LDS opt-in done on this handle's device
     bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
     int n_steps = 1, n_blocks = 1;
@@ -92,6 +93,7 @@ struct smcmi_handle {
     unsigned mbox_epoch = 0;
     double *d_snap = nullptr;         // single-handle runs that may use engine 3: the cloud the run started from and, behind it, its DevState (repeat after a segment time-out)
     int seg_timeouts = 0;             // runs repeated as launches after a segment time-out
+    int h_lag0 = 0;                   // source of an asynchronous copy (run2.hpp: RunParams::shift_lag switched off in mid-run)
     double *d_mix = nullptr;          // register mutation kernel, α < 1: dense mixture matrices per block (k_mix_prepare)
     int *d_mixpos = nullptr;
     // host-callback split

@@ -81,25 +81,31 @@ void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10) k2_prepare<D><<<1, 256, k2_lds_bytes(D), h->stream>>>(h->d_st, e->d_ctl, h->d_model, mp, nb, h->h_model.n_free, e->d_pre);
 }
-// one instantiation per (n_para, α = 1?): the two variants are compiled with different flags (Makefile SEGFLAGS / SEGFLAGS_MIX)
-template <int D, bool A1>
+// one instantiation per (n_para, α = 1?, riding?): the proposal kinds are compiled with different flags (Makefile SEGFLAGS / SEGFLAGS_MIX).
+// RIDE: fixed schedules under RunParams::shift_lag on one handle - a stage's correction row rides the mutation row in front of it (stage3.hpp k3_rides)
+template <int D, bool A1, bool RIDE>
 void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10) {
     const size_t lds = k3_lds_bytes(D, k3_sel_cols(D, A1));
-    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + e->g.Vl);            // workers, gatherers
-    if (!(e->seg_attr_set & (A1 ? 1 : 2))) {   // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
+    // workers + one gatherer per virtual shard.  One handle whose virtual shards are one or two blocks (stage3.hpp rows_direct / rows_two): the
+    // workers take each other's rows themselves and nobody reads a gatherer's totals - none is launched (a gatherer that nothing waits for has
+    // no flow control: one stage behind, it would poll for a tag its rows have already left and raise the waits' abort word)
+    const bool gatherers = !(e->g.nb2 <= 2 && sa.peers == nullptr);
+    const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + (gatherers ? e->g.Vl : 0));
+    constexpr int attr_bit = (A1 ? 1 : 2) << (RIDE ? 2 : 0);
+    if (!(e->seg_attr_set & attr_bit)) {       // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
-        hipFuncSetAttribute((const void *)k3_segment<D, A1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((k3_lds_bytes(D, k3_sel_cols(D, A1)) + 1023) / 1024 * 1024));
-        e->seg_attr_set |= (A1 ? 1 : 2);
+        hipFuncSetAttribute((const void *)k3_segment<D, A1, RIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((k3_lds_bytes(D, k3_sel_cols(D, A1)) + 1023) / 1024 * 1024));
+        e->seg_attr_set |= attr_bit;
     }
-    k3_segment<D, A1><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+    k3_segment<D, A1, RIDE><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
     }
 }
 template <int D>
-inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1) {
-    if (alpha1) launch_k3_seg<D, true>(h, ma, sa, nb);
-    else launch_k3_seg<D, false>(h, ma, sa, nb);
+inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1, bool ride) {
+    if (alpha1) { if (ride) launch_k3_seg<D, true, true>(h, ma, sa, nb); else launch_k3_seg<D, true, false>(h, ma, sa, nb); }
+    else { if (ride) launch_k3_seg<D, false, true>(h, ma, sa, nb); else launch_k3_seg<D, false, false>(h, ma, sa, nb); }
 }
 
 #define SMCMI_LAUNCH2_INSTANCES(X, D)                                                                                              \
@@ -112,28 +118,30 @@ inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Arg
 // stage; hoisted computations sunk back into the stage loop (-sink-insts-to-avoid-spills) 72 B, 35.6 µs; no machine LICM instead 229 VGPRs,
 // no spill, 35.2 µs (both together: 36.6).  The mixture variant needs both (251 VGPRs, no spill, 42.5 µs; LICM off alone: 77 spilled
 // registers, 45.3 µs).  K1 / K2 and the generic mutation kernels lose 1-2 % to the sinking and are indifferent to the LICM switch.
-#define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_seg<D, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
-                                      X template void launch_k3_seg<D, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
-#define SMCMI_LAUNCH3_ONE(D, A) template void launch_k3_seg<D, A>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+#define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_seg<D, true, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, false, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, true, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, false, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+#define SMCMI_LAUNCH3_ONE(D, A, R) template void launch_k3_seg<D, A, R>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
 #define SMCMI_LAUNCH2B_INSTANCES(X, D) X template void launch_k2b_mutate<D>(smcmi_handle *, const Mut2Args &, const Beg2Args &, int, bool);
 #define SMCMI_LAUNCH_ALL_D(M, X)                                                                                                          \
     M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10) M(X, 11) M(X, 12) M(X, 13) M(X, 14) M(X, 15) M(X, 16)
-// (the large-shard mutation kernel exists for n_para <= 10: beyond that the launcher is empty and instantiated where it is called)
+// (the large-shard mutation kernel and the segment kernel exist for n_para <= 10: beyond that the launchers are empty and instantiated where they are called)
 #define SMCMI_LAUNCH_B_D(M, X) M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10)
 #if defined(SMCMI_INST_D)
 SMCMI_LAUNCH2_INSTANCES(, SMCMI_INST_D)
-SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
+SMCMI_LAUNCH_B_D(SMCMI_LAUNCH3_INSTANCES, extern)
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST3_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
-SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0))
+SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0), (SMCMI_INST3_R != 0))
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST2B_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
-SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
+SMCMI_LAUNCH_B_D(SMCMI_LAUNCH3_INSTANCES, extern)
 SMCMI_LAUNCH2B_INSTANCES(, SMCMI_INST2B_D)
 #else
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
-SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH3_INSTANCES, extern)
+SMCMI_LAUNCH_B_D(SMCMI_LAUNCH3_INSTANCES, extern)
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #endif

@@ -19,7 +19,7 @@ constexpr int PROF2_BLOCKS = 4096;
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
-                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_ranges_all, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3, e->d_sel3};
+                    e->vt_gm, e->vt_pass, e->d_ranges, e->d_ranges_all, e->d_prof, e->d_pre, e->d_tick, e->d_tick3, e->d_rec3, e->d_to3, e->d_done3, e->d_gran3, e->d_sel3, e->d_transit3};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_note3) hipHostFree(e->h_note3);
@@ -108,10 +108,19 @@ static bool make_geo2_uneven(const smcmi_handle *h, Geo2 *out) {
     return false;
 }
 
+// The geometry a handle gets (ensure_eng2 builds it, eng2_eligible asks whether engine 2 serves it: ONE rule for both).  `single`: a run of
+// smcmi_run on one handle - not a communicator of one rank, whose handle keeps the geometry its larger worlds have.  The uneven cut replaces
+// only a geometry that would send the handle to engine 1; a cloud forced onto engine 2 (SMCMI_ENGINE=2) keeps the canonical cut a sharded
+// run of the same cloud has, so the file's contract - results do not depend on the number of handles - holds for it.
+static bool handle_geo2(const smcmi_handle *h, int world, int rank, bool single, Geo2 *out) {
+    static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 0;
+    if (!make_geo2(h, world, rank, single, out)) return false;
+    if (single && world == 1 && !out->wide && !out->direct && eng != 2) { Geo2 gu; if (make_geo2_uneven(h, &gu)) *out = gu; }
+    return true;
+}
 static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
     Geo2 g;
-    if (!make_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
-    if (single && world == 1 && !g.wide && !g.direct) { Geo2 gu; if (make_geo2_uneven(h, &gu)) g = gu; }
+    if (!handle_geo2(h, world, rank, single, &g)) return set_err(SMCMI_ERR_UNSUPPORTED, "engine 2: unsupported shard geometry");
     if (h->e2 && h->e2->world == world && h->e2->g.direct == g.direct && h->e2->g.inker == g.inker && h->e2->g.nb2 == g.nb2 && h->e2->g.v0 == g.v0 && h->e2->g.t2 == g.t2 && h->e2->g.nb1 == g.nb1 && h->e2->g.wide == g.wide && h->e2->g.V == g.V && h->e2->g.nv == g.nv) return 0;
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     Eng2 *e = new Eng2();
@@ -161,17 +170,16 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
 // results independent of the number of handles).  A single handle with a larger cloud keeps engine 1: its kernels fill the chip
 // there and one-block set-up launches are cheap next to them (engine 2's reduced geometry measured 10-15 % behind at N >= 1e6).
 // SMCMI_ENGINE=1 / =2 force one engine wherever it can run (development, tests).
-static bool eng2_eligible(const smcmi_handle *h, int world) {
+static bool eng2_eligible(const smcmi_handle *h, int world, bool single) {
     static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 0;
     if (eng == 1 || h->d > 16) return false;
     Geo2 g;
-    if (!make_geo2(h, world, 0, world == 1, &g)) return false;
-    if (world == 1 && !g.wide && !g.direct) { Geo2 gu; if (make_geo2_uneven(h, &gu)) g = gu; }
+    if (!handle_geo2(h, world, 0, single, &g)) return false;
     if (g.wide) {                     // n_para 11 .. 16: the same two-launch stage around the generic mutation body (SMCMI_ENGINE_WIDE=0: engine 1's stage)
         static const int wide_on = getenv("SMCMI_ENGINE_WIDE") ? atoi(getenv("SMCMI_ENGINE_WIDE")) : 1;
         return wide_on != 0;
     }
-    return eng == 2 || world > 1 || g.direct;
+    return eng == 2 || world > 1 || !single || g.direct;      // (a communicator of one rank is a sharded run: the measurement vehicle for one rank's share)
 }
 
 // the row totals of K1 / K2 are taken by the last block of each virtual shard instead of a k2_reduce launch, while the mutation
@@ -396,6 +404,15 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     const bool cont = rc->continue_run != 0;
     std::vector<double> sched(rc->n_phi);
     for (int k = 0; k < rc->n_phi; ++k) sched[k] = pow((double)k / (double)(rc->n_phi - 1), rc->lambda);
+    // Fixed schedules (the reference's default, src/smc_main.jl:139,386-387): the energy shift of a stage's incremental weights lags the cloud's
+    // largest energy by one mutation (stage2.hpp Begin2::e_seen), so that inside a persistent segment a stage is ONE hand-over (stage3.hpp
+    // k3_rides).  The rule belongs to the run, not to the engine: launches, segments and any number of handles apply it alike and leave the
+    // same bits.  A shift is a common factor of all weights - W, ESS and log-MDD do not depend on it beyond rounding - but a lagged one does not
+    // bound the weights by 1: should a stage's sums overflow (the cloud's largest energy grew by more than ~350 / (ϕ_n - ϕ_{n-1}) in one
+    // mutation), the run goes on from that stage with the exact shift (below, at the batch's sync).  SMCMI_SHIFT_LAG=0: exact shifts from the
+    // start; =<k >= 3> (development): stage k's lagged shift is made to overflow.
+    static const int lag_env = getenv("SMCMI_SHIFT_LAG") ? atoi(getenv("SMCMI_SHIFT_LAG")) : 1;
+    bool shift_lag = !adaptive && lag_env != 0;
     // ---- per-handle set-up: run parameters and the stage-1 state in DevState (as engine 1), then imported into Ctl2
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
@@ -417,6 +434,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         rp.stall_on_exhaust = 1;
         rp.phi_rtol = rc->phi_rtol > 0.0 ? rc->phi_rtol : (rc->phi_rtol < 0.0 ? 0.0 : DEFAULT_PHI_RTOL);
         rp.stop_stage = rc->stop_after_stage > 0 ? rc->stop_after_stage : 0;
+        rp.shift_lag = shift_lag ? std::max(lag_env, 1) : 0;
         if (cont) {
             if (s.stage < 1 || s.stage >= h->cfg.max_stages) return set_err(SMCMI_ERR_STATE, "no loop state to continue from");
             if (s.phi_n >= 1.0) return set_err(SMCMI_ERR_STATE, "the run to continue has already reached phi = 1");
@@ -425,6 +443,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         } else {
             const int cur = s.cur;
             memset(&s, 0, sizeof(DevState));
+        s.e_seen = __builtin_nan("");
             s.rp = rp; s.cur = cur;
             s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
             s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
@@ -603,18 +622,26 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (the workers' blocks must be the selection kernels' blocks: one 512-slot tile per moment row - not so when a cloud is cut into 2 or 4
     // long virtual shards of more than 32 rows, whose gather blocks take two tiles each)
     const bool sel_inside = e3 && !seg_sys && g.hs.size() == 1 && d <= 10 && sel_in_env != 0 && h0->d_cum != nullptr && g0.nbg == g0.nb2 && g0.perg == T3 &&
-                            g0.V * g0.nb1 <= 256 && k3_sel_cols(d, rc->alpha == 1.0) > 0;
+                            g0.V * g0.nb1 <= 256;
     if (sel_inside) {
         Eng2 *e = h0->e2;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         Sel3Args &sl = e->h_sel3;                                  // (a member: the copy needs no sync)
         sl = Sel3Args{};
         sl.method = rc->resampling_method; sl.cum = h0->d_cum; sl.anc = h0->d_anc;
+        if (k3_sel_cols(d, rc->alpha == 1.0) == 0) {               // (mixture proposals beyond n_para 7: the particle in transit does not fit the kernel's LDS)
+            if (!e->d_transit3 && dmalloc(&e->d_transit3, nblk * (size_t)(d + 5) * T3)) return SMCMI_ERR_HIP;
+            sl.transit = e->d_transit3;
+        }
         sl.g_sel = e->d_gran3 + nblk * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; sl.gt_sel = sl.g_sel + nblk * 2 * 2;
         sl.g_gm = sl.gt_sel + (size_t)V2_MAXV * 2 * 2; sl.gt_gm = sl.g_gm + nblk * 72 * 2;
         HIP_TRY(hipMemcpyAsync(e->d_sel3, &sl, sizeof(sl), hipMemcpyHostToDevice, h0->stream));
     }
     static const int note3_on = getenv("SMCMI_SEG_NOTE") ? atoi(getenv("SMCMI_SEG_NOTE")) : 1;      // development: 0 = every batch ends with a copy and a sync
+    // (the note outlives a run and sequence numbers start over - sharded segments reset them, 65 535 launches wrap them: a note left by an
+    // earlier run must never equal the number a launch of this run is waited for under.  Every run ends with its stream drained, so nothing
+    // is in flight that could still write the word)
+    if (h0->e2->h_note3) *(volatile int *)h0->e2->h_note3 = -1;
     int force_sel = -1;          // the stage a segment left because it must resample: enqueued with its selection in front of the next segment
     bool status_pending = false; // ... and its status (code 6) is still set: the segment that enters at that stage's mutation clears it
     int last_note_seq = -1;      // sequence number of the latest segment launch that leaves a note; -1: the stream's last launch is not such a segment
@@ -817,6 +844,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             HIP_TRY(hipMemsetAsync(e->d_rec3, 0xFF, REC3_WORDS * sizeof(unsigned long long), h->stream));
             HIP_TRY(hipMemsetAsync(e->d_gran3, 0xFF, k3_table_words(e->g.Vl * e->g.nb2) * sizeof(unsigned long long), h->stream));
             e->seg_seq = 1;
+            if (e->h_note3) { HIP_TRY(hipStreamSynchronize(h->stream)); *(volatile int *)e->h_note3 = -1; }      // (once in 65 535 launches)
         }
         Mut2Args ma{};
         ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0; ma.n = n_first; ma.sel_enqueued = sel ? 1 : 0; ma.adaptive = adaptive ? 1 : 0;
@@ -832,6 +860,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (sa.clear_status && hk + 1 == g.hs.size()) status_pending = false;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
+        sa.row_par = (long long)k3_copy_words((int)nblk); sa.tot_par = seg_sys ? 0 : sa.row_par;       // stage n's tables: copy n & 1 (stage3.hpp Seg3Args)
         sa.sel = sel_inside ? e->d_sel3 : nullptr;
         if (seg_sys) {                                               // the totals tables every handle posts into: inside the mailbox allocation
             sa.peers = h->d_peers; sa.world = g.world;
@@ -851,7 +880,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (profile && sa.done_out) { hipEventCreate(&e0); hipEventCreate(&e1); evs3.push_back(e0); evs3.push_back(e1); hipEventRecord(e0, h->stream); }
         // (the stage counters of all launches of a run are cleared once, in front of its first segment: a fill per launch was 5 µs each)
         if (sa.done_out && seg_launches == 0) HIP_TRY(hipMemsetAsync(e->d_done3, 0, SEG3_MAX_LAUNCHES * sizeof(int), h->stream));
-#define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0)
+#define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0, shift_lag && !seg_sys)
         SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
         HIP_TRY(hipGetLastError());                  // (a rejected launch would otherwise surface as a bogus capacity / time-out error)
@@ -973,7 +1002,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     int pred_rl = cont ? h0->h_st.resampled_last : 0;
     int stall_stage = -1, stall_p = 0, stages_left_est = 1 << 30;
     int launched = 0;
-    res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0;
+    res->solver_stalls = 0; res->select_stalls = 0; res->spec_stalls = 0; res->shift_fallback_stage = 0;
     Ctl2 c{};
     const auto t0 = std::chrono::steady_clock::now();
     bool finished = false;
@@ -1023,8 +1052,6 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 // (the same rules one stage ahead; the last stage of a batch leaves it to a launch: the sync in between may change the mode)
                 int next_begin = -1;
                 if (bighelp && b + 1 < batch) {
-                    bool sel2 = true;
-                    if (predict_select) sel2 = (rc->tempering_target * (pred_rl ? N_tot : pred_ess) < thr * (1.0 + 1e-6)) && sel_mode != 2;
                     const bool cert2 = adaptive && (!spec_on || launched + 1 < 2);
                     next_begin = cert2 ? 0 : (adaptive ? 1 : 0);
                 }
@@ -1105,6 +1132,27 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             launched = sn - 1 - base;
             if (int e = read_ctl(&c)) return e;
         }
+        if (c.status.code == 9 && c.status.err == SMCMI_ERR_NAN_ESS && shift_lag && c.status.stage >= 2) {
+            // the sums of stage sn are not numbers under the LAGGED energy shift: nothing of the stage is committed (the state in memory is the
+            // one after stage sn - 1's mutation, as for every stage that stalls).  From here on the run shifts by the cloud's current maximum,
+            // which bounds every weight by 1 - if the sums still are not numbers, check_nan_ess's error stands (helpers.jl:270-305)
+            const int sn = c.status.stage;
+            shift_lag = false;
+            res->shift_fallback_stage = sn;
+            if (mbox) { if (int e = g.barrier()) return e; const auto it = mb_mut_at.find(sn - 1); mb_live[1] = it != mb_mut_at.end(); if (mb_live[1]) mb_cnt[1] = it->second; }
+            for (auto *h : g.hs) {
+                HIP_TRY(hipSetDevice(h->cfg.device));
+                h->h_lag0 = 0;
+                HIP_TRY(hipMemcpyAsync(&h->d_st->rp.shift_lag, &h->h_lag0, sizeof(int), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(hipMemsetAsync(&h->e2->d_ctl->status, 0, 4 * sizeof(int), h->stream));      // code, stage, err, pad
+            }
+            for (int &s : ev_stage) if (s >= sn) s = -1;
+            prepared_stage = begun_stage = -1;
+            force_sel = -1; status_pending = false;
+            launched = sn - 2 - base;
+            if (getenv("SMCMI_TRACE")) fprintf(stderr, "[smcmi2] stage %d: sums overflowed under the lagged energy shift - exact shifts from here on\n", sn);
+            continue;
+        }
         if (c.status.code == 1 || c.status.code == 5 || c.status.code == 9) break;
         const Post2 &p = c.ps[0].stage >= c.ps[1].stage ? c.ps[0] : c.ps[1];
         if (p.phi_n >= 1.0 || launched >= max_iter) {
@@ -1132,6 +1180,10 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
             fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the totals %lld | decision + proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the totals %lld | begin %lld | stage %lld\n",
                     h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
+            // (a riding launch takes the steps in another order - CORR (2), DRAW (7), BEGIN (8, 9), totals (3), proposal (4), MH (5), row (6): the stamps themselves)
+            fprintf(stderr, "[smcmi3]   stamps relative to the stage's first:");
+            for (int q = 1; q <= 9; ++q) fprintf(stderr, " [%d] %lld", q, pr[q] - pr[1]);
+            fprintf(stderr, "\n");
             {
                 long long sp[10];
                 HIP_TRY(hipMemcpy(sp, h0->e2->d_prof + 1300, sizeof(sp), hipMemcpyDeviceToHost));
@@ -1258,6 +1310,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     for (hipEvent_t e : evs) hipEventDestroy(e);
     // segments of engine 3: launches, the stages they completed and (profile mode) their HIP-event time
     res->n_segments = seg_launches; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
+    // (workers + gatherers; no gatherer where the workers take each other's rows: launch2.hpp launch_k3_seg)
+    res->segment_blocks = seg_launches > 0 ? g0.Vl * g0.nb2 + ((g0.nb2 <= 2 && !seg_sys) ? 0 : g0.Vl) : 0;
+    res->segment_state = h0->e2->e3_state; res->segment_timeouts = h0->seg_timeouts;
     if (seg_launches > 0) {
         const int nl = std::min(seg_launches, SEG3_MAX_LAUNCHES);
         std::vector<int> done(nl);

@@ -382,6 +382,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
             continue;
         }
         memset(&s, 0, sizeof(DevState));
+        s.e_seen = __builtin_nan("");
         s.rp = rp;
         s.stage = 1; s.j = 2; s.c = rc->c; s.accept = rc->target;
         s.ess_prev = rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts;
@@ -748,17 +749,19 @@ extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, sm
     if (int e = need_model(h, 2)) return e;
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
+    res->segment_blocks = 0; res->segment_state = 0; res->segment_timeouts = 0; res->shift_fallback_stage = 0;
     if (!h->nccl && !h->has_hostc) return set_err(SMCMI_ERR_STATE, "smcmi_comm_init / smcmi_comm_init_host has not been called on this handle");
     if (int e = check_lik_pair(h)) return e;
     ShardGroup g;
     g.hs = {h}; g.world = h->world; g.rccl = true; g.hostc = h->has_hostc;
-    if (!h->cb[0] && eng2_eligible(h, g.world)) return run2_guarded(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
+    if (!h->cb[0] && eng2_eligible(h, g.world, false)) return run2_guarded(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
     return run_sharded_impl(g, rc, res);                                             // n_para > 10, and every run with a host likelihood
 }
 
 extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res) {
     if (!hs || n < 1 || !rc || !res) return set_err(SMCMI_ERR_ARG, "bad argument");
     res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
+    res->segment_blocks = 0; res->segment_state = 0; res->segment_timeouts = 0; res->shift_fallback_stage = 0;
     ShardGroup g;
     long long expect = 0;
     for (int k = 0; k < n; ++k) {
@@ -771,6 +774,6 @@ extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_con
     }
     if (expect != hs[0]->cfg.n_parts) return set_err(SMCMI_ERR_ARG, "group handles do not cover n_parts");
     g.world = n; g.rccl = false;
-    if (!hs[0]->cb[0] && eng2_eligible(hs[0], g.world)) return run2_guarded(g, rc, res);
+    if (!hs[0]->cb[0] && eng2_eligible(hs[0], g.world, n == 1)) return run2_guarded(g, rc, res);
     return run_sharded_impl(g, rc, res);
 }

@@ -999,7 +999,7 @@ static int check_lik_pair(const smcmi_handle *h) {
 }
 struct ShardGroup;
 static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
-static bool eng2_eligible(const smcmi_handle *h, int world);
+static bool eng2_eligible(const smcmi_handle *h, int world, bool single);
 static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
 
 extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
@@ -1007,9 +1007,10 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     if (!rc || !res) return set_err(SMCMI_ERR_ARG, "null argument");
     if (h->cfg.n_local != h->cfg.n_parts) return set_err(SMCMI_ERR_UNSUPPORTED, "smcmi_run drives a single shard; use the shard-level calls for multi-GPU");
     res->n_segments = 0; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
+    res->segment_blocks = 0; res->segment_state = 0; res->segment_timeouts = 0; res->shift_fallback_stage = 0;
     if (int e = check_lik_pair(h)) return e;
     if (h->cb[0]) return run_callback(h, rc, res);                    // user likelihood on the host (callback.hpp)
-    if (eng2_eligible(h, 1)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
+    if (eng2_eligible(h, 1, true)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
     const int nf = h->h_model.n_free;
     if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
@@ -1044,6 +1045,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         s.rp = rp; s.done = 0; s.err = 0; s.skip_fold = 1; s.do_resample = 0;
     } else {
         memset(&s, 0, sizeof(DevState));
+        s.e_seen = __builtin_nan("");
         s.rp = rp; s.cur = cur;
         s.stage = 1; s.j = 2;                                   // i = 1, j = 2 (smc_main.jl:198-199)
         s.c = rc->c; s.accept = rc->target;                     // initialize_cloud_settings!, initialization.jl:196-211
@@ -1382,6 +1384,7 @@ extern "C" int smcmi_set_loop_state(smcmi_handle *h, const smcmi_loop_state *in)
     s.phi_n = in->phi_n; s.phi_prop = in->phi_prop; s.c = in->c; s.accept = in->accept;
     s.ess = in->ess; s.ess_prev = in->ess; s.logz = in->logmdd;
     s.done = 0; s.err = 0; s.do_resample = 0; s.cur = 0;
+    s.e_seen = __builtin_nan("");               // (saved scalars carry no energy maximum: the continuation's first begin takes the cloud's)
     h->last_n_stages = in->stage_index;
     return push_state(h);
 }

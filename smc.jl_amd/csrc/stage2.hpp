@@ -148,10 +148,15 @@ struct Begin2 {                   // stage n as decided at its begin (K1 / k2_be
     double accept;                // cloud.accept: acceptance rate of stage n-1's mutation (particle.jl:466-468)
     double e_shift, e_center;
     double cfac;                  // step-size multiplier 0.95 + 0.10 e^{16(a-t)} / (1 + e^{16(a-t)}) (smc_main.jl:453-455), stored by K1's block 0
+    double e_seen;                // the largest energy of the cloud as this begin learnt it (after stage n - 1's mutation).  Adaptive schedules shift
+                                  // stage n's incremental weights by it (e_shift = e_seen); fixed schedules under RunParams::shift_lag by the one the
+                                  // begin BEFORE learnt (e_shift = Post2::e_seen of stage n - 1), so that stage n's correction needs nothing of stage
+                                  // n - 1's mutation rows: one hand-over per stage (stage3.hpp)
 };
 struct Post2 {                    // stage n after its correction (K2, block 0); two copies, indexed by n & 1
     int stage, j, resampled_last, do_resample, resamples, fold_valid;
     double phi_n, phi_prop, ess, sumw, sumw2, logz, c, accept, e_center, e_shift;
+    double e_seen;                // Begin2::e_seen of the stage (NaN: none yet - a fresh run, a continuation from saved scalars)
     double shift[MAXD >= 16 ? 16 : MAXD];
 };
 struct Status2 {
@@ -486,6 +491,7 @@ static __global__ void k2_import(const DevState *st, Ctl2 *ctl, Records rec = Re
     p.fold_valid = 0;                                  // no mutation rows of this chain exist yet (fresh or continued run)
     p.phi_n = st->phi_n; p.phi_prop = st->phi_prop; p.ess = st->ess_prev; p.sumw = st->sumw; p.sumw2 = st->sumw2;
     p.logz = st->logz; p.c = st->c; p.accept = st->accept; p.e_center = st->e_center; p.e_shift = 0.0;
+    p.e_seen = st->e_seen;                             // (NaN on a fresh run; what k2_export left when a paused run goes on)
     for (int a = 0; a < (int)(sizeof(p.shift) / sizeof(double)); ++a) p.shift[a] = st->shift[a];
     c.ps[(st->stage & 1) ^ 1].stage = -1;
     c.bg.stage = -1;
@@ -499,6 +505,7 @@ static __global__ void k2_export(DevState *st, const Ctl2 *ctl) {
     st->stage = p.stage; st->j = p.j; st->resampled_last = p.resampled_last; st->do_resample = p.do_resample; st->resamples = p.resamples;
     st->phi_n = p.phi_n; st->phi_prop = p.phi_prop; st->ess_prev = p.ess; st->ess = p.ess; st->sumw = p.sumw; st->sumw2 = p.sumw2;
     st->logz = p.logz; st->c = p.c; st->accept = (s.code == 1 || s.code == 5) ? s.accept : p.accept; st->e_center = p.e_center;
+    st->e_seen = p.e_seen;
     if (ctl->bg.stage == p.stage) st->phi_prev = ctl->bg.phi_prev;
     for (int a = 0; a < (int)(sizeof(p.shift) / sizeof(double)); ++a) { st->shift[a] = p.shift[a]; st->mean[a] = p.shift[a]; }
     st->solver_passes = s.solver_passes;
@@ -547,6 +554,12 @@ __device__ inline int begin2_wave(int n, const Post2 &po, const RunParams &rp, c
     b.gprime = __longlong_as_double(0x7ff8000000000000ll); b.pred_delta = b.gprime;
     b.accept = accept;
     b.e_shift = fabs(emax_tot) < 1e300 ? emax_tot : po.e_shift;     // no live particle with a finite energy: keep the previous shift
+    b.e_seen = fabs(emax_tot) < 1e300 ? emax_tot : (fabs(po.e_seen) < 1e300 ? po.e_seen : po.e_shift);
+    // fixed schedules, RunParams::shift_lag: the shift is the maximum the PREVIOUS begin learnt (any common shift leaves W, ESS and log-MDD
+    // what they are up to rounding; this one is known before stage n - 1's mutation rows are: stage n's correction can ride them)
+    // (development, SMCMI_SHIFT_LAG=<k >= 3>: stage k's lagged shift is lowered by 1e6 - mathematically neutral, but its sums overflow: the
+    // fallback to exact shifts, run2.hpp, under test)
+    if (fixed && rp.shift_lag && fabs(po.e_seen) < 1e300) b.e_shift = po.e_seen - (rp.shift_lag == n ? 1e6 : 0.0);
     b.e_center = po.e_center;
     if (fixed) {
         b.phi_n = (n <= n_phi) ? sched[n - 1] : 1.0;
@@ -1110,7 +1123,9 @@ __device__ inline int decide2(const Begin2 &bg, double threshold, double phi_rto
         else verified = ess >= bg.ess_bar * (1.0 - 1e-13);
         if (!verified) return 4;
     }
-    if (isnan(ess)) return SMCMI_ERR_NAN_ESS;                      // check_nan_ess, helpers.jl:270-305
+    // check_nan_ess, helpers.jl:270-305 (sums that overflowed count as well: under a lagged energy shift - Begin2::e_seen - a cloud whose
+    // largest energy grew by more than ~350 / (ϕ_n - ϕ_{n-1}) in ONE mutation overflows Σ W̃²; the host then redoes the stage with the exact shift)
+    if (isnan(ess) || fabs(s1) > 1.7e308 || fabs(s2) > 1.7e308) return SMCMI_ERR_NAN_ESS;
     return ess < threshold ? 1 : 0;
 }
 
@@ -1583,7 +1598,7 @@ __device__ inline void post2(int n, const Begin2 &bg, const Post2 &po, const Run
     const double dlz = (bg.phi_n - bg.phi_prev) * (rp.pw == 0.0 ? bg.e_shift : 0.0);      // log of the common factor the shifted weights left out
     p.logz = po.logz + (log(s1 / (double)rp.n_parts) + dlz);
     p.c = po.c * bg.cfac;
-    p.accept = a; p.e_center = bg.e_center; p.e_shift = bg.e_shift;
+    p.accept = a; p.e_center = bg.e_center; p.e_shift = bg.e_shift; p.e_seen = bg.e_seen;
     *out = p;
 }
 

@@ -280,6 +280,98 @@ __device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int
     return true;
 }
 
+// A riding stage (k3_rides): the totals of stage n - 1's mutation rows AND of stage n's correction rows in ONE fetch - both went out before the
+// block waited for anything, and both are normally there when it looks (the mutation rows a correction and a set of draws ago): wavefront v
+// fetches shard v's granules of both tables at once, all loads in flight together, checking every tag; only a fetch that finds a word missing
+// falls back to the paced poll of the rows' first words.  One memory round trip where two gather_totals calls take four.  The sums are
+// gather_totals' (0 + x_0 + x_1 + ... over the shards; the maximum for the mutation row's RMAX_IDX; RPS = 2: two rows per shard totalled
+// as gather_vshard would).  tot_m[0, RMUT), tot_c[0, mc); vt: LDS, V2_MAXV * (72 + RMUT) doubles.  All threads call; false: timed out.
+template <int RPS = 1>
+__device__ inline bool gather_totals_pair(const unsigned long long *tbl_m, unsigned tag_m, const unsigned long long *tbl_c, int mc, unsigned tag_c, int nvs,
+                                          unsigned long long *to, int *s_to, double *tot_m, double *tot_c, double *vt) {
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    double *vt_c = vt, *vt_m = vt + V2_MAXV * 72;
+    const double ninf = -__builtin_inf();
+    // two rows of a shard as gather_vshard totals them (a row per slice: 0 + x; their sum; the identity for the six missing slices; 0 + that)
+    auto two = [&](double x0, double x1, bool mx) {
+        double p;
+        if (mx) { p = fmax(fmax(ninf, x0), fmax(ninf, x1)); p = fmax(p, ninf); p = fmax(p, ninf); p = fmax(ninf, p); }
+        else { p = (0.0 + x0) + (0.0 + x1); p = p + 0.0; p = p + 0.0; p = 0.0 + p; }
+        return p;
+    };
+    if (w < nvs) {                                                          // (wave-uniform)
+        const unsigned long long *row_m = tbl_m + (long long)w * RPS * RMUT * 2, *row_c = tbl_c + (long long)w * RPS * mc * 2;
+        const __amdgpu_buffer_rsrc_t rs_m = rows_rsrc(reinterpret_cast<const double *>(row_m), (long long)RPS * RMUT * 16);
+        const __amdgpu_buffer_rsrc_t rs_c = rows_rsrc(reinterpret_cast<const double *>(row_c), (long long)RPS * mc * 16);
+        const long long t_begin = wall_clock64();
+        for (int attempt = 0;; ++attempt) {
+            int bad = 0;
+            u32x4_t xc[2][RPS], xm[RPS];                                    // mc <= 128, RMUT <= 64
+#pragma unroll
+            for (int r = 0; r < RPS; ++r) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = lane + 64 * q;
+                    xc[q][r] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (r * mc + (k < mc ? k : mc - 1)) * 16, 0, 16);
+                }
+                xm[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, (r * RMUT + (lane < RMUT ? lane : RMUT - 1)) * 16, 0, 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = lane + 64 * q;
+                if (k < mc) {
+                    const double x0 = __hiloint2double((int)xc[q][0].z, (int)xc[q][0].x);
+                    bad |= (xc[q][0].y != tag_c) | (xc[q][0].w != tag_c);
+                    if constexpr (RPS == 1) vt_c[w * mc + k] = x0;
+                    else {
+                        bad |= (xc[q][1].y != tag_c) | (xc[q][1].w != tag_c);
+                        vt_c[w * mc + k] = two(x0, __hiloint2double((int)xc[q][1].z, (int)xc[q][1].x), false);
+                    }
+                }
+            }
+            if (lane < RMUT) {
+                const double x0 = __hiloint2double((int)xm[0].z, (int)xm[0].x);
+                bad |= (xm[0].y != tag_m) | (xm[0].w != tag_m);
+                if constexpr (RPS == 1) vt_m[w * RMUT + lane] = x0;
+                else {
+                    bad |= (xm[1].y != tag_m) | (xm[1].w != tag_m);
+                    vt_m[w * RMUT + lane] = two(x0, __hiloint2double((int)xm[1].z, (int)xm[1].x), lane == RMAX_IDX);
+                }
+            }
+            if (!__any(bad)) break;
+            if (*(volatile int *)s_to) break;
+            if (attempt == 0) {                                             // a word was not there yet: wait for the rows' first words as gather_totals does
+                if (lane < RPS) gran_poll(row_c + (long long)lane * mc * 2, tag_c, to, s_to);
+                else if (lane >= 32 && lane < 32 + RPS) gran_poll(row_m + (long long)(lane - 32) * RMUT * 2, tag_m, to, s_to);
+            } else {
+                if (lane == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                                  __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(to, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *s_to = 1;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (*(volatile int *)s_to) break;
+        }
+    }
+    __syncthreads();
+    if (*s_to) return false;
+    const int t = threadIdx.x;
+    if (t < mc) {
+        double a = 0.0;
+        for (int v = 0; v < nvs; ++v) a = a + vt_c[v * mc + t];
+        tot_c[t] = a;
+    } else if (t >= 128 && t < 128 + RMUT) {
+        const int k = t - 128;
+        const bool mx = k == RMAX_IDX;
+        double a = mx ? ninf : 0.0;
+        for (int v = 0; v < nvs; ++v) { const double x = vt_m[v * RMUT + k]; a = mx ? fmax(a, x) : a + x; }
+        tot_m[k] = a;
+    }
+    __syncthreads();
+    return true;
+}
+
 // Residency self-test of a handle's segment geometry (first use): `grid` blocks of T3 threads with enough LDS that a CU holds ONE of
 // them - the strictest placement the segment kernel can get - take a ticket; the last publishes a granule every block waits for
 // (bounded).  ok counts the blocks that saw it: anything but `grid` (or a raised time-out flag) keeps the handle on engine 2.
@@ -302,9 +394,9 @@ constexpr size_t k3_park_offset(int D) { return (k2_lds_bytes(D) + 15) / 16 * 2;
 constexpr size_t k3_lds_bytes(int D, int sel_cols = 0) {
     return k3_park_offset(D) * sizeof(double) + (size_t)(D + 2) * T3 * sizeof(double) + (size_t)sel_cols * T3 * sizeof(double);
 }
-// columns of LDS a segment kernel gets for the particle in transit (0: its selection stays outside).  The mixture variant carries
-// T3 x D doubles of static z columns and the dense mixture block: with them and the D + 5 columns a block outgrows a CU's 160 KB beyond n_para 7
-// (24 KB: a bound on the rest of the kernel's static arrays)
+// columns of LDS a segment kernel gets for the particle in transit (0: the particle is parked in device memory instead, Sel3Args::transit).
+// The mixture variant carries T3 x D doubles of static z columns and the dense mixture block: with them and the D + 5 columns a block
+// outgrows a CU's 160 KB beyond n_para 7 (24 KB: a bound on the rest of the kernel's static arrays)
 constexpr int k3_sel_cols(int D, bool alpha1) {
     return (alpha1 || 24 * 1024 + ((size_t)T3 * D + 3 * D * D + 3 * D + 2) * sizeof(double) + k3_lds_bytes(D, D + 5) <= 160 * 1024) ? D + 5 : 0;
 }
@@ -326,6 +418,8 @@ struct Sel3Args {
     long long *anc;                // ancestors (or null)
     unsigned long long *g_sel, *gt_sel;   // "my particle and cum values are written": [blocks][2 * 2] / [V2_MAXV][2 * 2] granules (a hand-over with no payload)
     unsigned long long *g_gm, *gt_gm;     // moment rows of the resampled cloud: [blocks][72 * 2] / [V2_MAXV][72 * 2]
+    double *transit;               // [blocks][(D + 5) * T3]: where a worker parks its particle during the selection when the kernel's LDS has no room
+                                   // for it (k3_sel_cols = 0: mixture proposals beyond n_para 7); null otherwise
 };
 struct Seg3Args {
     int n_first, n_last;           // stages this launch may run
@@ -337,6 +431,11 @@ struct Seg3Args {
     const double *sched;
     unsigned long long *g_cm, *g_mut;     // the workers' rows as granules: [blocks][MCM * 2] / [blocks][RMUT * 2] words
     unsigned long long *gt_cm, *gt_mut;   // the shard totals as granules: [V2_MAXV][MCM * 2] / [V2_MAXV][RMUT * 2], indexed by GLOBAL virtual shard
+    // every table exists twice, stage n's rows and totals live in copy n & 1 (row_par / tot_par words apart; tot_par = 0 with several handles,
+    // whose totals tables sit in the mailbox allocation): a block that publishes stage n + 1's correction row BEFORE it has read stage n's
+    // mutation totals (one hand-over per stage, below) overwrites nothing a slower block may still be waiting for - a copy is rewritten two
+    // stages later, which every block can only reach through hand-overs that need the slow block's next row
+    long long row_par, tot_par;
     // several handles (one per GPU; stage2.hpp peer mailbox): a gatherer posts its shard's totals into EVERY handle's tables - gt_cm / gt_mut
     // are this handle's copies inside its fine-grained mailbox allocation, peers[r] + off_cm / off_mut the same tables of handle r - and
     // every block reads its own handle's copy: the segment spans the GPUs with the hand-overs it has on one (two store -> load hops, the
@@ -362,7 +461,8 @@ struct Seg3Args {
     long long *gprof;              // ... and every block's hand-over stamps (K3_WALL)
     int prof_stage;
 };
-constexpr size_t k3_table_words(int blocks) { return (size_t)blocks * (72 + RMUT + 2 + 72) * 2 + (size_t)V2_MAXV * (72 + RMUT + 2 + 72) * 2; }
+constexpr size_t k3_copy_words(int blocks) { return (size_t)blocks * (72 + RMUT + 2 + 72) * 2 + (size_t)V2_MAXV * (72 + RMUT + 2 + 72) * 2; }
+constexpr size_t k3_table_words(int blocks) { return 2 * k3_copy_words(blocks); }      // (two copies: Seg3Args::row_par; the selection's tables use the first only)
 
 // Block 0 of a segment launch, when it has written everything it writes into Ctl2 (all its threads call, at a block-uniform point): Ctl2 as
 // the launch leaves it goes into host-mapped memory, then the launch's sequence number - the host that finds the number there has the state
@@ -513,18 +613,35 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
 #undef K3S
 }
 
-// grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard).
+// ONE hand-over per stage (fixed schedules, RunParams::shift_lag; the reference's default: use_fixed_schedule = true, src/smc_main.jl:139,386-387):
+// ϕ_{n+1} is the schedule's next entry and the energy shift of stage n + 1's incremental weights is the maximum the begin of stage n learnt
+// (Begin2::e_seen), so stage n + 1's correction row needs nothing of stage n's mutation totals - a worker forms and publishes it right behind
+// its mutation row, and the totals of both arrive together: the begin of stage n + 1 (acceptance rate -> c, the records) runs on the way to the
+// decision instead of behind a hand-over of its own.  True when stage n + 1's correction rides stage n's mutation rows: every block evaluates
+// it from the same values (po = Post2 of stage n); the stage must be sure to begin (begin2_wave's exits: ϕ = 1 reached, pause, capacity).
+// A kernel of its own (k3_segment<D, α1, RIDE = true>, launched for fixed schedules under shift_lag on one handle): the order of the stage
+// loop's three leading steps is then a compile-time matter in both instantiations - chosen at run time it cost every stage of an ADAPTIVE run
+// 0.8 µs and the mixture variant 14 spilled registers.  Inside a riding launch a stage that does not ride never begins (the conditions above
+// are begin2_wave's exits; Post2::e_seen is finite from the first begin on), so the riding order needs no second site for the correction.
+__device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const Post2 &po, int n, bool sys) {
+    return rp.use_fixed_schedule && rp.shift_lag && !sys && n < sa.n_last && po.phi_n < 1.0 && !(rp.stop_stage > 0 && n >= rp.stop_stage) && n + 1 <= rp.max_stages;
+}
+
+// grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard; W blocks
+// where the workers take the rows themselves: one handle with one or two blocks per virtual shard).
 // Worker b owns block (b / Vl) of local virtual shard (b % Vl): with the hardware's round-robin of consecutive blocks over the 8 XCDs
 // a virtual shard's workers and (W a multiple of 8) its gatherer share an XCD - placement is speed only, never correctness.
 // Every block - gatherers included - derives the stage's decisions itself from the V shard totals (decide2, post2, begin2_wave: same
 // inputs, same code, same result everywhere, as in engine 2's kernels), the workers also the proposal; worker 0 records them.
-template <int D, bool ALPHA1>
+template <int D, bool ALPHA1, bool RIDE>
 __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ RecA3 s_a;
     __shared__ RecB3<D> s_b[2];                                 // [n & 1]: Post2 of stage n lives on as "Post2 of n - 1" during stage n + 1
     __shared__ double s_vt[V2_MAXV * RMUT * 4], s_tot[pad2(NPF) > RMUT ? pad2(NPF) : RMUT], s_sw[64];
+    __shared__ double s_totm[RIDE ? RMUT : 2];                  // riding stages: the mutation totals arrive WITH the correction totals (gather_totals_pair)
+    static_assert(V2_MAXV * RMUT * 4 >= V2_MAXV * (72 + RMUT), "gather_totals_pair stages both tables in s_vt");
     __shared__ double red[(T3 / 64) * (cm_row_ld(NPF) > 64 ? cm_row_ld(NPF) : 64)];
     __shared__ int s_act, s_to, s_fail;
     __shared__ double s_cfac;
@@ -579,22 +696,22 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (rs0) reduce_rows<pad2(NPm), 1, T3>(ma.gmrows, s_vt, s_tot + 2);          // moments of the resampled cloud (k2_gather's rows) replace the correction's
     }
     const double inv_pre = INV_FACTORIAL[tid & 31];
-    // Stage n's begin from the totals of stage n - 1's mutation rows (in s_tot), by every block alike: 0 go on, 7 segment complete,
+    // Stage nb's begin from the totals of stage nb - 1's mutation rows (in s_tot), by every block alike: 0 go on, 7 segment complete,
     // else begin2_wave's code (finished / paused / error / no usable prediction: the writer has set the status).  Ends with a barrier.
-    auto next_begin = [&](const Post2 &po_n) -> int {
+    auto begin_stage = [&](int nb_, const Post2 &po_n, const double *tm) -> int {
         if (tid == 0) s_act = 7;
         if (tid < 64) {
             const int jj = po_n.j - 1 + tid;                    // the window of the proposed schedule the begin walks
             s_sw[tid] = (!rp.use_fixed_schedule && jj >= 0 && jj < rp.n_phi) ? sa.sched[jj] : 2.0;
         }
-        if (n < sa.n_last) {
+        if (nb_ <= sa.n_last) {
             if (tid < 64) {
-                const int act = begin2_wave(n + 1, po_n, rp, s_tot, s_tot[RMAX_IDX], true, 1, sa.sched, s_sw, &s_a.bg, &st->sol[0], writer, ma.rec,
+                const int act = begin2_wave(nb_, po_n, rp, tm, tm[RMAX_IDX], true, 1, sa.sched, s_sw, &s_a.bg, &st->sol[0], writer, ma.rec,
                                             &ctl->status, inv_pre);
                 if (tid == 0) s_act = act;
             } else if (tid == 64) {
-                // the step-size multiplier of stage n + 1 (smc_main.jl:453-455) from the acceptance rate begin2_wave folds
-                const double a = s_tot[EACC] / (double)rp.n_parts, tg = rp.target;
+                // the step-size multiplier of stage nb (smc_main.jl:453-455) from the acceptance rate begin2_wave folds
+                const double a = tm[EACC] / (double)rp.n_parts, tg = rp.target;
                 s_cfac = 0.95 + 0.10 * exp(16.0 * (a - tg)) / (1.0 + exp(16.0 * (a - tg)));
             }
         }
@@ -613,18 +730,27 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         const int vg = (int)blockIdx.x - W;
         static_assert(k3_lds_bytes(D) / sizeof(double) >= (size_t)GRP * (MCM > RMUT ? MCM : RMUT), "the gatherer stages a shard's rows (<= GRP of them) in the dynamic LDS");
         double *g_stage = sm;                                    // (a gatherer uses none of the workers' dynamic LDS: model constants, proposal, parked draws)
+        // (one hand-over per stage, see the workers: a stage whose correction rows ride the mutation rows in front of it has them swept and posted
+        // BEFORE this block takes the mutation totals and runs the begin - the workers wait for the correction totals, nothing else)
+        bool cm_posted = false;
+        auto sweep_cm = [&](int ns) -> bool {
+            const unsigned tg = sa.tag_base | (unsigned)ns;
+            const long long rp_ = (RIDE && (ns & 1)) ? sa.row_par : 0, tp_ = (RIDE && (ns & 1)) ? sa.tot_par : 0;
+            return gather_vshard<T3>(sa.g_cm + rp_ + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tg, sa.to, &s_to,
+                                     [&](int idx, double val) { post_total(sa.gt_cm + tp_, sa.off_cm, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tg); }, g_stage,
+                                     (sa.gprof && ns == sa.prof_stage) ? sa.gprof + 90 + 4 * vg : nullptr);
+        };
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
+            const long long rpar = (RIDE && (n & 1)) ? sa.row_par : 0, tpar = (RIDE && (n & 1)) ? sa.tot_par : 0;      // stage n's copy of the tables (riding launches)
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
             if (!entered) {
                 K3_WALL(sa.gprof, 40 + 6 * vg + 0);
-                if (!gather_vshard<T3>(sa.g_cm + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tag, sa.to, &s_to,
-                                       [&](int idx, double val) { post_total(sa.gt_cm, sa.off_cm, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tag); }, g_stage,
-                                       (sa.gprof && n == sa.prof_stage) ? sa.gprof + 90 + 4 * vg : nullptr)) break;
+                if (!cm_posted && !sweep_cm(n)) break;
                 K3_WALL(sa.gprof, 40 + 6 * vg + 1);
                 K3_WALL(sa.gprof, 40 + 6 * vg + 2);
                 // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
-                if (!gather_totals(sa.gt_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
+                if (!gather_totals(sa.gt_cm + tpar, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
             }
             const double ess = s_tot[0] * s_tot[0] / s_tot[1];
             int rs_g = entered ? rs0 : 0;
@@ -647,13 +773,15 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, rs_g, &s_b[n & 1].po);
             __syncthreads();
             K3_WALL(sa.gprof, 40 + 6 * vg + 3);
-            if (!gather_vshard<T3>(sa.g_mut + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to,
-                                   [&](int idx, double val) { post_total(sa.gt_mut, sa.off_mut, ((long long)(g.v0 + vg) * RMUT + idx) * 2, val, tag); }, g_stage,
+            if (!gather_vshard<T3>(sa.g_mut + rpar + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to,
+                                   [&](int idx, double val) { post_total(sa.gt_mut + tpar, sa.off_mut, ((long long)(g.v0 + vg) * RMUT + idx) * 2, val, tag); }, g_stage,
                                    (sa.gprof && n == sa.prof_stage) ? sa.gprof + 90 + 4 * vg + 2 : nullptr)) break;
             K3_WALL(sa.gprof, 40 + 6 * vg + 4);
+            cm_posted = false;
+            if (RIDE && k3_rides(rp, sa, s_b[n & 1].po, n, sys)) { if (!sweep_cm(n + 1)) break; cm_posted = true; }
             K3_WALL(sa.gprof, 40 + 6 * vg + 5);
-            if (!gather_totals(sa.gt_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
-            if (next_begin(s_b[n & 1].po) != 0) break;
+            if (!gather_totals(sa.gt_mut + tpar, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
+            if (begin_stage(n + 1, s_b[n & 1].po, s_tot) != 0) break;
         }
         return;
     }
@@ -695,80 +823,137 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     __syncthreads();
     int done = 0;
     bool timed_out = false;
-    unsigned long long *my_cm = sa.g_cm + (long long)rowi * MCM * 2, *my_mut = sa.g_mut + (long long)rowi * RMUT * 2;
     // one handle whose virtual shards are ONE block each (clouds of up to 4 096 particles): a shard's total is its only row (the canonical
-    // sum of one row adds zeros to it), so every worker takes the V rows themselves - one hop per hand-over instead of two; the gatherers
-    // still run and post totals (they follow the decisions with them), nobody waits for them
+    // sum of one row adds zeros to it), so every worker takes the V rows themselves - one hop per hand-over instead of two; no gatherer is
+    // launched for such a cloud (launch2.hpp launch_k3_seg)
     const bool rows_direct = g.nb2 == 1 && !sys;
     const bool rows_two = g.nb2 == 2 && !sys;                    // ... two blocks each (up to 8 192 particles: the reference's default 5 000): gather_totals<2>
-    const unsigned long long *t_cm = rows_direct ? sa.g_cm : sa.gt_cm, *t_mut = rows_direct ? sa.g_mut : sa.gt_mut;
+    // rides: this stage's correction row was formed in front of its begin, behind the previous stage's mutation row (k3_rides)
+    bool rides = false;
+    double v = 0.0;                                             // the particle's unnormalised weight W̃ of stage n (the entered stage: what K1 left)
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
         RecB3<D> &B = s_b[n & 1];
         const Post2 &po = s_b[(n - 1) & 1].po;                  // stage n - 1 as completed
         const unsigned tag = sa.tag_base | (unsigned)n;
+        // (stage n's copy of the tables: formed where they are used - the stage loop has no scalar registers to carry addresses across its phases)
+        // (only a riding launch needs the second copy - Seg3Args::row_par: with two hand-overs per stage nobody is ever a table ahead)
+#define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? sa.row_par : 0)
+#define K3_TPAR(stage) ((RIDE && ((stage) & 1)) ? sa.tot_par : 0)
         // the proposal arrays of THIS stage
         L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
         L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
-        // ================= correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block
-        const double phi = s_a.bg.phi_n, phi_prev = s_a.bg.phi_prev, esh = pw == 0.0 ? s_a.bg.e_shift : 0.0, e_center = s_a.bg.e_center;
-        const bool entered = sa.enter_mut && n == sa.n_first;   // this stage's correction (and selection) ran as launches: totals in s_tot
+        const bool first = n == sa.n_first;                     // (its begin ran in front of the loop, its draws are parked)
+        const bool entered = sa.enter_mut && first;             // this stage's correction (and selection) ran as launches: totals in s_tot
         int rs = entered ? rs0 : 0;
-        double v = entered ? v_entered : 0.0;
-        if (!entered) {
-            if constexpr (ALPHA1) {
-                // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
-                double xx[D + 1];
+        if (entered) v = v_entered;
+        // Three steps lead up to the stage's correction totals, in an order that depends on whether the correction rides (ONE site of code each:
+        // the stage loop has neither registers nor instruction cache for a second copy):
+        //   DRAW   the first proposal's random numbers of stage n (functions of (seed, particle, stage) only), under whatever hand-over is pending
+        //   BEGIN  the V shard totals of stage n - 1's mutation rows -> stage n's begin (smc_main.jl:378-396, helpers.jl:9-56)
+        //   CORR   correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block, published
+        // as DRAW, BEGIN, CORR when the begin decides ϕ_n (RIDE = false: adaptive schedules, several handles), as CORR, DRAW, BEGIN when ϕ_n and
+        // the energy shift are known beforehand (RIDE = true, k3_rides): then both rows of a block are out before it waits for anything.  (The
+        // first stage of a riding launch has its begin and its draws from the launch's prologue: CORR alone, on the begin's values.)
+        int act = 0;
 #pragma unroll
-                for (int a = 0; a <= D; ++a) xx[a] = 0.0;
-                if (live) {
-                    double inc;
-                    v = k2_cm_weight<D>([&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, xx, &inc);
-                    if (hist) {
-                        const double unshift = exp((phi - phi_prev) * esh);
-                        sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
-                    }
+        for (int ph = 0; ph < 3; ++ph) {
+            const int op = RIDE ? (ph == 0 ? 2 : ph - 1) : ph;           // 0 DRAW, 1 BEGIN, 2 CORR
+            if (op == 0) {
+                if (!first && n <= sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);
+                K3_STAMP(sa.prof, 7);
+            } else if (op == 1) {
+                if (first) continue;
+                const unsigned tag_p = sa.tag_base | (unsigned)(n - 1);
+                if (RIDE && rides) {
+                    // (this stage's correction row is out as well: both tables' totals in one fetch - the decision below finds s_tot filled; the
+                    // stage that ends a riding launch has no correction row: its begin takes the mutation totals alone)
+                    if (!(rows_two ? gather_totals_pair<2>(sa.g_mut + K3_RPAR(n - 1), tag_p, sa.g_cm + K3_RPAR(n), MCM, tag, g.V, sa.to, &s_to, s_totm, s_tot, s_vt)
+                                   : gather_totals_pair(rows_direct ? sa.g_mut + K3_RPAR(n - 1) : sa.gt_mut + K3_TPAR(n - 1), tag_p,
+                                                        rows_direct ? sa.g_cm + K3_RPAR(n) : sa.gt_cm + K3_TPAR(n), MCM, tag, g.V, sa.to, &s_to, s_totm, s_tot, s_vt))) { timed_out = true; act = -1; break; }
+                } else {
+                if (!(rows_two ? gather_totals<2>(sa.g_mut + K3_RPAR(n - 1), g.V, RMUT, RMAX_IDX, tag_p, sa.to, &s_to, s_tot, s_vt)
+                               : gather_totals(rows_direct ? sa.g_mut + K3_RPAR(n - 1) : sa.gt_mut + K3_TPAR(n - 1), g.V, RMUT, RMAX_IDX, tag_p, sa.to, &s_to, s_tot, s_vt, sys,
+                                               (writer && sys) ? sa.vt_mut_out : nullptr))) { timed_out = true; act = -1; break; }
                 }
-                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+                K3_STAMP(sa.prof, 8);
+                K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
+                act = begin_stage(n, po, (RIDE && rides) ? s_totm : s_tot);
+                constexpr int NWB = sizeof(Begin2) / sizeof(double);
+                if (act == 0 && writer && tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
+                K3_STAMP(sa.prof, 9);
+                if (act != 0) break;                            // leave: registers hold the cloud after stage n - 1
+                if (RIDE && !rides) {                           // (cannot happen, see k3_rides: this stage's correction row was due in front of the begin)
+                    if (writer && tid == 0) { ctl->status.err = SMCMI_ERR_STATE; ctl->status.stage = n; ctl->status.code = 9; __hip_atomic_store(sa.to, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    act = -1;
+                    break;
+                }
             } else {
-                // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
-                // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
-                constexpr int NCH = (NPF + 63) / 64;
-                double acc[NCH * 64];
+                if (entered || (RIDE && !first && !rides)) continue;      // (the stage that ends a riding launch: its begin, next, says so)
+                // (riding: what begin2_wave will put into Begin2 for a fixed schedule under shift_lag - the same values, before the begin has run)
+                const double phi = rides ? (n <= rp.n_phi ? sa.sched[n - 1] : 1.0) : s_a.bg.phi_n, phi_prev = rides ? po.phi_n : s_a.bg.phi_prev;
+                const double esh = pw == 0.0 ? (rides ? po.e_seen - (rp.shift_lag == n ? 1e6 : 0.0) : s_a.bg.e_shift) : 0.0;
+                unsigned long long *my_cm = sa.g_cm + K3_RPAR(n) + (long long)rowi * MCM * 2;
+                if constexpr (ALPHA1) {
+                    // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
+                    double xx[D + 1];
 #pragma unroll
-                for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
-                if (live) {
-                    double inc;
-                    v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
-                    if (hist) {
-                        const double unshift = exp((phi - phi_prev) * esh);
-                        sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                    for (int a = 0; a <= D; ++a) xx[a] = 0.0;
+                    if (live) {
+                        double inc;
+                        v = k2_cm_weight<D>([&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, xx, &inc);
+                        if (hist) {
+                            const double unshift = exp((phi - phi_prev) * esh);
+                            sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                        }
                     }
+                    k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+                } else {
+                    // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
+                    // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
+                    constexpr int NCH = (NPF + 63) / 64;
+                    double acc[NCH * 64];
+#pragma unroll
+                    for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+                    if (live) {
+                        double inc;
+                        v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
+                        if (hist) {
+                            const double unshift = exp((phi - phi_prev) * esh);
+                            sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                        }
+                    }
+                    k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
                 }
-                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+                if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
+                K3_STAMP(sa.prof, 2);
+                K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
             }
-            if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
         }
+        if (act != 0) break;
+        const double e_center = s_a.bg.e_center;
         const int jx_pre = (tid >= 64 && tid < 128) ? shuffle_partner(ma.seed, (unsigned)n, tid - 64, nf) : 0;     // (before the totals exist)
-        K3_STAMP(sa.prof, 2);
-        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
         // ---- the V shard totals -> decision (smc_main.jl:427-455) -> proposal (smc_main.jl:457-465, helpers.jl:215-260, mutation.jl:81)
-        if (!entered && !(rows_two ? gather_totals<2>(sa.g_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt)
-                                   : gather_totals(t_cm, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys))) { timed_out = true; break; }
+        if (!entered && !(RIDE && rides) && !(rows_two ? gather_totals<2>(sa.g_cm + K3_RPAR(n), g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt)
+                                   : gather_totals(rows_direct ? sa.g_cm + K3_RPAR(n) : sa.gt_cm + K3_TPAR(n), g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys))) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
         int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
         if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
             // ================= SELECTION inside the segment (k3_select_inside above): the particle goes through LDS - a call that took it in registers
-            // would cost the stage loop 26 registers and 38 spills for a path one stage in twenty takes
-            double *sto = z_park + (D + 2) * T3, *stx = sto + 5 * T3;
+            // would cost the stage loop 26 registers and 38 spills for a path one stage in twenty takes.  (A kernel whose static arrays leave no room
+            // for the D + 5 columns - mixture proposals beyond n_para 7 - parks it in the block's slice of a scratch buffer in device memory instead:
+            // the same thread writes and reads back every word, 60 KB per block that stay in the die's L2)
+            double *sto = z_park + (D + 2) * T3;
+            if constexpr (k3_sel_cols(D, ALPHA1) == 0) sto = sa.sel->transit + (long long)blockIdx.x * (D + 5) * T3;
+            double *stx = sto + 5 * T3;
             __syncthreads();
             sto[tid] = v;
 #pragma unroll
             for (int k = 0; k < D; ++k) stx[k * T3 + tid] = x[k];
             sto[T3 + tid] = like; sto[2 * T3 + tid] = lprior; sto[3 * T3 + tid] = like_prev; sto[4 * T3 + tid] = acc_val;
-            const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm, sa.to, &s_to, s_tot, s_vt, s_sw,
+            const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm + K3_RPAR(n), sa.to, &s_to, s_tot, s_vt, s_sw,
                                                 red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr, rows_direct, rows_two);
             if (bad) { timed_out = true; break; }
 #pragma unroll
@@ -832,6 +1017,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 5);
         {
             double *plain = ma.rows_mut + (long long)rowi * RMUT;      // (the launch after this one totals the last stage's rows from here)
+            unsigned long long *my_mut = sa.g_mut + K3_RPAR(n) + (long long)rowi * RMUT * 2;
             k2_mut_row_f<T3>(ma.adaptive != 0, like, like_prev, live ? Wt : 0.0, live ? acc_val : 0.0, e_center, live, rs != 0, red, L.red,
                              [&](int idx, double val) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; });
             if (tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
@@ -839,19 +1025,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         ++done;
         K3_STAMP(sa.prof, 6);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 2);
-        if (n < sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(n + 1), db0, ma.debug);      // stage n + 1's draws, under the hand-over
-        K3_STAMP(sa.prof, 7);
-        // ---- the V shard totals -> stage n + 1's begin (smc_main.jl:378-396, helpers.jl:9-56)
-        if (!(rows_two ? gather_totals<2>(sa.g_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt)
-                       : gather_totals(t_mut, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys, (writer && sys) ? sa.vt_mut_out : nullptr))) { timed_out = true; break; }
-        K3_STAMP(sa.prof, 8);
-        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
-        const int act = next_begin(B.po);
-        constexpr int NWB = sizeof(Begin2) / sizeof(double);
-        if (act == 0 && writer && tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
-        K3_STAMP(sa.prof, 9);
-        if (act != 0) break;                                    // leave: registers hold the cloud after stage n
+        if constexpr (RIDE) rides = k3_rides(rp, sa, B.po, n, sys);             // stage n + 1's correction row goes out right behind this row?
     }
+#undef K3_RPAR
+#undef K3_TPAR
     // ---- the cloud goes back to buffer 0 as the last completed stage left it
     if (live && !timed_out) {
 #pragma unroll

@@ -44,7 +44,9 @@ class Result(C.Structure):
                 ("accept", C.c_double), ("seconds", C.c_double), ("kernel_ms_mutate", C.c_double),
                 ("n_mutate_launches", C.c_int32), ("solver_passes", C.c_int64), ("solver_stalls", C.c_int32),
                 ("select_stalls", C.c_int32), ("spec_stalls", C.c_int32), ("paused", C.c_int32),
-                ("n_segments", C.c_int32), ("segment_stages", C.c_int32), ("kernel_ms_segments", C.c_double)]
+                ("n_segments", C.c_int32), ("segment_stages", C.c_int32), ("kernel_ms_segments", C.c_double),
+                ("segment_blocks", C.c_int32), ("segment_state", C.c_int32), ("segment_timeouts", C.c_int32),
+                ("shift_fallback_stage", C.c_int32)]
 
 
 class LoopState(C.Structure):

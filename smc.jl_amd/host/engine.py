@@ -269,7 +269,9 @@ class Engine:
         return dict(n_stages=res.n_stages, resamples=res.resamples, logmdd=res.logmdd, c=res.c, accept=res.accept,
                     seconds=res.seconds, kernel_ms_mutate=res.kernel_ms_mutate, n_mutate_launches=res.n_mutate_launches,
                     solver_passes=res.solver_passes, solver_stalls=res.solver_stalls, select_stalls=res.select_stalls, spec_stalls=res.spec_stalls,
-                    n_segments=res.n_segments, segment_stages=res.segment_stages, kernel_ms_segments=res.kernel_ms_segments)
+                    n_segments=res.n_segments, segment_stages=res.segment_stages, kernel_ms_segments=res.kernel_ms_segments,
+                    segment_blocks=res.segment_blocks, segment_state=res.segment_state, segment_timeouts=res.segment_timeouts,
+                    shift_fallback_stage=res.shift_fallback_stage)
 
     # ---- sharded whole-loop drivers (csrc/sharded.hpp) ---------------------------------------------------
     def comm_init(self, rank, world, unique_id):

@@ -45,7 +45,8 @@ mutable struct Result         # smcmi_result
     kernel_ms_mutate::Float64; n_mutate_launches::Int32; solver_passes::Int64; solver_stalls::Int32; select_stalls::Int32
     spec_stalls::Int32; paused::Int32
     n_segments::Int32; segment_stages::Int32; kernel_ms_segments::Float64
-    Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0)
+    segment_blocks::Int32; segment_state::Int32; segment_timeouts::Int32; shift_fallback_stage::Int32
+    Result() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0)
 end
 mutable struct LoopState      # smcmi_loop_state
     stage_index::Int32; j::Int32; resampled_last_period::Int32; resamples::Int32

@@ -1,6 +1,6 @@
-"""One rank of a multi-PROCESS sharded run on ONE GPU (tests/test_gpu_multiproc.py): the product driver - Engine.run_sharded ->
-smcmi_run_sharded -> csrc/run2.hpp run2_impl - with the host-mediated communicator over torch.distributed / gloo, the peer mailbox
-mapped between the processes through real hipIpcOpenMemHandle.  Writes its shard's results to <out>/rank<r>.json + .npy.
+"""One rank of a multi-PROCESS sharded run on ONE GPU (tests/test_gpu_multiproc.py, tests/test_gpu_fake_rccl.py): the product driver -
+Engine.run_sharded -> smcmi_run_sharded -> csrc/run2.hpp run2_impl - with the host-mediated communicator over torch.distributed / gloo
+or with the RCCL entry points (cfg["comm"] = "rccl"), the peer mailbox mapped between the processes through real hipIpcOpenMemHandle.  Writes its shard's results to <out>/rank<r>.json + .npy.
 
 usage: python -m tests.mp_shard_worker <rank> <world> <port> <out_dir> <json config>"""
 import hashlib
@@ -36,7 +36,9 @@ def main():
         eng.init_from_prior()
         if cfg.get("closure") == "tempered":
             eng.eval_cloud_callback(which=1, column=d + 2)      # old_loglh of the initial cloud (a bridge from prior draws)
-        shd.connect(eng, rank, world, comm="host")
+        # "host": the host-mediated communicator over gloo; "rccl": smcmi_comm_init - whatever library SMCMI_RCCL_PATH names (the tests: the
+        # shared-memory stand-in tests/fake_rccl, so that the driver's RCCL branch runs with ranks that share the one GPU)
+        shd.connect(eng, rank, world, comm=cfg.get("comm", "host"))
         runs = []
         for rep in range(cfg.get("reps", 1)):
             if rep:

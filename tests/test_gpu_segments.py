@@ -50,7 +50,9 @@ for rep in range(cfg.get("reps", 1)):
     o = dict(n_stages=r["n_stages"], resamples=r["resamples"], logmdd=float(r["logmdd"]).hex(), c=float(r["c"]).hex(), accept=float(r["accept"]).hex(),
              schedule=h(rec["schedule"]), ess=h(rec["ess"]), c_hist=h(rec["c_hist"]), accept_hist=h(rec["accept_hist"]), resampled=h(rec["resampled"]),
              cloud=h(e.download_cloud()), n_segments=r["n_segments"], segment_stages=r["segment_stages"],
-             stalls=[r["solver_stalls"], r["select_stalls"], r["spec_stalls"]], logmdd_f=r["logmdd"])
+             stalls=[r["solver_stalls"], r["select_stalls"], r["spec_stalls"]], logmdd_f=r["logmdd"],
+             shift_fallback_stage=r["shift_fallback_stage"], segment_blocks=r["segment_blocks"], segment_state=r["segment_state"],
+             segment_timeouts=r["segment_timeouts"])
     if cfg.get("history", True):
         w, W = e.history(r["n_stages"])
         o["w"], o["W"] = h(w), h(W)
@@ -112,21 +114,63 @@ def test_a_mispredicted_resample_leaves_the_segment_and_is_redone():
         assert a[k] == b[k], (k, a[k], b[k])
 
 
-@pytest.mark.parametrize("kw", [dict(use_fixed_schedule=True, n_phi=120), dict(use_fixed_schedule=False, tempering_target=0.95),
-                                dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial", n_blocks=2, n_mh_steps=2),
-                                dict(use_fixed_schedule=False, tempering_target=0.95, alpha=0.9, n_blocks=2)],
-                         ids=["fixed", "adaptive", "fixed_multinomial_2blocks", "adaptive_mixture_2blocks"])
-def test_selection_inside_the_segment_leaves_the_bits_of_the_selection_launches(kw):
-    """One handle (mixture proposals: n_para <= 7, where the particle in transit still fits a CU's LDS): a stage that must resample does so inside the segment (stage3.hpp k3_select_inside: the workers scan their
+@pytest.mark.parametrize("kw,d", [(dict(use_fixed_schedule=True, n_phi=120), 7), (dict(use_fixed_schedule=False, tempering_target=0.95), 7),
+                                  (dict(use_fixed_schedule=True, n_phi=80, resampling_method="multinomial", n_blocks=2, n_mh_steps=2), 7),
+                                  (dict(use_fixed_schedule=False, tempering_target=0.95, alpha=0.9, n_blocks=2), 7),
+                                  (dict(use_fixed_schedule=False, tempering_target=0.95, alpha=0.9), 10),
+                                  (dict(use_fixed_schedule=True, n_phi=100, alpha=0.9, n_blocks=3), 9)],
+                         ids=["fixed", "adaptive", "fixed_multinomial_2blocks", "adaptive_mixture_2blocks", "adaptive_mixture_d10", "fixed_mixture_d9_3blocks"])
+def test_selection_inside_the_segment_leaves_the_bits_of_the_selection_launches(kw, d):
+    """One handle: a stage that must resample does so inside the segment (stage3.hpp k3_select_inside: the workers scan their
     weights, find their ancestors and total the resampled cloud's moments with k2_scan's / k2_gather's own functions) - no stall, a run of
-    one or two launches, and the bits of a run whose segments leave for the selection launches (SMCMI_SEG_SELECT=0) and of a run of launches."""
-    cfg = dict(n=60_000, d=7, seed=17, spec_args=[7], kw=kw)
+    one or two launches, and the bits of a run whose segments leave for the selection launches (SMCMI_SEG_SELECT=0) and of a run of launches.
+    Mixture proposals beyond n_para 7 (the reference's own test configuration: 9 parameters, α = .9, test/smc.jl:26-29): the kernel's LDS has
+    no room for the particle in transit - it is parked in the block's slice of a device buffer (Sel3Args::transit) - same bits, same launch count."""
+    cfg = dict(n=60_000, d=d, seed=17, spec_args=[d], kw=kw)
     a = _run(cfg)[0]
     b = _run(cfg, {"SMCMI_SEG_SELECT": "0"})[0]
     c = _run(cfg, {"SMCMI_ENGINE3": "0"})[0]
     assert a["resamples"] >= 3 and a["stalls"][1] == 0 and a["n_segments"] <= 4 and b["n_segments"] > a["resamples"]
     for k in _KEYS:
         assert a[k] == b[k] == c[k], (k, a[k], b[k], c[k])
+
+
+def test_fixed_schedules_take_one_hand_over_per_stage_and_the_lagged_shift_is_neutral():
+    """Fixed schedules (the reference's default, src/smc_main.jl:139): the energy shift of a stage's incremental weights lags the cloud's largest
+    energy by one mutation (RunParams::shift_lag), so that inside a segment a stage's correction row rides the mutation row in front of it - ONE
+    hand-over per stage (stage3.hpp k3_rides).  The rule belongs to the run: launches (SMCMI_ENGINE3=0) leave the same bits - the parametrised
+    tests above and below compare them on five fixed-schedule configurations.  Here: the shift itself is neutral - against exact shifts
+    (SMCMI_SHIFT_LAG=0) the run has the same stages and resample decisions and its log-MDD, schedule and ESS path agree to rounding - and no
+    fallback was needed."""
+    cfg = dict(n=100_000, d=10, seed=1, kw=dict(use_fixed_schedule=True, n_phi=300))
+    a = _run(cfg)[0]
+    b = _run(cfg, {"SMCMI_SHIFT_LAG": "0"})[0]
+    c = _run(cfg, {"SMCMI_ENGINE3": "0"})[0]
+    assert a["n_segments"] == 1 and a["segment_stages"] == 299 and a["shift_fallback_stage"] == 0 and a["resamples"] >= 5
+    assert a["segment_state"] == 1 and a["segment_blocks"] == 8 * ((12_500 + 511) // 512) + 8 and a["segment_timeouts"] == 0
+    assert (a["n_stages"], a["resamples"], a["resampled"]) == (b["n_stages"], b["resamples"], b["resampled"])
+    assert abs(a["logmdd_f"] - b["logmdd_f"]) <= 1e-9 * abs(b["logmdd_f"]), (a["logmdd_f"], b["logmdd_f"])
+    assert abs(a["logmdd_f"] - models.gauss_logmdd(10)) < 0.2
+    for k in _KEYS:
+        assert a[k] == c[k], (k, a[k], c[k])
+
+
+def test_sums_that_overflow_under_the_lagged_shift_switch_the_run_to_exact_shifts():
+    """A lagged shift does not bound the weights by 1: a cloud whose largest log-likelihood grows by more than ~350 / (ϕ_n - ϕ_{n-1}) in ONE
+    mutation overflows Σ W̃² at the next stage (decide2 counts sums that are not finite as check_nan_ess's case).  Nothing of that stage is
+    committed; the host switches the run to exact shifts from that stage on (smcmi_result::shift_fallback_stage) - segments and launches
+    alike, same bits - and the result is the run exact shifts give from the start: same stages, same resample decisions, log-MDD to rounding.
+    SMCMI_SHIFT_LAG=12 (development) lowers stage 12's lagged shift by 1e6: the sums of that stage do overflow."""
+    cfg = dict(n=20_000, d=10, seed=3, kw=dict(use_fixed_schedule=True, n_phi=60))
+    a = _run(cfg, {"SMCMI_SHIFT_LAG": "12"})[0]
+    b = _run(cfg, {"SMCMI_SHIFT_LAG": "0"})[0]
+    c = _run(cfg, {"SMCMI_SHIFT_LAG": "12", "SMCMI_ENGINE3": "0"})[0]
+    assert a["shift_fallback_stage"] == 12 and b["shift_fallback_stage"] == 0 and c["shift_fallback_stage"] == 12
+    assert a["n_segments"] >= 2 and c["n_segments"] == 0
+    assert (a["n_stages"], a["resamples"], a["resampled"]) == (b["n_stages"], b["resamples"], b["resampled"]) and a["n_stages"] == 60
+    assert abs(a["logmdd_f"] - b["logmdd_f"]) <= 1e-9 * abs(b["logmdd_f"]), (a["logmdd_f"], b["logmdd_f"])
+    for k in _KEYS:
+        assert a[k] == c[k], (k, a[k], c[k])
 
 
 def test_a_segment_time_out_repeats_the_run_as_launches():
