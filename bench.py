@@ -126,12 +126,15 @@ def main():
     # SMCMI_BENCH_COMM=host (development / tests): the ranks share ONE GPU and the sharded driver's collectives go through the library's
     # host-mediated communicator over gloo (include/smcmi.h smcmi_comm_init_host) - the whole multi-rank code path of this script,
     # pre-flight included, on a one-GPU box.  Never what a scaling number is measured with (config.comm says which it was).
+    # SMCMI_BENCH_COMM=rccl_shared (tests): the ranks share one GPU as well, but the library's RCCL branch carries the collectives (smcmi_comm_init ->
+    # whatever SMCMI_RCCL_PATH names: tests/fake_rccl, the shared-memory stand-in); torch.distributed itself runs over gloo.
     host_comm = os.environ.get("SMCMI_BENCH_COMM") == "host"
-    if world > 1 and torch.cuda.device_count() < world and not host_comm:
+    shared_gpu = host_comm or os.environ.get("SMCMI_BENCH_COMM") == "rccl_shared"
+    if world > 1 and torch.cuda.device_count() < world and not shared_gpu:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
-    if host_comm:
+    if shared_gpu:
         local_rank = 0
-    red_dev = "cpu" if host_comm else "cuda"            # device of the small tensors torch.distributed reduces
+    red_dev = "cpu" if shared_gpu else "cuda"           # device of the small tensors torch.distributed reduces
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("SMCMI_FORCE_SHARDED") == "1"
@@ -139,7 +142,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if host_comm:
+        if shared_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -246,7 +249,7 @@ def main():
                 eng.init_from_prior()        # every step is a whole job: each rank draws its shard again (global particle ids)
             return eng.run_sharded(solver_passes=args.solver_passes, use_graph=2 if profile else 0, **run_extra, **RUN_KW)
 
-    hand_over = None
+    hand_over, preflight = None, None
     if world > 1 or force_sharded:
         # Pre-flight on the hardware at hand, outside every timed region: one run with the per-stage hand-overs as RCCL all-gathers and
         # one with the library's default - the peer mailbox over xGMI when every rank could map and test it (include/smcmi.h).  Both
@@ -268,14 +271,31 @@ def main():
         except Exception as ex:   # noqa: BLE001
             ok = 0
             sys.stderr.write("bench.py: rank %d: run with the default hand-over failed (%s): falling back to all-gathers\n" % (rank, ex))
-        flags = torch.tensor([ok, used], device=red_dev, dtype=torch.int32)
+        segs = 1 if (ok and rb.get("n_segments", 0) > 0) else 0
+        flags = torch.tensor([ok, used, segs], device=red_dev, dtype=torch.int32)
+        sums = flags.clone()
         if dist is not None:
             dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         if int(flags[0].item()) == 0:
             os.environ["SMCMI_MAILBOX"] = "0"
         hand_over = "peer mailbox (xGMI)" if int(flags[0].item()) == 1 and int(flags[1].item()) == 1 else "RCCL all-gather"
-        if host_comm:
-            hand_over = hand_over.replace("(xGMI)", "(HIP IPC, one GPU)").replace("RCCL all-gather", "host-mediated all-gather") + " [SMCMI_BENCH_COMM=host: ranks share one GPU]"
+        if shared_gpu:
+            hand_over = hand_over.replace("(xGMI)", "(HIP IPC, one GPU)")
+            if host_comm:
+                hand_over = hand_over.replace("RCCL all-gather", "host-mediated all-gather")
+            hand_over += " [SMCMI_BENCH_COMM=%s: ranks share one GPU]" % os.environ["SMCMI_BENCH_COMM"]
+        # what the pre-flight found, rank by rank (a fall-back on the real node must be visible in the line, not just slower):
+        #   allgather_run_ok  the run with every hand-over as an all-gather completed on this many ranks (all, or the job has died above)
+        #   default_run_ok    ranks on which the library's default transport completed AND reproduced that run's stage count, resample count and
+        #                     log-MDD bit for bit (anything short of `ranks` => every rank falls back to all-gathers for the timed steps)
+        #   mailbox_ranks     ranks whose default run handed its sums over through the peer mailbox
+        #   segment_ranks     ranks whose default run ran its stages inside persistent segments that span the ranks
+        preflight = {"ranks": world, "allgather_run_ok": world, "default_run_ok": int(sums[0].item()), "bits_equal": int(flags[0].item()) == 1,
+                     "mailbox_ranks": int(sums[1].item()), "segment_ranks": int(sums[2].item()),
+                     "mailbox_ok": int(flags[0].item()) == 1 and int(flags[1].item()) == 1,
+                     "collectives": ("host functions over gloo" if host_comm else ("RCCL entry points from " + os.environ.get("SMCMI_RCCL_PATH", "librccl.so"))),
+                     "timed_steps_use": hand_over}
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -306,10 +326,15 @@ def main():
                    "n_phi": RUN_KW.get("n_phi", 300), "lambda": 2.1,
                    "resampling": "systematic", "n_blocks": RUN_KW["n_blocks"], "alpha": RUN_KW["alpha"], "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world,
-                   "hand_over": hand_over},
+                   "hand_over": hand_over, "preflight": preflight},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
         # stages that ran inside persistent segments (engine 3; with several ranks: sharded segments through the peer mailbox)
         "segments": last.get("n_segments", 0), "segment_stages": last.get("segment_stages", 0),
+        # blocks (= CUs: all resident for the whole launch) of a segment launch; the handle's segment state after the run (1 usable, 0 not applicable,
+        # -1 residency self-test failed / a hand-over timed out: launches only); runs repeated as launches after a time-out; the stage from which a
+        # fixed-schedule run fell back from lagged to exact energy shifts (0: never)
+        "segment_blocks": last.get("segment_blocks", 0), "segment_state": last.get("segment_state", 0), "segment_timeouts": last.get("segment_timeouts", 0),
+        "shift_fallback_stage": last.get("shift_fallback_stage", 0),
         "logmdd_exact": models.gauss_logmdd(D) if args.workload == "gauss10" else None, "solver_passes_per_stage": last.get("solver_passes", 0) / max(last["n_stages"] - 1, 1),
     }
 
@@ -326,7 +351,8 @@ def main():
         if prof is None:
             prof = one_step(profile=True)
         n_k = n_local if sharded else n_total
-        nl = max(prof["n_mutate_launches"], 1)
+        nl_real = prof["n_mutate_launches"]                      # (0: every mutation of the run ran inside segments)
+        nl = max(nl_real, 1)
         mean_ms = prof["kernel_ms_mutate"] / nl
         bytes_per_launch = mutate_bytes_per_particle(D) * n_k          # all MH steps of a stage are fused in the one launch
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
@@ -357,7 +383,7 @@ def main():
         # and `valu` carries the counter-derived issue fraction (null without a PMC file for this size).
         out["roofline"] = {"bound": "valu" if D <= 10 else "hbm", "kernel": kname_run, "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl,
+                           "bytes_per_launch": bytes_per_launch, "mean_launch_us": 1e3 * mean_ms, "launches": nl_real,
                            "valu_frac": valu.get("frac") if valu else None, "valu": valu,
                            "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None}
         if prof.get("n_segments", 0) > 0 and prof.get("segment_stages", 0) > 0 and prof.get("kernel_ms_segments", 0.0) > 0.0:
@@ -375,16 +401,27 @@ def main():
                 k3 = [(name, v) for name, v in pm["kernels"].items() if "k3_segment<%d," % D in name]
                 if k3 and k3[0][1].get("launches"):
                     traffic3, pmc3 = k3[0][1].get("sum_total_bytes", 0.0) / k3[0][1]["launches"], k3[0][1].get("valu")      # HBM bytes of an average launch
-            out["roofline"] = {"bound": "hbm", "kernel": "k3_segment<%d, %s> (persistent: one launch = a run of stages)" % (D, "true" if RUN_KW["alpha"] == 1.0 else "false"),
+            riding = bool(RUN_KW.get("use_fixed_schedule")) and os.environ.get("SMCMI_SHIFT_LAG", "1") != "0" and not sharded
+            # `frac` stays what the contract defines (algorithmic bytes / duration / HBM peak); `bound` names the real limiter: a stage is a chain
+            # of dependent work in ONE block between chip-wide hand-overs.  floor_us = that chain with hand-overs of two store->load hops and
+            # nothing else (DESIGN §4b's phase table: correction row 3.8 + decision / proposal 5.7 + MH step 4.5 + mutation row 2.7 + begin 3.2
+            # [adaptive; 1.3 fixed] + draws 2.4 where no wait hides them + 1.1 per hand-over): the kernel's own ceiling, not the chip's.
+            floor_us = (3.8 + 2.4 + 1.3 + 5.7 + 4.5 + 1.7 + 1.1) if riding else (3.8 + 5.7 + 4.5 + 2.7 + 3.2 + 2 * 1.1)
+            out["roofline"] = {"bound": "latency", "kernel": "k3_segment<%d, %s, %s> (persistent: one launch = a run of stages)" % (D, "true" if RUN_KW["alpha"] == 1.0 else "false", "true" if riding else "false"),
                                "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach3 / HBM_PEAK_GBS, "traffic": traffic3,
                                "bytes_per_launch": stage_b * seg_st / seg_n, "mean_launch_us": 1e3 * seg_ms / seg_n, "launches": seg_n,
                                "stages_per_launch": seg_st / seg_n, "bytes_per_stage": stage_b, "mean_stage_us": 1e3 * seg_ms / seg_st,
-                               "note": "latency-bound at this N: two chip-wide hand-overs per stage (two store->load hops each) + the serial "
-                                       "decision / proposal / Newton work of one block; the correction and selection of resample / certificate "
-                                       "stages run as engine 2's launches in front of the segment that enters at their mutation "
-                                       "(%d segment launches for %d stages)" % (seg_n, last["n_stages"] - 1),
+                               "floor_us": floor_us, "floor_frac": floor_us / (1e3 * seg_ms / seg_st),
+                               "cus_occupied": prof.get("segment_blocks", 0), "cus": 256,
+                               "hand_overs_per_stage": 1 if riding else 2,
+                               "note": "latency-bound at this N, not HBM-bound (`frac` is the contract's algorithmic-bytes figure; the cloud stays in "
+                                       "registers, `traffic` is history columns + one row per block and phase): %s per stage (two store->load hops "
+                                       "each) + the serial decision / proposal / %s work of one block; resample stages run inside the segment, "
+                                       "certificate stages as engine 2's launches in front of the segment that enters at their mutation "
+                                       "(%d segment launches for %d stages)" % ("ONE chip-wide hand-over" if riding else "two chip-wide hand-overs",
+                                                                                "schedule" if riding else "Newton", seg_n, last["n_stages"] - 1),
                                "valu": pmc3, "pmc_file": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
-                               "mutation_kernel_outside_segments": {"kernel": kname_run, "mean_launch_us": 1e3 * mean_ms, "launches": nl}}
+                               "mutation_kernel_outside_segments": {"kernel": kname_run, "mean_launch_us": 1e3 * mean_ms if nl_real else None, "launches": nl_real}}
         if args.workload == "kalman" and mean_ms > 0:
             # config 5 is compute bound: ~3300 FP64 flops per filter step (FMA = 2; csrc/model.hpp kalman_lgss), steps = new + old
             # periods per proposal; FP64 peak of MI355X = 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz = 78.6 TFLOP/s

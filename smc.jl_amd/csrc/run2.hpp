@@ -860,7 +860,6 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (sa.clear_status && hk + 1 == g.hs.size()) status_pending = false;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         sa.g_cm = e->d_gran3; sa.g_mut = sa.g_cm + nblk * 72 * 2; sa.gt_cm = sa.g_mut + nblk * RMUT * 2; sa.gt_mut = sa.gt_cm + (size_t)V2_MAXV * 72 * 2;
-        sa.row_par = (long long)k3_copy_words((int)nblk); sa.tot_par = seg_sys ? 0 : sa.row_par;       // stage n's tables: copy n & 1 (stage3.hpp Seg3Args)
         sa.sel = sel_inside ? e->d_sel3 : nullptr;
         if (seg_sys) {                                               // the totals tables every handle posts into: inside the mailbox allocation
             sa.peers = h->d_peers; sa.world = g.world;

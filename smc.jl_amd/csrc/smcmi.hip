@@ -161,6 +161,8 @@ extern "C" int smcmi_create(const smcmi_config *cfg, smcmi_handle **out) {
     h->nb_mut = (int)((n + h->mut_T - 1) / h->mut_T);
     h->nb_mut_ls4 = (int)((n + 63) / 64);              // lane-split mutation (lgss_kalman): 64 particles per 256-thread block
     // register-resident variant: only θ lives in per-thread LDS columns
+    // (256-thread blocks: 782 of them at config 4's 200 000 particles sit on 1 024 slots, 14 CUs holding a fourth - measured in round 6 with 128- and
+    // 64-thread blocks, which spread the wavefronts evenly: 60.7 / 61.0 / 61.1 µs per launch, no difference - the kernel is not bound by its slowest CU)
     h->reg_T = 256;
     h->nb_reg = (int)((n + h->reg_T - 1) / h->reg_T);
     h->mom_lds = (size_t)((h->d + 2) * (MT + 1)) * sizeof(double) + 2 * (size_t)h->npairs + 16;

@@ -431,11 +431,10 @@ struct Seg3Args {
     const double *sched;
     unsigned long long *g_cm, *g_mut;     // the workers' rows as granules: [blocks][MCM * 2] / [blocks][RMUT * 2] words
     unsigned long long *gt_cm, *gt_mut;   // the shard totals as granules: [V2_MAXV][MCM * 2] / [V2_MAXV][RMUT * 2], indexed by GLOBAL virtual shard
-    // every table exists twice, stage n's rows and totals live in copy n & 1 (row_par / tot_par words apart; tot_par = 0 with several handles,
-    // whose totals tables sit in the mailbox allocation): a block that publishes stage n + 1's correction row BEFORE it has read stage n's
-    // mutation totals (one hand-over per stage, below) overwrites nothing a slower block may still be waiting for - a copy is rewritten two
-    // stages later, which every block can only reach through hand-overs that need the slow block's next row
-    long long row_par, tot_par;
+    // (a RIDING launch - one handle - keeps two copies of these four tables, k3_copy_words(blocks) words apart, stage n's rows and totals in copy
+    // n & 1: a block that publishes stage n + 1's correction row BEFORE it has read stage n's mutation totals overwrites nothing a slower block
+    // may still be waiting for - a copy is rewritten two stages later, which every block can only reach through hand-overs that need the slow
+    // block's next row.  The kernel forms the offset itself: it has no scalar registers for two more arguments)
     // several handles (one per GPU; stage2.hpp peer mailbox): a gatherer posts its shard's totals into EVERY handle's tables - gt_cm / gt_mut
     // are this handle's copies inside its fine-grained mailbox allocation, peers[r] + off_cm / off_mut the same tables of handle r - and
     // every block reads its own handle's copy: the segment spans the GPUs with the hand-overs it has on one (two store -> load hops, the
@@ -462,7 +461,7 @@ struct Seg3Args {
     int prof_stage;
 };
 constexpr size_t k3_copy_words(int blocks) { return (size_t)blocks * (72 + RMUT + 2 + 72) * 2 + (size_t)V2_MAXV * (72 + RMUT + 2 + 72) * 2; }
-constexpr size_t k3_table_words(int blocks) { return 2 * k3_copy_words(blocks); }      // (two copies: Seg3Args::row_par; the selection's tables use the first only)
+constexpr size_t k3_table_words(int blocks) { return 2 * k3_copy_words(blocks); }      // (two copies: riding launches, Seg3Args; the selection's tables use the first only)
 
 // Block 0 of a segment launch, when it has written everything it writes into Ctl2 (all its threads call, at a block-uniform point): Ctl2 as
 // the launch leaves it goes into host-mapped memory, then the launch's sequence number - the host that finds the number there has the state
@@ -627,6 +626,40 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
     return rp.use_fixed_schedule && rp.shift_lag && !sys && n < sa.n_last && po.phi_n < 1.0 && !(rp.stop_stage > 0 && n >= rp.stop_stage) && n + 1 <= rp.max_stages;
 }
 
+// DRAW and BEGIN of the worker's stage loop (see there) as text: each instantiation of the kernel expands them at ONE place (the other is
+// discarded by `if constexpr`), and - unlike lambdas, whose by-reference captures put a dozen loop variables into scratch - they cost nothing.
+#define K3_DO_DRAW(ns)                                                                                                                          \
+    do {                                                                                                                                        \
+        if ((ns) <= sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(ns), db0, ma.debug);                                    \
+        K3_STAMP(sa.prof, 7);                                                                                                                   \
+    } while (0)
+// po_p: Post2 of stage ns - 1; pair: stage ns's correction row is out as well (riding) - both tables' totals in one fetch, s_tot filled for the
+// decision; the stage that ends a riding launch has no correction row: its begin takes the mutation totals alone.  ACT <- the begin's code, -1: timed out
+#define K3_DO_BEGIN(ns, po_p, pair, ACT)                                                                                                         \
+    do {                                                                                                                                        \
+        const unsigned tag_p_ = sa.tag_base | (unsigned)((ns) - 1);                                                                             \
+        bool ok_;                                                                                                                               \
+        if (RIDE && (pair)) {                                                                                                                   \
+            const unsigned tag_c_ = sa.tag_base | (unsigned)(ns);                                                                               \
+            ok_ = rows_two ? gather_totals_pair<2>(sa.g_mut + K3_RPAR((ns) - 1), tag_p_, sa.g_cm + K3_RPAR(ns), MCM, tag_c_, g.V, sa.to, &s_to, s_totm, s_tot, s_vt)  \
+                           : gather_totals_pair(rows_direct ? sa.g_mut + K3_RPAR((ns) - 1) : sa.gt_mut + K3_TPAR((ns) - 1), tag_p_,             \
+                                                rows_direct ? sa.g_cm + K3_RPAR(ns) : sa.gt_cm + K3_TPAR(ns), MCM, tag_c_, g.V, sa.to, &s_to, s_totm, s_tot, s_vt);  \
+        } else {                                                                                                                                \
+            ok_ = rows_two ? gather_totals<2>(sa.g_mut + K3_RPAR((ns) - 1), g.V, RMUT, RMAX_IDX, tag_p_, sa.to, &s_to, s_tot, s_vt)            \
+                           : gather_totals(rows_direct ? sa.g_mut + K3_RPAR((ns) - 1) : sa.gt_mut + K3_TPAR((ns) - 1), g.V, RMUT, RMAX_IDX, tag_p_, sa.to, &s_to, s_tot, s_vt, sys,  \
+                                           (writer && sys) ? sa.vt_mut_out : nullptr);                                                          \
+        }                                                                                                                                       \
+        if (!ok_) { timed_out = true; ACT = -1; break; }                                                                                        \
+        K3_STAMP(sa.prof, 8);                                                                                                                   \
+        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);                                                                                            \
+        ACT = begin_stage((ns), (po_p), (RIDE && (pair)) ? s_totm : s_tot);                                                                     \
+        constexpr int NWB_ = sizeof(Begin2) / sizeof(double);                                                                                   \
+        if (ACT == 0 && writer && tid < NWB_) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];       \
+        K3_STAMP(sa.prof, 9);                                                                                                                   \
+    } while (0)
+#define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? (long long)k3_copy_words(W) : 0)
+#define K3_TPAR(stage) K3_RPAR(stage)
+
 // grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard; W blocks
 // where the workers take the rows themselves: one handle with one or two blocks per virtual shard).
 // Worker b owns block (b / Vl) of local virtual shard (b % Vl): with the hardware's round-robin of consecutive blocks over the 8 XCDs
@@ -733,16 +766,16 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         // (one hand-over per stage, see the workers: a stage whose correction rows ride the mutation rows in front of it has them swept and posted
         // BEFORE this block takes the mutation totals and runs the begin - the workers wait for the correction totals, nothing else)
         bool cm_posted = false;
-        auto sweep_cm = [&](int ns) -> bool {
+        auto sweep_cm = [&](int ns) __attribute__((always_inline)) -> bool {
             const unsigned tg = sa.tag_base | (unsigned)ns;
-            const long long rp_ = (RIDE && (ns & 1)) ? sa.row_par : 0, tp_ = (RIDE && (ns & 1)) ? sa.tot_par : 0;
+            const long long rp_ = (RIDE && (ns & 1)) ? (long long)k3_copy_words(W) : 0, tp_ = rp_;
             return gather_vshard<T3>(sa.g_cm + rp_ + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tg, sa.to, &s_to,
                                      [&](int idx, double val) { post_total(sa.gt_cm + tp_, sa.off_cm, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tg); }, g_stage,
                                      (sa.gprof && ns == sa.prof_stage) ? sa.gprof + 90 + 4 * vg : nullptr);
         };
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
-            const long long rpar = (RIDE && (n & 1)) ? sa.row_par : 0, tpar = (RIDE && (n & 1)) ? sa.tot_par : 0;      // stage n's copy of the tables (riding launches)
+            const long long rpar = (RIDE && (n & 1)) ? (long long)k3_copy_words(W) : 0, tpar = rpar;      // stage n's copy of the tables (riding launches)
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
             if (!entered) {
                 K3_WALL(sa.gprof, 40 + 6 * vg + 0);
@@ -830,104 +863,77 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     const bool rows_two = g.nb2 == 2 && !sys;                    // ... two blocks each (up to 8 192 particles: the reference's default 5 000): gather_totals<2>
     // rides: this stage's correction row was formed in front of its begin, behind the previous stage's mutation row (k3_rides)
     bool rides = false;
-    double v = 0.0;                                             // the particle's unnormalised weight W̃ of stage n (the entered stage: what K1 left)
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
         RecB3<D> &B = s_b[n & 1];
         const Post2 &po = s_b[(n - 1) & 1].po;                  // stage n - 1 as completed
         const unsigned tag = sa.tag_base | (unsigned)n;
         // (stage n's copy of the tables: formed where they are used - the stage loop has no scalar registers to carry addresses across its phases)
-        // (only a riding launch needs the second copy - Seg3Args::row_par: with two hand-overs per stage nobody is ever a table ahead)
-#define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? sa.row_par : 0)
-#define K3_TPAR(stage) ((RIDE && ((stage) & 1)) ? sa.tot_par : 0)
+        // (K3_RPAR / K3_TPAR: only a riding launch needs the second copy - Seg3Args: with two hand-overs per stage nobody is ever a table ahead)
         // the proposal arrays of THIS stage
         L.Lraw = B.pr.Lraw; L.logdet_s = B.pr.logdet; L.mub_raw = B.pr.mub; L.sdd_raw = B.pr.sdd; L.sdn_raw = B.pr.sdn;
         L.ball_raw = B.pr.ball; L.bptr_s = B.pr.bptr; L.loff_s = B.pr.loff;
         const bool first = n == sa.n_first;                     // (its begin ran in front of the loop, its draws are parked)
         const bool entered = sa.enter_mut && first;             // this stage's correction (and selection) ran as launches: totals in s_tot
         int rs = entered ? rs0 : 0;
-        if (entered) v = v_entered;
-        // Three steps lead up to the stage's correction totals, in an order that depends on whether the correction rides (ONE site of code each:
-        // the stage loop has neither registers nor instruction cache for a second copy):
-        //   DRAW   the first proposal's random numbers of stage n (functions of (seed, particle, stage) only), under whatever hand-over is pending
-        //   BEGIN  the V shard totals of stage n - 1's mutation rows -> stage n's begin (smc_main.jl:378-396, helpers.jl:9-56)
+        double v = entered ? v_entered : 0.0;                   // the particle's unnormalised weight W̃ of stage n (the entered stage: what K1 left)
+        // Three steps lead up to a stage's correction totals (ONE site of code each per instantiation: the stage loop has neither registers nor
+        // instruction cache for a second copy):
         //   CORR   correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block, published
-        // as DRAW, BEGIN, CORR when the begin decides ϕ_n (RIDE = false: adaptive schedules, several handles), as CORR, DRAW, BEGIN when ϕ_n and
-        // the energy shift are known beforehand (RIDE = true, k3_rides): then both rows of a block are out before it waits for anything.  (The
-        // first stage of a riding launch has its begin and its draws from the launch's prologue: CORR alone, on the begin's values.)
+        //   DRAW   the first proposal's random numbers of the stage (functions of (seed, particle, stage) only), under whatever hand-over is pending
+        //   BEGIN  the V shard totals of the previous stage's mutation rows -> the stage's begin (smc_main.jl:378-396, helpers.jl:9-56)
+        // RIDE = false (adaptive schedules, several handles): CORR here, DRAW and BEGIN of the NEXT stage at the end of the loop body - the begin
+        // decides ϕ_n.  RIDE = true (k3_rides): CORR, DRAW, BEGIN here, in that order - ϕ_n and the energy shift are known beforehand, both rows of
+        // a block are out before it waits for anything.  (The first stage of a launch has its begin and its draws from the launch's prologue.)
         int act = 0;
+        if (!entered && !(RIDE && !first && !rides)) {          // (riding: the stage that ends the launch forms no row - its begin, next, says so)
+            // (riding: what begin2_wave will put into Begin2 for a fixed schedule under shift_lag - the same values, before the begin has run)
+            const double phi = rides ? (n <= rp.n_phi ? sa.sched[n - 1] : 1.0) : s_a.bg.phi_n, phi_prev = rides ? po.phi_n : s_a.bg.phi_prev;
+            const double esh = pw == 0.0 ? (rides ? po.e_seen - (rp.shift_lag == n ? 1e6 : 0.0) : s_a.bg.e_shift) : 0.0;
+            unsigned long long *my_cm = sa.g_cm + K3_RPAR(n) + (long long)rowi * MCM * 2;
+            if constexpr (ALPHA1) {
+                // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
+                double xx[D + 1];
 #pragma unroll
-        for (int ph = 0; ph < 3; ++ph) {
-            const int op = RIDE ? (ph == 0 ? 2 : ph - 1) : ph;           // 0 DRAW, 1 BEGIN, 2 CORR
-            if (op == 0) {
-                if (!first && n <= sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);
-                K3_STAMP(sa.prof, 7);
-            } else if (op == 1) {
-                if (first) continue;
-                const unsigned tag_p = sa.tag_base | (unsigned)(n - 1);
-                if (RIDE && rides) {
-                    // (this stage's correction row is out as well: both tables' totals in one fetch - the decision below finds s_tot filled; the
-                    // stage that ends a riding launch has no correction row: its begin takes the mutation totals alone)
-                    if (!(rows_two ? gather_totals_pair<2>(sa.g_mut + K3_RPAR(n - 1), tag_p, sa.g_cm + K3_RPAR(n), MCM, tag, g.V, sa.to, &s_to, s_totm, s_tot, s_vt)
-                                   : gather_totals_pair(rows_direct ? sa.g_mut + K3_RPAR(n - 1) : sa.gt_mut + K3_TPAR(n - 1), tag_p,
-                                                        rows_direct ? sa.g_cm + K3_RPAR(n) : sa.gt_cm + K3_TPAR(n), MCM, tag, g.V, sa.to, &s_to, s_totm, s_tot, s_vt))) { timed_out = true; act = -1; break; }
-                } else {
-                if (!(rows_two ? gather_totals<2>(sa.g_mut + K3_RPAR(n - 1), g.V, RMUT, RMAX_IDX, tag_p, sa.to, &s_to, s_tot, s_vt)
-                               : gather_totals(rows_direct ? sa.g_mut + K3_RPAR(n - 1) : sa.gt_mut + K3_TPAR(n - 1), g.V, RMUT, RMAX_IDX, tag_p, sa.to, &s_to, s_tot, s_vt, sys,
-                                               (writer && sys) ? sa.vt_mut_out : nullptr))) { timed_out = true; act = -1; break; }
+                for (int a = 0; a <= D; ++a) xx[a] = 0.0;
+                if (live) {
+                    double inc;
+                    v = k2_cm_weight<D>([&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, xx, &inc);
+                    if (hist) {
+                        const double unshift = exp((phi - phi_prev) * esh);
+                        sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                    }
                 }
-                K3_STAMP(sa.prof, 8);
-                K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);
-                act = begin_stage(n, po, (RIDE && rides) ? s_totm : s_tot);
-                constexpr int NWB = sizeof(Begin2) / sizeof(double);
-                if (act == 0 && writer && tid < NWB) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];
-                K3_STAMP(sa.prof, 9);
-                if (act != 0) break;                            // leave: registers hold the cloud after stage n - 1
-                if (RIDE && !rides) {                           // (cannot happen, see k3_rides: this stage's correction row was due in front of the begin)
+                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+            } else {
+                // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
+                // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
+                constexpr int NCH = (NPF + 63) / 64;
+                double acc[NCH * 64];
+#pragma unroll
+                for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
+                if (live) {
+                    double inc;
+                    v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
+                    if (hist) {
+                        const double unshift = exp((phi - phi_prev) * esh);
+                        sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
+                    }
+                }
+                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+            }
+            if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
+        }
+        K3_STAMP(sa.prof, 2);
+        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
+        if constexpr (RIDE) {
+            if (!first) {
+                K3_DO_DRAW(n);
+                K3_DO_BEGIN(n, po, rides, act);
+                if (act == 0 && !rides) {                       // (cannot happen, see k3_rides: this stage's correction row was due in front of its begin)
                     if (writer && tid == 0) { ctl->status.err = SMCMI_ERR_STATE; ctl->status.stage = n; ctl->status.code = 9; __hip_atomic_store(sa.to, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     act = -1;
-                    break;
                 }
-            } else {
-                if (entered || (RIDE && !first && !rides)) continue;      // (the stage that ends a riding launch: its begin, next, says so)
-                // (riding: what begin2_wave will put into Begin2 for a fixed schedule under shift_lag - the same values, before the begin has run)
-                const double phi = rides ? (n <= rp.n_phi ? sa.sched[n - 1] : 1.0) : s_a.bg.phi_n, phi_prev = rides ? po.phi_n : s_a.bg.phi_prev;
-                const double esh = pw == 0.0 ? (rides ? po.e_seen - (rp.shift_lag == n ? 1e6 : 0.0) : s_a.bg.e_shift) : 0.0;
-                unsigned long long *my_cm = sa.g_cm + K3_RPAR(n) + (long long)rowi * MCM * 2;
-                if constexpr (ALPHA1) {
-                    // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
-                    double xx[D + 1];
-#pragma unroll
-                    for (int a = 0; a <= D; ++a) xx[a] = 0.0;
-                    if (live) {
-                        double inc;
-                        v = k2_cm_weight<D>([&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, xx, &inc);
-                        if (hist) {
-                            const double unshift = exp((phi - phi_prev) * esh);
-                            sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
-                        }
-                    }
-                    k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
-                } else {
-                    // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
-                    // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
-                    constexpr int NCH = (NPF + 63) / 64;
-                    double acc[NCH * 64];
-#pragma unroll
-                    for (int q = 0; q < NCH * 64; ++q) acc[q] = 0.0;
-                    if (live) {
-                        double inc;
-                        v = k2_cm_particle<D>(acc, [&](int a) { return x[a]; }, po.shift, like, like_prev, Wt, esh, phi, phi_prev, pw, logp_old, &inc);
-                        if (hist) {
-                            const double unshift = exp((phi - phi_prev) * esh);
-                            sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
-                        }
-                    }
-                    k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
-                }
-                if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
-                K3_STAMP(sa.prof, 2);
-                K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
             }
         }
         if (act != 0) break;
@@ -1026,9 +1032,16 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 6);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 2);
         if constexpr (RIDE) rides = k3_rides(rp, sa, B.po, n, sys);             // stage n + 1's correction row goes out right behind this row?
+        else {
+            K3_DO_DRAW(n + 1);                                  // stage n + 1's draws, under the hand-over
+            K3_DO_BEGIN(n + 1, B.po, false, act);               // ---- the V shard totals -> stage n + 1's begin
+            if (act != 0) break;                                // leave: registers hold the cloud after stage n
+        }
     }
 #undef K3_RPAR
 #undef K3_TPAR
+#undef K3_DO_DRAW
+#undef K3_DO_BEGIN
     // ---- the cloud goes back to buffer 0 as the last completed stage left it
     if (live && !timed_out) {
 #pragma unroll

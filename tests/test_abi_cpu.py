@@ -65,11 +65,14 @@ def test_mutation_kernel_keeps_three_waves_per_simd(libmod):
     txt = open(rep).read()
     # (round 4: four wavefronts per SIMD since the main translation unit is compiled without machine LICM - 127 / 128 VGPRs, one below
     # the step; the segment kernels without a spilled VGPR since they are, Makefile MAINFLAGS / SEGFLAGS)
-    for key in ("k3_segmentILi10ELb1E", "k3_segmentILi10ELb0E"):
+    # (<n_para 10, α = 1?, riding?>: the two-hand-over variants - the headline's - and the riding α = 1 variant without a spilled VGPR; the riding
+    # mixture variant may keep a couple)
+    for key, max_spill, max_scratch in (("k3_segmentILi10ELb1ELb0E", 0, 64), ("k3_segmentILi10ELb0ELb0E", 0, 64), ("k3_segmentILi10ELb1ELb1E", 0, 64),
+                                        ("k3_segmentILi10ELb0ELb1E", 4, 96)):
         m = re.search(r"Function Name: _ZN5smcmi\d+" + key + r"[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*VGPRs Spill: (\d+)", txt)
         assert m, key
-        assert int(m.group(1)) == 0, (key, m.group(1))
-        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", txt[m.start():m.end()]).group(1)) <= 64, key
+        assert int(m.group(1)) <= max_spill, (key, m.group(1))
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", txt[m.start():m.end()]).group(1)) <= max_scratch, key
     for key, min_occ, max_scratch in (("k_mutate_regILi10ELb1E", 4, 64), ("k_mutate_regILi9ELb1E", 4, 64)):
         m = re.search(r"Function Name: _ZN5smcmi\d+" + key + r"[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*Occupancy \[waves/SIMD\]: (\d+)", txt)
         assert m, key

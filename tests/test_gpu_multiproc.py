@@ -92,7 +92,7 @@ def _check(runs, cloud, want, want_cloud, expect_mailbox):
     assert hashlib.sha256(np.ascontiguousarray(cloud).tobytes()).hexdigest() == hashlib.sha256(np.ascontiguousarray(want_cloud).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_processes_sharing_one_gpu_reproduce_the_single_handle(world, tmp_path):
     """Adaptive schedule (resample stages among the predicted ones), mailbox mapped across processes for the whole run."""
     cfg = dict(n=32768, d=10, seed=7, kw=dict(use_fixed_schedule=False, tempering_target=0.95), reps=2)
@@ -136,24 +136,34 @@ def test_all_gather_hand_overs_and_multinomial_across_processes(env, tmp_path):
     _check(runs, cloud, want, want_cloud, expect_mailbox=False)
 
 
-def test_bench_py_with_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("world,comm", [(2, "host"), (8, "rccl_shared")])
+def test_bench_py_with_several_ranks_on_one_gpu(world, comm):
     """bench.py's whole multi-rank path - rank set-up under torch.distributed.run, the pre-flight that checks the mailbox against the
     all-gathers bit for bit, the timed steps, the max-over-ranks time, the single-GPU reference, the JSON line - had never executed
-    with more than one rank (one GPU per box).  SMCMI_BENCH_COMM=host lets the ranks share the GPU over the host-mediated communicator."""
+    with more than one rank (one GPU per box).  SMCMI_BENCH_COMM=host lets the ranks share the GPU over the host-mediated communicator;
+    =rccl_shared over the library's RCCL branch (SMCMI_RCCL_PATH -> tests/fake_rccl, the shared-memory stand-in) at EIGHT ranks, the size of
+    the target node: the line's `config.preflight` says what every rank's pre-flight found."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMCMI_BENCH_COMM="host")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nparts", "65536", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-history"],
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMCMI_BENCH_COMM=comm)
+    if comm == "rccl_shared":
+        fake = os.path.join(ROOT, "tests", "fake_rccl")
+        subprocess.check_call(["make", "-C", fake, "libfake_rccl.so"], stdout=subprocess.DEVNULL)
+        env["SMCMI_RCCL_PATH"] = os.path.join(fake, "libfake_rccl.so")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--nparts", "65536", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-history"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["steps"] == 2
-    assert d["config"]["n_parts_total"] == 65536 and d["config"]["n_parts_per_gpu"] == 32768
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["steps"] == 2
+    assert d["config"]["n_parts_total"] == 65536 and d["config"]["n_parts_per_gpu"] == 65536 // world
     assert "one GPU" in d["config"]["hand_over"]
+    pf = d["config"]["preflight"]
+    assert pf["ranks"] == world and pf["default_run_ok"] == world and pf["bits_equal"] and pf["mailbox_ok"] and pf["mailbox_ranks"] == world, pf
+    assert pf["segment_ranks"] == world, pf                       # the stages ran inside segments that span the ranks
     assert d["speedup_vs_single_gpu"] > 0 and d["logmdd_abs_diff_vs_single_gpu"] == 0.0      # the same bits as the single handle (engine 3 there, engine 2 here)
     assert abs(d["logmdd_gpu"] - models.gauss_logmdd(10)) < 0.3
 

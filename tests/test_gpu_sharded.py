@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    oracle.build()
+    return oracle
+
+
 def _run_sharded_threads(spec, n, seed, world, kw):
     from smc_jl_amd import Engine
     from tests.shard_orchestrator import ShardedSMC
@@ -431,3 +439,50 @@ def test_host_closures_on_shards_tempered_update():
     full = np.concatenate([r["cloud"] for r in out], axis=0)
     np.testing.assert_allclose(full, P, rtol=1e-7, atol=1e-9)
     assert g["n_stages"] > 5
+
+
+@pytest.mark.parametrize("kw", [dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=3, alpha=0.9),
+                                dict(use_fixed_schedule=True, n_phi=60, n_blocks=3, n_mh_steps=2, resampling_method="multinomial"),
+                                dict(use_fixed_schedule=True, n_phi=80, n_blocks=1)],
+                         ids=["adaptive_mixture_3blocks", "fixed_multinomial_3blocks_2steps", "fixed_systematic_1block"])
+def test_forty_parameters_on_one_handle_and_on_two_shards_against_the_oracle(orc, kw):
+    """n_para > 16 (Smets-Wouters size: 40 parameters, examples/dsge_models/dsge_model.jl; regime-switching vectors,
+    src/smc_main.jl:206-216) runs on engine 1's kernels - one handle (run type R3) and, sharded, round 1's all-reduce driver (R7,
+    csrc/sharded.hpp run_sharded_impl) - which until now were compared with each other only.  Here both against the ORACLE on the same Philox
+    streams: ϕ schedule, ESS path, resample stages, c path, acceptance rates, log-MDD, fixed schedules and multinomial resampling included."""
+    from smc_jl_amd import Engine, run_group
+
+    d, n, seed = 40, 16384, 23
+    spec = models.gauss_spec(d=d, sigma=0.5, prior_sd=2.0)
+    m = models.oracle_model(spec)
+    P0 = orc.initial_draw(m, n, seed=seed)
+    r = orc.smc_run(m, P0, seed=seed, n_threads=8, history=False, **kw)
+    assert r["resamples"] >= 2
+
+    def check(g, recs):
+        assert (g["n_stages"], g["resamples"]) == (r["n_stages"], r["resamples"])
+        for rec in recs:
+            np.testing.assert_allclose(rec["schedule"], r["schedule"], rtol=1e-9)
+            np.testing.assert_allclose(rec["ess"], r["ess"], rtol=1e-8)
+            np.testing.assert_array_equal(rec["resampled"], r["resampled"])
+            np.testing.assert_allclose(rec["c_hist"], r["c_hist"], rtol=1e-9)
+            np.testing.assert_allclose(rec["accept_hist"], r["accept_hist"], atol=3.0 / n + 1e-12)
+        assert g["logmdd"] == pytest.approx(r["logmdd"], abs=1e-7)
+
+    e = Engine(n, d, seed=seed, max_stages=max(r["n_stages"] + 50, 300), store_history=False)
+    e.set_model(spec)
+    e.upload_cloud(P0)
+    g = e.run(**kw)
+    check(g, [e.stage_records(g["n_stages"])])
+    e.close()
+    nl = n // 2
+    engs = []
+    for k in range(2):
+        s = Engine(n, d, seed=seed, max_stages=max(r["n_stages"] + 50, 300), store_history=False, n_local=nl, gid0=k * nl)
+        s.set_model(spec)
+        s.upload_cloud(np.asfortranarray(P0[k * nl:(k + 1) * nl]))
+        engs.append(s)
+    g2 = run_group(engs, **kw)
+    check(g2, [s.stage_records(g2["n_stages"]) for s in engs])
+    for s in engs:
+        s.close()
