@@ -98,7 +98,6 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nparts", type=int, default=0, help="particles in total (default: 100 000 at --gpus 1, 1 000 000 at --gpus N > 1)")
-    ap.add_argument("--mode", default="direct", choices=["direct", "graph"], help="stage launch mode")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-history", action="store_true")
     ap.add_argument("--no-ref", action="store_true", help="--gpus N > 1: skip the single-GPU run of the same workload on rank 0")
@@ -213,7 +212,7 @@ def main():
 
         def one_step(profile=False):
             reset()
-            return eng.run(use_graph=(2 if profile else (1 if args.mode == "graph" else 0)), solver_passes=args.solver_passes,
+            return eng.run(use_graph=(2 if profile else 0), solver_passes=args.solver_passes,
                            sync_every=args.sync_every, phi_rtol=args.phi_rtol, **run_extra, **RUN_KW)
     else:
         # one process per GPU: equal contiguous shards, RCCL communicator bootstrapped through torch.distributed
@@ -324,7 +323,7 @@ def main():
                          else "lgss_kalman13_tempered_update_old40_new80_adaptive_phi_n%s" % (("%dk" % (n_total // 1000)) if n_total % 1000 == 0 else str(n_total))),
                    "n_parts_total": n_total, "n_parts_per_gpu": n_local, "n_para": D, "tempering_target": RUN_KW.get("tempering_target", 0.97),
                    "n_phi": RUN_KW.get("n_phi", 300), "lambda": 2.1,
-                   "resampling": "systematic", "n_blocks": RUN_KW["n_blocks"], "alpha": RUN_KW["alpha"], "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": args.mode,
+                   "resampling": "systematic", "n_blocks": RUN_KW["n_blocks"], "alpha": RUN_KW["alpha"], "n_mh_steps": RUN_KW["n_mh_steps"], "launch_mode": "direct",
                    "history": not args.no_history, "parallelism": "particles sharded x%d" % world,
                    "hand_over": hand_over, "preflight": preflight},
         "n_stages": last["n_stages"], "resamples": last["resamples"], "logmdd_gpu": last["logmdd"],
@@ -365,7 +364,7 @@ def main():
 
         kname = ("k_mutate_reg<%d," % D) if D <= 10 else ("k2w_mutate<%d," % D)
         # (small clouds and sharded runs use engine 2's k2_mutate, a single handle with a larger cloud engine 1's k_mutate_reg;
-        # n_para 11..16: k2w_mutate - engine 2's prologue in front of the generic mutation body - or, SMCMI_ENGINE_WIDE=0, engine 1's k_mutate)
+        # n_para 11..16: k2w_mutate - engine 2's prologue in front of the generic mutation body - or, SMCMI_ENGINE=1, engine 1's k_mutate)
         kname_run = ("k2_mutate<%d,...> / k2b_mutate<%d,...> / k_mutate_reg<%d,...>" % (D, D, D)) if D <= 10 else ("k2w_mutate<%d,...>" % D)
         traffic, valu = None, None
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_n%d.json" % (args.workload, n_k))),
@@ -438,7 +437,7 @@ def main():
             tf = flops / (mean_ms * 1e-3) / 1e12
             lanes = os.environ.get("SMCMI_KALMAN_LANES", "")
             split = lanes == "4" or (lanes != "1" and n_k <= 32768)
-            wide = os.environ.get("SMCMI_ENGINE_WIDE", "1") != "0" and os.environ.get("SMCMI_ENGINE", "0") != "1"
+            wide = os.environ.get("SMCMI_ENGINE", "0") != "1"
             kk = (lambda ls: ("k2w_mutate<13, %d> (decision + proposal prologue, then the filter)" % ls) if wide else ("k_mutate<0, %d>" % ls))
             kname5 = (kk(4) + " / kalman_lgss_quad: four lanes per particle (the default up to 32 768 particles per handle)" if split else
                       kk(1) + " / kalman_lgss_wave: one thread per particle, structure values through DPP operands")

@@ -71,7 +71,8 @@ typedef struct {
     double log_prob_old_data;              /* :161 */
     int32_t solver_passes;                 /* kernel passes enqueued for the adaptive-ϕ solver per stage (0 => default 1); a stage that needs more is resumed */
     int32_t sync_every;                    /* adaptive schedule: host checks the done flag every k stages (0 => default) */
-    int32_t use_graph;                     /* 1: replay the stage as a hipGraph; 2: direct launches + HIP events around the mutation kernel */
+    int32_t use_graph;                     /* 2: HIP events around the mutation kernel / the segment launches (smcmi_result::kernel_ms_*); 0 otherwise.
+                                              (1 replayed the stage as a hipGraph until round 5: no faster than direct launches, retired - taken as 0) */
     double initial_ess;                    /* cloud.ESS[1] for a tempered update started from an old cloud (0 => n_parts; initialization.jl:199-200) */
     double phi_rtol;                       /* relative bracket width accepted as the adaptive-ϕ root on stages that run certificate
                                               passes (0 => 1e-12; <0 => adjacent floats, and no stage is predicted).  Stages on the
@@ -293,10 +294,6 @@ int smcmi_mailbox_import(smcmi_handle *h, int32_t rank, int32_t world, const uin
 int smcmi_mailbox_selftest(smcmi_handle *h, int32_t rank, int32_t world, int32_t rounds, int32_t *errors_out);
 int smcmi_mailbox_active(smcmi_handle *h, int32_t *active_out);   /* 1: the last sharded run handed its per-stage sums over through the mailbox */
 int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_config *rc, smcmi_result *res);
-/* development aid: mean duration (µs, HIP events on the handle's stream) of `reps` back-to-back launches of one stage kernel on
-   the current cloud.  which: 0 pass16(p=0) 1 pass16(p=1, with decision prologue) 2 correction 3 post_correct 4 scan 5 resample_gather
-   6 moments 7 moments_reduce 8 prepare_mutation 9 mutate 10 stage_begin 11 empty kernel */
-int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t reps, double *usec_per_launch);
 /* parity aid: compute_proposal_densities(para_draw, para_subset, d_subset = MvNormal(mu, Sigma), c, alpha) (src/helpers.jl:128-164;
    quirk Q1: the diagonal component's density uses the unscaled Σ_ii) evaluated by the dense mixture code of the alpha < 1 mutation
    kernels on the current device, for one block of d <= 16 entries; Sigma row-major d x d.  q0 / q1 as the reference returns them. */

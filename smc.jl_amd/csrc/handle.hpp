@@ -118,13 +118,12 @@ struct smcmi_handle {
     bool run_adaptive = false;   // the enqueued stage belongs to an adaptive-schedule run (mutation leaves energy sums)
     int noop_grid = 4096;          // grid cap of the selection kernels inside smcmi_run (they are no-ops on most stages)
     bool launch_alpha1 = false;
-    long long *d_prof = nullptr;   // development only (smcmi_debug_time_kernel with which = 9 and SMCMI_PROF_MUT=1)
+    long long *d_prof = nullptr;   // development only (SMCMI_PROF2: engine 1's phase stamps)
     // host-mapped progress words of a fixed-schedule run enqueued without selection kernels (smcmi_run): [0] stage index the device
     // has begun, [1] != 0: a stage stalled because it resamples after all.  h_note is the host view, d_note the device alias.
     volatile int *h_note = nullptr;
     int *d_note = nullptr;
     bool note_on = false;          // the stage being enqueued posts to the words
-    hipGraphExec_t graph_exec = nullptr;
     int graph_sig = 0;
     Eng2 *e2 = nullptr;            // engine 2 (stage2.hpp / run2.hpp): rows, virtual-shard totals, Ctl2
     // host likelihoods (callback.hpp)

@@ -1299,7 +1299,7 @@ static __global__ void __launch_bounds__(TB) k_zero_bad_weights(CloudPtrs cl, co
     if (col(cl, st->cur, d)[i] == SMCMI_NEG_INF) col(cl, st->cur, cl.R - 1)[i] = 0.0;
 }
 // normalize_weights! (src/particle.jl:362-366): W *= n_parts, W /= sum(W); st->sumw holds the fixed-order sum
-static __global__ void __launch_bounds__(TB) k_normalize_weights_n(CloudPtrs cl, const DevState *st, double n_parts) {
+static __global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st, double n_parts) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     double *w = col(cl, st->cur, cl.R - 1);
@@ -1619,14 +1619,6 @@ static __global__ void __launch_bounds__(TB) k_reduce_rows(const double *partial
     }
 }
 
-// normalize_weights! as its own pass (src/particle.jl:362-366) for the stand-alone correction call
-static __global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st) {
-    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
-    if (i >= cl.n) return;
-    double *w = col(cl, st->cur, cl.R - 1);
-    w[i] = (w[i] * (double)st->rp.n_parts) / st->sumw;
-}
-
 // per-chunk weight sums in the layout k_post_correct / k_scan_weights expect (partials[2 b])
 static __global__ void __launch_bounds__(TB) k_weight_chunk_sums(CloudPtrs cl, const DevState *st, double *partials) {
     __shared__ double red[(TB / 64) * 2];
@@ -1644,7 +1636,6 @@ static __global__ void k_chunk_offsets(DevState *st, const double *partials, int
     for (int b = 0; b < nb; ++b) { chunk_off[b] = run; run += partials[2 * (long long)b]; }
     if (set_sum) st->sumw = run;
 }
-static __global__ void k_flip(DevState *st) { st->cur ^= 1; }
 
 // θ_bar, R from the moment partials; free subset + symmetrisation (src/smc_main.jl:457-465); random blocks
 // (generate_free_blocks/all_blocks, src/helpers.jl:215-260, Fisher-Yates on Philox); then per block the scaled
@@ -3037,8 +3028,6 @@ static __global__ void __launch_bounds__(TB) k_initialize_likelihoods_wave(Cloud
     }
 }
 
-// empty kernel (event-overhead calibration, smcmi_run profile mode)
-static __global__ void k_noop(const DevState *st) { (void)st; }
 // device-to-device copy of a cloud (n doubles, 16-byte aligned buffers): the runtime's blit kernel took 221 µs for the 12 MB of config 2,
 // a grid-stride copy with 16-byte accesses runs at HBM speed (~10 µs)
 static __global__ void __launch_bounds__(256) k_copy_f64(double *dst, const double *src, long long n) {

@@ -70,7 +70,7 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     // every geometry cuts a virtual shard the same way, so all of them total the same rows (<= 128 rows per virtual shard: the blocks
     // grow beyond 512 particles for nv > 65 536, where the direct geometry does not exist)
     g.nb1 = (int)std::max<long long>(1, g.direct ? g.nb2 : std::min<long long>((g.nv + 511) / 512, 128));
-    if (getenv("SMCMI_E2_NB1")) g.nb1 = std::max(1, std::min(atoi(getenv("SMCMI_E2_NB1")), g.direct ? 64 : 128));   // development only
+    if (getenv("SMCMI_E2_NB1")) g.nb1 = std::max(1, std::min(atoi(getenv("SMCMI_E2_NB1")), g.direct ? 64 : 128));   // development only (tools/shard_rank_prof.sh: one rank's share of a larger run)
     g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;                        // whole passes of the block
     g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? 32 : 256));
     g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
@@ -175,9 +175,8 @@ static bool eng2_eligible(const smcmi_handle *h, int world, bool single) {
     if (eng == 1 || h->d > 16) return false;
     Geo2 g;
     if (!handle_geo2(h, world, 0, single, &g)) return false;
-    if (g.wide) {                     // n_para 11 .. 16: the same two-launch stage around the generic mutation body (SMCMI_ENGINE_WIDE=0: engine 1's stage)
-        static const int wide_on = getenv("SMCMI_ENGINE_WIDE") ? atoi(getenv("SMCMI_ENGINE_WIDE")) : 1;
-        return wide_on != 0;
+    if (g.wide) {                     // n_para 11 .. 16: the same two-launch stage around the generic mutation body (SMCMI_ENGINE=1: engine 1's stage)
+        return true;
     }
     return eng == 2 || world > 1 || !single || g.direct;      // (a communicator of one rank is a sharded run: the measurement vehicle for one rank's share)
 }
@@ -199,157 +198,8 @@ static bool fused_tails(const Eng2 *e) {
     default: CALL(16); break;                                                                                                             \
     }
 
-// ---- peer mailbox (stage2.hpp): allocation and the table of peer addresses
-// clear the sticky time-out flag and (re)load the time-out (SMCMI_MAILBOX_TIMEOUT_MS, default 10 s; read at every run)
-static int mbox_reset_flag(smcmi_handle *h, hipStream_t s) {
-    const char *ms = getenv("SMCMI_MAILBOX_TIMEOUT_MS");
-    const unsigned long long fl[MB_FLAG_WORDS] = {0ull, ms && atof(ms) > 0.0 ? (unsigned long long)(atof(ms) * 1e5) : (unsigned long long)MB_TIMEOUT_TICKS_DEFAULT};
-    if (s) { HIP_TRY(hipMemcpyAsync(h->d_mbox + MB_WORDS, fl, sizeof(fl), hipMemcpyHostToDevice, s)); HIP_TRY(hipStreamSynchronize(s)); }
-    else HIP_TRY(hipMemcpy(h->d_mbox + MB_WORDS, fl, sizeof(fl), hipMemcpyHostToDevice));
-    return 0;
-}
-static int mbox_alloc(smcmi_handle *h) {
-    if (h->d_mbox) return 0;
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    // fine-grained: stores from a peer GPU and this GPU's polling loads meet in memory, not in a die's L2
-    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * MB_ALLOC_WORDS, hipDeviceMallocFinegrained));
-    HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_ALLOC_WORDS));
-    if (int e = mbox_reset_flag(h, nullptr)) return e;
-    HIP_TRY(hipDeviceSynchronize());              // (null-stream fill: not ordered with the handle's non-blocking stream)
-    return 0;
-}
-static int mbox_set_peers(smcmi_handle *h, const std::vector<unsigned long long *> &peers) {
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    if (h->d_peers) { hipFree(h->d_peers); h->d_peers = nullptr; }
-    HIP_TRY(hipMalloc((void **)&h->d_peers, sizeof(unsigned long long *) * peers.size()));
-    HIP_TRY(hipMemcpy(h->d_peers, peers.data(), sizeof(unsigned long long *) * peers.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipDeviceSynchronize());
-    h->h_peers = peers;
-    return 0;
-}
-// several handles of one process (tests; SMCMI_MAILBOX=1): every handle sees the others' tables directly
-static int mbox_setup_group(ShardGroup &g) {
-    std::vector<unsigned long long *> peers(g.hs.size());
-    for (auto *h : g.hs) {
-        if (int e = mbox_alloc(h)) return e;
-        peers[shard_rank(h)] = h->d_mbox;
-    }
-    for (auto *h : g.hs)
-        if (h->h_peers != peers) { if (int e = mbox_set_peers(h, peers)) return e; }
-    return 0;
-}
-// ---- peer mailbox across processes: HIP IPC handles of the tables, exchanged by the caller or through the communicator
-// One block: `rounds` exchanges of a (rank, round)-dependent row with every peer over the real transport; errs += mismatches / time-outs.
-static __global__ void k_mbox_selftest(unsigned long long *const *peers, const unsigned long long *mine, int world, int rank, int rounds, int *errs) {
-    const int t = threadIdx.x;
-    int bad = 0;
-    for (int q = 0; q < rounds; ++q) {
-        const unsigned tag = 0x7F000000u | (unsigned)q;
-        const long long table = (long long)(q & 1) * MB_TABLE_WORDS;
-        if (t < 16)
-            for (int r = 0; r < world; ++r) mb_store(peers[r] + table + ((long long)rank * MB_LD + t) * 2, 1000.0 * rank + q + t / 16.0, tag);
-        for (int idx = t; idx < world * 16; idx += blockDim.x) {
-            const int r = idx / 16, k = idx % 16;
-            const double x = mb_load(mine + table + ((long long)r * MB_LD + k) * 2, tag, const_cast<unsigned long long *>(mine) + MB_WORDS);
-            if (!(x == 1000.0 * r + q + k / 16.0)) ++bad;
-        }
-        __syncthreads();                     // (a rank re-uses a table two rounds later: only after it has read it)
-    }
-    if (bad) atomicAdd(errs, bad);
-}
-static void mbox_close_peers(smcmi_handle *h) {
-    for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);
-    h->ipc_opened.clear();
-    h->h_peers.clear();
-}
-static int mbox_export(smcmi_handle *h, uint8_t *out64) {
-    if (int e = mbox_alloc(h)) return e;
-    hipIpcMemHandle_t hd;
-    HIP_TRY(hipIpcGetMemHandle(&hd, h->d_mbox));
-    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
-    memcpy(out64, &hd, 64);
-    return 0;
-}
-static int mbox_import(smcmi_handle *h, int world, int rank, const uint8_t *all) {
-    if (world < 1 || world > V2_MAXV || rank < 0 || rank >= world) return set_err(SMCMI_ERR_ARG, "mailbox: bad (rank, world)");
-    if (int e = mbox_alloc(h)) return e;
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    mbox_close_peers(h);
-    std::vector<unsigned long long *> peers((size_t)world, nullptr);
-    for (int r = 0; r < world; ++r) {
-        if (r == rank) { peers[r] = h->d_mbox; continue; }
-        hipIpcMemHandle_t hd;
-        memcpy(&hd, all + 64 * (size_t)r, 64);
-        void *p = nullptr;
-        if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
-            (void)hipGetLastError();
-            mbox_close_peers(h);
-            return set_err(SMCMI_ERR_HIP, "mailbox: hipIpcOpenMemHandle failed for rank " + std::to_string(r));
-        }
-        h->ipc_opened.push_back(p);
-        peers[r] = (unsigned long long *)p;
-    }
-    return mbox_set_peers(h, peers);
-}
-// errors (mismatches + time-outs) of `rounds` exchanges with every peer; every rank must call it at the same time
-static int mbox_selftest(smcmi_handle *h, int world, int rank, int rounds, int *errs_out) {
-    if (!h->d_peers || (int)h->h_peers.size() != world) return set_err(SMCMI_ERR_STATE, "mailbox: peers not imported");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    int *d_err = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_err, sizeof(int)));
-    HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), h->stream));
-    k_mbox_selftest<<<1, 128, 0, h->stream>>>(h->d_peers, h->d_mbox, world, rank, rounds, d_err);
-    int e = 0;
-    HIP_TRY(hipMemcpyAsync(&e, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    hipFree(d_err);
-    *errs_out = e;
-    return 0;
-}
-// One handle per process (RCCL or the host-mediated communicator): map every rank's table through the communicator and test the
-// transport; all ranks reach the same verdict (h->mbox_ok) - anything short of a clean self-test on every rank leaves the all-gathers
-// in place.
-static int mbox_setup_remote(ShardGroup &g) {
-    smcmi_handle *h = g.hs[0];
-    if (h->mbox_tried) return 0;
-    h->mbox_tried = true; h->mbox_ok = false;
-    if (h->world > V2_MAXV) return 0;
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const int world = h->world, rank = h->rank;
-    uint8_t mine[64] = {0};
-    double fail = mbox_export(h, mine) ? 1.0 : 0.0;
-    double *d_send = nullptr, *d_recv = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_send, 64));
-    HIP_TRY(hipMalloc((void **)&d_recv, 64 * (size_t)world));
-    HIP_TRY(hipMemcpyAsync(d_send, mine, 64, hipMemcpyHostToDevice, h->stream));
-    if (int e = g.allgather([=](smcmi_handle *) { return (const double *)d_send; }, [=](smcmi_handle *) { return d_recv; }, (size_t)8)) {   // 64 bytes = 8 doubles per rank
-        hipFree(d_send); hipFree(d_recv);
-        return e;
-    }
-    std::vector<uint8_t> all(64 * (size_t)world);
-    HIP_TRY(hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    hipFree(d_send); hipFree(d_recv);
-    if (fail == 0.0 && mbox_import(h, world, rank, all.data())) fail = 1.0;
-    auto agree = [&](double mine_bad, double *total) -> int {           // sum of the ranks' failure counts
-        HIP_TRY(hipMemcpyAsync(h->d_comm, &mine_bad, sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (int e = g.allreduce([](smcmi_handle *hh) { return hh->d_comm; }, 1)) return e;
-        HIP_TRY(hipMemcpyAsync(total, h->d_comm, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        return 0;
-    };
-    double total = 0.0;
-    if (int e = agree(fail, &total)) return e;
-    if (total != 0.0) { mbox_close_peers(h); return 0; }               // some rank could not map: everybody keeps the all-gathers
-    int errs = 0;
-    if (mbox_selftest(h, world, rank, 256, &errs)) errs = 1;
-    if (int e = agree((double)errs, &total)) return e;
-    if (total != 0.0) { mbox_close_peers(h); return 0; }
-    h->mbox_ok = true;
-    return 0;
-}
-static long long mbox_table(int kind, unsigned cnt) { return (long long)(kind * 2 + (int)(cnt & 1u)) * MB_TABLE_WORDS; }
-static unsigned mbox_tag(unsigned epoch, unsigned cnt) { return ((epoch & 0x7Fu) << 24) | (cnt & 0xFFFFFFu); }      // (never 0xFFFFFFFF: a cleared word)
+#include "mailbox.hpp"
+#include "prof2.hpp"
 
 // Engine 3 serves a single handle in the direct geometry whose blocks are all resident at one per CU; the first use runs the residency
 // self-test (k3_census) and a failure - or SMCMI_ENGINE3=0 - leaves the handle on engine 2's launches for good.
@@ -461,10 +311,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl, h->rec, cont ? 0 : 1, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target);
         HIP_TRY(hipMemsetAsync(h->e2->d_tick, 0, 2 * V2_MAXV * TICK2_STRIDE * sizeof(int), h->stream));
         // random numbers drawn ahead: while K1 leaves most CUs idle (small clouds = the direct geometry with 512-thread mutation blocks)
-        static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
         Eng2 *e = h->e2;
         e->rng_ahead = false; e->z_ahead = 0; e->n_steps = rc->n_mh_steps; e->n_blocks = rc->n_blocks;
-        if (!no_ra && e->g.inker && e->g.t2 == 512 && e->g.Vl * e->g.nb1 <= 160) {
+        if (e->g.inker && e->g.t2 == 512 && e->g.Vl * e->g.nb1 <= 160) {
             const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)rc->n_mh_steps * (size_t)rc->n_blocks;
             if (need > h->zbuf_cap) {
                 if (h->d_zbuf) { hipFree(h->d_zbuf); h->d_zbuf = nullptr; h->zbuf_cap = 0; }
@@ -503,13 +352,12 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (bighelp) {
         // the first proposals' random numbers are drawn by blocks of K1 that follow the correction blocks onto the CUs and run under the helper
         // block's serial work: as many proposals per particle as fit that window (SMCMI_RNG_AHEAD_PART draws, default 250 000: engine 1's measure)
-        static const int no_ra = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
         static const long long part = getenv("SMCMI_RNG_AHEAD_PART") ? atoll(getenv("SMCMI_RNG_AHEAD_PART")) : 250000;
         for (auto *h : g.hs) {
             Eng2 *e = h->e2;
             const int za = (int)std::min<long long>((long long)rc->n_mh_steps * rc->n_blocks, part / std::max<long long>(1, h->n));
             e->z_ahead = 0;
-            if (no_ra || za < 1) continue;
+            if (za < 1) continue;
             HIP_TRY(hipSetDevice(h->cfg.device));
             const size_t need = (size_t)h->n * (size_t)(h->d + 2) * (size_t)za;
             if (need > h->zbuf_cap) {
@@ -596,7 +444,8 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (!multi && !g.rccl && g.hs.size() == 1) { if (int e = seg3_ready(h0, &e3)) return e; }
     // several handles: the segments span them when the peer mailbox is up (the gatherers post their shard totals into every handle's
     // tables, stage3.hpp Seg3Args::peers) and every handle's grid passed its residency self-test - all ranks must take the same decision
-    static const int e3_multi = getenv("SMCMI_ENGINE3_SHARDED") ? atoi(getenv("SMCMI_ENGINE3_SHARDED")) : 1;
+    static const int e3_env = getenv("SMCMI_ENGINE3") ? atoi(getenv("SMCMI_ENGINE3")) : 1;       // 0 off, 1 default, 2 one handle only, 3 also for in-process groups of any size
+    const int e3_multi = e3_env == 2 ? 0 : (e3_env == 3 ? 2 : 1);
     // (handles of ONE process share the device's few hardware queues: beyond two of them a handle's persistent launch can sit in a queue
     // in front of the launch it waits for - the in-process group driver, a test vehicle, keeps to launches there; =2 forces segments)
     const bool seg_sys = (multi || g.rccl) && mbox;      // (a one-rank communicator with SMCMI_MAILBOX=2: the measurement vehicle for one rank's share)
@@ -637,7 +486,6 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         sl.g_gm = sl.gt_sel + (size_t)V2_MAXV * 2 * 2; sl.gt_gm = sl.g_gm + nblk * 72 * 2;
         HIP_TRY(hipMemcpyAsync(e->d_sel3, &sl, sizeof(sl), hipMemcpyHostToDevice, h0->stream));
     }
-    static const int note3_on = getenv("SMCMI_SEG_NOTE") ? atoi(getenv("SMCMI_SEG_NOTE")) : 1;      // development: 0 = every batch ends with a copy and a sync
     // (the note outlives a run and sequence numbers start over - sharded segments reset them, 65 535 launches wrap them: a note left by an
     // earlier run must never equal the number a launch of this run is waited for under.  Every run ends with its stream drained, so nothing
     // is in flight that could still write the word)
@@ -669,7 +517,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     const bool profile = rc->use_graph == 2;
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_stage;
-    static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
+    const int dbg = 0;           // (the mutation kernels' ablation bits: retired as a switch in round 6)
     // large shards with helper blocks: the stage whose decision + proposal K1's helper leaves in Prop2Glob (no k2_prepare launch for it), and
     // the stage whose begin the mutation launch in front of it ran (no k2_begin launch for it) with that spec_expected
     int prepared_stage = -1, begun_stage = -1, begun_spec = 0;
@@ -868,7 +716,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             sa.vt_mut_out = e->vt_mut;
         }
         sa.rec = e->d_rec3;
-        sa.note = (!seg_sys && g.hs.size() == 1 && note3_on) ? (int *)e->d_note3 : nullptr; sa.note_seq = (int)e->seg_seq;
+        sa.note = (!seg_sys && g.hs.size() == 1) ? (int *)e->d_note3 : nullptr; sa.note_seq = (int)e->seg_seq;
         if (sa.note) { last_note_seq = (int)e->seg_seq; }
         sa.tag_base = e->seg_seq << 16; sa.to = e->d_to3; sa.hist_w = h->d_hist_w; sa.hist_ld = h->n;
         sa.done_out = (h == h0 && seg_launches < SEG3_MAX_LAUNCHES) ? e->d_done3 + seg_launches : nullptr;
@@ -1172,105 +1020,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // (a batch that ended with a segment's exit note was read before the launch had finished: everything behind this line reads what it left)
     HIP_TRY(hipSetDevice(h0->cfg.device));
     HIP_TRY(hipStreamSynchronize(h0->stream));
-    if (h0->e2->d_prof) {
-        long long pr[128];
-        HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));
-        if (seg_launches > 0) {
-            // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
-            fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the totals %lld | decision + proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the totals %lld | begin %lld | stage %lld\n",
-                    h0->e2->prof_stage, pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[9] - pr[1]);
-            // (a riding launch takes the steps in another order - CORR (2), DRAW (7), BEGIN (8, 9), totals (3), proposal (4), MH (5), row (6): the stamps themselves)
-            fprintf(stderr, "[smcmi3]   stamps relative to the stage's first:");
-            for (int q = 1; q <= 9; ++q) fprintf(stderr, " [%d] %lld", q, pr[q] - pr[1]);
-            fprintf(stderr, "\n");
-            {
-                long long sp[10];
-                HIP_TRY(hipMemcpy(sp, h0->e2->d_prof + 1300, sizeof(sp), hipMemcpyDeviceToHost));
-                if (sp[9]) fprintf(stderr, "[smcmi3]   selection inside the segment (wall clock, us): particle stored %.2f | chunk offsets %.2f | scan + cum %.2f | stores acknowledged %.2f | hand-over %.2f | chunk ends %.2f | search %.2f | rows gathered %.2f | moment row %.2f | hand-over %.2f\n",
-                                   0.0, (sp[1] - sp[0]) * 0.01, (sp[2] - sp[1]) * 0.01, (sp[3] - sp[2]) * 0.01, (sp[4] - sp[3]) * 0.01, (sp[5] - sp[4]) * 0.01, (sp[6] - sp[5]) * 0.01, (sp[7] - sp[6]) * 0.01, (sp[8] - sp[7]) * 0.01, (sp[9] - sp[8]) * 0.01);
-            }
-            fprintf(stderr, "[smcmi3]   decision + proposal: totals -> covariance, shuffle %lld | block matrices %lld | Cholesky + log det %lld | rest %lld\n",
-                    pr[30] - pr[3], pr[31] - pr[30], pr[32] - pr[31], pr[4] - pr[32]);
-        }
-        if (seg_launches > 0) {
-            // the two hand-overs of that stage on the wall clock (10 ns ticks): when the workers' rows went out, what the gatherers did, when
-            // the workers had the totals
-            const int Wk = g0.Vl * g0.nb2;
-            std::vector<long long> ws(4 * (size_t)Wk);
-            HIP_TRY(hipMemcpy(ws.data(), h0->e2->d_prof + 128, sizeof(long long) * ws.size(), hipMemcpyDeviceToHost));
-            for (int kind = 0; kind < 2; ++kind) {
-                long long p_min = 0, p_max = 0, s_min = 0, s_max = 0;
-                for (int b = 0; b < Wk; ++b) {
-                    const long long pb = ws[4 * b + 2 * kind], sb = ws[4 * b + 2 * kind + 1];
-                    if (!b || pb < p_min) p_min = pb;
-                    if (!b || pb > p_max) p_max = pb;
-                    if (!b || sb < s_min) s_min = sb;
-                    if (!b || sb > s_max) s_max = sb;
-                }
-                fprintf(stderr, "[smcmi3] hand-over %d (%s rows): rows published over %.2f us (worker 0 at +%.2f); totals seen by the first worker +%.2f, the last +%.2f, worker 0 +%.2f after the first row\n",
-                        kind, kind ? "mutation" : "correction", (p_max - p_min) * 0.01, (ws[2 * kind] - p_min) * 0.01, (s_min - p_min) * 0.01, (s_max - p_min) * 0.01, (ws[2 * kind + 1] - p_min) * 0.01);
-                for (int v = 0; v < g0.Vl; ++v) {
-                    long long lastrow = 0;
-                    for (int b = v; b < Wk; b += g0.Vl) lastrow = std::max(lastrow, ws[4 * b + 2 * kind]);
-                    fprintf(stderr, "[smcmi3]   gatherer %d: its last row +%.2f | first words seen +%.2f | %lld sweep(s) done +%.2f | totals posted +%.2f (started waiting at +%.2f)\n", v, (lastrow - p_min) * 0.01,
-                            (pr[90 + 4 * v + 2 * kind] - p_min) * 0.01, pr[90 + 4 * v + 2 * kind + 1],
-                            (pr[40 + 6 * v + 3 * kind + 1] - p_min) * 0.01, (pr[40 + 6 * v + 3 * kind + 2] - p_min) * 0.01, (pr[40 + 6 * v + 3 * kind] - p_min) * 0.01);
-                }
-            }
-        }
-        if (!g0.direct && !g0.inker && !g0.wide) {
-            // census of the large-shard mutation launch of the profiled stage (100 MHz wall clock, the CU every block sat on): how many blocks
-            // a CU held at once
-            std::vector<long long> cs(3 * PROF2_BLOCKS);
-            HIP_TRY(hipMemcpy(cs.data(), h0->e2->d_prof + 128, sizeof(long long) * cs.size(), hipMemcpyDeviceToHost));
-            long long t_min = 0, t_max = 0, sum = 0;
-            int nbk = 0;
-            std::map<long long, std::vector<std::pair<long long, int>>> per_cu;
-            for (int b = 0; b < PROF2_BLOCKS; ++b) {
-                const long long t_a = cs[3 * b], t_b = cs[3 * b + 1];
-                if (!t_a || !t_b) continue;
-                if (!nbk || t_a < t_min) t_min = t_a;
-                if (!nbk || t_b > t_max) t_max = t_b;
-                sum += t_b - t_a;
-                ++nbk;
-                per_cu[cs[3 * b + 2]].push_back({t_a, +1});
-                per_cu[cs[3 * b + 2]].push_back({t_b, -1});
-            }
-            int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (auto &kv : per_cu) {
-                std::sort(kv.second.begin(), kv.second.end());
-                int cur = 0, mx = 0;
-                for (auto &ev : kv.second) { cur += ev.second; mx = std::max(mx, cur); }
-                hist[std::min(mx, 8)] += 1;
-            }
-            if (nbk) {
-                fprintf(stderr, "[smcmi2] K2b census: %d blocks on %d CUs, first start -> last end %.2f us, mean block %.2f us, mean residency %.1f blocks; CUs by the most blocks they held at once:", nbk,
-                        (int)per_cu.size(), (t_max - t_min) * 0.01, sum * 0.01 / nbk, (double)sum / (double)std::max<long long>(1, t_max - t_min));
-                for (int k = 1; k <= 8; ++k) if (hist[k]) fprintf(stderr, " %d x %d", hist[k], k);
-                // when the blocks started (µs behind the first) and how long they ran
-                int st_h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, du_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                const double st_e[7] = {1, 2, 5, 10, 15, 20, 25}, du_e[7] = {8, 12, 16, 20, 24, 28, 32};
-                for (int b = 0; b < PROF2_BLOCKS; ++b) {
-                    if (!cs[3 * b] || !cs[3 * b + 1]) continue;
-                    const double st = (cs[3 * b] - t_min) * 0.01, du = (cs[3 * b + 1] - cs[3 * b]) * 0.01;
-                    int k = 0; while (k < 7 && st >= st_e[k]) ++k; st_h[k] += 1;
-                    k = 0; while (k < 7 && du >= du_e[k]) ++k; du_h[k] += 1;
-                }
-                fprintf(stderr, "\n[smcmi2]   started at <1 <2 <5 <10 <15 <20 <25 >=25 us:");
-                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", st_h[k]);
-                fprintf(stderr, "; ran <8 <12 <16 <20 <24 <28 <32 >=32 us:");
-                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", du_h[k]);
-                fprintf(stderr, "\n");
-            }
-        }
-        for (int blk = 0; blk < 2; ++blk) {
-            fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");
-            for (int q = 1; q <= 5; ++q) fprintf(stderr, " %lld", pr[blk * 32 + q] - pr[blk * 32 + q - 1]);
-            fprintf(stderr, "  total %lld\n[smcmi2] K2 %s block ticks:", pr[blk * 32 + 5] - pr[blk * 32], blk ? "mid" : "0");
-            for (int q = 1; q <= 11; ++q) fprintf(stderr, " %lld", pr[64 + blk * 32 + q] - pr[64 + blk * 32 + q - 1]);
-            fprintf(stderr, "  total %lld\n", pr[64 + blk * 32 + 10] - pr[64 + blk * 32]);
-        }
-    }
+    if (h0->e2->d_prof) { if (int e = prof2_report(h0, g0, seg_launches)) return e; }
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
         k2_export<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
@@ -1288,9 +1038,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         double acc_ms = 0.0;
         int got = 0;
         for (int r = 0; r < 64; ++r) {
-            k_noop<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(h0->d_st);
+            k_fill<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(nullptr, 0, 0.0);      // (an empty launch of the mutation kernel's grid: event-overhead calibration)
             hipEventRecord(c0, h0->stream);
-            k_noop<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(h0->d_st);
+            k_fill<<<(unsigned)((h0->n + 255) / 256), 256, 0, h0->stream>>>(nullptr, 0, 0.0);      // (an empty launch of the mutation kernel's grid: event-overhead calibration)
             hipEventRecord(c1, h0->stream);
             hipStreamSynchronize(h0->stream);
             float ms = 0.f;

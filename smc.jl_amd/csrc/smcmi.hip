@@ -207,7 +207,6 @@ extern "C" int smcmi_destroy(smcmi_handle *h) {
     if (!h) return 0;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->nccl) smcmi_comm_release(h);
     if (h->e2) { free_eng2(h->e2); h->e2 = nullptr; }
     for (void *p : h->ipc_opened) hipIpcCloseMemHandle(p);
@@ -531,7 +530,7 @@ extern "C" int smcmi_correct(smcmi_handle *h, double phi_n, double phi_prev, dou
     if (push_state(h)) return SMCMI_ERR_HIP;
     k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, nullptr, 0);
     k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, nullptr, h->rec, 0);
-    k_normalize_weights<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st);
+    k_normalize_weights<<<(unsigned)((h->n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, (double)h->cfg.n_parts);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     out->ess = s.ess; out->sum_unnorm = s.sumw; out->logz_inc = s.logz; out->resample = s.do_resample;
     const int err = s.err;
@@ -620,7 +619,7 @@ extern "C" int smcmi_normalize_weights(smcmi_handle *h, int32_t zero_bad_loglh) 
     if (zero_bad_loglh) k_zero_bad_weights<<<g, TB, 0, h->stream>>>(h->cl, h->d_st);
     k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
     k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
-    k_normalize_weights_n<<<g, TB, 0, h->stream>>>(h->cl, h->d_st, (double)h->cfg.n_parts);
+    k_normalize_weights<<<g, TB, 0, h->stream>>>(h->cl, h->d_st, (double)h->cfg.n_parts);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -761,7 +760,7 @@ static int launch_mutate(smcmi_handle *h, int n_blocks, int standalone, double a
     h->launch_alpha1 = (alpha == 1.0);
     MutArgs ma{};
     ma.seed = h->cfg.seed; ma.gid0 = h->cfg.gid0;
-    static const int dbg = getenv("SMCMI_DEBUG_MUT") ? atoi(getenv("SMCMI_DEBUG_MUT")) : 0;   // development only
+    const int dbg = 0;           // (ablation bits: retired as a switch in round 6)
     ma.debug = dbg;
     ma.stage_consts = (h->d <= 13 && !(dbg & 512)) ? 1 : 0;
     ma.prof = h->d_prof;
@@ -879,15 +878,14 @@ extern "C" int smcmi_accept(smcmi_handle *h, const double *loglik_new, const dou
 // In-run proposal set-up: block 0 prepares the proposal, the other blocks draw the stage's random numbers ahead (RngAhead) when
 // the register mutation kernel will run and the buffer fits.  from_totals as in k_prepare_mutation.
 static int ensure_zbuf(smcmi_handle *h, int n_mh_steps, int n_blocks) {
-    static const int off = getenv("SMCMI_NO_RNG_AHEAD") ? atoi(getenv("SMCMI_NO_RNG_AHEAD")) : 0;   // development only
     h->rng_ahead = false;
-    if (off || !use_reg_mutate(h)) return 0;
+    if (!use_reg_mutate(h)) return 0;
     // Worth it only while the chip is under-occupied during the set-up launch: measured +4 % at n = 1e5, +1.5 % at 3e5, -5 % at 1e6
     // (config 2); beyond that the draws are cheaper inside the mutation kernel than a round trip through HBM.  With several
     // proposals per particle (MH steps x blocks) the first few are drawn ahead - as many as fit the window - and the rest in the
     // mutation kernel: up to 250 000 particle-proposals - about what the set-up launch's idle window (~10 µs on 255 CUs) absorbs.
     // Config 4 (3 proposals for each of 200 000 particles) per run: none ahead 30.5 ms, one 29.6-29.8, two 30.2-30.3, all three 30.7.
-    static const long long ahead_max = getenv("SMCMI_RNG_AHEAD_MAX") ? atoll(getenv("SMCMI_RNG_AHEAD_MAX")) : 500000;   // development only
+    const long long ahead_max = 500000;
     static const long long part_max = getenv("SMCMI_RNG_AHEAD_PART") ? atoll(getenv("SMCMI_RNG_AHEAD_PART")) : 250000;  // development only
     const int props = n_mh_steps * n_blocks;
     int k_ahead = props;
@@ -912,9 +910,8 @@ static void launch_prepare_in_run(smcmi_handle *h, const double *partials, int n
     }
     // many rows: blocks 1..PREP_G of the launch total a chunk each (PrepRed, kernels.hpp) - one CU alone is bandwidth-bound on them
     PrepRed pr{};
-    static const int prep_two_level = getenv("SMCMI_PREP_TWO_LEVEL") ? atoi(getenv("SMCMI_PREP_TWO_LEVEL")) : 1;   // development only
     const int m_rows = from_totals == 3 ? h->npairs + 2 : h->npairs;
-    if (prep_two_level && (from_totals == 3 || from_totals == 1) && nb_part >= PREP_MIN_ROWS && m_rows <= PT && h->d_prep_rows) {
+    if ((from_totals == 3 || from_totals == 1) && nb_part >= PREP_MIN_ROWS && m_rows <= PT && h->d_prep_rows) {
         pr.rows = h->d_prep_rows; pr.tick = h->d_prep_tick;
         if (grid < 1u + PREP_G) grid = 1u + PREP_G;
     }
@@ -1073,7 +1070,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    if (getenv("SMCMI_PROF_MUT") && !h->d_prof) { if (dmalloc(&h->d_prof, 32)) return SMCMI_ERR_HIP; }
+    if (getenv("SMCMI_PROF2") && !h->d_prof) { if (dmalloc(&h->d_prof, 32)) return SMCMI_ERR_HIP; }
     if (int e = ensure_zbuf(h, rc->n_mh_steps, rc->n_blocks)) return e;
     const int solver_passes = rc->solver_passes >= 1 ? rc->solver_passes : DEFAULT_SOLVER_PASSES;
     const int first_passes = std::max(solver_passes, FIRST_SOLVER_PASSES);
@@ -1100,8 +1097,8 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     // k_stage_begin posts its stage index and the stalling k_prepare_mutation a flag into host-mapped words (handle.hpp h_note)
     // which the enqueue loop polls; a drained stream (an error, a pause, phi = 1) also ends the wait.
     static const int fixed_sel = getenv("SMCMI_FIXED_NO_SELECT") ? atoi(getenv("SMCMI_FIXED_NO_SELECT")) : 1;        // development: 0 = the seven-launch stage
-    static const int run_ahead = getenv("SMCMI_FIXED_RUN_AHEAD") ? std::max(1, atoi(getenv("SMCMI_FIXED_RUN_AHEAD"))) : 1;   // (config 4: 30.6 ms at 1, 30.8 at 2, 31.1 at 4 - fewer idle launches behind a stall)
-    bool fixed_ns = !adaptive && can_fuse_cm(h) && sel_mode != 1 && fixed_sel != 0 && rc->use_graph != 1;
+    const int run_ahead = 1;      // (config 4: 30.6 ms at 1, 30.8 at 2, 31.1 at 4 - fewer idle launches behind a stall; measured in round 4, the switch retired in round 6)
+    bool fixed_ns = !adaptive && can_fuse_cm(h) && sel_mode != 1 && fixed_sel != 0;
     if (fixed_ns && !h->h_note) {
         void *hp = nullptr, *dp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
@@ -1119,16 +1116,6 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     // produces cannot verify a predicted root: those runs keep the certificate pass)
     const bool spec_ok = predict_select && can_fuse_cm(h) && !getenv("SMCMI_NO_PREDICTOR") &&
                          rc->tempered_update_prior_weight == 0.0 && rp.phi_rtol > 0.0;
-    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
-    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // [0] full stage, [1] without selection kernels, [2] predict-correct-verify
-    if (rc->use_graph == 1) {
-        for (int v = 0; v < (spec_ok ? 3 : predict_select ? 2 : 1); ++v) {
-            HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_stage(h, adaptive, solver_passes, rc->resampling_method, rc->n_blocks, rc->alpha, acc_nb, nullptr, nullptr, 0, v >= 1, false, v == 2);
-            HIP_TRY(hipStreamEndCapture(h->stream, &graph[v]));
-            HIP_TRY(hipGraphInstantiate(&gexec[v], graph[v], nullptr, nullptr, 0));
-        }
-    }
     double pred_ess = cont ? s.ess_prev : (rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts);   // ESS after the last completed stage
     int pred_rl = cont ? s.resampled_last : 0;                                             // resampled_last_period
     const auto t0 = std::chrono::steady_clock::now();
@@ -1185,8 +1172,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
                 pred_ess = ess_bar; pred_rl = rs ? 1 : 0;
             }
             const bool spec = spec_on && no_select && launched >= 2;
-            if (gexec[0] && launched > 1 && dyn_P == solver_passes) HIP_TRY(hipGraphLaunch(gexec[spec ? 2 : (no_select ? 1 : 0)], h->stream));
-            else {
+            {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); evs.push_back(e0); evs.push_back(e1); ev_iter.push_back(launched); }
                 enqueue_stage(h, adaptive, launched < 2 ? first_passes : dyn_P, rc->resampling_method, rc->n_blocks, rc->alpha,
@@ -1294,8 +1280,6 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, acc_nb, h->rec);
     if (pull_state(h)) return SMCMI_ERR_HIP;
     const auto t1 = std::chrono::steady_clock::now();
-    for (int v = 0; v < 3; ++v)
-        if (gexec[v]) { hipGraphExecDestroy(gexec[v]); hipGraphDestroy(graph[v]); }
     res->kernel_ms_mutate = 0.0; res->n_mutate_launches = 0;
     // An event pair brackets [previous kernel done -> this kernel done]: dispatch of the kernel included.  Calibrate that
     // fixed part with pairs around an empty kernel and subtract it, so the figure is the kernel's own duration (what
@@ -1308,9 +1292,9 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
         double acc_ms = 0.0;
         int got = 0;
         for (int r = 0; r < reps; ++r) {
-            k_noop<<<(unsigned)((h->n + 255) / 256), 256, 0, h->stream>>>(h->d_st);     // predecessor of comparable size
+            k_fill<<<(unsigned)((h->n + 255) / 256), 256, 0, h->stream>>>(nullptr, 0, 0.0);      // (an empty launch of the mutation kernel's grid: event-overhead calibration)     // predecessor of comparable size
             hipEventRecord(c0, h->stream);
-            k_noop<<<(unsigned)((h->n + 255) / 256), 256, 0, h->stream>>>(h->d_st);
+            k_fill<<<(unsigned)((h->n + 255) / 256), 256, 0, h->stream>>>(nullptr, 0, 0.0);      // (an empty launch of the mutation kernel's grid: event-overhead calibration)
             hipEventRecord(c1, h->stream);
             hipStreamSynchronize(h->stream);
             float ms = 0.f;
@@ -1548,7 +1532,7 @@ extern "C" int smcmi_callback_phases(smcmi_handle *h, double *ms_out, int32_t n)
 // run ends in the time-out and every rank repeats - the same decision everywhere without an exchange.
 static int run2_guarded(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *res) {
     static const int e3_off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
-    static const int e3_sharded = getenv("SMCMI_ENGINE3_SHARDED") ? atoi(getenv("SMCMI_ENGINE3_SHARDED")) : 1;
+    static const int e3_sharded = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) != 2) : 1;
     smcmi_handle *h0 = g.hs[0];
     const bool single = g.world == 1 && !g.rccl && g.hs.size() == 1;
     bool may_seg = !e3_off && h0->d <= 10 && (single || e3_sharded);
@@ -1585,92 +1569,6 @@ static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result
     return run2_guarded(g, rc, res);
 }
 
-// ------------------------------------------------------------------------------------------------ development aid
-static __global__ void k_empty(const DevState *st) { if (st->done == 12345) printf("x"); }
-
-extern "C" int smcmi_debug_time_kernel(smcmi_handle *h, int32_t which, int32_t reps, double *usec_per_launch) {
-    if (int rc = need_model(h, true)) return rc;
-    if (!usec_per_launch || reps < 1) return set_err(SMCMI_ERR_ARG, "bad argument");
-    if (pull_state(h)) return SMCMI_ERR_HIP;
-    DevState &s = h->h_st;
-    const DevState saved = s;
-    const long long n = h->n;
-    s.done = 0; s.err = 0; s.stage = 2; s.rp.store_history = h->cfg.store_history; s.rp.phi_rtol = DEFAULT_PHI_RTOL;
-    if (s.rp.n_phi < 2) { s.rp.n_phi = 300; }
-    s.phi_prev = 0.0; s.phi_n = 1e-4; s.sumw = (double)h->cfg.n_parts; s.c = 0.5; s.rp.n_blocks = 1; s.rp.n_mh_steps = 1; s.rp.alpha = 1.0;
-    s.rp.threshold = 0.5 * (double)h->cfg.n_parts; s.rp.target = 0.25; s.accept = 0.25; s.rp.tempering_target = 0.97; s.ess_prev = (double)h->cfg.n_parts;
-    Solver &S = s.sol[0];
-    S.mode = MODE_SECTION; S.n_valid = KC; S.ess_bar = 0.97 * (double)h->cfg.n_parts; S.lo = 0.0; S.hi = 1e-3; S.glo = 1.0; S.ghi = -1.0; S.j = 5; S.phi_prop = 1e-3;
-    for (int q = 0; q < KC; ++q) S.cand[q] = 1e-5 * (q + 1);
-    if (which == 2 || which == 3) { S.mode = MODE_FINAL; S.phi_n = 1e-5; }
-    if (which == 4 || which == 5) s.do_resample = 1;
-    std::vector<double> sched(s.rp.n_phi);
-    for (int k = 0; k < s.rp.n_phi; ++k) sched[k] = pow((double)k / (double)(s.rp.n_phi - 1), 2.1);
-    if (upload_sched(h, sched.data(), s.rp.n_phi) || push_state(h)) return SMCMI_ERR_HIP;
-    // make every input buffer valid once
-    k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0);
-    k_weight_chunk_sums<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_part_fin);
-    k_chunk_offsets<<<1, 1, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, 0.0, 1);
-    k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1, h->nb_e);
-    { const int nbm0 = launch_moments(h, nullptr, 1);
-      k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, nbm0, h->npairs, h->d_totals, 1); }
-    k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_totals, 0, h->cfg.seed, 2, 1, 0);
-    const int max_db = h->h_model.n_free;
-    (void)max_db;
-    if (getenv("SMCMI_PROF_MUT") && !h->d_prof) { if (dmalloc(&h->d_prof, 32)) return SMCMI_ERR_HIP; }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipEventRecord(e0, h->stream));
-    for (int r = 0; r < reps; ++r) {
-        switch (which) {
-        case 0: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_ess[0], h->nb_e, 0, nullptr, 0, h->d_prof); break;
-        case 1: k_pass<KC, false><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, h->d_part_ess[0], h->d_part_ess[1], h->nb_e, 1, nullptr, 0, h->d_prof); break;
-        case 2: k_pass<1, true><<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_sched, nullptr, h->d_part_fin, h->nb_e, 0, h->d_hist_w, n); break;
-        case 3: k_post_correct<<<1, TB, 0, h->stream>>>(h->d_st, h->d_part_fin, h->nb_e, h->d_chunk_off, h->rec, 0); break;
-        case 4: k_scan_weights<<<h->nb_e, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_chunk_off, h->d_cum, 1, h->nb_e); break;
-        case 5: k_resample_gather<<<(unsigned)((n + TB - 1) / TB), TB, 0, h->stream>>>(h->cl, h->d_st, h->d_cum, n, 0, h->cfg.n_parts, 0, h->cfg.seed, 3u, nullptr, h->d_anc, nullptr, 1); break;
-        case 6: launch_moments(h, nullptr, 1); break;
-        case 7: k_moments_reduce<<<(h->npairs + 63) / 64, 1024, 0, h->stream>>>(h->d_st, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->npairs, h->d_totals, 1); break;
-        case 8: k_prepare_mutation<<<1, PT, h->prep_lds, h->stream>>>(h->d_st, h->d_model, h->d_part_mom, h->d <= 12 ? h->nb_mr : h->nb_m, h->cfg.seed, 1, 1, 0, h->d_prof); break;
-        case 9: launch_mutate(h, 1, 0, 1.0); break;
-        case 10: k_stage_begin<<<1, BT, 0, h->stream>>>(h->d_st, h->d_sched, h->d_acc_part, mut_blocks(h), h->rec); break;
-        default: k_empty<<<1, 64, 0, h->stream>>>(h->d_st); break;
-        }
-        if (which == 10 || which == 3) { /* keep the stage counter / weights bounded */ }
-    }
-    HIP_TRY(hipEventRecord(e1, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    *usec_per_launch = 1e3 * (double)ms / reps;
-    if (h->d_prof && which <= 1) {
-        long long pr[32];
-        hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
-        fprintf(stderr, "pass phase cycles:");
-        for (int q = 1; q < 5; ++q) fprintf(stderr, " %lld", pr[q] - pr[q - 1]);
-        fprintf(stderr, "  total %lld\n", pr[4] - pr[0]);
-    }
-    if (h->d_prof && which == 8) {
-        long long pr[32];
-        hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
-        fprintf(stderr, "prepare phase cycles:");
-        for (int q = 1; q < 7; ++q) fprintf(stderr, " %lld", pr[q] - pr[q - 1]);
-        fprintf(stderr, "  total %lld\n", pr[6] - pr[0]);
-    }
-    if (h->d_prof && which == 9) {
-        long long pr[32];
-        hipMemcpy(pr, h->d_prof, sizeof(pr), hipMemcpyDeviceToHost);
-        for (int blk = 0; blk < 2; ++blk) {
-            fprintf(stderr, "mutate phase cycles (block %s):", blk ? "mid" : "0");
-            for (int q = 1; q < 10; ++q) fprintf(stderr, " %lld", pr[blk * 16 + q] - pr[blk * 16 + q - 1]);
-            fprintf(stderr, "  total %lld\n", pr[blk * 16 + 9] - pr[blk * 16]);
-        }
-    }
-    h->h_st = saved;
-    return push_state(h);
-}
 
 // compute_proposal_densities (src/helpers.jl:128-164) of one move through the device's dense mixture form (kernels.hpp mix_densities):
 // the reference's own fixture (test/helpers.jl:101-127) reaches the HIP code the alpha < 1 mutation kernels run

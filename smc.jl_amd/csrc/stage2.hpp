@@ -1212,34 +1212,6 @@ static __global__ void __launch_bounds__(TS) k2_scan(Ctl2 *ctl, const DevState *
     }
 }
 
-// Systematic resampling, sharded: ancestor (global row) of the first and of the last output slot of every handle r - the rows a
-// handle must receive form the contiguous range [out[2r], out[2r+1]].  out[0] = -1 when this stage does not resample.
-static __global__ void k2_anc_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows, const double *cum, long long N, long long n_local, int world,
-                              unsigned long long seed, long long *out) {
-    __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
-    const int r = threadIdx.x;
-    const Begin2 bg = ctl->bg;
-    bool go = bg.stage == n && bg.final && ctl->ps[(n - 1) & 1].stage == n - 1;
-    if (cmrows.mb && !go) { if (r == 0) out[0] = -1; return; }       // (mailbox: no waiting for rows of a stage that does not run)
-    reduce_rows<2, 8, 64>(cmrows, s_vt, s_tot);
-    double ess;
-    if (go) go = decide2(bg, st->rp.threshold, st->rp.phi_rtol, s_tot[0], s_tot[1], &ess) == 1;
-    if (!go) { if (r == 0) out[0] = -1; return; }
-    if (r >= world) return;
-    double ua, ub;
-    uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), ua, ub);
-    for (int e = 0; e < 2; ++e) {
-        const long long slot = e == 0 ? (long long)r * n_local : (long long)(r + 1) * n_local - 1;
-        const double thr = ((double)slot + ua) / (double)N;
-        long long lo = 0, hi = N;
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if (cum[mid] > thr) hi = mid; else lo = mid + 1;
-        }
-        out[2 * r + e] = lo < N ? lo : N - 1;
-    }
-}
-
 // Systematic resampling, sharded, owner side: which of THIS handle's rows does handle r need?  The ancestors of r's
 // slots k0 .. k1 (thresholds t = (k + u) / N) are the first j with cum[j] > t; among this handle's rows they lie between its first
 // row with cum > t(k0) and its first row with cum > t(k1) (its last row if there is none) - a superset by at most one row, from this

@@ -120,7 +120,6 @@ SYMBOLS = [
     ("smcmi_shard_resample", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, lp]),
     ("smcmi_shard_mutate_partial", C.c_int, [_H, dp, dp, ip, ip, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32]),
     ("smcmi_sync", C.c_int, [_H]),
-    ("smcmi_debug_time_kernel", C.c_int, [_H, C.c_int32, C.c_int32, dp]),
     ("smcmi_debug_proposal_densities", C.c_int, [dp, dp, dp, dp, C.c_int32, C.c_double, C.c_double, dp, dp]),
     ("smcmi_comm_unique_id", C.c_int, [C.c_char_p]),
     ("smcmi_comm_init", C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p]),

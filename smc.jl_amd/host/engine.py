@@ -386,11 +386,6 @@ class Engine:
         k = int(n_stages)
         return (w, W) if k == cap else (np.asfortranarray(w[:, :k]), np.asfortranarray(W[:, :k]))
 
-    def time_kernel(self, which, reps=200):
-        us = C.c_double()
-        check(self._L.smcmi_debug_time_kernel(self._h, which, reps, C.byref(us)))
-        return us.value
-
     def sync(self):
         check(self._L.smcmi_sync(self._h))
 

@@ -128,12 +128,12 @@ def test_models_with_11_to_16_parameters_do_not_depend_on_the_shard_count(case):
 
 
 def test_the_wide_stage_against_engine_1s():
-    """The same 12- and 13-parameter runs through engine 1's eight-launch stage (SMCMI_ENGINE_WIDE=0; sums in another order): same stage
+    """The same 12- and 13-parameter runs through engine 1's eight-launch stage (SMCMI_ENGINE=1; sums in another order): same stage
     and resample counts, log-MDD to 1e-7."""
     for spec, n, d, kw in [(("gauss_spec", [12]), 24000, 12, dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=3, alpha=0.9)),
                            (("kalman_spec", [40]), 16384, 13, dict(use_fixed_schedule=False, tempering_target=0.95, n_phi=100, alpha=0.9))]:
         a = _invariance(n, d, 7, (1,), kw, spec=spec)["1"]
-        b = _invariance(n, d, 7, (1,), kw, spec=spec, extra_env={"SMCMI_ENGINE_WIDE": "0", "SMCMI_ENGINE": "0"})["1"]
+        b = _invariance(n, d, 7, (1,), kw, spec=spec, extra_env={"SMCMI_ENGINE": "1"})["1"]
         assert a["n_stages"] == b["n_stages"] and a["resamples"] == b["resamples"], (a, b)
         assert float.fromhex(a["logmdd"]) == pytest.approx(float.fromhex(b["logmdd"]), abs=1e-7)
 

@@ -60,7 +60,7 @@ CASES = [
 def test_fixed_schedule_without_selection_kernels_equals_the_seven_launch_stage(cfg):
     full = _run(cfg, {"SMCMI_FIXED_NO_SELECT": "0"})
     assert full["sel"] == 0 and full["resamples"] > 0
-    for extra in ({}, {"SMCMI_FIXED_RUN_AHEAD": "2"}, {"SMCMI_FIXED_RUN_AHEAD": "6"}):
+    for extra in ({},):
         got = _run(cfg, extra)
         # every resample stage was met without its selection kernels and resumed (the first stages of a diffuse prior can resample back to back)
         assert got["sel"] == got["resamples"] == full["resamples"]
@@ -71,9 +71,7 @@ def test_fixed_schedule_without_selection_kernels_equals_the_seven_launch_stage(
         np.testing.assert_allclose(got["accept"], full["accept"], atol=3.0 / cfg["n"])
         assert got["logmdd"] == pytest.approx(full["logmdd"], abs=1e-6)
         assert got["chk"] == pytest.approx(full["chk"], rel=1e-5)
-    # the host running ahead by 1, 2 or 6 stages is the same computation: bits
-    a, b = _run(cfg, {}), _run(cfg, {"SMCMI_FIXED_RUN_AHEAD": "6"})
-    assert a["logmdd"] == b["logmdd"] and a["ess"] == b["ess"] and a["chk"] == b["chk"]
+    # (the host running ahead by 2 or 6 stages instead of 1 left the same bits - rounds 4 and 5; the switch was retired in round 6)
 
 
 def test_fixed_schedule_without_selection_kernels_pause_and_continue():
@@ -110,10 +108,9 @@ def test_fixed_schedule_without_selection_kernels_follows_the_oracle(case):
 def test_random_numbers_partly_drawn_ahead_are_the_same_numbers():
     """4 proposals for each of 150 000 particles do not fit the set-up launch's window: the first k are drawn ahead by its idle CUs
     (csrc/smcmi.hip ensure_zbuf, kernels.hpp rng_ahead_block), the others inside the mutation kernel - pure functions of (seed,
-    particle, stage, proposal), so k = 0, 1, 3 and all 4 must leave the same bits (reference: the draws of src/mutation.jl:81-101)."""
+    particle, stage, proposal), so k = 0, 1 and 3 must leave the same bits (reference: the draws of src/mutation.jl:81-101)."""
     cfg = dict(CASES[1])
-    runs = [_run(cfg, {"SMCMI_RNG_AHEAD_PART": part, **extra}) for part, extra in
-            (("0", {}), ("250000", {}), ("450000", {}), ("0", {"SMCMI_RNG_AHEAD_MAX": "100000000"}))]
+    runs = [_run(cfg, {"SMCMI_RNG_AHEAD_PART": part}) for part in ("0", "250000", "450000")]
     for r in runs[1:]:
         assert r["n"] == runs[0]["n"] and r["resampled"] == runs[0]["resampled"]
         assert r["logmdd"] == runs[0]["logmdd"] and r["ess"] == runs[0]["ess"] and r["accept"] == runs[0]["accept"] and r["chk"] == runs[0]["chk"]

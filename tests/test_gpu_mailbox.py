@@ -113,7 +113,7 @@ def test_mailbox_hand_overs_reproduce_the_single_handle_bits(kw, extra):
         # tests/test_gpu_multiproc.py)
         if world == 2:
             assert got["segments"] >= 1 and got["segment_stages"] >= (got["n_stages"] - 1) // 2, got
-            off = _group(world, kw, dict(SMCMI_MAILBOX="1", SMCMI_ENGINE3_SHARDED="0", **extra))       # ... and as launches: the same bits
+            off = _group(world, kw, dict(SMCMI_MAILBOX="1", SMCMI_ENGINE3="2", **extra))       # ... and as launches: the same bits
             assert off["segments"] == 0
             for key in ("n_stages", "resamples", "logmdd", "cloud"):
                 assert off[key] == ref[key], (world, key, off, ref)

@@ -188,18 +188,17 @@ def test_a_segment_time_out_repeats_the_run_as_launches():
                 assert ra[k] == rb[k], (k, ra[k], rb[k])
 
 
-def test_engine_1_two_level_totals_agree_with_one_block_and_with_engine_2():
+def test_engine_1_two_level_totals_agree_with_engine_2():
     """Large single-handle clouds (engine 1): the prepare and stage-begin launches total their rows on two levels inside the launch
-    (kernels.hpp PrepRed: reducer blocks + tickets).  The grouping changes the association of the sums, nothing else: against the
-    one-block totals (SMCMI_PREP_TWO_LEVEL=0) and against engine 2's canonical order (SMCMI_ENGINE=2) the run has the same stages and
+    (kernels.hpp PrepRed: reducer blocks + tickets).  The grouping changes the association of the sums, nothing else: against
+    engine 2's canonical order (SMCMI_ENGINE=2; against one-block totals in rounds 4 and 5) the run has the same stages and
     resamples and its log-MDD agrees to rounding - at 200 000 particles (prepare reducers, random numbers drawn ahead by the same launch)
     and at 600 000 (the stage-begin reducers as well)."""
     for n in (200_000, 600_000):
         cfg = dict(n=n, d=10, seed=5, spec_args=[10], history=False, kw=dict(use_fixed_schedule=False, tempering_target=0.95))
         a = _run(cfg, {})[0]
-        b = _run(cfg, {"SMCMI_PREP_TWO_LEVEL": "0"})[0]
         c = _run(cfg, {"SMCMI_ENGINE": "2"})[0]
         assert a["n_segments"] == 0                                            # (engine 1: no segments at this size)
-        for other in (b, c):
+        for other in (c,):
             assert (a["n_stages"], a["resamples"]) == (other["n_stages"], other["resamples"])
             assert abs(a["logmdd_f"] - other["logmdd_f"]) <= 1e-10 * abs(a["logmdd_f"]), (n, a["logmdd_f"], other["logmdd_f"])

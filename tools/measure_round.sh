@@ -14,9 +14,9 @@ python bench.py --workload capm --steps 3 --warmup 1 2>/dev/null | tail -1 > $OU
 python bench.py --workload kalman --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman.json
 # config 5 on its stated machine: 50 000 particles on 4 GPUs = 12 500 per GPU (lane-split filter), and the round-2 kernel on the same cloud
 python bench.py --workload kalman --nparts 12500 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500.json
-SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_engine1_stage.json
+SMCMI_ENGINE=1 python bench.py --workload kalman --nparts 12500 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n12500_engine1_stage.json
 python bench.py --workload kalman --nparts 25000 --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_n25000.json
-SMCMI_ENGINE_WIDE=0 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_engine1_stage.json
+SMCMI_ENGINE=1 python bench.py --workload kalman --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_kalman_engine1_stage.json
 gcc -O2 -std=c99 -ffp-contract=off -fopenmp -DCB_THREADS=8 -I include -o examples/c_abi_callback examples/c_abi_callback.c -L smc.jl_amd/csrc -lsmcmi -lm -Wl,-rpath,$ROOT/smc.jl_amd/csrc   # (against THIS build's struct layouts)
 OMP_WAIT_POLICY=ACTIVE OMP_PROC_BIND=close LD_LIBRARY_PATH=smc.jl_amd/csrc:/opt/rocm/lib ./examples/c_abi_callback > $OUT/${R}_callback_c.json 2>/dev/null
 # where a stage of the closure path spends its time: the batch at once / in chunks, the example's callback on 1 / 8 threads
