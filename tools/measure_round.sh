@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round measurement pipeline (one MI355X): every file profiles/README.md lists, into gpurun_out/final/.
 # usage (GPU box): bash tools/measure_round.sh [rNN]
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -24,6 +24,13 @@ bash tools/callback_phases.sh > $OUT/${R}_callback_phases.json 2>/dev/null
 # FP64 matrix pipe beside the vector pipe (config 5's question: tools/ubench/mfma_f64.hip)
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -w -o mfma_f64 mfma_f64.hip > /dev/null 2>&1 && ./mfma_f64 > $OUT/${R}_mfma_f64.json 2>/dev/null)
 python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_alpha09.json
+# the reference's default schedule (fixed, 300 stages) at 100 000 / 5 000 / 1 000 particles: one hand-over per stage, and with exact shifts (two)
+python tools/fixed_schedule.py > $OUT/${R}_fixed_schedule.txt 2>/dev/null
+SMCMI_SHIFT_LAG=0 python tools/fixed_schedule.py 100000 5000 >> $OUT/${R}_fixed_schedule.txt 2>/dev/null
+# the driver's RCCL branch as 8 ranks sharing this GPU (tests/fake_rccl): the multi-rank bench line with its pre-flight verdict
+make -C tests/fake_rccl libfake_rccl.so > /dev/null 2>&1
+HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_BENCH_COMM=rccl_shared SMCMI_RCCL_PATH=$ROOT/tests/fake_rccl/libfake_rccl.so python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29520 \
+    bench.py --gpus 8 --steps 2 --warmup 1 --no-cpu --no-history --nparts 65536 2>/dev/null | grep '^{' | tail -1 > $OUT/${R}_bench_8ranks_one_gpu_fake_rccl.json
 python bench.py --alpha 0.9 --nparts 1000000 --no-history --no-cpu --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_1e6_alpha09.json
 # one rank's share of config 3 on 8 GPUs (125 000 particles, every hand-over through the all-gather path of a 1-rank RCCL communicator)
 HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
@@ -59,6 +66,7 @@ kt kalman --workload kalman --steps 2 --warmup 1
 kt kalman_n12500 --workload kalman --nparts 12500 --steps 2 --warmup 1
 kt gauss10_n1000000_alpha09 --alpha 0.9 --nparts 1000000 --no-history --steps 1 --warmup 1
 pmc gauss10_n100000 100000 --steps 3 --warmup 1
+kt gauss10_n100000_alpha09 --alpha 0.9 --steps 3 --warmup 1
 pmc kalman_n50000 50000 --workload kalman --steps 2 --warmup 1
 pmc kalman_n12500 12500 --workload kalman --nparts 12500 --steps 2 --warmup 1
 pmc gauss10_n1000000 1000000 --nparts 1000000 --no-history --steps 1 --warmup 1
