@@ -47,8 +47,9 @@ struct Eng2 {
     // a segment's exit note in host-mapped memory (one handle): [0] = the launch sequence number of the segment that has left, behind it a copy of
     // Ctl2 - the host learns of a batch's end (or of a stage that must resample) without a device-to-host copy and a stream sync
     void *h_note3 = nullptr, *d_note3 = nullptr;
+    int seg_ch = 1;                  // 512-particle chunks per segment worker (2: one handle of 126 977 .. 253 952 particles, α = 1, a cheap likelihood)
     int e3_state = 0;                // 0 untested, 1 usable (residency self-test passed), -1 off for this handle
-    int seg_attr_set = 0;         /* bits 0 / 1: α = 1 / mixture variant, bits 2 / 3: their riding instantiations */       // k3_segment's dynamic-LDS opt-in done on this handle's device
+    int seg_attr_set = 0;         /* bits 0 / 1: α = 1 / mixture variant, bits 2 / 3: their riding instantiations, bits 4 / 5: two chunks per worker */       // k3_segment's dynamic-LDS opt-in done on this handle's device
     bool wide_attr_set = false;      // k2w_mutate's dynamic-LDS opt-in done on this handle's device
     bool rng_ahead = false;          // K1 carries blocks that draw the mutation's random numbers into the handle's zbuf
     int n_steps = 1, n_blocks = 1;

@@ -83,10 +83,21 @@ void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
 }
 // one instantiation per (n_para, α = 1?, riding?): the proposal kinds are compiled with different flags (Makefile SEGFLAGS / SEGFLAGS_MIX).
 // RIDE: fixed schedules under RunParams::shift_lag on one handle - a stage's correction row rides the mutation row in front of it (stage3.hpp k3_rides)
-template <int D, bool A1, bool RIDE>
+// CH = 2: two 512-particle chunks per worker (α = 1, one handle of up to 253 952 particles: run2.hpp seg3_ready), translation units of their own (inst3c / inst3cr)
+template <int D, bool A1, bool RIDE, int CH = 1>
 void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb) {
     Eng2 *e = h->e2;
-    if constexpr (D <= 10) {
+    if constexpr (D <= 10 && CH == 2) {
+        static_assert(A1, "two chunks per worker: the α = 1 kernel only");
+        const size_t lds2 = k3_lds_bytes(D, D + 6);             // (the parked chunk: D + 6 columns where the one-chunk kernel keeps the particle in transit)
+        const unsigned grid2 = (unsigned)(e->g.Vl * ((e->g.nb2 + 1) / 2) + e->g.Vl);
+        constexpr int bit2 = RIDE ? 32 : 16;
+        if (!(e->seg_attr_set & bit2)) {
+            hipFuncSetAttribute((const void *)k3_segment<D, true, RIDE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((lds2 + 1023) / 1024 * 1024));
+            e->seg_attr_set |= bit2;
+        }
+        k3_segment<D, true, RIDE, 2><<<grid2, T3, lds2, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+    } else if constexpr (D <= 10) {
     const size_t lds = k3_lds_bytes(D, k3_sel_cols(D, A1));
     // workers + one gatherer per virtual shard.  One handle whose virtual shards are one or two blocks (stage3.hpp rows_direct / rows_two): the
     // workers take each other's rows themselves and nobody reads a gatherer's totals - none is launched (a gatherer that nothing waits for has
@@ -104,6 +115,10 @@ void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int 
 }
 template <int D>
 inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1, bool ride) {
+    if (h->e2->seg_ch == 2) {             // (seg3_ready grants two chunks to α = 1 runs only)
+        if (ride) launch_k3_seg<D, true, true, 2>(h, ma, sa, nb); else launch_k3_seg<D, true, false, 2>(h, ma, sa, nb);
+        return;
+    }
     if (alpha1) { if (ride) launch_k3_seg<D, true, true>(h, ma, sa, nb); else launch_k3_seg<D, true, false>(h, ma, sa, nb); }
     else { if (ride) launch_k3_seg<D, false, true>(h, ma, sa, nb); else launch_k3_seg<D, false, false>(h, ma, sa, nb); }
 }
@@ -121,8 +136,10 @@ inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Arg
 #define SMCMI_LAUNCH3_INSTANCES(X, D) X template void launch_k3_seg<D, true, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
                                       X template void launch_k3_seg<D, false, false>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
                                       X template void launch_k3_seg<D, true, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
-                                      X template void launch_k3_seg<D, false, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
-#define SMCMI_LAUNCH3_ONE(D, A, R) template void launch_k3_seg<D, A, R>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+                                      X template void launch_k3_seg<D, false, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, true, false, 2>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, true, true, 2>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+#define SMCMI_LAUNCH3_ONE(D, A, R, C) template void launch_k3_seg<D, A, R, C>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
 #define SMCMI_LAUNCH2B_INSTANCES(X, D) X template void launch_k2b_mutate<D>(smcmi_handle *, const Mut2Args &, const Beg2Args &, int, bool);
 #define SMCMI_LAUNCH_ALL_D(M, X)                                                                                                          \
     M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10) M(X, 11) M(X, 12) M(X, 13) M(X, 14) M(X, 15) M(X, 16)
@@ -134,7 +151,7 @@ SMCMI_LAUNCH_B_D(SMCMI_LAUNCH3_INSTANCES, extern)
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST3_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
-SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0), (SMCMI_INST3_R != 0))
+SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0), (SMCMI_INST3_R != 0), SMCMI_INST3_C)
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST2B_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)

@@ -56,7 +56,9 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
     // direct: every block totals the per-block rows itself - one handle, <= GRP rows per virtual shard, and the 512-thread mutation
     // blocks (one per CU) resident at once
-    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= 256) ? 1 : 0;
+    // (beyond 256 blocks - up to 62 per virtual shard - the persistent segments give every worker two chunks: stage3.hpp k3_segment<D, true, RIDE, 2>;
+    // eng2_eligible keeps such a cloud on engine 1 unless its run qualifies for them)
+    g.direct = (single && world == 1 && g.nb2 <= GRP && (long long)g.nb2 * V <= 2 * (256 - V2_MAXV)) ? 1 : 0;
     if (getenv("SMCMI_E2_REDUCED")) g.direct = 0;                                    // development: force the k2_reduce path on one handle
     // several handles with small shards: one 512-thread mutation block per CU as well, prologues in the kernels, fed by the gathered totals
     g.inker = (g.direct || (!single && (long long)g.nb2 * g.Vl <= 256)) ? 1 : 0;
@@ -95,7 +97,7 @@ static bool make_geo2_uneven(const smcmi_handle *h, Geo2 *out) {
         if ((long long)(V - 1) * g.nv >= g.n) continue;                              // (no empty virtual shard)
         g.wide = 0; g.t2 = 512;
         g.nb2 = (int)((g.nv + g.t2 - 1) / g.t2);
-        if (!(g.nb2 <= GRP && (long long)g.nb2 * V <= 256)) continue;
+        if (!(g.nb2 <= GRP && (long long)g.nb2 * V <= 2 * (256 - V2_MAXV))) continue;
         g.direct = 1; g.inker = 1;
         g.nb1 = g.nb2;
         g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;
@@ -170,11 +172,20 @@ static int ensure_eng2(smcmi_handle *h, int world, int rank, bool single) {
 // results independent of the number of handles).  A single handle with a larger cloud keeps engine 1: its kernels fill the chip
 // there and one-block set-up launches are cheap next to them (engine 2's reduced geometry measured 10-15 % behind at N >= 1e6).
 // SMCMI_ENGINE=1 / =2 force one engine wherever it can run (development, tests).
-static bool eng2_eligible(const smcmi_handle *h, int world, bool single) {
+// Two chunks per segment worker (one handle of 126 977 .. 253 952 particles) pay where a stage is hand-overs and serial work, not likelihood
+// evaluations: α = 1, one block, one MH step, a likelihood that is a handful of flops per datum.  (Measured in round 5: the 10-dim Gaussian at
+// 250 000 particles 47.5 against engine 1's 63 µs per stage; config 4 - CAPM, three MH steps - 30.6 against 29.6 ms per run: MH-bound runs stay on engine 1.)
+static bool two_chunk_run(const smcmi_handle *h, const smcmi_run_config *rc) {
+    auto cheap = [](int fam) { return fam == SMCMI_LIK_GAUSS_ISO || fam == SMCMI_LIK_LINREG || fam == SMCMI_LIK_NONE; };
+    return rc && rc->alpha == 1.0 && h->d <= 10 && rc->n_blocks == 1 && rc->n_mh_steps == 1 && cheap(h->h_model.lik[0].family) && cheap(h->h_model.lik[1].family);
+}
+static bool eng2_eligible(const smcmi_handle *h, int world, bool single, const smcmi_run_config *rc) {
     static const int eng = getenv("SMCMI_ENGINE") ? atoi(getenv("SMCMI_ENGINE")) : 0;
     if (eng == 1 || h->d > 16) return false;
     Geo2 g;
     if (!handle_geo2(h, world, 0, single, &g)) return false;
+    // (one handle with more than 256 - V blocks: only the two-chunk segments make engine 2's geometry worth it there)
+    if (single && world == 1 && g.direct && (long long)g.nb2 * g.V > 256 - V2_MAXV && !two_chunk_run(h, rc) && eng != 2) return false;
     if (g.wide) {                     // n_para 11 .. 16: the same two-launch stage around the generic mutation body (SMCMI_ENGINE=1: engine 1's stage)
         return true;
     }
@@ -209,14 +220,19 @@ static int seg3_time_out_words(smcmi_handle *h, double ms) {
     HIP_TRY(hipMemcpyAsync(h->e2->d_to3, h->e2->h_to3, sizeof(h->e2->h_to3), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
-static int seg3_ready(smcmi_handle *h, bool *ok) {
+static int seg3_ready(smcmi_handle *h, bool *ok, bool two_ok = false) {
     Eng2 *e = h->e2;
     *ok = false;
     static const int off = getenv("SMCMI_ENGINE3") ? (atoi(getenv("SMCMI_ENGINE3")) == 0) : 0;
     const Geo2 &g = e->g;
-    const int grid = g.Vl * g.nb2 + g.Vl;                      // workers + one gatherer per virtual shard, one CU each
     int n_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+    // workers + one gatherer per virtual shard, one CU each; a cloud with more 512-particle blocks than that gives every worker two of them
+    // (one handle, a run two_chunk_run admits: `two_ok`)
+    const int ch = (g.Vl * g.nb2 + g.Vl <= n_cu) ? 1 : 2;
+    if (ch == 2 && !two_ok) return 0;
+    const int grid = g.Vl * ((g.nb2 + ch - 1) / ch) + g.Vl;
+    if (e->seg_ch != ch) { e->seg_ch = ch; if (e->e3_state > 0) e->e3_state = 0; }      // (another grid: the residency self-test again)
     if (off || !(g.direct || g.inker) || g.wide || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
     if (e->e3_state < 0) return 0;
     if (e->e3_state == 0) {
@@ -441,7 +457,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
 
     // ---- engine 3: runs of stages that neither resample nor need a certificate pass become one persistent launch each
     bool e3 = false;
-    if (!multi && !g.rccl && g.hs.size() == 1) { if (int e = seg3_ready(h0, &e3)) return e; }
+    if (!multi && !g.rccl && g.hs.size() == 1) { if (int e = seg3_ready(h0, &e3, two_chunk_run(h0, rc))) return e; }
     // several handles: the segments span them when the peer mailbox is up (the gatherers post their shard totals into every handle's
     // tables, stage3.hpp Seg3Args::peers) and every handle's grid passed its residency self-test - all ranks must take the same decision
     static const int e3_env = getenv("SMCMI_ENGINE3") ? atoi(getenv("SMCMI_ENGINE3")) : 1;       // 0 off, 1 default, 2 one handle only, 3 also for in-process groups of any size
@@ -470,7 +486,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     static const int sel_in_env = getenv("SMCMI_SEG_SELECT") ? atoi(getenv("SMCMI_SEG_SELECT")) : 1;      // development: 0 = the segment leaves, selection as launches
     // (the workers' blocks must be the selection kernels' blocks: one 512-slot tile per moment row - not so when a cloud is cut into 2 or 4
     // long virtual shards of more than 32 rows, whose gather blocks take two tiles each)
-    const bool sel_inside = e3 && !seg_sys && g.hs.size() == 1 && d <= 10 && sel_in_env != 0 && h0->d_cum != nullptr && g0.nbg == g0.nb2 && g0.perg == T3 &&
+    const bool sel_inside = e3 && !seg_sys && g.hs.size() == 1 && d <= 10 && h0->e2->seg_ch == 1 && sel_in_env != 0 && h0->d_cum != nullptr && g0.nbg == g0.nb2 && g0.perg == T3 &&
                             g0.V * g0.nb1 <= 256;
     if (sel_inside) {
         Eng2 *e = h0->e2;
@@ -1060,7 +1076,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // segments of engine 3: launches, the stages they completed and (profile mode) their HIP-event time
     res->n_segments = seg_launches; res->segment_stages = 0; res->kernel_ms_segments = 0.0;
     // (workers + gatherers; no gatherer where the workers take each other's rows: launch2.hpp launch_k3_seg)
-    res->segment_blocks = seg_launches > 0 ? g0.Vl * g0.nb2 + ((g0.nb2 <= 2 && !seg_sys) ? 0 : g0.Vl) : 0;
+    res->segment_blocks = seg_launches > 0 ? g0.Vl * ((g0.nb2 + h0->e2->seg_ch - 1) / h0->e2->seg_ch) + ((g0.nb2 <= 2 && !seg_sys) ? 0 : g0.Vl) : 0;
     res->segment_state = h0->e2->e3_state; res->segment_timeouts = h0->seg_timeouts;
     if (seg_launches > 0) {
         const int nl = std::min(seg_launches, SEG3_MAX_LAUNCHES);

@@ -754,7 +754,7 @@ extern "C" int smcmi_run_sharded(smcmi_handle *h, const smcmi_run_config *rc, sm
     if (int e = check_lik_pair(h)) return e;
     ShardGroup g;
     g.hs = {h}; g.world = h->world; g.rccl = true; g.hostc = h->has_hostc;
-    if (!h->cb[0] && eng2_eligible(h, g.world, false)) return run2_guarded(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
+    if (!h->cb[0] && eng2_eligible(h, g.world, false, rc)) return run2_guarded(g, rc, res);      // n_para <= 10: the two-launch stage (stage2.hpp / run2.hpp)
     return run_sharded_impl(g, rc, res);                                             // n_para > 10, and every run with a host likelihood
 }
 
@@ -774,6 +774,6 @@ extern "C" int smcmi_run_group(smcmi_handle **hs, int32_t n, const smcmi_run_con
     }
     if (expect != hs[0]->cfg.n_parts) return set_err(SMCMI_ERR_ARG, "group handles do not cover n_parts");
     g.world = n; g.rccl = false;
-    if (!hs[0]->cb[0] && eng2_eligible(hs[0], g.world, n == 1)) return run2_guarded(g, rc, res);
+    if (!hs[0]->cb[0] && eng2_eligible(hs[0], g.world, n == 1, rc)) return run2_guarded(g, rc, res);
     return run_sharded_impl(g, rc, res);
 }

@@ -998,7 +998,7 @@ static int check_lik_pair(const smcmi_handle *h) {
 }
 struct ShardGroup;
 static int run_callback(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
-static bool eng2_eligible(const smcmi_handle *h, int world, bool single);
+static bool eng2_eligible(const smcmi_handle *h, int world, bool single, const smcmi_run_config *rc);
 static int run2_single(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res);
 
 extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_result *res) {
@@ -1009,7 +1009,7 @@ extern "C" int smcmi_run(smcmi_handle *h, const smcmi_run_config *rc, smcmi_resu
     res->segment_blocks = 0; res->segment_state = 0; res->segment_timeouts = 0; res->shift_fallback_stage = 0;
     if (int e = check_lik_pair(h)) return e;
     if (h->cb[0]) return run_callback(h, rc, res);                    // user likelihood on the host (callback.hpp)
-    if (eng2_eligible(h, 1, true)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
+    if (eng2_eligible(h, 1, true, rc)) return run2_single(h, rc, res);          // n_para <= 10: the two-launch stage (stage2.hpp)
     const int nf = h->h_model.n_free;
     if (rc->n_blocks < 1 || rc->n_blocks > nf || ((nf + rc->n_blocks - 1) / rc->n_blocks) * (rc->n_blocks - 1) >= nf)
         return set_err(SMCMI_ERR_ARG, "n_blocks incompatible with the number of free parameters");
@@ -1536,7 +1536,7 @@ static int run2_guarded(ShardGroup &g, const smcmi_run_config *rc, smcmi_result 
     smcmi_handle *h0 = g.hs[0];
     const bool single = g.world == 1 && !g.rccl && g.hs.size() == 1;
     bool may_seg = !e3_off && h0->d <= 10 && (single || e3_sharded);
-    for (auto *h : g.hs) may_seg = may_seg && h->n <= 131072 && (!h->e2 || h->e2->e3_state >= 0);
+    for (auto *h : g.hs) may_seg = may_seg && h->n <= (single ? 253952 : 131072) && (!h->e2 || h->e2->e3_state >= 0);
     const long long state_n = (long long)((sizeof(DevState) + 7) / 8);     // (doubles)
     if (may_seg) {
         for (auto *h : g.hs) {

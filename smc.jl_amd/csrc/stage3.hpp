@@ -632,7 +632,7 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
 // discarded by `if constexpr`), and - unlike lambdas, whose by-reference captures put a dozen loop variables into scratch - they cost nothing.
 #define K3_DO_DRAW(ns)                                                                                                                          \
     do {                                                                                                                                        \
-        if ((ns) <= sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)(ns), db0, ma.debug);                                    \
+        if ((ns) <= sa.n_last) k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid_park, (unsigned)(ns), db0, ma.debug);                               \
         K3_STAMP(sa.prof, 7);                                                                                                                   \
     } while (0)
 // po_p: Post2 of stage ns - 1; pair: stage ns's correction row is out as well (riding) - both tables' totals in one fetch, s_tot filled for the
@@ -659,8 +659,22 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
         if (ACT == 0 && writer && tid < NWB_) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];       \
         K3_STAMP(sa.prof, 9);                                                                                                                   \
     } while (0)
-#define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? (long long)k3_copy_words(W) : 0)
+#define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0)
 #define K3_TPAR(stage) K3_RPAR(stage)
+// CH = 2: exchange the chunk in registers with the parked one (thread-private LDS slots: no barrier)
+#define K3_SWAP_CHUNKS()                                                                                                                        \
+    do {                                                                                                                                        \
+        if constexpr (CH > 1) {                                                                                                                 \
+            double *s2_ = st2 + tid;                                                                                                            \
+            _Pragma("unroll") for (int k_ = 0; k_ < D; ++k_) { const double t_ = s2_[k_ * T3]; s2_[k_ * T3] = x[k_]; x[k_] = t_; }              \
+            { double t_; t_ = s2_[D * T3]; s2_[D * T3] = like; like = t_; t_ = s2_[(D + 1) * T3]; s2_[(D + 1) * T3] = lprior; lprior = t_;      \
+              t_ = s2_[(D + 2) * T3]; s2_[(D + 2) * T3] = like_prev; like_prev = t_; t_ = s2_[(D + 3) * T3]; s2_[(D + 3) * T3] = acc_val; acc_val = t_; \
+              t_ = s2_[(D + 4) * T3]; s2_[(D + 4) * T3] = Wt; Wt = t_; t_ = s2_[(D + 5) * T3]; s2_[(D + 5) * T3] = v; v = t_; }                \
+            cur ^= 1;                                                                                                                           \
+            beg = beg_c[cur]; end = end_c[cur]; i = beg + tid; live = i < end; has = has_c[cur]; rowi = rowi_c[cur];                            \
+            pid = (unsigned long long)(ma.gid0 + i);                                                                                            \
+        }                                                                                                                                       \
+    } while (0)
 
 // grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard; W blocks
 // where the workers take the rows themselves: one handle with one or two blocks per virtual shard).
@@ -668,7 +682,11 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
 // a virtual shard's workers and (W a multiple of 8) its gatherer share an XCD - placement is speed only, never correctness.
 // Every block - gatherers included - derives the stage's decisions itself from the V shard totals (decide2, post2, begin2_wave: same
 // inputs, same code, same result everywhere, as in engine 2's kernels), the workers also the proposal; worker 0 records them.
-template <int D, bool ALPHA1, bool RIDE>
+// CH = 2 (α = 1 only; one handle of 126 977 .. 253 952 particles with a cheap likelihood, run2.hpp seg3_ready): a worker owns TWO consecutive
+// 512-particle chunks of its virtual shard - one in registers, one parked in LDS ((D + 6) columns behind the parking area), exchanged between
+// the per-particle phases; it publishes two rows per hand-over and pays the serial phases and the hand-overs once.  Such a segment leaves at a
+// stage that must resample (its selection runs as launches).
+template <int D, bool ALPHA1, bool RIDE, int CH = 1>
 __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -686,7 +704,8 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     __shared__ double mixzt[ALPHA1 ? 1 : T3 * D];
     Mut2Lds<D> L(sm);
     const int tid = threadIdx.x;
-    const int W = g.Vl * g.nb2;
+    const int nbw = (g.nb2 + CH - 1) / CH;                      // workers per virtual shard
+    const int W = g.Vl * nbw;
     const bool worker = (int)blockIdx.x < W, writer = blockIdx.x == 0;
     if (tid == 0) { s_rp = st->rp; s_to = 0; }
     if (tid < nf) L.fi[tid] = md->free_inds[tid];
@@ -770,14 +789,14 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         bool cm_posted = false;
         auto sweep_cm = [&](int ns) __attribute__((always_inline)) -> bool {
             const unsigned tg = sa.tag_base | (unsigned)ns;
-            const long long rp_ = (RIDE && (ns & 1)) ? (long long)k3_copy_words(W) : 0, tp_ = rp_;
+            const long long rp_ = (RIDE && (ns & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0, tp_ = rp_;
             return gather_vshard<T3>(sa.g_cm + rp_ + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tg, sa.to, &s_to,
                                      [&](int idx, double val) { post_total(sa.gt_cm + tp_, sa.off_cm, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tg); }, g_stage,
                                      (sa.gprof && ns == sa.prof_stage) ? sa.gprof + 90 + 4 * vg : nullptr);
         };
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
-            const long long rpar = (RIDE && (n & 1)) ? (long long)k3_copy_words(W) : 0, tpar = rpar;      // stage n's copy of the tables (riding launches)
+            const long long rpar = (RIDE && (n & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0, tpar = rpar;      // stage n's copy of the tables (riding launches)
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
             if (!entered) {
                 K3_WALL(sa.gprof, 40 + 6 * vg + 0);
@@ -824,26 +843,54 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     // the first proposal's random numbers of the NEXT stage, drawn while the block waits for that stage's begin (they depend on (seed,
     // particle, stage) only) and parked here, slot-major: z_park[slot * T3 + tid], slots = MH uniform, mixture uniform, D normals
     double *z_park = sm + k3_park_offset(D);
-    const int vl = (int)blockIdx.x % g.Vl, r = (int)blockIdx.x / g.Vl, rowi = vl * g.nb2 + r;       // row index = engine 2's block index
+    const int vl = (int)blockIdx.x % g.Vl, wr = (int)blockIdx.x / g.Vl;
     const double pw = rp.pw, logp_old = rp.logp_old, nrm_N = ma.n_parts;
     const bool hist = rp.store_history && sa.hist_w != nullptr;
-    long long beg, end;
-    vchunk(g, vl, r, T3, beg, end);
-    const long long i = beg + tid;
-    const bool live = i < end;
-    const long long il = live ? i : (end > beg ? end - 1 : 0);
-    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    // chunk c of this worker = block (wr CH + c) of the virtual shard (row index = engine 2's block index); a chunk beyond the shard's last
+    // block holds nothing and publishes nothing.  (CH = 1: nothing below ever changes `i`, `live`, `rowi`, `pid` - constants to the compiler)
+    long long beg_c[CH], end_c[CH];
+    int rowi_c[CH];
+    bool has_c[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int rc = wr * CH + c;
+        has_c[c] = rc < g.nb2;
+        rowi_c[c] = vl * g.nb2 + (has_c[c] ? rc : g.nb2 - 1);
+        vchunk(g, vl, rc, T3, beg_c[c], end_c[c]);
+        if (!has_c[c]) beg_c[c] = end_c[c];
+    }
+    int cur = 0;                                                // the chunk in registers
+    long long beg = beg_c[0], end = end_c[0], i = beg + tid;
+    bool live = i < end, has = has_c[0];
+    int rowi = rowi_c[0];
+    unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    const unsigned long long pid_park = pid;                    // (the draws parked ahead are chunk 0's)
+    double *st2 = z_park + (D + 2) * T3;                        // CH = 2: the parked chunk [θ_1..θ_D | loglh | logprior | old_loglh | accept | W | W̃][T3]
     double x[D], like, lprior, like_prev, Wt, acc_val;
+    double v_entered;                                           // the unnormalised weight K1 left for the entered stage
     // (entered at the mutation of a stage that resampled: the gathered cloud is in buffer 1 - k2_gather - as K2 reads it)
+    {
+        const long long il = live ? i : (end > beg ? end - 1 : 0);
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = col(cl, rs0, k)[il];
-    like = col(cl, rs0, D)[il]; lprior = col(cl, rs0, D + 1)[il]; like_prev = col(cl, rs0, D + 2)[il];
-    acc_val = col(cl, 0, D + 3)[il]; Wt = col(cl, 0, D + 4)[il];
-    double v_entered = sa.enter_mut ? ma.wt[il] : 0.0;          // the unnormalised weight K1 left for the entered stage
-    if (!live) {
+        for (int k = 0; k < D; ++k) x[k] = col(cl, rs0, k)[il];
+        like = col(cl, rs0, D)[il]; lprior = col(cl, rs0, D + 1)[il]; like_prev = col(cl, rs0, D + 2)[il];
+        acc_val = col(cl, 0, D + 3)[il]; Wt = col(cl, 0, D + 4)[il];
+        v_entered = sa.enter_mut ? ma.wt[il] : 0.0;
+        if (!live) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = 0.0;
-        like = lprior = like_prev = 0.0;
+            for (int k = 0; k < D; ++k) x[k] = 0.0;
+            like = lprior = like_prev = 0.0;
+        }
+    }
+    if constexpr (CH > 1) {
+        const long long i1 = beg_c[1] + tid;
+        const bool live1 = i1 < end_c[1];
+        const long long il = live1 ? i1 : (end_c[1] > beg_c[1] ? end_c[1] - 1 : 0);
+        double *s2 = st2 + tid;
+#pragma unroll
+        for (int k = 0; k < D + 3; ++k) s2[k * T3] = live1 ? col(cl, rs0, k)[il] : 0.0;
+        s2[(D + 3) * T3] = col(cl, 0, D + 3)[il]; s2[(D + 4) * T3] = col(cl, 0, D + 4)[il];
+        s2[(D + 5) * T3] = sa.enter_mut ? ma.wt[il] : 0.0;
     }
     for (int k = tid; k < D; k += T3) {
         L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
@@ -854,7 +901,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     LikView lv[2];
     k2_stage_lik<T3>(ma.lik[0], ma.lik[1], L.l_par, L.l_dat, lv);     // once per segment (the mutation rows' scratch is `red`, not this area)
     const int db0 = nb == 1 ? nf : (nf + nb - 1) / nb;          // entries of the first random block
-    k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
+    k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid_park, (unsigned)n, db0, ma.debug);      // (later stages: under the wait for their begin)
     __syncthreads();
     int done = 0;
     bool timed_out = false;
@@ -865,6 +912,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     const bool rows_two = g.nb2 == 2 && !sys;                    // ... two blocks each (up to 8 192 particles: the reference's default 5 000): gather_totals<2>
     // rides: this stage's correction row was formed in front of its begin, behind the previous stage's mutation row (k3_rides)
     bool rides = false;
+    double v = v_entered;                                       // the particle's unnormalised weight W̃ of the stage (CH = 2: travels with its chunk)
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
         RecB3<D> &B = s_b[n & 1];
@@ -878,7 +926,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         const bool first = n == sa.n_first;                     // (its begin ran in front of the loop, its draws are parked)
         const bool entered = sa.enter_mut && first;             // this stage's correction (and selection) ran as launches: totals in s_tot
         int rs = entered ? rs0 : 0;
-        double v = entered ? v_entered : 0.0;                   // the particle's unnormalised weight W̃ of stage n (the entered stage: what K1 left)
+        if constexpr (CH == 1) v = entered ? v_entered : 0.0;   // W̃ of stage n (the entered stage: what K1 left)
         // Three steps lead up to a stage's correction totals (ONE site of code each per instantiation: the stage loop has neither registers nor
         // instruction cache for a second copy):
         //   CORR   correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block, published
@@ -892,7 +940,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             // (riding: what begin2_wave will put into Begin2 for a fixed schedule under shift_lag - the same values, before the begin has run)
             const double phi = rides ? (n <= rp.n_phi ? sa.sched[n - 1] : 1.0) : s_a.bg.phi_n, phi_prev = rides ? po.phi_n : s_a.bg.phi_prev;
             const double esh = pw == 0.0 ? (rides ? po.e_seen - (rp.shift_lag == n ? 1e6 : 0.0) : s_a.bg.e_shift) : 0.0;
+#pragma unroll
+            for (int it = 0; it < CH; ++it) {                   // (CH = 2: the chunk in registers, then the parked one - which stays in registers for the MH step)
             unsigned long long *my_cm = sa.g_cm + K3_RPAR(n) + (long long)rowi * MCM * 2;
+            if constexpr (CH > 1) v = 0.0;
             if constexpr (ALPHA1) {
                 // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
                 double xx[D + 1];
@@ -906,7 +957,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                         sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
                     }
                 }
-                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { if (has) gran_store(my_cm + idx * 2, val, tag); });
             } else {
                 // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
                 // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
@@ -922,9 +973,11 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                         sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
                     }
                 }
-                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { gran_store(my_cm + idx * 2, val, tag); });
+                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { if (has) gran_store(my_cm + idx * 2, val, tag); });
             }
-            if (tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
+            if (has && tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
+            if (it + 1 < CH) K3_SWAP_CHUNKS();
+            }
         }
         K3_STAMP(sa.prof, 2);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
@@ -1006,15 +1059,16 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 4);
         // ================= mutation (src/mutation.jl:56-138): normalize_weights!, the MH steps, one row per block
         const double phi_n = B.po.phi_n, nrm_sumw = B.po.sumw;
+        for (int it = 0; it < CH; ++it) {                       // (CH = 2: the parked chunk's turn first - it is in registers since the correction)
         double accept = 0.0;
         double step_prob, uc, z[D];
-        {
+        if (CH == 1 || cur == 0) {
             const double *p = z_park + tid;                     // (written by this thread)
             step_prob = p[0];
             uc = p[T3];
 #pragma unroll
             for (int e = 0; e < D; ++e) z[e] = p[(2 + e) * T3];
-        }
+        } else draw2<D>(ma.seed, pid, (unsigned)n, 0u, db0, ma.debug, step_prob, uc, z);       // (only chunk 0's first proposal is drawn ahead)
         if (live) {
             Wt = rs ? 1.0 : (v * nrm_N) / nrm_sumw;             // W·N then /ΣW̃, two roundings like the reference (particle.jl:362-366); 1 after a resample
             if (ma.hist_W && ma.store_history) ma.hist_W[(long long)(n - 1) * ma.hist_ld + i] = Wt;
@@ -1027,8 +1081,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             double *plain = ma.rows_mut + (long long)rowi * RMUT;      // (the launch after this one totals the last stage's rows from here)
             unsigned long long *my_mut = sa.g_mut + K3_RPAR(n) + (long long)rowi * RMUT * 2;
             k2_mut_row_f<T3>(ma.adaptive != 0, like, like_prev, live ? Wt : 0.0, live ? acc_val : 0.0, e_center, live, rs != 0, red, L.red,
-                             [&](int idx, double val) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; });
-            if (tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
+                             [&](int idx, double val) { if (has) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; } });
+            if (has && tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
+        }
+        if (it + 1 < CH) K3_SWAP_CHUNKS();
         }
         ++done;
         K3_STAMP(sa.prof, 6);
@@ -1044,12 +1100,21 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
 #undef K3_TPAR
 #undef K3_DO_DRAW
 #undef K3_DO_BEGIN
+#undef K3_SWAP_CHUNKS
     // ---- the cloud goes back to buffer 0 as the last completed stage left it
     if (live && !timed_out) {
 #pragma unroll
         for (int k = 0; k < D; ++k) col(cl, 0, k)[i] = x[k];
         col(cl, 0, D)[i] = like; col(cl, 0, D + 1)[i] = lprior; col(cl, 0, D + 2)[i] = like_prev;
         col(cl, 0, D + 3)[i] = acc_val; col(cl, 0, D + 4)[i] = Wt;
+    }
+    if constexpr (CH > 1) {
+        const long long io = beg_c[cur ^ 1] + tid;
+        if (io < end_c[cur ^ 1] && !timed_out) {
+            const double *s2 = st2 + tid;
+#pragma unroll
+            for (int k = 0; k < D + 5; ++k) col(cl, 0, k)[io] = s2[k * T3];
+        }
     }
     if (writer && tid == 0) {
         if (sa.done_out) *sa.done_out = done;
