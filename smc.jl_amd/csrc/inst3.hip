@@ -7,4 +7,7 @@
 #ifndef SMCMI_INST3_C
 #define SMCMI_INST3_C 1
 #endif
+#if SMCMI_INST3_C == 2
+#define SMCMI_K3_CH2 1              // (stage3.hpp: the two-chunk text of the segment kernel)
+#endif
 #include "launch2.hpp"

@@ -661,6 +661,11 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
     } while (0)
 #define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0)
 #define K3_TPAR(stage) K3_RPAR(stage)
+// TWO CHUNKS PER WORKER (k3_segment<D, true, RIDE, 2>) is compiled from this same kernel body in translation units of its own, which define
+// SMCMI_K3_CH2 (inst3.hip with -DSMCMI_INST3_C=2).  Everywhere else the few places where the variants differ expand to the one-chunk text of
+// round 5 - not to `if constexpr (CH == 1)` equivalents: the segment kernel's code generation is that touchy (the same kernel with the
+// variants' differences as dead template branches ran the headline's stage 0.5 µs - 1.6 % - slower: profiles/r06_codegen_ab.txt).
+#ifdef SMCMI_K3_CH2
 // CH = 2: exchange the chunk in registers with the parked one (thread-private LDS slots: no barrier)
 #define K3_SWAP_CHUNKS()                                                                                                                        \
     do {                                                                                                                                        \
@@ -675,6 +680,18 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
             pid = (unsigned long long)(ma.gid0 + i);                                                                                            \
         }                                                                                                                                       \
     } while (0)
+#define K3_HAS has                                                       /* this chunk exists (the last worker of a shard with an odd block count has one) */
+#define K3_CHUNKS_BEGIN for (int it = 0; it < CH; ++it) {                /* the chunk in registers, then the parked one */
+#define K3_CHUNKS_END if (it + 1 < CH) K3_SWAP_CHUNKS(); }
+#define K3_PARKED_DRAWS (cur == 0)                                       /* only chunk 0's first proposal is drawn ahead */
+#define K3_V_RESET() v = 0.0
+#else
+#define K3_HAS true
+#define K3_CHUNKS_BEGIN {
+#define K3_CHUNKS_END }
+#define K3_PARKED_DRAWS true
+#define K3_V_RESET() (void)0
+#endif
 
 // grid = W + g.Vl blocks of T3 threads, every one resident (W = g.Vl * g.nb2 workers, then one gatherer per local virtual shard; W blocks
 // where the workers take the rows themselves: one handle with one or two blocks per virtual shard).
@@ -704,8 +721,12 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     __shared__ double mixzt[ALPHA1 ? 1 : T3 * D];
     Mut2Lds<D> L(sm);
     const int tid = threadIdx.x;
-    const int nbw = (g.nb2 + CH - 1) / CH;                      // workers per virtual shard
-    const int W = g.Vl * nbw;
+#ifdef SMCMI_K3_CH2
+    const int W = g.Vl * ((g.nb2 + CH - 1) / CH);               // (workers per virtual shard: every one owns CH blocks of it)
+#else
+    static_assert(CH == 1, "two chunks per worker: a translation unit that defines SMCMI_K3_CH2 (inst3.hip -DSMCMI_INST3_C=2)");
+    const int W = g.Vl * g.nb2;
+#endif
     const bool worker = (int)blockIdx.x < W, writer = blockIdx.x == 0;
     if (tid == 0) { s_rp = st->rp; s_to = 0; }
     if (tid < nf) L.fi[tid] = md->free_inds[tid];
@@ -843,6 +864,30 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     // the first proposal's random numbers of the NEXT stage, drawn while the block waits for that stage's begin (they depend on (seed,
     // particle, stage) only) and parked here, slot-major: z_park[slot * T3 + tid], slots = MH uniform, mixture uniform, D normals
     double *z_park = sm + k3_park_offset(D);
+#ifndef SMCMI_K3_CH2
+    const int vl = (int)blockIdx.x % g.Vl, r = (int)blockIdx.x / g.Vl, rowi = vl * g.nb2 + r;       // row index = engine 2's block index
+    const double pw = rp.pw, logp_old = rp.logp_old, nrm_N = ma.n_parts;
+    const bool hist = rp.store_history && sa.hist_w != nullptr;
+    long long beg, end;
+    vchunk(g, vl, r, T3, beg, end);
+    const long long i = beg + tid;
+    const bool live = i < end;
+    const long long il = live ? i : (end > beg ? end - 1 : 0);
+    const unsigned long long pid = (unsigned long long)(ma.gid0 + i);
+    const unsigned long long pid_park = pid;                    // (the two-chunk variant parks chunk 0's draws: stage3.hpp under SMCMI_K3_CH2)
+    double x[D], like, lprior, like_prev, Wt, acc_val;
+    // (entered at the mutation of a stage that resampled: the gathered cloud is in buffer 1 - k2_gather - as K2 reads it)
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = col(cl, rs0, k)[il];
+    like = col(cl, rs0, D)[il]; lprior = col(cl, rs0, D + 1)[il]; like_prev = col(cl, rs0, D + 2)[il];
+    acc_val = col(cl, 0, D + 3)[il]; Wt = col(cl, 0, D + 4)[il];
+    double v_entered = sa.enter_mut ? ma.wt[il] : 0.0;          // the unnormalised weight K1 left for the entered stage
+    if (!live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = 0.0;
+        like = lprior = like_prev = 0.0;
+    }
+#else
     const int vl = (int)blockIdx.x % g.Vl, wr = (int)blockIdx.x / g.Vl;
     const double pw = rp.pw, logp_old = rp.logp_old, nrm_N = ma.n_parts;
     const bool hist = rp.store_history && sa.hist_w != nullptr;
@@ -854,7 +899,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int rc = wr * CH + c;
-        has_c[c] = rc < g.nb2;
+        has_c[c] = CH == 1 || rc < g.nb2;                  // (CH = 1: every worker has its block - a constant, no predicate around the row stores)
         rowi_c[c] = vl * g.nb2 + (has_c[c] ? rc : g.nb2 - 1);
         vchunk(g, vl, rc, T3, beg_c[c], end_c[c]);
         if (!has_c[c]) beg_c[c] = end_c[c];
@@ -892,6 +937,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         s2[(D + 3) * T3] = col(cl, 0, D + 3)[il]; s2[(D + 4) * T3] = col(cl, 0, D + 4)[il];
         s2[(D + 5) * T3] = sa.enter_mut ? ma.wt[il] : 0.0;
     }
+#endif
     for (int k = tid; k < D; k += T3) {
         L.m_lo[k] = md->lo[k]; L.m_hi[k] = md->hi[k]; L.m_a[k] = md->prior_a[k]; L.m_b[k] = md->prior_b[k]; L.m_k[k] = md->prior_k[k];
         L.m_fix[k] = md->fixed[k]; L.m_fam[k] = md->prior_family[k];
@@ -912,7 +958,9 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     const bool rows_two = g.nb2 == 2 && !sys;                    // ... two blocks each (up to 8 192 particles: the reference's default 5 000): gather_totals<2>
     // rides: this stage's correction row was formed in front of its begin, behind the previous stage's mutation row (k3_rides)
     bool rides = false;
-    double v = v_entered;                                       // the particle's unnormalised weight W̃ of the stage (CH = 2: travels with its chunk)
+#ifdef SMCMI_K3_CH2
+    double v = v_entered;                                       // the particle's unnormalised weight W̃ of the stage: travels with its chunk
+#endif
     for (;; ++n) {
         K3_STAMP(sa.prof, 1);
         RecB3<D> &B = s_b[n & 1];
@@ -926,7 +974,9 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         const bool first = n == sa.n_first;                     // (its begin ran in front of the loop, its draws are parked)
         const bool entered = sa.enter_mut && first;             // this stage's correction (and selection) ran as launches: totals in s_tot
         int rs = entered ? rs0 : 0;
-        if constexpr (CH == 1) v = entered ? v_entered : 0.0;   // W̃ of stage n (the entered stage: what K1 left)
+#ifndef SMCMI_K3_CH2
+        double v = entered ? v_entered : 0.0;                   // the particle's unnormalised weight W̃ of stage n (the entered stage: what K1 left)
+#endif
         // Three steps lead up to a stage's correction totals (ONE site of code each per instantiation: the stage loop has neither registers nor
         // instruction cache for a second copy):
         //   CORR   correction at ϕ_n (src/smc_main.jl:401-420) + moments: one row per block, published
@@ -940,10 +990,9 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             // (riding: what begin2_wave will put into Begin2 for a fixed schedule under shift_lag - the same values, before the begin has run)
             const double phi = rides ? (n <= rp.n_phi ? sa.sched[n - 1] : 1.0) : s_a.bg.phi_n, phi_prev = rides ? po.phi_n : s_a.bg.phi_prev;
             const double esh = pw == 0.0 ? (rides ? po.e_seen - (rp.shift_lag == n ? 1e6 : 0.0) : s_a.bg.e_shift) : 0.0;
-#pragma unroll
-            for (int it = 0; it < CH; ++it) {                   // (CH = 2: the chunk in registers, then the parked one - which stays in registers for the MH step)
+            K3_CHUNKS_BEGIN                                     // (two chunks: the one in registers, then the parked one - which stays in registers for the MH step)
             unsigned long long *my_cm = sa.g_cm + K3_RPAR(n) + (long long)rowi * MCM * 2;
-            if constexpr (CH > 1) v = 0.0;
+            K3_V_RESET();
             if constexpr (ALPHA1) {
                 // (one particle per thread: the row's sums are formed where the butterflies need them - no accumulator array alive)
                 double xx[D + 1];
@@ -957,7 +1006,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                         sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
                     }
                 }
-                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { if (has) gran_store(my_cm + idx * 2, val, tag); });
+                k2_cm_row_one<D, T3 / 64>(v, xx, live, red, [&](int idx, double val) { if (K3_HAS) gran_store(my_cm + idx * 2, val, tag); });
             } else {
                 // (the mixture kernel: the same sums, same bits, through the accumulator form - its register allocation takes that better:
                 // 115 against 164 scratch reloads in the stage loop, 48.7 against 59.8 µs per stage)
@@ -973,11 +1022,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                         sa.hist_w[(long long)(n - 1) * sa.hist_ld + i] = inc * unshift;
                     }
                 }
-                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { if (has) gran_store(my_cm + idx * 2, val, tag); });
+                k2_cm_row_f<D>(acc, red, [&](int idx, double val) { if (K3_HAS) gran_store(my_cm + idx * 2, val, tag); });
             }
-            if (has && tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
-            if (it + 1 < CH) K3_SWAP_CHUNKS();
-            }
+            if (K3_HAS && tid >= NPF && tid < MCM) gran_store(my_cm + tid * 2, 0.0, tag);         // (the pad columns of the even row width)
+            K3_CHUNKS_END
         }
         K3_STAMP(sa.prof, 2);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
@@ -1059,10 +1107,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_STAMP(sa.prof, 4);
         // ================= mutation (src/mutation.jl:56-138): normalize_weights!, the MH steps, one row per block
         const double phi_n = B.po.phi_n, nrm_sumw = B.po.sumw;
-        for (int it = 0; it < CH; ++it) {                       // (CH = 2: the parked chunk's turn first - it is in registers since the correction)
+        K3_CHUNKS_BEGIN                                         // (two chunks: the parked chunk's turn first - it is in registers since the correction)
         double accept = 0.0;
         double step_prob, uc, z[D];
-        if (CH == 1 || cur == 0) {
+        if (K3_PARKED_DRAWS) {
             const double *p = z_park + tid;                     // (written by this thread)
             step_prob = p[0];
             uc = p[T3];
@@ -1081,11 +1129,10 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             double *plain = ma.rows_mut + (long long)rowi * RMUT;      // (the launch after this one totals the last stage's rows from here)
             unsigned long long *my_mut = sa.g_mut + K3_RPAR(n) + (long long)rowi * RMUT * 2;
             k2_mut_row_f<T3>(ma.adaptive != 0, like, like_prev, live ? Wt : 0.0, live ? acc_val : 0.0, e_center, live, rs != 0, red, L.red,
-                             [&](int idx, double val) { if (has) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; } });
-            if (has && tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
+                             [&](int idx, double val) { if (K3_HAS) { gran_store(my_mut + idx * 2, val, tag); plain[idx] = val; } });
+            if (K3_HAS && tid == RMUT - 1) gran_store(my_mut + tid * 2, 0.0, tag);                  // (column 33 is unused)
         }
-        if (it + 1 < CH) K3_SWAP_CHUNKS();
-        }
+        K3_CHUNKS_END
         ++done;
         K3_STAMP(sa.prof, 6);
         K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 2);
@@ -1101,6 +1148,11 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
 #undef K3_DO_DRAW
 #undef K3_DO_BEGIN
 #undef K3_SWAP_CHUNKS
+#undef K3_HAS
+#undef K3_CHUNKS_BEGIN
+#undef K3_CHUNKS_END
+#undef K3_PARKED_DRAWS
+#undef K3_V_RESET
     // ---- the cloud goes back to buffer 0 as the last completed stage left it
     if (live && !timed_out) {
 #pragma unroll
@@ -1108,7 +1160,8 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         col(cl, 0, D)[i] = like; col(cl, 0, D + 1)[i] = lprior; col(cl, 0, D + 2)[i] = like_prev;
         col(cl, 0, D + 3)[i] = acc_val; col(cl, 0, D + 4)[i] = Wt;
     }
-    if constexpr (CH > 1) {
+#ifdef SMCMI_K3_CH2
+    {
         const long long io = beg_c[cur ^ 1] + tid;
         if (io < end_c[cur ^ 1] && !timed_out) {
             const double *s2 = st2 + tid;
@@ -1116,6 +1169,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             for (int k = 0; k < D + 5; ++k) col(cl, 0, k)[io] = s2[k * T3];
         }
     }
+#endif
     if (writer && tid == 0) {
         if (sa.done_out) *sa.done_out = done;
         if (timed_out) { ctl->status.err = SMCMI_ERR_TIMEOUT; ctl->status.stage = n; ctl->status.code = 9; }

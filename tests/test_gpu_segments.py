@@ -230,9 +230,9 @@ def test_engine_1_two_level_totals_agree_with_engine_2():
     and at 600 000 (the stage-begin reducers as well)."""
     for n in (200_000, 600_000):
         cfg = dict(n=n, d=10, seed=5, spec_args=[10], history=False, kw=dict(use_fixed_schedule=False, tempering_target=0.95))
-        a = _run(cfg, {})[0]
+        a = _run(cfg, {"SMCMI_ENGINE": "1"})[0]                                 # (200 000 particles of this model would run in two-chunk segments since round 6)
         c = _run(cfg, {"SMCMI_ENGINE": "2"})[0]
-        assert a["n_segments"] == 0                                            # (engine 1: no segments at this size)
+        assert a["n_segments"] == 0                                            # (engine 1: no segments)
         for other in (c,):
             assert (a["n_stages"], a["resamples"]) == (other["n_stages"], other["resamples"])
             assert abs(a["logmdd_f"] - other["logmdd_f"]) <= 1e-10 * abs(a["logmdd_f"]), (n, a["logmdd_f"], other["logmdd_f"])
