@@ -4,8 +4,10 @@
 
 static int prof2_report(smcmi_handle *h0, const Geo2 &g0, int seg_launches) {
     {
-        long long pr[128];
-        HIP_TRY(hipMemcpy(pr, h0->e2->d_prof, sizeof(pr), hipMemcpyDeviceToHost));
+        long long pr[128], gt[64], gp[64];
+        HIP_TRY(hipMemcpy(pr, h0->e2->d_prof + PROF2_SEG0, 64 * sizeof(long long), hipMemcpyDeviceToHost));      // worker 0 of a segment
+        HIP_TRY(hipMemcpy(gt, h0->e2->d_prof + PROF2_GATH, sizeof(gt), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(gp, h0->e2->d_prof + PROF2_GPOLL, sizeof(gp), hipMemcpyDeviceToHost));
         if (seg_launches > 0) {
             // worker block 0's phases of stage prof_stage and the decider's (its clock has another origin: only its own differences mean anything)
             fprintf(stderr, "[smcmi3] stage %d worker 0 ticks: correction + row %lld | wait for the totals %lld | decision + proposal %lld | MH steps %lld | mutation row %lld | next stage's draws %lld | wait for the totals %lld | begin %lld | stage %lld\n",
@@ -16,7 +18,7 @@ static int prof2_report(smcmi_handle *h0, const Geo2 &g0, int seg_launches) {
             fprintf(stderr, "\n");
             {
                 long long sp[10];
-                HIP_TRY(hipMemcpy(sp, h0->e2->d_prof + 1300, sizeof(sp), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(sp, h0->e2->d_prof + PROF2_SEL, sizeof(sp), hipMemcpyDeviceToHost));
                 if (sp[9]) fprintf(stderr, "[smcmi3]   selection inside the segment (wall clock, us): particle stored %.2f | chunk offsets %.2f | scan + cum %.2f | stores acknowledged %.2f | hand-over %.2f | chunk ends %.2f | search %.2f | rows gathered %.2f | moment row %.2f | hand-over %.2f\n",
                                    0.0, (sp[1] - sp[0]) * 0.01, (sp[2] - sp[1]) * 0.01, (sp[3] - sp[2]) * 0.01, (sp[4] - sp[3]) * 0.01, (sp[5] - sp[4]) * 0.01, (sp[6] - sp[5]) * 0.01, (sp[7] - sp[6]) * 0.01, (sp[8] - sp[7]) * 0.01, (sp[9] - sp[8]) * 0.01);
             }
@@ -28,7 +30,7 @@ static int prof2_report(smcmi_handle *h0, const Geo2 &g0, int seg_launches) {
             // the workers had the totals
             const int Wk = g0.Vl * g0.nb2;
             std::vector<long long> ws(4 * (size_t)Wk);
-            HIP_TRY(hipMemcpy(ws.data(), h0->e2->d_prof + 128, sizeof(long long) * ws.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ws.data(), h0->e2->d_prof + PROF2_WORK, sizeof(long long) * ws.size(), hipMemcpyDeviceToHost));
             for (int kind = 0; kind < 2; ++kind) {
                 long long p_min = 0, p_max = 0, s_min = 0, s_max = 0;
                 for (int b = 0; b < Wk; ++b) {
@@ -44,8 +46,8 @@ static int prof2_report(smcmi_handle *h0, const Geo2 &g0, int seg_launches) {
                     long long lastrow = 0;
                     for (int b = v; b < Wk; b += g0.Vl) lastrow = std::max(lastrow, ws[4 * b + 2 * kind]);
                     fprintf(stderr, "[smcmi3]   gatherer %d: its last row +%.2f | first words seen +%.2f | %lld sweep(s) done +%.2f | totals posted +%.2f (started waiting at +%.2f)\n", v, (lastrow - p_min) * 0.01,
-                            (pr[90 + 4 * v + 2 * kind] - p_min) * 0.01, pr[90 + 4 * v + 2 * kind + 1],
-                            (pr[40 + 6 * v + 3 * kind + 1] - p_min) * 0.01, (pr[40 + 6 * v + 3 * kind + 2] - p_min) * 0.01, (pr[40 + 6 * v + 3 * kind] - p_min) * 0.01);
+                            (gp[4 * v + 2 * kind] - p_min) * 0.01, gp[4 * v + 2 * kind + 1],
+                            (gt[6 * v + 3 * kind + 1] - p_min) * 0.01, (gt[6 * v + 3 * kind + 2] - p_min) * 0.01, (gt[6 * v + 3 * kind] - p_min) * 0.01);
                 }
             }
         }
@@ -53,7 +55,7 @@ static int prof2_report(smcmi_handle *h0, const Geo2 &g0, int seg_launches) {
             // census of the large-shard mutation launch of the profiled stage (100 MHz wall clock, the CU every block sat on): how many blocks
             // a CU held at once
             std::vector<long long> cs(3 * PROF2_BLOCKS);
-            HIP_TRY(hipMemcpy(cs.data(), h0->e2->d_prof + 128, sizeof(long long) * cs.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(cs.data(), h0->e2->d_prof + PROF2_CENSUS, sizeof(long long) * cs.size(), hipMemcpyDeviceToHost));
             long long t_min = 0, t_max = 0, sum = 0;
             int nbk = 0;
             std::map<long long, std::vector<std::pair<long long, int>>> per_cu;
@@ -94,6 +96,7 @@ static int prof2_report(smcmi_handle *h0, const Geo2 &g0, int seg_launches) {
                 fprintf(stderr, "\n");
             }
         }
+        HIP_TRY(hipMemcpy(pr, h0->e2->d_prof + PROF2_K1, 128 * sizeof(long long), hipMemcpyDeviceToHost));          // K1's and K2's stamps
         for (int blk = 0; blk < 2; ++blk) {
             fprintf(stderr, "[smcmi2] K1 %s block ticks:", blk ? "mid" : "0");
             for (int q = 1; q <= 5; ++q) fprintf(stderr, " %lld", pr[blk * 32 + q] - pr[blk * 32 + q - 1]);

@@ -15,7 +15,6 @@
 
 
 constexpr int SEG3_MAX_LAUNCHES = 4096;     // segment launches of one run whose stage counts are kept for the profile (more are not timed)
-constexpr int PROF2_BLOCKS = 4096;
 static void free_eng2(Eng2 *e) {
     if (!e) return;
     void *ptrs[] = {e->d_ctl, e->rows_mut, e->rows_cm, e->csum, e->csum_full, e->rows_gm, e->rows_pass[0], e->rows_pass[1], e->vt_mut, e->vt_cm,
@@ -340,9 +339,9 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
     }
     if (getenv("SMCMI_PROF2") && !h0->e2->d_prof) {
-        // ([128, 128 + 3 * PROF2_BLOCKS): wall-clock start / end and CU of every block of that stage's large-shard mutation launch - the census below)
-        if (dmalloc(&h0->e2->d_prof, 128 + 3 * PROF2_BLOCKS)) return SMCMI_ERR_HIP;
-        HIP_TRY(hipMemset(h0->e2->d_prof, 0, (128 + 3 * PROF2_BLOCKS) * sizeof(long long)));
+        // (the buffer's layout: stage2.hpp PROF2_*)
+        if (dmalloc(&h0->e2->d_prof, PROF2_WORDS)) return SMCMI_ERR_HIP;
+        HIP_TRY(hipMemset(h0->e2->d_prof, 0, PROF2_WORDS * sizeof(long long)));
         HIP_TRY(hipDeviceSynchronize());
         h0->e2->prof_stage = atoi(getenv("SMCMI_PROF2"));
     }
@@ -524,7 +523,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
                 Eng2 *e = h->e2;
                 e->seg_seq = 0;
                 HIP_TRY(hipMemsetAsync(e->d_gran3, 0xFF, k3_table_words(e->g.Vl * e->g.nb2) * sizeof(unsigned long long), h->stream));
-                HIP_TRY(hipMemsetAsync(h->d_mbox + MB_SEG_OFF, 0xFF, sizeof(unsigned long long) * 2 * MB_SEG_KIND_WORDS, h->stream));
+                HIP_TRY(hipMemsetAsync(h->d_mbox + MB_SEG_OFF, 0xFF, sizeof(unsigned long long) * 2 * MB_SEG_COPY_WORDS, h->stream));
                 HIP_TRY(hipStreamSynchronize(h->stream));
             }
             if (int e = g.barrier()) return e;           // nobody posts before every table is cleared
@@ -661,7 +660,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             ma.n_steps = rc->n_mh_steps; ma.store_history = h->cfg.store_history; ma.has_other = h->h_model.has_other_priors;
             ma.alpha = rc->alpha; ma.n_parts = (double)h->cfg.n_parts;
             ma.hist_W = h->d_hist_W; ma.hist_ld = h->n; ma.rec = h->rec; ma.debug = dbg;
-            ma.prof = (e->d_prof && n == e->prof_stage) ? e->d_prof + 64 : nullptr;
+            ma.prof = (e->d_prof && n == e->prof_stage) ? e->d_prof + PROF2_K2 : nullptr;
             if (!inker && prepared_stage != n) {                // decision + proposal once, by one block (unless K1's helper block left them)
                 Mut2Args mp = ma;
                 mp.pre = nullptr;
@@ -736,14 +735,14 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         if (sa.note) { last_note_seq = (int)e->seg_seq; }
         sa.tag_base = e->seg_seq << 16; sa.to = e->d_to3; sa.hist_w = h->d_hist_w; sa.hist_ld = h->n;
         sa.done_out = (h == h0 && seg_launches < SEG3_MAX_LAUNCHES) ? e->d_done3 + seg_launches : nullptr;
-        sa.prof = (h == h0 && e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof : nullptr;
+        sa.prof = (h == h0 && e->d_prof && n_first <= e->prof_stage && e->prof_stage <= n_last) ? e->d_prof + PROF2_SEG0 : nullptr;
         sa.prof_stage = e->prof_stage;
-        sa.gprof = sa.prof;
+        sa.gprof = sa.prof ? e->d_prof : nullptr;            // (the wall-clock stamps of every block: absolute PROF2_* offsets)
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && sa.done_out) { hipEventCreate(&e0); hipEventCreate(&e1); evs3.push_back(e0); evs3.push_back(e1); hipEventRecord(e0, h->stream); }
         // (the stage counters of all launches of a run are cleared once, in front of its first segment: a fill per launch was 5 µs each)
         if (sa.done_out && seg_launches == 0) HIP_TRY(hipMemsetAsync(e->d_done3, 0, SEG3_MAX_LAUNCHES * sizeof(int), h->stream));
-#define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0, shift_lag && !seg_sys)
+#define SMCMI_CALL(D) launch_k3_segment<D>(h, ma, sa, rc->n_blocks, rc->alpha == 1.0, shift_lag)
         SMCMI_D_SWITCH(d, SMCMI_CALL)
 #undef SMCMI_CALL
         HIP_TRY(hipGetLastError());                  // (a rejected launch would otherwise surface as a bogus capacity / time-out error)

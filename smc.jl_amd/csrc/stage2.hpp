@@ -37,7 +37,17 @@ constexpr int T1 = 512;           // threads of a correction block
 constexpr int GRP = 64;           // rows per canonical reduction group
 constexpr int pad2(int m) { return (m + 1) & ~1; }   // row widths are even: rows are totalled with 16-byte loads (pad column = 0)
 
-// development aid (SMCMI_PROF2=1): shader-clock stamps of thread 0 of block 0 (slots 0..31) and of the middle block (32..63)
+// development aid (SMCMI_PROF2=<stage>): ONE layout of the handle's stamp buffer (Eng2::d_prof, long long), so that no two users share a slot
+// whatever mix of launches and segments the profiled stage runs through:
+//   [PROF2_K1, +64)  K1's stamps: block 0 at +0.., the middle block at +32..   [PROF2_K2, +64)  K2's likewise (K2_STAMP below)
+//   [PROF2_CENSUS, + 3 PROF2_BLOCKS)   wall-clock start / end and CU of every block of a large-shard mutation launch (stage2b.hpp)
+//   [PROF2_SEG0, +64)   worker 0 of a segment: shader-clock stamps 1..9, the proposal's at +30..33 (K3_STAMP)
+//   [PROF2_SEL, +16)    ... its in-place selection (wall clock)
+//   [PROF2_GATH + 6 v, +6)  gatherer v's hand-over stamps, [PROF2_GPOLL + 4 v, +4) its polls    [PROF2_WORK + 4 b, +4)  worker b's hand-over stamps (wall clock)
+constexpr int PROF2_BLOCKS = 4096;
+constexpr int PROF2_K1 = 0, PROF2_K2 = 64, PROF2_CENSUS = 128, PROF2_SEG0 = PROF2_CENSUS + 3 * PROF2_BLOCKS, PROF2_SEL = PROF2_SEG0 + 64,
+              PROF2_GATH = PROF2_SEL + 16, PROF2_GPOLL = PROF2_GATH + 64, PROF2_WORK = PROF2_GPOLL + 64, PROF2_WORDS = PROF2_WORK + 4 * 256;
+// shader-clock stamps of thread 0 of block 0 (slots 0..31) and of the middle block (32..63)
 #define K2_STAMP(prof, slot)                                                                                                   \
     do {                                                                                                                      \
         if ((prof) != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {                       \
@@ -99,7 +109,8 @@ constexpr int MB_FLAG_WORDS = 2;                               // behind the tab
 // virtual shard's totals into every handle's copy, every block reads its own handle's) - [V2_MAXV][MB_LD] granule pairs per kind
 constexpr int MB_SEG_OFF = MB_WORDS + MB_FLAG_WORDS;
 constexpr int MB_SEG_KIND_WORDS = V2_MAXV * MB_LD * 2;
-constexpr int MB_ALLOC_WORDS = MB_SEG_OFF + 2 * MB_SEG_KIND_WORDS;
+constexpr int MB_SEG_COPY_WORDS = 2 * MB_SEG_KIND_WORDS;        // both kinds; a riding launch uses two copies by stage parity (stage3.hpp Seg3Args)
+constexpr int MB_ALLOC_WORDS = MB_SEG_OFF + 2 * MB_SEG_COPY_WORDS;
 __device__ inline void mb_store(unsigned long long *w, double v, unsigned tag) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -58,11 +58,11 @@ SMCMI_FP_CONTRACT
     const Mut2Lds<D> L(sm);
     K2_STAMP(ma.prof, 0);
     // (development, SMCMI_PROF2: every block's start / end on the 100 MHz wall clock -> the residency census run2_impl prints)
-    if (ma.prof != nullptr && tid == 0 && blockIdx.x < 4096) {
+    if (ma.prof != nullptr && tid == 0 && blockIdx.x < PROF2_BLOCKS) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-        ma.prof[64 + 3 * blockIdx.x] = wall_clock64();
-        ma.prof[64 + 3 * blockIdx.x + 2] = (long long)(((xcc & 0xFu) << 16) | (hw & 0xFF00u));        // (XCC | SE, SH, CU: the CU the block sits on)
+        ma.prof[(PROF2_CENSUS - PROF2_K2) + 3 * blockIdx.x] = wall_clock64();
+        ma.prof[(PROF2_CENSUS - PROF2_K2) + 3 * blockIdx.x + 2] = (long long)(((xcc & 0xFu) << 16) | (hw & 0xFF00u));        // (XCC | SE, SH, CU: the CU the block sits on)
     }
     const double nrm_N = ma.n_parts;
     const int nrm_hist = ma.store_history;
@@ -150,7 +150,7 @@ SMCMI_FP_CONTRACT
     K2_STAMP(ma.prof, 10);
     tail_reduce<T, RMUT>(ma.tail, ma.rows_mut, (int)blockIdx.x / g.nb2, g.nb2, RMUT, RMAX_IDX, 0);
     K2_STAMP(ma.prof, 11);
-    if (ma.prof != nullptr && tid == 0 && blockIdx.x < 4096) ma.prof[64 + 3 * blockIdx.x + 1] = wall_clock64();
+    if (ma.prof != nullptr && tid == 0 && blockIdx.x < PROF2_BLOCKS) ma.prof[(PROF2_CENSUS - PROF2_K2) + 3 * blockIdx.x + 1] = wall_clock64();
 }
 
 }  // namespace smcmi

@@ -290,7 +290,7 @@ __device__ inline bool gather_totals(const unsigned long long *tbl, int nvs, int
 // as gather_vshard would).  tot_m[0, RMUT), tot_c[0, mc); vt: LDS, V2_MAXV * (72 + RMUT) doubles.  All threads call; false: timed out.
 template <int RPS = 1>
 __device__ inline bool gather_totals_pair(const unsigned long long *tbl_m, unsigned tag_m, const unsigned long long *tbl_c, int mc, unsigned tag_c, int nvs,
-                                          unsigned long long *to, int *s_to, double *tot_m, double *tot_c, double *vt) {
+                                          unsigned long long *to, int *s_to, double *tot_m, double *tot_c, double *vt, bool sys = false, double *vt_out = nullptr) {
     const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     double *vt_c = vt, *vt_m = vt + V2_MAXV * 72;
     const double ninf = -__builtin_inf();
@@ -314,9 +314,11 @@ __device__ inline bool gather_totals_pair(const unsigned long long *tbl_m, unsig
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int k = lane + 64 * q;
-                    xc[q][r] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (r * mc + (k < mc ? k : mc - 1)) * 16, 0, 16);
+                    const int off = (r * mc + (k < mc ? k : mc - 1)) * 16;
+                    xc[q][r] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, /*sc0 sc1: system scope*/ 17) : __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, 16);
                 }
-                xm[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, (r * RMUT + (lane < RMUT ? lane : RMUT - 1)) * 16, 0, 16);
+                const int offm = (r * RMUT + (lane < RMUT ? lane : RMUT - 1)) * 16;
+                xm[r] = sys ? __builtin_amdgcn_raw_buffer_load_b128(rs_m, offm, 0, 17) : __builtin_amdgcn_raw_buffer_load_b128(rs_m, offm, 0, 16);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -343,8 +345,8 @@ __device__ inline bool gather_totals_pair(const unsigned long long *tbl_m, unsig
             if (!__any(bad)) break;
             if (*(volatile int *)s_to) break;
             if (attempt == 0) {                                             // a word was not there yet: wait for the rows' first words as gather_totals does
-                if (lane < RPS) gran_poll(row_c + (long long)lane * mc * 2, tag_c, to, s_to);
-                else if (lane >= 32 && lane < 32 + RPS) gran_poll(row_m + (long long)(lane - 32) * RMUT * 2, tag_m, to, s_to);
+                if (lane < RPS) gran_poll(row_c + (long long)lane * mc * 2, tag_c, to, s_to, sys);
+                else if (lane >= 32 && lane < 32 + RPS) gran_poll(row_m + (long long)(lane - 32) * RMUT * 2, tag_m, to, s_to, sys);
             } else {
                 if (lane == 0 && (wall_clock64() - t_begin > (long long)__hip_atomic_load(to + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
                                   __hip_atomic_load(to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -367,7 +369,7 @@ __device__ inline bool gather_totals_pair(const unsigned long long *tbl_m, unsig
         const int k = t - 128;
         const bool mx = k == RMAX_IDX;
         double a = mx ? ninf : 0.0;
-        for (int v = 0; v < nvs; ++v) { const double x = vt_m[v * RMUT + k]; a = mx ? fmax(a, x) : a + x; }
+        for (int v = 0; v < nvs; ++v) { const double x = vt_m[v * RMUT + k]; a = mx ? fmax(a, x) : a + x; if (vt_out) vt_out[v * RMUT + k] = x; }
         tot_m[k] = a;
     }
     __syncthreads();
@@ -433,7 +435,8 @@ struct Seg3Args {
     const double *sched;
     unsigned long long *g_cm, *g_mut;     // the workers' rows as granules: [blocks][MCM * 2] / [blocks][RMUT * 2] words
     unsigned long long *gt_cm, *gt_mut;   // the shard totals as granules: [V2_MAXV][MCM * 2] / [V2_MAXV][RMUT * 2], indexed by GLOBAL virtual shard
-    // (a RIDING launch - one handle - keeps two copies of these four tables, k3_copy_words(blocks) words apart, stage n's rows and totals in copy
+    // (a RIDING launch keeps two copies of these four tables - the rows' k3_copy_words(blocks) words apart, the totals' too on one handle and
+    // MB_SEG_COPY_WORDS apart in the mailbox allocation of several handles - stage n's rows and totals in copy
     // n & 1: a block that publishes stage n + 1's correction row BEFORE it has read stage n's mutation totals overwrites nothing a slower block
     // may still be waiting for - a copy is rewritten two stages later, which every block can only reach through hand-overs that need the slow
     // block's next row.  The kernel forms the offset itself: it has no scalar registers for two more arguments)
@@ -502,7 +505,7 @@ __device__ inline void k3_leave_note(const Seg3Args &sa, const Ctl2 *ctl) {
     } while (0)
 
 // (development, SMCMI_PROF2: the hand-overs of the profiled stage on the 100 MHz wall clock, which all dies share - worker b's slots at
-// prof[128 + 4 b ..], gatherer v's at prof[40 + 6 v ..]; run2_impl prints the spread)
+// PROF2_WORK + 4 b, gatherer v's at PROF2_GATH + 6 v (stage2.hpp: the buffer's layout); prof2.hpp prints the spread)
 #define K3_WALL(prof, idx)                                                                                                    \
     do {                                                                                                                      \
         if ((prof) != nullptr && threadIdx.x == 0 && n == sa.prof_stage) (prof)[(idx)] = wall_clock64();                       \
@@ -625,7 +628,8 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
 // 0.8 µs and the mixture variant 14 spilled registers.  Inside a riding launch a stage that does not ride never begins (the conditions above
 // are begin2_wave's exits; Post2::e_seen is finite from the first begin on), so the riding order needs no second site for the correction.
 __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const Post2 &po, int n, bool sys) {
-    return rp.use_fixed_schedule && rp.shift_lag && !sys && n < sa.n_last && po.phi_n < 1.0 && !(rp.stop_stage > 0 && n >= rp.stop_stage) && n + 1 <= rp.max_stages;
+    (void)sys;
+    return rp.use_fixed_schedule && rp.shift_lag && n < sa.n_last && po.phi_n < 1.0 && !(rp.stop_stage > 0 && n >= rp.stop_stage) && n + 1 <= rp.max_stages;
 }
 
 // DRAW and BEGIN of the worker's stage loop (see there) as text: each instantiation of the kernel expands them at ONE place (the other is
@@ -645,7 +649,8 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
             const unsigned tag_c_ = sa.tag_base | (unsigned)(ns);                                                                               \
             ok_ = rows_two ? gather_totals_pair<2>(sa.g_mut + K3_RPAR((ns) - 1), tag_p_, sa.g_cm + K3_RPAR(ns), MCM, tag_c_, g.V, sa.to, &s_to, s_totm, s_tot, s_vt)  \
                            : gather_totals_pair(rows_direct ? sa.g_mut + K3_RPAR((ns) - 1) : sa.gt_mut + K3_TPAR((ns) - 1), tag_p_,             \
-                                                rows_direct ? sa.g_cm + K3_RPAR(ns) : sa.gt_cm + K3_TPAR(ns), MCM, tag_c_, g.V, sa.to, &s_to, s_totm, s_tot, s_vt);  \
+                                                rows_direct ? sa.g_cm + K3_RPAR(ns) : sa.gt_cm + K3_TPAR(ns), MCM, tag_c_, g.V, sa.to, &s_to, s_totm, s_tot, s_vt, sys,  \
+                                                (writer && sys) ? sa.vt_mut_out : nullptr);                                                     \
         } else {                                                                                                                                \
             ok_ = rows_two ? gather_totals<2>(sa.g_mut + K3_RPAR((ns) - 1), g.V, RMUT, RMAX_IDX, tag_p_, sa.to, &s_to, s_tot, s_vt)            \
                            : gather_totals(rows_direct ? sa.g_mut + K3_RPAR((ns) - 1) : sa.gt_mut + K3_TPAR((ns) - 1), g.V, RMUT, RMAX_IDX, tag_p_, sa.to, &s_to, s_tot, s_vt, sys,  \
@@ -653,14 +658,14 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
         }                                                                                                                                       \
         if (!ok_) { timed_out = true; ACT = -1; break; }                                                                                        \
         K3_STAMP(sa.prof, 8);                                                                                                                   \
-        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 3);                                                                                            \
+        K3_WALL(sa.gprof, PROF2_WORK + 4 * blockIdx.x + 3);                                                                                            \
         ACT = begin_stage((ns), (po_p), (RIDE && (pair)) ? s_totm : s_tot);                                                                     \
         constexpr int NWB_ = sizeof(Begin2) / sizeof(double);                                                                                   \
         if (ACT == 0 && writer && tid < NWB_) reinterpret_cast<double *>(&ctl->bg)[tid] = reinterpret_cast<const double *>(&s_a.bg)[tid];       \
         K3_STAMP(sa.prof, 9);                                                                                                                   \
     } while (0)
 #define K3_RPAR(stage) ((RIDE && ((stage) & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0)
-#define K3_TPAR(stage) K3_RPAR(stage)
+#define K3_TPAR(stage) ((RIDE && ((stage) & 1)) ? (sys ? (long long)MB_SEG_COPY_WORDS : (long long)k3_copy_words(g.Vl * g.nb2)) : 0)
 // TWO CHUNKS PER WORKER (k3_segment<D, true, RIDE, 2>) is compiled from this same kernel body in translation units of its own, which define
 // SMCMI_K3_CH2 (inst3.hip with -DSMCMI_INST3_C=2).  Everywhere else the few places where the variants differ expand to the one-chunk text of
 // round 5 - not to `if constexpr (CH == 1)` equivalents: the segment kernel's code generation is that touchy (the same kernel with the
@@ -810,20 +815,20 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         bool cm_posted = false;
         auto sweep_cm = [&](int ns) __attribute__((always_inline)) -> bool {
             const unsigned tg = sa.tag_base | (unsigned)ns;
-            const long long rp_ = (RIDE && (ns & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0, tp_ = rp_;
+            const long long rp_ = (RIDE && (ns & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0, tp_ = K3_TPAR(ns);
             return gather_vshard<T3>(sa.g_cm + rp_ + (long long)vg * g.nb2 * MCM * 2, g.nb2, MCM, -1, tg, sa.to, &s_to,
-                                     [&](int idx, double val) { post_total(sa.gt_cm + tp_, sa.off_cm, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tg); }, g_stage,
-                                     (sa.gprof && ns == sa.prof_stage) ? sa.gprof + 90 + 4 * vg : nullptr);
+                                     [&](int idx, double val) { post_total(sa.gt_cm + tp_, sa.off_cm + tp_, ((long long)(g.v0 + vg) * MCM + idx) * 2, val, tg); }, g_stage,
+                                     (sa.gprof && ns == sa.prof_stage) ? sa.gprof + PROF2_GPOLL + 4 * vg : nullptr);
         };
         for (;; ++n) {
             const unsigned tag = sa.tag_base | (unsigned)n;
-            const long long rpar = (RIDE && (n & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0, tpar = rpar;      // stage n's copy of the tables (riding launches)
+            const long long rpar = (RIDE && (n & 1)) ? (long long)k3_copy_words(g.Vl * g.nb2) : 0, tpar = K3_TPAR(n);      // stage n's copy of the tables (riding launches)
             const bool entered = sa.enter_mut && n == sa.n_first;        // (its correction totals and decision are there: the entry block above)
             if (!entered) {
-                K3_WALL(sa.gprof, 40 + 6 * vg + 0);
+                K3_WALL(sa.gprof, PROF2_GATH + 6 * vg + 0);
                 if (!cm_posted && !sweep_cm(n)) break;
-                K3_WALL(sa.gprof, 40 + 6 * vg + 1);
-                K3_WALL(sa.gprof, 40 + 6 * vg + 2);
+                K3_WALL(sa.gprof, PROF2_GATH + 6 * vg + 1);
+                K3_WALL(sa.gprof, PROF2_GATH + 6 * vg + 2);
                 // the decision every worker takes from the V totals (a stage that does not go on mutates nothing: no rows to wait for)
                 if (!gather_totals(sa.gt_cm + tpar, g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
             }
@@ -847,14 +852,14 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             }
             if (tid == 0) post2(n, s_a.bg, s_b[(n - 1) & 1].po, rp, s_tot[0], s_tot[1], ess, rs_g, &s_b[n & 1].po);
             __syncthreads();
-            K3_WALL(sa.gprof, 40 + 6 * vg + 3);
+            K3_WALL(sa.gprof, PROF2_GATH + 6 * vg + 3);
             if (!gather_vshard<T3>(sa.g_mut + rpar + (long long)vg * g.nb2 * RMUT * 2, g.nb2, RMUT, RMAX_IDX, tag, sa.to, &s_to,
-                                   [&](int idx, double val) { post_total(sa.gt_mut + tpar, sa.off_mut, ((long long)(g.v0 + vg) * RMUT + idx) * 2, val, tag); }, g_stage,
-                                   (sa.gprof && n == sa.prof_stage) ? sa.gprof + 90 + 4 * vg + 2 : nullptr)) break;
-            K3_WALL(sa.gprof, 40 + 6 * vg + 4);
+                                   [&](int idx, double val) { post_total(sa.gt_mut + tpar, sa.off_mut + tpar, ((long long)(g.v0 + vg) * RMUT + idx) * 2, val, tag); }, g_stage,
+                                   (sa.gprof && n == sa.prof_stage) ? sa.gprof + PROF2_GPOLL + 4 * vg + 2 : nullptr)) break;
+            K3_WALL(sa.gprof, PROF2_GATH + 6 * vg + 4);
             cm_posted = false;
             if (RIDE && k3_rides(rp, sa, s_b[n & 1].po, n, sys)) { if (!sweep_cm(n + 1)) break; cm_posted = true; }
-            K3_WALL(sa.gprof, 40 + 6 * vg + 5);
+            K3_WALL(sa.gprof, PROF2_GATH + 6 * vg + 5);
             if (!gather_totals(sa.gt_mut + tpar, g.V, RMUT, RMAX_IDX, tag, sa.to, &s_to, s_tot, s_vt, sys)) break;
             if (begin_stage(n + 1, s_b[n & 1].po, s_tot) != 0) break;
         }
@@ -1028,7 +1033,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             K3_CHUNKS_END
         }
         K3_STAMP(sa.prof, 2);
-        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 0);
+        K3_WALL(sa.gprof, PROF2_WORK + 4 * blockIdx.x + 0);
         if constexpr (RIDE) {
             if (!first) {
                 K3_DO_DRAW(n);
@@ -1046,7 +1051,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (!entered && !(RIDE && rides) && !(rows_two ? gather_totals<2>(sa.g_cm + K3_RPAR(n), g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt)
                                    : gather_totals(rows_direct ? sa.g_cm + K3_RPAR(n) : sa.gt_cm + K3_TPAR(n), g.V, MCM, -1, tag, sa.to, &s_to, s_tot, s_vt, sys))) { timed_out = true; break; }
         K3_STAMP(sa.prof, 3);
-        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 1);
+        K3_WALL(sa.gprof, PROF2_WORK + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
         int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
         if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
@@ -1063,7 +1068,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             for (int k = 0; k < D; ++k) stx[k * T3 + tid] = x[k];
             sto[T3 + tid] = like; sto[2 * T3 + tid] = lprior; sto[3 * T3 + tid] = like_prev; sto[4 * T3 + tid] = acc_val;
             const int bad = k3_select_inside<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, rowi, i, beg, end, tag, n, ma.seed, ma.gid0, sa.g_cm + K3_RPAR(n), sa.to, &s_to, s_tot, s_vt, s_sw,
-                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.prof + 1300 : nullptr, rows_direct, rows_two);
+                                                red, z_park, stx, sto, po.shift, (sa.prof && writer && n == sa.prof_stage) ? sa.gprof + PROF2_SEL : nullptr, rows_direct, rows_two);
             if (bad) { timed_out = true; break; }
 #pragma unroll
             for (int k = 0; k < D; ++k) x[k] = stx[k * T3 + tid];
@@ -1135,7 +1140,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_CHUNKS_END
         ++done;
         K3_STAMP(sa.prof, 6);
-        K3_WALL(sa.gprof, 128 + 4 * blockIdx.x + 2);
+        K3_WALL(sa.gprof, PROF2_WORK + 4 * blockIdx.x + 2);
         if constexpr (RIDE) rides = k3_rides(rp, sa, B.po, n, sys);             // stage n + 1's correction row goes out right behind this row?
         else {
             K3_DO_DRAW(n + 1);                                  // stage n + 1's draws, under the hand-over
