@@ -58,7 +58,8 @@ def main():
                              ess=hashlib.sha256(np.ascontiguousarray(rec["ess"]).tobytes()).hexdigest(),
                              accept=hashlib.sha256(np.ascontiguousarray(rec["accept_hist"]).tobytes()).hexdigest(),
                              stalls=[r.get("solver_stalls", 0), r.get("select_stalls", 0), r.get("spec_stalls", 0)],
-                             mailbox=bool(eng.mailbox_active()), seconds=r["seconds"]))
+                             mailbox=bool(eng.mailbox_active()), seconds=r["seconds"], segments=r.get("n_segments", 0),
+                             segment_stages=r.get("segment_stages", 0), shift_fallback_stage=r.get("shift_fallback_stage", 0)))
             if cfg.get("full_records"):
                 runs[-1]["schedule_values"] = [float(x) for x in rec["schedule"]]
         np.save(os.path.join(out, "cloud%d.npy" % rank), cloud)

@@ -102,6 +102,29 @@ def test_processes_sharing_one_gpu_reproduce_the_single_handle(world, tmp_path):
     _check(runs, cloud, want, want_cloud, expect_mailbox=True)
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_fixed_schedule_segments_across_processes_take_one_hand_over_per_stage(world, tmp_path):
+    """The reference's default schedule on sharded segments: every rank's segment kernel rides (stage n+1's correction row on stage n's
+    mutation row, the totals tables in two copies inside the mailbox allocation, csrc/stage3.hpp K3_TPAR) - the bits of one handle, and of the
+    same ranks with exact energy shifts switched on from a stage in the middle of the run (SMCMI_SHIFT_LAG=k: the fallback of an overflowing sum)."""
+    cfg = dict(n=32768, d=10, seed=9, kw=dict(use_fixed_schedule=True, n_phi=120), reps=2)
+    want, want_cloud = _single(cfg)
+    assert want["resamples"] >= 3
+    runs, cloud = _spawn(world, cfg, tmp_path)
+    _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+    for rank_runs in runs:
+        for r in rank_runs:
+            assert r["segments"] >= 1 and r["segment_stages"] >= 100, r
+            assert r["shift_fallback_stage"] == 0, r
+    if world == 2:
+        sub = tmp_path / "fb"
+        sub.mkdir()
+        want_fb, cloud_fb = _single(cfg, env_extra={"SMCMI_SHIFT_LAG": "40"})
+        runs_fb, cloud2 = _spawn(world, cfg, sub, env_extra={"SMCMI_SHIFT_LAG": "40"})
+        _check(runs_fb, cloud2, want_fb, cloud_fb, expect_mailbox=True)
+        assert all(r["shift_fallback_stage"] == 40 for rr in runs_fb for r in rr), runs_fb
+
+
 def test_large_shards_across_processes(tmp_path):
     """Two processes of 200 000 particles each - shards beyond one 512-particle block per CU run engine 2's large-shard stage
     (csrc/stage2b.hpp): the helper block of every rank's K1 launch polls the IPC-mapped mailbox for BOTH ranks' correction totals, the helper

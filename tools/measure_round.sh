@@ -27,6 +27,8 @@ python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 
 # the reference's default schedule (fixed, 300 stages) at 100 000 / 5 000 / 1 000 particles: one hand-over per stage, and with exact shifts (two)
 python tools/fixed_schedule.py > $OUT/${R}_fixed_schedule.txt 2>/dev/null
 SMCMI_SHIFT_LAG=0 python tools/fixed_schedule.py 100000 5000 >> $OUT/${R}_fixed_schedule.txt 2>/dev/null
+# ... and one rank's share of such a run on 8 GPUs (125 000 particles, sharded segments): riding / exact shifts
+bash tools/fixed_schedule_shard.sh >> $OUT/${R}_fixed_schedule.txt 2>/dev/null
 # the driver's RCCL branch as 8 ranks sharing this GPU (tests/fake_rccl): the multi-rank bench line with its pre-flight verdict
 make -C tests/fake_rccl libfake_rccl.so > /dev/null 2>&1
 HSA_ENABLE_IPC_MODE_LEGACY=0 SMCMI_BENCH_COMM=rccl_shared SMCMI_RCCL_PATH=$ROOT/tests/fake_rccl/libfake_rccl.so python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29520 \
