@@ -645,16 +645,17 @@ __device__ inline double energy_or_ninf(double like, double like_prev, double w,
 }
 
 // Largest energy of the live cloud per block -> emax_part[blockIdx.x] (run start; afterwards the mutation epilogue keeps it)
-static __global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const DevState *st, double *emax_part) {
+// (stride, buf: engine 2 takes the maxima in its mutation-row layout - rows_mut[b][RMAX_IDX] - from buffer 0)
+static __global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const DevState *st, double *emax_part, int stride = 1, int buf = -1) {
     __shared__ double smem[TB / 64];
-    const int R = cl.R, src = st->cur;
+    const int R = cl.R, src = buf >= 0 ? buf : st->cur;
     const double *loglh = col(cl, src, R - 5), *old = col(cl, src, R - 3), *w = col(cl, src, R - 1);
     long long beg, end;
     block_chunk(cl.n, gridDim.x, blockIdx.x, beg, end);
     double m = -__builtin_inf();
     for (long long i = beg + threadIdx.x; i < end; i += TB) m = fmax(m, energy_or_ninf(loglh[i], old[i], w[i], true));
     m = block_max(m, smem, TB / 64);
-    if (threadIdx.x == 0) emax_part[blockIdx.x] = m;
+    if (threadIdx.x == 0) emax_part[(long long)blockIdx.x * stride] = m;
 }
 
 template <int K, bool FINAL>
@@ -1583,15 +1584,12 @@ __device__ inline void emax_publish(const double *emax_part, int nb, double *ema
     em = block_max(em, smem, TB / 64);
     if ((int)threadIdx.x < world) emax_slots[threadIdx.x] = ((int)threadIdx.x == rank) ? fmax(em, -1e300) : 0.0;
 }
-static __global__ void __launch_bounds__(TB) k_emax_publish(const double *emax_part, int nb, double *emax_slots, int rank, int world) {
-    __shared__ double smem[TB / 64];
-    emax_publish(emax_part, nb, emax_slots, rank, world, smem);
-}
 static __global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, int nb, int m, double *out, const double *emax_part = nullptr,
                                                         int emax_nb = 0, double *emax_slots = nullptr, int rank = 0, int world = 1) {
     __shared__ double scratch[TB];
     __shared__ double smem[TB / 64];
     if (emax_part) emax_publish(emax_part, emax_nb, emax_slots, rank, world, smem);
+    if (m == 0) return;                  // (the maxima alone: the sharded driver's run start)
     if (m == 1) {
         const double tot = final_sum1(partials, nb, scratch);
         if (threadIdx.x == 0) out[0] = tot;
@@ -2975,56 +2973,46 @@ static __global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const Mo
 
 // initialize_likelihoods! (src/initialization.jl:153-186): retire loglh to old_loglh, then evaluate the (new-data) likelihood
 // and the prior at every particle.  Out-of-bounds parameters give -Inf (the reference would throw ParamBoundsError here).
-static __global__ void __launch_bounds__(TB) k_initialize_likelihoods(CloudPtrs cl, const ModelDev *md) {
-    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
-    if (i >= cl.n) return;
-    const int d = md->d;
-    double thl[MAXD];
-    for (int k = 0; k < d; ++k) thl[k] = col(cl, 0, k)[i];
-    auto TH = [&](int k) { return thl[k]; };
-    col(cl, 0, d + 2)[i] = col(cl, 0, d)[i];
-    double ll = SMCMI_NEG_INF, lp = SMCMI_NEG_INF;
-    if (in_bounds(*md, TH)) { ll = loglik(md->lik[0], d, TH); lp = logprior(*md, TH); }
-    col(cl, 0, d)[i] = ll;
-    col(cl, 0, d + 1)[i] = lp;
-}
-
-// the same for the lgss_kalman family with four lanes per particle (model.hpp kalman_lgss_quad; 64 particles per 256-thread block):
-// the values the lane-split mutation compares its proposals with come from the same filter
-static __global__ void __launch_bounds__(256, 1) k_initialize_likelihoods_ls4(CloudPtrs cl, const ModelDev *md) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int q = threadIdx.x & 3, slot_i = threadIdx.x >> 2;
-    const long long i = (long long)blockIdx.x * 64 + slot_i;
-    const bool live = i < cl.n;
-    double thl[13];
-    for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : (k >= 8 && k < 12 ? 0.5 : 0.0);
-    auto TH = [&](int k) { return thl[k]; };
-    const bool inb = live && in_bounds(*md, TH);
-    // (every lane runs the filter: its structure values travel through DPP operands)
-    const KalmanLL r = kalman_lgss_quad(thl, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux, (lds_bytes)sm + slot_i * KALMAN4_SLOT_BYTES, q);
-    if (live && q == 0) {
-        col(cl, 0, 13 + 2)[i] = col(cl, 0, 13)[i];
-        col(cl, 0, 13)[i] = inb ? r.ll : SMCMI_NEG_INF;
-        col(cl, 0, 13 + 1)[i] = inb ? logprior(*md, TH) : SMCMI_NEG_INF;
-    }
-}
-
-// ... and with one thread per particle through the filter whose structure values travel through DPP operands (kalman_lgss_wave):
-// whole wavefronts call it, lanes without a particle on ρ = 0, σ = 0.5
-static __global__ void __launch_bounds__(TB) k_initialize_likelihoods_wave(CloudPtrs cl, const ModelDev *md) {
-    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
-    const bool live = i < cl.n;
-    double thl[13];
-    for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : (k >= 8 && k < 12 ? 0.5 : 0.0);
-    auto TH = [&](int k) { return thl[k]; };
-    const bool inb = live && in_bounds(*md, TH);
-    KalmanTheta kt;
-    for (int k = 0; k < 13; ++k) kt.v[k] = thl[k];
-    const KalmanLL r = kalman_lgss_wave(kt, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux);
-    if (live) {
-        col(cl, 0, 13 + 2)[i] = col(cl, 0, 13)[i];
-        col(cl, 0, 13)[i] = inb ? r.ll : SMCMI_NEG_INF;
-        col(cl, 0, 13 + 1)[i] = inb ? logprior(*md, TH) : SMCMI_NEG_INF;
+// KIND 0: any family, one thread per particle (TB threads).  The lgss_kalman family takes the values the mutation compares its proposals
+// with from the filter the mutation runs: KIND 4 four lanes per particle (model.hpp kalman_lgss_quad; 64 particles per 256-thread block,
+// dynamic LDS 64 slots), KIND 1 one thread per particle through kalman_lgss_wave - whole wavefronts call either (their structure values
+// travel through DPP operands), lanes without a particle on rho = 0, sigma = 0.5.
+template <int KIND>
+static __global__ void __launch_bounds__(256, 1) k_initialize_likelihoods(CloudPtrs cl, const ModelDev *md) {
+    static_assert(TB == 256, "one block size for the three kinds");
+    if constexpr (KIND == 0) {
+        const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+        if (i >= cl.n) return;
+        const int d = md->d;
+        double thl[MAXD];
+        for (int k = 0; k < d; ++k) thl[k] = col(cl, 0, k)[i];
+        auto TH = [&](int k) { return thl[k]; };
+        col(cl, 0, d + 2)[i] = col(cl, 0, d)[i];
+        double ll = SMCMI_NEG_INF, lp = SMCMI_NEG_INF;
+        if (in_bounds(*md, TH)) { ll = loglik(md->lik[0], d, TH); lp = logprior(*md, TH); }
+        col(cl, 0, d)[i] = ll;
+        col(cl, 0, d + 1)[i] = lp;
+    } else {
+        extern __shared__ __attribute__((aligned(16))) double sm[];
+        const int q = threadIdx.x & 3, slot_i = threadIdx.x >> 2;
+        const long long i = KIND == 4 ? (long long)blockIdx.x * 64 + slot_i : (long long)blockIdx.x * TB + threadIdx.x;
+        const bool live = i < cl.n;
+        double thl[13];
+        for (int k = 0; k < 13; ++k) thl[k] = live ? col(cl, 0, k)[i] : (k >= 8 && k < 12 ? 0.5 : 0.0);
+        auto TH = [&](int k) { return thl[k]; };
+        const bool inb = live && in_bounds(*md, TH);
+        KalmanLL r;
+        if constexpr (KIND == 4) r = kalman_lgss_quad(thl, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux, (lds_bytes)sm + slot_i * KALMAN4_SLOT_BYTES, q);
+        else {
+            KalmanTheta kt;
+            for (int k = 0; k < 13; ++k) kt.v[k] = thl[k];
+            r = kalman_lgss_wave(kt, md->lik[0].data, md->lik[0].cols, 0, md->lik[0].aux);
+        }
+        if (live && (KIND != 4 || q == 0)) {
+            col(cl, 0, 13 + 2)[i] = col(cl, 0, 13)[i];
+            col(cl, 0, 13)[i] = inb ? r.ll : SMCMI_NEG_INF;
+            col(cl, 0, 13 + 1)[i] = inb ? logprior(*md, TH) : SMCMI_NEG_INF;
+        }
     }
 }
 

@@ -323,7 +323,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
             }
         }
         // (the run's first records ride on the import kernel: four 8-byte host copies and a stream sync less per run)
-        k2_import<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl, h->rec, cont ? 0 : 1, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target);
+        k2_state<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl, 1, h->rec, cont ? 0 : 1, rc->initial_ess > 0.0 ? rc->initial_ess : (double)h->cfg.n_parts, rc->c, rc->target);
         HIP_TRY(hipMemsetAsync(h->e2->d_tick, 0, 2 * V2_MAXV * TICK2_STRIDE * sizeof(int), h->stream));
         // random numbers drawn ahead: while K1 leaves most CUs idle (small clouds = the direct geometry with 512-thread mutation blocks)
         Eng2 *e = h->e2;
@@ -449,7 +449,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // energy maximum of the initial cloud in the mutation-row layout (stage 2's energy shift)
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        k2_energy_max<<<g0.Vl * g0.nb2, g0.t2, 0, h->stream>>>(h->cl, h->e2->g, h->e2->rows_mut);
+        k_energy_max<<<g0.Vl * g0.nb2, TB, 0, h->stream>>>(h->cl, h->d_st, h->e2->rows_mut + RMAX_IDX, RMUT, 0);   // (a maximum: the blocks need not be the rows' particles)
     }
     // (mutation rows of 256-thread blocks are paired: the canonical row stands for 512 particles, whatever the block size)
     if (int e = publish(&Eng2::rows_mut, &Eng2::vt_mut, g0.nb2, RMUT, RMAX_IDX, 0)) return e;
@@ -1038,7 +1038,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     if (h0->e2->d_prof) { if (int e = prof2_report(h0, g0, seg_launches)) return e; }
     for (auto *h : g.hs) {
         HIP_TRY(hipSetDevice(h->cfg.device));
-        k2_export<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl);
+        k2_state<<<1, 64, 0, h->stream>>>(h->d_st, h->e2->d_ctl, 0);
         if (pull_state(h)) return SMCMI_ERR_HIP;
         h->last_n_stages = h->h_st.stage;
     }

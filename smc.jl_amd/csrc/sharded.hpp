@@ -406,7 +406,7 @@ static int run_sharded_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_res
         HIP_TRY(hipSetDevice(h->cfg.device));
         const int nb0 = mut_blocks(h);
         k_energy_max<<<nb0, TB, 0, h->stream>>>(h->cl, h->d_st, h->d_emax_part);
-        k_emax_publish<<<1, TB, 0, h->stream>>>(h->d_emax_part, nb0, h->d_tot_acc + ES, shard_rank(h), g.world);
+        k_reduce_partials<<<1, TB, 0, h->stream>>>(nullptr, 0, 0, nullptr, h->d_emax_part, nb0, h->d_tot_acc + ES, shard_rank(h), g.world);
     }
     if (int rc2 = g.allreduce([](smcmi_handle *h) { return h->d_tot_acc + ES; }, g.world)) return rc2;
     } else {                                  // stage 2's begin folds "the last acceptance rate": none yet

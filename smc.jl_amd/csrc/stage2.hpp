@@ -492,25 +492,7 @@ __device__ inline void vchunk(const Geo2 &g, int vl, int r, long long per, long 
 // Engine 2 keeps its loop state in Ctl2; the C ABI's stand-alone calls, pause / continue and the result read DevState.  One
 // thread copies one into the other at the start / end of a run.
 // fresh: a new run's first records (ϕ_1 = 0, ESS, c, target acceptance: smc_main.jl:337-352) are written here, not by four host copies
-static __global__ void k2_import(const DevState *st, Ctl2 *ctl, Records rec = Records{}, int fresh = 0, double ess0 = 0.0, double c0 = 0.0, double acc0 = 0.0) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (fresh) { rec.phi[0] = 0.0; rec.ess[0] = ess0; rec.c[0] = c0; rec.accept[0] = acc0; }
-    Ctl2 c;
-    memset(&c, 0, sizeof(c));
-    Post2 &p = c.ps[st->stage & 1];
-    p.stage = st->stage; p.j = st->j; p.resampled_last = st->resampled_last; p.do_resample = 0; p.resamples = st->resamples;
-    p.fold_valid = 0;                                  // no mutation rows of this chain exist yet (fresh or continued run)
-    p.phi_n = st->phi_n; p.phi_prop = st->phi_prop; p.ess = st->ess_prev; p.sumw = st->sumw; p.sumw2 = st->sumw2;
-    p.logz = st->logz; p.c = st->c; p.accept = st->accept; p.e_center = st->e_center; p.e_shift = 0.0;
-    p.e_seen = st->e_seen;                             // (NaN on a fresh run; what k2_export left when a paused run goes on)
-    for (int a = 0; a < (int)(sizeof(p.shift) / sizeof(double)); ++a) p.shift[a] = st->shift[a];
-    c.ps[(st->stage & 1) ^ 1].stage = -1;
-    c.bg.stage = -1;
-    c.status.solver_passes = st->solver_passes;
-    *ctl = c;
-}
-static __global__ void k2_export(DevState *st, const Ctl2 *ctl) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ inline void k2_export_state(DevState *st, const Ctl2 *ctl) {
     const Post2 &p = ctl->ps[0].stage >= ctl->ps[1].stage ? ctl->ps[0] : ctl->ps[1];
     const Status2 &s = ctl->status;
     st->stage = p.stage; st->j = p.j; st->resampled_last = p.resampled_last; st->do_resample = p.do_resample; st->resamples = p.resamples;
@@ -524,19 +506,24 @@ static __global__ void k2_export(DevState *st, const Ctl2 *ctl) {
     st->done = s.code == 1 ? 1 : (s.code == 5 ? 5 : (s.code == 9 ? 1 : (s.code ? s.code : 0)));
     st->skip_fold = 0;
 }
-
-// largest energy of the live cloud per mutation block -> rows_mut[b][RMAX_IDX] (run start; afterwards the mutation epilogue)
-static __global__ void __launch_bounds__(512) k2_energy_max(CloudPtrs cl, Geo2 g, double *rows_mut) {
-    __shared__ double smem[8];
-    const int vl = blockIdx.x / g.nb2, r = blockIdx.x % g.nb2;
-    long long beg, end;
-    vchunk(g, vl, r, g.t2, beg, end);
-    const int R = cl.R;
-    const long long i = beg + threadIdx.x;
-    double m = -__builtin_inf();
-    if (i < end) m = energy_or_ninf(col(cl, 0, R - 5)[i], col(cl, 0, R - 3)[i], col(cl, 0, R - 1)[i], true);
-    m = block_max(m, smem, (int)blockDim.x / 64);
-    if (threadIdx.x == 0) rows_mut[(long long)blockIdx.x * RMUT + RMAX_IDX] = m;
+// to_ctl: DevState -> Ctl2 (a run starts); else Ctl2 -> DevState (it ends).  One kernel: the two directions are never needed in one launch
+static __global__ void k2_state(DevState *st, Ctl2 *ctl, int to_ctl, Records rec = Records{}, int fresh = 0, double ess0 = 0.0, double c0 = 0.0, double acc0 = 0.0) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!to_ctl) { k2_export_state(st, ctl); return; }
+    if (fresh) { rec.phi[0] = 0.0; rec.ess[0] = ess0; rec.c[0] = c0; rec.accept[0] = acc0; }
+    Ctl2 c;
+    memset(&c, 0, sizeof(c));
+    Post2 &p = c.ps[st->stage & 1];
+    p.stage = st->stage; p.j = st->j; p.resampled_last = st->resampled_last; p.do_resample = 0; p.resamples = st->resamples;
+    p.fold_valid = 0;                                  // no mutation rows of this chain exist yet (fresh or continued run)
+    p.phi_n = st->phi_n; p.phi_prop = st->phi_prop; p.ess = st->ess_prev; p.sumw = st->sumw; p.sumw2 = st->sumw2;
+    p.logz = st->logz; p.c = st->c; p.accept = st->accept; p.e_center = st->e_center; p.e_shift = 0.0;
+    p.e_seen = st->e_seen;                             // (NaN on a fresh run; what the export left when a paused run goes on)
+    for (int a = 0; a < (int)(sizeof(p.shift) / sizeof(double)); ++a) p.shift[a] = st->shift[a];
+    c.ps[(st->stage & 1) ^ 1].stage = -1;
+    c.bg.stage = -1;
+    c.status.solver_passes = st->solver_passes;
+    *ctl = c;
 }
 
 // ------------------------------------------------------------------------------------------------ stage begin
