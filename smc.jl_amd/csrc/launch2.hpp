@@ -98,7 +98,9 @@ void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int 
         }
         k3_segment<D, true, RIDE, 2><<<grid2, T3, lds2, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
     } else if constexpr (D <= 10) {
-    const size_t lds = k3_lds_bytes(D, k3_sel_cols(D, A1));
+    // (a gatherer stages its shard's rows in the dynamic LDS: beyond GRP rows per virtual shard - several handles with 32 769 .. 65 536
+    // particles per virtual shard - the small-n_para and the large mixture kernels' allocation would not hold them)
+    const size_t lds = std::max(k3_lds_bytes(D, k3_sel_cols(D, A1)), e->g.nb2 > GRP ? k3_gather_lds_bytes(D) : (size_t)0);
     // workers + one gatherer per virtual shard.  One handle whose virtual shards are one or two blocks (stage3.hpp rows_direct / rows_two): the
     // workers take each other's rows themselves and nobody reads a gatherer's totals - none is launched (a gatherer that nothing waits for has
     // no flow control: one stage behind, it would poll for a tag its rows have already left and raise the waits' abort word)
@@ -107,7 +109,7 @@ void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int 
     constexpr int attr_bit = (A1 ? 1 : 2) << (RIDE ? 2 : 0);
     if (!(e->seg_attr_set & attr_bit)) {       // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
-        hipFuncSetAttribute((const void *)k3_segment<D, A1, RIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((k3_lds_bytes(D, k3_sel_cols(D, A1)) + 1023) / 1024 * 1024));
+        hipFuncSetAttribute((const void *)k3_segment<D, A1, RIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((std::max(k3_lds_bytes(D, k3_sel_cols(D, A1)), k3_gather_lds_bytes(D)) + 1023) / 1024 * 1024));
         e->seg_attr_set |= attr_bit;
     }
     k3_segment<D, A1, RIDE><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);

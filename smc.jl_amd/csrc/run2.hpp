@@ -232,7 +232,8 @@ static int seg3_ready(smcmi_handle *h, bool *ok, bool two_ok = false) {
     if (ch == 2 && !two_ok) return 0;
     const int grid = g.Vl * ((g.nb2 + ch - 1) / ch) + g.Vl;
     if (e->seg_ch != ch) { e->seg_ch = ch; if (e->e3_state > 0) e->e3_state = 0; }      // (another grid: the residency self-test again)
-    if (off || !(g.direct || g.inker) || g.wide || !e->d_rec3 || g.nb1 != g.nb2 || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
+    // (a gatherer totals at most two canonical groups of rows: stage3.hpp gather_vshard)
+    if (off || !(g.direct || g.inker) || g.wide || !e->d_rec3 || g.nb1 != g.nb2 || g.nb2 > 2 * GRP || g.per1 != T3 || g.t2 != T3 || grid > n_cu || h->cfg.max_stages >= 65536) return 0;
     if (e->e3_state < 0) return 0;
     if (e->e3_state == 0) {
         int *d_ok = nullptr;

@@ -126,7 +126,7 @@ __device__ inline void gran_poll(const unsigned long long *w, unsigned tag, unsi
 // doubles), where reduce_vshard_f does its additions in the canonical order.  (Until round 5 the reduction's own units loaded the rows:
 // 144 threads with 32 loads each, two thirds of them the clamped last row - 4.9 µs per sweep against ~1 here.)  A word that was not
 // there yet repeats the sweep (rows arrive within a fraction of a µs of each other).  false: timed out.
-// post(idx, total): called by the thread that ends up with total idx (two columns per thread).  nr <= GRP: ONE canonical group, i.e.
+// post(idx, total): called by the thread that ends up with total idx (two columns per thread).  nr <= 2 GRP; per canonical group of GRP rows
 // reduce_vshard_f's arithmetic (slices 2h, 2h+1 in ascending row order, the tree across the quad, 0 + group) without its hand-over of the
 // group totals through LDS and the two barriers around it.
 template <int NT, class POST>
@@ -177,26 +177,39 @@ __device__ inline bool gather_vshard(const unsigned long long *tbl, int nr, int 
         const int h = u & 3, pr = u >> 2;
         const bool mx0 = 2 * pr == max_idx, mx1 = 2 * pr + 1 == max_idx;
         const double ninf = -__builtin_inf(), id0 = mx0 ? ninf : 0.0, id1 = mx1 ? ninf : 0.0;
-        double a0[2] = {id0, id0}, a1[2] = {id1, id1};
+        // one canonical group of rows [r_beg, r_end): slices 2h, 2h+1 in ascending row order, the tree across the quad
+        auto group = [&](int r_beg, int r_end, double &p0, double &p1) __attribute__((always_inline)) {
+            double a0[2] = {id0, id0}, a1[2] = {id1, id1};
 #pragma unroll
-        for (int j = 0; j < GRP / 8; ++j) {
+            for (int j = 0; j < GRP / 8; ++j) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = 2 * h + q + 8 * j;
-                const double2 x = reinterpret_cast<const double2 *>(stage + (r < nr ? r : nr - 1) * m)[pr];
-                const double x0 = r < nr ? x.x : id0, x1 = r < nr ? x.y : id1;
-                a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
-                a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
+                for (int q = 0; q < 2; ++q) {
+                    const int r = r_beg + 2 * h + q + 8 * j;
+                    const double2 x = reinterpret_cast<const double2 *>(stage + (r < r_end ? r : r_end - 1) * m)[pr];
+                    const double x0 = r < r_end ? x.x : id0, x1 = r < r_end ? x.y : id1;
+                    a0[q] = mx0 ? fmax(a0[q], x0) : a0[q] + x0;
+                    a1[q] = mx1 ? fmax(a1[q], x1) : a1[q] + x1;
+                }
             }
+            p0 = mx0 ? fmax(a0[0], a0[1]) : a0[0] + a0[1]; p1 = mx1 ? fmax(a1[0], a1[1]) : a1[0] + a1[1];
+            const double q0 = fetch_xor<1>(p0), q1 = fetch_xor<1>(p1);
+            p0 = mx0 ? fmax(p0, q0) : p0 + q0; p1 = mx1 ? fmax(p1, q1) : p1 + q1;
+            const double r0 = fetch_xor<2>(p0), r1 = fetch_xor<2>(p1);
+            p0 = mx0 ? fmax(p0, r0) : p0 + r0; p1 = mx1 ? fmax(p1, r1) : p1 + r1;
+        };
+        double p0, p1;
+        group(0, nr < GRP ? nr : GRP, p0, p1);
+        double run0 = mx0 ? fmax(ninf, p0) : 0.0 + p0, run1 = mx1 ? fmax(ninf, p1) : 0.0 + p1;
+        // (a shard of more than GRP rows - several handles with 32 769 .. 65 536 particles per virtual shard - is two canonical groups, added to
+        // 0 in ascending order like reduce_vshard_f's: until round 6 the rows beyond the first group were silently left out.  A branch of its
+        // own: as a loop over the groups it cost the one-group sweep of the headline 0.4 µs per stage)
+        if (__builtin_expect(nr > GRP, 0)) {
+            group(GRP, nr, p0, p1);
+            run0 = mx0 ? fmax(run0, p0) : run0 + p0; run1 = mx1 ? fmax(run1, p1) : run1 + p1;
         }
-        double p0 = mx0 ? fmax(a0[0], a0[1]) : a0[0] + a0[1], p1 = mx1 ? fmax(a1[0], a1[1]) : a1[0] + a1[1];
-        const double q0 = fetch_xor<1>(p0), q1 = fetch_xor<1>(p1);
-        p0 = mx0 ? fmax(p0, q0) : p0 + q0; p1 = mx1 ? fmax(p1, q1) : p1 + q1;
-        const double r0 = fetch_xor<2>(p0), r1 = fetch_xor<2>(p1);
-        p0 = mx0 ? fmax(p0, r0) : p0 + r0; p1 = mx1 ? fmax(p1, r1) : p1 + r1;
         if (h == 0) {
-            post(2 * pr, mx0 ? fmax(ninf, p0) : 0.0 + p0);
-            post(2 * pr + 1, mx1 ? fmax(ninf, p1) : 0.0 + p1);
+            post(2 * pr, run0);
+            post(2 * pr + 1, run1);
         }
     }
     return true;
@@ -393,6 +406,11 @@ static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned lo
     if (threadIdx.x == 0 && good && s_w[0] == 0x5e6u) atomicAdd(ok, 1);
 }
 
+// dynamic LDS a gatherer needs for the rows of its virtual shard (at most 2 GRP = 128 of them, 72 or RMUT columns)
+constexpr size_t k3_gather_lds_bytes(int D) {
+    const size_t npf = (size_t)(D + 1) * (D + 2) / 2 + 2, mcm = npf + (npf & 1);
+    return (size_t)2 * GRP * (mcm > (size_t)RMUT ? mcm : (size_t)RMUT) * sizeof(double);
+}
 constexpr size_t k3_park_offset(int D) { return (k2_lds_bytes(D) + 15) / 16 * 2; }          // in doubles, 16-byte aligned
 // (k2's arrays | the parking area (D + 2) T3 | the particle in transit through an in-place selection: (D + 5) T3, see k3_sel_cols)
 constexpr size_t k3_lds_bytes(int D, int sel_cols = 0) {
@@ -808,7 +826,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     if (!worker) {
         // ================================================================ GATHERER of local virtual shard vg
         const int vg = (int)blockIdx.x - W;
-        static_assert(k3_lds_bytes(D) / sizeof(double) >= (size_t)GRP * (MCM > RMUT ? MCM : RMUT), "the gatherer stages a shard's rows (<= GRP of them) in the dynamic LDS");
+        // (the gatherer stages a shard's rows - at most 2 GRP of them - in the dynamic LDS: launch2.hpp launch_k3_seg sizes it, k3_gather_lds_bytes)
         double *g_stage = sm;                                    // (a gatherer uses none of the workers' dynamic LDS: model constants, proposal, parked draws)
         // (one hand-over per stage, see the workers: a stage whose correction rows ride the mutation rows in front of it has them swept and posted
         // BEFORE this block takes the mutation totals and runs the begin - the workers wait for the correction totals, nothing else)

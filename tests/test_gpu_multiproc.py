@@ -125,6 +125,18 @@ def test_fixed_schedule_segments_across_processes_take_one_hand_over_per_stage(w
         assert all(r["shift_fallback_stage"] == 40 for rr in runs_fb for r in rr), runs_fb
 
 
+@pytest.mark.parametrize("n", [66002, 130046])
+def test_sharded_segments_total_virtual_shards_of_more_than_64_rows(n, tmp_path):
+    """2 x odd particles: two virtual shards of 65 / 127 rows - what a rank of an 8-GPU run of 260 000 .. 520 000 particles holds.  The
+    gatherer of such a shard totals TWO canonical groups of rows (csrc/stage3.hpp gather_vshard; until round 6 it left the second one out:
+    wrong totals, found by this configuration).  One rank with the mailbox forced on - the only way such a shard's workers fit one GPU."""
+    cfg = dict(n=n, d=10, seed=7, kw=dict(use_fixed_schedule=False, tempering_target=0.95), reps=1)
+    want, want_cloud = _single(cfg)
+    runs, cloud = _spawn(1, cfg, tmp_path, env_extra={"SMCMI_MAILBOX": "2"})
+    _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+    assert runs[0][0]["segments"] >= 1 and runs[0][0]["segment_stages"] >= want["n_stages"] // 2, runs[0][0]
+
+
 def test_large_shards_across_processes(tmp_path):
     """Two processes of 200 000 particles each - shards beyond one 512-particle block per CU run engine 2's large-shard stage
     (csrc/stage2b.hpp): the helper block of every rank's K1 launch polls the IPC-mapped mailbox for BOTH ranks' correction totals, the helper
