@@ -12,12 +12,19 @@ static int mbox_reset_flag(smcmi_handle *h, hipStream_t s) {
     else HIP_TRY(hipMemcpy(h->d_mbox + MB_WORDS, fl, sizeof(fl), hipMemcpyHostToDevice));
     return 0;
 }
+// words behind the tables for the selection inside sharded segments (stage2.hpp MB_SEL_OFF): only handles whose shard can run segments
+// (n_para <= 10, at most 131 072 particles); every handle of a run has the same (N, n, n_para), hence the same layout
+static size_t mbox_sel_words(const smcmi_handle *h) {
+    if (h->d > 10 || h->n > 131072) return 0;
+    return (size_t)MB_SEL_TABLE_WORDS + (size_t)h->cfg.n_parts + (size_t)(h->d + 4) * (size_t)h->n;
+}
 static int mbox_alloc(smcmi_handle *h) {
     if (h->d_mbox) return 0;
     HIP_TRY(hipSetDevice(h->cfg.device));
     // fine-grained: stores from a peer GPU and this GPU's polling loads meet in memory, not in a die's L2
-    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * MB_ALLOC_WORDS, hipDeviceMallocFinegrained));
-    HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * MB_ALLOC_WORDS));
+    const size_t words = (size_t)MB_ALLOC_WORDS + mbox_sel_words(h);
+    HIP_TRY(hipExtMallocWithFlags((void **)&h->d_mbox, sizeof(unsigned long long) * words, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(h->d_mbox, 0xFF, sizeof(unsigned long long) * words));
     if (int e = mbox_reset_flag(h, nullptr)) return e;
     HIP_TRY(hipDeviceSynchronize());              // (null-stream fill: not ordered with the handle's non-blocking stream)
     return 0;

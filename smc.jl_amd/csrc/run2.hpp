@@ -486,9 +486,17 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     static const int sel_in_env = getenv("SMCMI_SEG_SELECT") ? atoi(getenv("SMCMI_SEG_SELECT")) : 1;      // development: 0 = the segment leaves, selection as launches
     // (the workers' blocks must be the selection kernels' blocks: one 512-slot tile per moment row - not so when a cloud is cut into 2 or 4
     // long virtual shards of more than 32 rows, whose gather blocks take two tiles each)
-    const bool sel_inside = e3 && !seg_sys && g.hs.size() == 1 && d <= 10 && h0->e2->seg_ch == 1 && sel_in_env != 0 && h0->d_cum != nullptr && g0.nbg == g0.nb2 && g0.perg == T3 &&
-                            g0.V * g0.nb1 <= 256;
-    if (sel_inside) {
+    // Several handles (sharded segments): the same, with what the handles exchange - chunk sums, the cum column, the ancestors' rows - in the
+    // mailbox allocation every peer has mapped (stage3.hpp Sel3Args, mailbox.hpp mbox_sel_words); the worker's scratch holds up to 1 024 chunk
+    // sums / chunk ends there (n_para >= 3 at that size)
+    const int sel_ncg = (int)((g0.N + SEL_GCH - 1) / SEL_GCH), sel_nch = g0.V * g0.nb1;
+    const bool sel_one = !seg_sys && g.hs.size() == 1 && h0->d_cum != nullptr && sel_nch <= 256;
+    const bool sel_sys = seg_sys && mbox_sel_words(h0) > 0 && sel_ncg <= 1024 && 16 + 2 * sel_nch + 256 <= (d + 2) * T3 && 16 + sel_ncg + 2 * SEL_GCH <= (d + 2) * T3;
+    const bool sel_inside = e3 && (sel_one || sel_sys) && d <= 10 && h0->e2->seg_ch == 1 && sel_in_env != 0 && g0.nbg == g0.nb2 && g0.perg == T3;
+    if (sel_inside)
+      for (auto *hh : g.hs) {
+        smcmi_handle *h0 = hh;                                     // (shadows: one Sel3Args per handle)
+        HIP_TRY(hipSetDevice(h0->cfg.device));
         Eng2 *e = h0->e2;
         const size_t nblk = (size_t)e->g.Vl * e->g.nb2;
         Sel3Args &sl = e->h_sel3;                                  // (a member: the copy needs no sync)
@@ -500,8 +508,16 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         }
         sl.g_sel = e->d_gran3 + nblk * (72 + RMUT) * 2 + (size_t)V2_MAXV * (72 + RMUT) * 2; sl.gt_sel = sl.g_sel + nblk * 2 * 2;
         sl.g_gm = sl.gt_sel + (size_t)V2_MAXV * 2 * 2; sl.gt_gm = sl.g_gm + nblk * 72 * 2;
+        if (sel_sys) {
+            sl.peers = h0->d_peers; sl.mine = h0->d_mbox; sl.world = g.world; sl.chunk0 = e->g.v0 * e->g.nb1; sl.n_loc = h0->n;
+            sl.off_cs = MB_SEL_OFF; sl.off_sel = sl.off_cs + MB_SEL_CS_WORDS; sl.off_gm = sl.off_sel + MB_SEL_T_WORDS;
+            sl.off_cum = MB_SEL_OFF + MB_SEL_TABLE_WORDS; sl.off_rows = sl.off_cum + h0->cfg.n_parts;
+            sl.cum = nullptr;
+            // (tags restart with every run of sharded segments: the tables the peers post into start cleared, like the segments' own below)
+            HIP_TRY(hipMemsetAsync(h0->d_mbox + MB_SEL_OFF, 0xFF, sizeof(unsigned long long) * MB_SEL_TABLE_WORDS, h0->stream));
+        }
         HIP_TRY(hipMemcpyAsync(e->d_sel3, &sl, sizeof(sl), hipMemcpyHostToDevice, h0->stream));
-    }
+      }
     // (the note outlives a run and sequence numbers start over - sharded segments reset them, 65 535 launches wrap them: a note left by an
     // earlier run must never equal the number a launch of this run is waited for under.  Every run ends with its stream drained, so nothing
     // is in flight that could still write the word)

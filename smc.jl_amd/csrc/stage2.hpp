@@ -111,6 +111,10 @@ constexpr int MB_SEG_OFF = MB_WORDS + MB_FLAG_WORDS;
 constexpr int MB_SEG_KIND_WORDS = V2_MAXV * MB_LD * 2;
 constexpr int MB_SEG_COPY_WORDS = 2 * MB_SEG_KIND_WORDS;        // both kinds; a riding launch uses two copies by stage parity (stage3.hpp Seg3Args)
 constexpr int MB_ALLOC_WORDS = MB_SEG_OFF + 2 * MB_SEG_COPY_WORDS;
+// behind them, in handles small enough for segments (mailbox.hpp mbox_sel_words): what a selection INSIDE sharded segments exchanges (stage3.hpp
+// Sel3Args) - three tables of granules, then the whole cloud's cum column [N] and this handle's rows [(n_para + 4)][n] as plain doubles
+constexpr long long MB_SEL_CS_WORDS = 1024 * 2, MB_SEL_T_WORDS = V2_MAXV * 2 * 2, MB_SEL_GM_WORDS = V2_MAXV * 72 * 2;
+constexpr long long MB_SEL_OFF = MB_ALLOC_WORDS, MB_SEL_TABLE_WORDS = MB_SEL_CS_WORDS + MB_SEL_T_WORDS + MB_SEL_GM_WORDS;
 __device__ inline void mb_store(unsigned long long *w, double v, unsigned tag) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -442,6 +442,16 @@ struct Sel3Args {
     unsigned long long *g_gm, *gt_gm;     // moment rows of the resampled cloud: [blocks][72 * 2] / [V2_MAXV][72 * 2]
     double *transit;               // [blocks][(D + 5) * T3]: where a worker parks its particle during the selection when the kernel's LDS has no room
                                    // for it (k3_sel_cols = 0: mixture proposals beyond n_para 7); null otherwise
+    // several handles (selection inside SHARDED segments): what the handles exchange lives in every handle's mailbox allocation - fine-grained
+    // memory every peer has mapped - at the same word offsets (run2.hpp sel3_area): tables of granules the peers POST into (every worker its
+    // chunk sum, every gatherer its shard's totals), the whole cloud's cum column (every worker writes its 512 values into every handle's copy),
+    // and this handle's particles as the stage found them, which the peers READ their ancestors' rows from
+    unsigned long long *const *peers;     // null: one handle
+    unsigned long long *mine;      // this handle's allocation
+    int world, chunk0;             // chunk0: global index of this handle's first chunk (v0 * nb1)
+    long long n_loc;               // particles per handle
+    long long off_cs, off_sel, off_gm;    // granules: chunk sums [V nb1], "written" totals [V2_MAXV][2], moment totals [V2_MAXV][72]
+    long long off_cum, off_rows;   // doubles: cum [N], rows [(D + 4)][n_loc]
 };
 struct Seg3Args {
     int n_first, n_last;           // stages this launch may run
@@ -544,71 +554,120 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     const Sel3Args sl = *selp;
     const int tid = threadIdx.x;
     const bool live = i < end;
-    double *s_cs = sc, *s_scr = sc + 256, *s_off = sc + 512, *s_w = sc + 768, *s_ce = sc + 776, *s_cw = sc + 1034;
-    long long *s_r = reinterpret_cast<long long *>(sc + 1032);
-    const int cap_w = (D + 2) * T3 - 1034;
-    const __amdgpu_buffer_rsrc_t cl_rsrc = rows_rsrc(buf0, (long long)cl_R * cl_n * 8);
-    const __amdgpu_buffer_rsrc_t cum_rsrc = rows_rsrc(sl.cum, Ng * 8);
+    const bool sys = sl.peers != nullptr;                       // several handles: see Sel3Args
+    // scratch: the tile scan's and the search's few words in front; the chunk sums and offsets (phases 2-3) under the chunk ends and the
+    // staged cum values (phases 5-6).  Up to 1 024 chunks / chunk ends (several handles; one handle has at most 248)
+    double *s_w = sc, *s_cs = sc + 16, *s_scr = s_cs + nchunks, *s_off = s_scr + 256, *s_ce = sc + 16;
+    long long *s_r = reinterpret_cast<long long *>(sc + 8);
+    const int ncg = (int)((Ng + SEL_GCH - 1) / SEL_GCH);
+    double *s_cw = s_ce + ncg;
+    const int cap_w = (D + 2) * T3 - 16 - ncg;
+    double *rows = sys ? reinterpret_cast<double *>(sl.mine + sl.off_rows) : buf0;
+    const long long rows_n = sys ? sl.n_loc : cl_n;
+    double *cum = sys ? reinterpret_cast<double *>(sl.mine + sl.off_cum) : sl.cum;
+    const __amdgpu_buffer_rsrc_t cl_rsrc = rows_rsrc(rows, (long long)(sys ? D + 4 : cl_R) * rows_n * 8);
+    const __amdgpu_buffer_rsrc_t cum_rsrc = rows_rsrc(cum, Ng * 8);
     __syncthreads();
-    // (1) my particle as stage n - 1 left it -> buffer 0, agent scope (other dies read it below)
+    // (1) my particle as stage n - 1 left it -> buffer 0 (several handles: my rows of the exchange area), other dies / handles read it below
     if (live) {
 #pragma unroll
-        for (int k = 0; k < D + 4; ++k) row_store(buf0 + (long long)k * cl_n + i, k < D ? stx[k * T3 + tid] : sto[(1 + k - D) * T3 + tid], true);
+        for (int k = 0; k < D + 4; ++k) {
+            const double val = k < D ? stx[k * T3 + tid] : sto[(1 + k - D) * T3 + tid];
+            if (sys) __hip_atomic_store(rows + (long long)k * rows_n + i, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else row_store(rows + (long long)k * rows_n + i, val, true);
+        }
     }
     K3S(0);
-    // (2) the chunk sums = entry 0 of every block's correction row (published under this stage's tag) -> chunk offsets
-    if (tid < nchunks) {
-        const unsigned long long *wd = g_cm + (long long)tid * MCM * 2;
-        gran_poll(wd, tag, to, s_to);
-        gran_poll(wd + 1, tag, to, s_to);
+    // (2) the chunk sums = entry 0 of every block's correction row (published under this stage's tag) -> chunk offsets.  Several handles:
+    // every worker posts its own into every handle's table first
+    if (sys && tid < sl.world) {
+        const unsigned long long *wd = g_cm + (long long)rowi * MCM * 2;
         const unsigned long long w0 = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w1 = __hip_atomic_load(wd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_cs[tid] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        gran_store_sys(sl.peers[tid] + sl.off_cs + (long long)(sl.chunk0 + rowi) * 2, __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0), tag);
+    }
+    for (int c = tid; c < nchunks; c += T3) {
+        const unsigned long long *wd = sys ? sl.mine + sl.off_cs + (long long)c * 2 : g_cm + (long long)c * MCM * 2;
+        gran_poll(wd, tag, to, s_to, sys);
+        gran_poll(wd + 1, tag, to, s_to, sys);
+        const unsigned long long w0 = sys ? __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w1 = sys ? __hip_atomic_load(wd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(wd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cs[c] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
     }
     __syncthreads();
     if (*s_to) return 1;
     sel_chunk_offsets([&](int b) { return s_cs[b]; }, nchunks, s_scr, s_off);
     K3S(1);
-    // (3) the cum values of my chunk (k2_scan's arithmetic on W̃)
+    // (3) the cum values of my chunk (k2_scan's arithmetic on W̃); several handles: into every handle's copy of the column
     {
         double tt;
         const double incl = sel_tile_scan(live ? sto[tid] : 0.0, s_w, &tt);
-        if (live) row_store(sl.cum + i, (s_off[rowi] + incl) / s_tot[0], true);
+        const double cv = (s_off[(sys ? sl.chunk0 : 0) + rowi] + incl) / s_tot[0];
+        if (live) {
+            if (sys) {
+                for (int pr = 0; pr < sl.world; ++pr)
+                    __hip_atomic_store(reinterpret_cast<double *>(sl.peers[pr] + sl.off_cum) + gid0 + i, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else row_store(cum + i, cv, true);
+        }
     }
     K3S(2);
     // (4) hand-over: every store above is acknowledged before this block says so
+    // (several handles: the rows and cum values went out as system-scope stores into fine-grained memory - written through, acknowledged by the
+    // memory that holds them; a system-scope FENCE here would write back the die's whole L2 first: measured 20 µs)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     K3S(3);
     if (tid < 2) gran_store(sl.g_sel + ((long long)rowi * 2 + tid) * 2, 0.0, tag);
     if (!(rows_two ? gather_totals<2>(sl.g_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt)
-                   : gather_totals(rows_direct ? sl.g_sel : sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false))) return 1;
+                   : gather_totals(sys ? sl.mine + sl.off_sel : (rows_direct ? sl.g_sel : sl.gt_sel), V, 2, -1, tag, to, s_to, s_sw, s_vt, sys))) return 1;
     K3S(4);
     // (5) ancestors of my output slots
     double u_sys = 0.0, ub_;
     if (sl.method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub_);
     auto ldcum = [&](long long j) { return load_f64_sc1(cum_rsrc, (unsigned)j * 8u); };
-    const int ncg = (int)((Ng + SEL_GCH - 1) / SEL_GCH);
-    const bool staged = sl.method != SMCMI_RESAMPLE_MULTINOMIAL && ncg <= 256;
+    const bool staged = sl.method != SMCMI_RESAMPLE_MULTINOMIAL && ncg <= 1024 && cap_w >= 2 * SEL_GCH;
     if (staged) sel_chunk_ends(ldcum, 0, Ng, ncg, s_ce);
     K3S(5);
     const long long slot = gid0 + (live ? i : (end > beg ? end - 1 : 0));
     const double ua = sel_threshold(sl.method, seed, slot, n, u_sys, Ng);
     const long long anc_i = (end > beg) ? sel_search_tile(ua, staged, ncg, s_ce, s_cw, s_r, ldcum, 0, Ng, cap_w) : 0;
     K3S(6);
-    // (6) the ancestor's row becomes my particle
+    // (6) the ancestor's row becomes my particle (several handles: out of the rows of the handle that holds it - one buffer descriptor per
+    // handle some lane of the wavefront reads from; a tile's ancestors are consecutive rows, so that is one handle, two at a boundary)
     double xx[DAm];
     xx[0] = 1.0;
 #pragma unroll
     for (int q = 0; q < D; ++q) xx[q + 1] = 0.0;
-    if (live) {
-        if (sl.anc) sl.anc[i] = anc_i;
+    {
+        if (live && sl.anc) sl.anc[i] = anc_i;
         double row[D + 4];
 #pragma unroll
-        for (int q = 0; q < D + 4; ++q) row[q] = load_f64_sc1(cl_rsrc, (unsigned)(((long long)q * cl_n + anc_i) * 8));
+        for (int q = 0; q < D + 4; ++q) row[q] = 0.0;
+        if (!sys) {
+            if (live) {
 #pragma unroll
-        for (int q = 0; q < D + 4; ++q) { if (q < D) stx[q * T3 + tid] = row[q]; else sto[(1 + q - D) * T3 + tid] = row[q]; }
+                for (int q = 0; q < D + 4; ++q) row[q] = load_f64_sc1(cl_rsrc, (unsigned)(((long long)q * cl_n + anc_i) * 8));
+            }
+        } else {
+            const int ar = live ? (int)(anc_i / sl.n_loc) : -1;
+            const long long al = anc_i - (long long)ar * sl.n_loc;
+            for (int pr = 0; pr < sl.world; ++pr) {
+                if (!__any(ar == pr)) continue;                                   // (wave-uniform)
+                const __amdgpu_buffer_rsrc_t pr_rsrc = rows_rsrc(reinterpret_cast<const double *>(sl.peers[pr] + sl.off_rows), (long long)(D + 4) * sl.n_loc * 8);
+                if (ar == pr) {
 #pragma unroll
-        for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - shift[q];
+                    for (int q = 0; q < D + 4; ++q) {
+                        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(pr_rsrc, (int)(((long long)q * sl.n_loc + al) * 8), 0, /*sc0 sc1: system scope*/ 17);
+                        row[q] = __hiloint2double((int)v.y, (int)v.x);
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < D + 4; ++q) { if (q < D) stx[q * T3 + tid] = row[q]; else sto[(1 + q - D) * T3 + tid] = row[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) xx[q + 1] = row[q] - shift[q];
+        }
     }
     K3S(7);
     // (7) the moment row of my block (pair sums x̃_a x̃_b about the shift, all weights 1: 0 + x̃_a x̃_b is the accumulator k2_gather holds for a
@@ -629,7 +688,7 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
     if (tid >= NPm && tid < MGM) gran_store(my_gm + tid * 2, 0.0, tag);
     K3S(8);
     if (!(rows_two ? gather_totals<2>(sl.g_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt)
-                   : gather_totals(rows_direct ? sl.g_gm : sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false))) return 1;
+                   : gather_totals(sys ? sl.mine + sl.off_gm : (rows_direct ? sl.g_gm : sl.gt_gm), V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, sys))) return 1;
     K3S(9);
     return 0;
 #undef K3S
@@ -859,12 +918,18 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
                     // SELECTION inside the segment (the workers' side is below): "everything is written", then the moment rows of the resampled cloud
                     constexpr int MGM = pad2(Mut2Lds<D>::NP);
                     const Sel3Args sl = *sa.sel;
+                    // (several handles: the totals go into every handle's tables, Sel3Args)
+                    auto post_sel = [&](unsigned long long *mine_t, long long off, long long w, double val) {
+                        if (sl.peers) { for (int pr = 0; pr < sl.world; ++pr) gran_store_sys(sl.peers[pr] + off + w, val, tag); }
+                        else gran_store(mine_t + w, val, tag);
+                    };
+                    const bool ssys = sl.peers != nullptr;
                     if (!gather_vshard<T3>(sl.g_sel + (long long)vg * g.nb2 * 2 * 2, g.nb2, 2, -1, tag, sa.to, &s_to,
-                                           [&](int idx, double val) { gran_store(sl.gt_sel + ((long long)(g.v0 + vg) * 2 + idx) * 2, val, tag); }, g_stage)) break;
-                    if (!gather_totals(sl.gt_sel, g.V, 2, -1, tag, sa.to, &s_to, s_sw, s_vt, false)) break;
+                                           [&](int idx, double val) { post_sel(sl.gt_sel, sl.off_sel, ((long long)(g.v0 + vg) * 2 + idx) * 2, val); }, g_stage)) break;
+                    if (!gather_totals(ssys ? sl.mine + sl.off_sel : sl.gt_sel, g.V, 2, -1, tag, sa.to, &s_to, s_sw, s_vt, ssys)) break;
                     if (!gather_vshard<T3>(sl.g_gm + (long long)vg * g.nb2 * MGM * 2, g.nb2, MGM, -1, tag, sa.to, &s_to,
-                                           [&](int idx, double val) { gran_store(sl.gt_gm + ((long long)(g.v0 + vg) * MGM + idx) * 2, val, tag); }, g_stage)) break;
-                    if (!gather_totals(sl.gt_gm, g.V, MGM, -1, tag, sa.to, &s_to, s_tot + 2, s_vt, false)) break;
+                                           [&](int idx, double val) { post_sel(sl.gt_gm, sl.off_gm, ((long long)(g.v0 + vg) * MGM + idx) * 2, val); }, g_stage)) break;
+                    if (!gather_totals(ssys ? sl.mine + sl.off_gm : sl.gt_gm, g.V, MGM, -1, tag, sa.to, &s_to, s_tot + 2, s_vt, ssys)) break;
                     rs_g = 1;
                 } else if (dec != 0) break;
             }

@@ -35,17 +35,22 @@ def _logs(log_dir, world):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_rccl_branch_as_processes_on_one_gpu_reproduces_the_single_handle(world, tmp_path, fake_env):
+@pytest.mark.parametrize("world,inside", [(2, True), (2, False), (4, False), (8, True), (8, False)])
+def test_rccl_branch_as_processes_on_one_gpu_reproduces_the_single_handle(world, inside, tmp_path, fake_env):
     """Adaptive schedule with resample stages, two runs per handle: the mailbox is mapped through ncclAllGather and agreed on through
-    ncclAllReduce, the stages run inside sharded segments, resample stages exchange rows through ncclSend / ncclRecv groups - at world = 8
-    the size the target node has (8 x 4 096 particles: one virtual shard per rank)."""
+    ncclAllReduce, the stages run inside sharded segments - at world = 8 the size the target node has (8 x 4 096 particles: one virtual shard
+    per rank).  inside: the resample stages stay inside the segments as well (chunk sums, cum column and ancestors' rows through the mailbox
+    allocation: csrc/stage3.hpp Sel3Args) - no collective call between the first and the last stage; else (SMCMI_SEG_SELECT=0) the segments
+    leave at them and the rows travel through ncclSend / ncclRecv groups."""
     cfg = dict(n=32768, d=10, seed=7, comm="rccl", kw=dict(use_fixed_schedule=False, tempering_target=0.95), reps=2)
     want, want_cloud = _single(cfg)
     assert want["resamples"] >= 3
     log_dir = tmp_path / "log"
     log_dir.mkdir()
-    runs, cloud = _spawn(world, cfg, tmp_path, env_extra=dict(fake_env, SMCMI_FAKE_RCCL_LOG=str(log_dir)))
+    extra = dict(fake_env, SMCMI_FAKE_RCCL_LOG=str(log_dir))
+    if not inside:
+        extra["SMCMI_SEG_SELECT"] = "0"
+    runs, cloud = _spawn(world, cfg, tmp_path, env_extra=extra)
     _check(runs, cloud, want, want_cloud, expect_mailbox=True)
     # the call sequence: the same collectives with the same counts in the same order on every rank; every group's sends are received
     logs = _logs(str(log_dir), world)
@@ -53,6 +58,12 @@ def test_rccl_branch_as_processes_on_one_gpu_reproduces_the_single_handle(world,
     assert all(s == seq[0] for s in seq), "ranks posted different collective sequences"
     groups = [[ln for ln in lg if ln[0] == "group"] for lg in logs]
     assert all(len(g) == len(groups[0]) for g in groups)
+    if inside:
+        assert len(groups[0]) == 0                                       # no row exchange by collectives: the selection ran inside the segments
+        for rank_runs in runs:
+            for r in rank_runs:
+                assert r["segments"] <= 4 and r["segment_stages"] >= want["n_stages"] - 4, r
+        return
     assert len(groups[0]) >= 2 * want["resamples"]                       # one group per resample stage and run (reps = 2)
     for k in range(len(groups[0])):
         sent = sum(int(g[k][3].split("=")[1]) for g in groups)
@@ -61,10 +72,11 @@ def test_rccl_branch_as_processes_on_one_gpu_reproduces_the_single_handle(world,
     assert any(int(g[k][3].split("=")[1]) > 0 for g in groups for k in range(len(g)))      # rows did cross ranks
 
 
-@pytest.mark.parametrize("method,env", [("systematic", {"SMCMI_MAILBOX": "0"}), ("multinomial", {"SMCMI_MAILBOX": "0"}), ("systematic", {})])
+@pytest.mark.parametrize("method,env", [("systematic", {"SMCMI_MAILBOX": "0"}), ("multinomial", {"SMCMI_MAILBOX": "0"}), ("systematic", {}), ("multinomial", {})])
 def test_rccl_branch_fixed_schedule_both_resamplers_both_transports(method, env, tmp_path, fake_env):
     """Fixed schedule (the reference's default), two MH steps; hand-overs as ncclAllGather (SMCMI_MAILBOX=0) or through the mailbox; rows by
-    send / recv groups (systematic) or by all-gathers of weights and clouds (multinomial).  Four ranks."""
+    send / recv groups (systematic) or by all-gathers of weights and clouds (multinomial) - with the mailbox the stages run as sharded segments
+    and either resampler selects inside them.  Four ranks."""
     cfg = dict(n=16384, d=10, seed=11, comm="rccl", kw=dict(use_fixed_schedule=True, n_phi=40, n_mh_steps=2, resampling_method=method))
     want, want_cloud = _single(cfg)
     assert want["resamples"] >= 1

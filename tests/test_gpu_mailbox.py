@@ -98,6 +98,7 @@ def _group(world, kw, env):
 @pytest.mark.parametrize("kw,extra", [
     (dict(use_fixed_schedule=False, tempering_target=0.95, n_blocks=2, alpha=0.9), {}),
     (dict(use_fixed_schedule=True, n_phi=60, n_mh_steps=2), {}),
+    (dict(use_fixed_schedule=False, tempering_target=0.9, resampling_method="multinomial"), {}),
     # every stage's selection is left out on purpose: each resample stage stalls and is resumed (tags rewound, fresh tags posted)
     (dict(use_fixed_schedule=False, tempering_target=0.95), {"SMCMI_NO_SELECT_PREDICT": "2"}),
 ])

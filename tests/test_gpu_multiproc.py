@@ -100,6 +100,10 @@ def test_processes_sharing_one_gpu_reproduce_the_single_handle(world, tmp_path):
     assert want["resamples"] >= 3
     runs, cloud = _spawn(world, cfg, tmp_path)
     _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+    # the resample stages stay inside the sharded segments (csrc/stage3.hpp Sel3Args: chunk sums, cum column and rows through the mailbox allocation)
+    for rank_runs in runs:
+        for r in rank_runs:
+            assert r["segments"] <= 4 and r["segment_stages"] >= want["n_stages"] - 4, r
 
 
 @pytest.mark.parametrize("world", [2, 8])
