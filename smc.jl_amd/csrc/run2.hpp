@@ -73,7 +73,9 @@ static bool make_geo2(const smcmi_handle *h, int world, int rank, bool single, G
     g.nb1 = (int)std::max<long long>(1, g.direct ? g.nb2 : std::min<long long>((g.nv + 511) / 512, 128));
     if (getenv("SMCMI_E2_NB1")) g.nb1 = std::max(1, std::min(atoi(getenv("SMCMI_E2_NB1")), g.direct ? 64 : 128));   // development only (tools/shard_rank_prof.sh: one rank's share of a larger run)
     g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;                        // whole passes of the block
-    g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? 32 : 256));
+    // (one 512-slot tile per gather block up to GRP rows per virtual shard on one handle as on several: a cloud of 4 x odd or 2 x odd particles -
+    // 33 .. 64 rows per shard - had two-tile blocks on one handle until round 6, i.e. moment rows summed in another order than its sharded runs')
+    g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, g.direct ? GRP : 256));
     g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
     // (a virtual shard of at most 256 particles: one gather block of ONE 512-slot tile all the same - the block a segment worker is, so that
     // clouds of a few thousand particles resample inside their segments too)
