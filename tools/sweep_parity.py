@@ -7,6 +7,8 @@ from smc_jl_amd import Engine
 from tests import models
 from oracle import oracle as orc
 
+# SWEEP_SIZES=n1,n2,...: cloud sizes to draw from (default: small ones; odd / 2 x odd / 4 x odd sizes reach the other cuts of a handle)
+SIZES = [int(x) for x in os.environ.get("SWEEP_SIZES", "2048,4096,6000").split(",")]
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 worst = 0.0
 only = set(int(x) for x in sys.argv[3:])          # optional: trial numbers to run (with a per-stage divergence report)
@@ -30,7 +32,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     kw = dict(n_blocks=nb, n_mh_steps=int(rs.randint(1, 3)), alpha=float(rs.choice([1.0, 0.9, 0.5])),
               use_fixed_schedule=bool(rs.randint(0, 2)), n_phi=int(rs.choice([30, 60])), tempering_target=float(rs.choice([0.9, 0.95])),
               resampling_method=str(rs.choice(["systematic", "multinomial"])), threshold_ratio=float(rs.choice([0.5, 0.8])))
-    n, seed = int(rs.choice([2048, 4096, 6000])), int(rs.randint(1, 1000))
+    n, seed = int(rs.choice(SIZES)), int(rs.randint(1, 1000))
     if only and trial not in only:
         continue
     e = Engine(n, d, seed=seed, max_stages=1500)
