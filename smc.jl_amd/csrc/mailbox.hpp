@@ -15,7 +15,7 @@ static int mbox_reset_flag(smcmi_handle *h, hipStream_t s) {
 // words behind the tables for the selection inside sharded segments (stage2.hpp MB_SEL_OFF): only handles whose shard can run segments
 // (n_para <= 10, at most 131 072 particles); every handle of a run has the same (N, n, n_para), hence the same layout
 static size_t mbox_sel_words(const smcmi_handle *h) {
-    if (h->d > 10 || h->n > 131072) return 0;
+    if (h->d > 10 || h->n > 131072 || h->cfg.n_parts > (long long)V2_MAXV * 65536) return 0;      // (segments: correction rows of 512 particles, at most 128 per virtual shard)
     return (size_t)MB_SEL_TABLE_WORDS + (size_t)h->cfg.n_parts + (size_t)(h->d + 4) * (size_t)h->n;
 }
 static int mbox_alloc(smcmi_handle *h) {

@@ -26,6 +26,7 @@ def run(world, n, d, seed, kw, env):
     p = subprocess.run([sys.executable, "-c", W, str(world), str(n), str(d), str(seed), json.dumps(kw)], env=dict(os.environ, **env), capture_output=True, text=True, cwd=ROOT)
     if p.returncode: return dict(crash=p.stderr[-300:])
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+SIZES = [int(x) for x in os.environ.get("SWEEP_SIZES", "16384,32768,65536").split(",")]
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
@@ -35,7 +36,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     kw = dict(n_blocks=nb, n_mh_steps=int(rs.randint(1, 3)), alpha=float(rs.choice([1.0, 0.9, 0.5])), use_fixed_schedule=bool(rs.randint(0, 2)),
               n_phi=int(rs.choice([30, 60])), tempering_target=float(rs.choice([0.9, 0.95])), resampling_method=str(rs.choice(["systematic", "multinomial"])),
               threshold_ratio=float(rs.choice([0.5, 0.8])))
-    n, seed, world = int(rs.choice([16384, 32768, 65536])), int(rs.randint(1, 1000)), int(rs.choice([2, 4, 8]))
+    n, seed, world = int(rs.choice(SIZES)), int(rs.randint(1, 1000)), int(rs.choice([2, 4, 8]))
+    while n % world: world //= 2                       # (SWEEP_SIZES: 2 x odd and 4 x odd sizes reach the cuts into two and four virtual shards)
     ref = run(1, n, d, seed, kw, {"SMCMI_ENGINE": "2"})
     a = run(world, n, d, seed, kw, {})
     b = run(world, n, d, seed, kw, {"SMCMI_MAILBOX": "1"})
