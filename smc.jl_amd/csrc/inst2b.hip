@@ -3,4 +3,5 @@
 #ifndef SMCMI_INST2B_D
 #error "compile with -DSMCMI_INST2B_D=<n_para>"
 #endif
+#define SMCMI_INST_UNIT 1               // (the engines' non-template kernels belong to smcmi.hip: kernels.hpp)
 #include "launch2.hpp"

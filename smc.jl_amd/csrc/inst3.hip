@@ -10,4 +10,5 @@
 #if SMCMI_INST3_C == 2
 #define SMCMI_K3_CH2 1              // (stage3.hpp: the two-chunk text of the segment kernel)
 #endif
+#define SMCMI_INST_UNIT 1               // (the engines' non-template kernels belong to smcmi.hip: kernels.hpp)
 #include "launch2.hpp"

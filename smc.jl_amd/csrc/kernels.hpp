@@ -646,6 +646,9 @@ __device__ inline double energy_or_ninf(double like, double like_prev, double w,
 
 // Largest energy of the live cloud per block -> emax_part[blockIdx.x] (run start; afterwards the mutation epilogue keeps it)
 // (stride, buf: engine 2 takes the maxima in its mutation-row layout - rows_mut[b][RMAX_IDX] - from buffer 0)
+// (SMCMI_INST_UNIT: the instantiation units - inst2.hip, inst2b.hip, inst3.hip, 76 of the 77 translation units - launch none of the non-template
+// kernels of this file, stage2.hpp and stage3.hpp; compiled there all the same they were 40 % of the library and a third of its build time)
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const DevState *st, double *emax_part, int stride = 1, int buf = -1) {
     __shared__ double smem[TB / 64];
     const int R = cl.R, src = buf >= 0 ? buf : st->cur;
@@ -657,6 +660,7 @@ static __global__ void __launch_bounds__(TB) k_energy_max(CloudPtrs cl, const De
     m = block_max(m, smem, TB / 64);
     if (threadIdx.x == 0) emax_part[(long long)blockIdx.x * stride] = m;
 }
+#endif
 
 template <int K, bool FINAL>
 __global__ void __launch_bounds__(TB) k_pass(CloudPtrs cl, DevState *st, const double *sched, const double *partials_prev,
@@ -803,6 +807,7 @@ __global__ void __launch_bounds__(TB) k_correct_moments(CloudPtrs cl, DevState *
 // A spec stage whose prediction could not be used (or failed verification) is resumed by the certificate-pass path: rebuild the
 // plain schedule-walk candidates in solver copy 0 from the loop scalars (ϕ_prop and j are only committed by post_write, so they
 // still are the values the stage started with; ESS_bar / g(ϕ_{n-1}) were stored by k_stage_begin).
+#ifndef SMCMI_INST_UNIT
 static __global__ void k_solver_rearm(DevState *st, const double *sched) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Solver &S = st->sol[0];
@@ -816,8 +821,10 @@ static __global__ void k_solver_rearm(DevState *st, const double *sched) {
     for (int q = 1; j + q - 2 < n_phi && nv < KC; ++q) { S.cand[nv] = sched[j + q - 2]; S.cj[nv] = q; ++nv; }
     S.n_valid = nv;
 }
+#endif
 
 // decision of the last solver pass without a correction (stand-alone smcmi_solve_phi)
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const double *sched, const double *partials_prev, int nb_prev, int p) {
     __shared__ double scratch[TB];
     __shared__ double tot[2 * KC];
@@ -825,11 +832,13 @@ static __global__ void __launch_bounds__(TB) k_solver_finish(DevState *st, const
     if (st->done) return;
     solver_prologue(st, sched, partials_prev, nb_prev, p, &S, scratch, tot, 1);
 }
+#endif
 
 // Stage begin (src/smc_main.jl:378-396 + src/helpers.jl:14-20): bump the stage index, fold the previous
 // mutation's acceptance sums into cloud.accept, flip the cloud buffer after a resample, pick ϕ_n from the fixed
 // schedule or arm the adaptive solver with its first candidates (solver copy 0).
 constexpr int BT = 1024;  // threads of the stage-begin block: enough slices that the partial reduction is one round of loads
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const double *sched, const double *acc_partials,
                                                     int acc_nb, Records rec, const double *esum_partials = nullptr, long long *prof = nullptr,
                                                     int spec_expected = 0, const double *emax_part = nullptr, int emax_n = 0, PrepRed rr = PrepRed{},
@@ -1073,6 +1082,7 @@ static __global__ void __launch_bounds__(BT) k_stage_begin(DevState *st, const d
     if (lane == 0) { S.n_valid = nv; S.mode = MODE_SCAN; }
     SMCMI_STAMP(prof, 5);
 }
+#endif
 
 // Inclusive scan of W̃/ΣW̃ over chunk `vb` (cumsum(weights ./ sum(weights)), src/resample.jl:29,47): thread t owns IPT
 // consecutive items so the running sum follows particle order; `carry` = sum of the preceding chunks.
@@ -1145,6 +1155,7 @@ __device__ inline int post_write(DevState *st, const Records &rec, const PostIn 
     return rs;
 }
 
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const double *partials, int nb, double *chunk_off,
                                                      Records rec, int sol_slot, CloudPtrs cl = CloudPtrs{}, double *cum = nullptr) {
     __shared__ double scratch[TB];
@@ -1196,10 +1207,12 @@ static __global__ void __launch_bounds__(TB) k_post_correct(DevState *st, const 
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ resampling
 // Inclusive scan of W̃/ΣW̃ (cumsum(weights ./ sum(weights)), src/resample.jl:29,47) in the block chunks of the
 // correction pass; chunk offsets come from k_post_correct.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const DevState *st, const double *chunk_off,
                                                      double *cum, int force, int n_chunks) {
     __shared__ double s_tot[TB];
@@ -1208,12 +1221,14 @@ static __global__ void __launch_bounds__(TB) k_scan_weights(CloudPtrs cl, const 
     const double total = st->sumw;
     for (int vb = blockIdx.x; vb < n_chunks; vb += gridDim.x) scan_chunk(w, cl.n, n_chunks, vb, chunk_off[vb], total, cum, s_tot);
 }
+#endif
 
 // Selection for output slot k: ancestor = first j with cum[j] > thr (src/resample.jl:51-70 systematic walk, :33-41
 // multinomial findfirst; fall-through, which the reference turns into index 0 / nothing and is reachable only by
 // round-off, clamps to the last index), then cloud.particles = particles[new_inds, :] and reset_weights!
 // (src/smc_main.jl:440-442): the thread copies its ancestor's R-1 columns into the other cloud buffer and sets W = 1.
 // full != nullptr: rows come from an all-gathered n_cum x R cloud (multi-GPU) and go to the current buffer.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, const DevState *st, const double *cum, long long n_cum,
                                                         long long slot0, long long n_parts_total, int method,
                                                         unsigned long long seed, unsigned stage, const double *offsets,
@@ -1260,11 +1275,13 @@ static __global__ void __launch_bounds__(TB) k_resample_gather(CloudPtrs cl, con
     col(cl, dst, R - 1)[k] = 1.0;
     }
 }
+#endif
 
 // Bridge resampling of a tempered update (src/smc_main.jl:266-279): n_out rows of the old cloud `src` are drawn by its
 // weights (cum = cumsum(weights ./ sum(weights)) over the n_src old particles) and written to rows [0, n_out) of `dst`
 // WITH their old weights (update_cloud! copies whole rows; the weights are only reset after the second resample, :322).
 // Systematic search range is start_ind:n_parts of the *output* length (resample.jl:54, quirk Q5) -> lim = min(n_out, n_src).
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_bridge_gather(CloudPtrs src, int src_buf, const double *cum, long long n_src,
                                                       CloudPtrs dst, int dst_buf, long long n_out, int method,
                                                       unsigned long long seed, unsigned stage, const double *offsets,
@@ -1291,25 +1308,31 @@ static __global__ void __launch_bounds__(TB) k_bridge_gather(CloudPtrs src, int 
     if (anc) anc[k] = a;
     for (int c = 0; c < src.R; ++c) col(dst, dst_buf, c)[k] = col(src, src_buf, c)[a];
 }
+#endif
 
 // zero_bad_loglh_weights! (src/particle.jl:392-396): weight 0 where loglh == -Inf
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_zero_bad_weights(CloudPtrs cl, const DevState *st) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     const int d = cl.R - 5;
     if (col(cl, st->cur, d)[i] == SMCMI_NEG_INF) col(cl, st->cur, cl.R - 1)[i] = 0.0;
 }
+#endif
 // normalize_weights! (src/particle.jl:362-366): W *= n_parts, W /= sum(W); st->sumw holds the fixed-order sum
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_normalize_weights(CloudPtrs cl, const DevState *st, double n_parts) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n) return;
     double *w = col(cl, st->cur, cl.R - 1);
     w[i] = (w[i] * n_parts) / st->sumw;
 }
+#endif
 
 // Systematic resampling, sharded: ancestor (global row) of the first and of the last output slot of every shard r - the rows a
 // shard must receive form the contiguous range [out[2r], out[2r+1]] (thresholds ascend with the slot).  Same threshold and
 // upper_bound as k_resample_gather.  out[0] = -1 when this stage does not resample.  One wavefront, lane r = shard r.
+#ifndef SMCMI_INST_UNIT
 static __global__ void k_anc_ranges(const DevState *st, const double *cum, long long N, long long n_local, int world, unsigned long long seed,
                              long long *out) {
     const int r = threadIdx.x;
@@ -1328,6 +1351,7 @@ static __global__ void k_anc_ranges(const DevState *st, const double *cum, long 
         out[2 * r + e] = lo < N ? lo : N - 1;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ moments
 // One pass over (θ, W̃): normalise the weights (normalize_weights!, src/particle.jl:362-366: W*N then /ΣW; or 1 after a
@@ -1335,6 +1359,7 @@ static __global__ void k_anc_ranges(const DevState *st, const double *cum, long 
 // Σ w x̃ x̃ᵀ, x̃ = (1, θ - shift), from which weighted_mean / weighted_cov follow (src/particle.jl:481-483, 526-529).
 // Particles are staged through LDS in tiles so every (a,b) pair is accumulated from on-chip data.
 constexpr int MT = 256;                      // particles per LDS tile
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *st, double *partials, double *hist_W,
                                                 long long hist_ld, int standalone) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1423,6 +1448,7 @@ static __global__ void __launch_bounds__(TB) k_moments(CloudPtrs cl, DevState *s
         }
     }
 }
+#endif
 
 // Register-resident variant for d <= 12: one thread streams particles (coalesced 8-byte column reads) and keeps all
 // (d+1)(d+2)/2 augmented pair sums in VGPRs with compile-time indices - no LDS traffic in the main loop, 1 FMA per pair
@@ -1533,6 +1559,7 @@ __global__ void __launch_bounds__(TB) k_moments_reg(CloudPtrs cl, DevState *st, 
 
 // Fixed-order reduction of the moment partials: totals[p] for the (d+1)(d+2)/2 pairs, 1024 threads per block:
 // thread (s, idx) sums blocks b = s (mod 16) of pair p0 + idx; grid = ceil(npairs / 64).
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(1024) k_moments_reduce(const DevState *st, const double *partials, int nb, int npairs,
                                                          double *totals, int standalone) {
     __shared__ double scratch[1024];
@@ -1554,6 +1581,7 @@ static __global__ void __launch_bounds__(1024) k_moments_reduce(const DevState *
         totals[p0 + t] = tot;
     }
 }
+#endif
 
 // totals of the augmented pair sums -> θ_bar (st->mean), R (st->cov); the shift moves to the new mean
 __device__ inline void moments_from_totals(DevState *st, const double *totals, int d, int t, int nt) {
@@ -1571,9 +1599,11 @@ __device__ inline void moments_from_totals(DevState *st, const double *totals, i
     __syncthreads();
     for (int a = t; a < d; a += nt) st->shift[a] = st->mean[a];
 }
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(64) k_finalize_moments(DevState *st, const double *totals, int d) {
     moments_from_totals(st, totals, d, threadIdx.x, 64);
 }
+#endif
 
 // generic fixed-order reduction of block partials into out[0..m) (1 block)
 // Optional: also reduce the per-block energy maxima of this shard into its slot of `emax_slots` (the other shards' slots get 0:
@@ -1584,6 +1614,7 @@ __device__ inline void emax_publish(const double *emax_part, int nb, double *ema
     em = block_max(em, smem, TB / 64);
     if ((int)threadIdx.x < world) emax_slots[threadIdx.x] = ((int)threadIdx.x == rank) ? fmax(em, -1e300) : 0.0;
 }
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_reduce_partials(const double *partials, int nb, int m, double *out, const double *emax_part = nullptr,
                                                         int emax_nb = 0, double *emax_slots = nullptr, int rank = 0, int world = 1) {
     __shared__ double scratch[TB];
@@ -1598,9 +1629,11 @@ static __global__ void __launch_bounds__(TB) k_reduce_partials(const double *par
     const double tot = final_sum(partials, nb, m, scratch);
     if (threadIdx.x < m) out[threadIdx.x] = tot;
 }
+#endif
 
 // First level of a two-level row reduction for very many partial rows (N >= ~3e5: one row per 256 particles): block g totals the
 // rows of its contiguous chunk in fixed order -> out[g][m]; the consumer then totals gridDim.x rows instead of nb.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_reduce_rows(const double *partials, int nb, int m, double *out, const double *emax_in = nullptr,
                                                     double *emax_out = nullptr) {
     __shared__ double scratch[TB];
@@ -1616,8 +1649,10 @@ static __global__ void __launch_bounds__(TB) k_reduce_rows(const double *partial
         if (threadIdx.x == 0) emax_out[blockIdx.x] = em;
     }
 }
+#endif
 
 // per-chunk weight sums in the layout k_post_correct / k_scan_weights expect (partials[2 b])
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_weight_chunk_sums(CloudPtrs cl, const DevState *st, double *partials) {
     __shared__ double red[(TB / 64) * 2];
     const double *w = col(cl, st->cur, cl.R - 1);
@@ -1628,12 +1663,15 @@ static __global__ void __launch_bounds__(TB) k_weight_chunk_sums(CloudPtrs cl, c
     const double tot = block_reduce_many<2>(acc, red);
     if (threadIdx.x < 2) partials[2 * (long long)blockIdx.x + threadIdx.x] = tot;
 }
+#endif
+#ifndef SMCMI_INST_UNIT
 static __global__ void k_chunk_offsets(DevState *st, const double *partials, int nb, double *chunk_off, double base,
                                 int set_sum) {
     double run = base;
     for (int b = 0; b < nb; ++b) { chunk_off[b] = run; run += partials[2 * (long long)b]; }
     if (set_sum) st->sumw = run;
 }
+#endif
 
 // θ_bar, R from the moment partials; free subset + symmetrisation (src/smc_main.jl:457-465); random blocks
 // (generate_free_blocks/all_blocks, src/helpers.jl:215-260, Fisher-Yates on Philox); then per block the scaled
@@ -1739,6 +1777,7 @@ __device__ inline void rng_ahead_block(const DevState *st, const ModelDev *md, u
         }
 }
 
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, const ModelDev *md, const double *partials, int nb_part,
                                                          unsigned long long seed, int from_totals, int gen_blocks,
                                                          int standalone, long long *prof = nullptr, RngAhead ra = RngAhead{}, int sol_slot = 0,
@@ -1975,6 +2014,7 @@ static __global__ void __launch_bounds__(PT) k_prepare_mutation(DevState *st, co
     }
     SMCMI_STAMP(prof, 6);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ mutation
 // One thread = one particle: n_mh_steps x n_blocks random-walk-mixture Metropolis-Hastings moves
@@ -2920,6 +2960,7 @@ __device__ inline double prior_draw_in_bounds(unsigned long long seed, unsigned 
 }
 // initial_draw! / one_draw (src/initialization.jl:23-119): prior draws with bounds rejection, re-draw until the
 // log-likelihood is finite.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const DevState *st, const ModelDev *md,
                                                    unsigned long long seed, long long gid0, int *fail_flag) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
@@ -2949,9 +2990,11 @@ static __global__ void __launch_bounds__(TB) k_init_prior(CloudPtrs cl, const De
     col(cl, dst, d + 3)[i] = 0.0;
     col(cl, dst, d + 4)[i] = 1.0;
 }
+#endif
 
 // Prior draw of the particles whose attempt[i] >= 0 - the draws k_init_prior makes on outer attempt attempt[i] (same Philox tags, same
 // bounds redraws) - with the log-prior; the likelihood comes from the host (callback.hpp): initial_draw! with a user closure.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const ModelDev *md, unsigned long long seed, long long gid0, const int *attempt) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= cl.n || attempt[i] < 0) return;
@@ -2970,6 +3013,7 @@ static __global__ void __launch_bounds__(TB) k_draw_prior(CloudPtrs cl, const Mo
     col(cl, 0, d + 3)[i] = 0.0;
     col(cl, 0, d + 4)[i] = 1.0;
 }
+#endif
 
 // initialize_likelihoods! (src/initialization.jl:153-186): retire loglh to old_loglh, then evaluate the (new-data) likelihood
 // and the prior at every particle.  Out-of-bounds parameters give -Inf (the reference would throw ParamBoundsError here).
@@ -3018,6 +3062,7 @@ static __global__ void __launch_bounds__(256, 1) k_initialize_likelihoods(CloudP
 
 // device-to-device copy of a cloud (n doubles, 16-byte aligned buffers): the runtime's blit kernel took 221 µs for the 12 MB of config 2,
 // a grid-stride copy with 16-byte accesses runs at HBM speed (~10 µs)
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(256) k_copy_f64(double *dst, const double *src, long long n) {
     const long long n2 = n >> 1, stride = (long long)gridDim.x * blockDim.x;
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
@@ -3032,10 +3077,13 @@ static inline void launch_copy_f64(double *dst, const double *src, long long n, 
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(2048, (n / 2 + 255) / 256));
     k_copy_f64<<<grid, 256, 0, s>>>(dst, src, n);
 }
+#endif
 
+#ifndef SMCMI_INST_UNIT
 static __global__ void k_fill(double *p, long long n, double v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+#endif
 
 }  // namespace smcmi

@@ -399,11 +399,13 @@ __device__ inline void reduce_vshard(const double *base0, int nr_raw, int m, int
     const double run = reduce_vshard_f<NT, decltype(ldrow), MMAX>(ldrow, nr_raw, m, max_idx, pair);
     if ((int)threadIdx.x < m) row_store(out_v + threadIdx.x, run, COH);     // (COH: a block of the same launch may read the totals)
 }
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(RT) k2_reduce(const double *rows, int nr_raw, int m, int max_idx, double *out, int pair) {
     const int v = blockIdx.x;
     if (m <= 72) reduce_vshard<RT>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
     else reduce_vshard<RT, false, 160>(rows + (long long)v * nr_raw * m, nr_raw, m, max_idx, out + (long long)v * m, pair);
 }
+#endif
 
 // The same totals without a launch of their own (sharded runs, large clouds): every block of a row-producing kernel takes a
 // ticket of its virtual shard once its row is stored; the block that draws the last ticket totals the shard's rows - in the
@@ -511,6 +513,7 @@ __device__ inline void k2_export_state(DevState *st, const Ctl2 *ctl) {
     st->skip_fold = 0;
 }
 // to_ctl: DevState -> Ctl2 (a run starts); else Ctl2 -> DevState (it ends).  One kernel: the two directions are never needed in one launch
+#ifndef SMCMI_INST_UNIT
 static __global__ void k2_state(DevState *st, Ctl2 *ctl, int to_ctl, Records rec = Records{}, int fresh = 0, double ess0 = 0.0, double c0 = 0.0, double acc0 = 0.0) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (!to_ctl) { k2_export_state(st, ctl); return; }
@@ -529,6 +532,7 @@ static __global__ void k2_state(DevState *st, Ctl2 *ctl, int to_ctl, Records rec
     c.status.solver_passes = st->solver_passes;
     *ctl = c;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ stage begin
 // src/smc_main.jl:378-396 + src/helpers.jl:9-56 (see k_stage_begin in kernels.hpp for the predictor and the candidate set): run
@@ -708,6 +712,7 @@ __device__ inline int begin2_block(int n, DevState *st, Ctl2 *ctl, const Rows2 &
 }
 
 // stage begin as its own launch (certificate path: the solver is armed in DevState::sol[0]); 1 block
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, int n, Rows2 mrows, const double *sched, Records rec, int spec_expected = 0) {
     __shared__ Post2 s_po;
     __shared__ Begin2 s_bg;
@@ -715,6 +720,7 @@ static __global__ void __launch_bounds__(T1) k2_begin(DevState *st, Ctl2 *ctl, i
     __shared__ int s_act;
     begin2_block<T1>(n, st, ctl, mrows, spec_expected, sched, rec, &s_po, &s_bg, s_vt, s_tot, s_sw, &s_act);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ certificate passes
 // One pass over (loglh, old_loglh, weight) for the <= KC candidates of solver copy (p-1)&1 (see k_pass in kernels.hpp); the
@@ -746,6 +752,7 @@ __device__ inline void solver_prologue2(DevState *st, const double *sched, const
     if (blockIdx.x == 0 && t < NW && *s_flag != 2) reinterpret_cast<double *>(&st->sol[p & 1])[t] = reinterpret_cast<const double *>(S)[t];
 }
 
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st, Ctl2 *ctl, Geo2 g, int n, int p, Rows2 prev, const double *sched,
                                               double *rows_out) {
     constexpr int K = KC;
@@ -787,9 +794,11 @@ static __global__ void __launch_bounds__(T1) k2_pass(CloudPtrs cl, DevState *st,
     if (threadIdx.x < 2 * K) rows_out[(long long)blockIdx.x * (2 * K) + threadIdx.x] = total;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status.solver_passes += 1;
 }
+#endif
 
 // decision of the last enqueued pass: ϕ_n certified -> Begin2 becomes final; otherwise the stage stalls (code 2) until the host
 // enqueues more passes (which continue the same search from solver copy (P-1)&1 and its rows).  1 block.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, int n, int P, Rows2 prev, const double *sched) {
     __shared__ double s_vt[V2_MAXV * 2 * KC * 2], s_tot[2 * KC], s_srt[KC];
     __shared__ Solver S;
@@ -804,6 +813,7 @@ static __global__ void __launch_bounds__(T1) k2_finish(DevState *st, Ctl2 *ctl, 
     __threadfence();
     ctl->bg.final = 1;
 }
+#endif
 
 // Random numbers of proposal t (mh_step * n_blocks + block) of one particle (src/mutation.jl:66,133, helpers.jl:87-100; RNG
 // contract in DESIGN.md): the MH uniform of this decision, the mixture-component uniform and the block's normals.  Box-Muller is
@@ -1183,6 +1193,7 @@ __device__ inline double sel_tile_scan(double w, double *s_w, double *tile_total
 // c_begin / c_end / i_off: scan the chunks [c_begin, c_end) only, reading and writing at (global index - i_off) - a handle of a sharded
 // run scans ITS particles' weights into its local cum column from the all-gathered chunk sums (the offsets, the total and therefore
 // the values are those of a scan over the whole cloud).
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(TS) k2_scan(Ctl2 *ctl, const DevState *st, Geo2 g, int n, Rows2 cmrows, const double *wt_full,
                                               const double *csum_full, double *cum, int c_begin = 0, int c_end = -1, long long i_off = 0) {
     __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2], scratch[256], s_off[1024], s_w[TS / 64];
@@ -1213,12 +1224,14 @@ static __global__ void __launch_bounds__(TS) k2_scan(Ctl2 *ctl, const DevState *
         }
     }
 }
+#endif
 
 // Systematic resampling, sharded, owner side: which of THIS handle's rows does handle r need?  The ancestors of r's
 // slots k0 .. k1 (thresholds t = (k + u) / N) are the first j with cum[j] > t; among this handle's rows they lie between its first
 // row with cum > t(k0) and its first row with cum > t(k1) (its last row if there is none) - a superset by at most one row, from this
 // handle's own cum column alone.  out[2 r], out[2 r + 1] = global indices of that range, -1 / -1 if r needs none of the rows;
 // out[2 world] = 1 if the stage resamples, else 0 (nothing else is valid then).
+#ifndef SMCMI_INST_UNIT
 static __global__ void k2_owner_ranges(Ctl2 *ctl, const DevState *st, int n, Rows2 cmrows, const double *cum_local, long long N, long long n_local,
                                        long long gid0, int world, unsigned long long seed, long long *out, const double *csum_full, int c_first) {
     __shared__ double s_vt[V2_MAXV * 2 * 8], s_tot[2];
@@ -1254,6 +1267,7 @@ static __global__ void k2_owner_ranges(Ctl2 *ctl, const DevState *st, int n, Row
     out[2 * r] = none ? -1 : gid0 + res[0];
     out[2 * r + 1] = none ? -1 : gid0 + (res[1] < n_local ? res[1] : n_local - 1);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ selection: gather + moments
 // Output slot k: ancestor = first j with cum[j] > threshold (src/resample.jl:33-70; fall-through clamps to the last index), its

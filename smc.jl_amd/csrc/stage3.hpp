@@ -392,6 +392,7 @@ __device__ inline bool gather_totals_pair(const unsigned long long *tbl_m, unsig
 // Residency self-test of a handle's segment geometry (first use): `grid` blocks of T3 threads with enough LDS that a CU holds ONE of
 // them - the strictest placement the segment kernel can get - take a ticket; the last publishes a granule every block waits for
 // (bounded).  ok counts the blocks that saw it: anything but `grid` (or a raised time-out flag) keeps the handle on engine 2.
+#ifndef SMCMI_INST_UNIT
 static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned long long *rec, unsigned tag, unsigned long long *to, int *ok) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_to;
@@ -405,6 +406,7 @@ static __global__ void __launch_bounds__(T3, 2) k3_census(int *tick, unsigned lo
     const bool good = rec3_wait(rec, s_w, 1, tag, to, &s_to);
     if (threadIdx.x == 0 && good && s_w[0] == 0x5e6u) atomicAdd(ok, 1);
 }
+#endif
 
 // dynamic LDS a gatherer needs for the rows of its virtual shard (at most 2 GRP = 128 of them, 72 or RMUT columns)
 constexpr size_t k3_gather_lds_bytes(int D) {
