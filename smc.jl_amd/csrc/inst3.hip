@@ -7,6 +7,9 @@
 #ifndef SMCMI_INST3_C
 #define SMCMI_INST3_C 1
 #endif
+#ifndef SMCMI_INST3_S
+#define SMCMI_INST3_S 0               // 1: several handles (Seg3Args::peers)
+#endif
 #if SMCMI_INST3_C == 2
 #define SMCMI_K3_CH2 1              // (stage3.hpp: the two-chunk text of the segment kernel)
 #endif

@@ -84,7 +84,8 @@ void launch_k2_prepare(smcmi_handle *h, const Mut2Args &mp, int nb) {
 // one instantiation per (n_para, α = 1?, riding?): the proposal kinds are compiled with different flags (Makefile SEGFLAGS / SEGFLAGS_MIX).
 // RIDE: fixed schedules under RunParams::shift_lag on one handle - a stage's correction row rides the mutation row in front of it (stage3.hpp k3_rides)
 // CH = 2: two 512-particle chunks per worker (α = 1, one handle of up to 253 952 particles: run2.hpp seg3_ready), translation units of their own (inst3c / inst3cr)
-template <int D, bool A1, bool RIDE, int CH = 1>
+// SYS: several handles (Seg3Args::peers set): translation units of their own as well (inst3s / inst3ms / inst3rs / inst3mrs)
+template <int D, bool A1, bool RIDE, int CH = 1, bool SYS = false>
 void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb) {
     Eng2 *e = h->e2;
     if constexpr (D <= 10 && CH == 2) {
@@ -106,19 +107,24 @@ void launch_k3_seg(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int 
     // no flow control: one stage behind, it would poll for a tag its rows have already left and raise the waits' abort word)
     const bool gatherers = !(e->g.nb2 <= 2 && sa.peers == nullptr);
     const unsigned grid = (unsigned)(e->g.Vl * e->g.nb2 + (gatherers ? e->g.Vl : 0));
-    constexpr int attr_bit = (A1 ? 1 : 2) << (RIDE ? 2 : 0);
+    constexpr int attr_bit = ((A1 ? 1 : 2) << (RIDE ? 2 : 0)) << (SYS ? 6 : 0);
     if (!(e->seg_attr_set & attr_bit)) {       // (per handle = per device: a function attribute belongs to the device's copy of the kernel)
         // (opt in to more than the default 64 KB per block: the kernel's static arrays come on top of `lds`; a CU has 160 KB)
-        hipFuncSetAttribute((const void *)k3_segment<D, A1, RIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((std::max(k3_lds_bytes(D, k3_sel_cols(D, A1)), k3_gather_lds_bytes(D)) + 1023) / 1024 * 1024));
+        hipFuncSetAttribute((const void *)k3_segment<D, A1, RIDE, 1, SYS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((std::max(k3_lds_bytes(D, k3_sel_cols(D, A1)), k3_gather_lds_bytes(D)) + 1023) / 1024 * 1024));
         e->seg_attr_set |= attr_bit;
     }
-    k3_segment<D, A1, RIDE><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
+    k3_segment<D, A1, RIDE, 1, SYS><<<grid, T3, lds, h->stream>>>(h->cl, h->d_st, e->d_ctl, h->d_model, e->g, ma, sa, nb, h->h_model.n_free);
     }
 }
 template <int D>
 inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Args &sa, int nb, bool alpha1, bool ride) {
     if (h->e2->seg_ch == 2) {             // (seg3_ready grants two chunks to α = 1 runs only)
         if (ride) launch_k3_seg<D, true, true, 2>(h, ma, sa, nb); else launch_k3_seg<D, true, false, 2>(h, ma, sa, nb);
+        return;
+    }
+    if (sa.peers != nullptr) {            // several handles
+        if (alpha1) { if (ride) launch_k3_seg<D, true, true, 1, true>(h, ma, sa, nb); else launch_k3_seg<D, true, false, 1, true>(h, ma, sa, nb); }
+        else { if (ride) launch_k3_seg<D, false, true, 1, true>(h, ma, sa, nb); else launch_k3_seg<D, false, false, 1, true>(h, ma, sa, nb); }
         return;
     }
     if (alpha1) { if (ride) launch_k3_seg<D, true, true>(h, ma, sa, nb); else launch_k3_seg<D, true, false>(h, ma, sa, nb); }
@@ -140,8 +146,12 @@ inline void launch_k3_segment(smcmi_handle *h, const Mut2Args &ma, const Seg3Arg
                                       X template void launch_k3_seg<D, true, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
                                       X template void launch_k3_seg<D, false, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
                                       X template void launch_k3_seg<D, true, false, 2>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
-                                      X template void launch_k3_seg<D, true, true, 2>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
-#define SMCMI_LAUNCH3_ONE(D, A, R, C) template void launch_k3_seg<D, A, R, C>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+                                      X template void launch_k3_seg<D, true, true, 2>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, true, false, 1, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, false, false, 1, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, true, true, 1, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int); \
+                                      X template void launch_k3_seg<D, false, true, 1, true>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
+#define SMCMI_LAUNCH3_ONE(D, A, R, C, S) template void launch_k3_seg<D, A, R, C, S>(smcmi_handle *, const Mut2Args &, const Seg3Args &, int);
 #define SMCMI_LAUNCH2B_INSTANCES(X, D) X template void launch_k2b_mutate<D>(smcmi_handle *, const Mut2Args &, const Beg2Args &, int, bool);
 #define SMCMI_LAUNCH_ALL_D(M, X)                                                                                                          \
     M(X, 1) M(X, 2) M(X, 3) M(X, 4) M(X, 5) M(X, 6) M(X, 7) M(X, 8) M(X, 9) M(X, 10) M(X, 11) M(X, 12) M(X, 13) M(X, 14) M(X, 15) M(X, 16)
@@ -153,7 +163,7 @@ SMCMI_LAUNCH_B_D(SMCMI_LAUNCH3_INSTANCES, extern)
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST3_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)
-SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0), (SMCMI_INST3_R != 0), SMCMI_INST3_C)
+SMCMI_LAUNCH3_ONE(SMCMI_INST3_D, (SMCMI_INST3_A != 0), (SMCMI_INST3_R != 0), SMCMI_INST3_C, (SMCMI_INST3_S != 0))
 SMCMI_LAUNCH_B_D(SMCMI_LAUNCH2B_INSTANCES, extern)
 #elif defined(SMCMI_INST2B_D)
 SMCMI_LAUNCH_ALL_D(SMCMI_LAUNCH2_INSTANCES, extern)

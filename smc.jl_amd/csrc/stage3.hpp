@@ -787,7 +787,7 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
 // 512-particle chunks of its virtual shard - one in registers, one parked in LDS ((D + 6) columns behind the parking area), exchanged between
 // the per-particle phases; it publishes two rows per hand-over and pays the serial phases and the hand-overs once.  Such a segment leaves at a
 // stage that must resample (its selection runs as launches).
-template <int D, bool ALPHA1, bool RIDE, int CH = 1>
+template <int D, bool ALPHA1, bool RIDE, int CH = 1, bool SYS = false>
 __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -879,7 +879,9 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         __syncthreads();
         return s_act;
     };
-    const bool sys = sa.peers != nullptr;
+    // (SYS: several handles, Seg3Args::peers - a compile-time matter: with the two kinds of hand-over behind run-time branches the one-handle
+    // kernel carried 30 more spilled scalar registers and ran the headline's stage 0.5 µs slower)
+    constexpr bool sys = SYS;
     auto post_total = [&](unsigned long long *mine, long long off, long long w, double val, unsigned tg) {
         if (sys) { for (int pr = 0; pr < sa.world; ++pr) gran_store_sys(sa.peers[pr] + off + w, val, tg); }
         else gran_store(mine + w, val, tg);
