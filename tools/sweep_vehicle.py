@@ -18,6 +18,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
               n_phi=int(rs.choice([30, 60])), tempering_target=float(rs.choice([0.9, 0.95])), resampling_method=str(rs.choice(["systematic", "multinomial"])),
               threshold_ratio=float(rs.choice([0.5, 0.8])))
     if rs.randint(0, 3) == 0: kw["pause_at"] = int(rs.randint(3, 25))      # an intermediate save point, continued in place (both sides alike)
+    if not kw["use_fixed_schedule"] and kw.get("pause_at", 0) > 8: kw["pause_at"] = 3 + kw["pause_at"] % 6      # (a short adaptive run must still reach it)
     # the cut: V = 8 (n = 8 k, up to 31 rows per shard), 4 (n = 4 odd, up to 63), 2 (n = 2 odd, up to 127), 1 (n odd, up to 128 rows)
     V = int(rs.choice([8, 4, 2, 1]))
     rows = int(rs.randint(1, {8: 31, 4: 63, 2: 127, 1: 128}[V] + 1))
