@@ -8,10 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.test_gpu_multiproc import _spawn, _single, _check
 
+# SWEEP_D=lo,hi: range of n_para (default 1..10: the register kernels and the segments; 11..16: the wide two-launch stage, at most 65 536 per shard)
+DLO, DHI = [int(x) for x in os.environ.get("SWEEP_D", "1,10").split(",")]
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
-    d = int(rs.randint(1, 11))
+    d = int(rs.randint(DLO, DHI + 1))
     nb = int(rs.randint(1, min(d, 3) + 1))
     while ((d + nb - 1) // nb) * (nb - 1) >= d: nb -= 1
     kw = dict(n_blocks=nb, n_mh_steps=int(rs.randint(1, 3)), alpha=float(rs.choice([1.0, 0.9, 0.5])), use_fixed_schedule=bool(rs.randint(0, 2)),
@@ -33,7 +35,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
         want, want_cloud = _single(cfg)
         td = pathlib.Path(tempfile.mkdtemp())
         runs, cloud = _spawn(1, cfg, td, env_extra={"SMCMI_MAILBOX": "2"})
-        _check(runs, cloud, want, want_cloud, expect_mailbox=True)
+        _check(runs, cloud, want, want_cloud, expect_mailbox=True if d <= 10 else None)        # (n_para > 10: whatever transport the wide stage takes)
         r = runs[0][0]
         print(json.dumps(dict(trial=trial, ok=True, V=V, n=n, d=d, **kw, stages=r["n_stages"], resamples=r["resamples"], segments=r["segments"], segment_stages=r["segment_stages"])), flush=True)
     except AssertionError as ex:
