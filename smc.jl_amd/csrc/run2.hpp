@@ -102,7 +102,7 @@ static bool make_geo2_uneven(const smcmi_handle *h, Geo2 *out) {
         g.direct = 1; g.inker = 1;
         g.nb1 = g.nb2;
         g.per1 = ((g.nv + g.nb1 - 1) / g.nb1 + T1 - 1) / T1 * T1;
-        g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, 32));
+        g.nbg = (int)std::max<long long>(1, std::min<long long>((g.nv + 511) / 512, GRP));      // (one tile per gather block, like make_geo2's: in-place selection beyond 32 rows)
         g.perg = ((g.nv + g.nbg - 1) / g.nbg + 255) / 256 * 256;
         if (g.perg < 512) g.perg = 512;
         *out = g;
@@ -492,9 +492,11 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
     // mailbox allocation every peer has mapped (stage3.hpp Sel3Args, mailbox.hpp mbox_sel_words); the worker's scratch holds up to 1 024 chunk
     // sums / chunk ends there (n_para >= 3 at that size)
     const int sel_ncg = (int)((g0.N + SEL_GCH - 1) / SEL_GCH), sel_nch = g0.V * g0.nb1;
-    const bool sel_one = !seg_sys && g.hs.size() == 1 && h0->d_cum != nullptr && sel_nch <= 256;
-    const bool sel_sys = seg_sys && mbox_sel_words(h0) > 0 && sel_ncg <= 1024 && 16 + 2 * sel_nch + 256 <= (d + 2) * T3 && 16 + sel_ncg + 2 * SEL_GCH <= (d + 2) * T3;
-    const bool sel_inside = e3 && (sel_one || sel_sys) && d <= 10 && h0->e2->seg_ch == 1 && sel_in_env != 0 && g0.nbg == g0.nb2 && g0.perg == T3;
+    const bool sel_lds = sel_ncg <= 1024 && 16 + 2 * sel_nch + 256 <= (d + 2) * T3 && 16 + sel_ncg + 2 * SEL_GCH <= (d + 2) * T3;      // (the worker's scratch: chunk sums, then chunk ends + staged cum values)
+    const bool sel_one = !seg_sys && g.hs.size() == 1 && h0->d_cum != nullptr && sel_lds;
+    const bool sel_sys = seg_sys && mbox_sel_words(h0) > 0 && sel_lds && h0->e2->seg_ch == 1;
+    // (two chunks per worker - one handle of up to 253 952 particles -: k3_select_two, the chunk in registers through Sel3Args::transit)
+    const bool sel_inside = e3 && (sel_one || sel_sys) && d <= 10 && sel_in_env != 0 && g0.nbg == g0.nb2 && g0.perg == T3;
     if (sel_inside)
       for (auto *hh : g.hs) {
         smcmi_handle *h0 = hh;                                     // (shadows: one Sel3Args per handle)
@@ -504,7 +506,7 @@ static int run2_impl(ShardGroup &g, const smcmi_run_config *rc, smcmi_result *re
         Sel3Args &sl = e->h_sel3;                                  // (a member: the copy needs no sync)
         sl = Sel3Args{};
         sl.method = rc->resampling_method; sl.cum = h0->d_cum; sl.anc = h0->d_anc;
-        if (k3_sel_cols(d, rc->alpha == 1.0) == 0) {               // (mixture proposals beyond n_para 7: the particle in transit does not fit the kernel's LDS)
+        if (k3_sel_cols(d, rc->alpha == 1.0) == 0 || e->seg_ch == 2) {      // (mixture proposals beyond n_para 7: the particle in transit does not fit the kernel's LDS; two chunks: the one in registers)
             if (!e->d_transit3 && dmalloc(&e->d_transit3, nblk * (size_t)(d + 5) * T3)) return SMCMI_ERR_HIP;
             sl.transit = e->d_transit3;
         }

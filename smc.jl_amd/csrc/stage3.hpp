@@ -696,6 +696,124 @@ __device__ __attribute__((noinline)) int k3_select_inside(const Sel3Args *selp, 
 #undef K3S
 }
 
+#ifdef SMCMI_K3_CH2
+// The same for a worker of TWO chunks (k3_segment<D, true, RIDE, 2>; one handle): both chunks' particles and cum values are written before the first
+// hand-over, both chunks' ancestors are found and fetched behind it, both moment rows go out before the second - two hand-overs as for one chunk.
+// A chunk: stx [θ_1..θ_D][T3]; sto columns 1..4 = loglh | logprior | old_loglh | accept; wv = W̃ (the chunk in registers travels through the
+// block's slice of Sel3Args::transit in k3_select_inside's layout, the parked one stays where it is: stx = its LDS columns, sto = column D - 1 on,
+// wv = its column D + 5).  has = false: the worker's second chunk lies beyond its virtual shard - no rows, nothing posted.
+struct Sel2Chunk { double *stx, *sto; const double *wv; int rowi, has; long long beg, end; };
+struct Sel2Geo { int rowi, has; long long beg, end; };             // chunk c of a worker (block-uniform, left in LDS once per launch)
+template <int D>
+__device__ __attribute__((noinline)) int k3_select_two(const Sel3Args *selp, double *buf0, long long cl_n, int cl_R, long long Ng, int nchunks, int V, const Sel2Geo *geo, int cur, double *tr, double *st2,
+                                                       unsigned tag, int n, unsigned long long seed, long long gid0, const unsigned long long *g_cm, unsigned long long *to, int *s_to,
+                                                       double *s_tot, double *s_vt, double *s_sw, double *red, double *sc, const double *shift) {
+    constexpr int NPm = Mut2Lds<D>::NP, MGM = pad2(NPm), DAm = D + 1, NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
+    const Sel3Args sl = *selp;
+    const int tid = threadIdx.x;
+    // [0]: the chunk that was in registers (chunk `cur`, now in the transit slice), [1]: the parked one
+    const Sel2Geo g0 = geo[cur], g1 = geo[cur ^ 1];
+    const Sel2Chunk ch[2] = {Sel2Chunk{tr + 5 * T3, tr, tr, g0.rowi, g0.has, g0.beg, g0.end},
+                             Sel2Chunk{st2, st2 + (D - 1) * T3, st2 + (D + 5) * T3, g1.rowi, g1.has, g1.beg, g1.end}};
+    const long long ci[2] = {ch[0].beg + tid, ch[1].beg + tid};
+    double *s_w = sc, *s_cs = sc + 16, *s_scr = s_cs + nchunks, *s_off = s_scr + 256, *s_ce = sc + 16;
+    long long *s_r = reinterpret_cast<long long *>(sc + 8);
+    const int ncg = (int)((Ng + SEL_GCH - 1) / SEL_GCH);
+    double *s_cw = s_ce + ncg;
+    const int cap_w = (D + 2) * T3 - 16 - ncg;
+    const __amdgpu_buffer_rsrc_t cl_rsrc = rows_rsrc(buf0, (long long)cl_R * cl_n * 8);
+    const __amdgpu_buffer_rsrc_t cum_rsrc = rows_rsrc(sl.cum, Ng * 8);
+    __syncthreads();
+    // (1) the particles as stage n - 1 left them -> buffer 0
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (ch[q].has && ci[q] < ch[q].end) {
+#pragma unroll
+            for (int k = 0; k < D + 4; ++k) row_store(buf0 + (long long)k * cl_n + ci[q], k < D ? ch[q].stx[k * T3 + tid] : ch[q].sto[(1 + k - D) * T3 + tid], true);
+        }
+    }
+    // (2) the chunk sums = entry 0 of every correction row -> chunk offsets
+    for (int c = tid; c < nchunks; c += T3) {
+        const unsigned long long *wd = g_cm + (long long)c * MCM * 2;
+        gran_poll(wd, tag, to, s_to);
+        gran_poll(wd + 1, tag, to, s_to);
+        const unsigned long long w0 = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w1 = __hip_atomic_load(wd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cs[c] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+    }
+    __syncthreads();
+    if (*s_to) return 1;
+    sel_chunk_offsets([&](int b) { return s_cs[b]; }, nchunks, s_scr, s_off);
+    // (3) the cum values of both chunks (k2_scan's arithmetic on W̃)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (!ch[q].has) continue;                                   // (block-uniform)
+        const bool live = ci[q] < ch[q].end;
+        double tt;
+        const double incl = sel_tile_scan(live ? ch[q].wv[tid] : 0.0, s_w, &tt);
+        if (live) row_store(sl.cum + ci[q], (s_off[ch[q].rowi] + incl) / s_tot[0], true);
+    }
+    // (4) hand-over: every store above is acknowledged before this block says so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (ch[q].has && tid < 2) gran_store(sl.g_sel + ((long long)ch[q].rowi * 2 + tid) * 2, 0.0, tag);
+    if (!gather_totals(sl.gt_sel, V, 2, -1, tag, to, s_to, s_sw, s_vt, false)) return 1;
+    // (5) ancestors of the output slots, (6) their rows become the particles
+    double u_sys = 0.0, ub_;
+    if (sl.method != SMCMI_RESAMPLE_MULTINOMIAL) uniform_pair(seed, 0ull, (unsigned)n, rng_tag(P_RES, 0, 0), u_sys, ub_);
+    auto ldcum = [&](long long j) { return load_f64_sc1(cum_rsrc, (unsigned)j * 8u); };
+    const bool staged = sl.method != SMCMI_RESAMPLE_MULTINOMIAL && ncg <= 1024 && cap_w >= 2 * SEL_GCH;
+    if (staged) sel_chunk_ends(ldcum, 0, Ng, ncg, s_ce);
+    double xx[2][DAm];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        xx[q][0] = 1.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) xx[q][a + 1] = 0.0;
+        if (!ch[q].has) continue;
+        const long long beg = ch[q].beg, end = ch[q].end, i = ci[q];
+        const bool live = i < end;
+        const long long slot = gid0 + (live ? i : (end > beg ? end - 1 : 0));
+        const double ua = sel_threshold(sl.method, seed, slot, n, u_sys, Ng);
+        __syncthreads();                                            // (the previous chunk's search is done with s_r / s_cw)
+        const long long anc_i = (end > beg) ? sel_search_tile(ua, staged, ncg, s_ce, s_cw, s_r, ldcum, 0, Ng, cap_w) : 0;
+        if (live) {
+            if (sl.anc) sl.anc[i] = anc_i;
+            double row[D + 4];
+#pragma unroll
+            for (int k = 0; k < D + 4; ++k) row[k] = load_f64_sc1(cl_rsrc, (unsigned)(((long long)k * cl_n + anc_i) * 8));
+#pragma unroll
+            for (int k = 0; k < D + 4; ++k) { if (k < D) ch[q].stx[k * T3 + tid] = row[k]; else ch[q].sto[(1 + k - D) * T3 + tid] = row[k]; }
+#pragma unroll
+            for (int k = 0; k < D; ++k) xx[q][k + 1] = row[k] - shift[k];
+        }
+    }
+    // (7) the moment rows of both blocks, published; (8) the totals of the resampled cloud's moments replace the correction's
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (!ch[q].has) continue;
+        const bool live = ci[q] < ch[q].end;
+        unsigned long long *my_gm = sl.g_gm + (long long)ch[q].rowi * MGM * 2;
+        cm_row_chunks<NPm, T3 / 64>(red, [&](auto C, double (&a)[CMW]) __attribute__((always_inline)) {
+            constexpr int c = decltype(C)::value;
+            static_for<CMW>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int idx = c * CMW + decltype(Q)::value, qq = decltype(Q)::value;
+                double val = 0.0;
+                if constexpr (idx < NPm) {
+                    constexpr int pa = cm_pair_a(DAm, idx + 2), pb = cm_pair_b(DAm, idx + 2);
+                    val = 0.0 + xx[q][pa] * xx[q][pb];
+                }
+                a[qq] = live ? val : 0.0;
+            });
+        }, [&](int idx, double val) { gran_store(my_gm + idx * 2, val, tag); });
+        if (tid >= NPm && tid < MGM) gran_store(my_gm + tid * 2, 0.0, tag);
+    }
+    if (!gather_totals(sl.gt_gm, V, MGM, -1, tag, to, s_to, s_tot + 2, s_vt, false)) return 1;
+    return 0;
+}
+#endif
+
 // ONE hand-over per stage (fixed schedules, RunParams::shift_lag; the reference's default: use_fixed_schedule = true, src/smc_main.jl:139,386-387):
 // ϕ_{n+1} is the schedule's next entry and the energy shift of stage n + 1's incremental weights is the maximum the begin of stage n learnt
 // (Begin2::e_seen), so stage n + 1's correction row needs nothing of stage n's mutation totals - a worker forms and publishes it right behind
@@ -785,8 +903,8 @@ __device__ inline bool k3_rides(const RunParams &rp, const Seg3Args &sa, const P
 // inputs, same code, same result everywhere, as in engine 2's kernels), the workers also the proposal; worker 0 records them.
 // CH = 2 (α = 1 only; one handle of 126 977 .. 253 952 particles with a cheap likelihood, run2.hpp seg3_ready): a worker owns TWO consecutive
 // 512-particle chunks of its virtual shard - one in registers, one parked in LDS ((D + 6) columns behind the parking area), exchanged between
-// the per-particle phases; it publishes two rows per hand-over and pays the serial phases and the hand-overs once.  Such a segment leaves at a
-// stage that must resample (its selection runs as launches).
+// the per-particle phases; it publishes two rows per hand-over and pays the serial phases and the hand-overs once.  A stage that must resample
+// does so in place (k3_select_two).
 template <int D, bool ALPHA1, bool RIDE, int CH = 1, bool SYS = false>
 __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, DevState *st, Ctl2 *ctl, const ModelDev *md, Geo2 g, Mut2Args ma, Seg3Args sa, int nb, int nf) {
     constexpr int NPF = Mut2Lds<D>::NPF, MCM = pad2(NPF);
@@ -799,6 +917,9 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
     __shared__ double red[(T3 / 64) * (cm_row_ld(NPF) > 64 ? cm_row_ld(NPF) : 64)];
     __shared__ int s_act, s_to, s_fail;
     __shared__ double s_cfac;
+#ifdef SMCMI_K3_CH2
+    __shared__ Sel2Geo s_ch2[2];                                // the worker's two chunks, for an in-place selection (k3_select_two)
+#endif
     __shared__ RunParams s_rp;                                  // (by value in registers it costs ~40 SGPRs for the whole launch)
     __shared__ double mixbuf[ALPHA1 ? 1 : MixDense<D>::DOUBLES + D * D];
     __shared__ int mixpos[ALPHA1 ? 1 : D];
@@ -997,6 +1118,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         if (!has_c[c]) beg_c[c] = end_c[c];
     }
     int cur = 0;                                                // the chunk in registers
+    if (tid < CH) s_ch2[tid] = Sel2Geo{rowi_c[tid ? CH - 1 : 0], has_c[tid ? CH - 1 : 0] ? 1 : 0, beg_c[tid ? CH - 1 : 0], end_c[tid ? CH - 1 : 0]};     // (read behind the stage loop's barriers)
     long long beg = beg_c[0], end = end_c[0], i = beg + tid;
     bool live = i < end, has = has_c[0];
     int rowi = rowi_c[0];
@@ -1141,6 +1263,7 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
         K3_WALL(sa.gprof, PROF2_WORK + 4 * blockIdx.x + 1);
         double ess = s_tot[0] * s_tot[0] / s_tot[1];
         int dec = entered ? 0 : decide2(s_a.bg, rp.threshold, rp.phi_rtol, s_tot[0], s_tot[1], &ess);
+#ifndef SMCMI_K3_CH2
         if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
             // ================= SELECTION inside the segment (k3_select_inside above): the particle goes through LDS - a call that took it in registers
             // would cost the stage loop 26 registers and 38 spills for a path one stage in twenty takes.  (A kernel whose static arrays leave no room
@@ -1165,6 +1288,28 @@ __global__ void __launch_bounds__(T3, SMCMI_K3_WAVES) k3_segment(CloudPtrs cl, D
             __syncthreads();
             rs = 1; dec = 0;
         }
+#else
+        if (__builtin_expect(dec == 1 && sa.sel != nullptr, 0)) {
+            // ================= SELECTION inside a two-chunk segment (k3_select_two): the chunk in registers travels through the block's slice of
+            // Sel3Args::transit, the parked one stays in its LDS columns
+            double *tr = sa.sel->transit + (long long)blockIdx.x * (D + 5) * T3;
+            __syncthreads();
+            tr[tid] = v;
+#pragma unroll
+            for (int k = 0; k < D; ++k) tr[(5 + k) * T3 + tid] = x[k];
+            tr[T3 + tid] = like; tr[2 * T3 + tid] = lprior; tr[3 * T3 + tid] = like_prev; tr[4 * T3 + tid] = acc_val;
+            const int bad = k3_select_two<D>(sa.sel, cl.buf[0], cl.n, cl.R, g.N, g.V * g.nb1, g.V, s_ch2, cur, tr, st2, tag, n, ma.seed, ma.gid0, sa.g_cm + K3_RPAR(n), sa.to, &s_to, s_tot, s_vt, s_sw,
+                                             red, z_park, po.shift);
+            if (bad) { timed_out = true; break; }
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = tr[(5 + k) * T3 + tid];
+            like = tr[T3 + tid]; lprior = tr[2 * T3 + tid]; like_prev = tr[3 * T3 + tid]; acc_val = tr[4 * T3 + tid];
+            // chunk 0's draws of this stage again (the parking area was the selection's scratch)
+            k3_draw_park<D, !ALPHA1>(z_park, ma.seed, pid_park, (unsigned)n, db0, ma.debug);
+            __syncthreads();
+            rs = 1; dec = 0;
+        }
+#endif
         if (dec != 0) {                                         // leave: nothing of the stage is committed, registers hold the cloud after stage n - 1
             if (writer && tid == 0) {
                 if (dec < 0) { ma.rec.phi[n - 1] = s_a.bg.phi_n; ma.rec.ess[n - 1] = ess; ctl->status.err = dec; }

@@ -184,12 +184,18 @@ def test_two_chunks_per_worker_keep_clouds_up_to_254000_particles_inside_segment
     k3_segment<D, true, RIDE, 2>) - and publishes two rows per hand-over; the serial phases and the hand-overs are paid once (VERDICT r5 missing 4:
     the reference's loop has no size cliff, src/smc_main.jl:472-481).  Same bits as the same geometry's launches (SMCMI_ENGINE3=0); against
     engine 1 (SMCMI_ENGINE=1, what such a cloud ran on until round 5; sums in another order) the same stages and resample decisions and the
-    log-MDD to rounding.  Such segments leave to resample (selection as launches)."""
+    log-MDD to rounding.  A stage that must resample does so inside the segment (k3_select_two: both chunks' rows, cum values and moment rows
+    between the two hand-overs one chunk needs; SMCMI_SEG_SELECT=0: the segment leaves instead - the same bits)."""
     a = _run(cfg)[0]
     b = _run(cfg, {"SMCMI_ENGINE3": "0"})[0]
     c = _run(cfg, {"SMCMI_ENGINE": "1"})[0]
     nb2 = -(-(-(-cfg["n"] // 8)) // 512)
-    assert a["n_segments"] >= 2 and b["n_segments"] == 0 and c["n_segments"] == 0
+    assert a["n_segments"] >= 1 and b["n_segments"] == 0 and c["n_segments"] == 0
+    off = _run(cfg, {"SMCMI_SEG_SELECT": "0"})[0]                        # the segments leave at the resample stages
+    assert off["n_segments"] > a["n_segments"]
+    for k in _KEYS:
+        if k in off:
+            assert a[k] == off[k], (k, a[k], off[k])
     assert a["segment_blocks"] == 8 * ((nb2 + 1) // 2) + 8 and a["segment_state"] == 1, (a["segment_blocks"], nb2)
     assert a["segment_stages"] >= (a["n_stages"] - 1) // 2
     for k in _KEYS:
