@@ -27,6 +27,9 @@ python bench.py --alpha 0.9 --no-cpu --steps 5 --warmup 1 2>/dev/null | tail -1 
 # the reference's default schedule (fixed, 300 stages) at 100 000 / 5 000 / 1 000 particles: one hand-over per stage, and with exact shifts (two)
 python tools/fixed_schedule.py > $OUT/${R}_fixed_schedule.txt 2>/dev/null
 SMCMI_SHIFT_LAG=0 python tools/fixed_schedule.py 100000 5000 >> $OUT/${R}_fixed_schedule.txt 2>/dev/null
+# clouds beyond 131 072 particles on one handle: two chunks per segment worker (adaptive: config 2's schedule; the default schedule)
+python bench.py --nparts 250000 --no-history --no-cpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${R}_bench_n250000.json
+python tools/fixed_schedule.py 250000 2>/dev/null | head -1 >> $OUT/${R}_fixed_schedule.txt
 # ... and one rank's share of such a run on 8 GPUs (125 000 particles, sharded segments): riding / exact shifts
 bash tools/fixed_schedule_shard.sh >> $OUT/${R}_fixed_schedule.txt 2>/dev/null
 # the driver's RCCL branch as 8 ranks sharing this GPU (tests/fake_rccl): the multi-rank bench line with its pre-flight verdict
