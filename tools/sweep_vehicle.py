@@ -35,7 +35,13 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
         want, want_cloud = _single(cfg)
         td = pathlib.Path(tempfile.mkdtemp())
         runs, cloud = _spawn(1, cfg, td, env_extra={"SMCMI_MAILBOX": "2"})
-        _check(runs, cloud, want, want_cloud, expect_mailbox=True if d <= 10 else None)        # (n_para > 10: whatever transport the wide stage takes)
+        if d > 16:     # round 1's all-reduce driver adds the shards' partial sums in another order than one handle's blocks: decisions equal, values to rounding
+            r0 = runs[0][0]
+            assert (r0["n_stages"], r0["resamples"]) == (want["n_stages"], want["resamples"]), (r0["n_stages"], r0["resamples"], want["n_stages"], want["resamples"])
+            assert abs(float.fromhex(r0["logmdd"]) - float.fromhex(want["logmdd"])) <= 1e-9 * abs(float.fromhex(want["logmdd"])), (r0["logmdd"], want["logmdd"])
+            np.testing.assert_allclose(cloud, want_cloud, rtol=1e-6, atol=1e-8)
+        else:
+            _check(runs, cloud, want, want_cloud, expect_mailbox=True if d <= 10 else None)        # (n_para > 10: whatever transport the wide stage takes)
         r = runs[0][0]
         print(json.dumps(dict(trial=trial, ok=True, V=V, n=n, d=d, **kw, stages=r["n_stages"], resamples=r["resamples"], segments=r["segments"], segment_stages=r["segment_stages"])), flush=True)
     except AssertionError as ex:
