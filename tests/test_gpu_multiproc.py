@@ -129,11 +129,13 @@ def test_fixed_schedule_segments_across_processes_take_one_hand_over_per_stage(w
         assert all(r["shift_fallback_stage"] == 40 for rr in runs_fb for r in rr), runs_fb
 
 
-@pytest.mark.parametrize("n", [66002, 130046])
+@pytest.mark.parametrize("n", [66002, 130046, 104092])
 def test_sharded_segments_total_virtual_shards_of_more_than_64_rows(n, tmp_path):
     """2 x odd particles: two virtual shards of 65 / 127 rows - what a rank of an 8-GPU run of 260 000 .. 520 000 particles holds.  The
     gatherer of such a shard totals TWO canonical groups of rows (csrc/stage3.hpp gather_vshard; until round 6 it left the second one out:
-    wrong totals, found by this configuration).  One rank with the mailbox forced on - the only way such a shard's workers fit one GPU."""
+    wrong totals, found by this configuration).  One rank with the mailbox forced on - the only way such a shard's workers fit one GPU.
+    104 092 = 4 x odd: four shards of 51 rows - one handle cut its gather blocks into two tiles there until round 6 (run2.hpp make_geo2: nbg),
+    i.e. summed the resampled cloud's moments in another order than the same cloud on several handles: last-bit differences."""
     cfg = dict(n=n, d=10, seed=7, kw=dict(use_fixed_schedule=False, tempering_target=0.95), reps=1)
     want, want_cloud = _single(cfg)
     runs, cloud = _spawn(1, cfg, tmp_path, env_extra={"SMCMI_MAILBOX": "2"})
