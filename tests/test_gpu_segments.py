@@ -177,7 +177,8 @@ def test_sums_that_overflow_under_the_lagged_shift_switch_the_run_to_exact_shift
     dict(n=250_000, d=10, seed=3, kw=dict(use_fixed_schedule=False, tempering_target=0.97), history=False),
     dict(n=200_000, d=10, seed=5, kw=dict(use_fixed_schedule=True, n_phi=120), history=True),
     dict(n=150_004, d=6, seed=9, spec_args=[6], kw=dict(use_fixed_schedule=False, tempering_target=0.95, pause_at=9), history=False),
-], ids=["adaptive_250000", "fixed_200000_history", "uneven_150004_pause"])
+    dict(n=160_000, d=8, seed=4, spec_args=[8], kw=dict(use_fixed_schedule=True, n_phi=60, resampling_method="multinomial", threshold_ratio=0.8), history=False),
+], ids=["adaptive_250000", "fixed_200000_history", "uneven_150004_pause", "fixed_160000_multinomial"])
 def test_two_chunks_per_worker_keep_clouds_up_to_254000_particles_inside_segments(cfg):
     """One handle of 126 977 .. 253 952 particles (more 512-particle blocks than CUs) with α = 1, one block, one MH step and a cheap likelihood:
     every segment worker owns TWO chunks - one in registers, one parked in LDS, exchanged between the per-particle phases (stage3.hpp
